@@ -1,0 +1,135 @@
+/*
+ * libmind_hip.so -- C-ABI of the MI355X-native MIND hot path.
+ *
+ * The reference (HKUST-Aerial-Robotics/MIND) is pure Python and has no FFI of its own; every entry
+ * point below cites the reference Python interface it replaces.  All functions return 0 on success
+ * or a negative MIND_E* code; no exception crosses the boundary.  The caller owns every buffer it
+ * passes in (host or device as stated); the library never frees caller memory.  One context per
+ * (process, GPU); calls on one context are serialised on its HIP stream.
+ */
+#ifndef MIND_HIP_H
+#define MIND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIND_OK 0
+#define MIND_EINVAL (-1)   /* bad argument / shape */
+#define MIND_ENOMEM (-2)   /* device allocation failed */
+#define MIND_EHIP (-3)     /* HIP runtime error, see mind_last_error_string */
+#define MIND_ESTATE (-4)   /* weights not loaded, context destroyed ... */
+#define MIND_ENOTFOUND (-5)/* tensor name missing from the state_dict table */
+
+typedef struct mind_ctx mind_ctx;
+
+/* replaces MINDPlanner.init_device (planners/mind/planner.py:35-39).  `stream` is a hipStream_t
+ * on which all work of this context is queued (NULL = the device's default stream).  */
+int mind_ctx_create(int device, void *stream, mind_ctx **out);
+int mind_ctx_destroy(mind_ctx *ctx);
+const char *mind_last_error_string(mind_ctx *ctx);
+/* blocks until all work queued on the context's stream is done */
+int mind_ctx_synchronize(mind_ctx *ctx);
+
+/* One tensor of ckpt["state_dict"] (planners/mind/planner.py:46-47): fp32, C-contiguous, host. */
+typedef struct {
+  const char *name;     /* reference state_dict key, e.g. "fusion_net.proj_actor.0.weight" */
+  const float *data;    /* host pointer */
+  int64_t numel;
+} mind_tensor_desc;
+
+/* replaces network.load_state_dict(ckpt["state_dict"]) + .to(device) (planner.py:47-48).  The
+ * library re-lays the 328 tensors out into its packed device blob (MFMA fragment order). */
+int mind_weights_load(mind_ctx *ctx, const mind_tensor_desc *tensors, int n_tensors);
+
+/* Inputs of ScenePredNet.pre_process / forward (planners/mind/networks/network.py:582-606) for a
+ * batch of B scenes (= AIME scenario-tree nodes).  Scene b has a_b = actor_off[b+1]-actor_off[b]
+ * agents (ego first) and l_b lane polylines; its token order is [agents, lanes, cls].
+ * Device pointers unless stated. */
+typedef struct {
+  int n_scenes;
+  const int32_t *actor_off;   /* HOST [B+1] prefix sums (ACTOR_IDCS are contiguous ranges)        */
+  const int32_t *lane_off;    /* HOST [B+1]                                                       */
+  const float *actors;        /* [A,14,48]  ACTORS  (mind/utils.py:114-139)                       */
+  const float *lanes;         /* [L,10,16]  LANES   (mind/utils.py:103-110); may be NULL if lane_feat */
+  const float *lane_feat;     /* [L,128] optional LaneNet output computed earlier (reuse across tree
+                                 nodes of one plan: lane node features do not change), or NULL    */
+  const float *actor_ctrs;    /* [A,2] TRAJS_CTRS, [A,2] TRAJS_VECS                               */
+  const float *actor_vecs;
+  const float *lane_ctrs;     /* [L,2] lane_ctrs, lane_vecs of each scene's LANE_GRAPH            */
+  const float *lane_vecs;
+  const float *const *rpe;    /* HOST array of B device pointers to RPE['scene'] [5,n,n], or NULL
+                                 to have it computed in-kernel from ctrs/vecs (utils.py:193-212)  */
+  const float *tgt_nodes;     /* [B,10,16] TGT_NODES                                               */
+  const float *tgt_rpe;       /* [B,20]    TGT_RPE                                                 */
+} mind_scene_batch;
+
+/* Outputs of ScenePredNet.forward (network.py:545-556): res_cls, res_reg, res_aux[0]. */
+typedef struct {
+  float *cls;        /* [B,6]          softmax mode probabilities                                  */
+  float *reg;        /* [A,6,60,5]     (x, y, exp sx, exp sy, exp rho)  agent-local frame          */
+  float *vel;        /* [A,6,60,2]                                                                 */
+  float *lane_feat;  /* optional [L,128]: LaneNet output written back for reuse (may be NULL)      */
+  float *actor_emb;  /* optional debug taps [A,128] fused actor tokens, may be NULL                */
+  float *cls_emb;    /* optional [B,128] fused cls token, may be NULL                              */
+} mind_pred_out;
+
+/* replaces ScenePredNet.forward over the whole AIME batch (scenario_tree.py:69-71). */
+int mind_predict_batch(mind_ctx *ctx, const mind_scene_batch *in, mind_pred_out *out);
+
+/* Per-kernel timing of the last mind_predict_batch measured with HIP events on the context stream:
+ * returns the number of fusion pair-kernel launches and their summed milliseconds. */
+int mind_last_fusion_stats(mind_ctx *ctx, int *n_launches, float *total_ms, double *pairs_processed);
+/* enable/disable event timing (off by default: events add a little latency) */
+int mind_set_profiling(mind_ctx *ctx, int enable);
+
+/* Debug taps used by the parity tests only: run just the first n (0..6) fusion layers on the next
+ * mind_predict_batch calls, and read internal device buffers ("x", "ST", "QK", "edge", "part",
+ * "actor_feat", "tokpos") back to the host.  mind_debug_read returns the number of floats copied (or
+ * the buffer's size when host == NULL) or a negative error. */
+int mind_debug_set_layers(mind_ctx *ctx, int n);
+int64_t mind_debug_read(mind_ctx *ctx, const char *name, float *host, int64_t max_floats);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tree-iLQR contingency solves: replaces TrajectoryTreeOptimizer.init_warm_start_cost_tree /
+ * warm_start_solve / init_cost_tree / solve (planners/mind/trajectory_tree.py:19-147) together with
+ * iLQR.fit (planners/ilqr/solver.py:80-167), TreeCost (ilqr/cost.py:326-446) and the potentials
+ * (ilqr/potential.py).  One cost tree per scenario tree; all trees of a plan are solved in one call.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int n_nodes;              /* M trajectory nodes, keys 0..M-1 in creation order (LIFO DFS, Q13)  */
+  const int32_t *parent;    /* HOST [M] parent key, -1 for node 0 (child of the x0 root)          */
+  const float *prob;        /* HOST [M] scenario-node probability (fp32 as in the reference)      */
+  int n_agents;             /* a (agent 0 = ego)                                                  */
+  const float *agent_mean;  /* HOST [M, a, 2] predicted mean of every agent at the node's step    */
+  const float *agent_cov;   /* HOST [M, a]    max-sigma                                           */
+} mind_cost_tree;
+
+typedef struct {
+  double dt, wheelbase;                 /* 0.2, 2.5 (trajectory_tree.py:15)                        */
+  double w_des_state[6];                /* diag of w_des_state                                     */
+  double w_state_con[6];                /* diag of w_state_con                                     */
+  double state_lower[6], state_upper[6];
+  double w_ctrl[2];                     /* diag of w_ctrl                                          */
+  double w_tgt, w_ego, w_ego_cov_offset, w_exo, w_exo_cov_offset, w_exo_cost_offset;
+  double grid_res; int grid_w, grid_h;  /* 0.4, 256, 256                                           */
+  int max_iter;                         /* 100                                                     */
+} mind_ilqr_cfg;
+
+typedef struct { int iterations; int converged; double J; double mu; } mind_ilqr_stats;
+
+/* x0[6] = (x,y,v,yaw,a,delta); target_lane HOST [P,2] float64 (gt_tgt_lane as float64);
+ * us_init HOST [sum M, 2] (NULL = zeros); use_exo = 0 builds the warm-start tree (lane term only).
+ * Outputs HOST xs [sum M, 6], us [sum M, 2], stats [n_trees]. */
+int mind_ilqr_solve_trees(mind_ctx *ctx, const mind_ilqr_cfg *cfg, const mind_cost_tree *trees,
+                          int n_trees, const double *x0, const double *target_lane, int n_lane_pts,
+                          double target_vel, int use_exo, const double *us_init, double *xs,
+                          double *us, mind_ilqr_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIND_HIP_H */

@@ -1,0 +1,96 @@
+"""ctypes binding of libmind_hip.so (C-ABI in include/mind_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmind_hip.so")
+
+MIND_OK = 0
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("numel", C.c_int64)]
+
+
+class SceneBatch(C.Structure):
+    _fields_ = [("n_scenes", C.c_int), ("actor_off", C.POINTER(C.c_int32)), ("lane_off", C.POINTER(C.c_int32)),
+                ("actors", C.c_void_p), ("lanes", C.c_void_p), ("lane_feat", C.c_void_p),
+                ("actor_ctrs", C.c_void_p), ("actor_vecs", C.c_void_p), ("lane_ctrs", C.c_void_p),
+                ("lane_vecs", C.c_void_p), ("rpe", C.POINTER(C.c_void_p)), ("tgt_nodes", C.c_void_p),
+                ("tgt_rpe", C.c_void_p)]
+
+
+class PredOut(C.Structure):
+    _fields_ = [("cls", C.c_void_p), ("reg", C.c_void_p), ("vel", C.c_void_p), ("lane_feat", C.c_void_p),
+                ("actor_emb", C.c_void_p), ("cls_emb", C.c_void_p)]
+
+
+class CostTree(C.Structure):
+    _fields_ = [("n_nodes", C.c_int), ("parent", C.POINTER(C.c_int32)), ("prob", C.POINTER(C.c_float)),
+                ("n_agents", C.c_int), ("agent_mean", C.POINTER(C.c_float)), ("agent_cov", C.POINTER(C.c_float))]
+
+
+class IlqrCfg(C.Structure):
+    _fields_ = [("dt", C.c_double), ("wheelbase", C.c_double), ("w_des_state", C.c_double * 6),
+                ("w_state_con", C.c_double * 6), ("state_lower", C.c_double * 6), ("state_upper", C.c_double * 6),
+                ("w_ctrl", C.c_double * 2), ("w_tgt", C.c_double), ("w_ego", C.c_double),
+                ("w_ego_cov_offset", C.c_double), ("w_exo", C.c_double), ("w_exo_cov_offset", C.c_double),
+                ("w_exo_cost_offset", C.c_double), ("grid_res", C.c_double), ("grid_w", C.c_int), ("grid_h", C.c_int),
+                ("max_iter", C.c_int)]
+
+
+class IlqrStats(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("J", C.c_double), ("mu", C.c_double)]
+
+
+EXPORTS = ["mind_ctx_create", "mind_ctx_destroy", "mind_last_error_string", "mind_ctx_synchronize",
+           "mind_weights_load", "mind_predict_batch", "mind_last_fusion_stats", "mind_set_profiling",
+           "mind_ilqr_solve_trees", "mind_debug_set_layers", "mind_debug_read"]
+
+_lib = None
+
+
+def load():
+    """Load the library (raises if it has not been built: run ``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: the HIP extension must be built (hipcc --offload-arch=gfx950); "
+                          "there is no CPU fallback for the product path")
+    lib = C.CDLL(LIB_PATH)
+    lib.mind_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.mind_ctx_destroy.argtypes = [C.c_void_p]
+    lib.mind_last_error_string.argtypes = [C.c_void_p]
+    lib.mind_last_error_string.restype = C.c_char_p
+    lib.mind_ctx_synchronize.argtypes = [C.c_void_p]
+    lib.mind_weights_load.argtypes = [C.c_void_p, C.POINTER(TensorDesc), C.c_int]
+    lib.mind_predict_batch.argtypes = [C.c_void_p, C.POINTER(SceneBatch), C.POINTER(PredOut)]
+    lib.mind_last_fusion_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)]
+    lib.mind_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    lib.mind_ilqr_solve_trees.argtypes = [C.c_void_p, C.POINTER(IlqrCfg), C.POINTER(CostTree), C.c_int,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_double, C.c_int,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(IlqrStats)]
+    lib.mind_debug_set_layers.argtypes = [C.c_void_p, C.c_int]
+    lib.mind_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64]
+    for n in EXPORTS:
+        getattr(lib, n)
+        if n not in ("mind_last_error_string", "mind_debug_read"):
+            getattr(lib, n).restype = C.c_int
+    lib.mind_debug_read.restype = C.c_int64
+    _lib = lib
+    return lib
+
+
+class MindError(RuntimeError):
+    pass
+
+
+def check(lib, ctx, rc, what):
+    if rc != MIND_OK:
+        msg = lib.mind_last_error_string(ctx) if ctx else b""
+        raise MindError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

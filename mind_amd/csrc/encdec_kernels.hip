@@ -1,0 +1,534 @@
+// Actor / lane polyline encoders and the K-mode Bezier scene decoder for gfx950 (fp32).
+//
+// Reference semantics:
+//   ActorNet      planners/mind/networks/network.py:12-61, layers.py:36-60 (Conv1d), :140-188 (Res1d)
+//   LaneNet       network.py:64-121
+//   SceneDecoder  network.py:343-556 (bezier branch :408-421,:514-523; basis :449-464)
+//
+// Each kernel keeps a whole instance (one agent's FPN pyramid / two lane polylines / one scene's
+// mode tokens / four agents' mode embeddings) resident in LDS and streams the weights, stored
+// transposed ([in][out]) so a wave reads consecutive floats, from L2.  These are <3% of the
+// predictor FLOPs; the dominant kernel is fusion_kernels.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NT 256
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __shfl_xor(v, 32, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 1, 64);
+  return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// out[r][o] = b[o] + sum_k in[r][k] WT[k][o],  r < R (compile time), o < NOUT; K % 4 == 0.
+// `in` rows must be 16-byte aligned (ldi % 4 == 0).  Caller syncs before/after.
+template <int R>
+__device__ __forceinline__ void dense(const float *in, int ldi, int K, const float *__restrict__ WT,
+                                      const float *__restrict__ b, int NOUT, float *out, int ldo) {
+  for (int o = threadIdx.x; o < NOUT; o += NT) {
+    float acc[R];
+    const float bv = b ? b[o] : 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = bv;
+    for (int k = 0; k < K; k += 4) {
+      const float w0 = WT[(size_t)k * NOUT + o];
+      const float w1 = WT[(size_t)(k + 1) * NOUT + o];
+      const float w2 = WT[(size_t)(k + 2) * NOUT + o];
+      const float w3 = WT[(size_t)(k + 3) * NOUT + o];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const f32x4 x = *(const f32x4 *)(in + r * ldi + k);
+        acc[r] = fmaf(w0, x[0], acc[r]);
+        acc[r] = fmaf(w1, x[1], acc[r]);
+        acc[r] = fmaf(w2, x[2], acc[r]);
+        acc[r] = fmaf(w3, x[3], acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[r * ldo + o] = acc[r];
+  }
+}
+
+// LayerNorm (+ReLU) over `n` features of each of R rows, in place; one wave per row (4 waves).
+__device__ __forceinline__ void ln_rows(float *buf, int ld, int R, int n, const float *__restrict__ g,
+                                        const float *__restrict__ be, bool relu) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < R; r += 4) {
+    float s = 0.f;
+    for (int k = lane; k < n; k += 64) s += buf[r * ld + k];
+    const float mean = wave_sum(s) / (float)n;
+    float v = 0.f;
+    for (int k = lane; k < n; k += 64) { const float d = buf[r * ld + k] - mean; v = fmaf(d, d, v); }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)n + 1e-5f);
+    for (int k = lane; k < n; k += 64) {
+      float y = (buf[r * ld + k] - mean) * rstd * g[k] + be[k];
+      if (relu) y = fmaxf(y, 0.f);
+      buf[r * ld + k] = y;
+    }
+  }
+}
+
+// =================================================================================================
+// LaneNet: PL polylines (10 points each) per workgroup.
+// =================================================================================================
+struct LaneW {
+  const float *pW, *pb, *pg, *pbe;  // proj 16->128 (+LN)
+  // aggre blocks 0/1: fc1.0, fc1.3, fc2.0 (256->128), fc2.3, norm
+  const float *f10W[2], *f10b[2], *f10g[2], *f10be[2];
+  const float *f13W[2], *f13b[2], *f13g[2], *f13be[2];
+  const float *f20W[2], *f20b[2], *f20g[2], *f20be[2];
+  const float *f23W[2], *f23b[2], *f23g[2], *f23be[2];
+  const float *ng[2], *nbe[2];
+};
+
+#define PL 2
+#define LR (PL * 10)
+
+__global__ __launch_bounds__(NT) void k_lane_net(const float *__restrict__ feats, int n_poly,
+                                                 float *__restrict__ out, LaneW W) {
+  __shared__ __attribute__((aligned(16))) float xin[LR][16];
+  __shared__ __attribute__((aligned(16))) float x[LR][128];
+  __shared__ __attribute__((aligned(16))) float hcat[LR][256];
+  __shared__ __attribute__((aligned(16))) float t1[LR][128];
+  const int tid = threadIdx.x;
+  const int p0 = blockIdx.x * PL;
+  for (int i = tid; i < LR * 16; i += NT) {
+    const int r = i / 16, c = i % 16;
+    const int pl = p0 + r / 10;
+    xin[r][c] = pl < n_poly ? feats[((size_t)pl * 10 + r % 10) * 16 + c] : 0.f;
+  }
+  __syncthreads();
+  dense<LR>(&xin[0][0], 16, 16, W.pW, W.pb, 128, &x[0][0], 128);
+  __syncthreads();
+  ln_rows(&x[0][0], 128, LR, 128, W.pg, W.pbe, true);
+  __syncthreads();
+  for (int blk = 0; blk < 2; ++blk) {
+    dense<LR>(&x[0][0], 128, 128, W.f10W[blk], W.f10b[blk], 128, &t1[0][0], 128);
+    __syncthreads();
+    ln_rows(&t1[0][0], 128, LR, 128, W.f10g[blk], W.f10be[blk], true);
+    __syncthreads();
+    dense<LR>(&t1[0][0], 128, 128, W.f13W[blk], W.f13b[blk], 128, &hcat[0][0], 256);
+    __syncthreads();
+    ln_rows(&hcat[0][0], 256, LR, 128, W.f13g[blk], W.f13be[blk], true);
+    __syncthreads();
+    // max-pool over the 10 points, broadcast into the second half of the concat
+    for (int i = tid; i < PL * 128; i += NT) {
+      const int pl = i / 128, c = i % 128;
+      float m = hcat[pl * 10][c];
+      for (int q = 1; q < 10; ++q) m = fmaxf(m, hcat[pl * 10 + q][c]);
+      for (int q = 0; q < 10; ++q) hcat[pl * 10 + q][128 + c] = m;
+    }
+    __syncthreads();
+    dense<LR>(&hcat[0][0], 256, 256, W.f20W[blk], W.f20b[blk], 128, &t1[0][0], 128);
+    __syncthreads();
+    ln_rows(&t1[0][0], 128, LR, 128, W.f20g[blk], W.f20be[blk], true);
+    __syncthreads();
+    dense<LR>(&t1[0][0], 128, 128, W.f23W[blk], W.f23b[blk], 128, &hcat[0][0], 256);
+    __syncthreads();
+    ln_rows(&hcat[0][0], 256, LR, 128, W.f23g[blk], W.f23be[blk], true);
+    __syncthreads();
+    for (int i = tid; i < LR * 128; i += NT) x[i / 128][i % 128] += hcat[i / 128][i % 128];
+    __syncthreads();
+    ln_rows(&x[0][0], 128, LR, 128, W.ng[blk], W.nbe[blk], false);
+    __syncthreads();
+  }
+  for (int i = tid; i < PL * 128; i += NT) {
+    const int pl = i / 128, c = i % 128;
+    if (p0 + pl < n_poly) {
+      float m = x[pl * 10][c];
+      for (int q = 1; q < 10; ++q) m = fmaxf(m, x[pl * 10 + q][c]);
+      out[(size_t)(p0 + pl) * 128 + c] = m;
+    }
+  }
+}
+
+// =================================================================================================
+// ActorNet: one agent per workgroup; the whole 4-scale pyramid lives in LDS.
+// Conv weights are stored [ci][dk][co] (transposed) so that thread <-> co reads are coalesced.
+// =================================================================================================
+struct ResW { const float *c1, *g1, *b1, *c2, *g2, *b2, *ds, *gd, *bd; };
+struct ActorW {
+  ResW res[9];                 // groups.{0..3}.{0,1}, output
+  const float *latW[4], *latG[4], *latB[4];
+};
+
+// out[co][t] = sum_ci sum_dk W[ci][dk][co] * in[ci][t*stride + dk - pad], raw (no norm)
+template <int TCH>
+__device__ __forceinline__ void conv_chunk(const float *in, int Cin, int Tin, const float *__restrict__ W,
+                                           int Cout, int Tout, int stride, int ksz, float *out) {
+  const int tid = threadIdx.x;
+  const int co = tid % Cout;
+  const int chunk = tid / Cout;
+  const int t0 = chunk * TCH;
+  const int pad = (ksz - 1) / 2;
+  if (t0 < Tout) {
+  float acc[TCH];
+#pragma unroll
+  for (int i = 0; i < TCH; ++i) acc[i] = 0.f;
+  for (int ci = 0; ci < Cin; ++ci) {
+    for (int dk = 0; dk < ksz; ++dk) {
+      const float w = W[((size_t)ci * ksz + dk) * Cout + co];
+#pragma unroll
+      for (int i = 0; i < TCH; ++i) {
+        const int ti = (t0 + i) * stride + dk - pad;
+        const float xv = (ti >= 0 && ti < Tin) ? in[ci * Tin + ti] : 0.f;
+        acc[i] = fmaf(w, xv, acc[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TCH; ++i)
+    if (t0 + i < Tout) out[co * Tout + t0 + i] = acc[i];
+  }
+}
+
+__device__ __forceinline__ void conv(const float *in, int Cin, int Tin, const float *W, int Cout, int Tout,
+                                     int stride, int ksz, float *out) {
+  const int per = (Cout * Tout + NT - 1) / NT;  // outputs per thread
+  const int chunks = NT / Cout > 0 ? NT / Cout : 1;
+  int tch = (Tout + chunks - 1) / chunks;
+  (void)per;
+  if (Cout > NT) {  // not used (max Cout = 256)
+    return;
+  }
+  if (tch <= 3) conv_chunk<3>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out);
+  else if (tch <= 6) conv_chunk<6>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out);
+  else if (tch <= 12) conv_chunk<12>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out);
+  else conv_chunk<24>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out);
+}
+
+// GroupNorm(1 group) over C x T, per-channel affine, optional residual add and ReLU, in place.
+__device__ __forceinline__ void gn(float *buf, int C, int T, const float *__restrict__ g,
+                                   const float *__restrict__ b, const float *resid, bool relu, float *red) {
+  const int n = C * T;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += NT) s += buf[i];
+  const float mean = block_sum(s, red) / (float)n;
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += NT) { const float d = buf[i] - mean; v = fmaf(d, d, v); }
+  const float rstd = 1.0f / sqrtf(block_sum(v, red) / (float)n + 1e-5f);
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const int c = i / T;
+    float y = (buf[i] - mean) * rstd * g[c] + b[c];
+    if (resid) y += resid[i];
+    if (relu) y = fmaxf(y, 0.f);
+    buf[i] = y;
+  }
+  __syncthreads();
+}
+
+// Res1d (layers.py:175-188): out written to `out`; uses scratch t1, t2 (each >= Cout*Tout floats)
+__device__ __forceinline__ void res1d(const float *in, int Cin, int Tin, const ResW &w, int Cout, int stride,
+                                      float *out, float *t1, float *t2, float *red) {
+  const int Tout = Tin / stride;
+  conv(in, Cin, Tin, w.c1, Cout, Tout, stride, 3, t1);
+  __syncthreads();
+  gn(t1, Cout, Tout, w.g1, w.b1, nullptr, true, red);
+  conv(t1, Cout, Tout, w.c2, Cout, Tout, 1, 3, out);
+  __syncthreads();
+  const float *resid = in;
+  if (w.ds) {
+    conv(in, Cin, Tin, w.ds, Cout, Tout, stride, 1, t2);
+    __syncthreads();
+    gn(t2, Cout, Tout, w.gd, w.bd, nullptr, false, red);
+    resid = t2;
+  }
+  gn(out, Cout, Tout, w.g2, w.b2, resid, true, red);
+}
+
+// LDS carve (floats): xin 672 | o0 1536 | o1 1536 | o2 1536 | o3 1536 | ta 1536 | tb 1536 | tc 1536
+//                     | fa 6144 | fb 6144 ; the final Res1d output reuses the (dead) o0..tc region.
+#define ACT_LDS_FLOATS (672 + 7 * 1536 + 2 * 6144 + 8)
+__global__ __launch_bounds__(NT) void k_actor_net(const float *__restrict__ actors, int n_actors,
+                                                  float *__restrict__ out, ActorW W) {
+  extern __shared__ float sm[];
+  float *xin = sm;
+  float *o0 = sm + 672, *o1 = o0 + 1536, *o2 = o1 + 1536, *o3 = o2 + 1536;
+  float *ta = o3 + 1536, *tb = ta + 1536, *tc = tb + 1536;
+  float *fa = tc + 1536, *fb = fa + 6144;
+  float *red = fb + 6144;
+  float *fo = o0;  // 10752 floats available, needs 6144
+  const int tid = threadIdx.x;
+  const int a = blockIdx.x;
+  if (a >= n_actors) return;
+  for (int i = tid; i < 14 * 48; i += NT) xin[i] = actors[(size_t)a * 14 * 48 + i];
+  __syncthreads();
+  res1d(xin, 14, 48, W.res[0], 32, 1, ta, tb, tc, red);
+  res1d(ta, 32, 48, W.res[1], 32, 1, o0, tb, tc, red);
+  res1d(o0, 32, 48, W.res[2], 64, 2, ta, tb, tc, red);
+  res1d(ta, 64, 24, W.res[3], 64, 1, o1, tb, tc, red);
+  res1d(o1, 64, 24, W.res[4], 128, 2, ta, tb, tc, red);
+  res1d(ta, 128, 12, W.res[5], 128, 1, o2, tb, tc, red);
+  res1d(o2, 128, 12, W.res[6], 256, 2, ta, tb, tc, red);
+  res1d(ta, 256, 6, W.res[7], 256, 1, o3, tb, tc, red);
+  // FPN top-down (network.py:55-58): lateral = conv3 + GN, no activation
+  conv(o3, 256, 6, W.latW[3], 128, 6, 1, 3, fa);
+  __syncthreads();
+  gn(fa, 128, 6, W.latG[3], W.latB[3], nullptr, false, red);
+  float *cur = fa, *nxt = fb;
+  for (int g = 2; g >= 0; --g) {
+    const float *src_o = g == 2 ? o2 : (g == 1 ? o1 : o0);
+    const int C = g == 2 ? 128 : (g == 1 ? 64 : 32);
+    const int T = g == 2 ? 12 : (g == 1 ? 24 : 48);
+    const int Th = T / 2;
+    conv(src_o, C, T, W.latW[g], 128, T, 1, 3, nxt);
+    __syncthreads();
+    gn(nxt, 128, T, W.latG[g], W.latB[g], nullptr, false, red);
+    // x2 linear upsample of `cur` (align_corners=False) added to the lateral
+    for (int i = tid; i < 128 * T; i += NT) {
+      const int c = i / T, t = i % T;
+      float src = (t + 0.5f) * 0.5f - 0.5f;
+      src = src < 0.f ? 0.f : src;
+      const int i0 = (int)src;
+      const int i1 = i0 + 1 < Th ? i0 + 1 : Th - 1;
+      const float l1 = src - (float)i0;
+      nxt[i] += (1.0f - l1) * cur[c * Th + i0] + l1 * cur[c * Th + i1];
+    }
+    __syncthreads();
+    float *t = cur; cur = nxt; nxt = t;
+  }
+  // output Res1d(128,128) at T = 48 (network.py:60); only the last time column is kept
+  {
+    const ResW &w = W.res[8];
+    conv(cur, 128, 48, w.c1, 128, 48, 1, 3, nxt);
+    __syncthreads();
+    gn(nxt, 128, 48, w.g1, w.b1, nullptr, true, red);
+    conv(nxt, 128, 48, w.c2, 128, 48, 1, 3, fo);
+    __syncthreads();
+    gn(fo, 128, 48, w.g2, w.b2, cur, true, red);
+  }
+  if (tid < 128) out[(size_t)a * 128 + tid] = fo[tid * 48 + 47];
+}
+extern "C" size_t mind_actor_lds_bytes() { return (size_t)ACT_LDS_FLOATS * sizeof(float); }
+
+// =================================================================================================
+// SceneDecoder, scene part: target embedding, 6 mode tokens through ctx_proj + 2 encoder layers,
+// mode probabilities.  One workgroup per scene.
+// =================================================================================================
+struct DecW {
+  const float *rpeW, *rpeb, *rpeg, *rpebe;                       // proj_rpe 20(->pad 20)->128
+  const float *t0W, *t0b, *t0g, *t0be, *t3W, *t3b, *t3g, *t3be;  // proj_tgt
+  const float *c0W, *c0b, *c0g, *c0be, *c3W, *c3b, *c3g, *c3be;  // ctx_proj 128->384->768
+  const float *a0W, *a0b, *a0g, *a0be, *a3W, *a3b, *a3g, *a3be;  // actor_proj
+  const float *inW[2], *inb[2], *outW[2], *outb[2], *l1W[2], *l1b[2], *l2W[2], *l2b[2];
+  const float *n1g[2], *n1b[2], *n2g[2], *n2b[2];
+  const float *k0W, *k0b, *k0g, *k0be, *k3W, *k3b, *k3g, *k3be, *k6W, *k6b;  // cls head
+  const float *r0W, *r0b, *r0g, *r0be, *r3W, *r3b, *r3g, *r3be, *r6W, *r6b;  // reg head
+  const float *T, *Tp;                                                           // [60][8], [60][7]
+};
+
+__global__ __launch_bounds__(NT) void k_dec_scene(const float *__restrict__ x /*[tokens,128]*/,
+                                                  const int *__restrict__ cls_row /*[B]*/,
+                                                  const float *__restrict__ tgt_feat /*[B,128]*/,
+                                                  const float *__restrict__ tgt_rpe /*[B,20]*/,
+                                                  float *__restrict__ Cout /*[B,6,128]*/,
+                                                  float *__restrict__ tgt_out /*[B,128]*/,
+                                                  float *__restrict__ cls_out /*[B,6]*/, DecW W) {
+  __shared__ __attribute__((aligned(16))) float v0[1][256];
+  __shared__ __attribute__((aligned(16))) float v1[1][768];
+  __shared__ __attribute__((aligned(16))) float C[6][128];
+  __shared__ __attribute__((aligned(16))) float qkv[6][384];
+  __shared__ __attribute__((aligned(16))) float att[6][128];
+  __shared__ __attribute__((aligned(16))) float ff[6][1536];
+  __shared__ __attribute__((aligned(16))) float t2[6][128];
+  __shared__ float sc[4][6][6];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  // ---- target embedding (network.py:491-495)
+  if (tid < 20) v1[0][tid] = tgt_rpe[(size_t)b * 20 + tid];
+  __syncthreads();
+  dense<1>(&v1[0][0], 768, 20, W.rpeW, W.rpeb, 128, &v0[0][128], 256);
+  if (tid < 128) v0[0][tid] = tgt_feat[(size_t)b * 128 + tid];
+  __syncthreads();
+  ln_rows(&v0[0][128], 256, 1, 128, W.rpeg, W.rpebe, true);
+  __syncthreads();
+  dense<1>(&v0[0][0], 256, 256, W.t0W, W.t0b, 128, &v1[0][0], 768);
+  __syncthreads();
+  ln_rows(&v1[0][0], 768, 1, 128, W.t0g, W.t0be, true);
+  __syncthreads();
+  dense<1>(&v1[0][0], 768, 128, W.t3W, W.t3b, 128, &v0[0][0], 256);
+  __syncthreads();
+  ln_rows(&v0[0][0], 256, 1, 128, W.t3g, W.t3be, true);
+  __syncthreads();
+  if (tid < 128) tgt_out[(size_t)b * 128 + tid] = v0[0][tid];
+  __syncthreads();
+  // ---- ctx_proj: cls token -> 6 mode tokens (network.py:501)
+  if (tid < 128) v0[0][tid] = x[(size_t)cls_row[b] * 128 + tid];
+  __syncthreads();
+  dense<1>(&v0[0][0], 256, 128, W.c0W, W.c0b, 384, &v1[0][0], 768);
+  __syncthreads();
+  ln_rows(&v1[0][0], 768, 1, 384, W.c0g, W.c0be, true);
+  __syncthreads();
+  dense<1>(&v1[0][0], 768, 384, W.c3W, W.c3b, 768, &ff[0][0], 1536);
+  __syncthreads();
+  ln_rows(&ff[0][0], 1536, 1, 768, W.c3g, W.c3be, true);
+  __syncthreads();
+  for (int i = tid; i < 768; i += NT) C[i / 128][i % 128] = ff[0][i];
+  __syncthreads();
+  // ---- 2 post-norm encoder layers over the 6 mode tokens (4 heads x 32, ffn 1536)
+  for (int L = 0; L < 2; ++L) {
+    dense<6>(&C[0][0], 128, 128, W.inW[L], W.inb[L], 384, &qkv[0][0], 384);
+    __syncthreads();
+    if (tid < 4 * 36) {
+      const int hd = tid / 36, s = (tid % 36) / 6, t = tid % 6;
+      float d = 0.f;
+      for (int k = 0; k < 32; ++k) d = fmaf(qkv[s][hd * 32 + k], qkv[t][128 + hd * 32 + k], d);
+      sc[hd][s][t] = d / sqrtf(32.0f);
+    }
+    __syncthreads();
+    if (tid < 24) {
+      const int hd = tid / 6, s = tid % 6;
+      float m = -INFINITY;
+      for (int t = 0; t < 6; ++t) m = fmaxf(m, sc[hd][s][t]);
+      float e[6], sum = 0.f;
+      for (int t = 0; t < 6; ++t) { e[t] = expf(sc[hd][s][t] - m); sum += e[t]; }
+      for (int t = 0; t < 6; ++t) sc[hd][s][t] = e[t] / sum;
+    }
+    __syncthreads();
+    for (int i = tid; i < 6 * 128; i += NT) {
+      const int s = i / 128, c = i % 128, hd = c / 32;
+      float o = 0.f;
+      for (int t = 0; t < 6; ++t) o = fmaf(sc[hd][s][t], qkv[t][256 + c], o);
+      att[s][c] = o;
+    }
+    __syncthreads();
+    dense<6>(&att[0][0], 128, 128, W.outW[L], W.outb[L], 128, &t2[0][0], 128);
+    __syncthreads();
+    for (int i = tid; i < 768; i += NT) C[i / 128][i % 128] += t2[i / 128][i % 128];
+    __syncthreads();
+    ln_rows(&C[0][0], 128, 6, 128, W.n1g[L], W.n1b[L], false);
+    __syncthreads();
+    dense<6>(&C[0][0], 128, 128, W.l1W[L], W.l1b[L], 1536, &ff[0][0], 1536);
+    __syncthreads();
+    for (int i = tid; i < 6 * 1536; i += NT) ff[i / 1536][i % 1536] = fmaxf(ff[i / 1536][i % 1536], 0.f);
+    __syncthreads();
+    dense<6>(&ff[0][0], 1536, 1536, W.l2W[L], W.l2b[L], 128, &t2[0][0], 128);
+    __syncthreads();
+    for (int i = tid; i < 768; i += NT) C[i / 128][i % 128] += t2[i / 128][i % 128];
+    __syncthreads();
+    ln_rows(&C[0][0], 128, 6, 128, W.n2g[L], W.n2b[L], false);
+    __syncthreads();
+  }
+  for (int i = tid; i < 768; i += NT) Cout[(size_t)b * 768 + i] = C[i / 128][i % 128];
+  // ---- cls head on the mode tokens only (network.py:512, Q6), softmax over the 6 modes
+  dense<6>(&C[0][0], 128, 128, W.k0W, W.k0b, 128, &att[0][0], 128);
+  __syncthreads();
+  ln_rows(&att[0][0], 128, 6, 128, W.k0g, W.k0be, true);
+  __syncthreads();
+  dense<6>(&att[0][0], 128, 128, W.k3W, W.k3b, 128, &t2[0][0], 128);
+  __syncthreads();
+  ln_rows(&t2[0][0], 128, 6, 128, W.k3g, W.k3be, true);
+  __syncthreads();
+  for (int k = tid >> 6; k < 6; k += 4) {
+    const int lane = tid & 63;
+    float s = t2[k][lane] * W.k6W[lane] + t2[k][lane + 64] * W.k6W[lane + 64];
+    s = wave_sum(s);
+    if (lane == 0) sc[0][0][k] = s + W.k6b[0];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float m = -INFINITY;
+    for (int k = 0; k < 6; ++k) m = fmaxf(m, sc[0][0][k]);
+    float e[6], sum = 0.f;
+    for (int k = 0; k < 6; ++k) { e[k] = expf(sc[0][0][k] - m); sum += e[k]; }
+    for (int k = 0; k < 6; ++k) cls_out[(size_t)b * 6 + k] = e[k] / sum;
+  }
+}
+
+// =================================================================================================
+// SceneDecoder, actor part: RA agents per workgroup -> reg [a,6,60,5], vel [a,6,60,2]
+// =================================================================================================
+#define RA 4
+__global__ __launch_bounds__(NT) void k_dec_actor(const float *__restrict__ x /*[tokens,128]*/,
+                                                  const int *__restrict__ actor_row /*[A]*/,
+                                                  const int *__restrict__ actor_scene /*[A]*/, int n_actors,
+                                                  const float *__restrict__ Cmode /*[B,6,128]*/,
+                                                  const float *__restrict__ tgt /*[B,128]*/,
+                                                  float *__restrict__ reg, float *__restrict__ vel, DecW W) {
+  __shared__ __attribute__((aligned(16))) float xin[RA][128];
+  __shared__ __attribute__((aligned(16))) float h1[RA][384];
+  __shared__ __attribute__((aligned(16))) float h2[RA][768];
+  __shared__ __attribute__((aligned(16))) float E[RA * 6][128];
+  __shared__ __attribute__((aligned(16))) float t1[RA * 6][128];
+  __shared__ float prm[RA * 6][40];
+  const int tid = threadIdx.x;
+  const int a0 = blockIdx.x * RA;
+  for (int i = tid; i < RA * 128; i += NT) {
+    const int r = i / 128, a = a0 + r;
+    xin[r][i % 128] = a < n_actors ? x[(size_t)actor_row[a] * 128 + i % 128] : 0.f;
+  }
+  __syncthreads();
+  dense<RA>(&xin[0][0], 128, 128, W.a0W, W.a0b, 384, &h1[0][0], 384);
+  __syncthreads();
+  ln_rows(&h1[0][0], 384, RA, 384, W.a0g, W.a0be, true);
+  __syncthreads();
+  dense<RA>(&h1[0][0], 384, 384, W.a3W, W.a3b, 768, &h2[0][0], 768);
+  __syncthreads();
+  ln_rows(&h2[0][0], 768, RA, 768, W.a3g, W.a3be, true);
+  __syncthreads();
+  // embed = cls_embed + actor_embed (+ tgt on mode 0 only)  (network.py:506-510)
+  for (int i = tid; i < RA * 768; i += NT) {
+    const int r = i / 768, k = (i % 768) / 128, c = i % 128;
+    const int a = a0 + r;
+    float v = 0.f;
+    if (a < n_actors) {
+      const int sc = actor_scene[a];
+      v = h2[r][k * 128 + c] + Cmode[((size_t)sc * 6 + k) * 128 + c];
+      if (k == 0) v += tgt[(size_t)sc * 128 + c];
+    }
+    E[r * 6 + k][c] = v;
+  }
+  __syncthreads();
+  dense<RA * 6>(&E[0][0], 128, 128, W.r0W, W.r0b, 128, &t1[0][0], 128);
+  __syncthreads();
+  ln_rows(&t1[0][0], 128, RA * 6, 128, W.r0g, W.r0be, true);
+  __syncthreads();
+  dense<RA * 6>(&t1[0][0], 128, 128, W.r3W, W.r3b, 128, &E[0][0], 128);
+  __syncthreads();
+  ln_rows(&E[0][0], 128, RA * 6, 128, W.r3g, W.r3be, true);
+  __syncthreads();
+  // 128 -> 40 = 8 control points x (x, y, sx, sy, rho)
+  for (int i = tid; i < RA * 6 * 40; i += NT) {
+    const int r = i / 40, o = i % 40;
+    float acc = W.r6b[o];
+    for (int k = 0; k < 128; ++k) acc = fmaf(W.r6W[k * 40 + o], E[r][k], acc);
+    prm[r][o] = acc;
+  }
+  __syncthreads();
+  // Bezier evaluation (network.py:515-523,545): pos = T P, cov = exp(T S), vel = Tp dP / 6
+  for (int i = tid; i < RA * 6 * 60; i += NT) {
+    const int r = i / 60, t = i % 60;
+    const int a = a0 + r / 6, k = r % 6;
+    if (a >= n_actors) continue;
+    float o5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < 8; ++c) {
+      const float tv = W.T[t * 8 + c];
+#pragma unroll
+      for (int d = 0; d < 5; ++d) o5[d] = fmaf(tv, prm[r][c * 5 + d], o5[d]);
+    }
+    float v2[2] = {0.f, 0.f};
+    for (int c = 0; c < 7; ++c) {
+      const float tv = W.Tp[t * 7 + c];
+      v2[0] = fmaf(tv, prm[r][(c + 1) * 5 + 0] - prm[r][c * 5 + 0], v2[0]);
+      v2[1] = fmaf(tv, prm[r][(c + 1) * 5 + 1] - prm[r][c * 5 + 1], v2[1]);
+    }
+    float *ro = reg + (((size_t)a * 6 + k) * 60 + t) * 5;
+    ro[0] = o5[0]; ro[1] = o5[1]; ro[2] = expf(o5[2]); ro[3] = expf(o5[3]); ro[4] = expf(o5[4]);
+    float *vo = vel + (((size_t)a * 6 + k) * 60 + t) * 2;
+    vo[0] = v2[0] / 6.0f; vo[1] = v2[1] / 6.0f;
+  }
+}

@@ -1,0 +1,698 @@
+// libmind_hip.so: C-ABI (include/mind_hip.h) over the hand-written gfx950 kernels.
+// Host side: context, state_dict -> packed device blob, per-call job tables, kernel launches.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mind_hip.h"
+#include "encdec_kernels.hip"
+#include "fusion_kernels.hip"
+#include "ilqr_kernels.hip"
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct WeightBlob {
+  std::vector<float> host;
+  std::map<std::string, size_t> off;
+  size_t add(const std::string &key, const std::vector<float> &v) {
+    while (host.size() % 64) host.push_back(0.f);  // 256-byte alignment
+    size_t o = host.size();
+    host.insert(host.end(), v.begin(), v.end());
+    off[key] = o;
+    return o;
+  }
+};
+
+}  // namespace
+
+struct mind_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  // weights
+  float *wdev = nullptr;
+  bool have_weights = false;
+  WeightBlob blob;
+  LaneW laneW;
+  ActorW actorW;
+  DecW decW;
+  TokWeights tokW[7];  // [L]: epilogue of layer L-1 (L>=1) + prologue of layer L (L<=5); [0] = init
+  const float *WAe[6], *WAp[6], *vtab[6], *rtab = nullptr;
+  // workspaces (grow only)
+  DevBuf edge, x, ST, QK, part, tokpos, meta, jobs, actor_feat, lane_feat, tgt_feat, cmode, tgt_emb,
+      rows, rpe_ptrs;
+  // ilqr workspaces
+  DevBuf ilqr_dev;
+  // profiling
+  bool profiling = false;
+  int n_pair_launch = 0;
+  float pair_ms = 0.f;
+  double pairs_done = 0.0;
+  std::vector<hipEvent_t> ev;
+  int n_cu = 256;
+  int debug_layers = 6;
+  int last_ntok = 0;
+  long long last_edge_pairs = 0;
+  int last_slots = 0, last_A = 0, last_B = 0;
+};
+
+static int fail(mind_ctx *c, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                        \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(c, MIND_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+static int ensure(mind_ctx *c, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return MIND_OK;
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes + bytes / 4 + 4096;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    e = hipMalloc(&b.p, bytes);
+    want = bytes;
+    if (e != hipSuccess) return fail(c, MIND_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  b.cap = want;
+  return MIND_OK;
+}
+
+extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
+  if (!out) return MIND_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MIND_EHIP;
+  if (device < 0 || device >= n) return MIND_EINVAL;
+  mind_ctx *c = new mind_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete c; return MIND_EHIP; }
+  // NULL = the device's default (null) stream, which is what torch.cuda.current_stream() is unless the
+  // caller switched streams; the library never creates a stream behind the caller's back.
+  c->stream = (hipStream_t)stream;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+  (void)hipFuncSetAttribute((const void *)k_pair<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_pair<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_actor_net, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_lds_bytes());
+  *out = c;
+  return MIND_OK;
+}
+
+extern "C" int mind_ctx_destroy(mind_ctx *c) {
+  if (!c) return MIND_EINVAL;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  DevBuf *bufs[] = {&c->edge, &c->x, &c->ST, &c->QK, &c->part, &c->tokpos, &c->meta, &c->jobs, &c->actor_feat,
+                    &c->lane_feat, &c->tgt_feat, &c->cmode, &c->tgt_emb, &c->rows, &c->rpe_ptrs, &c->ilqr_dev};
+  for (DevBuf *b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  if (c->wdev) (void)hipFree(c->wdev);
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return MIND_OK;
+}
+
+extern "C" const char *mind_last_error_string(mind_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int mind_ctx_synchronize(mind_ctx *c) {
+  if (!c) return MIND_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MIND_OK;
+}
+
+extern "C" int mind_set_profiling(mind_ctx *c, int enable) {
+  if (!c) return MIND_EINVAL;
+  c->profiling = enable != 0;
+  return MIND_OK;
+}
+
+extern "C" int mind_last_fusion_stats(mind_ctx *c, int *n_launches, float *total_ms, double *pairs) {
+  if (!c) return MIND_EINVAL;
+  if (n_launches) *n_launches = c->n_pair_launch;
+  if (total_ms) *total_ms = c->pair_ms;
+  if (pairs) *pairs = c->pairs_done;
+  return MIND_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// weight packing
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+struct SD {
+  std::map<std::string, std::pair<const float *, int64_t>> m;
+  std::string missing;
+  const float *get(const std::string &k, int64_t numel) {
+    auto it = m.find(k);
+    if (it == m.end() || it->second.second != numel) {
+      if (missing.empty()) missing = k;
+      return nullptr;
+    }
+    return it->second.first;
+  }
+};
+
+std::vector<float> vec(const float *p, size_t n) { return p ? std::vector<float>(p, p + n) : std::vector<float>(n, 0.f); }
+
+// [out][in] -> [in][out]
+std::vector<float> transpose(const float *w, int n_out, int n_in, int row_stride = -1, int col0 = 0) {
+  if (row_stride < 0) row_stride = n_in;
+  std::vector<float> t((size_t)n_out * n_in, 0.f);
+  if (!w) return t;
+  for (int o = 0; o < n_out; ++o)
+    for (int k = 0; k < n_in; ++k) t[(size_t)k * n_out + o] = w[(size_t)o * row_stride + col0 + k];
+  return t;
+}
+
+// MFMA 16x16x4 A-fragment order: [ob 8][s4 8][lane 64][w 4] = W[16 ob + (lane&15)][16 s4 + 4 (lane>>4) + w]
+std::vector<float> pack_afrag(const float *w, int row_stride) {
+  std::vector<float> t(16384, 0.f);
+  if (!w) return t;
+  for (int ob = 0; ob < 8; ++ob)
+    for (int s4 = 0; s4 < 8; ++s4)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int k = 0; k < 4; ++k)
+          t[((size_t)(ob * 8 + s4) * 64 + lane) * 4 + k] =
+              w[(size_t)(16 * ob + (lane & 15)) * row_stride + 16 * s4 + 4 * (lane >> 4) + k];
+  return t;
+}
+
+// conv weight [co][ci][k] -> [ci][k][co]
+std::vector<float> conv_t(const float *w, int co, int ci, int k) {
+  std::vector<float> t((size_t)co * ci * k, 0.f);
+  if (!w) return t;
+  for (int o = 0; o < co; ++o)
+    for (int i = 0; i < ci; ++i)
+      for (int d = 0; d < k; ++d) t[((size_t)i * k + d) * co + o] = w[((size_t)o * ci + i) * k + d];
+  return t;
+}
+
+}  // namespace
+
+extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, int n) {
+  if (!c || !tensors || n <= 0) return MIND_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  SD sd;
+  for (int i = 0; i < n; ++i)
+    if (tensors[i].name && tensors[i].data) sd.m[tensors[i].name] = {tensors[i].data, tensors[i].numel};
+  WeightBlob &B = c->blob;
+  B.host.clear();
+  B.off.clear();
+  auto lin_ln = [&](const std::string &key, const std::string &p, int idx, int n_out, int n_in) {
+    // Linear @idx (transposed) + LayerNorm @idx+1
+    B.add(key + ".W", transpose(sd.get(p + "." + std::to_string(idx) + ".weight", (int64_t)n_out * n_in), n_out, n_in));
+    B.add(key + ".b", vec(sd.get(p + "." + std::to_string(idx) + ".bias", n_out), n_out));
+    B.add(key + ".g", vec(sd.get(p + "." + std::to_string(idx + 1) + ".weight", n_out), n_out));
+    B.add(key + ".be", vec(sd.get(p + "." + std::to_string(idx + 1) + ".bias", n_out), n_out));
+  };
+  // ---- lane_net
+  lin_ln("lane.proj", "lane_net.proj", 0, 128, 16);
+  for (int b = 0; b < 2; ++b) {
+    std::string p = "lane_net.aggre" + std::to_string(b + 1), k = "lane.a" + std::to_string(b);
+    lin_ln(k + ".f10", p + ".fc1", 0, 128, 128);
+    lin_ln(k + ".f13", p + ".fc1", 3, 128, 128);
+    lin_ln(k + ".f20", p + ".fc2", 0, 128, 256);
+    lin_ln(k + ".f23", p + ".fc2", 3, 128, 128);
+    B.add(k + ".ng", vec(sd.get(p + ".norm.weight", 128), 128));
+    B.add(k + ".nb", vec(sd.get(p + ".norm.bias", 128), 128));
+  }
+  // ---- actor_net
+  {
+    const int chans[4] = {32, 64, 128, 256};
+    int n_in = 14;
+    int ri = 0;
+    auto res = [&](const std::string &p, int ci, int co, bool ds) {
+      std::string k = "act.r" + std::to_string(ri++);
+      B.add(k + ".c1", conv_t(sd.get(p + ".conv1.weight", (int64_t)co * ci * 3), co, ci, 3));
+      B.add(k + ".c2", conv_t(sd.get(p + ".conv2.weight", (int64_t)co * co * 3), co, co, 3));
+      B.add(k + ".g1", vec(sd.get(p + ".bn1.weight", co), co));
+      B.add(k + ".b1", vec(sd.get(p + ".bn1.bias", co), co));
+      B.add(k + ".g2", vec(sd.get(p + ".bn2.weight", co), co));
+      B.add(k + ".b2", vec(sd.get(p + ".bn2.bias", co), co));
+      if (ds) {
+        B.add(k + ".ds", conv_t(sd.get(p + ".downsample.0.weight", (int64_t)co * ci), co, ci, 1));
+        B.add(k + ".gd", vec(sd.get(p + ".downsample.1.weight", co), co));
+        B.add(k + ".bd", vec(sd.get(p + ".downsample.1.bias", co), co));
+      }
+    };
+    for (int g = 0; g < 4; ++g) {
+      res("actor_net.groups." + std::to_string(g) + ".0", n_in, chans[g], true);
+      res("actor_net.groups." + std::to_string(g) + ".1", chans[g], chans[g], false);
+      n_in = chans[g];
+    }
+    res("actor_net.output", 128, 128, false);
+    for (int g = 0; g < 4; ++g) {
+      std::string p = "actor_net.lateral." + std::to_string(g), k = "act.lat" + std::to_string(g);
+      B.add(k + ".W", conv_t(sd.get(p + ".conv.weight", (int64_t)128 * chans[g] * 3), 128, chans[g], 3));
+      B.add(k + ".g", vec(sd.get(p + ".norm.weight", 128), 128));
+      B.add(k + ".b", vec(sd.get(p + ".norm.bias", 128), 128));
+    }
+  }
+  // ---- fusion_net
+  lin_ln("fus.pa", "fusion_net.proj_actor", 0, 128, 128);
+  lin_ln("fus.pl", "fusion_net.proj_lane", 0, 128, 128);
+  {
+    // rpe table [32 chunks][8][4]: k<5 W_r[f][k], 5 bias, 6 gamma, 7 beta, f = 4 chunk + w
+    const float *W = sd.get("fusion_net.proj_rpe_scene.0.weight", 128 * 5);
+    const float *b = sd.get("fusion_net.proj_rpe_scene.0.bias", 128);
+    const float *g = sd.get("fusion_net.proj_rpe_scene.1.weight", 128);
+    const float *be = sd.get("fusion_net.proj_rpe_scene.1.bias", 128);
+    std::vector<float> t(1024, 0.f);
+    if (W && b && g && be)
+      for (int ch = 0; ch < 32; ++ch)
+        for (int w = 0; w < 4; ++w) {
+          const int f = 4 * ch + w;
+          for (int k = 0; k < 5; ++k) t[ch * 32 + k * 4 + w] = W[f * 5 + k];
+          t[ch * 32 + 20 + w] = b[f];
+          t[ch * 32 + 24 + w] = g[f];
+          t[ch * 32 + 28 + w] = be[f];
+        }
+    B.add("fus.rtab", t);
+  }
+  for (int L = 0; L < 6; ++L) {
+    std::string p = "fusion_net.fuse_scene.fusion." + std::to_string(L), k = "fus.L" + std::to_string(L);
+    const float *Wm = sd.get(p + ".proj_memory.0.weight", 128 * 384);
+    B.add(k + ".WAe", pack_afrag(Wm, 384));
+    B.add(k + ".WsT", transpose(Wm, 128, 128, 384, 128));
+    B.add(k + ".WtT", transpose(Wm, 128, 128, 384, 256));
+    B.add(k + ".bm", vec(sd.get(p + ".proj_memory.0.bias", 128), 128));
+    std::vector<float> vt(VT_SIZE, 0.f);
+    auto put = [&](int off, const float *src) {
+      if (src) memcpy(vt.data() + off, src, 128 * sizeof(float));
+    };
+    put(VT_GM, sd.get(p + ".proj_memory.1.weight", 128));
+    put(VT_BM, sd.get(p + ".proj_memory.1.bias", 128));
+    if (L != 5) {
+      B.add(k + ".WAp", pack_afrag(sd.get(p + ".proj_edge.0.weight", 128 * 128), 128));
+      put(VT_BP, sd.get(p + ".proj_edge.0.bias", 128));
+      put(VT_GP, sd.get(p + ".proj_edge.1.weight", 128));
+      put(VT_BEP, sd.get(p + ".proj_edge.1.bias", 128));
+      put(VT_GE, sd.get(p + ".norm_edge.weight", 128));
+      put(VT_BE, sd.get(p + ".norm_edge.bias", 128));
+    }
+    B.add(k + ".vtab", vt);
+    const float *Win = sd.get(p + ".multihead_attn.in_proj_weight", 384 * 128);
+    const float *bin = sd.get(p + ".multihead_attn.in_proj_bias", 384);
+    B.add(k + ".WqT", transpose(Win, 128, 128));
+    B.add(k + ".Wk", vec(Win ? Win + 128 * 128 : nullptr, 128 * 128));
+    B.add(k + ".WvT", transpose(Win ? Win + 2 * 128 * 128 : nullptr, 128, 128));
+    B.add(k + ".bq", vec(bin, 128));
+    B.add(k + ".bv", vec(bin ? bin + 256 : nullptr, 128));
+    B.add(k + ".WoT", transpose(sd.get(p + ".multihead_attn.out_proj.weight", 128 * 128), 128, 128));
+    B.add(k + ".bo", vec(sd.get(p + ".multihead_attn.out_proj.bias", 128), 128));
+    B.add(k + ".W1T", transpose(sd.get(p + ".linear1.weight", 256 * 128), 256, 128));
+    B.add(k + ".b1", vec(sd.get(p + ".linear1.bias", 256), 256));
+    B.add(k + ".W2T", transpose(sd.get(p + ".linear2.weight", 128 * 256), 128, 256));
+    B.add(k + ".b2", vec(sd.get(p + ".linear2.bias", 128), 128));
+    B.add(k + ".g2", vec(sd.get(p + ".norm2.weight", 128), 128));
+    B.add(k + ".be2", vec(sd.get(p + ".norm2.bias", 128), 128));
+    B.add(k + ".g3", vec(sd.get(p + ".norm3.weight", 128), 128));
+    B.add(k + ".be3", vec(sd.get(p + ".norm3.bias", 128), 128));
+  }
+  // ---- pred_scene
+  lin_ln("dec.rpe", "pred_scene.proj_rpe", 0, 128, 20);
+  lin_ln("dec.t0", "pred_scene.proj_tgt", 0, 128, 256);
+  lin_ln("dec.t3", "pred_scene.proj_tgt", 3, 128, 128);
+  lin_ln("dec.c0", "pred_scene.ctx_proj", 0, 384, 128);
+  lin_ln("dec.c3", "pred_scene.ctx_proj", 3, 768, 384);
+  lin_ln("dec.a0", "pred_scene.actor_proj", 0, 384, 128);
+  lin_ln("dec.a3", "pred_scene.actor_proj", 3, 768, 384);
+  for (int L = 0; L < 2; ++L) {
+    std::string p = "pred_scene.ctx_sat.layers." + std::to_string(L), k = "dec.e" + std::to_string(L);
+    B.add(k + ".inW", transpose(sd.get(p + ".self_attn.in_proj_weight", 384 * 128), 384, 128));
+    B.add(k + ".inb", vec(sd.get(p + ".self_attn.in_proj_bias", 384), 384));
+    B.add(k + ".outW", transpose(sd.get(p + ".self_attn.out_proj.weight", 128 * 128), 128, 128));
+    B.add(k + ".outb", vec(sd.get(p + ".self_attn.out_proj.bias", 128), 128));
+    B.add(k + ".l1W", transpose(sd.get(p + ".linear1.weight", 1536 * 128), 1536, 128));
+    B.add(k + ".l1b", vec(sd.get(p + ".linear1.bias", 1536), 1536));
+    B.add(k + ".l2W", transpose(sd.get(p + ".linear2.weight", 128 * 1536), 128, 1536));
+    B.add(k + ".l2b", vec(sd.get(p + ".linear2.bias", 128), 128));
+    B.add(k + ".n1g", vec(sd.get(p + ".norm1.weight", 128), 128));
+    B.add(k + ".n1b", vec(sd.get(p + ".norm1.bias", 128), 128));
+    B.add(k + ".n2g", vec(sd.get(p + ".norm2.weight", 128), 128));
+    B.add(k + ".n2b", vec(sd.get(p + ".norm2.bias", 128), 128));
+  }
+  for (const char *hn : {"cls", "reg"}) {
+    std::string p = std::string("pred_scene.") + hn, k = std::string("dec.") + hn;
+    lin_ln(k + "0", p, 0, 128, 128);
+    lin_ln(k + "3", p, 3, 128, 128);
+    const int nl = strcmp(hn, "cls") == 0 ? 1 : 40;
+    B.add(k + "6.W", transpose(sd.get(p + ".6.weight", (int64_t)nl * 128), nl, 128));
+    B.add(k + "6.b", vec(sd.get(p + ".6.bias", nl), nl));
+  }
+  {
+    // Bezier basis (network.py:449-464): float64 numpy -> fp32 (Q21)
+    std::vector<float> T(60 * 8), Tp(60 * 7);
+    auto comb = [](int n, int k) { double r = 1; for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i; return r; };
+    for (int t = 0; t < 60; ++t) {
+      double ts = (t == 59) ? 1.0 : (double)t * (1.0 / 59.0);
+      // numpy linspace: start + arange * step, step = 1/59; last point exactly 1
+      ts = (t == 59) ? 1.0 : 0.0 + (double)t * (1.0 / 59.0);
+      for (int i = 0; i < 8; ++i) T[t * 8 + i] = (float)(comb(7, i) * std::pow(1.0 - ts, 7 - i) * std::pow(ts, i));
+      for (int i = 0; i < 7; ++i) Tp[t * 7 + i] = (float)(7.0 * comb(6, i) * std::pow(1.0 - ts, 6 - i) * std::pow(ts, i));
+    }
+    B.add("dec.T", T);
+    B.add("dec.Tp", Tp);
+  }
+  if (!sd.missing.empty()) return fail(c, MIND_ENOTFOUND, "state_dict tensor missing or wrong size: %s", sd.missing.c_str());
+
+  if (c->wdev) (void)hipFree(c->wdev);
+  c->wdev = nullptr;
+  HIPCHK(c, hipMalloc((void **)&c->wdev, B.host.size() * sizeof(float)));
+  HIPCHK(c, hipMemcpy(c->wdev, B.host.data(), B.host.size() * sizeof(float), hipMemcpyHostToDevice));
+  auto P = [&](const std::string &k) -> const float * {
+    auto it = B.off.find(k);
+    return it == B.off.end() ? nullptr : c->wdev + it->second;
+  };
+  // ---- pointer tables
+  LaneW &lw = c->laneW;
+  lw.pW = P("lane.proj.W"); lw.pb = P("lane.proj.b"); lw.pg = P("lane.proj.g"); lw.pbe = P("lane.proj.be");
+  for (int b = 0; b < 2; ++b) {
+    std::string k = "lane.a" + std::to_string(b);
+    lw.f10W[b] = P(k + ".f10.W"); lw.f10b[b] = P(k + ".f10.b"); lw.f10g[b] = P(k + ".f10.g"); lw.f10be[b] = P(k + ".f10.be");
+    lw.f13W[b] = P(k + ".f13.W"); lw.f13b[b] = P(k + ".f13.b"); lw.f13g[b] = P(k + ".f13.g"); lw.f13be[b] = P(k + ".f13.be");
+    lw.f20W[b] = P(k + ".f20.W"); lw.f20b[b] = P(k + ".f20.b"); lw.f20g[b] = P(k + ".f20.g"); lw.f20be[b] = P(k + ".f20.be");
+    lw.f23W[b] = P(k + ".f23.W"); lw.f23b[b] = P(k + ".f23.b"); lw.f23g[b] = P(k + ".f23.g"); lw.f23be[b] = P(k + ".f23.be");
+    lw.ng[b] = P(k + ".ng"); lw.nbe[b] = P(k + ".nb");
+  }
+  ActorW &aw = c->actorW;
+  for (int r = 0; r < 9; ++r) {
+    std::string k = "act.r" + std::to_string(r);
+    aw.res[r].c1 = P(k + ".c1"); aw.res[r].g1 = P(k + ".g1"); aw.res[r].b1 = P(k + ".b1");
+    aw.res[r].c2 = P(k + ".c2"); aw.res[r].g2 = P(k + ".g2"); aw.res[r].b2 = P(k + ".b2");
+    aw.res[r].ds = P(k + ".ds"); aw.res[r].gd = P(k + ".gd"); aw.res[r].bd = P(k + ".bd");
+  }
+  for (int g = 0; g < 4; ++g) {
+    std::string k = "act.lat" + std::to_string(g);
+    aw.latW[g] = P(k + ".W"); aw.latG[g] = P(k + ".g"); aw.latB[g] = P(k + ".b");
+  }
+  c->rtab = P("fus.rtab");
+  for (int L = 0; L < 6; ++L) {
+    std::string k = "fus.L" + std::to_string(L);
+    c->WAe[L] = P(k + ".WAe");
+    c->WAp[L] = P(k + ".WAp");
+    c->vtab[L] = P(k + ".vtab");
+  }
+  for (int L = 0; L <= 6; ++L) {
+    TokWeights &w = c->tokW[L];
+    memset(&w, 0, sizeof(w));
+    if (L >= 1) {
+      std::string k = "fus.L" + std::to_string(L - 1);
+      w.WvT = P(k + ".WvT"); w.bv = P(k + ".bv"); w.WoT = P(k + ".WoT"); w.bo = P(k + ".bo");
+      w.g2 = P(k + ".g2"); w.b2 = P(k + ".be2"); w.W1T = P(k + ".W1T"); w.b1 = P(k + ".b1");
+      w.W2T = P(k + ".W2T"); w.bb2 = P(k + ".b2"); w.g3 = P(k + ".g3"); w.b3 = P(k + ".be3");
+    }
+    if (L <= 5) {
+      std::string k = "fus.L" + std::to_string(L);
+      w.WsT = P(k + ".WsT"); w.WtT = P(k + ".WtT"); w.bm = P(k + ".bm");
+      w.WqT = P(k + ".WqT"); w.bq = P(k + ".bq"); w.Wk = P(k + ".Wk");
+    }
+    w.WpaT = P("fus.pa.W"); w.bpa = P("fus.pa.b"); w.gpa = P("fus.pa.g"); w.bepa = P("fus.pa.be");
+    w.WplT = P("fus.pl.W"); w.bpl = P("fus.pl.b"); w.gpl = P("fus.pl.g"); w.bepl = P("fus.pl.be");
+  }
+  DecW &d = c->decW;
+  d.rpeW = P("dec.rpe.W"); d.rpeb = P("dec.rpe.b"); d.rpeg = P("dec.rpe.g"); d.rpebe = P("dec.rpe.be");
+  d.t0W = P("dec.t0.W"); d.t0b = P("dec.t0.b"); d.t0g = P("dec.t0.g"); d.t0be = P("dec.t0.be");
+  d.t3W = P("dec.t3.W"); d.t3b = P("dec.t3.b"); d.t3g = P("dec.t3.g"); d.t3be = P("dec.t3.be");
+  d.c0W = P("dec.c0.W"); d.c0b = P("dec.c0.b"); d.c0g = P("dec.c0.g"); d.c0be = P("dec.c0.be");
+  d.c3W = P("dec.c3.W"); d.c3b = P("dec.c3.b"); d.c3g = P("dec.c3.g"); d.c3be = P("dec.c3.be");
+  d.a0W = P("dec.a0.W"); d.a0b = P("dec.a0.b"); d.a0g = P("dec.a0.g"); d.a0be = P("dec.a0.be");
+  d.a3W = P("dec.a3.W"); d.a3b = P("dec.a3.b"); d.a3g = P("dec.a3.g"); d.a3be = P("dec.a3.be");
+  for (int L = 0; L < 2; ++L) {
+    std::string k = "dec.e" + std::to_string(L);
+    d.inW[L] = P(k + ".inW"); d.inb[L] = P(k + ".inb"); d.outW[L] = P(k + ".outW"); d.outb[L] = P(k + ".outb");
+    d.l1W[L] = P(k + ".l1W"); d.l1b[L] = P(k + ".l1b"); d.l2W[L] = P(k + ".l2W"); d.l2b[L] = P(k + ".l2b");
+    d.n1g[L] = P(k + ".n1g"); d.n1b[L] = P(k + ".n1b"); d.n2g[L] = P(k + ".n2g"); d.n2b[L] = P(k + ".n2b");
+  }
+  d.k0W = P("dec.cls0.W"); d.k0b = P("dec.cls0.b"); d.k0g = P("dec.cls0.g"); d.k0be = P("dec.cls0.be");
+  d.k3W = P("dec.cls3.W"); d.k3b = P("dec.cls3.b"); d.k3g = P("dec.cls3.g"); d.k3be = P("dec.cls3.be");
+  d.k6W = P("dec.cls6.W"); d.k6b = P("dec.cls6.b");
+  d.r0W = P("dec.reg0.W"); d.r0b = P("dec.reg0.b"); d.r0g = P("dec.reg0.g"); d.r0be = P("dec.reg0.be");
+  d.r3W = P("dec.reg3.W"); d.r3b = P("dec.reg3.b"); d.r3g = P("dec.reg3.g"); d.r3be = P("dec.reg3.be");
+  d.r6W = P("dec.reg6.W"); d.r6b = P("dec.reg6.b");
+  d.T = P("dec.T"); d.Tp = P("dec.Tp");
+  c->have_weights = true;
+  return MIND_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// predictor forward
+// -------------------------------------------------------------------------------------------------
+__global__ void k_tokpos(const TokMeta *__restrict__ meta, int n_tok, const float *__restrict__ actr,
+                         const float *__restrict__ avec, const float *__restrict__ lctr,
+                         const float *__restrict__ lvec, float *__restrict__ tokpos) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tok) return;
+  const TokMeta m = meta[t];
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (m.type == 0 && actr) o = make_float4(actr[m.src * 2], actr[m.src * 2 + 1], avec[m.src * 2], avec[m.src * 2 + 1]);
+  if (m.type == 1 && lctr) o = make_float4(lctr[m.src * 2], lctr[m.src * 2 + 1], lvec[m.src * 2], lvec[m.src * 2 + 1]);
+  ((float4 *)tokpos)[t] = o;
+}
+
+extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_pred_out *out) {
+  if (!c || !in || !out) return MIND_EINVAL;
+  if (!c->have_weights) return fail(c, MIND_ESTATE, "weights not loaded");
+  const int Bn = in->n_scenes;
+  if (Bn <= 0 || !in->actor_off || !in->lane_off || !in->actors || !in->tgt_nodes || !in->tgt_rpe || !out->cls ||
+      !out->reg || !out->vel)
+    return fail(c, MIND_EINVAL, "null input/output pointer");
+  if (!in->lanes && !in->lane_feat) return fail(c, MIND_EINVAL, "need lanes or lane_feat");
+  if (!in->rpe && !(in->actor_ctrs && in->actor_vecs && in->lane_ctrs && in->lane_vecs))
+    return fail(c, MIND_EINVAL, "need rpe or ctrs/vecs");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const int A = in->actor_off[Bn], Ltot = in->lane_off[Bn];
+  if (A <= 0 || Ltot < 0) return fail(c, MIND_EINVAL, "empty batch");
+
+  // ---- host tables: tokens, jobs
+  std::vector<TokMeta> meta;
+  std::vector<PairJob> jobs;
+  std::vector<int> actor_row(A), actor_scene(A), cls_row(Bn);
+  long long edge_pairs = 0;
+  int ntok = 0;
+  long long total_cols = 0;
+  for (int b = 0; b < Bn; ++b) {
+    const int a = in->actor_off[b + 1] - in->actor_off[b], l = in->lane_off[b + 1] - in->lane_off[b];
+    if (a <= 0 || l < 0) return fail(c, MIND_EINVAL, "scene %d has %d agents, %d lanes", b, a, l);
+    total_cols += a + l + 1;
+  }
+  const int target_jobs = c->n_cu * 4 * 2;
+  int slot = 0;
+  double pairs_full = 0, pairs_l5 = 0;
+  for (int b = 0; b < Bn; ++b) {
+    const int a = in->actor_off[b + 1] - in->actor_off[b], l = in->lane_off[b + 1] - in->lane_off[b];
+    const int N = a + l + 1;
+    const int tiles = (N + 15) / 16;
+    int ns = (int)((target_jobs + total_cols - 1) / total_cols);
+    ns = ns < 1 ? 1 : ns;
+    ns = ns > 8 ? 8 : ns;
+    ns = ns > tiles ? tiles : ns;
+    for (int j = 0; j < N; ++j) {
+      TokMeta m;
+      memset(&m, 0, sizeof(m));
+      m.type = j < a ? 0 : (j < a + l ? 1 : 2);
+      m.src = j < a ? in->actor_off[b] + j : (j < a + l ? in->lane_off[b] + (j - a) : 0);
+      m.slot0 = slot;
+      m.nsplit = ns;
+      m.flags = (j < a || j == N - 1) ? 1 : 0;
+      meta.push_back(m);
+      for (int s = 0; s < ns; ++s) {
+        PairJob J;
+        memset(&J, 0, sizeof(J));
+        J.edge_base = edge_pairs;
+        J.N = N;
+        J.j = j;
+        J.t0 = (int)((long long)tiles * s / ns);
+        J.t1 = (int)((long long)tiles * (s + 1) / ns);
+        J.tok_base = ntok;
+        J.slot = slot++;
+        J.flags = m.flags;
+        J.scene = b;
+        jobs.push_back(J);
+      }
+      if (j < a) { actor_row[in->actor_off[b] + j] = ntok + j; actor_scene[in->actor_off[b] + j] = b; }
+    }
+    cls_row[b] = ntok + N - 1;
+    ntok += N;
+    edge_pairs += (long long)N * N;
+    pairs_full += (double)N * N;
+    pairs_l5 += (double)N * (a + 1);
+  }
+  const int njobs = (int)jobs.size();
+
+  // ---- workspaces
+  int rc;
+  if ((rc = ensure(c, c->edge, (size_t)edge_pairs * 128 * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->x, (size_t)ntok * 128 * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->ST, (size_t)ntok * 256 * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->QK, (size_t)ntok * 1024 * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->part, (size_t)slot * PART_STRIDE * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->tokpos, (size_t)ntok * 4 * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->meta, meta.size() * sizeof(TokMeta)))) return rc;
+  if ((rc = ensure(c, c->jobs, jobs.size() * sizeof(PairJob)))) return rc;
+  if ((rc = ensure(c, c->actor_feat, (size_t)A * 128 * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->lane_feat, (size_t)(Ltot > 0 ? Ltot : 1) * 128 * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->tgt_feat, (size_t)Bn * 128 * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->cmode, (size_t)Bn * 768 * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->tgt_emb, (size_t)Bn * 128 * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->rows, (size_t)(2 * A + Bn) * sizeof(int)))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->meta.p, meta.data(), meta.size() * sizeof(TokMeta), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->jobs.p, jobs.data(), jobs.size() * sizeof(PairJob), hipMemcpyHostToDevice, st));
+  std::vector<int> rows(2 * A + Bn);
+  memcpy(rows.data(), actor_row.data(), A * sizeof(int));
+  memcpy(rows.data() + A, actor_scene.data(), A * sizeof(int));
+  memcpy(rows.data() + 2 * A, cls_row.data(), Bn * sizeof(int));
+  HIPCHK(c, hipMemcpyAsync(c->rows.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  const float *const *rpe_dev = nullptr;
+  if (in->rpe) {
+    if ((rc = ensure(c, c->rpe_ptrs, (size_t)Bn * sizeof(float *)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->rpe_ptrs.p, in->rpe, (size_t)Bn * sizeof(float *), hipMemcpyHostToDevice, st));
+    rpe_dev = (const float *const *)c->rpe_ptrs.p;
+  }
+  // the host vectors above must outlive the async copies
+  HIPCHK(c, hipStreamSynchronize(st));
+
+  const TokMeta *dmeta = (const TokMeta *)c->meta.p;
+  const PairJob *djobs = (const PairJob *)c->jobs.p;
+  float *x = (float *)c->x.p, *ST = (float *)c->ST.p, *QK = (float *)c->QK.p, *part = (float *)c->part.p;
+  float *edge = (float *)c->edge.p, *tokpos = (float *)c->tokpos.p;
+  float *actor_feat = (float *)c->actor_feat.p;
+  const float *lane_feat = in->lane_feat;
+
+  // ---- encoders
+  hipLaunchKernelGGL(k_actor_net, dim3(A), dim3(256), mind_actor_lds_bytes(), st, in->actors, A, actor_feat, c->actorW);
+  if (!lane_feat) {
+    float *lf = out->lane_feat ? out->lane_feat : (float *)c->lane_feat.p;
+    if (Ltot > 0)
+      hipLaunchKernelGGL(k_lane_net, dim3((Ltot + PL - 1) / PL), dim3(256), 0, st, in->lanes, Ltot, lf, c->laneW);
+    lane_feat = lf;
+  } else if (out->lane_feat && out->lane_feat != in->lane_feat && Ltot > 0) {
+    HIPCHK(c, hipMemcpyAsync(out->lane_feat, in->lane_feat, (size_t)Ltot * 128 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  hipLaunchKernelGGL(k_lane_net, dim3((Bn + PL - 1) / PL), dim3(256), 0, st, in->tgt_nodes, Bn, (float *)c->tgt_feat.p, c->laneW);
+  hipLaunchKernelGGL(k_tokpos, dim3((ntok + 255) / 256), dim3(256), 0, st, dmeta, ntok, in->actor_ctrs, in->actor_vecs,
+                     in->lane_ctrs, in->lane_vecs, tokpos);
+
+  // ---- fusion: init tokens + 6 x (pair kernel, token kernel)
+  const int tok_blocks = (ntok + TPW - 1) / TPW;
+  hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(128), 0, st, dmeta, ntok, 1 | 4, actor_feat, lane_feat, x, part, ST, QK,
+                     c->tokW[0]);
+  int grid = (njobs + 3) / 4;
+  if (grid > c->n_cu) grid = c->n_cu;
+  const size_t lds = mind_pair_lds_bytes();
+  c->n_pair_launch = 0;
+  c->pairs_done = 0;
+  if (c->profiling && c->ev.size() < 12) {
+    while (c->ev.size() < 12) {
+      hipEvent_t e;
+      HIPCHK(c, hipEventCreate(&e));
+      c->ev.push_back(e);
+    }
+  }
+  c->last_ntok = ntok; c->last_edge_pairs = edge_pairs; c->last_slots = slot; c->last_A = A; c->last_B = Bn;
+  for (int L = 0; L < c->debug_layers; ++L) {
+    const int um = L < 4 ? 0 : (L == 4 ? 1 : 2);
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2 * L], st));
+    if (L == 0)
+      hipLaunchKernelGGL(k_pair<0>, dim3(grid), dim3(256), lds, st, djobs, njobs, edge, ST, QK, part, c->WAe[L], c->WAp[L],
+                         c->vtab[L], c->rtab, tokpos, rpe_dev, um);
+    else
+      hipLaunchKernelGGL(k_pair<1>, dim3(grid), dim3(256), lds, st, djobs, njobs, edge, ST, QK, part, c->WAe[L],
+                         L == 5 ? c->WAe[L] : c->WAp[L], c->vtab[L], c->rtab, tokpos, rpe_dev, um);
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2 * L + 1], st));
+    c->n_pair_launch++;
+    c->pairs_done += (L == 5) ? pairs_l5 : pairs_full;
+    const int mode = 2 | (L < 5 ? 4 : 8);
+    hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(128), 0, st, dmeta, ntok, mode, actor_feat, lane_feat, x, part, ST, QK,
+                       c->tokW[L + 1]);
+  }
+  // ---- decoder
+  const int *d_actor_row = (const int *)c->rows.p;
+  const int *d_actor_scene = d_actor_row + A;
+  const int *d_cls_row = d_actor_row + 2 * A;
+  hipLaunchKernelGGL(k_dec_scene, dim3(Bn), dim3(256), 0, st, x, d_cls_row, (const float *)c->tgt_feat.p, in->tgt_rpe,
+                     (float *)c->cmode.p, (float *)c->tgt_emb.p, out->cls, c->decW);
+  hipLaunchKernelGGL(k_dec_actor, dim3((A + RA - 1) / RA), dim3(256), 0, st, x, d_actor_row, d_actor_scene, A,
+                     (const float *)c->cmode.p, (const float *)c->tgt_emb.p, out->reg, out->vel, c->decW);
+  if (out->actor_emb || out->cls_emb) {
+    // debug taps: gather fused tokens
+    for (int a = 0; a < A && out->actor_emb; ++a)
+      HIPCHK(c, hipMemcpyAsync(out->actor_emb + (size_t)a * 128, x + (size_t)actor_row[a] * 128, 128 * sizeof(float),
+                               hipMemcpyDeviceToDevice, st));
+    for (int b = 0; b < Bn && out->cls_emb; ++b)
+      HIPCHK(c, hipMemcpyAsync(out->cls_emb + (size_t)b * 128, x + (size_t)cls_row[b] * 128, 128 * sizeof(float),
+                               hipMemcpyDeviceToDevice, st));
+  }
+  HIPCHK(c, hipGetLastError());
+  if (c->profiling) {
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->pair_ms = 0.f;
+    for (int L = 0; L < c->debug_layers; ++L) {
+      float ms = 0.f;
+      HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2 * L], c->ev[2 * L + 1]));
+      c->pair_ms += ms;
+    }
+  }
+  return MIND_OK;
+}
+
+extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *, const mind_cost_tree *, int, const double *,
+                                     const double *, int, double, int, const double *, double *, double *,
+                                     mind_ilqr_stats *) {
+  return fail(c, MIND_ESTATE, "mind_ilqr_solve_trees: not built yet");
+}
+
+// ---- debug taps (tests only): run only the first n fusion layers; read back internal buffers
+extern "C" int mind_debug_set_layers(mind_ctx *c, int n) {
+  if (!c || n < 0 || n > 6) return MIND_EINVAL;
+  c->debug_layers = n;
+  return MIND_OK;
+}
+extern "C" int64_t mind_debug_read(mind_ctx *c, const char *name, float *host, int64_t max_floats) {
+  if (!c || !name) return MIND_EINVAL;
+  const void *src = nullptr;
+  int64_t n = 0;
+  std::string k = name;
+  if (k == "x") { src = c->x.p; n = (int64_t)c->last_ntok * 128; }
+  else if (k == "ST") { src = c->ST.p; n = (int64_t)c->last_ntok * 256; }
+  else if (k == "QK") { src = c->QK.p; n = (int64_t)c->last_ntok * 1024; }
+  else if (k == "edge") { src = c->edge.p; n = c->last_edge_pairs * 128; }
+  else if (k == "part") { src = c->part.p; n = (int64_t)c->last_slots * PART_STRIDE; }
+  else if (k == "actor_feat") { src = c->actor_feat.p; n = (int64_t)c->last_A * 128; }
+  else if (k == "tokpos") { src = c->tokpos.p; n = (int64_t)c->last_ntok * 4; }
+  else if (k == "cmode") { src = c->cmode.p; n = (int64_t)c->last_B * 768; }
+  else if (k == "tgt_emb") { src = c->tgt_emb.p; n = (int64_t)c->last_B * 128; }
+  else if (k == "tgt_feat") { src = c->tgt_feat.p; n = (int64_t)c->last_B * 128; }
+  else return MIND_EINVAL;
+  if (!host) return n;
+  if (n > max_floats) n = max_floats;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return MIND_EHIP;
+  if (hipMemcpy(host, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return MIND_EHIP;
+  return n;
+}

@@ -180,7 +180,7 @@ def _mha_self(sd, p, x, nhead, dtype):
     return _lin(o, sd, p + ".out_proj", dtype)
 
 
-def scene_decoder(sd, cls_tok, actors, tgt_feat, tgt_rpe, dtype=torch.float32):
+def scene_decoder(sd, cls_tok, actors, tgt_feat, tgt_rpe, dtype=torch.float32, taps=None):
     """One scene: cls_tok [128], actors [a,128], tgt_feat [128], tgt_rpe [20].
     Returns cls [1,6], reg [a,6,60,5], vel [a,6,60,2]."""
     a = actors.shape[0]
@@ -198,6 +198,9 @@ def scene_decoder(sd, cls_tok, actors, tgt_feat, tgt_rpe, dtype=torch.float32):
         C = _ln(C + _mha_self(sd, p + ".self_attn", C, 4, dtype), sd, p + ".norm1", dtype)
         ff = _lin(torch.relu(_lin(C, sd, p + ".linear1", dtype)), sd, p + ".linear2", dtype)
         C = _ln(C + ff, sd, p + ".norm2", dtype)
+    if taps is not None:
+        taps["tgt_emb"] = tgt.clone()
+        taps["cmode"] = C.clone()
     A = mm_proj(actors, "actor_proj")                      # [6,a,128]
     E = C + A
     E = torch.cat([E[:1] + tgt.view(1, 1, D), E[1:]], dim=0)   # target embedding on mode 0 only (Q6)
@@ -239,7 +242,11 @@ def forward(sd, batch, dtype=torch.float32, taps=None):
             a_new, _, c_new = fusion_net(sd, act[ai], lan[li], r, dtype, ft)
             if taps is not None:
                 taps["fusion"].append(ft)
-            c, rg, v = scene_decoder(sd, c_new, a_new, tgt[b], batch["TGT_RPE"][b], dtype)
+            dt = {} if taps is not None else None
+            c, rg, v = scene_decoder(sd, c_new, a_new, tgt[b], batch["TGT_RPE"][b], dtype, dt)
+            if taps is not None:
+                taps.setdefault("dec", []).append(dt)
+                taps["tgt_feat"] = tgt.clone()
             res_cls.append(c)
             res_reg.append(rg)
             res_vel.append(v)
