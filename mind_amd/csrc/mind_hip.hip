@@ -662,10 +662,158 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   return MIND_OK;
 }
 
-extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *, const mind_cost_tree *, int, const double *,
-                                     const double *, int, double, int, const double *, double *, double *,
-                                     mind_ilqr_stats *) {
-  return fail(c, MIND_ESTATE, "mind_ilqr_solve_trees: not built yet");
+// -------------------------------------------------------------------------------------------------
+// tree-iLQR host side
+// -------------------------------------------------------------------------------------------------
+extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_cost_tree *trees, int n_trees,
+                                     const double *x0, const double *target_lane, int n_lane_pts, double target_vel,
+                                     int use_exo, const double *us_init, double *xs, double *us,
+                                     mind_ilqr_stats *stats) {
+  if (!c || !cfg || !trees || n_trees <= 0 || !x0 || !target_lane || n_lane_pts < 2 || !xs || !us)
+    return fail(c, MIND_EINVAL, "mind_ilqr_solve_trees: bad argument");
+  if (cfg->grid_w < 3 || cfg->grid_h < 3 || cfg->max_iter < 0) return fail(c, MIND_EINVAL, "bad grid / max_iter");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const int W = cfg->grid_w, H = cfg->grid_h;
+  // ---- grid coordinates exactly as numpy builds them (ilqr/utils.py:7-13)
+  std::vector<double> gx(W), gy(H);
+  const double fsx = (double)(W - 1) * cfg->grid_res, fsy = (double)(H - 1) * cfg->grid_res;
+  const double offx = x0[0] - 0.5 * fsx, offy = x0[1] - 0.5 * fsy;
+  {
+    const double sx = fsx / (double)(W - 1), sy = fsy / (double)(H - 1);
+    for (int i = 0; i < W; ++i) gx[i] = (double)i * sx + 0.0;
+    gx[W - 1] = fsx;
+    for (int i = 0; i < H; ++i) gy[i] = (double)i * sy + 0.0;
+    gy[H - 1] = fsy;
+    for (int i = 0; i < W; ++i) gx[i] += offx;
+    for (int i = 0; i < H; ++i) gy[i] += offy;
+  }
+  // ---- layout of one device arena: [doubles | floats | ints | tree structs]
+  size_t nd = 0, nf = 0, ni = 0;
+  auto takeD = [&](size_t n) { size_t o = nd; nd += (n + 1) & ~(size_t)1; return o; };
+  auto takeF = [&](size_t n) { size_t o = nf; nf += (n + 3) & ~(size_t)3; return o; };
+  auto takeI = [&](size_t n) { size_t o = ni; ni += (n + 3) & ~(size_t)3; return o; };
+  const size_t o_gx = takeD(W), o_gy = takeD(H), o_lane = takeD((size_t)n_lane_pts * 2), o_quad = takeD((size_t)W * H);
+  struct TL { size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist; int M, a, nl; };
+  std::vector<TL> tl(n_trees);
+  long Mtot = 0;
+  for (int t = 0; t < n_trees; ++t) {
+    const mind_cost_tree &tr = trees[t];
+    if (tr.n_nodes <= 0 || !tr.parent || !tr.prob || tr.n_agents <= 0 || (use_exo && (!tr.agent_mean || !tr.agent_cov)))
+      return fail(c, MIND_EINVAL, "tree %d: bad arrays", t);
+    const size_t M = tr.n_nodes;
+    TL &L = tl[t];
+    L.M = (int)M; L.a = tr.n_agents;
+    L.xs = takeD(6 * M); L.us = takeD(2 * M); L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M);
+    L.Lxx = takeD(36 * M); L.k = takeD(2 * M); L.K = takeD(12 * M); L.Vx = takeD(6 * M); L.Vxx = takeD(36 * M);
+    L.xsn = takeD(60 * M); L.usn = takeD(20 * M); L.Ln = takeD(10 * M); L.stats = takeD(4);
+    L.prob = takeF(M); L.mean = takeF(M * tr.n_agents * 2); L.cov = takeF(M * tr.n_agents);
+    L.parent = takeI(M); L.lnodes = takeI(M); L.cstart = takeI(M + 1); L.clist = takeI(M);
+    Mtot += (long)M;
+  }
+  // levels need the depth first
+  std::vector<std::vector<int>> lvl_start(n_trees), lvl_nodes(n_trees), cst(n_trees), cls(n_trees);
+  for (int t = 0; t < n_trees; ++t) {
+    const mind_cost_tree &tr = trees[t];
+    const int M = tr.n_nodes;
+    std::vector<int> depth(M, 0);
+    int maxd = 0;
+    for (int i = 0; i < M; ++i) {
+      const int p = tr.parent[i];
+      if (i == 0 ? p != -1 : (p < 0 || p >= i)) return fail(c, MIND_EINVAL, "tree %d: node %d has parent %d", t, i, p);
+      depth[i] = i == 0 ? 0 : depth[p] + 1;
+      maxd = depth[i] > maxd ? depth[i] : maxd;
+    }
+    tl[t].nl = maxd + 1;
+    lvl_start[t].assign(maxd + 2, 0);
+    for (int i = 0; i < M; ++i) lvl_start[t][depth[i] + 1]++;
+    for (int d = 0; d <= maxd; ++d) lvl_start[t][d + 1] += lvl_start[t][d];
+    lvl_nodes[t].resize(M);
+    std::vector<int> fill(maxd + 1, 0);
+    for (int i = 0; i < M; ++i) lvl_nodes[t][lvl_start[t][depth[i]] + fill[depth[i]]++] = i;
+    cst[t].assign(M + 1, 0);
+    for (int i = 1; i < M; ++i) cst[t][tr.parent[i] + 1]++;
+    for (int i = 0; i < M; ++i) cst[t][i + 1] += cst[t][i];
+    cls[t].assign(M > 1 ? M : 1, 0);
+    std::vector<int> cf(M, 0);
+    for (int i = 1; i < M; ++i) cls[t][cst[t][tr.parent[i]] + cf[tr.parent[i]]++] = i;
+    tl[t].lstart = takeI(maxd + 2);
+  }
+  const size_t bytesD = nd * sizeof(double), bytesF = nf * sizeof(float), bytesI = ni * sizeof(int);
+  const size_t o_structs = bytesD + bytesF + bytesI;
+  const size_t total = o_structs + (size_t)n_trees * sizeof(IlqrTreeDev);
+  int rc;
+  if ((rc = ensure(c, c->ilqr_dev, total))) return rc;
+  char *base = (char *)c->ilqr_dev.p;
+  double *dD = (double *)base;
+  float *dF = (float *)(base + bytesD);
+  int *dI = (int *)(base + bytesD + bytesF);
+  // host staging of the read-only part
+  std::vector<double> hD(nd, 0.0);
+  std::vector<float> hF(nf, 0.f);
+  std::vector<int> hI(ni, 0);
+  memcpy(hD.data() + o_gx, gx.data(), W * sizeof(double));
+  memcpy(hD.data() + o_gy, gy.data(), H * sizeof(double));
+  memcpy(hD.data() + o_lane, target_lane, (size_t)n_lane_pts * 2 * sizeof(double));
+  std::vector<IlqrTreeDev> hT(n_trees);
+  long moff = 0;
+  for (int t = 0; t < n_trees; ++t) {
+    const mind_cost_tree &tr = trees[t];
+    const TL &L = tl[t];
+    const size_t M = L.M;
+    if (us_init) memcpy(hD.data() + L.us, us_init + moff * 2, 2 * M * sizeof(double));
+    memcpy(hF.data() + L.prob, tr.prob, M * sizeof(float));
+    if (tr.agent_mean) memcpy(hF.data() + L.mean, tr.agent_mean, M * L.a * 2 * sizeof(float));
+    if (tr.agent_cov) memcpy(hF.data() + L.cov, tr.agent_cov, M * L.a * sizeof(float));
+    memcpy(hI.data() + L.parent, tr.parent, M * sizeof(int));
+    memcpy(hI.data() + L.lstart, lvl_start[t].data(), lvl_start[t].size() * sizeof(int));
+    memcpy(hI.data() + L.lnodes, lvl_nodes[t].data(), M * sizeof(int));
+    memcpy(hI.data() + L.cstart, cst[t].data(), (M + 1) * sizeof(int));
+    memcpy(hI.data() + L.clist, cls[t].data(), cls[t].size() * sizeof(int));
+    IlqrTreeDev &D = hT[t];
+    D.M = L.M; D.n_agents = L.a; D.n_levels = L.nl; D.pad = 0;
+    D.parent = dI + L.parent; D.level_start = dI + L.lstart; D.level_nodes = dI + L.lnodes;
+    D.child_start = dI + L.cstart; D.child_list = dI + L.clist;
+    D.prob = dF + L.prob; D.mean = dF + L.mean; D.cov = dF + L.cov;
+    D.xs = dD + L.xs; D.us = dD + L.us; D.Fx = dD + L.Fx; D.L = dD + L.L; D.Lx = dD + L.Lx; D.Lxx = dD + L.Lxx;
+    D.k = dD + L.k; D.K = dD + L.K; D.Vx = dD + L.Vx; D.Vxx = dD + L.Vxx;
+    D.xs_new = dD + L.xsn; D.us_new = dD + L.usn; D.L_new = dD + L.Ln; D.stats = dD + L.stats;
+    moff += (long)M;
+  }
+  HIPCHK(c, hipMemcpyAsync(dD, hD.data(), bytesD, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dF, hF.data(), bytesF, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dI, hI.data(), bytesI, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(base + o_structs, hT.data(), (size_t)n_trees * sizeof(IlqrTreeDev), hipMemcpyHostToDevice, st));
+  IlqrConst K;
+  memset(&K, 0, sizeof(K));
+  K.dt = cfg->dt; K.wb = cfg->wheelbase;
+  for (int i = 0; i < 6; ++i) { K.w_des[i] = cfg->w_des_state[i]; K.w_con[i] = cfg->w_state_con[i]; K.lb[i] = cfg->state_lower[i]; K.ub[i] = cfg->state_upper[i]; K.x0[i] = x0[i]; }
+  K.w_ctrl[0] = cfg->w_ctrl[0]; K.w_ctrl[1] = cfg->w_ctrl[1];
+  K.w_tgt = cfg->w_tgt; K.w_ego = cfg->w_ego; K.w_ego_off = cfg->w_ego_cov_offset; K.w_exo = cfg->w_exo;
+  K.w_exo_off = cfg->w_exo_cov_offset; K.w_exo_cost = cfg->w_exo_cost_offset;
+  K.res = cfg->grid_res; K.off_x = offx; K.off_y = offy; K.target_vel = target_vel;
+  K.W = W; K.H = H; K.max_iter = cfg->max_iter; K.use_exo = use_exo;
+  for (int j = 0; j < IL_NA; ++j) K.alphas[j] = std::pow(1.1, -(double)(j * j));
+  K.gx = dD + o_gx; K.gy = dD + o_gy; K.quad = dD + o_quad;
+  hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, K.gx, K.gy, W, H, dD + o_lane, n_lane_pts, dD + o_quad);
+  hipLaunchKernelGGL(k_ilqr, dim3(n_trees), dim3(IL_THREADS), 0, st, (const IlqrTreeDev *)(base + o_structs), K);
+  HIPCHK(c, hipGetLastError());
+  moff = 0;
+  std::vector<double> hs(4 * n_trees);
+  for (int t = 0; t < n_trees; ++t) {
+    const TL &L = tl[t];
+    HIPCHK(c, hipMemcpyAsync(xs + moff * 6, dD + L.xs, (size_t)L.M * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(us + moff * 2, dD + L.us, (size_t)L.M * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hs.data() + 4 * t, dD + L.stats, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    moff += L.M;
+  }
+  HIPCHK(c, hipStreamSynchronize(st));
+  if (stats)
+    for (int t = 0; t < n_trees; ++t) {
+      stats[t].iterations = (int)hs[4 * t]; stats[t].converged = (int)hs[4 * t + 1];
+      stats[t].J = hs[4 * t + 2]; stats[t].mu = hs[4 * t + 3];
+    }
+  return MIND_OK;
 }
 
 // ---- debug taps (tests only): run only the first n fusion layers; read back internal buffers

@@ -123,6 +123,43 @@ class HipPredictor:
         _lib.check(self.lib, self.ctx, rc, "mind_predict_batch")
         return out
 
+    # ------------------------------------------------------------------------------------------
+    def ilqr_solve(self, cfg, flats, x0, lane, target_vel, use_exo, us_init=None):
+        """Solve all cost trees of a plan in one launch.  ``flats``: list of dicts with parent int32 [M],
+        prob f32 [M], mean f32 [M,a,2], cov f32 [M,a] (trajectory-node arrays in creation order);
+        ``cfg``: ``_lib.IlqrCfg``.  Returns (xs list[[M,6]], us list[[M,2]], stats list[dict])."""
+        n = len(flats)
+        trees = (_lib.CostTree * n)()
+        keep = []
+        Ms = []
+        for i, f in enumerate(flats):
+            par = np.ascontiguousarray(f["parent"], np.int32)
+            prob = np.ascontiguousarray(f["prob"], np.float32)
+            mean = np.ascontiguousarray(f["mean"], np.float32)
+            cov = np.ascontiguousarray(f["cov"], np.float32)
+            keep += [par, prob, mean, cov]
+            trees[i].n_nodes = len(par)
+            trees[i].parent = par.ctypes.data_as(C.POINTER(C.c_int32))
+            trees[i].prob = prob.ctypes.data_as(C.POINTER(C.c_float))
+            trees[i].n_agents = mean.shape[1]
+            trees[i].agent_mean = mean.ctypes.data_as(C.POINTER(C.c_float))
+            trees[i].agent_cov = cov.ctypes.data_as(C.POINTER(C.c_float))
+            Ms.append(len(par))
+        Mt = int(sum(Ms))
+        x0 = np.ascontiguousarray(x0, np.float64)
+        lane = np.ascontiguousarray(lane, np.float64)
+        xs = np.zeros((Mt, 6))
+        us = np.zeros((Mt, 2))
+        st = (_lib.IlqrStats * n)()
+        ui = None if us_init is None else np.ascontiguousarray(np.concatenate(us_init), np.float64)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+        rc = self.lib.mind_ilqr_solve_trees(self.ctx, C.byref(cfg), trees, n, dp(x0), dp(lane), len(lane),
+                                            C.c_double(float(target_vel)), int(use_exo), dp(ui), dp(xs), dp(us), st)
+        _lib.check(self.lib, self.ctx, rc, "mind_ilqr_solve_trees")
+        offs = np.cumsum([0] + Ms)
+        return ([xs[offs[i]:offs[i + 1]] for i in range(n)], [us[offs[i]:offs[i + 1]] for i in range(n)],
+                [dict(iterations=st[i].iterations, converged=st[i].converged, J=st[i].J, mu=st[i].mu) for i in range(n)])
+
     def predict_numpy_batch(self, pb, use_rpe=False, **kw):
         """Convenience for tests: ``pb`` as produced by ``mind_amd.synth.predictor_batch`` (numpy)."""
         dev = self.device
