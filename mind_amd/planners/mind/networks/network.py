@@ -1,0 +1,84 @@
+"""``ScenePredNet``: the reference's predictor call surface (planners/mind/networks/network.py:559-606)
+over the hand-written HIP kernels.  ``pre_process(data)`` / ``__call__(data_in)`` / ``load_state_dict`` /
+``to`` / ``eval`` behave like the torch module they replace; there is no torch compute inside."""
+import numpy as np
+import torch
+
+from ....runtime import get_runtime
+
+
+class ScenePredNet:
+    computes_rpe_in_kernel = True   # RPE (mind/utils.py:193-212) is evaluated inside the fusion kernel
+
+    def __init__(self, cfg=None, device=None):
+        self.cfg = cfg or {}
+        self.device = device
+        idx = device.index if isinstance(device, torch.device) and device.index is not None else 0
+        self.rt = get_runtime(idx)
+        self.last_lane_feat = None
+        self._loaded = False
+
+    # torch.nn.Module look-alikes -----------------------------------------------------------------
+    def load_state_dict(self, sd, strict=True):
+        self.rt.load_state_dict(sd)
+        self._loaded = True
+        return self
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        return iter(())
+
+    # ---------------------------------------------------------------------------------------------
+    def pre_process(self, data):
+        """Host batch dict (collate layout, mind/utils.py:142-168) -> device tensors + offsets."""
+        dev = self.rt.device
+        g = lambda t: (t if isinstance(t, torch.Tensor) else torch.as_tensor(t)).to(dev, torch.float32, non_blocking=True).contiguous()
+        a_off = [0]
+        for i in data["ACTOR_IDCS"]:
+            a_off.append(a_off[-1] + len(i))
+        l_off = [0]
+        for i in data["LANE_IDCS"]:
+            l_off.append(l_off[-1] + len(i))
+        out = {"actors": g(data["ACTORS"]), "a_off": a_off, "l_off": l_off, "tgt_nodes": g(data["TGT_NODES"]),
+               "tgt_rpe": g(data["TGT_RPE"]), "lanes": None, "lane_feat": None, "rpe": None,
+               "lane_shared": bool(data.get("LANE_SHARED", False))}
+        if "ACTOR_CTRS" in data:
+            out.update(actor_ctrs=g(data["ACTOR_CTRS"]), actor_vecs=g(data["ACTOR_VECS"]),
+                       lane_ctrs=g(data["LANE_CTRS"]), lane_vecs=g(data["LANE_VECS"]))
+        else:   # reference-style input: precomputed RPE tensors only
+            out.update(actor_ctrs=None, actor_vecs=None, lane_ctrs=None, lane_vecs=None)
+            out["rpe"] = [g(r["scene"] if isinstance(r, dict) else r) for r in data["RPE"]]
+        cache = data.get("LANE_FEAT_CACHE")
+        B = len(a_off) - 1
+        if cache is not None and out["lane_shared"] and cache.shape[0] * B == l_off[-1]:
+            out["lane_feat"] = cache.repeat(B, 1) if B > 1 else cache
+        else:
+            out["lanes"] = g(data["LANES"])
+        return out
+
+    def __call__(self, d):
+        if not self._loaded:
+            raise RuntimeError("ScenePredNet: load_state_dict() has not been called")
+        want = d["lane_feat"] is None
+        o = self.rt.predict(d["actors"], d["a_off"], d["lanes"], d["l_off"], d["actor_ctrs"], d["actor_vecs"],
+                            d["lane_ctrs"], d["lane_vecs"], d["tgt_nodes"], d["tgt_rpe"], rpe=d["rpe"],
+                            lane_feat=d["lane_feat"], want_lane_feat=want)
+        B = len(d["a_off"]) - 1
+        if want and d["lane_shared"] and "lane_feat" in o:
+            l0 = d["l_off"][1]
+            self.last_lane_feat = o["lane_feat"][:l0]
+        elif not want:
+            self.last_lane_feat = d["lane_feat"][:d["l_off"][1]]
+        else:
+            self.last_lane_feat = None
+        res_cls = [o["cls"][b:b + 1] for b in range(B)]
+        res_reg = [o["reg"][d["a_off"][b]:d["a_off"][b + 1]] for b in range(B)]
+        res_aux = [(o["vel"][d["a_off"][b]:d["a_off"][b + 1]], None, None) for b in range(B)]
+        return res_cls, res_reg, res_aux
+
+    forward = __call__

@@ -1,0 +1,192 @@
+"""``MINDPlanner`` facade with the call surface ``agent.py`` uses (reference planners/mind/planner.py:
+12-224): ``MINDPlanner(config_dir)``, ``update_target_lane``, ``update_state_ctrl``, ``plan(lcl_smp) ->
+(ok, ctrl(a, delta), [[scenario_tree], [trajectory_tree]])``, ``update_observation``.
+
+plan() = AIME scenario tree (batched predictor on the GPU) -> contingency tree-iLQR for every
+scenario tree (all trees in one launch) -> min-cost tree -> first control.
+"""
+import json
+import os
+from collections import namedtuple
+from importlib import import_module
+
+import numpy as np
+import torch
+
+from .scenario_tree import ScenarioTreeGenerator
+from .trajectory_tree import TrajectoryTreeOptimizer
+
+try:   # the real AV2 schema when it is installed next to the reference
+    from av2.datasets.motion_forecasting.data_schema import ObjectState, Track, TrackCategory
+except Exception:   # same field order as av2 0.2.1 (constructed positionally, planner.py:61-64,69-71)
+    ObjectState = namedtuple("ObjectState", "observed timestep position heading velocity")
+
+    class Track:
+        def __init__(self, track_id, object_states, object_type, category):
+            self.track_id, self.object_states, self.object_type, self.category = track_id, object_states, object_type, category
+
+    class TrackCategory:
+        TRACK_FRAGMENT, UNSCORED_TRACK, SCORED_TRACK, FOCAL_TRACK = range(4)
+
+
+def _import_cfg(name):
+    try:
+        return import_module(name)
+    except ImportError:
+        return import_module("mind_amd." + name)
+
+
+class MINDPlanner:
+    def __init__(self, config_dir):
+        self.obs_len = 50
+        self.plan_len = 50
+        self.agent_obs = {}
+        self.state = None
+        self.ctrl = None
+        self.gt_tgt_lane = None
+        self.last_ctrl_seq = []
+        self.timing = {}
+        if isinstance(config_dir, dict):
+            self.planner_cfg = config_dir
+        else:
+            with open(config_dir, "r") as f:
+                self.planner_cfg = json.load(f)
+        self.init_device()
+        self.init_network()
+        self.init_scen_tree_gen()
+        self.init_traj_tree_opt()
+
+    # ------------------------------------------------------------------------------------------
+    def init_device(self):
+        if not (self.planner_cfg.get("use_cuda", True) and torch.cuda.is_available()):
+            raise RuntimeError("MINDPlanner (MI355X build) needs a GPU: there is no CPU execution path")
+        self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+
+    def init_network(self):
+        self.network_cfg = _import_cfg(self.planner_cfg["network_config"]).NetCfg()
+        net_cfg = self.network_cfg.get_net_cfg()
+        from .networks.network import ScenePredNet
+        self.network = ScenePredNet(net_cfg, self.device)
+        path = self.planner_cfg["ckpt_path"]
+        if str(path).startswith("formula:"):
+            from ...weights import formula_state_dict
+            sd = formula_state_dict(int(path.split(":")[1]), as_torch=True)
+        else:
+            sd = torch.load(path, map_location="cpu")["state_dict"]
+        self.network.load_state_dict(sd)
+        self.network = self.network.to(self.device)
+        self.network.eval()
+
+    def init_scen_tree_gen(self):
+        cfg = _import_cfg(self.planner_cfg["planning_config"]).ScenTreeCfg()
+        self.scen_tree_gen = ScenarioTreeGenerator(self.device, self.network, self.obs_len, self.plan_len, cfg)
+
+    def init_traj_tree_opt(self):
+        cfg = _import_cfg(self.planner_cfg["planning_config"]).TrajTreeCfg()
+        self.traj_tree_opt = TrajectoryTreeOptimizer(cfg, self.network.rt)
+
+    # ------------------------------------------------------------------------------------------
+    def to_object_state(self, agent):
+        s = agent.state
+        return ObjectState(True, agent.timestep, (s[0], s[1]), s[3], (s[2] * np.cos(s[3]), s[2] * np.sin(s[3])))
+
+    def update_observation(self, lcl_smp):
+        """50-frame sliding Track per agent; agents missing from this frame get an unobserved dummy."""
+        seen = {"AV"}
+        ego = lcl_smp.ego_agent
+        if "AV" not in self.agent_obs:
+            self.agent_obs["AV"] = Track("AV", [], ego.type, TrackCategory.FOCAL_TRACK)
+        self.agent_obs["AV"].object_states.append(self.to_object_state(ego))
+        for agent in lcl_smp.exo_agents:
+            if agent.id not in self.agent_obs:
+                self.agent_obs[agent.id] = Track(agent.id, [], agent.type, TrackCategory.TRACK_FRAGMENT)
+            self.agent_obs[agent.id].object_states.append(self.to_object_state(agent))
+            seen.add(agent.id)
+        for tr in self.agent_obs.values():
+            if tr.track_id not in seen:
+                last = tr.object_states[-1]
+                tr.object_states.append(ObjectState(False, last.timestep, last.position, last.heading, last.velocity))
+            if len(tr.object_states) > self.obs_len:
+                tr.object_states.pop(0)
+
+    def update_state_ctrl(self, state, ctrl):
+        self.state = state
+        self.ctrl = ctrl
+
+    def update_target_lane(self, gt_tgt_lane):
+        self.gt_tgt_lane = gt_tgt_lane
+
+    # ------------------------------------------------------------------------------------------
+    def plan(self, lcl_smp):
+        import time
+        t0 = time.perf_counter()
+        self.scen_tree_gen.reset()
+        lane, info = self.resample_target_lane(lcl_smp)
+        self.scen_tree_gen.set_target_lane(lane, info)
+        n0 = self.scen_tree_gen.n_expanded
+        scen_trees = self.scen_tree_gen.branch_aime(lcl_smp, self.agent_obs)
+        t1 = time.perf_counter()
+        if len(scen_trees) < 0:
+            return False, None, None
+        traj_trees = self.traj_tree_opt.solve_batch(scen_trees, self.state, self.ctrl, self.gt_tgt_lane,
+                                                    lcl_smp.target_velocity)
+        t2 = time.perf_counter()
+        best, min_cost = None, np.inf
+        for i, tt in enumerate(traj_trees):
+            cost = self.evaluate_traj_tree(lcl_smp, tt)
+            if cost < min_cost:
+                min_cost, best = cost, i
+        opt = traj_trees[best]
+        nxt = opt.get_node(opt.get_root().children_keys[0])
+        ret_ctrl = nxt.data[0][-2:]          # (a, delta) of the first rolled-out state (Q15)
+        self.timing = {"aime_s": t1 - t0, "ilqr_s": t2 - t1, "total_s": time.perf_counter() - t0,
+                       "nodes_expanded": self.scen_tree_gen.n_expanded - n0, "n_scen_trees": len(scen_trees),
+                       "best_traj_idx": best}
+        return True, ret_ctrl, [[scen_trees[best]], [traj_trees[best]]]
+
+    def resample_target_lane(self, lcl_smp):
+        """1 m resampling of the target lane and its per-point info (planner.py:147-171)."""
+        lane = lcl_smp.target_lane
+        infos = lcl_smp.target_lane_info
+        pts, idx = [], []
+        for i in range(len(lane) - 1):
+            seg = lane[i:i + 2]
+            n = int(np.ceil(np.linalg.norm(seg[0] - seg[1]) / 1.0))
+            for j in range(n):
+                pts.append(seg[0] + (j / n) * (seg[1] - seg[0]))
+                idx.append(i)
+        pts.append(lane[-1])
+        idx.append(len(lane) - 1)
+        idx = np.asarray(idx)
+        return np.array(pts), [np.array(np.asarray(info)[idx]) for info in infos]
+
+    def get_traj_tree(self, scen_tree, lcl_smp):
+        o = self.traj_tree_opt
+        o.init_warm_start_cost_tree(scen_tree, self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)
+        xs, us = o.warm_start_solve()
+        o.init_cost_tree(scen_tree, self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)
+        return o.solve(us), o.debug
+
+    def evaluate_traj_tree(self, lcl_smp, traj_tree):
+        """mean over nodes of .1 jerk^2 + 5 steer_rate^2 + .01 (v_tgt - v)^2 + .01 dist(target lane) (:180-198)."""
+        comfort = eff = tgt = 0.0
+        for node in traj_tree.nodes.values():
+            state, ctrl = node.data[0], node.data[1]
+            comfort += 0.1 * ctrl[0] ** 2
+            comfort += 5.0 * ctrl[1] ** 2
+            eff += 0.01 * (lcl_smp.target_velocity - state[2]) ** 2
+            tgt += 0.01 * self.get_dist_to_target_lane(lcl_smp, state)
+        return (comfort + eff + tgt) / len(traj_tree.nodes)
+
+    def get_dist_to_target_lane(self, lcl_smp, state):
+        lane = lcl_smp.target_lane
+        px, py = state[:2]
+        sx, sy = lane[:-1].T
+        ex, ey = lane[1:].T
+        dx, dy = ex - sx, ey - sy
+        l2 = dx ** 2 + dy ** 2
+        assert np.all(l2 != 0.0), "Polyline segments should not have zero lengths."
+        t = np.clip(((px - sx) * dx + (py - sy) * dy) / l2, 0, 1)
+        nx, ny = sx + t * dx, sy + t * dy
+        k = np.argmin(np.sqrt((px - nx) ** 2 + (py - ny) ** 2))
+        return np.linalg.norm(np.array((nx[k], ny[k])) - state[:2])

@@ -1,0 +1,378 @@
+"""AIME (Adaptive Interaction Modality Exploration) scenario-tree generator.
+
+Call surface of the reference ``planners/mind/scenario_tree.py`` (``ScenarioTreeGenerator(device,
+network, obs_len, pred_len, config)``, ``reset``, ``set_target_lane``, ``branch_aime``); the batched
+scene prediction of every round runs on the MI355X through ``network`` (``ScenePredNet`` ->
+libmind_hip.so), the per-round bookkeeping is vectorised numpy on the host (float32, the dtype the
+reference computes these steps in).
+
+Reference map (file:line in planners/mind/scenario_tree.py):
+  branch_aime :38-58, init_scenario_tree :60-67, create_nodes :73-80, decide_branch :82-100,
+  get_branch_set :102-108, set_target_lane :110-120, process_data :122-206, get_scenario_tree :208-272,
+  prune_merge :281-412, prepare_root_data :414-465, update_obser :467-567, get_branch_time :592-611,
+  get_high_level_command :613-652.  Quirks Q5, Q8, Q12, Q20 are reproduced.
+"""
+import numpy as np
+import torch
+
+from ..basic.tree import Node, Tree
+from . import utils as U
+
+F32 = np.float32
+
+
+class ScenarioData:
+    def __init__(self, data, obs_data, branch_flag=False, end_flag=False, terminate_flag=False):
+        self.data = data
+        self.obs_data = obs_data
+        self.branch_flag = branch_flag
+        self.end_flag = end_flag
+        self.terminate_flag = terminate_flag
+
+
+def _np(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+class ScenarioTreeGenerator:
+    def __init__(self, device, network, obs_len=50, pred_len=60, config=None):
+        self.device = device
+        self.network = network
+        self.obs_len = obs_len
+        self.pred_len = pred_len
+        self.seq_len = obs_len + pred_len
+        self.config = config
+        self.tree = Tree()
+        self.lane_graph = None
+        self.lane_feat_in = None      # [l,10,16] instance-frame lane features (constant within a plan)
+        self.lane_feat_cache = None   # LaneNet output on device, reused by every tree node of the plan
+        self.target_lane = None
+        self.target_lane_info = None
+        self.ego_idx = 0
+        self.branch_depth = 0
+        self.n_expanded = 0           # scenes pushed through the predictor (metric: nodes expanded)
+
+    # ------------------------------------------------------------------------------------------
+    def reset(self):
+        self.branch_depth = 0
+        self.tree = Tree()
+        self.lane_feat_cache = None
+
+    def set_target_lane(self, target_lane, target_lane_info):
+        self.target_lane = np.asarray(target_lane).astype(F32) if np.asarray(target_lane).dtype != np.float64 \
+            else np.asarray(target_lane)
+        # the reference keeps the lane in whatever dtype numpy gave it and moves it to a torch tensor;
+        # every consumer computes in float32 after mixing with float32 operands
+        self.target_lane = np.asarray(target_lane, dtype=F32)
+        cols = [np.asarray(target_lane_info[0])[:, None], np.asarray(target_lane_info[1]),
+                np.asarray(target_lane_info[2]), np.asarray(target_lane_info[3]),
+                np.asarray(target_lane_info[4])[:, None], np.asarray(target_lane_info[5])[:, None]]
+        self.target_lane_info = np.concatenate(cols, axis=-1).astype(F32)
+
+    # ------------------------------------------------------------------------------------------
+    def branch_aime(self, lcl_smp, agent_obs):
+        root = self.process_data(lcl_smp, agent_obs)
+        self.init_scenario_tree(root)
+        branch_nodes = self.get_branch_set()
+        while branch_nodes:
+            batch = [n.data.obs_data for n in branch_nodes]
+            pred = self.predict_scenes(batch)
+            self.create_nodes(self.prune_merge(batch, pred))
+            self.decide_branch()
+            branch_nodes = self.get_branch_set()
+        assert len(self.get_end_set()) > 0, "No end node found in the scenario tree."
+        return self.get_scenario_tree()
+
+    def init_scenario_tree(self, root):
+        self.prepare_root_data(root)
+        self.tree.add_node(Node("root", None, ScenarioData(None, root, branch_flag=True)))
+        pred = self.predict_scenes([root])
+        self.create_nodes(self.prune_merge([root], pred))
+        self.decide_branch()
+
+    # ------------------------------------------------------------------------------------------
+    def collate(self, scenes):
+        """Batch dict in the layout ScenePredNet.pre_process reads (mind/utils.py:142-168)."""
+        a_counts = [len(s["ACTORS"]) for s in scenes]
+        l_counts = [s["LANES"].shape[0] for s in scenes]
+        a_off = np.concatenate([[0], np.cumsum(a_counts)])
+        l_off = np.concatenate([[0], np.cumsum(l_counts)])
+        data = {
+            "BATCH_SIZE": len(scenes),
+            "ACTORS": torch.from_numpy(np.concatenate([s["ACTORS"] for s in scenes])),
+            "ACTOR_IDCS": [torch.arange(a_off[i], a_off[i + 1]) for i in range(len(scenes))],
+            "LANES": torch.from_numpy(np.concatenate([s["LANES"] for s in scenes])),
+            "LANE_IDCS": [torch.arange(l_off[i], l_off[i + 1]) for i in range(len(scenes))],
+            "TGT_NODES": torch.from_numpy(np.stack([s["TGT_NODES"] for s in scenes])),
+            "TGT_RPE": torch.from_numpy(np.stack([s["TGT_RPE"] for s in scenes]).reshape(len(scenes), -1)),
+            "ACTOR_CTRS": torch.from_numpy(np.concatenate([s["TRAJS_CTRS"] for s in scenes])),
+            "ACTOR_VECS": torch.from_numpy(np.concatenate([s["TRAJS_VECS"] for s in scenes])),
+            "LANE_CTRS": torch.from_numpy(np.concatenate([s["LANE_CTRS"] for s in scenes])),
+            "LANE_VECS": torch.from_numpy(np.concatenate([s["LANE_VECS"] for s in scenes])),
+            "LANE_SHARED": all(s["LANES"] is scenes[0]["LANES"] for s in scenes),
+            "LANE_FEAT_CACHE": self.lane_feat_cache,
+        }
+        if not getattr(self.network, "computes_rpe_in_kernel", False):
+            data["RPE"] = [{"scene": torch.from_numpy(U.get_rpe(np.concatenate([s["TRAJS_CTRS"], s["LANE_CTRS"]]),
+                                                                np.concatenate([s["TRAJS_VECS"], s["LANE_VECS"]]))),
+                            "scene_mask": None} for s in scenes]
+        return data
+
+    def predict_scenes(self, scenes):
+        data = self.collate(scenes)
+        self.n_expanded += len(scenes)
+        out = self.network(self.network.pre_process(data))
+        cache = getattr(self.network, "last_lane_feat", None)
+        if cache is not None and data["LANE_SHARED"]:
+            self.lane_feat_cache = cache
+        return out
+
+    def create_nodes(self, pred_bar):
+        for pred in pred_bar:
+            self.tree.add_node(Node(pred["SCEN_ID"], pred["PARENT_ID"], ScenarioData(pred, None)))
+
+    def decide_branch(self):
+        for l in self.tree.get_leaf_nodes():
+            d = l.data
+            if d.branch_flag:
+                d.branch_flag = False
+                d.terminate_flag = True
+            elif not d.end_flag:
+                if l.depth >= self.config.max_depth:
+                    d.terminate_flag = True
+                else:
+                    t_b = self.get_branch_time(d.data)
+                    if t_b < self.pred_len:
+                        d.obs_data, d.data = self.update_obser(d.data)
+                        d.branch_flag = True
+                    else:
+                        d.end_flag = True
+
+    def get_branch_set(self):
+        out = [l for l in self.tree.get_leaf_nodes() if l.data.branch_flag]
+        self.branch_depth += 1
+        return out
+
+    def get_end_set(self):
+        return [n for n in self.tree.get_leaf_nodes() if n.data.end_flag]
+
+    # ------------------------------------------------------------------------------------------
+    def process_data(self, lcl_smp, agent_obs):
+        pos, ang, vel, types, flags, tids, cats = U.get_agent_trajectories(agent_obs)
+        cur_vel = lcl_smp.ego_agent.state[2]
+        orig, rot, theta, pos_n, ang_n, vel_n, ctrs, vecs = U.normalize_agents(pos, ang, vel)
+        lane_graph = U.lane_graph_from_map(lcl_smp.map_data, orig, rot)
+        self.lane_graph = lane_graph
+        self.lane_feat_in = U.lane_features(lane_graph)
+        s = self._scene_inputs(orig, rot, pos_n, ang_n, vel_n, types, flags, ctrs, vecs, cur_vel,
+                               lane_graph["lane_ctrs"], lane_graph["lane_vecs"])
+        s["TRAJS_TID"], s["TRAJS_CAT"] = tids, cats
+        return s
+
+    def _scene_inputs(self, orig, rot, pos_n, ang_n, vel_n, types, pad, ctrs, vecs, cur_vel, lane_ctrs, lane_vecs):
+        tgt_pts, tgt_nodes, (tgt_ctr, tgt_vec) = self.get_high_level_command(orig, rot, cur_vel)
+        tgt_rpe = U.get_rpe(np.stack([tgt_ctr, ctrs[0]]), np.stack([tgt_vec, vecs[0]]))
+        return {"ORIG": orig, "ROT": rot, "TRAJS_POS_OBS": pos_n, "TRAJS_ANG_OBS": ang_n, "TRAJS_VEL_OBS": vel_n,
+                "TRAJS_TYPE": types, "PAD_OBS": pad, "TRAJS_CTRS": ctrs, "TRAJS_VECS": vecs,
+                "ACTORS": U.actor_features(pos_n, ang_n, vel_n, types, pad), "LANES": self.lane_feat_in,
+                "LANE_CTRS": np.ascontiguousarray(lane_ctrs, F32), "LANE_VECS": np.ascontiguousarray(lane_vecs, F32),
+                "TGT_PTS": tgt_pts, "TGT_NODES": tgt_nodes, "TGT_RPE": tgt_rpe.reshape(-1)}
+
+    def get_high_level_command(self, orig, rot, cur_vel, min_vel=0.5):
+        lane = self.target_lane
+        d = lane - orig
+        closest = int(np.argmin(np.sqrt((d * d).sum(-1))))
+        # python float - float32 tensor -> float32 arithmetic from the first subtraction on
+        travel = max(cur_vel, min_vel) * self.config.tar_time_ahead
+        idx = closest
+        while idx < len(lane) - 1 and travel > 0:
+            idx += 1
+            step = lane[idx] - lane[idx - 1]
+            travel = F32(travel) - np.sqrt((step * step).sum(), dtype=F32)
+        if idx == len(lane) - 1:
+            idx -= 1
+        idx = max(5, min(idx, len(lane) - 6))
+        sel = np.arange(idx - 5, idx + 6)
+        pts = lane[sel]
+        info = self.target_lane_info[sel][1:]
+        assert len(pts) == 11
+        ctrln = np.matmul(pts - orig, rot)
+        anch_pos = ctrln.mean(axis=0, dtype=F32)
+        dv = ctrln[-1] - ctrln[0]
+        anch_vec = dv / np.sqrt((dv * dv).sum(), dtype=F32)
+        anch_rot = np.array([[anch_vec[0], -anch_vec[1]], [anch_vec[1], anch_vec[0]]], dtype=F32)
+        ctrln = np.matmul(ctrln - anch_pos, anch_rot)
+        ctrs = (ctrln[:-1] + ctrln[1:]) / F32(2.0)
+        vecs = ctrln[1:] - ctrln[:-1]
+        tgt_nodes = np.concatenate([ctrs, vecs, info], axis=-1).astype(F32)
+        return pts.copy(), tgt_nodes, (anch_pos.astype(F32), anch_vec.astype(F32))
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _to_world(local, ctrs, vecs, rot, orig, translate=True):
+        """((x R_i^T) + c_i) R^T + o  with R_i = rot(atan2(vec_i)) (scenario_tree.py:328-339), batched."""
+        th = np.arctan2(vecs[:, 1], vecs[:, 0])
+        c, s = np.cos(th), np.sin(th)
+        Ri = np.stack([np.stack([c, -s], -1), np.stack([s, c], -1)], -2).astype(F32)       # [a,2,2]
+        out = np.matmul(local, np.transpose(Ri, (0, 2, 1)))
+        if translate:
+            out = out + ctrs[:, None, :]
+        out = np.matmul(out, rot.T)
+        if translate:
+            out = out + orig
+        return out.astype(F32), th
+
+    def prepare_root_data(self, root):
+        rot, orig = root["ROT"], root["ORIG"]
+        theta_g = np.arctan2(rot[1, 0], rot[0, 0])
+        pos_w, th = self._to_world(root["TRAJS_POS_OBS"], root["TRAJS_CTRS"], root["TRAJS_VECS"], rot, orig)
+        vel_w, _ = self._to_world(root["TRAJS_VEL_OBS"], root["TRAJS_CTRS"], root["TRAJS_VECS"], rot, orig, False)
+        root["TRAJS_POS_HIST"] = pos_w
+        root["TRAJS_VEL_HIST"] = vel_w
+        root["TRAJS_ANG_HIST"] = (root["TRAJS_ANG_OBS"] + th[:, None] + theta_g).astype(F32)
+        a, T = pos_w.shape[:2]
+        root["TRAJS_COV_HIST"] = np.full((a, T, 1), 1e-5, F32)
+        root["SCEN_PROB"] = 1.0
+        root["SCEN_ID"] = "root"
+        root["PARENT_ID"] = None
+        root["CUR_T"] = 0
+        root["END_T"] = self.pred_len
+        return root
+
+    def prune_merge(self, scenes, out):
+        res_cls_b, res_reg_b, res_aux_b = out
+        kept = []
+        for idx, sc in enumerate(scenes):
+            rot, orig = sc["ROT"], sc["ORIG"]
+            ctrs, vecs = sc["TRAJS_CTRS"], sc["TRAJS_VECS"]
+            theta_g = np.arctan2(rot[1, 0], rot[0, 0])
+            reg = _np(res_reg_b[idx]).astype(F32, copy=False)       # [a,6,60,5]
+            cls = _np(res_cls_b[idx]).astype(F32, copy=False)       # [1,6]
+            vel = _np(res_aux_b[idx][0]).astype(F32, copy=False)    # [a,6,60,2]
+            ang_loc = U.get_angle(vel)                               # from the un-rotated velocity
+            order = np.argsort(-cls[0], kind="stable")
+            cands = []
+            for k in order:
+                prob = cls[0, k] * sc["SCEN_PROB"]
+                pos_w, th = self._to_world(reg[:, k, :, :2], ctrs, vecs, rot, orig)
+                vel_w, _ = self._to_world(vel[:, k], ctrs, vecs, rot, orig, False)
+                ang_w = (ang_loc[:, k] + th[:, None] + theta_g).astype(F32)
+                cov = U.get_max_covariance(reg[:, k, :, 2:]) + sc["TRAJS_COV_HIST"][:, -1][:, None]
+                L = self.seq_len
+                data = {
+                    "SCEN_PROB": F32(prob), "CUR_T": sc["CUR_T"], "END_T": sc["END_T"],
+                    "PARENT_ID": sc["SCEN_ID"], "SCEN_ID": "{}_{}_{}".format(self.branch_depth, idx, int(k)),
+                    "TRAJS_TYPE": sc["TRAJS_TYPE"], "TRAJS_TID": sc["TRAJS_TID"], "TRAJS_CAT": sc["TRAJS_CAT"],
+                    "TRAJS_POS_HIST": np.concatenate([sc["TRAJS_POS_HIST"], pos_w], axis=1)[:, :L],
+                    "TRAJS_COV_HIST": np.concatenate([sc["TRAJS_COV_HIST"], cov.astype(F32)], axis=1)[:, :L],
+                    "TRAJS_ANG_HIST": np.concatenate([sc["TRAJS_ANG_HIST"], ang_w], axis=1)[:, :L],
+                    "TRAJS_VEL_HIST": np.concatenate([sc["TRAJS_VEL_HIST"], vel_w], axis=1)[:, :L],
+                    "TGT_PTS": sc["TGT_PTS"],
+                }
+                if data["SCEN_PROB"] < F32(0.001):
+                    continue
+                if self.target_lane is not None and self.ego_idx is not None:
+                    ego_mean = data["TRAJS_POS_HIST"][self.ego_idx][-1]
+                    ego_cov = data["TRAJS_COV_HIST"][self.ego_idx][-1]
+                    dis = U.get_distance_to_polyline(self.target_lane, ego_mean)
+                    if (dis - ego_cov > self.config.tar_dist_thres).any():
+                        continue
+                # topology signature: cumulative winding of (exo - ego) over the predicted steps
+                rel = pos_w[1:] - pos_w[0:1]
+                rel = rel / np.sqrt((rel * rel).sum(-1, keepdims=True))
+                phi = np.arctan2(rel[..., 1], rel[..., 0])
+                dphi = phi[:, 1:] - phi[:, :-1]
+                dphi = np.arctan2(np.sin(dphi), np.cos(dphi))
+                topo = dphi.sum(axis=1, dtype=F32) if len(dphi) else np.zeros(0, F32)
+                cands.append((data, topo))
+            # greedy merge of modes whose signatures differ by <= pi/6 for every exo agent
+            thr = F32(np.pi / 6)
+            while cands:
+                sel, stopo = cands[0]
+                kept.append(sel)
+                rest = []
+                for cd in cands[1:]:
+                    diff = stopo - cd[1]
+                    diff = np.arctan2(np.sin(diff), np.cos(diff))
+                    if ((np.abs(diff) - thr) > 0).sum() > 0:
+                        rest.append(cd)
+                cands = rest
+        return kept
+
+    def get_branch_time(self, d):
+        cov = d["TRAJS_COV_HIST"]
+        cur_t, end_t = d["CUR_T"], d["END_T"]
+        compare_t = self.obs_len + cur_t + (1 if cur_t == 0 else 0)
+        for t in range(cur_t + 1, end_t):
+            if t % 2 == 1:
+                continue
+            if (cov[:, self.obs_len + t] / cov[:, compare_t] > 9).sum() > 0:
+                d["END_T"] = t
+                return t
+        return end_t
+
+    def update_obser(self, cur):
+        end_t, cur_t = cur["END_T"], cur["CUR_T"]
+        keep = self.obs_len + (end_t - cur_t)
+        for k in ("TRAJS_POS_HIST", "TRAJS_COV_HIST", "TRAJS_ANG_HIST", "TRAJS_VEL_HIST"):
+            cur[k] = cur[k][:, :keep]
+        o = self.obs_len
+        pos, cov = cur["TRAJS_POS_HIST"][:, -o:], cur["TRAJS_COV_HIST"][:, -o:]
+        ang, vel = cur["TRAJS_ANG_HIST"][:, -o:], cur["TRAJS_VEL_HIST"][:, -o:]
+        orig, rot, theta, pos_n, ang_n, vel_n, ctrs, vecs = U.normalize_agents(pos, ang, vel)
+        # lane anchors re-expressed in the new AV frame (get_new_lane_graph, utils.py:171-177); the
+        # instance-frame node features (and hence LaneNet's output) are unchanged
+        lane_ctrs = np.matmul(self.lane_graph["lane_ctrs"] - orig, rot)
+        lane_vecs = np.matmul(self.lane_graph["lane_vecs"], rot)
+        cur_vel = np.sqrt((vel_n[0, -1] * vel_n[0, -1]).sum(), dtype=F32)
+        pad = np.ones(ang.shape, F32)[:, :o]
+        s = self._scene_inputs(orig, rot, pos_n, ang_n, vel_n, cur["TRAJS_TYPE"], pad, ctrs, vecs, cur_vel,
+                               lane_ctrs, lane_vecs)
+        s.update({"SCEN_PROB": cur["SCEN_PROB"], "SCEN_ID": cur["SCEN_ID"], "PARENT_ID": cur["PARENT_ID"],
+                  "CUR_T": end_t, "END_T": self.pred_len, "TRAJS_TID": cur["TRAJS_TID"], "TRAJS_CAT": cur["TRAJS_CAT"],
+                  "TRAJS_POS_HIST": pos.copy(), "TRAJS_COV_HIST": cov.copy(), "TRAJS_ANG_HIST": ang.copy(),
+                  "TRAJS_VEL_HIST": vel.copy()})
+        return s, cur
+
+    # ------------------------------------------------------------------------------------------
+    def get_scenario_tree(self):
+        root = self.tree.get_root()
+        for node in self.get_end_set():              # label every node on a finished branch
+            while node.parent_key is not None:
+                node.data.end_flag = True
+                node = self.tree.get_node(node.parent_key)
+        probs = {}
+        order = {}
+        for key in root.children_keys:
+            top = self.tree.get_node(key)
+            if not top.data.end_flag:
+                continue
+            probs[key] = 1.0
+            order[key] = [key]
+            queue = [top]
+            while queue:
+                cur = queue.pop(0)
+                ch = [self.tree.get_node(k) for k in cur.children_keys]
+                ch = [c for c in ch if c.data.end_flag]
+                total = 0.0
+                for c in ch:
+                    total = total + c.data.data["SCEN_PROB"]
+                for c in ch:
+                    probs[c.key] = c.data.data["SCEN_PROB"] / total * probs[cur.key]
+                    order[key].append(c.key)
+                    queue.append(c)
+        trees = []
+        o = self.obs_len
+        for key, keys in order.items():
+            t = Tree()
+            for k in keys:
+                n = self.tree.get_node(k)
+                d = n.data.data
+                dur = d["END_T"] - d["CUR_T"]
+                t.add_node(Node(k, None if k == key else n.parent_key,
+                                [probs[k], d["TRAJS_POS_HIST"][:, o:o + dur, :], d["TRAJS_COV_HIST"][:, o:o + dur, :],
+                                 d["TGT_PTS"]]))
+            trees.append(t)
+        return trees

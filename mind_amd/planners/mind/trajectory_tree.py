@@ -1,0 +1,122 @@
+"""Contingency planner: scenario tree -> cost tree -> tree-iLQR on the MI355X.
+
+Call surface of the reference ``planners/mind/trajectory_tree.py:12-177``
+(``init_warm_start_cost_tree`` / ``warm_start_solve`` / ``init_cost_tree`` / ``solve`` / ``debug``).
+The reference builds a 256x256 float64 potential field per trajectory node on the CPU and runs a
+Python iLQR; here ``init_*`` only flattens the scenario tree (LIFO DFS, every even sub-step -> one
+trajectory node, Q13) and the solve is one persistent HIP kernel (libmind_hip.so:
+mind_ilqr_solve_trees).  ``solve_batch`` solves all scenario trees of a plan in two launches.
+"""
+import numpy as np
+
+from ... import _lib
+from ...runtime import get_runtime
+from ..basic.tree import Node, Tree
+
+
+def flatten_scenario_tree(scen_tree):
+    """-> dict(parent i32 [M], prob f32 [M], mean f32 [M,a,2], cov f32 [M,a]); trajectory node keys are
+    the array indices (creation order of trajectory_tree.py:30-54: stack pop() = last child first)."""
+    parent, prob, mean, cov = [], [], [], []
+    last = {}
+    stack = [scen_tree.get_root()]
+    while stack:
+        node = stack.pop()
+        p, trajs, covs = node.data[0], node.data[1], node.data[2]
+        li = last[node.parent_key] if node.parent_key is not None else -1
+        steps = np.arange(0, trajs.shape[1], 2)
+        for i in steps:
+            cur = len(parent)
+            parent.append(li)
+            li = cur
+        prob.extend([np.float32(p)] * len(steps))
+        mean.append(np.transpose(trajs[:, steps, :], (1, 0, 2)))
+        cov.append(np.transpose(covs[:, steps, 0], (1, 0)))
+        last[node.key] = len(parent) - 1
+        stack.extend(scen_tree.get_node(k) for k in node.children_keys)
+    return dict(parent=np.asarray(parent, np.int32), prob=np.asarray(prob, np.float32),
+                mean=np.ascontiguousarray(np.concatenate(mean), np.float32),
+                cov=np.ascontiguousarray(np.concatenate(cov), np.float32))
+
+
+def ilqr_cfg_from(config, block, max_iter=100):
+    """TrajTreeCfg (w_opt_cfg / opt_cfg dict) -> C struct."""
+    o = getattr(config, block)
+    c = _lib.IlqrCfg()
+    c.dt, c.wheelbase = config.dt, 2.5                       # trajectory_tree.py:15
+    c.w_des_state[:] = list(np.diag(o["w_des_state"]))
+    c.w_state_con[:] = list(np.diag(o["w_state_con"]))
+    c.state_lower[:] = list(o["state_lower_bound"])
+    c.state_upper[:] = list(o["state_upper_bound"])
+    c.w_ctrl[:] = list(np.diag(o["w_ctrl"]))
+    c.w_tgt = o["w_tgt"]
+    c.w_ego, c.w_ego_cov_offset = o.get("w_ego", 0.0), o.get("w_ego_cov_offset", 0.0)
+    c.w_exo, c.w_exo_cov_offset, c.w_exo_cost_offset = o.get("w_exo", 0.0), o.get("w_exo_cov_offset", 0.0), o.get("w_exo_cost_offset", 0.0)
+    c.grid_res = o["smooth_grid_res"]
+    c.grid_w, c.grid_h = o["smooth_grid_size"][1], o["smooth_grid_size"][0]
+    c.max_iter = max_iter
+    return c
+
+
+def to_traj_tree(flat, x0, xs, us, action_size=2):
+    """root key -1 holds [x0, 0]; node k holds [xs[k], us[k]] (trajectory_tree.py:140-146)."""
+    t = Tree()
+    t.add_node(Node(-1, None, [x0, np.zeros(action_size)]))
+    for k in range(len(flat["parent"])):
+        t.add_node(Node(k, int(flat["parent"][k]), [xs[k], us[k]]))
+    return t
+
+
+class TrajectoryTreeOptimizer:
+    def __init__(self, config=None, runtime=None):
+        self.config = config
+        self.rt = runtime
+        self.cost_tree = None
+        self.debug = None
+        self._job = None
+
+    def _runtime(self):
+        if self.rt is None:
+            self.rt = get_runtime()
+        return self.rt
+
+    def _get_init_state(self, init_state, init_ctrl):
+        return np.array([init_state[0], init_state[1], init_state[2], init_state[3], init_ctrl[0], init_ctrl[1]],
+                        dtype=np.float64)
+
+    def _prepare(self, scen_tree, init_state, init_ctrl, target_lane, target_vel, warm):
+        self._job = dict(flat=flatten_scenario_tree(scen_tree), x0=self._get_init_state(init_state, init_ctrl),
+                         lane=np.asarray(target_lane, np.float64), tv=float(target_vel), warm=warm)
+        self.cost_tree = self._job["flat"]
+
+    def init_warm_start_cost_tree(self, scen_tree, init_state, init_ctrl, target_lane, target_vel):
+        self._prepare(scen_tree, init_state, init_ctrl, target_lane, target_vel, True)
+
+    def init_cost_tree(self, scen_tree, init_state, init_ctrl, target_lane, target_vel):
+        self._prepare(scen_tree, init_state, init_ctrl, target_lane, target_vel, False)
+
+    def _solve(self, us_init):
+        j = self._job
+        cfg = ilqr_cfg_from(self.config, "w_opt_cfg" if j["warm"] else "opt_cfg")
+        xs, us, st = self._runtime().ilqr_solve(cfg, [j["flat"]], j["x0"], j["lane"], j["tv"], 0 if j["warm"] else 1,
+                                                None if us_init is None else [np.asarray(us_init, np.float64)])
+        self.debug = st[0]
+        return xs[0], us[0]
+
+    def warm_start_solve(self, us_init=None):
+        return self._solve(us_init)
+
+    def solve(self, us_init=None):
+        xs, us = self._solve(us_init)
+        return to_traj_tree(self._job["flat"], self._job["x0"], xs, us, self.config.action_size)
+
+    # all scenario trees of one plan: 2 launches (warm start, full) instead of 2 x n_trees solves
+    def solve_batch(self, scen_trees, init_state, init_ctrl, target_lane, target_vel):
+        flats = [flatten_scenario_tree(t) for t in scen_trees]
+        x0 = self._get_init_state(init_state, init_ctrl)
+        lane = np.asarray(target_lane, np.float64)
+        rt = self._runtime()
+        _, us_w, st_w = rt.ilqr_solve(ilqr_cfg_from(self.config, "w_opt_cfg"), flats, x0, lane, target_vel, 0)
+        xs, us, st = rt.ilqr_solve(ilqr_cfg_from(self.config, "opt_cfg"), flats, x0, lane, target_vel, 1, us_w)
+        self.debug = dict(warm=st_w, full=st)
+        return [to_traj_tree(f, x0, x, u, self.config.action_size) for f, x, u in zip(flats, xs, us)]

@@ -1,0 +1,229 @@
+"""Host-side array helpers of the AIME scenario-tree generator (numpy, float32 where the reference
+computes in torch float32).
+
+Mirrors the call surface / numerics of the reference ``planners/mind/utils.py``:
+  get_agent_trajectories :245-342   Track histories -> padded [a,50,*] arrays (NN pad pos/heading,
+                                    zero pad velocity, agents unobserved at the last step skipped, AV first)
+  lane_graph_from_map    :345-483   (``update_lane_graph_from_argo``) without shapely: arc-length
+                                    resampling of 10-pt centre lines into 15 m pieces x 10 sub-segments
+  get_origin_rotation    :180-190   frame at history step 49
+  get_rpe                :193-242   5-channel relative pose encoding
+  actor_features         :114-139   (``actor_gather``)  [a,14,48]
+  lane_features          :103-110   (``graph_gather``)  [l,10,16]
+  get_distance_to_polyline :502-513, get_max_covariance :536-551, get_angle :215-216
+Everything is vectorised over agents (the reference loops in Python, scenario_tree.py:146-152).
+"""
+import numpy as np
+
+OBS_LEN = 50
+F32 = np.float32
+
+_CROSSABLE = {"DASH_SOLID_YELLOW", "DASH_SOLID_WHITE", "DASHED_WHITE", "DASHED_YELLOW", "DOUBLE_DASH_YELLOW",
+              "DOUBLE_DASH_WHITE"}
+_NOT_CROSSABLE = {"DOUBLE_SOLID_YELLOW", "DOUBLE_SOLID_WHITE", "SOLID_YELLOW", "SOLID_WHITE", "SOLID_DASH_WHITE",
+                  "SOLID_DASH_YELLOW", "SOLID_BLUE"}
+_TYPE_SLOT = {"VEHICLE": 0, "PEDESTRIAN": 1, "MOTORCYCLIST": 2, "CYCLIST": 3, "BUS": 4, "UNKNOWN": 5}
+
+
+def _name(x):
+    """Enum member (av2 or look-alike) or plain string -> upper-case name."""
+    n = getattr(x, "name", x)
+    return str(n).upper()
+
+
+def get_angle(vel):
+    return np.arctan2(vel[..., 1], vel[..., 0])
+
+
+def get_max_covariance(data):
+    return np.maximum(data[..., 0], data[..., 1])[..., None]
+
+
+def rot2(theta):
+    """[[cos, -sin], [sin, cos]] in float32 (get_origin_rotation :185-186)."""
+    c, s = np.cos(theta, dtype=F32), np.sin(theta, dtype=F32)
+    return np.array([[c, -s], [s, c]], dtype=F32)
+
+
+def get_origin_rotation(traj_pos, traj_ang):
+    orig = traj_pos[OBS_LEN - 1]
+    theta = traj_ang[OBS_LEN - 1]
+    return orig, rot2(theta), theta
+
+
+def _nn_fill(vals, have):
+    """Nearest-neighbour padding along axis 0 (forward fill, then backward fill) (:38-58)."""
+    n = len(have)
+    idx = np.where(have, np.arange(n), -1)
+    fwd = np.maximum.accumulate(idx)
+    first = int(np.argmax(have))
+    fwd[fwd < 0] = first
+    return vals[fwd]
+
+
+def get_agent_trajectories(agent_obs):
+    """agent_obs: {id: Track(track_id, object_states, object_type, category)}; 'AV' is moved first.
+    Returns pos [a,50,2] f32, ang [a,50] f32, vel [a,50,2] f32, type [a,50,7] i16, flags [a,50] i16, tids, cats."""
+    keys = list(agent_obs.keys())
+    order = [keys.index("AV")] + [i for i, k in enumerate(keys) if k != "AV"]
+    P, A, V, T, Fl, tids, cats = [], [], [], [], [], [], []
+    for rank, ki in enumerate(order):
+        key = keys[ki]
+        states = agent_obs[key].object_states
+        if states[-1].observed is False:
+            continue
+        n = len(states)
+        obs = np.array([bool(s.observed) for s in states])
+        ts = np.arange(OBS_LEN - n, OBS_LEN)[obs]
+        have = np.zeros(OBS_LEN, bool)
+        have[ts] = True
+        pos = np.zeros((OBS_LEN, 2))
+        ang = np.zeros(OBS_LEN)
+        vel = np.zeros((OBS_LEN, 2))
+        pos[ts] = np.array([list(s.position) for s in states], dtype=float).reshape(n, 2)[obs]
+        ang[ts] = np.array([s.heading for s in states], dtype=float)[obs]
+        vel[ts] = np.array([list(s.velocity) for s in states], dtype=float).reshape(n, 2)[obs]
+        pos, ang = _nn_fill(pos, have), _nn_fill(ang, have)
+        slot = _TYPE_SLOT.get(_name(agent_obs[key].object_type), 6)
+        typ = np.zeros((OBS_LEN, 7))
+        typ[ts, slot] = 1
+        P.append(pos); A.append(ang); V.append(vel); T.append(typ); Fl.append(have.astype(np.int16))
+        tids.append(key)
+        cats.append("av" if rank == 0 else "exo")
+    return (np.array(P).astype(F32), np.array(A).astype(F32), np.array(V).astype(F32),
+            np.array(T).astype(np.int16), np.array(Fl).astype(np.int16), tids, cats)
+
+
+def normalize_agents(pos, ang, vel):
+    """AV-centric then per-agent-centric frames (scenario_tree.py:128-158, vectorised).
+    pos [a,50,2], ang [a,50], vel [a,50,2] float32 (world or previous frame).
+    Returns orig [2], rot [2,2], theta, pos_n, ang_n, vel_n, ctrs [a,2], vecs [a,2]."""
+    orig, rot, theta = get_origin_rotation(pos[0], ang[0])
+    pos = np.matmul(pos - orig, rot)
+    ang = ang - theta
+    vel = np.matmul(vel, rot)
+    ctrs = pos[:, OBS_LEN - 1].copy()
+    th = ang[:, OBS_LEN - 1].copy()
+    c, s = np.cos(th), np.sin(th)
+    R = np.stack([np.stack([c, -s], -1), np.stack([s, c], -1)], -2).astype(F32)   # [a,2,2]
+    pos_n = np.matmul(pos - ctrs[:, None, :], R)
+    ang_n = ang - th[:, None]
+    vel_n = np.matmul(vel, R)
+    vecs = np.stack([c, s], -1).astype(F32)
+    return orig, rot, theta, pos_n.astype(F32), ang_n.astype(F32), vel_n.astype(F32), ctrs.astype(F32), vecs
+
+
+def actor_features(pos_n, ang_n, vel_n, types, pad):
+    """[a,14,48]: [dx,dy, cos,sin, vx,vy, 7-way type, pad flag]; first 2 of the 50 steps dropped (Q11)."""
+    disp = np.zeros_like(pos_n)
+    disp[:, 1:] = pos_n[:, 1:] - pos_n[:, :-1]
+    feat = np.concatenate([disp, np.stack([np.cos(ang_n), np.sin(ang_n)], -1), vel_n, types.astype(F32),
+                           pad.astype(F32)[..., None]], axis=-1)
+    return np.ascontiguousarray(np.transpose(feat, (0, 2, 1))[..., 2:], dtype=F32)
+
+
+def get_rpe(ctrs, vecs, radius=100.0):
+    """[5,n,n]: cos/sin(v_j, v_i), cos/sin(v_j, c_j - c_i), |c_j - c_i| * 2 / radius (float32)."""
+    d = ctrs[None, :, :] - ctrs[:, None, :]
+    dist = np.sqrt((d * d).sum(-1))
+    v1 = np.broadcast_to(vecs[None, :, :], d.shape)
+    v2 = np.broadcast_to(vecs[:, None, :], d.shape)
+
+    def cs(a, b):
+        den = np.sqrt((a * a).sum(-1)) * np.sqrt((b * b).sum(-1)) + F32(1e-10)
+        return (a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) / den, (a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]) / den
+
+    c1, s1 = cs(v1, v2)
+    c2, s2 = cs(v1, d)
+    return np.stack([c1, s1, c2, s2, dist * F32(2) / F32(radius)]).astype(F32)
+
+
+def get_distance_to_polyline(polyline, point):
+    """min over segments of |closest point - point| (float32, :486-513), vectorised."""
+    p1, p2 = polyline[:-1], polyline[1:]
+    seg = p2 - p1
+    t = ((point - p1) * seg).sum(-1) / (seg * seg).sum(-1)
+    t = np.clip(t, 0, 1)
+    closest = p1 + t[:, None] * seg
+    d = closest - point
+    return np.sqrt((d * d).sum(-1)).min()
+
+
+# ---------------------------------------------------------------------------------------------
+# lane graph featuriser (reference update_lane_graph_from_argo, no shapely)
+# ---------------------------------------------------------------------------------------------
+def _interp_along(cl, cum, s):
+    s = np.clip(s, 0.0, cum[-1])
+    k = np.clip(np.searchsorted(cum, s, side="right") - 1, 0, len(cl) - 2)
+    seg = cum[k + 1] - cum[k]
+    t = np.where(seg > 0, (s - cum[k]) / np.where(seg > 0, seg, 1.0), 0.0)
+    return cl[k] + t[:, None] * (cl[k + 1] - cl[k])
+
+
+def lane_graph_from_map(static_map, orig, rot, seg_length=15.0, n_sub=10):
+    """Lane polylines of an AV2-style static map in the AV frame (orig [2], rot [2,2]):
+    node_ctrs/node_vecs [l,10,2] f32 (instance frame), lane_ctrs/lane_vecs [l,2] f32 (AV frame), flags i16."""
+    orig = np.asarray(orig)
+    rot = np.asarray(rot)
+    node_ctrs, node_vecs, lane_ctrs, lane_vecs = [], [], [], []
+    lane_type, intersect, cross_left, cross_right, left, right = [], [], [], [], [], []
+    for lane_id, lane in static_map.vector_lane_segments.items():
+        cl = np.asarray(static_map.get_lane_segment_centerline(lane_id))[:, 0:2].astype(float)
+        assert cl.shape[0] == n_sub, f"[Error] Wrong num of points in lane - {lane_id}:{cl.shape[0]}"
+        cum = np.concatenate([[0.0], np.cumsum(np.linalg.norm(np.diff(cl, axis=0), axis=1))])
+        length = cum[-1]
+        num_segs = max(int(np.floor(length / seg_length)), 1)
+        ds = length / num_segs
+        lt = np.zeros(3)
+        lt[{"VEHICLE": 0, "BIKE": 1, "BUS": 2}[_name(lane.lane_type)]] = 1
+
+        def mark(m):
+            v = np.zeros(3)
+            n = _name(m)
+            v[0 if n in _CROSSABLE else (1 if n in _NOT_CROSSABLE else 2)] = 1
+            return v
+
+        ml, mr = mark(lane.left_mark_type), mark(lane.right_mark_type)
+        for i in range(num_segs):
+            pts = _interp_along(cl, cum, np.linspace(i * ds, (i + 1) * ds, n_sub + 1))
+            ctrln = (pts - orig).dot(rot)
+            anch_pos = np.mean(ctrln, axis=0)
+            dv = ctrln[-1] - ctrln[0]
+            anch_vec = dv / np.linalg.norm(dv)
+            anch_rot = np.array([[anch_vec[0], -anch_vec[1]], [anch_vec[1], anch_vec[0]]])
+            lane_ctrs.append(anch_pos)
+            lane_vecs.append(anch_vec)
+            ctrln = (ctrln - anch_pos).dot(anch_rot)
+            node_ctrs.append(np.asarray((ctrln[:-1] + ctrln[1:]) / 2.0, F32))
+            node_vecs.append(np.asarray(ctrln[1:] - ctrln[:-1], F32))
+            lane_type.append(np.repeat(lt[None], n_sub, 0))
+            intersect.append(np.full(n_sub, 1.0 if lane.is_intersection else 0.0, F32))
+            cross_left.append(np.repeat(ml[None], n_sub, 0))
+            cross_right.append(np.repeat(mr[None], n_sub, 0))
+            left.append(np.full(n_sub, 0.0 if lane.left_neighbor_id is None else 1.0, F32))
+            right.append(np.full(n_sub, 0.0 if lane.right_neighbor_id is None else 1.0, F32))
+    g = dict()
+    g["node_ctrs"] = np.stack(node_ctrs).astype(F32)
+    g["node_vecs"] = np.stack(node_vecs).astype(F32)
+    g["lane_ctrs"] = np.array(lane_ctrs).astype(F32)
+    g["lane_vecs"] = np.array(lane_vecs).astype(F32)
+    g["lane_type"] = np.stack(lane_type).astype(np.int16)
+    g["intersect"] = np.stack(intersect).astype(np.int16)
+    g["cross_left"] = np.stack(cross_left).astype(np.int16)
+    g["cross_right"] = np.stack(cross_right).astype(np.int16)
+    g["left"] = np.stack(left).astype(np.int16)
+    g["right"] = np.stack(right).astype(np.int16)
+    g["num_nodes"] = g["node_ctrs"].shape[0] * g["node_ctrs"].shape[1]
+    g["num_lanes"] = g["lane_ctrs"].shape[0]
+    return g
+
+
+update_lane_graph_from_argo = lane_graph_from_map   # reference name
+
+
+def lane_features(g):
+    """[l,10,16] = [ctr xy, vec xy, intersect, lane_type(3), cross_left(3), cross_right(3), left, right]."""
+    f = np.concatenate([g["node_ctrs"], g["node_vecs"], g["intersect"][..., None].astype(F32),
+                        g["lane_type"].astype(F32), g["cross_left"].astype(F32), g["cross_right"].astype(F32),
+                        g["left"][..., None].astype(F32), g["right"][..., None].astype(F32)], axis=-1)
+    return np.ascontiguousarray(f, dtype=F32)

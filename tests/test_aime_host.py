@@ -1,0 +1,108 @@
+"""CPU: the AIME scenario-tree bookkeeping (mind_amd.planners.mind.scenario_tree) driven by the scripted
+FakeNet, against golden decisions captured from the reference ScenarioTreeGenerator (node-id sets,
+parents, sibling probabilities, window lengths, world-frame trajectories)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fake_net import FakeNet  # noqa: E402
+
+from mind_amd.planners.basic.tree import Node, Tree
+from mind_amd.planners.mind import utils as U
+from mind_amd.planners.mind.configs.planning.demo_1 import ScenTreeCfg
+from mind_amd.planners.mind.planner import MINDPlanner
+from mind_amd.planners.mind.scenario_tree import ScenarioTreeGenerator
+from mind_amd.synth import SynthWorld
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = dict(np.load(os.path.join(ROOT, "tests", "golden", "aime.npz")))
+CASES = [
+    ("w6", dict(n_agents=6, n_lanes=3, n_segs=8, seed=1), dict()),
+    ("w3_nogrowth", dict(n_agents=3, n_lanes=2, n_segs=6, seed=2), dict(growth=(0.02,) * 6)),
+    ("w9_branch", dict(n_agents=9, n_lanes=3, n_segs=8, seed=3),
+     dict(lateral=(0.0, 9.0, -9.0, 0.1, -6.0, 0.2), growth=(0.3, 0.25, 0.1, 0.02, 0.4, 0.03))),
+    ("w5_deep", dict(n_agents=5, n_lanes=3, n_segs=8, seed=4),
+     dict(lateral=(0.0, 9.0, -9.0, 4.0, -6.0, 0.2), growth=(0.5, 0.45, 0.4, 0.5, 0.4, 0.3),
+          probs=(0.3, 0.25, 0.2, 0.15, 0.0995, 0.0005))),
+    ("w1_ego_only", dict(n_agents=1, n_lanes=2, n_segs=6, seed=5), dict()),
+]
+
+
+def run_aime(wkw, nkw):
+    w = SynthWorld(**wkw)
+    lcl = w.local_semantic_map(4.9)
+    obs = w.tracks(4.9, drop={2: 30} if wkw["n_agents"] > 2 else None)
+    lane, info = MINDPlanner.resample_target_lane(MINDPlanner.__new__(MINDPlanner), lcl)
+    net = FakeNet(**nkw)
+    g = ScenarioTreeGenerator(torch.device("cpu"), net, 50, 50, ScenTreeCfg())
+    g.reset()
+    g.set_target_lane(lane, info)
+    return g, net, g.branch_aime(lcl, obs)
+
+
+@pytest.mark.parametrize("name,wkw,nkw", CASES)
+def test_aime_matches_reference_golden(name, wkw, nkw):
+    g, net, trees = run_aime(wkw, nkw)
+    assert list(net.calls) == list(G[name + "_batches"])                         # scenes per AIME round
+    assert list(g.tree.nodes.keys()) == list(G[name + "_internal_keys"])         # identical node-id set/order
+    flags = np.array([[n.data.branch_flag, n.data.end_flag, n.data.terminate_flag] for n in g.tree.nodes.values()])
+    assert np.array_equal(flags, G[name + "_internal_flags"])
+    assert len(trees) == int(G[name + "_ntrees"])
+    for ti, t in enumerate(trees):
+        keys = list(t.nodes.keys())
+        assert keys == list(G[f"{name}_t{ti}_keys"])
+        assert [str(t.nodes[k].parent_key) for k in keys] == list(G[f"{name}_t{ti}_parents"])
+        assert [t.nodes[k].data[1].shape[1] for k in keys] == list(G[f"{name}_t{ti}_durs"])      # END_T - CUR_T
+        probs = np.array([float(np.ravel(t.nodes[k].data[0])[0]) for k in keys])
+        assert np.abs(probs - G[f"{name}_t{ti}_probs"]).max() < 1e-6
+        for k in keys:
+            d = t.nodes[k].data
+            assert d[1].dtype == np.float32 and d[2].dtype == np.float32
+            assert np.abs(d[1][:, ::5] - G[f"{name}_t{ti}_{k}_pos"]).max() < 1e-3       # metres, world frame
+            assert np.abs(d[2][:, ::5] - G[f"{name}_t{ti}_{k}_cov"]).max() < 1e-5
+            assert np.abs(np.asarray(d[3]) - G[f"{name}_t{ti}_{k}_tgt"]).max() < 1e-4
+
+
+def test_tracks_padding_and_order():
+    w = SynthWorld(n_agents=4, n_lanes=2, n_segs=6, seed=1)
+    obs = w.tracks(4.9, drop={2: 30})
+    # make agent 3 unobserved at the last step: it must be skipped
+    last = obs[w.agent_ids[3]].object_states[-1]
+    last.observed = False
+    pos, ang, vel, typ, flags, tids, cats = U.get_agent_trajectories(obs)
+    assert tids == ["AV", w.agent_ids[1], w.agent_ids[2]] and cats == ["av", "exo", "exo"]
+    assert pos.shape == (3, 50, 2) and pos.dtype == np.float32 and flags.dtype == np.int16
+    assert flags[2].sum() == 20 and np.all(flags[2][:30] == 0)
+    assert np.all(pos[2, :30] == pos[2, 30]) and np.all(vel[2, :30] == 0)       # NN pad pos, zero pad vel
+    assert np.all(typ[2, :30] == 0) and typ[2, 30:].sum() == 20
+
+
+def test_lane_graph_shapes_and_frames():
+    w = SynthWorld(n_agents=2, n_lanes=3, n_segs=5, seg_len=32.0, seed=1)
+    g = U.lane_graph_from_map(w, np.array([10.0, 1.0], np.float32), U.rot2(np.float32(0.1)))
+    assert g["num_lanes"] == 3 * 5 * 2          # 32 m segments -> floor(32.x/15) = 2 pieces each
+    assert g["node_ctrs"].shape == (30, 10, 2) and g["node_ctrs"].dtype == np.float32
+    assert np.abs(g["node_ctrs"].mean(axis=1)).max() < 1e-2            # instance frame is centred
+    assert np.allclose(np.linalg.norm(g["lane_vecs"], axis=1), 1.0, atol=1e-6)
+    f = U.lane_features(g)
+    assert f.shape == (30, 10, 16) and set(np.unique(f[..., 4:])) <= {0.0, 1.0}
+
+
+def test_tree_container_contract():
+    t = Tree()
+    t.add_node(Node("r", None, 0))
+    t.add_node(Node("a", "r", 1))
+    t.add_node(Node("b", "r", 2))
+    t.add_node(Node("c", "a", 3))
+    assert t.leaves == ["b", "c"] and t.get_node("c").depth == 2 and t.size() == 4
+    assert [n.key for n in t.retrieve_nodes_to_root("c")] == ["c", "a", "r"]
+    with pytest.raises(KeyError):
+        t.add_node(Node("x", "nope", 0))
+    with pytest.raises(ValueError):
+        t.add_node(Node("a", "r", 0))
+    with pytest.raises(KeyError):
+        t.get_node("zz")

@@ -1,0 +1,59 @@
+"""GPU parity: HIP tree-iLQR (through the C-ABI) against the C oracle and the reference goldens."""
+import os
+
+import numpy as np
+import pytest
+
+from mind_amd.synth import scripted_scenario_tree
+from oracle import ilqr as oi
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = dict(np.load(os.path.join(ROOT, "tests", "golden", "ilqr.npz")))
+
+
+@pytest.mark.parametrize("kind,a,max_iter", [("straight", 3, 100), ("lead", 4, 100), ("branch3", 6, 100),
+                                              ("branch3", 40, 100), ("deep", 3, 4)])
+def test_hip_ilqr_matches_reference_golden(kind, a, max_iter, hip_predictor):
+    key = f"{kind}_a{a}_it{max_iter}"
+    sst = scripted_scenario_tree(kind, a)
+    cfg = oi.default_cfg(max_iter=max_iter)
+    flat = oi.flatten(sst["nodes"])
+    x0 = oi.init_state(sst["state"], sst["ctrl"])
+    xs_w, us_w, st_w = hip_predictor.ilqr_solve(cfg, [flat], x0, sst["target_lane"], sst["target_vel"], 0)
+    xs_f, us_f, st_f = hip_predictor.ilqr_solve(cfg, [flat], x0, sst["target_lane"], sst["target_vel"], 1, us_init=us_w)
+    # tolerance: float64; well below the 1e-3 m the north star asks for
+    assert np.abs(xs_w[0] - G[key + "_xs_w"]).max() < 1e-8
+    assert np.abs(xs_f[0] - G[key + "_xs_f"]).max() < 1e-7
+    assert np.abs(us_f[0] - G[key + "_us_f"]).max() < 1e-7
+    assert st_f[0]["mu"] == G[key + "_Jf"][1]                      # identical accept/reject history
+    assert abs(st_f[0]["J"] - G[key + "_Jf"][0]) < 1e-8 * max(1.0, abs(st_f[0]["J"]))
+
+
+@pytest.mark.parametrize("kind,a", [("lead", 5), ("branch3", 12), ("deep", 4)])
+def test_hip_ilqr_matches_oracle_and_batches(kind, a, hip_predictor):
+    """several trees in one launch give the same result as one by one; compared with the C oracle."""
+    sst = scripted_scenario_tree(kind, a, seed=2)
+    cfg = oi.default_cfg(max_iter=6)
+    flat = oi.flatten(sst["nodes"])
+    x0 = oi.init_state(sst["state"], sst["ctrl"])
+    ref = oi.solve(cfg, flat, x0, sst["target_lane"], sst["target_vel"], 1)
+    sst2 = scripted_scenario_tree("straight", a, seed=2)
+    flat2 = oi.flatten(sst2["nodes"])
+    xs, us, st = hip_predictor.ilqr_solve(cfg, [flat, flat2, flat], x0, sst["target_lane"], sst["target_vel"], 1)
+    assert np.abs(xs[0] - ref["xs"]).max() < 1e-9 and np.array_equal(xs[0], xs[2])
+    ref2 = oi.solve(cfg, flat2, x0, sst["target_lane"], sst["target_vel"], 1)
+    assert np.abs(xs[1] - ref2["xs"]).max() < 1e-9
+    assert st[0]["iterations"] == ref["iterations"] and st[0]["mu"] == ref["mu"]
+
+
+def test_hip_ilqr_grid_border_and_outside(hip_predictor):
+    """start near / outside the 102 m field: exercises the misplaced border windows (Q4) and clamping."""
+    sst = scripted_scenario_tree("straight", 3)
+    cfg = oi.default_cfg(max_iter=3)
+    flat = oi.flatten(sst["nodes"])
+    lane = sst["target_lane"] + np.array([49.0, 50.5])      # lane far from the ego: trajectories pulled to the border
+    x0 = oi.init_state(sst["state"], sst["ctrl"])
+    ref = oi.solve(cfg, flat, x0, lane, sst["target_vel"], 1)
+    xs, us, st = hip_predictor.ilqr_solve(cfg, [flat], x0, lane, sst["target_vel"], 1)
+    assert np.abs(xs[0] - ref["xs"]).max() < 1e-7

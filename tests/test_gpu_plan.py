@@ -1,0 +1,53 @@
+"""GPU: one full MINDPlanner.plan() (HIP predictor over the AIME tree + HIP tree-iLQR) on synthetic
+worlds against the reference's plan() captured in tests/golden/plan.npz (formula weights)."""
+import os
+
+import numpy as np
+import pytest
+
+from mind_amd.synth import SynthWorld
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = dict(np.load(os.path.join(ROOT, "tests", "golden", "plan.npz")))
+CFG = os.path.join(ROOT, "mind_amd", "planners", "mind", "configs", "synthetic.json")
+
+
+def make_planner(world):
+    from mind_amd.planners.mind.planner import MINDPlanner
+    pl = MINDPlanner(CFG)
+    for s in range(50):
+        pl.update_observation(world.local_semantic_map(round(0.1 * s, 6)))
+    lcl = world.local_semantic_map(4.9)
+    pl.update_target_lane(np.asarray(world.target_lane[::2], dtype=np.float64))
+    pl.update_state_ctrl(lcl.ego_agent.state, np.array([0.0, 0.0]))
+    return pl, lcl
+
+
+@pytest.mark.parametrize("name,wkw", [("p6", dict(n_agents=6, n_lanes=3, n_segs=8, seed=1)),
+                                      ("p12", dict(n_agents=12, n_lanes=3, n_segs=10, seed=2))])
+def test_plan_matches_reference(name, wkw, hip_predictor):
+    pl, lcl = make_planner(SynthWorld(**wkw))
+    ok, ctrl, (st, tt) = pl.plan(lcl)
+    assert ok
+    st, tt = st[0], tt[0]
+    keys = list(st.nodes.keys())
+    assert keys == list(G[name + "_scen_keys"])                       # same surviving branch (selection index)
+    probs = np.array([float(np.ravel(st.nodes[k].data[0])[0]) for k in keys])
+    assert np.abs(probs - G[name + "_scen_probs"]).max() < 1e-5
+    for k in keys:
+        assert np.abs(st.nodes[k].data[1][:, ::5] - G[f"{name}_scen_{k}_pos"]).max() < 1e-3     # agent trajectories [m]
+        assert np.abs(st.nodes[k].data[2][:, ::5] - G[f"{name}_scen_{k}_cov"]).max() < 1e-3
+    tk = [k for k in tt.nodes.keys() if k != -1]
+    assert np.array_equal(np.array([tt.nodes[k].parent_key for k in tk]), G[name + "_traj_parent"])
+    xs = np.array([tt.nodes[k].data[0] for k in tk])
+    assert np.abs(xs - G[name + "_traj_xs"]).max() < 1e-3                                        # ego trajectory [m]
+    assert np.abs(np.asarray(ctrl) - G[name + "_ctrl"]).max() < 1e-3
+
+
+def test_plan_repeatable_and_timed(hip_predictor):
+    pl, lcl = make_planner(SynthWorld(n_agents=6, n_lanes=3, n_segs=8, seed=1))
+    r1 = pl.plan(lcl)
+    r2 = pl.plan(lcl)
+    assert np.array_equal(r1[1], r2[1])
+    assert pl.timing["nodes_expanded"] >= 1 and pl.timing["total_s"] < 5.0

@@ -1,0 +1,77 @@
+"""CPU: the C tree-iLQR oracle against golden vectors captured from the imported reference
+(tools/gen_golden.py: ilqr, potential) and, in the build container, against the reference itself."""
+import os
+
+import numpy as np
+import pytest
+
+from mind_amd.synth import scripted_scenario_tree
+from oracle import ilqr as oi
+from oracle import ref_harness as rh
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = dict(np.load(os.path.join(ROOT, "tests", "golden", "ilqr.npz")))
+CASES = [("straight", 3, 100), ("lead", 4, 100), ("branch3", 6, 100), ("branch3", 40, 100), ("deep", 3, 4)]
+
+
+def run_oracle(kind, a, max_iter):
+    sst = scripted_scenario_tree(kind, a)
+    cfg = oi.default_cfg(max_iter=max_iter)
+    flat = oi.flatten(sst["nodes"])
+    x0 = oi.init_state(sst["state"], sst["ctrl"])
+    w = oi.solve(cfg, flat, x0, sst["target_lane"], sst["target_vel"], 0)
+    f = oi.solve(cfg, flat, x0, sst["target_lane"], sst["target_vel"], 1, us_init=w["us"])
+    return flat, w, f
+
+
+@pytest.mark.parametrize("kind,a,max_iter", CASES)
+def test_oracle_ilqr_matches_golden(kind, a, max_iter):
+    key = f"{kind}_a{a}_it{max_iter}"
+    flat, w, f = run_oracle(kind, a, max_iter)
+    assert np.array_equal(flat["parent"], G[key + "_parent"])          # LIFO DFS creation order (Q13)
+    # float64, same operation order as numpy up to BLAS summation order: agreement ~1e-13
+    assert np.abs(w["xs"] - G[key + "_xs_w"]).max() < 1e-9
+    assert np.abs(w["us"] - G[key + "_us_w"]).max() < 1e-9
+    assert np.abs(f["xs"] - G[key + "_xs_f"]).max() < 1e-8
+    assert np.abs(f["us"] - G[key + "_us_f"]).max() < 1e-8
+    assert abs(w["J"] - G[key + "_Jw"][0]) < 1e-9 * max(1, abs(w["J"])) and w["mu"] == G[key + "_Jw"][1]
+    assert abs(f["J"] - G[key + "_Jf"][0]) < 1e-9 * max(1, abs(f["J"])) and f["mu"] == G[key + "_Jf"][1]
+
+
+def test_potential_field_matches_golden():
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "potential.npz")))
+    F, off, res = g["F"], g["off"], float(g["res"])
+    for p, v in zip(g["pts"], g["vals"]):
+        out = oi.field_eval(F, res, off, p[0], p[1])
+        assert np.allclose(out, v, rtol=1e-12, atol=1e-12), (p, out, v)
+
+
+def test_flatten_every_even_substep_and_lifo_order():
+    sst = scripted_scenario_tree("branch3", 3)
+    flat = oi.flatten(sst["nodes"])
+    durs = {k: d[1].shape[1] for k, _, d in sst["nodes"]}
+    assert len(flat["parent"]) == sum((d + 1) // 2 for d in durs.values())
+    assert flat["parent"][0] == -1 and all(flat["parent"][1:] < np.arange(1, len(flat["parent"])))
+    # root scenario node has 16 steps -> 8 trajectory nodes; the LAST child ("1_0_4") is expanded first
+    assert flat["parent"][8] == 7 and np.isclose(flat["prob"][8], 0.094)
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not rh.available(), reason="reference tree not present")
+def test_oracle_matches_imported_reference_live():
+    m = rh.ref_modules()
+    Tree, Node = m["planners.basic.tree"].Tree, m["planners.basic.tree"].Node
+    TTO = m["planners.mind.trajectory_tree"].TrajectoryTreeOptimizer
+    cfgmod = m["planners.mind.configs.planning.demo_1"]
+    sst = scripted_scenario_tree("lead", 5, seed=3)
+    tree = Tree()
+    for k, p, d in sst["nodes"]:
+        tree.add_node(Node(k, p, d))
+    opt = TTO(cfgmod.TrajTreeCfg())
+    opt.init_warm_start_cost_tree(tree, sst["state"], sst["ctrl"], sst["target_lane"], sst["target_vel"])
+    xs_w, us_w = opt.warm_start_solve()
+    opt.init_cost_tree(tree, sst["state"], sst["ctrl"], sst["target_lane"], sst["target_vel"])
+    opt.solve(us_w)
+    flat, w, f = oi.contingency(oi.default_cfg(), sst["nodes"], sst["state"], sst["ctrl"], sst["target_lane"], sst["target_vel"])
+    assert np.abs(w["xs"] - xs_w).max() < 1e-9 and np.abs(f["xs"] - opt.ilqr.xs).max() < 1e-8
+    assert f["mu"] == opt.ilqr._mu

@@ -57,7 +57,180 @@ def gen_predictor():
     print("predictor.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
 
 
-SECTIONS = {"predictor": gen_predictor}
+# ----------------------------------------------------------------------------------------------
+ILQR_CASES = [("straight", 3, 100), ("lead", 4, 100), ("branch3", 6, 100), ("branch3", 40, 100), ("deep", 3, 4)]
+
+
+def _ref_tree(nodes):
+    m = rh.ref_modules()
+    Tree, Node = m["planners.basic.tree"].Tree, m["planners.basic.tree"].Node
+    t = Tree()
+    for k, p, d in nodes:
+        t.add_node(Node(k, p, d))
+    return t
+
+
+def gen_ilqr():
+    """G5/G6: cost-tree construction order + iLQR results of the reference TrajectoryTreeOptimizer
+    (closed-form bicycle stand-in for the Theano dynamics) on scripted scenario trees."""
+    from mind_amd.synth import scripted_scenario_tree
+    m = rh.ref_modules()
+    TTO = m["planners.mind.trajectory_tree"].TrajectoryTreeOptimizer
+    cfgmod = m["planners.mind.configs.planning.demo_1"]
+    out = {}
+    for kind, a, max_iter in ILQR_CASES:
+        sst = scripted_scenario_tree(kind, a)
+        tree = _ref_tree(sst["nodes"])
+        opt = TTO(cfgmod.TrajTreeCfg())
+        opt.init_warm_start_cost_tree(tree, sst["state"], sst["ctrl"], sst["target_lane"], sst["target_vel"])
+        M = opt.cost_tree.tree.size() - 1
+        xs_w, us_w = opt.ilqr.fit(np.zeros((M, 2)), opt.cost_tree, n_iterations=max_iter)
+        xs_w, us_w = xs_w.copy(), us_w.copy()
+        Jw, muw = opt.ilqr.J_opt, opt.ilqr._mu
+        opt.init_cost_tree(tree, sst["state"], sst["ctrl"], sst["target_lane"], sst["target_vel"])
+        parents = np.array([opt.cost_tree.tree.nodes[k].parent_key for k in range(M)], np.int32)
+        xs_f, us_f = opt.ilqr.fit(us_w, opt.cost_tree, n_iterations=max_iter)
+        key = f"{kind}_a{a}_it{max_iter}"
+        # a few per-node costs at the final iterate (field spot values, G5)
+        Lf = np.array([float(np.ravel(opt.cost_tree.l(xs_f[i], us_f[i], i))[0]) for i in range(M)])
+        out.update({key + "_parent": parents, key + "_xs_w": xs_w, key + "_us_w": us_w, key + "_Jw": np.array([Jw, muw]),
+                    key + "_xs_f": xs_f.copy(), key + "_us_f": us_f.copy(),
+                    key + "_Jf": np.array([opt.ilqr.J_opt, opt.ilqr._mu]), key + "_Lf": Lf})
+        print(key, "M", M, "Jw %.8g Jf %.8g" % (Jw, opt.ilqr.J_opt))
+    np.savez_compressed(os.path.join(GOLD, "ilqr.npz"), **out)
+
+
+def gen_potential():
+    """G4: PotentialField value / gradient / Hessian on a random field incl. all 8 border cases and
+    .5 rounding ties (banker's rounding)."""
+    m = rh.ref_modules()
+    PF = m["planners.ilqr.potential"].PotentialField
+    rng = np.random.default_rng(7)
+    W = H = 32
+    res = 0.4
+    off = np.array([3.0, -2.0])
+    x = np.linspace(0.0, (W - 1) * res, W) + off[0]
+    y = np.linspace(0.0, (H - 1) * res, H) + off[1]
+    xx, yy = np.meshgrid(x, y)
+    F = rng.random((H, W)) * 10.0
+    pf = PF(off, res, xx, yy, F)
+    pts = []
+    for ix in (0, 1, 15, W - 2, W - 1):
+        for iy in (0, 1, 15, H - 2, H - 1):
+            pts.append([x[ix] + 0.13, y[iy] - 0.11])
+    pts += [[x[5] + 0.5 * res, y[6]], [x[6] + 0.5 * res, y[7] + 0.5 * res], [x[0] - 3.0, y[3]], [x[W - 1] + 2.0, y[H - 1] + 5.0]]
+    pts += list(np.stack([rng.uniform(x[0], x[-1], 40), rng.uniform(y[0], y[-1], 40)], 1))
+    pts = np.array(pts)
+    vals = []
+    for p in pts:
+        st = np.array([p[0], p[1], 0, 0, 0, 0.0])
+        g = pf.get_gradient(st)
+        h = pf.get_hessian(st)
+        vals.append([pf.get_potential(st), g[0], g[1], h[0, 0], h[1, 1], h[0, 1]])
+    np.savez_compressed(os.path.join(GOLD, "potential.npz"), F=F, off=off, res=np.array(res), pts=pts, vals=np.array(vals))
+    print("potential.npz", len(pts), "points")
+
+
+AIME_CASES = [
+    ("w6", dict(n_agents=6, n_lanes=3, n_segs=8, seed=1), dict()),
+    ("w3_nogrowth", dict(n_agents=3, n_lanes=2, n_segs=6, seed=2), dict(growth=(0.02,) * 6)),
+    ("w9_branch", dict(n_agents=9, n_lanes=3, n_segs=8, seed=3),
+     dict(lateral=(0.0, 9.0, -9.0, 0.1, -6.0, 0.2), growth=(0.3, 0.25, 0.1, 0.02, 0.4, 0.03))),
+    ("w5_deep", dict(n_agents=5, n_lanes=3, n_segs=8, seed=4),
+     dict(lateral=(0.0, 9.0, -9.0, 4.0, -6.0, 0.2), growth=(0.5, 0.45, 0.4, 0.5, 0.4, 0.3),
+          probs=(0.3, 0.25, 0.2, 0.15, 0.0995, 0.0005))),
+    ("w1_ego_only", dict(n_agents=1, n_lanes=2, n_segs=6, seed=5), dict()),
+]
+
+
+def synth_world(kw):
+    from mind_amd.synth import SynthWorld
+    return SynthWorld(object_type_cls=rh.ObjectType, lane_type_cls=rh.LaneType, lane_mark_cls=rh.LaneMarkType, **kw)
+
+
+def gen_aime():
+    """G3: AIME decisions of the reference ScenarioTreeGenerator driven by the scripted FakeNet."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fake_net import FakeNet
+    m = rh.ref_modules()
+    STG = m["planners.mind.scenario_tree"].ScenarioTreeGenerator
+    RefPlanner = m["planners.mind.planner"].MINDPlanner
+    cfgmod = m["planners.mind.configs.planning.demo_1"]
+    out = {}
+    for name, wkw, nkw in AIME_CASES:
+        w = synth_world(wkw)
+        lcl = w.local_semantic_map(4.9)
+        obs = w.tracks(4.9, state_cls=rh.ObjectState, track_cls=rh.Track, drop={2: 30} if wkw["n_agents"] > 2 else None)
+        lane, info = RefPlanner.resample_target_lane(RefPlanner.__new__(RefPlanner), lcl)
+        net = FakeNet(**nkw)
+        g = STG(torch.device("cpu"), net, 50, 50, cfgmod.ScenTreeCfg())
+        g.reset()
+        g.set_target_lane(lane, info)
+        trees = g.branch_aime(lcl, obs)
+        out[name + "_batches"] = np.array(net.calls)
+        out[name + "_internal_keys"] = np.array(list(g.tree.nodes.keys()))
+        out[name + "_internal_flags"] = np.array([[n.data.branch_flag, n.data.end_flag, n.data.terminate_flag]
+                                                  for n in g.tree.nodes.values()])
+        out[name + "_ntrees"] = np.array(len(trees))
+        for ti, t in enumerate(trees):
+            keys = list(t.nodes.keys())
+            out[f"{name}_t{ti}_keys"] = np.array(keys)
+            out[f"{name}_t{ti}_parents"] = np.array([str(t.nodes[k].parent_key) for k in keys])
+            out[f"{name}_t{ti}_probs"] = np.array([float(np.ravel(t.nodes[k].data[0])[0]) for k in keys], np.float64)
+            out[f"{name}_t{ti}_durs"] = np.array([t.nodes[k].data[1].shape[1] for k in keys])
+            for k in keys:
+                d = t.nodes[k].data
+                out[f"{name}_t{ti}_{k}_pos"] = d[1][:, ::5]      # every 5th step keeps the fixture small
+                out[f"{name}_t{ti}_{k}_cov"] = d[2][:, ::5]
+                out[f"{name}_t{ti}_{k}_tgt"] = np.asarray(d[3])
+        print(name, "batches", net.calls, "trees", [list(t.nodes.keys()) for t in trees])
+    np.savez_compressed(os.path.join(GOLD, "aime.npz"), **out)
+
+
+PLAN_CASES = [("p6", dict(n_agents=6, n_lanes=3, n_segs=8, seed=1)), ("p12", dict(n_agents=12, n_lanes=3, n_segs=10, seed=2))]
+
+
+def gen_plan():
+    """G7: one full reference MINDPlanner.plan() (torch-CPU predictor with the formula weights,
+    AIME, python tree-iLQR) on synthetic worlds: chosen tree, control, trees."""
+    import json
+    import tempfile
+    m = rh.ref_modules()
+    RefPlanner = m["planners.mind.planner"].MINDPlanner
+    tmp = tempfile.mkdtemp()
+    ck = os.path.join(tmp, "formula.tar")
+    torch.save({"state_dict": formula_state_dict(as_torch=True)}, ck)
+    cfgp = os.path.join(tmp, "cfg.json")
+    json.dump({"use_cuda": False, "network_config": "planners.mind.configs.networks.net_cfg", "ckpt_path": ck,
+               "planning_config": "planners.mind.configs.planning.demo_1"}, open(cfgp, "w"))
+    out = {}
+    for name, wkw in PLAN_CASES:
+        w = synth_world(wkw)
+        pl = RefPlanner(cfgp)
+        # 50 observation updates at 10 Hz ending at t = 4.9 s (as agent.py does before planning)
+        for s in range(50):
+            pl.update_observation(w.local_semantic_map(round(0.1 * s, 6)))
+        lcl = w.local_semantic_map(4.9)
+        pl.update_target_lane(np.asarray(w.target_lane[::2], dtype=np.float64))
+        pl.update_state_ctrl(lcl.ego_agent.state, np.array([0.0, 0.0]))
+        ok, ctrl, (st, tt) = pl.plan(lcl)
+        st, tt = st[0], tt[0]
+        out[name + "_ctrl"] = np.asarray(ctrl, np.float64)
+        keys = list(st.nodes.keys())
+        out[name + "_scen_keys"] = np.array(keys)
+        out[name + "_scen_probs"] = np.array([float(np.ravel(st.nodes[k].data[0])[0]) for k in keys])
+        for k in keys:
+            out[f"{name}_scen_{k}_pos"] = st.nodes[k].data[1][:, ::5]
+            out[f"{name}_scen_{k}_cov"] = st.nodes[k].data[2][:, ::5]
+        tk = [k for k in tt.nodes.keys() if k != -1]
+        out[name + "_traj_xs"] = np.array([tt.nodes[k].data[0] for k in tk])
+        out[name + "_traj_us"] = np.array([tt.nodes[k].data[1] for k in tk])
+        out[name + "_traj_parent"] = np.array([tt.nodes[k].parent_key for k in tk])
+        print(name, "ctrl", ctrl, "scen tree", keys, "traj nodes", len(tk))
+    np.savez_compressed(os.path.join(GOLD, "plan.npz"), **out)
+
+
+SECTIONS = {"predictor": gen_predictor, "ilqr": gen_ilqr, "potential": gen_potential, "aime": gen_aime, "plan": gen_plan}
 
 if __name__ == "__main__":
     torch.manual_seed(0)
