@@ -25,6 +25,10 @@
 #define IL_NA 10      // line-search candidates
 #define IL_THREADS 512
 #define IL_WAVES (IL_THREADS / 64)
+#define IL_MAXA 128   // agents per scene staged in LDS (cfg4: 64, stress: 128)
+#define IL_REL 15     // relevant-agent list length per node
+#define IL_LSUM 2048   // doubles of LDS used to stage the cost sums
+#define IL_RMARGIN 3.0  // [m] the list is exact for queries within this distance of the nominal state
 
 struct IlqrTreeDev {
   int M, n_agents, n_levels, pad;
@@ -33,12 +37,19 @@ struct IlqrTreeDev {
   const int *level_nodes;   // [M] nodes sorted by depth (ties: key)
   const int *child_start;   // [M+1]
   const int *child_list;    // [M-1] children in key order
+  // chain segments: maximal single-child paths; one wave walks a segment without workgroup barriers
+  int n_segs, n_slevels;
+  const int *seg_start;     // [n_segs+1] into seg_nodes (root -> leaf order inside a segment)
+  const int *seg_nodes;     // [M]
+  const int *slevel_start;  // [n_slevels+1] into slevel_segs (segments grouped by depth in the segment tree)
+  const int *slevel_segs;   // [n_segs]
   const float *prob;        // [M]
   const float *mean;        // [M,a,2]
   const float *cov;         // [M,a]
   // workspace (doubles)
   double *xs, *us, *Fx, *L, *Lx, *Lxx, *k, *K, *Vx, *Vxx;   // [M,*]
   double *xs_new, *us_new, *L_new;                            // [NA,M,*]
+  int *rel;                 // [M, IL_REL+1]: count (or -1 = overflow) + agent indices near the nominal state
   // outputs
   double *stats;            // [4]: iterations, converged, J, mu
 };
@@ -99,10 +110,27 @@ __device__ __forceinline__ void il_window_src(int xi, int yi, int W, int H, int 
 
 struct FieldOut { double val, gx, gy, hxx, hyy, hxy; };
 
+// Stage node i's agents into the wave's LDS table ag[e] = {mean_x, mean_y, sigma_e + offset (f32 add,
+// as the reference computes it), early-out threshold}: entry 0 = ego (offset w_ego_cov_offset).
+__device__ __forceinline__ void il_stage_agents(const IlqrConst &C, const IlqrTreeDev &T, int i, double *ag) {
+  const int lane = threadIdx.x & 63;
+  const float *mean = T.mean + (size_t)i * T.n_agents * 2;
+  const float *cov = T.cov + (size_t)i * T.n_agents;
+  IL_WFENCE();
+  for (int e = lane; e < T.n_agents; e += 64) {
+    const double ec = (double)(cov[e] + (float)(e == 0 ? C.w_ego_off : C.w_exo_off));
+    ag[4 * e + 0] = (double)mean[2 * e];
+    ag[4 * e + 1] = (double)mean[2 * e + 1];
+    ag[4 * e + 2] = ec;
+    ag[4 * e + 3] = ec * ec * 1.000000001;
+  }
+  IL_WFENCE();
+}
+
 // Cooperative (one wave) evaluation of node `i`'s potential field at (px, py).
 // cells[9] (LDS, per wave) receives the raw window; every lane returns the same FieldOut.
 __device__ __forceinline__ void il_field(const IlqrConst &C, const IlqrTreeDev &T, int i, double px, double py,
-                                         double *scr /* >= 64+9 doubles, per wave */, bool want_deriv, FieldOut &o) {
+                                         double *scr /* >= 64+9 doubles, per wave */, const double *ag, bool want_deriv, FieldOut &o) {
   const int lane = threadIdx.x & 63;
   long xi = (long)rint((px - C.off_x) / C.res);
   long yi = (long)rint((py - C.off_y) / C.res);
@@ -117,12 +145,12 @@ __device__ __forceinline__ void il_field(const IlqrConst &C, const IlqrTreeDev &
   double part = 0.0;
   if (lane < 63 && sy >= 0 && C.use_exo) {
     const double cx = C.gx[sx], cy = C.gy[sy];
-    const float *mean = T.mean + (size_t)i * T.n_agents * 2;
-    const float *cov = T.cov + (size_t)i * T.n_agents;
     for (int e = 1 + slot; e < T.n_agents; e += 7) {
-      const double ec = (double)(cov[e] + (float)C.w_exo_off);
-      const double dx = cx - (double)mean[2 * e], dy = cy - (double)mean[2 * e + 1];
-      double v = ec - sqrt(dx * dx + dy * dy);
+      const double ec = ag[4 * e + 2];
+      const double dx = cx - ag[4 * e], dy = cy - ag[4 * e + 1];
+      const double d2 = dx * dx + dy * dy;
+      if (d2 > ag[4 * e + 3]) continue;
+      double v = ec - sqrt(d2);
       v = v > 0.0 ? v : 0.0;
       if (v > 0.0) v += C.w_exo_cost;
       part += v;
@@ -139,10 +167,8 @@ __device__ __forceinline__ void il_field(const IlqrConst &C, const IlqrTreeDev &
       for (int s = 0; s < 7; ++s) covf += scr[lane + 9 * s];
       const double q = C.quad[(size_t)sy * C.W + sx];
       if (C.use_exo) {
-        const float *mean = T.mean + (size_t)i * T.n_agents * 2;
-        const float *cov = T.cov + (size_t)i * T.n_agents;
-        const double ego_cov = (double)(cov[0] + (float)C.w_ego_off);
-        const double dx = C.gx[sx] - (double)mean[0], dy = C.gy[sy] - (double)mean[1];
+        const double ego_cov = ag[2];
+        const double dx = C.gx[sx] - ag[0], dy = C.gy[sy] - ag[1];
         double ego = sqrt(dx * dx + dy * dy) - ego_cov;
         ego = ego > 0.0 ? ego : 0.0;
         cell_v = (wp * q + C.w_exo * covf) + C.w_ego * ego;
@@ -277,16 +303,19 @@ __device__ double il_np_sum(const double *a, long n) {
   return il_np_sum(a, n2) + il_np_sum(a + n2, n - n2);
 }
 
-// Riccati step for one node, cooperative over one wave (solver.py:352-421).  Vx/Vxx of `key` hold the
-// children sums on entry and the node's value function on exit.  Returns (wave-uniform) 1 if singular.
-__device__ __forceinline__ int il_gains(const IlqrConst &C, const IlqrTreeDev &T, int key, double mu, double *scr) {
+// Riccati step for one node, cooperative over one wave (solver.py:352-421).  On entry scr holds the
+// children-summed value function (Vxx at scr+36, Vx at scr+176); on exit it holds this node's value
+// function in the same place (so a chain is walked without touching global memory for V).
+// Returns (wave-uniform) 1 if Q_uu is singular.
+// pre[0..2]: this node's Fx[lane], Lxx[lane] (lanes < 36), Lx[lane-36] (lanes 36..41), loaded by the caller
+// one node ahead so that the global-memory latency overlaps the previous node's algebra.
+__device__ __forceinline__ int il_gains(const IlqrConst &C, const IlqrTreeDev &T, int key, double mu, double *scr,
+                                        double pre_fx, double pre_lxx, double pre_lx, double pre_u0, double pre_u1, double pre_p) {
   const int lane = threadIdx.x & 63;
   const int i = lane / 6, j = lane % 6;   // lanes 0..35 <-> (i,j)
   double *fx = scr, *Vxx = scr + 36, *Tm = scr + 72, *Qxx = scr + 108, *Qux = scr + 144, *Kk = scr + 156;
-  double *Qx = scr + 170, *Vx = scr + 176, *misc = scr + 182;   // misc: Qu[2], Quu[4], k[2], flag
-  IL_WFENCE();
-  if (lane < 36) { fx[lane] = T.Fx[(size_t)key * 36 + lane]; Vxx[lane] = T.Vxx[(size_t)key * 36 + lane]; }
-  if (lane < 6) Vx[lane] = T.Vx[(size_t)key * 6 + lane];
+  double *Qx = scr + 170, *Vx = scr + 176, *misc = scr + 182;   // misc: Qu[2], Quu[4], k[2]
+  if (lane < 36) fx[lane] = pre_fx;
   IL_WFENCE();
   const double dt = C.dt;
   if (lane < 36) {
@@ -300,7 +329,7 @@ __device__ __forceinline__ int il_gains(const IlqrConst &C, const IlqrTreeDev &T
     double s = 0.0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) s += fx[r * 6 + a] * Vx[r];
-    Qx[a] = T.Lx[(size_t)key * 6 + a] + s;
+    Qx[a] = pre_lx + s;
   }
   if (lane >= 42 && lane < 54) {  // Q_ux = f_u^T (V_xx + mu I) f_x ; f_u^T picks rows 4,5 scaled by dt
     const int a = (lane - 42) / 6, jj = (lane - 42) % 6;
@@ -315,12 +344,12 @@ __device__ __forceinline__ int il_gains(const IlqrConst &C, const IlqrTreeDev &T
   if (lane >= 54 && lane < 58) {  // Q_uu
     const int a = (lane - 54) / 2, b = (lane - 54) % 2;
     const double R = dt * (Vxx[(4 + a) * 6 + 4 + b] + ((a == b) ? mu : 0.0));
-    const double luu = (a == b) ? 2.0 * (C.w_ctrl[a] * (double)T.prob[key]) : 0.0;
+    const double luu = (a == b) ? 2.0 * (C.w_ctrl[a] * pre_p) : 0.0;
     misc[2 + a * 2 + b] = luu + R * dt;
   }
   if (lane >= 58 && lane < 60) {  // Q_u
     const int a = lane - 58;
-    const double lu = 2.0 * ((C.w_ctrl[a] * (double)T.prob[key]) * T.us[(size_t)key * 2 + a]);
+    const double lu = 2.0 * ((C.w_ctrl[a] * pre_p) * (a == 0 ? pre_u0 : pre_u1));
     misc[a] = lu + dt * Vx[4 + a];
   }
   IL_WFENCE();
@@ -328,7 +357,7 @@ __device__ __forceinline__ int il_gains(const IlqrConst &C, const IlqrTreeDev &T
     double s = 0.0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) s += Tm[i * 6 + r] * fx[r * 6 + j];
-    Qxx[lane] = T.Lxx[(size_t)key * 36 + lane] + s;
+    Qxx[lane] = pre_lxx + s;
   }
   // 2x2 solves with partial pivoting (LAPACK dgesv order): lanes 0..6 each own one right-hand side
   int singular = 0;
@@ -354,6 +383,7 @@ __device__ __forceinline__ int il_gains(const IlqrConst &C, const IlqrTreeDev &T
   if (singular) return 1;
   const double k0 = misc[6], k1 = misc[7];
   const double q00 = misc[2], q01 = misc[3], q10 = misc[4], q11 = misc[5];
+  double vnew = 0.0, vxnew = 0.0;
   if (lane < 36) {
     const double QuuK0j = q00 * Kk[j] + q01 * Kk[6 + j];
     const double QuuK1j = q10 * Kk[j] + q11 * Kk[6 + j];
@@ -366,144 +396,419 @@ __device__ __forceinline__ int il_gains(const IlqrConst &C, const IlqrTreeDev &T
     const double Quuk0 = q00 * k0 + q01 * k1, Quuk1 = q10 * k0 + q11 * k1;
     double v = Qx[a] + (Kk[a] * Quuk0 + Kk[6 + a] * Quuk1);
     v += (Kk[a] * misc[0] + Kk[6 + a] * misc[1]) + (Qux[a] * k0 + Qux[6 + a] * k1);
-    T.Vx[(size_t)key * 6 + a] = v;
+    vxnew = v;
   }
   if (lane >= 42 && lane < 54) T.K[(size_t)key * 12 + (lane - 42)] = Kk[lane - 42];
   if (lane == 54) { T.k[(size_t)key * 2] = k0; T.k[(size_t)key * 2 + 1] = k1; }
   IL_WFENCE();
-  if (lane < 36) T.Vxx[(size_t)key * 36 + lane] = 0.5 * (Tm[i * 6 + j] + Tm[j * 6 + i]);
+  if (lane < 36) vnew = 0.5 * (Tm[i * 6 + j] + Tm[j * 6 + i]);
+  IL_WFENCE();
+  if (lane < 36) Vxx[lane] = 0.0 + vnew;            // parent accumulates 0 + V[child] (solver.py:349-350)
+  if (lane >= 36 && lane < 42) Vx[lane - 36] = 0.0 + vxnew;
+  IL_WFENCE();
   return 0;
+}
+
+// x' = f(x, u) (trajectory_tree.py:168-175)
+__device__ __forceinline__ void il_dyn_sc(const IlqrConst &C, const double *x, const double *u, double *o) {
+  double s3, c3;
+  sincos(x[3], &s3, &c3);
+  o[0] = x[0] + x[2] * c3 * C.dt;
+  o[1] = x[1] + x[2] * s3 * C.dt;
+  o[2] = x[2] + x[4] * C.dt;
+  o[3] = x[3] + x[2] / C.wb * tan(x[5]) * C.dt;
+  o[4] = x[4] + u[0] * C.dt;
+  o[5] = x[5] + u[1] * C.dt;
+}
+
+// Value of node i's potential field at (px,py) for ONE lane group of 6 lanes (sub-lane r = 0..5):
+// the group's 9 window cells are split over the sub-lanes, the exo sum runs over all agents in
+// ascending order (the oracle's order) with an exact squared-distance early-out before each sqrt.
+// cells: LDS scratch of 9 doubles owned by the group.
+__device__ __forceinline__ double il_field_val_group(const IlqrConst &C, const IlqrTreeDev &T, float pf, double px, double py,
+                                                     int r, double *cells, const double *ag, const int *rel, int nrel) {
+  long xi = (long)rint((px - C.off_x) / C.res);
+  long yi = (long)rint((py - C.off_y) / C.res);
+  xi = xi < 0 ? 0 : (xi > C.W - 1 ? C.W - 1 : xi);
+  yi = yi < 0 ? 0 : (yi > C.H - 1 ? C.H - 1 : yi);
+  const double wp = (double)((float)C.w_tgt * pf);
+  for (int cell = r; cell < 9; cell += 6) {
+    int sy, sx;
+    il_window_src((int)xi, (int)yi, C.W, C.H, cell / 3, cell % 3, sy, sx);
+    double cell_v = 0.0;
+    if (sy >= 0) {
+      const double q = C.quad[(size_t)sy * C.W + sx];
+      if (C.use_exo) {
+        const double cx = C.gx[sx], cy = C.gy[sy];
+        double covf = 0.0;
+        // nrel >= 0: only the listed agents can reach this window (ascending order = the oracle's
+        // summation order with the zero terms dropped); nrel < 0: all agents
+        const int cnt = nrel >= 0 ? nrel : T.n_agents - 1;
+        for (int t = 0; t < cnt; ++t) {
+          const int e = nrel >= 0 ? rel[t] : t + 1;
+          const double dx = cx - ag[4 * e], dy = cy - ag[4 * e + 1];
+          const double d2 = dx * dx + dy * dy;
+          if (d2 > ag[4 * e + 3]) continue;              // max(ec - sqrt(d2), 0) == 0 exactly
+          double v = ag[4 * e + 2] - sqrt(d2);
+          v = v > 0.0 ? v : 0.0;
+          if (v > 0.0) v += C.w_exo_cost;
+          covf += v;
+        }
+        const double ego_cov = ag[2];
+        const double dx = cx - ag[0], dy = cy - ag[1];
+        double ego = sqrt(dx * dx + dy * dy) - ego_cov;
+        ego = ego > 0.0 ? ego : 0.0;
+        cell_v = (wp * q + C.w_exo * covf) + C.w_ego * ego;
+      } else {
+        cell_v = wp * q;
+      }
+    }
+    cells[cell] = cell_v;
+  }
+  IL_WFENCE();
+  double g[3][3], s[3][3];
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[rr][c] = cells[rr * 3 + c];
+  IL_WFENCE();
+  s[0][0] = (((g[0][0] + g[0][1]) + g[1][0]) + g[1][1]) / 4.0;
+  s[0][2] = (((g[0][1] + g[0][2]) + g[1][1]) + g[1][2]) / 4.0;
+  s[2][0] = (((g[1][0] + g[1][1]) + g[2][0]) + g[2][1]) / 4.0;
+  s[2][2] = (((g[1][1] + g[1][2]) + g[2][1]) + g[2][2]) / 4.0;
+  s[0][1] = (g[0][1] + g[1][1]) / 2.0;
+  s[1][0] = (g[1][0] + g[1][1]) / 2.0;
+  s[1][2] = (g[1][1] + g[1][2]) / 2.0;
+  s[2][1] = (g[1][1] + g[2][1]) / 2.0;
+  s[1][1] = g[1][1];
+  const double u = (px - C.gx[xi]) / C.res + 0.5;
+  const double v = (py - C.gy[yi]) / C.res + 0.5;
+  const double u1 = 1 - u, v1 = 1 - v;
+  return u1 * u1 * v1 * v1 * s[0][0] + u1 * u1 * 2.0 * v1 * v * s[1][0] + u1 * u1 * v * v * s[2][0] +
+         2.0 * u1 * u * v1 * v1 * s[0][1] + 2.0 * u1 * u * 2.0 * v1 * v * s[1][1] + 2.0 * u1 * u * v * v * s[2][1] +
+         u * u * v1 * v1 * s[0][2] + u * u * 2.0 * v1 * v * s[1][2] + u * u * v * v * s[2][2];
+}
+
+// Prefetched per-node operands (loaded one chain node ahead, written to LDS when the node is reached)
+struct IlNodePre { float mx[2], my[2], cv[2]; int relv; float prob; };
+
+__device__ __forceinline__ void il_prefetch_node(const IlqrConst &C, const IlqrTreeDev &T, int c, IlNodePre &P) {
+  const int lane = threadIdx.x & 63;
+  P.prob = T.prob[c];
+  P.relv = lane <= IL_REL ? T.rel[(size_t)c * (IL_REL + 1) + lane] : 0;
+  if (C.use_exo) {
+    const float *mean = T.mean + (size_t)c * T.n_agents * 2;
+    const float *cov = T.cov + (size_t)c * T.n_agents;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = lane + 64 * h;
+      if (e < T.n_agents) { P.mx[h] = mean[2 * e]; P.my[h] = mean[2 * e + 1]; P.cv[h] = cov[e]; }
+    }
+  }
+}
+
+// ag[e] = {mean, sigma + offset, threshold}; irel[0] = count, irel[1..] = relevant agent indices (LDS)
+__device__ __forceinline__ void il_commit_node(const IlqrConst &C, const IlqrTreeDev &T, const IlNodePre &P, double *ag, int *irel) {
+  const int lane = threadIdx.x & 63;
+  IL_WFENCE();
+  if (lane <= IL_REL) irel[lane] = P.relv;
+  if (C.use_exo) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = lane + 64 * h;
+      if (e < T.n_agents) {
+        const double ec = (double)(P.cv[h] + (float)(e == 0 ? C.w_ego_off : C.w_exo_off));
+        ag[4 * e + 0] = (double)P.mx[h];
+        ag[4 * e + 1] = (double)P.my[h];
+        ag[4 * e + 2] = ec;
+        ag[4 * e + 3] = ec * ec * 1.000000001;
+      }
+    }
+  }
+  IL_WFENCE();
+}
+
+// Roll ALL 10 line-search candidates along one chain segment in one wave (solver.py:202-240): lane
+// group a = lane/6 carries candidate a (its running state lives in registers), sub-lane r = lane%6
+// shares the group's field evaluation.  init != 0: nominal rollout (alpha = 0 for every group).
+__device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const IlqrTreeDev &T, int seg, int init, double *scr,
+                                                   double *ag) {
+  const int lane = threadIdx.x & 63;
+  const int M = T.M;
+  const int a = lane / 6 < IL_NA ? lane / 6 : IL_NA - 1;
+  const int r = lane % 6;
+  const bool writer = (lane < 6 * IL_NA) && r == 0;
+  const double alpha = init ? 0.0 : C.alphas[a];
+  double *cells = scr + 9 * (lane / 6);          // 11 groups x 9 doubles <= 192
+  const int s0 = T.seg_start[seg], s1 = T.seg_start[seg + 1];
+  const int p0 = T.parent[T.seg_nodes[s0]];
+  double xp[6], xo[6];
+  if (p0 < 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { xp[k] = C.x0[k]; xo[k] = C.x0[k]; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { xp[k] = T.xs_new[((size_t)a * M + p0) * 6 + k]; xo[k] = T.xs[(size_t)p0 * 6 + k]; }
+  }
+  // operands of the next chain node are prefetched while the current one is evaluated
+  int c = T.seg_nodes[s0];
+  double Kc[12], kc[2], uc[2], xoc[6];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Kc[k] = T.K[(size_t)c * 12 + k];
+  kc[0] = T.k[(size_t)c * 2]; kc[1] = T.k[(size_t)c * 2 + 1];
+  uc[0] = T.us[(size_t)c * 2]; uc[1] = T.us[(size_t)c * 2 + 1];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) xoc[k] = T.xs[(size_t)c * 6 + k];
+  int *irel = (int *)(scr + 160);          // 16 ints inside the wave scratch (cells use scr[0..99))
+  IlNodePre Pc, Pn;
+  il_prefetch_node(C, T, c, Pc);
+  for (int q = s0; q < s1; ++q) {
+    const int cn = q + 1 < s1 ? T.seg_nodes[q + 1] : c;
+    il_prefetch_node(C, T, cn, Pn);
+    double Kn[12], kn[2], un2[2], xon[6];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Kn[k] = T.K[(size_t)cn * 12 + k];
+    kn[0] = T.k[(size_t)cn * 2]; kn[1] = T.k[(size_t)cn * 2 + 1];
+    un2[0] = T.us[(size_t)cn * 2]; un2[1] = T.us[(size_t)cn * 2 + 1];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xon[k] = T.xs[(size_t)cn * 6 + k];
+    double u[2], x[6];
+    if (T.parent[c] < 0) {
+      u[0] = uc[0] + alpha * kc[0];
+      u[1] = uc[1] + alpha * kc[1];
+    } else {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        double sm = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) sm += Kc[b * 6 + jj] * (xp[jj] - xo[jj]);
+        u[b] = uc[b] + alpha * kc[b] + sm;
+      }
+    }
+    il_dyn_sc(C, xp, u, x);
+    int nrel = -1;
+    const int *rel = irel + 1;
+    il_commit_node(C, T, Pc, ag, irel);
+    if (C.use_exo) {
+      // the list was built around the nominal state xoc; it is exact while the query stays within
+      // IL_RMARGIN of it and inside the grid (no index clamping)
+      const int cnt = irel[0];
+      const double ddx = x[0] - xoc[0], ddy = x[1] - xoc[1];
+      const double fx_ = (x[0] - C.off_x) / C.res, fy_ = (x[1] - C.off_y) / C.res;
+      const bool inside = fx_ > 1.0 && fx_ < (double)(C.W - 2) && fy_ > 1.0 && fy_ < (double)(C.H - 2);
+      if (cnt >= 0 && !init && inside && ddx * ddx + ddy * ddy < IL_RMARGIN * IL_RMARGIN) nrel = cnt;
+    }
+    FieldOut fe;
+    fe.val = il_field_val_group(C, T, Pc.prob, x[0], x[1], r, cells, ag, rel, nrel);
+    if (writer) {
+      T.L_new[(size_t)a * M + c] = il_node_cost(C, (double)Pc.prob, x, u, fe, nullptr, nullptr, nullptr);
+      double *xn = T.xs_new + ((size_t)a * M + c) * 6, *un = T.us_new + ((size_t)a * M + c) * 2;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) xn[k] = x[k];
+      un[0] = u[0]; un[1] = u[1];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { xp[k] = x[k]; xo[k] = xoc[k]; xoc[k] = xon[k]; }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Kc[k] = Kn[k];
+    kc[0] = kn[0]; kc[1] = kn[1]; uc[0] = un2[0]; uc[1] = un2[1];
+    Pc = Pn;
+    c = cn;
+  }
+}
+
+// Derivatives at the accepted iterate (solver.py:285-294,308-320): embarrassingly parallel over nodes
+// because xs/us are already known (the accepted line-search candidate IS the next nominal rollout).
+// One wave per node, one matrix entry per lane (no private arrays: they would live in scratch memory).
+__device__ __forceinline__ void il_derivatives(const IlqrConst &C, const IlqrTreeDev &T, int c, double *scr, double *ag) {
+  const int lane = threadIdx.x & 63;
+  double x[6], u[2];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) x[k] = T.xs[(size_t)c * 6 + k];
+  u[0] = T.us[(size_t)c * 2]; u[1] = T.us[(size_t)c * 2 + 1];
+  const double p = (double)T.prob[c];
+  FieldOut fe;
+  if (C.use_exo) {
+    il_stage_agents(C, T, c, ag);
+    // relevant agents for the next line search: |mu_e - x| < (sigma_e + offset) + margin + window reach,
+    // compacted in ascending agent order with wave ballots
+    int *rl = T.rel + (size_t)c * (IL_REL + 1);
+    int cnt = 0;
+    for (int base = 1; base < T.n_agents; base += 64) {
+      const int e = base + lane;
+      bool hit = false;
+      if (e < T.n_agents) {
+        const double dx = ag[4 * e] - x[0], dy = ag[4 * e + 1] - x[1];
+        const double rr = ag[4 * e + 2] + IL_RMARGIN + 1.0;      // 1.0 > 1.5 cells * sqrt(2) * 0.4 m
+        hit = dx * dx + dy * dy < rr * rr;
+      }
+      const unsigned long long m = __ballot(hit);
+      const int rank = __popcll(m & ((1ull << lane) - 1ull));
+      if (hit && cnt >= 0 && cnt + rank < IL_REL) rl[1 + cnt + rank] = e;
+      const int tot = __popcll(m);
+      cnt = (cnt < 0 || cnt + tot > IL_REL) ? -1 : cnt + tot;
+    }
+    if (lane == 0) rl[0] = cnt;
+  }
+  il_field(C, T, c, x[0], x[1], scr, ag, true, fe);
+  double s3, c3;
+  sincos(x[3], &s3, &c3);
+  const double c5 = cos(x[5]);
+  const double t5 = tan(x[5]);
+  if (lane < 36) {
+    const int i = lane / 6, j = lane % 6;
+    // l_xx = field Hessian (xy block) + 2 W_des p + 2 W_con p on violated bounds
+    double h = 0.0;
+    if (i == 0 && j == 0) h += fe.hxx;
+    if ((i == 0 && j == 1) || (i == 1 && j == 0)) h += fe.hxy;
+    if (i == 1 && j == 1) h += fe.hyy;
+    if (i == j) {
+      h += 2.0 * (C.w_des[i] * p);
+      if (x[i] > C.ub[i] || x[i] < C.lb[i]) h += 2.0 * (C.w_con[i] * p);
+    }
+    T.Lxx[(size_t)c * 36 + lane] = h;
+    // f_x at the POST state (Q1)
+    double J = i == j ? 1.0 : 0.0;
+    if (i == 0 && j == 2) J = c3 * C.dt;
+    if (i == 0 && j == 3) J = -x[2] * s3 * C.dt;
+    if (i == 1 && j == 2) J = s3 * C.dt;
+    if (i == 1 && j == 3) J = x[2] * c3 * C.dt;
+    if (i == 2 && j == 4) J = C.dt;
+    if (i == 3 && j == 2) J = t5 / C.wb * C.dt;
+    if (i == 3 && j == 5) J = x[2] / C.wb / (c5 * c5) * C.dt;
+    T.Fx[(size_t)c * 36 + lane] = J;
+  } else if (lane < 42) {
+    const int k = lane - 36;
+    double g = 0.0;
+    if (k == 0) g += fe.gx;
+    if (k == 1) g += fe.gy;
+    const double xd = (k == 2) ? C.target_vel : 0.0;
+    g += 2.0 * ((C.w_des[k] * p) * (x[k] - xd));
+    const double w = C.w_con[k] * p;
+    if (x[k] > C.ub[k]) g += 2.0 * w * (x[k] - C.ub[k]);
+    else if (x[k] < C.lb[k]) g += 2.0 * w * (x[k] - C.lb[k]);
+    T.Lx[(size_t)c * 6 + k] = g;
+  } else if (lane == 42) {
+    T.L[c] = il_node_cost(C, p, x, u, fe, nullptr, nullptr, nullptr);
+  }
 }
 
 __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restrict__ trees, IlqrConst C) {
   const IlqrTreeDev T = trees[blockIdx.x];
   __shared__ double scr_all[IL_WAVES][192];
+  __shared__ double ag_all[IL_WAVES][4 * IL_MAXA];
+  __shared__ double lsum[IL_LSUM];
   __shared__ double Jnew[IL_NA];
   __shared__ double sh_mu, sh_delta, sh_J;
   __shared__ int sh_accepted, sh_converged, sh_stop, sh_sing, sh_pick;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double *scr = scr_all[wave];
+  double *ag = ag_all[wave];
   const int M = T.M;
-  if (tid == 0) { sh_mu = 1.0; sh_delta = 2.0; sh_accepted = 1; sh_converged = 0; sh_stop = 0; sh_J = 0.0; }
+  if (tid == 0) { sh_mu = 1.0; sh_delta = 2.0; sh_accepted = 1; sh_converged = 0; sh_stop = 0; sh_J = 0.0; sh_pick = 0; }
+  // ---- initial nominal rollout (solver.py:255-330) = candidate slot 0 with k = K = 0, alpha = 0
+  for (int q = tid; q < M * 2; q += IL_THREADS) T.k[q] = 0.0;
+  for (int q = tid; q < M * 12; q += IL_THREADS) T.K[q] = 0.0;
+  for (int q = tid; q < M * 6; q += IL_THREADS) T.xs[q] = 0.0;
+  __threadfence_block();
   __syncthreads();
-  int it = 0;
-  for (it = 0; it < C.max_iter; ++it) {
-    // ---------------- forward rollout with derivatives (solver.py:255-330) ----------------
-    if (sh_accepted) {
-      for (int d = 0; d < T.n_levels; ++d) {
-        const int lo = T.level_start[d], hi = T.level_start[d + 1];
-        for (int q = lo + wave; q < hi; q += IL_WAVES) {
-          const int c = T.level_nodes[q];
-          const int p = T.parent[c];
-          double xp[6], u[2], x[6];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) xp[k] = p < 0 ? C.x0[k] : T.xs[(size_t)p * 6 + k];
-          u[0] = T.us[(size_t)c * 2]; u[1] = T.us[(size_t)c * 2 + 1];
-          il_dyn(C, xp, u, x);
-          FieldOut fe;
-          il_field(C, T, c, x[0], x[1], scr, true, fe);
-          if (lane == 0) {
-            double lx[6], lxx[36], lud[4];
-            const double Lc = il_node_cost(C, (double)T.prob[c], x, u, fe, lx, lxx, lud);
-            T.L[c] = Lc;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { T.xs[(size_t)c * 6 + k] = x[k]; T.Lx[(size_t)c * 6 + k] = lx[k]; }
-#pragma unroll
-            for (int k = 0; k < 36; ++k) T.Lxx[(size_t)c * 36 + k] = lxx[k];
-            // f_x at the POST state (Q1)
-            double J[36];
-#pragma unroll
-            for (int k = 0; k < 36; ++k) J[k] = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) J[k * 6 + k] = 1.0;
-            J[0 * 6 + 2] = cos(x[3]) * C.dt;
-            J[0 * 6 + 3] = -x[2] * sin(x[3]) * C.dt;
-            J[1 * 6 + 2] = sin(x[3]) * C.dt;
-            J[1 * 6 + 3] = x[2] * cos(x[3]) * C.dt;
-            J[2 * 6 + 4] = C.dt;
-            J[3 * 6 + 2] = tan(x[5]) / C.wb * C.dt;
-            J[3 * 6 + 5] = x[2] / C.wb / (cos(x[5]) * cos(x[5])) * C.dt;
-#pragma unroll
-            for (int k = 0; k < 36; ++k) T.Fx[(size_t)c * 36 + k] = J[k];
-          }
-        }
-        __threadfence_block();
-        __syncthreads();
-      }
-      if (tid == 0) { sh_J = il_np_sum(T.L, M); sh_accepted = 0; }
-      __syncthreads();
-    }
-    // ---------------- backward pass (solver.py:332-373), deepest level first ----------------
-    for (int q = tid; q < M * 6; q += IL_THREADS) T.Vx[q] = 0.0;
-    for (int q = tid; q < M * 36; q += IL_THREADS) T.Vxx[q] = 0.0;
-    if (tid == 0) sh_sing = 0;
+  for (int d = 0; d < T.n_slevels; ++d) {
+    for (int q = T.slevel_start[d] + wave; q < T.slevel_start[d + 1]; q += IL_WAVES)
+      il_rollout_segment(C, T, T.slevel_segs[q], 1, scr, ag);
     __threadfence_block();
     __syncthreads();
+  }
+  int it = 0;
+  long long t_der = 0, t_bw = 0, t_ls = 0, t_sel = 0, t_mark = clock64();
+#define IL_MARK(acc) do { long long now_ = clock64(); acc += now_ - t_mark; t_mark = now_; } while (0)
+  for (it = 0; it < C.max_iter; ++it) {
+    if (sh_accepted) {
+      // adopt the accepted candidate as the nominal trajectory, then derivatives for all nodes in parallel
+      const int pick = sh_pick;
+      const double *xn = T.xs_new + (size_t)pick * M * 6, *un = T.us_new + (size_t)pick * M * 2;
+      for (int q = tid; q < M * 6; q += IL_THREADS) T.xs[q] = xn[q];
+      for (int q = tid; q < M * 2; q += IL_THREADS) T.us[q] = un[q];
+      __threadfence_block();
+      __syncthreads();
+      for (int c = wave; c < M; c += IL_WAVES) il_derivatives(C, T, c, scr, ag);
+      __threadfence_block();
+      __syncthreads();
+      if (M <= IL_LSUM) {
+        for (int q = tid; q < M; q += IL_THREADS) lsum[q] = T.L[q];
+        __syncthreads();
+        if (tid == 0) { sh_J = il_np_sum(lsum, M); sh_accepted = 0; }
+      } else if (tid == 0) { sh_J = il_np_sum(T.L, M); sh_accepted = 0; }
+      __syncthreads();
+    }
+    IL_MARK(t_der);
+    // ---------------- backward pass (solver.py:332-373): segments, deepest segment level first ----------------
+    if (tid == 0) sh_sing = 0;
+    __syncthreads();
     const double mu = sh_mu;
-    for (int d = T.n_levels - 1; d >= 0; --d) {
-      const int lo = T.level_start[d], hi = T.level_start[d + 1];
-      for (int q = lo + wave; q < hi; q += IL_WAVES) {
-        const int c = T.level_nodes[q];
-        // V[c] <- sum of children's value functions (children in key order, from zero)
-        if (lane < 42) {
+    for (int d = T.n_slevels - 1; d >= 0; --d) {
+      for (int q = T.slevel_start[d] + wave; q < T.slevel_start[d + 1]; q += IL_WAVES) {
+        const int seg = T.slevel_segs[q];
+        const int s0 = T.seg_start[seg], s1 = T.seg_start[seg + 1];
+        // the last node of the segment gathers its children (first nodes of child segments), key order, from 0
+        {
+          const int c = T.seg_nodes[s1 - 1];
           double acc = 0.0;
-          for (int e = T.child_start[c]; e < T.child_start[c + 1]; ++e) {
-            const int ch = T.child_list[e];
-            acc += lane < 36 ? T.Vxx[(size_t)ch * 36 + lane] : T.Vx[(size_t)ch * 6 + (lane - 36)];
-          }
-          if (lane < 36) T.Vxx[(size_t)c * 36 + lane] = acc; else T.Vx[(size_t)c * 6 + (lane - 36)] = acc;
+          if (lane < 42)
+            for (int e = T.child_start[c]; e < T.child_start[c + 1]; ++e) {
+              const int ch = T.child_list[e];
+              acc += lane < 36 ? T.Vxx[(size_t)ch * 36 + lane] : T.Vx[(size_t)ch * 6 + (lane - 36)];
+            }
+          IL_WFENCE();
+          if (lane < 36) scr[36 + lane] = acc;
+          else if (lane < 42) scr[176 + lane - 36] = acc;
+          IL_WFENCE();
         }
-        __threadfence_block();
-        if (il_gains(C, T, c, mu, scr) && lane == 0) sh_sing = 1;
+        int sing = 0;
+        double pfx = 0.0, plxx = 0.0, plx = 0.0, pu0, pu1, pp;
+        {
+          const int c = T.seg_nodes[s1 - 1];
+          if (lane < 36) { pfx = T.Fx[(size_t)c * 36 + lane]; plxx = T.Lxx[(size_t)c * 36 + lane]; }
+          else if (lane < 42) plx = T.Lx[(size_t)c * 6 + lane - 36];
+          pu0 = T.us[(size_t)c * 2]; pu1 = T.us[(size_t)c * 2 + 1]; pp = (double)T.prob[c];
+        }
+        for (int r = s1 - 1; r >= s0 && !sing; --r) {
+          double nfx = 0.0, nlxx = 0.0, nlx = 0.0, nu0 = 0.0, nu1 = 0.0, np_ = 0.0;
+          if (r > s0) {
+            const int cn = T.seg_nodes[r - 1];
+            if (lane < 36) { nfx = T.Fx[(size_t)cn * 36 + lane]; nlxx = T.Lxx[(size_t)cn * 36 + lane]; }
+            else if (lane < 42) nlx = T.Lx[(size_t)cn * 6 + lane - 36];
+            nu0 = T.us[(size_t)cn * 2]; nu1 = T.us[(size_t)cn * 2 + 1]; np_ = (double)T.prob[cn];
+          }
+          sing = il_gains(C, T, T.seg_nodes[r], mu, scr, pfx, plxx, plx, pu0, pu1, pp);
+          pfx = nfx; plxx = nlxx; plx = nlx; pu0 = nu0; pu1 = nu1; pp = np_;
+        }
+        if (sing) { if (lane == 0) sh_sing = 1; }
+        else {
+          const int c = T.seg_nodes[s0];   // value function of the segment head, for the parent's gather
+          if (lane < 36) T.Vxx[(size_t)c * 36 + lane] = scr[36 + lane];
+          else if (lane < 42) T.Vx[(size_t)c * 6 + lane - 36] = scr[176 + lane - 36];
+        }
       }
       __threadfence_block();
       __syncthreads();
     }
+    IL_MARK(t_bw);
     if (sh_sing) { __syncthreads(); continue; }   // LinAlgError: retry without raising mu (Q9)
-    // ---------------- line search: all 10 alphas rolled out concurrently (solver.py:180-253) -------
-    for (int d = 0; d < T.n_levels; ++d) {
-      const int lo = T.level_start[d], hi = T.level_start[d + 1];
-      const int items = (hi - lo) * IL_NA;
-      for (int w = wave; w < items; w += IL_WAVES) {
-        const int a = w % IL_NA, c = T.level_nodes[lo + w / IL_NA];
-        const int p = T.parent[c];
-        const double alpha = C.alphas[a];
-        double *xn = T.xs_new + ((size_t)a * M + c) * 6, *un = T.us_new + ((size_t)a * M + c) * 2;
-        double x[6], u[2], xp[6];
-        if (p < 0) {
-#pragma unroll
-          for (int k = 0; k < 6; ++k) xp[k] = C.x0[k];
-          u[0] = T.us[(size_t)c * 2] + alpha * T.k[(size_t)c * 2];
-          u[1] = T.us[(size_t)c * 2 + 1] + alpha * T.k[(size_t)c * 2 + 1];
-        } else {
-          const double *xpn = T.xs_new + ((size_t)a * M + p) * 6;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) xp[k] = xpn[k];
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            double s = 0.0;
-#pragma unroll
-            for (int jj = 0; jj < 6; ++jj) s += T.K[((size_t)c * 2 + b) * 6 + jj] * (xp[jj] - T.xs[(size_t)p * 6 + jj]);
-            u[b] = T.us[(size_t)c * 2 + b] + alpha * T.k[(size_t)c * 2 + b] + s;
-          }
-        }
-        il_dyn(C, xp, u, x);
-        FieldOut fe;
-        il_field(C, T, c, x[0], x[1], scr, false, fe);
-        if (lane == 0) {
-          const double Lc = il_node_cost(C, (double)T.prob[c], x, u, fe, nullptr, nullptr, nullptr);
-          T.L_new[(size_t)a * M + c] = Lc;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) xn[k] = x[k];
-          un[0] = u[0]; un[1] = u[1];
-        }
-      }
+    // ---------------- line search: all 10 alphas rolled out concurrently in lane groups (solver.py:180-253) -------
+    for (int d = 0; d < T.n_slevels; ++d) {
+      for (int q = T.slevel_start[d] + wave; q < T.slevel_start[d + 1]; q += IL_WAVES)
+        il_rollout_segment(C, T, T.slevel_segs[q], 0, scr, ag);
       __threadfence_block();
+      __syncthreads();
+    }
+    IL_MARK(t_ls);
+    if (M * IL_NA <= IL_LSUM) {
+      for (int q = tid; q < M * IL_NA; q += IL_THREADS) lsum[q] = T.L_new[q];
       __syncthreads();
     }
     if (tid < IL_NA) {
       double J = 0.0;   // python sum(): sequential
-      const double *Ln = T.L_new + (size_t)tid * M;
+      const double *Ln = (M * IL_NA <= IL_LSUM) ? lsum + (size_t)tid * M : T.L_new + (size_t)tid * M;
       for (int c = 0; c < M; ++c) J += Ln[c];
       Jnew[tid] = J;
     }
@@ -512,8 +817,8 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
       int pick = -1;
       for (int a = 0; a < IL_NA; ++a)
         if (Jnew[a] < sh_J) { pick = a; break; }
-      sh_pick = pick;
       if (pick >= 0) {
+        sh_pick = pick;
         if (fabs((sh_J - Jnew[pick]) / sh_J) < 1e-6) sh_converged = 1;
         sh_accepted = 1;
         sh_delta = fmin(1.0, sh_delta) / 2.0;
@@ -526,19 +831,21 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
       }
     }
     __syncthreads();
-    if (sh_pick >= 0) {
-      const double *xn = T.xs_new + (size_t)sh_pick * M * 6, *un = T.us_new + (size_t)sh_pick * M * 2;
-      for (int q = tid; q < M * 6; q += IL_THREADS) T.xs[q] = xn[q];
-      for (int q = tid; q < M * 2; q += IL_THREADS) T.us[q] = un[q];
-      __threadfence_block();
-    }
-    __syncthreads();
+    IL_MARK(t_sel);
     if (sh_converged || sh_stop) break;
+  }
+  // the reference returns the last ACCEPTED xs/us (Q19: J_opt is the cost before that step)
+  if (sh_accepted) {
+    const int pick = sh_pick;
+    const double *xn = T.xs_new + (size_t)pick * M * 6, *un = T.us_new + (size_t)pick * M * 2;
+    for (int q = tid; q < M * 6; q += IL_THREADS) T.xs[q] = xn[q];
+    for (int q = tid; q < M * 2; q += IL_THREADS) T.us[q] = un[q];
   }
   if (tid == 0) {
     T.stats[0] = (double)(it < C.max_iter ? it + 1 : it);
     T.stats[1] = (double)sh_converged;
     T.stats[2] = sh_J;
     T.stats[3] = sh_mu;
+    T.stats[4] = (double)t_der; T.stats[5] = (double)t_bw; T.stats[6] = (double)t_ls; T.stats[7] = (double)t_sel;
   }
 }

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -694,25 +695,27 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
   auto takeF = [&](size_t n) { size_t o = nf; nf += (n + 3) & ~(size_t)3; return o; };
   auto takeI = [&](size_t n) { size_t o = ni; ni += (n + 3) & ~(size_t)3; return o; };
   const size_t o_gx = takeD(W), o_gy = takeD(H), o_lane = takeD((size_t)n_lane_pts * 2), o_quad = takeD((size_t)W * H);
-  struct TL { size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist; int M, a, nl; };
+  struct TL { size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel; int M, a, nl, nseg, nsl; };
   std::vector<TL> tl(n_trees);
   long Mtot = 0;
   for (int t = 0; t < n_trees; ++t) {
     const mind_cost_tree &tr = trees[t];
     if (tr.n_nodes <= 0 || !tr.parent || !tr.prob || tr.n_agents <= 0 || (use_exo && (!tr.agent_mean || !tr.agent_cov)))
       return fail(c, MIND_EINVAL, "tree %d: bad arrays", t);
+    if (tr.n_agents > IL_MAXA) return fail(c, MIND_EINVAL, "tree %d: %d agents > %d supported", t, tr.n_agents, IL_MAXA);
     const size_t M = tr.n_nodes;
     TL &L = tl[t];
     L.M = (int)M; L.a = tr.n_agents;
     L.xs = takeD(6 * M); L.us = takeD(2 * M); L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M);
     L.Lxx = takeD(36 * M); L.k = takeD(2 * M); L.K = takeD(12 * M); L.Vx = takeD(6 * M); L.Vxx = takeD(36 * M);
-    L.xsn = takeD(60 * M); L.usn = takeD(20 * M); L.Ln = takeD(10 * M); L.stats = takeD(4);
+    L.xsn = takeD(60 * M); L.usn = takeD(20 * M); L.Ln = takeD(10 * M); L.stats = takeD(8);
     L.prob = takeF(M); L.mean = takeF(M * tr.n_agents * 2); L.cov = takeF(M * tr.n_agents);
-    L.parent = takeI(M); L.lnodes = takeI(M); L.cstart = takeI(M + 1); L.clist = takeI(M);
+    L.parent = takeI(M); L.lnodes = takeI(M); L.cstart = takeI(M + 1); L.clist = takeI(M); L.rel = takeI(M * (IL_REL + 1));
     Mtot += (long)M;
   }
   // levels need the depth first
   std::vector<std::vector<int>> lvl_start(n_trees), lvl_nodes(n_trees), cst(n_trees), cls(n_trees);
+  std::vector<std::vector<int>> sg_start(n_trees), sg_nodes(n_trees), sl_start(n_trees), sl_segs(n_trees);
   for (int t = 0; t < n_trees; ++t) {
     const mind_cost_tree &tr = trees[t];
     const int M = tr.n_nodes;
@@ -738,6 +741,35 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
     std::vector<int> cf(M, 0);
     for (int i = 1; i < M; ++i) cls[t][cst[t][tr.parent[i]] + cf[tr.parent[i]]++] = i;
     tl[t].lstart = takeI(maxd + 2);
+    // chain segments: a node starts a segment if it is node 0 or its parent has >= 2 children
+    std::vector<int> seg_of(M, -1), seg_depth;
+    auto nchild = [&](int i) { return cst[t][i + 1] - cst[t][i]; };
+    sg_start[t].clear(); sg_nodes[t].clear();
+    for (int i = 0; i < M; ++i) {
+      if (!(i == 0 || nchild(tr.parent[i]) >= 2)) continue;
+      const int sidx = (int)sg_start[t].size();
+      sg_start[t].push_back((int)sg_nodes[t].size());
+      seg_depth.push_back(i == 0 ? 0 : seg_depth[seg_of[tr.parent[i]]] + 1);
+      int c = i;
+      while (true) {
+        seg_of[c] = sidx;
+        sg_nodes[t].push_back(c);
+        if (nchild(c) != 1) break;
+        c = cls[t][cst[t][c]];
+      }
+    }
+    sg_start[t].push_back((int)sg_nodes[t].size());
+    const int nseg = (int)seg_depth.size();
+    int maxsd = 0;
+    for (int d : seg_depth) maxsd = d > maxsd ? d : maxsd;
+    sl_start[t].assign(maxsd + 2, 0);
+    for (int d : seg_depth) sl_start[t][d + 1]++;
+    for (int d = 0; d <= maxsd; ++d) sl_start[t][d + 1] += sl_start[t][d];
+    sl_segs[t].resize(nseg);
+    std::vector<int> sf(maxsd + 1, 0);
+    for (int sgi = 0; sgi < nseg; ++sgi) sl_segs[t][sl_start[t][seg_depth[sgi]] + sf[seg_depth[sgi]]++] = sgi;
+    tl[t].nseg = nseg; tl[t].nsl = maxsd + 1;
+    tl[t].sstart = takeI(nseg + 1); tl[t].snodes = takeI(M); tl[t].slstart = takeI(maxsd + 2); tl[t].slsegs = takeI(nseg);
   }
   const size_t bytesD = nd * sizeof(double), bytesF = nf * sizeof(float), bytesI = ni * sizeof(int);
   const size_t o_structs = bytesD + bytesF + bytesI;
@@ -770,10 +802,17 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
     memcpy(hI.data() + L.lnodes, lvl_nodes[t].data(), M * sizeof(int));
     memcpy(hI.data() + L.cstart, cst[t].data(), (M + 1) * sizeof(int));
     memcpy(hI.data() + L.clist, cls[t].data(), cls[t].size() * sizeof(int));
+    memcpy(hI.data() + L.sstart, sg_start[t].data(), sg_start[t].size() * sizeof(int));
+    memcpy(hI.data() + L.snodes, sg_nodes[t].data(), sg_nodes[t].size() * sizeof(int));
+    memcpy(hI.data() + L.slstart, sl_start[t].data(), sl_start[t].size() * sizeof(int));
+    memcpy(hI.data() + L.slsegs, sl_segs[t].data(), sl_segs[t].size() * sizeof(int));
     IlqrTreeDev &D = hT[t];
     D.M = L.M; D.n_agents = L.a; D.n_levels = L.nl; D.pad = 0;
     D.parent = dI + L.parent; D.level_start = dI + L.lstart; D.level_nodes = dI + L.lnodes;
     D.child_start = dI + L.cstart; D.child_list = dI + L.clist;
+    D.rel = dI + L.rel;
+    D.n_segs = L.nseg; D.n_slevels = L.nsl;
+    D.seg_start = dI + L.sstart; D.seg_nodes = dI + L.snodes; D.slevel_start = dI + L.slstart; D.slevel_segs = dI + L.slsegs;
     D.prob = dF + L.prob; D.mean = dF + L.mean; D.cov = dF + L.cov;
     D.xs = dD + L.xs; D.us = dD + L.us; D.Fx = dD + L.Fx; D.L = dD + L.L; D.Lx = dD + L.Lx; D.Lxx = dD + L.Lxx;
     D.k = dD + L.k; D.K = dD + L.K; D.Vx = dD + L.Vx; D.Vxx = dD + L.Vxx;
@@ -799,19 +838,22 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
   hipLaunchKernelGGL(k_ilqr, dim3(n_trees), dim3(IL_THREADS), 0, st, (const IlqrTreeDev *)(base + o_structs), K);
   HIPCHK(c, hipGetLastError());
   moff = 0;
-  std::vector<double> hs(4 * n_trees);
+  std::vector<double> hs(8 * n_trees);
   for (int t = 0; t < n_trees; ++t) {
     const TL &L = tl[t];
     HIPCHK(c, hipMemcpyAsync(xs + moff * 6, dD + L.xs, (size_t)L.M * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(us + moff * 2, dD + L.us, (size_t)L.M * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(hs.data() + 4 * t, dD + L.stats, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hs.data() + 8 * t, dD + L.stats, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
     moff += L.M;
   }
   HIPCHK(c, hipStreamSynchronize(st));
   if (stats)
     for (int t = 0; t < n_trees; ++t) {
-      stats[t].iterations = (int)hs[4 * t]; stats[t].converged = (int)hs[4 * t + 1];
-      stats[t].J = hs[4 * t + 2]; stats[t].mu = hs[4 * t + 3];
+      stats[t].iterations = (int)hs[8 * t]; stats[t].converged = (int)hs[8 * t + 1];
+      stats[t].J = hs[8 * t + 2]; stats[t].mu = hs[8 * t + 3];
+      if (getenv("MIND_ILQR_TRACE"))
+        fprintf(stderr, "[k_ilqr] tree %d it %d: cycles derivatives %.0f backward %.0f linesearch %.0f select %.0f\n", t,
+                stats[t].iterations, hs[8 * t + 4], hs[8 * t + 5], hs[8 * t + 6], hs[8 * t + 7]);
     }
   return MIND_OK;
 }
