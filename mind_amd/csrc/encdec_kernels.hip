@@ -44,7 +44,24 @@ __device__ __forceinline__ void dense(const float *in, int ldi, int K, const flo
     const float bv = b ? b[o] : 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = bv;
-    for (int k = 0; k < K; k += 4) {
+    int k = 0;
+    for (; k + 16 <= K; k += 16) {   // 16 weight loads in flight per thread (latency-bound on L2)
+      float w[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) w[q] = WT[(size_t)(k + q) * NOUT + o];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 x = *(const f32x4 *)(in + r * ldi + k + 4 * q4);
+          acc[r] = fmaf(w[4 * q4 + 0], x[0], acc[r]);
+          acc[r] = fmaf(w[4 * q4 + 1], x[1], acc[r]);
+          acc[r] = fmaf(w[4 * q4 + 2], x[2], acc[r]);
+          acc[r] = fmaf(w[4 * q4 + 3], x[3], acc[r]);
+        }
+      }
+    }
+    for (; k < K; k += 4) {
       const float w0 = WT[(size_t)k * NOUT + o];
       const float w1 = WT[(size_t)(k + 1) * NOUT + o];
       const float w2 = WT[(size_t)(k + 2) * NOUT + o];
@@ -179,7 +196,9 @@ __device__ __forceinline__ void conv_chunk(const float *in, int Cin, int Tin, co
   float acc[TCH];
 #pragma unroll
   for (int i = 0; i < TCH; ++i) acc[i] = 0.f;
+#pragma unroll 4
   for (int ci = 0; ci < Cin; ++ci) {
+#pragma unroll 3
     for (int dk = 0; dk < ksz; ++dk) {
       const float w = W[((size_t)ci * ksz + dk) * Cout + co];
 #pragma unroll

@@ -482,7 +482,7 @@ __device__ __forceinline__ float block_sum128(float v, float *red, int tid) {
 template <int K>
 __device__ __forceinline__ void matvec(float (&acc)[TPW], const float *__restrict__ WT, int ldo, int col,
                                        const float *xin, int ldx) {
-#pragma unroll 4
+#pragma unroll 16
   for (int k = 0; k < K; ++k) {
     const float w = WT[(size_t)k * ldo + col];
 #pragma unroll
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(128) void k_token(const TokMeta *__restrict__ meta,
 #pragma unroll
       for (int t = 0; t < TPW; ++t) acc[t] = bvv;
       const int hd = tid >> 4;
-#pragma unroll 4
+#pragma unroll 16
       for (int k = 0; k < 128; ++k) {
         const float w = W.WvT[k * 128 + tid];
 #pragma unroll

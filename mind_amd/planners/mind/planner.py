@@ -146,19 +146,17 @@ class MINDPlanner:
 
     def resample_target_lane(self, lcl_smp):
         """1 m resampling of the target lane and its per-point info (planner.py:147-171)."""
-        lane = lcl_smp.target_lane
+        lane = np.asarray(lcl_smp.target_lane)
         infos = lcl_smp.target_lane_info
-        pts, idx = [], []
-        for i in range(len(lane) - 1):
-            seg = lane[i:i + 2]
-            n = int(np.ceil(np.linalg.norm(seg[0] - seg[1]) / 1.0))
-            for j in range(n):
-                pts.append(seg[0] + (j / n) * (seg[1] - seg[0]))
-                idx.append(i)
-        pts.append(lane[-1])
-        idx.append(len(lane) - 1)
-        idx = np.asarray(idx)
-        return np.array(pts), [np.array(np.asarray(info)[idx]) for info in infos]
+        seg = lane[1:] - lane[:-1]
+        n = np.ceil(np.linalg.norm(seg, axis=1) / 1.0).astype(int)
+        idx = np.repeat(np.arange(len(n)), n)
+        j = np.arange(len(idx)) - np.repeat(np.cumsum(n) - n, n)
+        alpha = (j / n[idx]).astype(lane.dtype if lane.dtype == np.float32 else np.float64)
+        pts = lane[idx] + alpha[:, None] * seg[idx]
+        pts = np.concatenate([pts, lane[-1:]], axis=0)
+        idx = np.concatenate([idx, [len(lane) - 1]])
+        return pts, [np.array(np.asarray(info)[idx]) for info in infos]
 
     def get_traj_tree(self, scen_tree, lcl_smp):
         o = self.traj_tree_opt
@@ -168,15 +166,24 @@ class MINDPlanner:
         return o.solve(us), o.debug
 
     def evaluate_traj_tree(self, lcl_smp, traj_tree):
-        """mean over nodes of .1 jerk^2 + 5 steer_rate^2 + .01 (v_tgt - v)^2 + .01 dist(target lane) (:180-198)."""
-        comfort = eff = tgt = 0.0
-        for node in traj_tree.nodes.values():
-            state, ctrl = node.data[0], node.data[1]
-            comfort += 0.1 * ctrl[0] ** 2
-            comfort += 5.0 * ctrl[1] ** 2
-            eff += 0.01 * (lcl_smp.target_velocity - state[2]) ** 2
-            tgt += 0.01 * self.get_dist_to_target_lane(lcl_smp, state)
-        return (comfort + eff + tgt) / len(traj_tree.nodes)
+        """mean over nodes of .1 jerk^2 + 5 steer_rate^2 + .01 (v_tgt - v)^2 + .01 dist(target lane) (:180-198),
+        all nodes at once."""
+        nodes = list(traj_tree.nodes.values())
+        st = np.array([n.data[0] for n in nodes], dtype=np.float64)
+        ct = np.array([n.data[1] for n in nodes], dtype=np.float64)
+        comfort = (0.1 * ct[:, 0] ** 2 + 5.0 * ct[:, 1] ** 2).sum()
+        eff = (0.01 * (lcl_smp.target_velocity - st[:, 2]) ** 2).sum()
+        lane = np.asarray(lcl_smp.target_lane)
+        s, e = lane[:-1], lane[1:]
+        d = e - s
+        l2 = (d ** 2).sum(-1)
+        assert np.all(l2 != 0.0), "Polyline segments should not have zero lengths."
+        rel = st[:, None, :2] - s[None]
+        t = np.clip((rel * d[None]).sum(-1) / l2[None], 0, 1)
+        near = s[None] + t[..., None] * d[None]
+        dist = np.sqrt(((st[:, None, :2] - near) ** 2).sum(-1)).min(axis=1)
+        tgt = (0.01 * dist).sum()
+        return (comfort + eff + tgt) / len(nodes)
 
     def get_dist_to_target_lane(self, lcl_smp, state):
         lane = lcl_smp.target_lane

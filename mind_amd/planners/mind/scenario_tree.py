@@ -253,62 +253,73 @@ class ScenarioTreeGenerator:
             vel = _np(res_aux_b[idx][0]).astype(F32, copy=False)    # [a,6,60,2]
             ang_loc = U.get_angle(vel)                               # from the un-rotated velocity
             order = np.argsort(-cls[0], kind="stable")
+            a_, K_, T_ = reg.shape[:3]
+            # all K modes at once: [a, K*T, 2] through the same per-agent / global rotations
+            pos_all, th = self._to_world(reg[..., :2].reshape(a_, K_ * T_, 2), ctrs, vecs, rot, orig)
+            vel_all, _ = self._to_world(vel.reshape(a_, K_ * T_, 2), ctrs, vecs, rot, orig, False)
+            pos_all, vel_all = pos_all.reshape(a_, K_, T_, 2), vel_all.reshape(a_, K_, T_, 2)
+            ang_all = (ang_loc + th[:, None, None] + theta_g).astype(F32)
+            cov_all = U.get_max_covariance(reg[..., 2:]) + sc["TRAJS_COV_HIST"][:, -1][:, None, None]
+            # topology signatures of all modes at once: cumulative winding of (exo - ego)
+            rel = pos_all[1:] - pos_all[0:1]
+            rel = rel / np.sqrt((rel * rel).sum(-1, keepdims=True))
+            phi = np.arctan2(rel[..., 1], rel[..., 0])                       # [a-1, K, T]
+            dphi = phi[..., 1:] - phi[..., :-1]
+            dphi = np.arctan2(np.sin(dphi), np.cos(dphi))
+            topo_all = dphi.sum(axis=-1, dtype=F32)                          # [a-1, K]
+            L = self.seq_len
+            n_hist = sc["TRAJS_POS_HIST"].shape[1]
+            last = L - 1 - n_hist                                            # index of the last kept predicted step
             cands = []
             for k in order:
-                prob = cls[0, k] * sc["SCEN_PROB"]
-                pos_w, th = self._to_world(reg[:, k, :, :2], ctrs, vecs, rot, orig)
-                vel_w, _ = self._to_world(vel[:, k], ctrs, vecs, rot, orig, False)
-                ang_w = (ang_loc[:, k] + th[:, None] + theta_g).astype(F32)
-                cov = U.get_max_covariance(reg[:, k, :, 2:]) + sc["TRAJS_COV_HIST"][:, -1][:, None]
-                L = self.seq_len
-                data = {
-                    "SCEN_PROB": F32(prob), "CUR_T": sc["CUR_T"], "END_T": sc["END_T"],
-                    "PARENT_ID": sc["SCEN_ID"], "SCEN_ID": "{}_{}_{}".format(self.branch_depth, idx, int(k)),
-                    "TRAJS_TYPE": sc["TRAJS_TYPE"], "TRAJS_TID": sc["TRAJS_TID"], "TRAJS_CAT": sc["TRAJS_CAT"],
-                    "TRAJS_POS_HIST": np.concatenate([sc["TRAJS_POS_HIST"], pos_w], axis=1)[:, :L],
-                    "TRAJS_COV_HIST": np.concatenate([sc["TRAJS_COV_HIST"], cov.astype(F32)], axis=1)[:, :L],
-                    "TRAJS_ANG_HIST": np.concatenate([sc["TRAJS_ANG_HIST"], ang_w], axis=1)[:, :L],
-                    "TRAJS_VEL_HIST": np.concatenate([sc["TRAJS_VEL_HIST"], vel_w], axis=1)[:, :L],
-                    "TGT_PTS": sc["TGT_PTS"],
-                }
-                if data["SCEN_PROB"] < F32(0.001):
+                prob = F32(cls[0, k] * sc["SCEN_PROB"])
+                if prob < F32(0.001):
                     continue
                 if self.target_lane is not None and self.ego_idx is not None:
-                    ego_mean = data["TRAJS_POS_HIST"][self.ego_idx][-1]
-                    ego_cov = data["TRAJS_COV_HIST"][self.ego_idx][-1]
+                    if last >= 0:
+                        ego_mean, ego_cov = pos_all[self.ego_idx, k, last], cov_all[self.ego_idx, k, last]
+                    else:
+                        ego_mean, ego_cov = sc["TRAJS_POS_HIST"][self.ego_idx][L - 1], sc["TRAJS_COV_HIST"][self.ego_idx][L - 1]
                     dis = U.get_distance_to_polyline(self.target_lane, ego_mean)
                     if (dis - ego_cov > self.config.tar_dist_thres).any():
                         continue
-                # topology signature: cumulative winding of (exo - ego) over the predicted steps
-                rel = pos_w[1:] - pos_w[0:1]
-                rel = rel / np.sqrt((rel * rel).sum(-1, keepdims=True))
-                phi = np.arctan2(rel[..., 1], rel[..., 0])
-                dphi = phi[:, 1:] - phi[:, :-1]
-                dphi = np.arctan2(np.sin(dphi), np.cos(dphi))
-                topo = dphi.sum(axis=1, dtype=F32) if len(dphi) else np.zeros(0, F32)
-                cands.append((data, topo))
+                cands.append((int(k), prob, topo_all[:, k] if len(topo_all) else np.zeros(0, F32)))
             # greedy merge of modes whose signatures differ by <= pi/6 for every exo agent
             thr = F32(np.pi / 6)
+            selected = []
             while cands:
-                sel, stopo = cands[0]
-                kept.append(sel)
+                sel = cands[0]
+                selected.append(sel)
                 rest = []
                 for cd in cands[1:]:
-                    diff = stopo - cd[1]
+                    diff = sel[2] - cd[2]
                     diff = np.arctan2(np.sin(diff), np.cos(diff))
                     if ((np.abs(diff) - thr) > 0).sum() > 0:
                         rest.append(cd)
                 cands = rest
+            # only the surviving modes get their histories extended (world frame, truncated to seq_len, Q8)
+            for k, prob, _ in selected:
+                kept.append({
+                    "SCEN_PROB": prob, "CUR_T": sc["CUR_T"], "END_T": sc["END_T"],
+                    "PARENT_ID": sc["SCEN_ID"], "SCEN_ID": "{}_{}_{}".format(self.branch_depth, idx, k),
+                    "TRAJS_TYPE": sc["TRAJS_TYPE"], "TRAJS_TID": sc["TRAJS_TID"], "TRAJS_CAT": sc["TRAJS_CAT"],
+                    "TRAJS_POS_HIST": np.concatenate([sc["TRAJS_POS_HIST"], pos_all[:, k]], axis=1)[:, :L],
+                    "TRAJS_COV_HIST": np.concatenate([sc["TRAJS_COV_HIST"], cov_all[:, k].astype(F32)], axis=1)[:, :L],
+                    "TRAJS_ANG_HIST": np.concatenate([sc["TRAJS_ANG_HIST"], ang_all[:, k]], axis=1)[:, :L],
+                    "TRAJS_VEL_HIST": np.concatenate([sc["TRAJS_VEL_HIST"], vel_all[:, k]], axis=1)[:, :L],
+                    "TGT_PTS": sc["TGT_PTS"],
+                })
         return kept
 
     def get_branch_time(self, d):
         cov = d["TRAJS_COV_HIST"]
         cur_t, end_t = d["CUR_T"], d["END_T"]
         compare_t = self.obs_len + cur_t + (1 if cur_t == 0 else 0)
-        for t in range(cur_t + 1, end_t):
-            if t % 2 == 1:
-                continue
-            if (cov[:, self.obs_len + t] / cov[:, compare_t] > 9).sum() > 0:
+        ts = np.arange(cur_t + 1 + (cur_t + 1) % 2, end_t, 2)          # even t in (cur_t, end_t)
+        if len(ts):
+            hit = (cov[:, self.obs_len + ts, 0] / cov[:, compare_t, 0][:, None] > 9).any(axis=0)
+            if hit.any():
+                t = int(ts[int(np.argmax(hit))])
                 d["END_T"] = t
                 return t
         return end_t

@@ -73,16 +73,18 @@ def get_agent_trajectories(agent_obs):
         if states[-1].observed is False:
             continue
         n = len(states)
-        obs = np.array([bool(s.observed) for s in states])
+        raw = np.array([(s.observed, s.position[0], s.position[1], s.heading, s.velocity[0], s.velocity[1])
+                        for s in states], dtype=float)
+        obs = raw[:, 0] != 0
         ts = np.arange(OBS_LEN - n, OBS_LEN)[obs]
         have = np.zeros(OBS_LEN, bool)
         have[ts] = True
         pos = np.zeros((OBS_LEN, 2))
         ang = np.zeros(OBS_LEN)
         vel = np.zeros((OBS_LEN, 2))
-        pos[ts] = np.array([list(s.position) for s in states], dtype=float).reshape(n, 2)[obs]
-        ang[ts] = np.array([s.heading for s in states], dtype=float)[obs]
-        vel[ts] = np.array([list(s.velocity) for s in states], dtype=float).reshape(n, 2)[obs]
+        pos[ts] = raw[obs, 1:3]
+        ang[ts] = raw[obs, 3]
+        vel[ts] = raw[obs, 4:6]
         pos, ang = _nn_fill(pos, have), _nn_fill(ang, have)
         slot = _TYPE_SLOT.get(_name(agent_obs[key].object_type), 6)
         typ = np.zeros((OBS_LEN, 7))
@@ -160,13 +162,17 @@ def _interp_along(cl, cum, s):
     return cl[k] + t[:, None] * (cl[k + 1] - cl[k])
 
 
-def lane_graph_from_map(static_map, orig, rot, seg_length=15.0, n_sub=10):
-    """Lane polylines of an AV2-style static map in the AV frame (orig [2], rot [2,2]):
-    node_ctrs/node_vecs [l,10,2] f32 (instance frame), lane_ctrs/lane_vecs [l,2] f32 (AV frame), flags i16."""
-    orig = np.asarray(orig)
-    rot = np.asarray(rot)
-    node_ctrs, node_vecs, lane_ctrs, lane_vecs = [], [], [], []
-    lane_type, intersect, cross_left, cross_right, left, right = [], [], [], [], [], []
+_LANE_CACHE = {}
+
+
+def _static_lane_pieces(static_map, seg_length, n_sub):
+    """World-frame resampled polyline points [l, n_sub+1, 2] (float64) and per-piece flags; they do not
+    depend on the ego pose, so they are computed once per map object."""
+    key = (id(static_map), seg_length, n_sub)
+    hit = _LANE_CACHE.get(key)
+    if hit is not None and hit[0] is static_map:
+        return hit[1]
+    pts_all, flags = [], []
     for lane_id, lane in static_map.vector_lane_segments.items():
         cl = np.asarray(static_map.get_lane_segment_centerline(lane_id))[:, 0:2].astype(float)
         assert cl.shape[0] == n_sub, f"[Error] Wrong num of points in lane - {lane_id}:{cl.shape[0]}"
@@ -174,47 +180,54 @@ def lane_graph_from_map(static_map, orig, rot, seg_length=15.0, n_sub=10):
         length = cum[-1]
         num_segs = max(int(np.floor(length / seg_length)), 1)
         ds = length / num_segs
-        lt = np.zeros(3)
-        lt[{"VEHICLE": 0, "BIKE": 1, "BUS": 2}[_name(lane.lane_type)]] = 1
+        lt = {"VEHICLE": 0, "BIKE": 1, "BUS": 2}[_name(lane.lane_type)]
 
         def mark(m):
-            v = np.zeros(3)
             n = _name(m)
-            v[0 if n in _CROSSABLE else (1 if n in _NOT_CROSSABLE else 2)] = 1
-            return v
+            return 0 if n in _CROSSABLE else (1 if n in _NOT_CROSSABLE else 2)
 
-        ml, mr = mark(lane.left_mark_type), mark(lane.right_mark_type)
+        fl = (lt, 1 if lane.is_intersection else 0, mark(lane.left_mark_type), mark(lane.right_mark_type),
+              0 if lane.left_neighbor_id is None else 1, 0 if lane.right_neighbor_id is None else 1)
         for i in range(num_segs):
-            pts = _interp_along(cl, cum, np.linspace(i * ds, (i + 1) * ds, n_sub + 1))
-            ctrln = (pts - orig).dot(rot)
-            anch_pos = np.mean(ctrln, axis=0)
-            dv = ctrln[-1] - ctrln[0]
-            anch_vec = dv / np.linalg.norm(dv)
-            anch_rot = np.array([[anch_vec[0], -anch_vec[1]], [anch_vec[1], anch_vec[0]]])
-            lane_ctrs.append(anch_pos)
-            lane_vecs.append(anch_vec)
-            ctrln = (ctrln - anch_pos).dot(anch_rot)
-            node_ctrs.append(np.asarray((ctrln[:-1] + ctrln[1:]) / 2.0, F32))
-            node_vecs.append(np.asarray(ctrln[1:] - ctrln[:-1], F32))
-            lane_type.append(np.repeat(lt[None], n_sub, 0))
-            intersect.append(np.full(n_sub, 1.0 if lane.is_intersection else 0.0, F32))
-            cross_left.append(np.repeat(ml[None], n_sub, 0))
-            cross_right.append(np.repeat(mr[None], n_sub, 0))
-            left.append(np.full(n_sub, 0.0 if lane.left_neighbor_id is None else 1.0, F32))
-            right.append(np.full(n_sub, 0.0 if lane.right_neighbor_id is None else 1.0, F32))
+            pts_all.append(_interp_along(cl, cum, np.linspace(i * ds, (i + 1) * ds, n_sub + 1)))
+            flags.append(fl)
+    pts_all = np.stack(pts_all)
+    flags = np.asarray(flags)
+    L = len(flags)
+    one_hot = lambda idx: np.repeat(np.eye(3, dtype=np.int16)[idx][:, None, :], n_sub, 1)
+    static = dict(
+        pts=pts_all,
+        lane_type=one_hot(flags[:, 0]), cross_left=one_hot(flags[:, 2]), cross_right=one_hot(flags[:, 3]),
+        intersect=np.repeat(flags[:, 1:2], n_sub, 1).astype(np.int16),
+        left=np.repeat(flags[:, 4:5], n_sub, 1).astype(np.int16), right=np.repeat(flags[:, 5:6], n_sub, 1).astype(np.int16),
+        num_lanes=L)
+    _LANE_CACHE.clear()
+    _LANE_CACHE[key] = (static_map, static)
+    return static
+
+
+def lane_graph_from_map(static_map, orig, rot, seg_length=15.0, n_sub=10):
+    """Lane polylines of an AV2-style static map in the AV frame (orig [2], rot [2,2]):
+    node_ctrs/node_vecs [l,10,2] f32 (instance frame), lane_ctrs/lane_vecs [l,2] f32 (AV frame), flags i16."""
+    st = _static_lane_pieces(static_map, seg_length, n_sub)
+    orig = np.asarray(orig)
+    rot = np.asarray(rot)
+    ctrln = np.matmul(st["pts"] - orig, rot)                          # [l,11,2] float64, AV frame
+    anch_pos = ctrln.mean(axis=1)
+    dv = ctrln[:, -1] - ctrln[:, 0]
+    anch_vec = dv / np.linalg.norm(dv, axis=1, keepdims=True)
+    anch_rot = np.stack([np.stack([anch_vec[:, 0], -anch_vec[:, 1]], -1),
+                         np.stack([anch_vec[:, 1], anch_vec[:, 0]], -1)], -2)   # [l,2,2]
+    inst = np.matmul(ctrln - anch_pos[:, None, :], anch_rot)
     g = dict()
-    g["node_ctrs"] = np.stack(node_ctrs).astype(F32)
-    g["node_vecs"] = np.stack(node_vecs).astype(F32)
-    g["lane_ctrs"] = np.array(lane_ctrs).astype(F32)
-    g["lane_vecs"] = np.array(lane_vecs).astype(F32)
-    g["lane_type"] = np.stack(lane_type).astype(np.int16)
-    g["intersect"] = np.stack(intersect).astype(np.int16)
-    g["cross_left"] = np.stack(cross_left).astype(np.int16)
-    g["cross_right"] = np.stack(cross_right).astype(np.int16)
-    g["left"] = np.stack(left).astype(np.int16)
-    g["right"] = np.stack(right).astype(np.int16)
+    g["node_ctrs"] = ((inst[:, :-1] + inst[:, 1:]) / 2.0).astype(F32)
+    g["node_vecs"] = (inst[:, 1:] - inst[:, :-1]).astype(F32)
+    g["lane_ctrs"] = anch_pos.astype(F32)
+    g["lane_vecs"] = anch_vec.astype(F32)
+    for k in ("lane_type", "intersect", "cross_left", "cross_right", "left", "right"):
+        g[k] = st[k]
     g["num_nodes"] = g["node_ctrs"].shape[0] * g["node_ctrs"].shape[1]
-    g["num_lanes"] = g["lane_ctrs"].shape[0]
+    g["num_lanes"] = st["num_lanes"]
     return g
 
 
