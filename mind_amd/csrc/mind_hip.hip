@@ -503,14 +503,15 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
     if (a <= 0 || l < 0) return fail(c, MIND_EINVAL, "scene %d has %d agents, %d lanes", b, a, l);
     total_cols += a + l + 1;
   }
-  const int target_jobs = c->n_cu * 4 * 2;
   int slot = 0;
   double pairs_full = 0, pairs_l5 = 0;
   for (int b = 0; b < Bn; ++b) {
     const int a = in->actor_off[b + 1] - in->actor_off[b], l = in->lane_off[b + 1] - in->lane_off[b];
     const int N = a + l + 1;
     const int tiles = (N + 15) / 16;
-    int ns = (int)((target_jobs + total_cols - 1) / total_cols);
+    // split count depends on the scene's own size only, so a scene's result is bit-identical whatever
+    // batch it is collated into (needed for identical AIME node sets when rounds are sharded over GPUs)
+    int ns = (1024 + N - 1) / N;
     ns = ns < 1 ? 1 : ns;
     ns = ns > 8 ? 8 : ns;
     ns = ns > tiles ? tiles : ns;

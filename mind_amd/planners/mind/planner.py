@@ -86,6 +86,15 @@ class MINDPlanner:
         self.traj_tree_opt = TrajectoryTreeOptimizer(cfg, self.network.rt)
 
     # ------------------------------------------------------------------------------------------
+    def enable_sharding(self, group=None):
+        """Shard every AIME round's scenes and the contingency solves over the ranks of a
+        torch.distributed process group (one process per GPU)."""
+        from ...parallel import Shard
+        sh = Shard(group)
+        self.scen_tree_gen.shard = sh
+        self.traj_tree_opt.shard = sh
+        return sh
+
     def to_object_state(self, agent):
         s = agent.state
         return ObjectState(True, agent.timestep, (s[0], s[1]), s[3], (s[2] * np.cos(s[3]), s[2] * np.sin(s[3])))

@@ -53,6 +53,7 @@ class ScenarioTreeGenerator:
         self.ego_idx = 0
         self.branch_depth = 0
         self.n_expanded = 0           # scenes pushed through the predictor (metric: nodes expanded)
+        self.shard = None             # mind_amd.parallel.Shard: block-distribute each round's scenes over ranks
 
     # ------------------------------------------------------------------------------------------
     def reset(self):
@@ -78,8 +79,7 @@ class ScenarioTreeGenerator:
         branch_nodes = self.get_branch_set()
         while branch_nodes:
             batch = [n.data.obs_data for n in branch_nodes]
-            pred = self.predict_scenes(batch)
-            self.create_nodes(self.prune_merge(batch, pred))
+            self.create_nodes(self.expand(batch))
             self.decide_branch()
             branch_nodes = self.get_branch_set()
         assert len(self.get_end_set()) > 0, "No end node found in the scenario tree."
@@ -88,9 +88,20 @@ class ScenarioTreeGenerator:
     def init_scenario_tree(self, root):
         self.prepare_root_data(root)
         self.tree.add_node(Node("root", None, ScenarioData(None, root, branch_flag=True)))
-        pred = self.predict_scenes([root])
-        self.create_nodes(self.prune_merge([root], pred))
+        self.create_nodes(self.expand([root]))
         self.decide_branch()
+
+    def expand(self, batch):
+        """One AIME round: predict + prune/merge every scene of the branch set.  With a Shard the scenes
+        are block-distributed over the ranks and the kept children all-gathered (the round's only
+        exchange step); every rank ends up with the same list in batch order."""
+        if self.shard is None or self.shard.world == 1:
+            return self.prune_merge(batch, self.predict_scenes(batch))
+        from ...parallel import gather_blocks
+        lo, hi = self.shard.block(len(batch))
+        mine = batch[lo:hi]
+        kept = self.prune_merge(mine, self.predict_scenes(mine), idx_offset=lo) if mine else []
+        return gather_blocks(self.shard, kept)
 
     # ------------------------------------------------------------------------------------------
     def collate(self, scenes):
@@ -241,16 +252,17 @@ class ScenarioTreeGenerator:
         root["END_T"] = self.pred_len
         return root
 
-    def prune_merge(self, scenes, out):
+    def prune_merge(self, scenes, out, idx_offset=0):
         res_cls_b, res_reg_b, res_aux_b = out
         kept = []
-        for idx, sc in enumerate(scenes):
+        for lidx, sc in enumerate(scenes):
+            idx = lidx + idx_offset      # position in the round's full batch (part of the node id)
             rot, orig = sc["ROT"], sc["ORIG"]
             ctrs, vecs = sc["TRAJS_CTRS"], sc["TRAJS_VECS"]
             theta_g = np.arctan2(rot[1, 0], rot[0, 0])
-            reg = _np(res_reg_b[idx]).astype(F32, copy=False)       # [a,6,60,5]
-            cls = _np(res_cls_b[idx]).astype(F32, copy=False)       # [1,6]
-            vel = _np(res_aux_b[idx][0]).astype(F32, copy=False)    # [a,6,60,2]
+            reg = _np(res_reg_b[lidx]).astype(F32, copy=False)      # [a,6,60,5]
+            cls = _np(res_cls_b[lidx]).astype(F32, copy=False)      # [1,6]
+            vel = _np(res_aux_b[lidx][0]).astype(F32, copy=False)   # [a,6,60,2]
             ang_loc = U.get_angle(vel)                               # from the un-rotated velocity
             order = np.argsort(-cls[0], kind="stable")
             a_, K_, T_ = reg.shape[:3]

@@ -71,6 +71,8 @@ class TrajectoryTreeOptimizer:
     def __init__(self, config=None, runtime=None):
         self.config = config
         self.rt = runtime
+        self.shard = None       # mind_amd.parallel.Shard: deal the scenario trees round-robin over ranks
+        self.solver = None      # injectable for tests: solver(cfg, flats, x0, lane, tv, use_exo, us_init) -> (xs, us, st)
         self.cost_tree = None
         self.debug = None
         self._job = None
@@ -115,8 +117,16 @@ class TrajectoryTreeOptimizer:
         flats = [flatten_scenario_tree(t) for t in scen_trees]
         x0 = self._get_init_state(init_state, init_ctrl)
         lane = np.asarray(target_lane, np.float64)
-        rt = self._runtime()
-        _, us_w, st_w = rt.ilqr_solve(ilqr_cfg_from(self.config, "w_opt_cfg"), flats, x0, lane, target_vel, 0)
-        xs, us, st = rt.ilqr_solve(ilqr_cfg_from(self.config, "opt_cfg"), flats, x0, lane, target_vel, 1, us_w)
+        solve = self.solver if self.solver is not None else self._runtime().ilqr_solve
+        mine = list(range(len(flats))) if self.shard is None else self.shard.round_robin(len(flats))
+        xs, us, st_w, st = [], [], [], []
+        if mine:
+            sub = [flats[i] for i in mine]
+            _, us_w, st_w = solve(ilqr_cfg_from(self.config, "w_opt_cfg"), sub, x0, lane, target_vel, 0, None)
+            xs, us, st = solve(ilqr_cfg_from(self.config, "opt_cfg"), sub, x0, lane, target_vel, 1, us_w)
+        if self.shard is not None and self.shard.world > 1:
+            from ...parallel import gather_round_robin
+            res = gather_round_robin(self.shard, len(flats), list(zip(xs, us)))
+            xs, us = [r[0] for r in res], [r[1] for r in res]
         self.debug = dict(warm=st_w, full=st)
         return [to_traj_tree(f, x0, x, u, self.config.action_size) for f, x, u in zip(flats, xs, us)]
