@@ -349,8 +349,8 @@ __global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ job
       for (int hd = 0; hd < 8; ++hd) {
         const float mx = red_max16(sc[hd]);
         const float m_new = fmaxf(m_run[hd], mx);
-        const float scale = expf(m_run[hd] - m_new);
-        pr[hd] = valid ? expf(sc[hd] - m_new) : 0.f;
+        const float scale = __expf(m_run[hd] - m_new);
+        pr[hd] = valid ? __expf(sc[hd] - m_new) : 0.f;
         l_part[hd] = l_part[hd] * scale + pr[hd];
         mbar[0][hd] *= scale;
         mbar[1][hd] *= scale;
