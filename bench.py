@@ -156,6 +156,15 @@ def main():
     rt.set_profiling(False)
     total_pair_s = sum(pair_ms) * 1e-3
     achieved = F_MIN_N2 * pair_n2 / total_pair_s if total_pair_s > 0 else 0.0
+    # HBM traffic of k_pair from the committed PMC passes of this same command (FETCH_SIZE, WRITE_SIZE in
+    # separate rocprofv3 runs, gfx950 x2 correction on the fetch side): profiles/r01_pmc_k_pair.json
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_k_pair.json")
+    if args.workload == "demo1" and os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path))["k_pair_per_launch"]["hbm_bytes"]
+        except Exception:
+            traffic = None
     plans = args.steps * (1 if args.shard else world)
     value = 5.0 * plans / dt
     a = len(pl.agent_obs)
@@ -173,7 +182,7 @@ def main():
                    "agents": a, "lane_polylines": l, "expansions_per_plan": expansions // args.steps,
                    "scenario_trees_per_plan": pl.timing["n_scen_trees"], "parallelism": f"{world} independent scenes (one per GPU)"},
         "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F32_MFMA, "traffic": None, "kernel": "k_pair (RelaFusionLayer pair kernel)",
+                     "frac": achieved / PEAK_F32_MFMA, "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_k_pair.json)", "kernel": "k_pair (RelaFusionLayer pair kernel)",
                      "launches_profiled": pair_launch, "avg_launch_ms": (sum(pair_ms) / pair_launch) if pair_launch else None,
                      "algorithmic_flops_per_launch": (F_MIN_N2 * pair_n2 / pair_launch) if pair_launch else None,
                      "note": "algorithmic FLOPs = SURVEY 8(d) F_min N^2 term (754944*N^2 per expansion over 6 launches); "
