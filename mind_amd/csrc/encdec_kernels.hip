@@ -35,17 +35,69 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 }
 
 // out[r][o] = b[o] + sum_k in[r][k] WT[k][o],  r < R (compile time), o < NOUT; K % 4 == 0.
-// `in` rows must be 16-byte aligned (ldi % 4 == 0).  Caller syncs before/after.
+// `in` rows must be 16-byte aligned (ldi % 4 == 0).  These layers are latency-bound on streaming the
+// weights from L2, so when NOUT < blockDim the K range is split over KP thread groups (partials
+// reduced through the LDS scratch `part`, >= part_floats floats) and every thread keeps 16 weight
+// loads in flight.  Contains __syncthreads(): call from uniform control flow; caller syncs after.
 template <int R>
 __device__ __forceinline__ void dense(const float *in, int ldi, int K, const float *__restrict__ WT,
-                                      const float *__restrict__ b, int NOUT, float *out, int ldo) {
-  for (int o = threadIdx.x; o < NOUT; o += NT) {
-    float acc[R];
-    const float bv = b ? b[o] : 0.f;
+                                      const float *__restrict__ b, int NOUT, float *out, int ldo,
+                                      float *part = nullptr, int part_floats = 0) {
+  const int nthr = blockDim.x;
+  int KP = 1;
+  if (part && NOUT < nthr) {
+    KP = nthr / NOUT;
+    while (KP > 1 && (KP * R * NOUT > part_floats || (K / 4) < KP)) KP >>= 1;
+    // power of two
+    int p2 = 1;
+    while (p2 * 2 <= KP) p2 *= 2;
+    KP = p2;
+  }
+  if (KP == 1) {
+    for (int o = threadIdx.x; o < NOUT; o += nthr) {
+      float acc[R];
+      const float bv = b ? b[o] : 0.f;
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = bv;
-    int k = 0;
-    for (; k + 16 <= K; k += 16) {   // 16 weight loads in flight per thread (latency-bound on L2)
+      for (int r = 0; r < R; ++r) acc[r] = bv;
+      int k = 0;
+      for (; k + 16 <= K; k += 16) {
+        float w[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w[q] = WT[(size_t)(k + q) * NOUT + o];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 x = *(const f32x4 *)(in + r * ldi + k + 4 * q4);
+            acc[r] = fmaf(w[4 * q4 + 0], x[0], acc[r]);
+            acc[r] = fmaf(w[4 * q4 + 1], x[1], acc[r]);
+            acc[r] = fmaf(w[4 * q4 + 2], x[2], acc[r]);
+            acc[r] = fmaf(w[4 * q4 + 3], x[3], acc[r]);
+          }
+        }
+      }
+      for (; k < K; k += 4) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const f32x4 x = *(const f32x4 *)(in + r * ldi + k);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[r] = fmaf(WT[(size_t)(k + q) * NOUT + o], x[q], acc[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) out[r * ldo + o] = acc[r];
+    }
+    return;
+  }
+  const int kp = threadIdx.x / NOUT, o = threadIdx.x % NOUT;
+  const int Kc = ((K / 4 + KP - 1) / KP) * 4;
+  if (kp < KP) {
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    const int k0 = kp * Kc, k1 = min(K, k0 + Kc);
+    int k = k0;
+    for (; k + 16 <= k1; k += 16) {
       float w[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) w[q] = WT[(size_t)(k + q) * NOUT + o];
@@ -61,30 +113,31 @@ __device__ __forceinline__ void dense(const float *in, int ldi, int K, const flo
         }
       }
     }
-    for (; k < K; k += 4) {
-      const float w0 = WT[(size_t)k * NOUT + o];
-      const float w1 = WT[(size_t)(k + 1) * NOUT + o];
-      const float w2 = WT[(size_t)(k + 2) * NOUT + o];
-      const float w3 = WT[(size_t)(k + 3) * NOUT + o];
+    for (; k < k1; k += 4) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const f32x4 x = *(const f32x4 *)(in + r * ldi + k);
-        acc[r] = fmaf(w0, x[0], acc[r]);
-        acc[r] = fmaf(w1, x[1], acc[r]);
-        acc[r] = fmaf(w2, x[2], acc[r]);
-        acc[r] = fmaf(w3, x[3], acc[r]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[r] = fmaf(WT[(size_t)(k + q) * NOUT + o], x[q], acc[r]);
       }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) out[r * ldo + o] = acc[r];
+    for (int r = 0; r < R; ++r) part[(kp * R + r) * NOUT + o] = acc[r];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < R * NOUT; i += nthr) {
+    const int r = i / NOUT, oo = i % NOUT;
+    float v = b ? b[oo] : 0.f;
+    for (int q = 0; q < KP; ++q) v += part[(q * R + r) * NOUT + oo];
+    out[r * ldo + oo] = v;
   }
 }
 
 // LayerNorm (+ReLU) over `n` features of each of R rows, in place; one wave per row (4 waves).
 __device__ __forceinline__ void ln_rows(float *buf, int ld, int R, int n, const float *__restrict__ g,
                                         const float *__restrict__ be, bool relu) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int r = wave; r < R; r += 4) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int r = wave; r < R; r += nw) {
     float s = 0.f;
     for (int k = lane; k < n; k += 64) s += buf[r * ld + k];
     const float mean = wave_sum(s) / (float)n;
@@ -115,55 +168,58 @@ struct LaneW {
 #define PL 2
 #define LR (PL * 10)
 
-__global__ __launch_bounds__(NT) void k_lane_net(const float *__restrict__ feats, int n_poly,
+#define DT 1024   // threads of the latency-bound dense kernels (K-split over thread groups)
+__global__ __launch_bounds__(DT) void k_lane_net(const float *__restrict__ feats, int n_poly,
                                                  float *__restrict__ out, LaneW W) {
   __shared__ __attribute__((aligned(16))) float xin[LR][16];
   __shared__ __attribute__((aligned(16))) float x[LR][128];
   __shared__ __attribute__((aligned(16))) float hcat[LR][256];
   __shared__ __attribute__((aligned(16))) float t1[LR][128];
+  __shared__ __attribute__((aligned(16))) float part[2 * LR * 128];
+  const int PF = 2 * LR * 128;
   const int tid = threadIdx.x;
   const int p0 = blockIdx.x * PL;
-  for (int i = tid; i < LR * 16; i += NT) {
+  for (int i = tid; i < LR * 16; i += blockDim.x) {
     const int r = i / 16, c = i % 16;
     const int pl = p0 + r / 10;
     xin[r][c] = pl < n_poly ? feats[((size_t)pl * 10 + r % 10) * 16 + c] : 0.f;
   }
   __syncthreads();
-  dense<LR>(&xin[0][0], 16, 16, W.pW, W.pb, 128, &x[0][0], 128);
+  dense<LR>(&xin[0][0], 16, 16, W.pW, W.pb, 128, &x[0][0], 128, part, PF);
   __syncthreads();
   ln_rows(&x[0][0], 128, LR, 128, W.pg, W.pbe, true);
   __syncthreads();
   for (int blk = 0; blk < 2; ++blk) {
-    dense<LR>(&x[0][0], 128, 128, W.f10W[blk], W.f10b[blk], 128, &t1[0][0], 128);
+    dense<LR>(&x[0][0], 128, 128, W.f10W[blk], W.f10b[blk], 128, &t1[0][0], 128, part, PF);
     __syncthreads();
     ln_rows(&t1[0][0], 128, LR, 128, W.f10g[blk], W.f10be[blk], true);
     __syncthreads();
-    dense<LR>(&t1[0][0], 128, 128, W.f13W[blk], W.f13b[blk], 128, &hcat[0][0], 256);
+    dense<LR>(&t1[0][0], 128, 128, W.f13W[blk], W.f13b[blk], 128, &hcat[0][0], 256, part, PF);
     __syncthreads();
     ln_rows(&hcat[0][0], 256, LR, 128, W.f13g[blk], W.f13be[blk], true);
     __syncthreads();
     // max-pool over the 10 points, broadcast into the second half of the concat
-    for (int i = tid; i < PL * 128; i += NT) {
+    for (int i = tid; i < PL * 128; i += blockDim.x) {
       const int pl = i / 128, c = i % 128;
       float m = hcat[pl * 10][c];
       for (int q = 1; q < 10; ++q) m = fmaxf(m, hcat[pl * 10 + q][c]);
       for (int q = 0; q < 10; ++q) hcat[pl * 10 + q][128 + c] = m;
     }
     __syncthreads();
-    dense<LR>(&hcat[0][0], 256, 256, W.f20W[blk], W.f20b[blk], 128, &t1[0][0], 128);
+    dense<LR>(&hcat[0][0], 256, 256, W.f20W[blk], W.f20b[blk], 128, &t1[0][0], 128, part, PF);
     __syncthreads();
     ln_rows(&t1[0][0], 128, LR, 128, W.f20g[blk], W.f20be[blk], true);
     __syncthreads();
-    dense<LR>(&t1[0][0], 128, 128, W.f23W[blk], W.f23b[blk], 128, &hcat[0][0], 256);
+    dense<LR>(&t1[0][0], 128, 128, W.f23W[blk], W.f23b[blk], 128, &hcat[0][0], 256, part, PF);
     __syncthreads();
     ln_rows(&hcat[0][0], 256, LR, 128, W.f23g[blk], W.f23be[blk], true);
     __syncthreads();
-    for (int i = tid; i < LR * 128; i += NT) x[i / 128][i % 128] += hcat[i / 128][i % 128];
+    for (int i = tid; i < LR * 128; i += blockDim.x) x[i / 128][i % 128] += hcat[i / 128][i % 128];
     __syncthreads();
     ln_rows(&x[0][0], 128, LR, 128, W.ng[blk], W.nbe[blk], false);
     __syncthreads();
   }
-  for (int i = tid; i < PL * 128; i += NT) {
+  for (int i = tid; i < PL * 128; i += blockDim.x) {
     const int pl = i / 128, c = i % 128;
     if (p0 + pl < n_poly) {
       float m = x[pl * 10][c];
@@ -183,51 +239,80 @@ struct ActorW {
   const float *latW[4], *latG[4], *latB[4];
 };
 
-// out[co][t] = sum_ci sum_dk W[ci][dk][co] * in[ci][t*stride + dk - pad], raw (no norm)
+#define AT 1024   // threads of k_actor_net
+
+// out[co][t] = sum_ci sum_dk W[ci][dk][co] * in[ci][t*stride + dk - pad], raw (no norm).
+// thread = (co, time chunk of TCH outputs, K part): the Cin range is split over KP thread groups and the
+// partials are reduced through `part` (LDS, KP*Cout*Tout floats) -- the conv is latency-bound on the
+// weight stream, not on FLOPs.  Contains __syncthreads().
 template <int TCH>
 __device__ __forceinline__ void conv_chunk(const float *in, int Cin, int Tin, const float *__restrict__ W,
-                                           int Cout, int Tout, int stride, int ksz, float *out) {
+                                           int Cout, int Tout, int stride, int ksz, float *out, float *part, int KP) {
   const int tid = threadIdx.x;
-  const int co = tid % Cout;
-  const int chunk = tid / Cout;
-  const int t0 = chunk * TCH;
+  const int nch = (Tout + TCH - 1) / TCH;
+  const int groups = Cout * nch;
+  const int kp = tid / groups, g = tid % groups;
+  const int co = g % Cout, t0 = (g / Cout) * TCH;
   const int pad = (ksz - 1) / 2;
-  if (t0 < Tout) {
-  float acc[TCH];
+  const int cpk = (Cin + KP - 1) / KP;
+  if (kp < KP) {
+    float acc[TCH];
 #pragma unroll
-  for (int i = 0; i < TCH; ++i) acc[i] = 0.f;
+    for (int i = 0; i < TCH; ++i) acc[i] = 0.f;
+    const int c0 = kp * cpk, c1 = min(Cin, c0 + cpk);
 #pragma unroll 4
-  for (int ci = 0; ci < Cin; ++ci) {
+    for (int ci = c0; ci < c1; ++ci) {
 #pragma unroll 3
-    for (int dk = 0; dk < ksz; ++dk) {
-      const float w = W[((size_t)ci * ksz + dk) * Cout + co];
+      for (int dk = 0; dk < ksz; ++dk) {
+        const float w = W[((size_t)ci * ksz + dk) * Cout + co];
 #pragma unroll
-      for (int i = 0; i < TCH; ++i) {
-        const int ti = (t0 + i) * stride + dk - pad;
-        const float xv = (ti >= 0 && ti < Tin) ? in[ci * Tin + ti] : 0.f;
-        acc[i] = fmaf(w, xv, acc[i]);
+        for (int i = 0; i < TCH; ++i) {
+          const int ti = (t0 + i) * stride + dk - pad;
+          const float xv = (ti >= 0 && ti < Tin) ? in[ci * Tin + ti] : 0.f;
+          acc[i] = fmaf(w, xv, acc[i]);
+        }
       }
     }
-  }
+    float *dst = KP > 1 ? part + (size_t)kp * Cout * Tout : out;
 #pragma unroll
-  for (int i = 0; i < TCH; ++i)
-    if (t0 + i < Tout) out[co * Tout + t0 + i] = acc[i];
+    for (int i = 0; i < TCH; ++i)
+      if (t0 + i < Tout) dst[co * Tout + t0 + i] = acc[i];
+  }
+  if (KP > 1) {
+    __syncthreads();
+    for (int i = tid; i < Cout * Tout; i += AT) {
+      float v = part[i];
+      for (int q = 1; q < KP; ++q) v += part[(size_t)q * Cout * Tout + i];
+      out[i] = v;
+    }
   }
 }
 
+// chooses the time chunk so that (Cout x chunks) <= AT thread groups, then the K split that fits `part`
 __device__ __forceinline__ void conv(const float *in, int Cin, int Tin, const float *W, int Cout, int Tout,
-                                     int stride, int ksz, float *out) {
-  const int per = (Cout * Tout + NT - 1) / NT;  // outputs per thread
-  const int chunks = NT / Cout > 0 ? NT / Cout : 1;
-  int tch = (Tout + chunks - 1) / chunks;
-  (void)per;
-  if (Cout > NT) {  // not used (max Cout = 256)
-    return;
-  }
-  if (tch <= 3) conv_chunk<3>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out);
-  else if (tch <= 6) conv_chunk<6>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out);
-  else if (tch <= 12) conv_chunk<12>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out);
-  else conv_chunk<24>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out);
+                                     int stride, int ksz, float *out, float *part, int part_floats) {
+  int tch = 3;
+  while (Cout * ((Tout + tch - 1) / tch) > AT) tch *= 2;      // 3, 6, 12, 24
+  const int groups = Cout * ((Tout + tch - 1) / tch);
+  int KP = AT / groups;
+  while (KP > 1 && (KP * Cout * Tout > part_floats || KP > Cin)) KP >>= 1;
+  if (KP < 1) KP = 1;
+  if (tch <= 3) conv_chunk<3>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out, part, KP);
+  else if (tch <= 6) conv_chunk<6>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out, part, KP);
+  else if (tch <= 12) conv_chunk<12>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out, part, KP);
+  else conv_chunk<24>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out, part, KP);
+}
+
+// sum over the 16 waves of the actor kernel
+__device__ __forceinline__ float block_sum_a(float v, float *red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < AT / 64; ++w) s += red[w];
+  return s;
 }
 
 // GroupNorm(1 group) over C x T, per-channel affine, optional residual add and ReLU, in place.
@@ -235,12 +320,12 @@ __device__ __forceinline__ void gn(float *buf, int C, int T, const float *__rest
                                    const float *__restrict__ b, const float *resid, bool relu, float *red) {
   const int n = C * T;
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += NT) s += buf[i];
-  const float mean = block_sum(s, red) / (float)n;
+  for (int i = threadIdx.x; i < n; i += AT) s += buf[i];
+  const float mean = block_sum_a(s, red) / (float)n;
   float v = 0.f;
-  for (int i = threadIdx.x; i < n; i += NT) { const float d = buf[i] - mean; v = fmaf(d, d, v); }
-  const float rstd = 1.0f / sqrtf(block_sum(v, red) / (float)n + 1e-5f);
-  for (int i = threadIdx.x; i < n; i += NT) {
+  for (int i = threadIdx.x; i < n; i += AT) { const float d = buf[i] - mean; v = fmaf(d, d, v); }
+  const float rstd = 1.0f / sqrtf(block_sum_a(v, red) / (float)n + 1e-5f);
+  for (int i = threadIdx.x; i < n; i += AT) {
     const int c = i / T;
     float y = (buf[i] - mean) * rstd * g[c] + b[c];
     if (resid) y += resid[i];
@@ -252,16 +337,16 @@ __device__ __forceinline__ void gn(float *buf, int C, int T, const float *__rest
 
 // Res1d (layers.py:175-188): out written to `out`; uses scratch t1, t2 (each >= Cout*Tout floats)
 __device__ __forceinline__ void res1d(const float *in, int Cin, int Tin, const ResW &w, int Cout, int stride,
-                                      float *out, float *t1, float *t2, float *red) {
+                                      float *out, float *t1, float *t2, float *red, float *part, int pf) {
   const int Tout = Tin / stride;
-  conv(in, Cin, Tin, w.c1, Cout, Tout, stride, 3, t1);
+  conv(in, Cin, Tin, w.c1, Cout, Tout, stride, 3, t1, part, pf);
   __syncthreads();
   gn(t1, Cout, Tout, w.g1, w.b1, nullptr, true, red);
-  conv(t1, Cout, Tout, w.c2, Cout, Tout, 1, 3, out);
+  conv(t1, Cout, Tout, w.c2, Cout, Tout, 1, 3, out, part, pf);
   __syncthreads();
   const float *resid = in;
   if (w.ds) {
-    conv(in, Cin, Tin, w.ds, Cout, Tout, stride, 1, t2);
+    conv(in, Cin, Tin, w.ds, Cout, Tout, stride, 1, t2, part, pf);
     __syncthreads();
     gn(t2, Cout, Tout, w.gd, w.bd, nullptr, false, red);
     resid = t2;
@@ -271,8 +356,9 @@ __device__ __forceinline__ void res1d(const float *in, int Cin, int Tin, const R
 
 // LDS carve (floats): xin 672 | o0 1536 | o1 1536 | o2 1536 | o3 1536 | ta 1536 | tb 1536 | tc 1536
 //                     | fa 6144 | fb 6144 ; the final Res1d output reuses the (dead) o0..tc region.
-#define ACT_LDS_FLOATS (672 + 7 * 1536 + 2 * 6144 + 8)
-__global__ __launch_bounds__(NT) void k_actor_net(const float *__restrict__ actors, int n_actors,
+#define ACT_PART 6144
+#define ACT_LDS_FLOATS (672 + 7 * 1536 + 2 * 6144 + 16 + ACT_PART)
+__global__ __launch_bounds__(AT) void k_actor_net(const float *__restrict__ actors, int n_actors,
                                                   float *__restrict__ out, ActorW W) {
   extern __shared__ float sm[];
   float *xin = sm;
@@ -280,22 +366,24 @@ __global__ __launch_bounds__(NT) void k_actor_net(const float *__restrict__ acto
   float *ta = o3 + 1536, *tb = ta + 1536, *tc = tb + 1536;
   float *fa = tc + 1536, *fb = fa + 6144;
   float *red = fb + 6144;
+  float *part = red + 16;
+  const int pf = ACT_PART;
   float *fo = o0;  // 10752 floats available, needs 6144
   const int tid = threadIdx.x;
   const int a = blockIdx.x;
   if (a >= n_actors) return;
-  for (int i = tid; i < 14 * 48; i += NT) xin[i] = actors[(size_t)a * 14 * 48 + i];
+  for (int i = tid; i < 14 * 48; i += AT) xin[i] = actors[(size_t)a * 14 * 48 + i];
   __syncthreads();
-  res1d(xin, 14, 48, W.res[0], 32, 1, ta, tb, tc, red);
-  res1d(ta, 32, 48, W.res[1], 32, 1, o0, tb, tc, red);
-  res1d(o0, 32, 48, W.res[2], 64, 2, ta, tb, tc, red);
-  res1d(ta, 64, 24, W.res[3], 64, 1, o1, tb, tc, red);
-  res1d(o1, 64, 24, W.res[4], 128, 2, ta, tb, tc, red);
-  res1d(ta, 128, 12, W.res[5], 128, 1, o2, tb, tc, red);
-  res1d(o2, 128, 12, W.res[6], 256, 2, ta, tb, tc, red);
-  res1d(ta, 256, 6, W.res[7], 256, 1, o3, tb, tc, red);
+  res1d(xin, 14, 48, W.res[0], 32, 1, ta, tb, tc, red, part, pf);
+  res1d(ta, 32, 48, W.res[1], 32, 1, o0, tb, tc, red, part, pf);
+  res1d(o0, 32, 48, W.res[2], 64, 2, ta, tb, tc, red, part, pf);
+  res1d(ta, 64, 24, W.res[3], 64, 1, o1, tb, tc, red, part, pf);
+  res1d(o1, 64, 24, W.res[4], 128, 2, ta, tb, tc, red, part, pf);
+  res1d(ta, 128, 12, W.res[5], 128, 1, o2, tb, tc, red, part, pf);
+  res1d(o2, 128, 12, W.res[6], 256, 2, ta, tb, tc, red, part, pf);
+  res1d(ta, 256, 6, W.res[7], 256, 1, o3, tb, tc, red, part, pf);
   // FPN top-down (network.py:55-58): lateral = conv3 + GN, no activation
-  conv(o3, 256, 6, W.latW[3], 128, 6, 1, 3, fa);
+  conv(o3, 256, 6, W.latW[3], 128, 6, 1, 3, fa, part, pf);
   __syncthreads();
   gn(fa, 128, 6, W.latG[3], W.latB[3], nullptr, false, red);
   float *cur = fa, *nxt = fb;
@@ -304,11 +392,11 @@ __global__ __launch_bounds__(NT) void k_actor_net(const float *__restrict__ acto
     const int C = g == 2 ? 128 : (g == 1 ? 64 : 32);
     const int T = g == 2 ? 12 : (g == 1 ? 24 : 48);
     const int Th = T / 2;
-    conv(src_o, C, T, W.latW[g], 128, T, 1, 3, nxt);
+    conv(src_o, C, T, W.latW[g], 128, T, 1, 3, nxt, part, pf);
     __syncthreads();
     gn(nxt, 128, T, W.latG[g], W.latB[g], nullptr, false, red);
     // x2 linear upsample of `cur` (align_corners=False) added to the lateral
-    for (int i = tid; i < 128 * T; i += NT) {
+    for (int i = tid; i < 128 * T; i += AT) {
       const int c = i / T, t = i % T;
       float src = (t + 0.5f) * 0.5f - 0.5f;
       src = src < 0.f ? 0.f : src;
@@ -323,10 +411,10 @@ __global__ __launch_bounds__(NT) void k_actor_net(const float *__restrict__ acto
   // output Res1d(128,128) at T = 48 (network.py:60); only the last time column is kept
   {
     const ResW &w = W.res[8];
-    conv(cur, 128, 48, w.c1, 128, 48, 1, 3, nxt);
+    conv(cur, 128, 48, w.c1, 128, 48, 1, 3, nxt, part, pf);
     __syncthreads();
     gn(nxt, 128, 48, w.g1, w.b1, nullptr, true, red);
-    conv(nxt, 128, 48, w.c2, 128, 48, 1, 3, fo);
+    conv(nxt, 128, 48, w.c2, 128, 48, 1, 3, fo, part, pf);
     __syncthreads();
     gn(fo, 128, 48, w.g2, w.b2, cur, true, red);
   }
@@ -350,36 +438,40 @@ struct DecW {
   const float *T, *Tp;                                                           // [60][8], [60][7]
 };
 
-__global__ __launch_bounds__(NT) void k_dec_scene(const float *__restrict__ x /*[tokens,128]*/,
+#define DEC_SCENE_LDS_FLOATS (256 + 768 + 768 + 2304 + 768 + 9216 + 768 + 144 + 6144)
+__global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*[tokens,128]*/,
                                                   const int *__restrict__ cls_row /*[B]*/,
                                                   const float *__restrict__ tgt_feat /*[B,128]*/,
                                                   const float *__restrict__ tgt_rpe /*[B,20]*/,
                                                   float *__restrict__ Cout /*[B,6,128]*/,
                                                   float *__restrict__ tgt_out /*[B,128]*/,
                                                   float *__restrict__ cls_out /*[B,6]*/, DecW W) {
-  __shared__ __attribute__((aligned(16))) float v0[1][256];
-  __shared__ __attribute__((aligned(16))) float v1[1][768];
-  __shared__ __attribute__((aligned(16))) float C[6][128];
-  __shared__ __attribute__((aligned(16))) float qkv[6][384];
-  __shared__ __attribute__((aligned(16))) float att[6][128];
-  __shared__ __attribute__((aligned(16))) float ff[6][1536];
-  __shared__ __attribute__((aligned(16))) float t2[6][128];
-  __shared__ float sc[4][6][6];
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  float (*v0)[256] = (float (*)[256])(dsm);
+  float (*v1)[768] = (float (*)[768])(dsm + 256);
+  float (*C)[128] = (float (*)[128])(dsm + 1024);
+  float (*qkv)[384] = (float (*)[384])(dsm + 1792);
+  float (*att)[128] = (float (*)[128])(dsm + 4096);
+  float (*ff)[1536] = (float (*)[1536])(dsm + 4864);
+  float (*t2)[128] = (float (*)[128])(dsm + 14080);
+  float (*sc)[6][6] = (float (*)[6][6])(dsm + 14848);
+  float *part = dsm + 14992;
+  const int PF = 6144;
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   // ---- target embedding (network.py:491-495)
   if (tid < 20) v1[0][tid] = tgt_rpe[(size_t)b * 20 + tid];
   __syncthreads();
-  dense<1>(&v1[0][0], 768, 20, W.rpeW, W.rpeb, 128, &v0[0][128], 256);
+  dense<1>(&v1[0][0], 768, 20, W.rpeW, W.rpeb, 128, &v0[0][128], 256, part, PF);
   if (tid < 128) v0[0][tid] = tgt_feat[(size_t)b * 128 + tid];
   __syncthreads();
   ln_rows(&v0[0][128], 256, 1, 128, W.rpeg, W.rpebe, true);
   __syncthreads();
-  dense<1>(&v0[0][0], 256, 256, W.t0W, W.t0b, 128, &v1[0][0], 768);
+  dense<1>(&v0[0][0], 256, 256, W.t0W, W.t0b, 128, &v1[0][0], 768, part, PF);
   __syncthreads();
   ln_rows(&v1[0][0], 768, 1, 128, W.t0g, W.t0be, true);
   __syncthreads();
-  dense<1>(&v1[0][0], 768, 128, W.t3W, W.t3b, 128, &v0[0][0], 256);
+  dense<1>(&v1[0][0], 768, 128, W.t3W, W.t3b, 128, &v0[0][0], 256, part, PF);
   __syncthreads();
   ln_rows(&v0[0][0], 256, 1, 128, W.t3g, W.t3be, true);
   __syncthreads();
@@ -388,19 +480,19 @@ __global__ __launch_bounds__(NT) void k_dec_scene(const float *__restrict__ x /*
   // ---- ctx_proj: cls token -> 6 mode tokens (network.py:501)
   if (tid < 128) v0[0][tid] = x[(size_t)cls_row[b] * 128 + tid];
   __syncthreads();
-  dense<1>(&v0[0][0], 256, 128, W.c0W, W.c0b, 384, &v1[0][0], 768);
+  dense<1>(&v0[0][0], 256, 128, W.c0W, W.c0b, 384, &v1[0][0], 768, part, PF);
   __syncthreads();
   ln_rows(&v1[0][0], 768, 1, 384, W.c0g, W.c0be, true);
   __syncthreads();
-  dense<1>(&v1[0][0], 768, 384, W.c3W, W.c3b, 768, &ff[0][0], 1536);
+  dense<1>(&v1[0][0], 768, 384, W.c3W, W.c3b, 768, &ff[0][0], 1536, part, PF);
   __syncthreads();
   ln_rows(&ff[0][0], 1536, 1, 768, W.c3g, W.c3be, true);
   __syncthreads();
-  for (int i = tid; i < 768; i += NT) C[i / 128][i % 128] = ff[0][i];
+  for (int i = tid; i < 768; i += blockDim.x) C[i / 128][i % 128] = ff[0][i];
   __syncthreads();
   // ---- 2 post-norm encoder layers over the 6 mode tokens (4 heads x 32, ffn 1536)
   for (int L = 0; L < 2; ++L) {
-    dense<6>(&C[0][0], 128, 128, W.inW[L], W.inb[L], 384, &qkv[0][0], 384);
+    dense<6>(&C[0][0], 128, 128, W.inW[L], W.inb[L], 384, &qkv[0][0], 384, part, PF);
     __syncthreads();
     if (tid < 4 * 36) {
       const int hd = tid / 36, s = (tid % 36) / 6, t = tid % 6;
@@ -418,41 +510,41 @@ __global__ __launch_bounds__(NT) void k_dec_scene(const float *__restrict__ x /*
       for (int t = 0; t < 6; ++t) sc[hd][s][t] = e[t] / sum;
     }
     __syncthreads();
-    for (int i = tid; i < 6 * 128; i += NT) {
+    for (int i = tid; i < 6 * 128; i += blockDim.x) {
       const int s = i / 128, c = i % 128, hd = c / 32;
       float o = 0.f;
       for (int t = 0; t < 6; ++t) o = fmaf(sc[hd][s][t], qkv[t][256 + c], o);
       att[s][c] = o;
     }
     __syncthreads();
-    dense<6>(&att[0][0], 128, 128, W.outW[L], W.outb[L], 128, &t2[0][0], 128);
+    dense<6>(&att[0][0], 128, 128, W.outW[L], W.outb[L], 128, &t2[0][0], 128, part, PF);
     __syncthreads();
-    for (int i = tid; i < 768; i += NT) C[i / 128][i % 128] += t2[i / 128][i % 128];
+    for (int i = tid; i < 768; i += blockDim.x) C[i / 128][i % 128] += t2[i / 128][i % 128];
     __syncthreads();
     ln_rows(&C[0][0], 128, 6, 128, W.n1g[L], W.n1b[L], false);
     __syncthreads();
-    dense<6>(&C[0][0], 128, 128, W.l1W[L], W.l1b[L], 1536, &ff[0][0], 1536);
+    dense<6>(&C[0][0], 128, 128, W.l1W[L], W.l1b[L], 1536, &ff[0][0], 1536, part, PF);
     __syncthreads();
-    for (int i = tid; i < 6 * 1536; i += NT) ff[i / 1536][i % 1536] = fmaxf(ff[i / 1536][i % 1536], 0.f);
+    for (int i = tid; i < 6 * 1536; i += blockDim.x) ff[i / 1536][i % 1536] = fmaxf(ff[i / 1536][i % 1536], 0.f);
     __syncthreads();
-    dense<6>(&ff[0][0], 1536, 1536, W.l2W[L], W.l2b[L], 128, &t2[0][0], 128);
+    dense<6>(&ff[0][0], 1536, 1536, W.l2W[L], W.l2b[L], 128, &t2[0][0], 128, part, PF);
     __syncthreads();
-    for (int i = tid; i < 768; i += NT) C[i / 128][i % 128] += t2[i / 128][i % 128];
+    for (int i = tid; i < 768; i += blockDim.x) C[i / 128][i % 128] += t2[i / 128][i % 128];
     __syncthreads();
     ln_rows(&C[0][0], 128, 6, 128, W.n2g[L], W.n2b[L], false);
     __syncthreads();
   }
-  for (int i = tid; i < 768; i += NT) Cout[(size_t)b * 768 + i] = C[i / 128][i % 128];
+  for (int i = tid; i < 768; i += blockDim.x) Cout[(size_t)b * 768 + i] = C[i / 128][i % 128];
   // ---- cls head on the mode tokens only (network.py:512, Q6), softmax over the 6 modes
-  dense<6>(&C[0][0], 128, 128, W.k0W, W.k0b, 128, &att[0][0], 128);
+  dense<6>(&C[0][0], 128, 128, W.k0W, W.k0b, 128, &att[0][0], 128, part, PF);
   __syncthreads();
   ln_rows(&att[0][0], 128, 6, 128, W.k0g, W.k0be, true);
   __syncthreads();
-  dense<6>(&att[0][0], 128, 128, W.k3W, W.k3b, 128, &t2[0][0], 128);
+  dense<6>(&att[0][0], 128, 128, W.k3W, W.k3b, 128, &t2[0][0], 128, part, PF);
   __syncthreads();
   ln_rows(&t2[0][0], 128, 6, 128, W.k3g, W.k3be, true);
   __syncthreads();
-  for (int k = tid >> 6; k < 6; k += 4) {
+  for (int k = tid >> 6; k < 6; k += (int)(blockDim.x >> 6)) {
     const int lane = tid & 63;
     float s = t2[k][lane] * W.k6W[lane] + t2[k][lane + 64] * W.k6W[lane + 64];
     s = wave_sum(s);
@@ -472,35 +564,39 @@ __global__ __launch_bounds__(NT) void k_dec_scene(const float *__restrict__ x /*
 // SceneDecoder, actor part: RA agents per workgroup -> reg [a,6,60,5], vel [a,6,60,2]
 // =================================================================================================
 #define RA 4
-__global__ __launch_bounds__(NT) void k_dec_actor(const float *__restrict__ x /*[tokens,128]*/,
+#define DEC_ACTOR_LDS_FLOATS (512 + 1536 + 3072 + 3072 + 3072 + 960 + 6144)
+__global__ __launch_bounds__(DT) void k_dec_actor(const float *__restrict__ x /*[tokens,128]*/,
                                                   const int *__restrict__ actor_row /*[A]*/,
                                                   const int *__restrict__ actor_scene /*[A]*/, int n_actors,
                                                   const float *__restrict__ Cmode /*[B,6,128]*/,
                                                   const float *__restrict__ tgt /*[B,128]*/,
                                                   float *__restrict__ reg, float *__restrict__ vel, DecW W) {
-  __shared__ __attribute__((aligned(16))) float xin[RA][128];
-  __shared__ __attribute__((aligned(16))) float h1[RA][384];
-  __shared__ __attribute__((aligned(16))) float h2[RA][768];
-  __shared__ __attribute__((aligned(16))) float E[RA * 6][128];
-  __shared__ __attribute__((aligned(16))) float t1[RA * 6][128];
-  __shared__ float prm[RA * 6][40];
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  float (*xin)[128] = (float (*)[128])(dsm);
+  float (*h1)[384] = (float (*)[384])(dsm + 512);
+  float (*h2)[768] = (float (*)[768])(dsm + 2048);
+  float (*E)[128] = (float (*)[128])(dsm + 5120);
+  float (*t1)[128] = (float (*)[128])(dsm + 8192);
+  float (*prm)[40] = (float (*)[40])(dsm + 11264);
+  float *part = dsm + 12224;
+  const int PF = 6144;
   const int tid = threadIdx.x;
   const int a0 = blockIdx.x * RA;
-  for (int i = tid; i < RA * 128; i += NT) {
+  for (int i = tid; i < RA * 128; i += blockDim.x) {
     const int r = i / 128, a = a0 + r;
     xin[r][i % 128] = a < n_actors ? x[(size_t)actor_row[a] * 128 + i % 128] : 0.f;
   }
   __syncthreads();
-  dense<RA>(&xin[0][0], 128, 128, W.a0W, W.a0b, 384, &h1[0][0], 384);
+  dense<RA>(&xin[0][0], 128, 128, W.a0W, W.a0b, 384, &h1[0][0], 384, part, PF);
   __syncthreads();
   ln_rows(&h1[0][0], 384, RA, 384, W.a0g, W.a0be, true);
   __syncthreads();
-  dense<RA>(&h1[0][0], 384, 384, W.a3W, W.a3b, 768, &h2[0][0], 768);
+  dense<RA>(&h1[0][0], 384, 384, W.a3W, W.a3b, 768, &h2[0][0], 768, part, PF);
   __syncthreads();
   ln_rows(&h2[0][0], 768, RA, 768, W.a3g, W.a3be, true);
   __syncthreads();
   // embed = cls_embed + actor_embed (+ tgt on mode 0 only)  (network.py:506-510)
-  for (int i = tid; i < RA * 768; i += NT) {
+  for (int i = tid; i < RA * 768; i += blockDim.x) {
     const int r = i / 768, k = (i % 768) / 128, c = i % 128;
     const int a = a0 + r;
     float v = 0.f;
@@ -512,16 +608,16 @@ __global__ __launch_bounds__(NT) void k_dec_actor(const float *__restrict__ x /*
     E[r * 6 + k][c] = v;
   }
   __syncthreads();
-  dense<RA * 6>(&E[0][0], 128, 128, W.r0W, W.r0b, 128, &t1[0][0], 128);
+  dense<RA * 6>(&E[0][0], 128, 128, W.r0W, W.r0b, 128, &t1[0][0], 128, part, PF);
   __syncthreads();
   ln_rows(&t1[0][0], 128, RA * 6, 128, W.r0g, W.r0be, true);
   __syncthreads();
-  dense<RA * 6>(&t1[0][0], 128, 128, W.r3W, W.r3b, 128, &E[0][0], 128);
+  dense<RA * 6>(&t1[0][0], 128, 128, W.r3W, W.r3b, 128, &E[0][0], 128, part, PF);
   __syncthreads();
   ln_rows(&E[0][0], 128, RA * 6, 128, W.r3g, W.r3be, true);
   __syncthreads();
   // 128 -> 40 = 8 control points x (x, y, sx, sy, rho)
-  for (int i = tid; i < RA * 6 * 40; i += NT) {
+  for (int i = tid; i < RA * 6 * 40; i += blockDim.x) {
     const int r = i / 40, o = i % 40;
     float acc = W.r6b[o];
     for (int k = 0; k < 128; ++k) acc = fmaf(W.r6W[k * 40 + o], E[r][k], acc);
@@ -529,7 +625,7 @@ __global__ __launch_bounds__(NT) void k_dec_actor(const float *__restrict__ x /*
   }
   __syncthreads();
   // Bezier evaluation (network.py:515-523,545): pos = T P, cov = exp(T S), vel = Tp dP / 6
-  for (int i = tid; i < RA * 6 * 60; i += NT) {
+  for (int i = tid; i < RA * 6 * 60; i += blockDim.x) {
     const int r = i / 60, t = i % 60;
     const int a = a0 + r / 6, k = r % 6;
     if (a >= n_actors) continue;
@@ -551,3 +647,6 @@ __global__ __launch_bounds__(NT) void k_dec_actor(const float *__restrict__ x /*
     vo[0] = v2[0] / 6.0f; vo[1] = v2[1] / 6.0f;
   }
 }
+
+extern "C" size_t mind_dec_scene_lds_bytes() { return (size_t)DEC_SCENE_LDS_FLOATS * sizeof(float); }
+extern "C" size_t mind_dec_actor_lds_bytes() { return (size_t)DEC_ACTOR_LDS_FLOATS * sizeof(float); }

@@ -478,6 +478,42 @@ __device__ __forceinline__ float block_sum128(float v, float *red, int tid) {
   return red[0] + red[1];
 }
 
+__device__ __forceinline__ float wsum64(float v) {
+  v += __shfl_xor(v, 32, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 1, 64);
+  return v;
+}
+
+// LayerNorm statistics of TPW token rows at once (128 threads = one feature each): 4 barriers per
+// LayerNorm instead of 4 per token.  On exit pre[t] = (pre[t] - mean_t) and rstd[t] is set.
+__device__ __forceinline__ void ln_stats_multi(float (&pre)[TPW], float (&rstd)[TPW], float *red2, int tid) {
+  float s[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) s[t] = wsum64(pre[t]);
+  __syncthreads();
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) red2[(tid >> 6) * TPW + t] = s[t];
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const float mean = (red2[t] + red2[TPW + t]) * (1.0f / 128.0f);
+    pre[t] -= mean;
+    s[t] = wsum64(pre[t] * pre[t]);
+  }
+  __syncthreads();
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) red2[(tid >> 6) * TPW + t] = s[t];
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) rstd[t] = 1.0f / sqrtf((red2[t] + red2[TPW + t]) * (1.0f / 128.0f) + 1e-5f);
+}
+
 // y[t][tid] = sum_k WT[k*ldo + tid] * xin[t][k]  for t < TPW   (xin in LDS, row stride ldx)
 template <int K>
 __device__ __forceinline__ void matvec(float (&acc)[TPW], const float *__restrict__ WT, int ldo, int col,
@@ -500,6 +536,7 @@ __global__ __launch_bounds__(128) void k_token(const TokMeta *__restrict__ meta,
   __shared__ float tmp[TPW][260];       // scratch (o / h1 up to 256 wide)
   __shared__ float mb[TPW][8][132];     // normalised sum p*mem per head
   __shared__ float red[2];
+  __shared__ float red2[2 * TPW];
   __shared__ float cw[TPW][8][8];       // combine weights per (token, head, split<=8)
   const int tid = threadIdx.x;
   const int tok0 = blockIdx.x * TPW;
@@ -523,19 +560,22 @@ __global__ __launch_bounds__(128) void k_token(const TokMeta *__restrict__ meta,
     for (int t = 0; t < TPW; ++t) { aa[t] = W.bpa[tid]; al[t] = W.bpl[tid]; }
     matvec<128>(aa, W.WpaT, 128, tid, &tmp[0][0], 260);
     matvec<128>(al, W.WplT, 128, tid, &tmp[0][0], 260);
-    for (int t = 0; t < TPW; ++t) {
-      int type = 2;
-      if (t < nt) type = meta[tok0 + t].type;
-      const float pre = type == 0 ? aa[t] : al[t];
-      const float mean = block_sum128(pre, red, tid) * (1.0f / 128.0f);
-      const float d = pre - mean;
-      const float var = block_sum128(d * d, red, tid) * (1.0f / 128.0f);
-      const float rstd = 1.0f / sqrtf(var + 1e-5f);
-      const float g = type == 0 ? W.gpa[tid] : W.gpl[tid];
-      const float b = type == 0 ? W.bepa[tid] : W.bepl[tid];
-      float y = fmaxf(d * rstd * g + b, 0.f);
-      if (type == 2) y = 0.f;
-      xs[t][tid] = y;
+    {
+      int types[TPW];
+      float pre[TPW], rs[TPW];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        types[t] = (t < nt) ? meta[tok0 + t].type : 2;
+        pre[t] = types[t] == 0 ? aa[t] : al[t];
+      }
+      ln_stats_multi(pre, rs, red2, tid);
+      const float ga = W.gpa[tid], ba = W.bepa[tid], gl = W.gpl[tid], bl = W.bepl[tid];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        float y = fmaxf(pre[t] * rs[t] * (types[t] == 0 ? ga : gl) + (types[t] == 0 ? ba : bl), 0.f);
+        if (types[t] == 2) y = 0.f;
+        xs[t][tid] = y;
+      }
     }
     __syncthreads();
   } else {
@@ -570,19 +610,43 @@ __global__ __launch_bounds__(128) void k_token(const TokMeta *__restrict__ meta,
       for (int s = 0; s < 8; ++s) cw[t][hd][s] = wgt[s];
     }
     __syncthreads();
-    for (int t = 0; t < TPW; ++t) {
-      int ns = 0, slot0 = 0;
-      if (t < nt) {
-        const TokMeta m = meta[tok0 + t];
-        ns = ((mode & 8) && !(m.flags & 1)) ? 0 : m.nsplit;
-        slot0 = m.slot0;
+    {
+      // all (token, head) accumulators advance together over the split index, so that up to 64
+      // independent loads are in flight per thread (the serial version was latency-bound)
+      __shared__ int s_ns[TPW], s_slot0[TPW];
+      if (tid < TPW) {
+        int ns = 0, slot0 = 0;
+        if (tid < nt) {
+          const TokMeta m = meta[tok0 + tid];
+          ns = ((mode & 8) && !(m.flags & 1)) ? 0 : m.nsplit;
+          slot0 = m.slot0;
+        }
+        s_ns[tid] = ns;
+        s_slot0[tid] = slot0;
       }
-      for (int hd = 0; hd < 8; ++hd) {
-        float v = 0.f;
-        for (int s = 0; s < ns; ++s)
-          v = fmaf(cw[t][hd][s], part[(size_t)(slot0 + s) * PART_STRIDE + 16 + hd * 128 + tid], v);
-        mb[t][hd][tid] = v;
+      __syncthreads();
+      float v[TPW][8];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int hd = 0; hd < 8; ++hd) v[t][hd] = 0.f;
+      int nsmax = 0;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) nsmax = max(nsmax, s_ns[t]);
+      for (int sp = 0; sp < nsmax; ++sp) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          if (sp < s_ns[t]) {
+            const float *ps = part + (size_t)(s_slot0[t] + sp) * PART_STRIDE + 16 + tid;
+#pragma unroll
+            for (int hd = 0; hd < 8; ++hd) v[t][hd] = fmaf(cw[t][hd][sp], ps[hd * 128], v[t][hd]);
+          }
+        }
       }
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int hd = 0; hd < 8; ++hd) mb[t][hd][tid] = v[t][hd];
     }
     __syncthreads();
     // ---- o = W_v,h mbar_h + b_v  (thread f = hd*16+d uses head hd = f>>4)
@@ -610,13 +674,12 @@ __global__ __launch_bounds__(128) void k_token(const TokMeta *__restrict__ meta,
       for (int t = 0; t < TPW; ++t) acc[t] = b;
       matvec<128>(acc, W.WoT, 128, tid, &tmp[0][0], 260);
       const float g = W.g2[tid], be = W.b2[tid];
-      for (int t = 0; t < TPW; ++t) {
-        const float pre = xs[t][tid] + acc[t];
-        const float mean = block_sum128(pre, red, tid) * (1.0f / 128.0f);
-        const float d = pre - mean;
-        const float var = block_sum128(d * d, red, tid) * (1.0f / 128.0f);
-        xs[t][tid] = d * (1.0f / sqrtf(var + 1e-5f)) * g + be;
-      }
+      float pre[TPW], rs[TPW];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) pre[t] = xs[t][tid] + acc[t];
+      ln_stats_multi(pre, rs, red2, tid);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) xs[t][tid] = pre[t] * rs[t] * g + be;
       __syncthreads();
     }
     // ---- FFN 128 -> 256 -> 128, x2 = LN3(x1 + ff)
@@ -636,13 +699,12 @@ __global__ __launch_bounds__(128) void k_token(const TokMeta *__restrict__ meta,
       for (int t = 0; t < TPW; ++t) acc[t] = b;
       matvec<256>(acc, W.W2T, 128, tid, &tmp[0][0], 260);
       const float g = W.g3[tid], be = W.b3[tid];
-      for (int t = 0; t < TPW; ++t) {
-        const float pre = xs[t][tid] + acc[t];
-        const float mean = block_sum128(pre, red, tid) * (1.0f / 128.0f);
-        const float d = pre - mean;
-        const float var = block_sum128(d * d, red, tid) * (1.0f / 128.0f);
-        xs[t][tid] = d * (1.0f / sqrtf(var + 1e-5f)) * g + be;
-      }
+      float pre[TPW], rs[TPW];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) pre[t] = xs[t][tid] + acc[t];
+      ln_stats_multi(pre, rs, red2, tid);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) xs[t][tid] = pre[t] * rs[t] * g + be;
       __syncthreads();
     }
   }

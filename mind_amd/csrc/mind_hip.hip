@@ -119,6 +119,8 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   (void)hipFuncSetAttribute((const void *)k_pair<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_pair<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_actor_net, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_dec_actor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
   *out = c;
   return MIND_OK;
 }
@@ -588,16 +590,16 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   const float *lane_feat = in->lane_feat;
 
   // ---- encoders
-  hipLaunchKernelGGL(k_actor_net, dim3(A), dim3(256), mind_actor_lds_bytes(), st, in->actors, A, actor_feat, c->actorW);
+  hipLaunchKernelGGL(k_actor_net, dim3(A), dim3(AT), mind_actor_lds_bytes(), st, in->actors, A, actor_feat, c->actorW);
   if (!lane_feat) {
     float *lf = out->lane_feat ? out->lane_feat : (float *)c->lane_feat.p;
     if (Ltot > 0)
-      hipLaunchKernelGGL(k_lane_net, dim3((Ltot + PL - 1) / PL), dim3(256), 0, st, in->lanes, Ltot, lf, c->laneW);
+      hipLaunchKernelGGL(k_lane_net, dim3((Ltot + PL - 1) / PL), dim3(DT), 0, st, in->lanes, Ltot, lf, c->laneW);
     lane_feat = lf;
   } else if (out->lane_feat && out->lane_feat != in->lane_feat && Ltot > 0) {
     HIPCHK(c, hipMemcpyAsync(out->lane_feat, in->lane_feat, (size_t)Ltot * 128 * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
-  hipLaunchKernelGGL(k_lane_net, dim3((Bn + PL - 1) / PL), dim3(256), 0, st, in->tgt_nodes, Bn, (float *)c->tgt_feat.p, c->laneW);
+  hipLaunchKernelGGL(k_lane_net, dim3((Bn + PL - 1) / PL), dim3(DT), 0, st, in->tgt_nodes, Bn, (float *)c->tgt_feat.p, c->laneW);
   hipLaunchKernelGGL(k_tokpos, dim3((ntok + 255) / 256), dim3(256), 0, st, dmeta, ntok, in->actor_ctrs, in->actor_vecs,
                      in->lane_ctrs, in->lane_vecs, tokpos);
 
@@ -638,9 +640,9 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   const int *d_actor_row = (const int *)c->rows.p;
   const int *d_actor_scene = d_actor_row + A;
   const int *d_cls_row = d_actor_row + 2 * A;
-  hipLaunchKernelGGL(k_dec_scene, dim3(Bn), dim3(256), 0, st, x, d_cls_row, (const float *)c->tgt_feat.p, in->tgt_rpe,
+  hipLaunchKernelGGL(k_dec_scene, dim3(Bn), dim3(DT), mind_dec_scene_lds_bytes(), st, x, d_cls_row, (const float *)c->tgt_feat.p, in->tgt_rpe,
                      (float *)c->cmode.p, (float *)c->tgt_emb.p, out->cls, c->decW);
-  hipLaunchKernelGGL(k_dec_actor, dim3((A + RA - 1) / RA), dim3(256), 0, st, x, d_actor_row, d_actor_scene, A,
+  hipLaunchKernelGGL(k_dec_actor, dim3((A + RA - 1) / RA), dim3(DT), mind_dec_actor_lds_bytes(), st, x, d_actor_row, d_actor_scene, A,
                      (const float *)c->cmode.p, (const float *)c->tgt_emb.p, out->reg, out->vel, c->decW);
   if (out->actor_emb || out->cls_emb) {
     // debug taps: gather fused tokens
