@@ -25,6 +25,7 @@
 #define IL_NA 10      // line-search candidates
 #define IL_THREADS 512
 #define IL_WAVES (IL_THREADS / 64)
+#define IL_SPEC 4     // Levenberg-Marquardt values evaluated speculatively per step (see k_ilqr)
 #define IL_MAXA 128   // agents per scene staged in LDS (cfg4: 64, stress: 128)
 #define IL_REL 15     // relevant-agent list length per node
 #define IL_LSUM 2048   // doubles of LDS used to stage the cost sums
@@ -38,7 +39,7 @@ struct IlqrTreeDev {
   const int *child_start;   // [M+1]
   const int *child_list;    // [M-1] children in key order
   // chain segments: maximal single-child paths; one wave walks a segment without workgroup barriers
-  int n_segs, n_slevels;
+  int n_segs, n_slevels, max_level_segs, pad2;
   const int *seg_start;     // [n_segs+1] into seg_nodes (root -> leaf order inside a segment)
   const int *seg_nodes;     // [M]
   const int *slevel_start;  // [n_slevels+1] into slevel_segs (segments grouped by depth in the segment tree)
@@ -47,8 +48,9 @@ struct IlqrTreeDev {
   const float *mean;        // [M,a,2]
   const float *cov;         // [M,a]
   // workspace (doubles)
-  double *xs, *us, *Fx, *L, *Lx, *Lxx, *k, *K, *Vx, *Vxx;   // [M,*]
-  double *xs_new, *us_new, *L_new;                            // [NA,M,*]
+  double *xs, *us, *Fx, *L, *Lx, *Lxx;                        // [M,*]
+  double *k, *K, *Vx, *Vxx;                                   // [IL_SPEC][M,*]  (one set per speculative mu)
+  double *xs_new, *us_new, *L_new;                            // [IL_SPEC][NA,M,*]
   int *rel;                 // [M, IL_REL+1]: count (or -1 = overflow) + agent indices near the nominal state
   // outputs
   double *stats;            // [4]: iterations, converged, J, mu
@@ -693,19 +695,26 @@ __device__ __forceinline__ void il_derivatives(const IlqrConst &C, const IlqrTre
   }
 }
 
+// LM schedule after one rejection (solver.py:153-158)
+__device__ __forceinline__ void il_reject_update(double &mu, double &delta) {
+  delta = fmax(1.0, delta) * 2.0;
+  mu = fmax(1e-6, mu * delta);
+}
+
 __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restrict__ trees, IlqrConst C) {
   const IlqrTreeDev T = trees[blockIdx.x];
-  __shared__ double scr_all[IL_WAVES][192];
-  __shared__ double ag_all[IL_WAVES][4 * IL_MAXA];
-  __shared__ double lsum[IL_LSUM];
-  __shared__ double Jnew[IL_NA];
+  extern __shared__ double il_dsm[];
+  // LDS carve: per-wave scratch [IL_WAVES][192] | per-wave agent table [IL_WAVES][4*amax] | cost sums [IL_LSUM]
+  const int amax = T.n_agents;
+  double *scr = il_dsm + (size_t)(threadIdx.x >> 6) * 192;
+  double *ag = il_dsm + (size_t)IL_WAVES * 192 + (size_t)(threadIdx.x >> 6) * 4 * amax;
+  double *lsum = il_dsm + (size_t)IL_WAVES * 192 + (size_t)IL_WAVES * 4 * amax;
+  __shared__ double Jnew[IL_SPEC][IL_NA];
   __shared__ double sh_mu, sh_delta, sh_J;
-  __shared__ int sh_accepted, sh_converged, sh_stop, sh_sing, sh_pick;
+  __shared__ int sh_accepted, sh_converged, sh_stop, sh_sing, sh_pick, sh_slot, sh_it, sh_nspec;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double *scr = scr_all[wave];
-  double *ag = ag_all[wave];
   const int M = T.M;
-  if (tid == 0) { sh_mu = 1.0; sh_delta = 2.0; sh_accepted = 1; sh_converged = 0; sh_stop = 0; sh_J = 0.0; sh_pick = 0; }
+  if (tid == 0) { sh_mu = 1.0; sh_delta = 2.0; sh_accepted = 1; sh_converged = 0; sh_stop = 0; sh_J = 0.0; sh_pick = 0; sh_slot = 0; sh_it = 0; }
   // ---- initial nominal rollout (solver.py:255-330) = candidate slot 0 with k = K = 0, alpha = 0
   for (int q = tid; q < M * 2; q += IL_THREADS) T.k[q] = 0.0;
   for (int q = tid; q < M * 12; q += IL_THREADS) T.K[q] = 0.0;
@@ -718,14 +727,17 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
     __threadfence_block();
     __syncthreads();
   }
-  int it = 0;
   long long t_der = 0, t_bw = 0, t_ls = 0, t_sel = 0, t_mark = clock64();
 #define IL_MARK(acc) do { long long now_ = clock64(); acc += now_ - t_mark; t_mark = now_; } while (0)
-  for (it = 0; it < C.max_iter; ++it) {
+  // Each pass of this loop consumes 1..IL_SPEC reference iterations: the backward pass and line search are
+  // evaluated for the current mu AND for the next mu values the LM schedule would visit if the step keeps
+  // being rejected (a deterministic sequence); the first slot with an improving step is taken, exactly
+  // what the sequential loop of solver.py:133-158 would have reached.
+  while (sh_it < C.max_iter) {
     if (sh_accepted) {
       // adopt the accepted candidate as the nominal trajectory, then derivatives for all nodes in parallel
-      const int pick = sh_pick;
-      const double *xn = T.xs_new + (size_t)pick * M * 6, *un = T.us_new + (size_t)pick * M * 2;
+      const size_t off = ((size_t)sh_slot * IL_NA + sh_pick) * M;
+      const double *xn = T.xs_new + off * 6, *un = T.us_new + off * 2;
       for (int q = tid; q < M * 6; q += IL_THREADS) T.xs[q] = xn[q];
       for (int q = tid; q < M * 2; q += IL_THREADS) T.us[q] = un[q];
       __threadfence_block();
@@ -741,22 +753,38 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
       __syncthreads();
     }
     IL_MARK(t_der);
-    // ---------------- backward pass (solver.py:332-373): segments, deepest segment level first ----------------
-    if (tid == 0) sh_sing = 0;
+    // number of speculative slots this pass: bounded by waves, remaining iterations and the mu >= 1e10 stop
+    if (tid == 0) {
+      int ns = IL_SPEC;
+      const int maxseg = T.max_level_segs > 0 ? T.max_level_segs : 1;   // widest segment level
+      while (ns > 1 && ns * maxseg > IL_WAVES) --ns;
+      if (ns > C.max_iter - sh_it) ns = C.max_iter - sh_it;
+      double mu = sh_mu, de = sh_delta;
+      int cnt = 1;
+      for (; cnt < ns; ++cnt) { il_reject_update(mu, de); if (mu >= 1e10) break; }   // slot cnt would never be reached
+      sh_nspec = cnt < ns ? cnt : ns;
+      sh_sing = 0;
+    }
     __syncthreads();
-    const double mu = sh_mu;
+    const int nspec = sh_nspec;
+    // per-wave slot view: slot = item / segments
+    // ---------------- backward pass (solver.py:332-373): segments, deepest segment level first ----------------
     for (int d = T.n_slevels - 1; d >= 0; --d) {
-      for (int q = T.slevel_start[d] + wave; q < T.slevel_start[d + 1]; q += IL_WAVES) {
-        const int seg = T.slevel_segs[q];
+      const int lo = T.slevel_start[d], hi = T.slevel_start[d + 1];
+      for (int w = wave; w < (hi - lo) * nspec; w += IL_WAVES) {
+        const int slot = w / (hi - lo), seg = T.slevel_segs[lo + w % (hi - lo)];
+        double mu = sh_mu, de = sh_delta;
+        for (int e = 0; e < slot; ++e) il_reject_update(mu, de);
+        IlqrTreeDev Ts = T;
+        Ts.k += (size_t)slot * M * 2; Ts.K += (size_t)slot * M * 12; Ts.Vx += (size_t)slot * M * 6; Ts.Vxx += (size_t)slot * M * 36;
         const int s0 = T.seg_start[seg], s1 = T.seg_start[seg + 1];
-        // the last node of the segment gathers its children (first nodes of child segments), key order, from 0
         {
           const int c = T.seg_nodes[s1 - 1];
           double acc = 0.0;
           if (lane < 42)
             for (int e = T.child_start[c]; e < T.child_start[c + 1]; ++e) {
               const int ch = T.child_list[e];
-              acc += lane < 36 ? T.Vxx[(size_t)ch * 36 + lane] : T.Vx[(size_t)ch * 6 + (lane - 36)];
+              acc += lane < 36 ? Ts.Vxx[(size_t)ch * 36 + lane] : Ts.Vx[(size_t)ch * 6 + (lane - 36)];
             }
           IL_WFENCE();
           if (lane < 36) scr[36 + lane] = acc;
@@ -779,56 +807,77 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
             else if (lane < 42) nlx = T.Lx[(size_t)cn * 6 + lane - 36];
             nu0 = T.us[(size_t)cn * 2]; nu1 = T.us[(size_t)cn * 2 + 1]; np_ = (double)T.prob[cn];
           }
-          sing = il_gains(C, T, T.seg_nodes[r], mu, scr, pfx, plxx, plx, pu0, pu1, pp);
+          sing = il_gains(C, Ts, T.seg_nodes[r], mu, scr, pfx, plxx, plx, pu0, pu1, pp);
           pfx = nfx; plxx = nlxx; plx = nlx; pu0 = nu0; pu1 = nu1; pp = np_;
         }
-        if (sing) { if (lane == 0) sh_sing = 1; }
+        if (sing) { if (lane == 0) atomicOr(&sh_sing, 1 << slot); }
         else {
           const int c = T.seg_nodes[s0];   // value function of the segment head, for the parent's gather
-          if (lane < 36) T.Vxx[(size_t)c * 36 + lane] = scr[36 + lane];
-          else if (lane < 42) T.Vx[(size_t)c * 6 + lane - 36] = scr[176 + lane - 36];
+          if (lane < 36) Ts.Vxx[(size_t)c * 36 + lane] = scr[36 + lane];
+          else if (lane < 42) Ts.Vx[(size_t)c * 6 + lane - 36] = scr[176 + lane - 36];
         }
       }
       __threadfence_block();
       __syncthreads();
     }
     IL_MARK(t_bw);
-    if (sh_sing) { __syncthreads(); continue; }   // LinAlgError: retry without raising mu (Q9)
-    // ---------------- line search: all 10 alphas rolled out concurrently in lane groups (solver.py:180-253) -------
+    if (sh_sing & 1) {   // LinAlgError at the current mu: retry without raising mu (Q9) -- burns one iteration
+      if (tid == 0) sh_it += 1;
+      __syncthreads();
+      continue;
+    }
+    // slots behind a singular slot cannot be used this pass
+    int nuse = nspec;
+    for (int e = 1; e < nspec; ++e) if ((sh_sing >> e) & 1) { nuse = e; break; }
+    // ---------------- line search: 10 alphas in lane groups, `nuse` mu slots in parallel waves ----------------
     for (int d = 0; d < T.n_slevels; ++d) {
-      for (int q = T.slevel_start[d] + wave; q < T.slevel_start[d + 1]; q += IL_WAVES)
-        il_rollout_segment(C, T, T.slevel_segs[q], 0, scr, ag);
+      const int lo = T.slevel_start[d], hi = T.slevel_start[d + 1];
+      for (int w = wave; w < (hi - lo) * nuse; w += IL_WAVES) {
+        const int slot = w / (hi - lo), seg = T.slevel_segs[lo + w % (hi - lo)];
+        IlqrTreeDev Ts = T;
+        Ts.k += (size_t)slot * M * 2; Ts.K += (size_t)slot * M * 12;
+        Ts.xs_new += (size_t)slot * IL_NA * M * 6; Ts.us_new += (size_t)slot * IL_NA * M * 2; Ts.L_new += (size_t)slot * IL_NA * M;
+        il_rollout_segment(C, Ts, seg, 0, scr, ag);
+      }
       __threadfence_block();
       __syncthreads();
     }
     IL_MARK(t_ls);
-    if (M * IL_NA <= IL_LSUM) {
-      for (int q = tid; q < M * IL_NA; q += IL_THREADS) lsum[q] = T.L_new[q];
+    if (M * IL_NA * nuse <= IL_LSUM) {
+      for (int q = tid; q < M * IL_NA * nuse; q += IL_THREADS) lsum[q] = T.L_new[q];
       __syncthreads();
     }
-    if (tid < IL_NA) {
+    if (tid < IL_NA * nuse) {
       double J = 0.0;   // python sum(): sequential
-      const double *Ln = (M * IL_NA <= IL_LSUM) ? lsum + (size_t)tid * M : T.L_new + (size_t)tid * M;
+      const double *Ln = (M * IL_NA * nuse <= IL_LSUM) ? lsum + (size_t)tid * M : T.L_new + (size_t)tid * M;
       for (int c = 0; c < M; ++c) J += Ln[c];
-      Jnew[tid] = J;
+      Jnew[tid / IL_NA][tid % IL_NA] = J;
     }
     __syncthreads();
     if (tid == 0) {
-      int pick = -1;
-      for (int a = 0; a < IL_NA; ++a)
-        if (Jnew[a] < sh_J) { pick = a; break; }
-      if (pick >= 0) {
-        sh_pick = pick;
-        if (fabs((sh_J - Jnew[pick]) / sh_J) < 1e-6) sh_converged = 1;
-        sh_accepted = 1;
-        sh_delta = fmin(1.0, sh_delta) / 2.0;
-        sh_mu *= sh_delta;
-        if (sh_mu <= 1e-6) sh_mu = 0.0;
-      } else {
-        sh_delta = fmax(1.0, sh_delta) * 2.0;
-        sh_mu = fmax(1e-6, sh_mu * sh_delta);
-        if (sh_mu >= 1e10) sh_stop = 1;
+      double mu = sh_mu, de = sh_delta;
+      int it = sh_it;
+      bool done = false;
+      for (int slot = 0; slot < nuse && !done; ++slot) {
+        // (mu, de) is the LM state the reference holds when it runs this iteration
+        int pick = -1;
+        for (int a = 0; a < IL_NA; ++a)
+          if (Jnew[slot][a] < sh_J) { pick = a; break; }
+        it += 1;
+        if (pick >= 0) {
+          sh_pick = pick; sh_slot = slot;
+          if (fabs((sh_J - Jnew[slot][pick]) / sh_J) < 1e-6) sh_converged = 1;
+          sh_accepted = 1;
+          de = fmin(1.0, de) / 2.0;
+          mu *= de;
+          if (mu <= 1e-6) mu = 0.0;
+          done = true;
+        } else {
+          il_reject_update(mu, de);
+          if (mu >= 1e10) { sh_stop = 1; done = true; }
+        }
       }
+      sh_mu = mu; sh_delta = de; sh_it = it;
     }
     __syncthreads();
     IL_MARK(t_sel);
@@ -836,16 +885,18 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
   }
   // the reference returns the last ACCEPTED xs/us (Q19: J_opt is the cost before that step)
   if (sh_accepted) {
-    const int pick = sh_pick;
-    const double *xn = T.xs_new + (size_t)pick * M * 6, *un = T.us_new + (size_t)pick * M * 2;
+    const size_t off = ((size_t)sh_slot * IL_NA + sh_pick) * M;
+    const double *xn = T.xs_new + off * 6, *un = T.us_new + off * 2;
     for (int q = tid; q < M * 6; q += IL_THREADS) T.xs[q] = xn[q];
     for (int q = tid; q < M * 2; q += IL_THREADS) T.us[q] = un[q];
   }
   if (tid == 0) {
-    T.stats[0] = (double)(it < C.max_iter ? it + 1 : it);
+    T.stats[0] = (double)sh_it;
     T.stats[1] = (double)sh_converged;
     T.stats[2] = sh_J;
     T.stats[3] = sh_mu;
     T.stats[4] = (double)t_der; T.stats[5] = (double)t_bw; T.stats[6] = (double)t_ls; T.stats[7] = (double)t_sel;
   }
 }
+
+static inline size_t il_lds_bytes(int amax) { return ((size_t)IL_WAVES * 192 + (size_t)IL_WAVES * 4 * amax + IL_LSUM) * sizeof(double); }

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <string>
@@ -698,7 +699,7 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
   auto takeF = [&](size_t n) { size_t o = nf; nf += (n + 3) & ~(size_t)3; return o; };
   auto takeI = [&](size_t n) { size_t o = ni; ni += (n + 3) & ~(size_t)3; return o; };
   const size_t o_gx = takeD(W), o_gy = takeD(H), o_lane = takeD((size_t)n_lane_pts * 2), o_quad = takeD((size_t)W * H);
-  struct TL { size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel; int M, a, nl, nseg, nsl; };
+  struct TL { size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel; int M, a, nl, nseg, nsl, maxls; };
   std::vector<TL> tl(n_trees);
   long Mtot = 0;
   for (int t = 0; t < n_trees; ++t) {
@@ -710,8 +711,8 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
     TL &L = tl[t];
     L.M = (int)M; L.a = tr.n_agents;
     L.xs = takeD(6 * M); L.us = takeD(2 * M); L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M);
-    L.Lxx = takeD(36 * M); L.k = takeD(2 * M); L.K = takeD(12 * M); L.Vx = takeD(6 * M); L.Vxx = takeD(36 * M);
-    L.xsn = takeD(60 * M); L.usn = takeD(20 * M); L.Ln = takeD(10 * M); L.stats = takeD(8);
+    L.Lxx = takeD(36 * M); L.k = takeD(IL_SPEC * 2 * M); L.K = takeD(IL_SPEC * 12 * M); L.Vx = takeD(IL_SPEC * 6 * M); L.Vxx = takeD(IL_SPEC * 36 * M);
+    L.xsn = takeD(IL_SPEC * 60 * M); L.usn = takeD(IL_SPEC * 20 * M); L.Ln = takeD(IL_SPEC * 10 * M); L.stats = takeD(8);
     L.prob = takeF(M); L.mean = takeF(M * tr.n_agents * 2); L.cov = takeF(M * tr.n_agents);
     L.parent = takeI(M); L.lnodes = takeI(M); L.cstart = takeI(M + 1); L.clist = takeI(M); L.rel = takeI(M * (IL_REL + 1));
     Mtot += (long)M;
@@ -772,6 +773,8 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
     std::vector<int> sf(maxsd + 1, 0);
     for (int sgi = 0; sgi < nseg; ++sgi) sl_segs[t][sl_start[t][seg_depth[sgi]] + sf[seg_depth[sgi]]++] = sgi;
     tl[t].nseg = nseg; tl[t].nsl = maxsd + 1;
+    tl[t].maxls = 1;
+    for (int d = 0; d <= maxsd; ++d) tl[t].maxls = std::max(tl[t].maxls, sl_start[t][d + 1] - sl_start[t][d]);
     tl[t].sstart = takeI(nseg + 1); tl[t].snodes = takeI(M); tl[t].slstart = takeI(maxsd + 2); tl[t].slsegs = takeI(nseg);
   }
   const size_t bytesD = nd * sizeof(double), bytesF = nf * sizeof(float), bytesI = ni * sizeof(int);
@@ -814,7 +817,7 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
     D.parent = dI + L.parent; D.level_start = dI + L.lstart; D.level_nodes = dI + L.lnodes;
     D.child_start = dI + L.cstart; D.child_list = dI + L.clist;
     D.rel = dI + L.rel;
-    D.n_segs = L.nseg; D.n_slevels = L.nsl;
+    D.n_segs = L.nseg; D.n_slevels = L.nsl; D.max_level_segs = L.maxls; D.pad2 = 0;
     D.seg_start = dI + L.sstart; D.seg_nodes = dI + L.snodes; D.slevel_start = dI + L.slstart; D.slevel_segs = dI + L.slsegs;
     D.prob = dF + L.prob; D.mean = dF + L.mean; D.cov = dF + L.cov;
     D.xs = dD + L.xs; D.us = dD + L.us; D.Fx = dD + L.Fx; D.L = dD + L.L; D.Lx = dD + L.Lx; D.Lxx = dD + L.Lxx;
@@ -838,7 +841,11 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
   for (int j = 0; j < IL_NA; ++j) K.alphas[j] = std::pow(1.1, -(double)(j * j));
   K.gx = dD + o_gx; K.gy = dD + o_gy; K.quad = dD + o_quad;
   hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, K.gx, K.gy, W, H, dD + o_lane, n_lane_pts, dD + o_quad);
-  hipLaunchKernelGGL(k_ilqr, dim3(n_trees), dim3(IL_THREADS), 0, st, (const IlqrTreeDev *)(base + o_structs), K);
+  int amax = 1;
+  for (int t = 0; t < n_trees; ++t) amax = trees[t].n_agents > amax ? trees[t].n_agents : amax;
+  const size_t il_lds = il_lds_bytes(amax);
+  (void)hipFuncSetAttribute((const void *)k_ilqr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
+  hipLaunchKernelGGL(k_ilqr, dim3(n_trees), dim3(IL_THREADS), il_lds, st, (const IlqrTreeDev *)(base + o_structs), K);
   HIPCHK(c, hipGetLastError());
   moff = 0;
   std::vector<double> hs(8 * n_trees);
