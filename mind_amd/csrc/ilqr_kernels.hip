@@ -552,28 +552,20 @@ __device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const Ilq
 #pragma unroll
     for (int k = 0; k < 6; ++k) { xp[k] = T.xs_new[((size_t)a * M + p0) * 6 + k]; xo[k] = T.xs[(size_t)p0 * 6 + k]; }
   }
-  // operands of the next chain node are prefetched while the current one is evaluated
   int c = T.seg_nodes[s0];
-  double Kc[12], kc[2], uc[2], xoc[6];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) Kc[k] = T.K[(size_t)c * 12 + k];
-  kc[0] = T.k[(size_t)c * 2]; kc[1] = T.k[(size_t)c * 2 + 1];
-  uc[0] = T.us[(size_t)c * 2]; uc[1] = T.us[(size_t)c * 2 + 1];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) xoc[k] = T.xs[(size_t)c * 6 + k];
   int *irel = (int *)(scr + 160);          // 16 ints inside the wave scratch (cells use scr[0..99))
   IlNodePre Pc, Pn;
   il_prefetch_node(C, T, c, Pc);
   for (int q = s0; q < s1; ++q) {
     const int cn = q + 1 < s1 ? T.seg_nodes[q + 1] : c;
     il_prefetch_node(C, T, cn, Pn);
-    double Kn[12], kn[2], un2[2], xon[6];
+    double Kc[12], kc[2], uc[2], xoc[6];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) Kn[k] = T.K[(size_t)cn * 12 + k];
-    kn[0] = T.k[(size_t)cn * 2]; kn[1] = T.k[(size_t)cn * 2 + 1];
-    un2[0] = T.us[(size_t)cn * 2]; un2[1] = T.us[(size_t)cn * 2 + 1];
+    for (int k = 0; k < 12; ++k) Kc[k] = T.K[(size_t)c * 12 + k];
+    kc[0] = T.k[(size_t)c * 2]; kc[1] = T.k[(size_t)c * 2 + 1];
+    uc[0] = T.us[(size_t)c * 2]; uc[1] = T.us[(size_t)c * 2 + 1];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) xon[k] = T.xs[(size_t)cn * 6 + k];
+    for (int k = 0; k < 6; ++k) xoc[k] = T.xs[(size_t)c * 6 + k];
     double u[2], x[6];
     if (T.parent[c] < 0) {
       u[0] = uc[0] + alpha * kc[0];
@@ -610,10 +602,7 @@ __device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const Ilq
       un[0] = u[0]; un[1] = u[1];
     }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { xp[k] = x[k]; xo[k] = xoc[k]; xoc[k] = xon[k]; }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Kc[k] = Kn[k];
-    kc[0] = kn[0]; kc[1] = kn[1]; uc[0] = un2[0]; uc[1] = un2[1];
+    for (int k = 0; k < 6; ++k) { xp[k] = x[k]; xo[k] = xoc[k]; }
     Pc = Pn;
     c = cn;
   }
