@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """bench.py --gpus N --steps K --warmup W [--workload demo1|cfg4]
 
-A step = one planning cycle of the MIND hot path on one synthetic scene: AIME scenario tree (every
-tree node through the HIP predictor) + tree-iLQR contingency solves (warm start + full) for every
-scenario tree + tree selection.  In the reference closed loop a plan is issued every 5th simulator
-step (10 Hz planner, 50 Hz simulator; agent.py:156-157, simulator.py:58-103), so
-sim steps/s = 5 x plans/s.  One process per GPU; ranks run independent scenes (weak scaling, no
+A step = one planning cycle of the closed loop on one synthetic scene (mind_amd.closed_loop, mirroring
+simulator.py:58-103 / agent.py:277-331): 5 simulator steps of 0.02 s (observation fan-out, 10 Hz planner
+trigger, ego plant) containing one MINDPlanner.plan() = AIME scenario tree (every tree node through the
+HIP predictor) + tree-iLQR contingency solves (warm start + full) for every scenario tree + selection.
+value = simulator steps / wall time.  One process per GPU; ranks run independent scenes (weak scaling, no
 data-path collective); rank 0 prints ONE JSON line.
 """
 import argparse
@@ -43,6 +43,21 @@ def make_planner(wkw, scripted=True):
     pl.update_target_lane(np.asarray(w.target_lane[::2], dtype=np.float64))
     pl.update_state_ctrl(lcl.ego_agent.state, np.array([0.0, 0.0]))
     return pl, lcl, w
+
+
+def make_closed_loop(wkw, scripted=True):
+    """planner + closed-loop simulator advanced to the enable time (t = 4.0 s: 40 observation updates)."""
+    from mind_amd.closed_loop import ClosedLoopSim
+    from mind_amd.planners.mind.planner import MINDPlanner
+    from mind_amd.synth import ScriptedBranching, SynthWorld
+    cfg = os.path.join(ROOT, "mind_amd", "planners", "mind", "configs", "synthetic.json")
+    w = SynthWorld(**wkw)
+    pl = MINDPlanner(cfg)
+    if scripted:
+        pl.scen_tree_gen.network = ScriptedBranching(pl.network)
+    sim = ClosedLoopSim(w, pl)
+    sim.run_until(4.0)
+    return pl, sim, w
 
 
 def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees):
@@ -101,12 +116,11 @@ def main():
     wkw = dict(WORKLOADS[args.workload])
     if not args.shard:
         wkw["seed"] = wkw["seed"] + rank      # every rank plans its own scene (weak scaling)
-    pl, lcl, w = make_planner(wkw)
+    pl, sim, w = make_closed_loop(wkw)
     if args.shard and dist is not None:
         pl.enable_sharding()
     rt = pl.network.rt
-    for _ in range(args.warmup):
-        pl.plan(lcl)
+    sim.run_plans(max(args.warmup, 1))
     rt.set_profiling(True)                     # HIP-event timing of the fusion pair kernels on the ctx stream
     pair_ms, pair_launch, pair_n2 = [], 0, 0.0
     expansions = 0
@@ -119,12 +133,12 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    res = None
-    for _ in range(args.steps):
-        res = pl.plan(lcl)
-        expansions += pl.timing["nodes_expanded"]
+    n0 = pl.scen_tree_gen.n_expanded
+    sim_steps = sim.run_plans(args.steps)            # K planning cycles = ~5K simulator steps
+    expansions = pl.scen_tree_gen.n_expanded - n0
     barrier()
     dt = time.perf_counter() - t0
+    lcl = sim._observation()
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -165,8 +179,7 @@ def main():
             traffic = json.load(open(pmc_path))["k_pair_per_launch"]["hbm_bytes"]
         except Exception:
             traffic = None
-    plans = args.steps * (1 if args.shard else world)
-    value = 5.0 * plans / dt
+    value = sim_steps * (1 if args.shard else world) / dt
     a = len(pl.agent_obs)
     l = gen.lane_feat_in.shape[0]
     out = {
@@ -178,8 +191,9 @@ def main():
         "config": {"workload": f"{args.workload}-like synthetic scene: {a} agents x {l} lane polylines (N={a+l+1} tokens), "
                                f"one closed-loop planning cycle per step = AIME tree ({expansions // args.steps} node expansions, "
                                f"scripted mode branching on top of the real predictor forward: no trained checkpoint exists) + "
-                               f"tree-iLQR warm+full solves of {pl.timing['n_scen_trees']} scenario trees; 5 sim steps per plan",
-                   "agents": a, "lane_polylines": l, "expansions_per_plan": expansions // args.steps,
+                               f"tree-iLQR warm+full solves of {pl.timing['n_scen_trees']} scenario trees; closed loop: {sim_steps} simulator steps "
+                               f"(0.02 s) for {args.steps} plans",
+                   "agents": a, "lane_polylines": l, "expansions_per_plan": expansions // args.steps, "sim_steps_timed": sim_steps,
                    "scenario_trees_per_plan": pl.timing["n_scen_trees"], "parallelism": f"{world} independent scenes (one per GPU)"},
         "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_F32_MFMA, "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_k_pair.json)", "kernel": "k_pair (RelaFusionLayer pair kernel)",

@@ -1,0 +1,90 @@
+"""Headless closed-loop driver: the reference's simulator loop and MINDAgent trigger logic
+without rendering, so that "sim steps/s" can be measured on the GPU box where the reference harness
+cannot travel.
+
+Mirrors: Simulator.run_sim (simulator.py:51-107; 0.02 s steps), CustomizedAgent.check_trigger /
+check_enable (agent.py:255-286; planner at 10 Hz with plan_step = 0.1 - 1e-4, enabled from t = 4.0 s),
+MINDAgent.plan / update_observation (agent.py:324-331) and the ego plant kine_propagate
+(common/kinematics.py:22-36 with the simulator's wheelbase 3.0, max speed 15 m/s, max steer 45 deg;
+agent.py:298-299 -- the planner itself uses wheelbase 2.5, Q16).
+Exo agents replay the synthetic world's trajectories (the reference replays recorded AV2 tracks).
+"""
+from types import SimpleNamespace
+
+import numpy as np
+
+
+def kine_propagate(state, ctrl, dt, wb=2.5, max_spd=20.0, max_steer=np.deg2rad(45.0), max_acc=6.0, max_dec=-6.0):
+    x, y, v, yaw = state
+    a, delta = ctrl
+    a = np.clip(a, max_dec, max_acc)
+    delta = np.clip(delta, -max_steer, max_steer)
+    out = np.array([x + v * np.cos(yaw) * dt, y + v * np.sin(yaw) * dt, v + a * dt, yaw + v / wb * np.tan(delta) * dt])
+    out[2] = np.clip(out[2], -max_spd, max_spd)
+    return out
+
+
+class ClosedLoopSim:
+    SIM_STEP = 0.02
+    PLAN_STEP = 1.0 / 10 - 1e-4
+    WB, MAX_SPD, MAX_STR = 3.0, 15.0, np.deg2rad(45.0)
+
+    def __init__(self, world, planner, enable_time=4.0):
+        self.world = world
+        self.planner = planner
+        self.enable_time = enable_time
+        self.sim_time = 0.0
+        self.n_steps = 0
+        self.n_plans = 0
+        self.enabled = False
+        self.last_trigger = None
+        self.state = world.agent_state(0, 0.0)          # (x, y, v, yaw)
+        self.ctrl = np.array([0.0, 0.0])
+        self.timestep = 0.0
+        self.last_result = None
+        planner.update_target_lane(np.asarray(world.target_lane[::2], dtype=np.float64))
+
+    def _observation(self):
+        t = self.sim_time
+        w = self.world
+        ego_state = self.state if self.enabled else w.agent_state(0, t)
+        ego = SimpleNamespace(state=ego_state, type=w.object_type(0), id="AV", timestep=int(round(t / 0.1)))
+        exo = [SimpleNamespace(state=w.agent_state(i, t), type=w.object_type(i), id=w.agent_ids[i],
+                               timestep=int(round(t / 0.1))) for i in range(1, w.n_agents)]
+        return SimpleNamespace(ego_agent=ego, exo_agents=exo, map_data=w, target_lane=w.target_lane,
+                               target_lane_info=w.target_lane_info, target_velocity=w.target_velocity)
+
+    def step(self):
+        """One simulator step (0.02 s).  Returns True if a plan was computed in this step."""
+        planned = False
+        if self.sim_time >= self.enable_time and not self.enabled:
+            self.enabled = True                                  # check_enable: take over from the recording
+            self.state = self.world.agent_state(0, self.sim_time)
+            self.ctrl = np.array([0.0, 0.0])
+        if self.last_trigger is None or (self.sim_time - self.last_trigger) >= self.PLAN_STEP:
+            self.last_trigger = self.sim_time
+            lcl = self._observation()
+            self.planner.update_observation(lcl)
+            if self.enabled:
+                self.planner.update_state_ctrl(lcl.ego_agent.state, self.ctrl)
+                ok, self.ctrl, self.last_result = self.planner.plan(lcl)
+                if not ok:
+                    raise RuntimeError("plan failed")
+                self.n_plans += 1
+                planned = True
+        if self.enabled:
+            self.state = kine_propagate(self.state, self.ctrl, self.SIM_STEP, self.WB, self.MAX_SPD, self.MAX_STR)
+        self.sim_time += self.SIM_STEP
+        self.n_steps += 1
+        return planned
+
+    def run_until(self, t_end):
+        while self.sim_time < t_end - 1e-9:
+            self.step()
+
+    def run_plans(self, n):
+        """advance until n more plans were computed; returns the number of simulator steps taken."""
+        s0, p0 = self.n_steps, self.n_plans
+        while self.n_plans - p0 < n:
+            self.step()
+        return self.n_steps - s0

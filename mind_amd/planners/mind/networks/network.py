@@ -16,6 +16,7 @@ class ScenePredNet:
         idx = device.index if isinstance(device, torch.device) and device.index is not None else 0
         self.rt = get_runtime(idx)
         self.last_lane_feat = None
+        self.last_packed = None
         self._loaded = False
 
     # torch.nn.Module look-alikes -----------------------------------------------------------------
@@ -76,6 +77,7 @@ class ScenePredNet:
             self.last_lane_feat = d["lane_feat"][:d["l_off"][1]]
         else:
             self.last_lane_feat = None
+        self.last_packed = {"n": B, "cls": o["cls"], "reg": o["reg"], "vel": o["vel"], "a_off": d["a_off"]}
         res_cls = [o["cls"][b:b + 1] for b in range(B)]
         res_reg = [o["reg"][d["a_off"][b]:d["a_off"][b + 1]] for b in range(B)]
         res_aux = [(o["vel"][d["a_off"][b]:d["a_off"][b + 1]], None, None) for b in range(B)]

@@ -117,6 +117,15 @@ class MINDPlanner:
                 tr.object_states.append(ObjectState(False, last.timestep, last.position, last.heading, last.velocity))
             if len(tr.object_states) > self.obs_len:
                 tr.object_states.pop(0)
+            # array mirror of the track [n, (observed, x, y, heading, vx, vy)] used by the featuriser
+            s = tr.object_states[-1]
+            row = np.array([[float(s.observed), s.position[0], s.position[1], s.heading, s.velocity[0], s.velocity[1]]])
+            arr = getattr(tr, "_arr", None)
+            arr = row if arr is None else np.concatenate([arr, row])[-self.obs_len:]
+            try:
+                tr._arr = arr
+            except AttributeError:      # immutable Track type: the featuriser falls back to the object list
+                pass
 
     def update_state_ctrl(self, state, ctrl):
         self.state = state

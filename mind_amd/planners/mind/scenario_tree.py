@@ -254,6 +254,14 @@ class ScenarioTreeGenerator:
 
     def prune_merge(self, scenes, out, idx_offset=0):
         res_cls_b, res_reg_b, res_aux_b = out
+        packed = getattr(self.network, "last_packed", None)
+        if packed is not None and packed["n"] == len(scenes):
+            # one device->host copy per tensor for the whole round instead of three per scene
+            cls_all, reg_all, vel_all = (_np(packed[k]) for k in ("cls", "reg", "vel"))
+            off = packed["a_off"]
+            res_cls_b = [cls_all[i:i + 1] for i in range(len(scenes))]
+            res_reg_b = [reg_all[off[i]:off[i + 1]] for i in range(len(scenes))]
+            res_aux_b = [(vel_all[off[i]:off[i + 1]], None, None) for i in range(len(scenes))]
         kept = []
         for lidx, sc in enumerate(scenes):
             idx = lidx + idx_offset      # position in the round's full batch (part of the node id)

@@ -73,8 +73,10 @@ def get_agent_trajectories(agent_obs):
         if states[-1].observed is False:
             continue
         n = len(states)
-        raw = np.array([(s.observed, s.position[0], s.position[1], s.heading, s.velocity[0], s.velocity[1])
-                        for s in states], dtype=float)
+        raw = getattr(agent_obs[key], "_arr", None)       # maintained incrementally by MINDPlanner.update_observation
+        if raw is None or len(raw) != n:
+            raw = np.array([(s.observed, s.position[0], s.position[1], s.heading, s.velocity[0], s.velocity[1])
+                            for s in states], dtype=float)
         obs = raw[:, 0] != 0
         ts = np.arange(OBS_LEN - n, OBS_LEN)[obs]
         have = np.zeros(OBS_LEN, bool)

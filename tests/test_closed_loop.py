@@ -1,0 +1,74 @@
+"""f1: closed-loop driver.  CPU: plant and trigger logic (plant pinned against the imported reference
+in the build container); GPU: a short closed loop with the real planner."""
+import numpy as np
+import pytest
+
+from mind_amd.closed_loop import ClosedLoopSim, kine_propagate
+from mind_amd.synth import SynthWorld
+from oracle import ref_harness as rh
+
+
+def test_kine_propagate_values():
+    s = kine_propagate(np.array([1.0, 2.0, 3.0, 0.5]), np.array([1.0, 0.1]), 0.02, 3.0, 15.0, np.deg2rad(45.0))
+    exp = np.array([1.0 + 3.0 * np.cos(0.5) * 0.02, 2.0 + 3.0 * np.sin(0.5) * 0.02, 3.02, 0.5 + 3.0 / 3.0 * np.tan(0.1) * 0.02])
+    assert np.allclose(s, exp, atol=1e-15)
+    s = kine_propagate(np.array([0, 0, 14.99, 0.0]), np.array([9.0, 2.0]), 0.02, 3.0, 15.0, np.deg2rad(45.0))
+    assert s[2] == 15.0 and np.isclose(s[3], 14.99 / 3.0 * np.tan(np.deg2rad(45.0)) * 0.02)     # clipped a, delta, v
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not rh.available(), reason="reference tree not present")
+def test_kine_propagate_matches_reference():
+    rh.install()
+    from common.kinematics import kine_propagate as ref
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        st, ct = rng.normal(size=4) * [10, 10, 5, 1], rng.normal(size=2) * [4, 0.5]
+        assert np.array_equal(ref(st, ct, 0.02, 3.0, 15.0, np.deg2rad(45.0)), kine_propagate(st, ct, 0.02, 3.0, 15.0, np.deg2rad(45.0)))
+
+
+class _StubPlanner:
+    def __init__(self):
+        self.obs, self.plans, self.lane = 0, [], None
+
+    def update_target_lane(self, lane):
+        self.lane = lane
+
+    def update_observation(self, lcl):
+        self.obs += 1
+
+    def update_state_ctrl(self, s, c):
+        self.sc = (np.array(s), np.array(c))
+
+    def plan(self, lcl):
+        self.plans.append(round(lcl.ego_agent.timestep * 0.1, 3))
+        return True, np.array([0.5, 0.0]), None
+
+
+def test_trigger_schedule_matches_reference_counts():
+    """500 steps of 0.02 s: 100 observation updates (10 Hz), 60 plans for t in [4, 10)."""
+    w = SynthWorld(n_agents=3, n_lanes=2, n_segs=6, seed=1)
+    p = _StubPlanner()
+    sim = ClosedLoopSim(w, p)
+    for _ in range(500):
+        sim.step()
+    assert p.obs == 100 and len(p.plans) == 60 and sim.n_plans == 60
+    assert abs(sim.state[2] - (w.agent_speed[0] + 0.5 * 0.02 * 300)) < 0.2 or sim.state[2] == 15.0    # accelerating ego
+
+
+@pytest.mark.gpu
+def test_closed_loop_with_real_planner():
+    import os
+    from mind_amd.planners.mind.planner import MINDPlanner
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pl = MINDPlanner(os.path.join(root, "mind_amd", "planners", "mind", "configs", "synthetic.json"))
+    w = SynthWorld(n_agents=6, n_lanes=3, n_segs=8, seed=1)
+    sim = ClosedLoopSim(w, pl)
+    sim.run_until(4.0)
+    steps = sim.run_plans(4)
+    assert steps in (16, 20, 21) and sim.n_plans == 4
+    scen, traj = sim.last_result
+    assert len(scen) == 1 and len(traj) == 1 and np.all(np.isfinite(sim.state))
+    # the ego stays near its lane over the 0.4 s driven
+    d = np.abs(w.lane_y(1, sim.state[0]) - sim.state[1])
+    assert d < 1.0
