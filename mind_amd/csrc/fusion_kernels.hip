@@ -323,6 +323,34 @@ __global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ job
       ln_pairs(mem, vtq, VT_GM, VT_BM, true);
       SCHED_FENCE();
 
+      // ---- edge update e' = LN_e(e + ReLU(LN(W_p mem + b_p)))   (network.py:201-202)
+      if (do_update) {
+        frag8 up;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) up[b] = *(const f32x4 *)(vtq + VT_BP + 16 * b);
+        gemm128(up, lds + LDS_WAP, mem, lane);
+        ln_pairs(up, vtq, VT_GP, VT_BEP, true);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) up[b] += ef[b];
+        ln_pairs(up, vtq, VT_GE, VT_BE, false);
+        // store through the staging buffer: full 256-byte row segments
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+          for (int b2 = 0; b2 < 4; ++b2) *(f32x4 *)(stage + sw_pos(lp, 4 * b2 + lq)) = up[4 * hf + b2];
+          LDS_FENCE();
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const int r = 4 * n + (ll >> 4);
+            const int cp = ll & 15;
+            const f32x4 v = *(const f32x4 *)(stage + sw_pos(r, cp));
+            if (i0 + r < N)
+              *(f32x4 *)(edge + (((size_t)J.edge_base + (size_t)(i0 + r) * N + j) << 7) + hf * 64 + cp * 4) = v;
+          }
+          LDS_FENCE();
+        }
+      }
+      SCHED_FENCE();
       // ---- attention scores s[hd] = qk[j][hd] . mem  (K projection folded into qk)
       LDS_FENCE();
 #pragma unroll
@@ -386,33 +414,6 @@ __global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ job
         LDS_FENCE();
       }
 
-      // ---- edge update e' = LN_e(e + ReLU(LN(W_p mem + b_p)))   (network.py:201-202)
-      if (do_update) {
-        frag8 up;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) up[b] = *(const f32x4 *)(vtq + VT_BP + 16 * b);
-        gemm128(up, lds + LDS_WAP, mem, lane);
-        ln_pairs(up, vtq, VT_GP, VT_BEP, true);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) up[b] += ef[b];
-        ln_pairs(up, vtq, VT_GE, VT_BE, false);
-        // store through the staging buffer: full 256-byte row segments
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-          for (int b2 = 0; b2 < 4; ++b2) *(f32x4 *)(stage + sw_pos(lp, 4 * b2 + lq)) = up[4 * hf + b2];
-          LDS_FENCE();
-#pragma unroll
-          for (int n = 0; n < 4; ++n) {
-            const int r = 4 * n + (ll >> 4);
-            const int cp = ll & 15;
-            const f32x4 v = *(const f32x4 *)(stage + sw_pos(r, cp));
-            if (i0 + r < N)
-              *(f32x4 *)(edge + (((size_t)J.edge_base + (size_t)(i0 + r) * N + j) << 7) + hf * 64 + cp * 4) = v;
-          }
-          LDS_FENCE();
-        }
-      }
     }  // tiles
 
     // ---- column partial: m[8], l[8], mbar[8][128]
