@@ -51,8 +51,8 @@ struct PairJob {
 #define LDS_WAP 16384
 #define LDS_STAGE 32768               // 4 waves x 1024 floats
 #define LDS_PTAB (LDS_STAGE + 4096)   // 4 waves x 128 floats
-#define LDS_SVEC (LDS_PTAB + 512)     // 4 waves x 128 floats
-#define LDS_VT (LDS_SVEC + 512)       // 896 floats
+#define LDS_SVEC (LDS_PTAB + 512)     // 4 waves x 136 floats (S[j] + 8 softmax rescale factors)
+#define LDS_VT (LDS_SVEC + 544)       // 896 floats
 #define LDS_RT (LDS_VT + VT_SIZE)     // rpe table 32 chunks x 8 x 4 = 1024 floats
 #define LDS_TOTAL (LDS_RT + 1024)     // 39808 floats = 159232 bytes (<= 163840)
 
@@ -119,6 +119,7 @@ __device__ __forceinline__ void ln_pairs(frag8 &a, const float *vtq, int off_g, 
       if (relu) y = fmaxf(y, 0.f);
       a[b][w] = y;
     }
+    if (b & 1) SCHED_FENCE();
   }
 }
 
@@ -158,6 +159,14 @@ __device__ __forceinline__ int sw_pos(int r, int c) { return (r * 16 + (c ^ (r &
 // MODE 1: layers 1..5, edge read from HBM
 // update_mode 0: update every edge; 1: update only flagged columns; 2: run only flagged columns,
 // no edge update (last layer).
+#ifdef MIND_PAIR_TRACE
+#define PT_DECL long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pt_t = clock64();
+#define PT(i) do { long long n_ = clock64(); pt_[i] += n_ - pt_t; pt_t = n_; } while (0)
+#else
+#define PT_DECL
+#define PT(i)
+#endif
+
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ jobs, int n_jobs,
                                                  float *__restrict__ edge, const float *__restrict__ ST,
@@ -185,9 +194,10 @@ __global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ job
 
   float *stage = lds + LDS_STAGE + wave * 1024;
   float *ptab = lds + LDS_PTAB + wave * 128;
-  float *svec = lds + LDS_SVEC + wave * 128;
+  float *svec = lds + LDS_SVEC + wave * 136;
   const float *vt = lds + LDS_VT;
 
+  PT_DECL
   for (int job = blockIdx.x * 4 + wave; job < n_jobs; job += gridDim.x * 4) {
     const PairJob J = jobs[job];
     if (update_mode == 2 && !(J.flags & 1)) continue;
@@ -196,9 +206,22 @@ __global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ job
     const int j = J.j;
     LDS_FENCE();
     if (lane < 32) *(f32x4 *)(svec + lane * 4) = *(const f32x4 *)(ST + (size_t)(J.tok_base + j) * 256 + lane * 4);
-    float m_run[8], l_part[8];
+    // this lane's 4 heads (lane quarter q < 2: heads 4q..4q+3; quarters 2,3 carry MFMA padding rows)
+    float m_run[4], l_part[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { m_run[k] = -INFINITY; l_part[k] = 0.f; }
+    for (int k = 0; k < 4; ++k) { m_run[k] = -INFINITY; l_part[k] = 0.f; }
+    // A fragment of the folded query (W_k^T q / 4): row = head (8 used of 16), k-slot = feature
+    f32x4 qfrag[8];
+    {
+      const int hd = lane & 15;
+      const float *qp = QK + (size_t)(J.tok_base + j) * 1024 + (hd & 7) * 128 + 4 * q;
+#pragma unroll
+      for (int s4 = 0; s4 < 8; ++s4) {
+        f32x4 v = *(const f32x4 *)(qp + 16 * s4);
+        if (hd >= 8) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        qfrag[s4] = v;
+      }
+    }
     float mbar[2][8];  // feature 64*hf + lane, head
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
@@ -305,11 +328,13 @@ __global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ job
         }
       }
 
+      PT(0);
       // ---- memory = ReLU(LN(W_e e + S[j] + T[i]))   (network.py:197-199, rank-decomposed)
       frag8 mem;
 #pragma unroll
       for (int b = 0; b < 8; ++b) mem[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
       gemm128(mem, lds + LDS_WAE, ef, lane);
+      PT(1);
       {
         const float *Ti = ST + (size_t)(J.tok_base + ic) * 256 + 128 + lq * 4;
         const float *svq = svec + lq * 4;
@@ -318,17 +343,21 @@ __global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ job
           const f32x4 t4 = *(const f32x4 *)(Ti + 16 * b);
           const f32x4 s4 = *(const f32x4 *)(svq + 16 * b);
           mem[b] += t4 + s4;
+          if ((b & 3) == 3) SCHED_FENCE();
         }
       }
       ln_pairs(mem, vtq, VT_GM, VT_BM, true);
       SCHED_FENCE();
+      PT(2);
 
+      PT(5);
       // ---- edge update e' = LN_e(e + ReLU(LN(W_p mem + b_p)))   (network.py:201-202)
       if (do_update) {
         frag8 up;
 #pragma unroll
         for (int b = 0; b < 8; ++b) up[b] = *(const f32x4 *)(vtq + VT_BP + 16 * b);
         gemm128(up, lds + LDS_WAP, mem, lane);
+        PT(6);
         ln_pairs(up, vtq, VT_GP, VT_BEP, true);
 #pragma unroll
         for (int b = 0; b < 8; ++b) up[b] += ef[b];
@@ -351,47 +380,51 @@ __global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ job
         }
       }
       SCHED_FENCE();
-      // ---- attention scores s[hd] = qk[j][hd] . mem  (K projection folded into qk)
-      LDS_FENCE();
+      // ---- attention scores on the MFMA: S^T[head, pair] = QK_j[head, :] . mem^T[:, pair]; the memory
+      //      tile is already the B operand (chained layout).  Two accumulators hide the 40-cycle latency.
+      f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, sb = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
-        *(f32x4 *)(stage + (n * 64 + ll) * 4) = *(const f32x4 *)(QK + (size_t)(J.tok_base + j) * 1024 + (n * 64 + ll) * 4);
-      LDS_FENCE();
-      float sc[8];
+      for (int s4 = 0; s4 < 8; s4 += 2)
 #pragma unroll
-      for (int hd = 0; hd < 8; ++hd) {
-        float s = 0.f;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-          const f32x4 qv = *(const f32x4 *)(stage + lq * 4 + hd * 128 + 16 * b);
-#pragma unroll
-          for (int w = 0; w < 4; ++w) s = fmaf(qv[w], mem[b][w], s);
+        for (int w = 0; w < 4; ++w) {
+          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(qfrag[s4][w], mem[s4][w], sa, 0, 0, 0);
+          sb = __builtin_amdgcn_mfma_f32_16x16x4f32(qfrag[s4 + 1][w], mem[s4 + 1][w], sb, 0, 0, 0);
         }
-        s = red_quad(s);
-        sc[hd] = valid ? s : -INFINITY;
-        if (hd & 1) SCHED_FENCE();
-      }
-      // ---- online softmax over i
-      float pr[8];
+      sa += sb;       // lane (p, q): rows 4q..4q+3 = heads 4q..4q+3 of pair p (q < 2)
+      PT(3);
+      // ---- online softmax over i: lanes of quarter q own heads 4q..4q+3
+      float pr[4], scl[4];
 #pragma unroll
-      for (int hd = 0; hd < 8; ++hd) {
-        const float mx = red_max16(sc[hd]);
-        const float m_new = fmaxf(m_run[hd], mx);
-        const float scale = __expf(m_run[hd] - m_new);
-        pr[hd] = valid ? __expf(sc[hd] - m_new) : 0.f;
-        l_part[hd] = l_part[hd] * scale + pr[hd];
-        mbar[0][hd] *= scale;
-        mbar[1][hd] *= scale;
-        m_run[hd] = m_new;
+      for (int r = 0; r < 4; ++r) {
+        const float sv = valid ? sa[r] : -INFINITY;
+        const float mx = red_max16(sv);
+        const float m_new = fmaxf(m_run[r], mx);
+        scl[r] = __expf(m_run[r] - m_new);
+        pr[r] = valid ? __expf(sv - m_new) : 0.f;
+        l_part[r] = l_part[r] * scl[r] + pr[r];
+        m_run[r] = m_new;
       }
       LDS_FENCE();
-      if (q == 0) {
-        f32x4 a, b;
+      if (q < 2) {
+        f32x4 a;
         a[0] = pr[0]; a[1] = pr[1]; a[2] = pr[2]; a[3] = pr[3];
-        b[0] = pr[4]; b[1] = pr[5]; b[2] = pr[6]; b[3] = pr[7];
-        *(f32x4 *)(ptab + p * 8) = a;
-        *(f32x4 *)(ptab + p * 8 + 4) = b;
+        *(f32x4 *)(ptab + p * 8 + 4 * q) = a;
+        if (p == 0) {
+          f32x4 b;
+          b[0] = scl[0]; b[1] = scl[1]; b[2] = scl[2]; b[3] = scl[3];
+          *(f32x4 *)(svec + 128 + 4 * q) = b;        // rescale factors, broadcast through LDS
+        }
       }
+      LDS_FENCE();
+      {
+        const f32x4 s0 = *(const f32x4 *)(svec + 128), s1 = *(const f32x4 *)(svec + 132);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          mbar[0][k] *= s0[k]; mbar[1][k] *= s0[k];
+          mbar[0][k + 4] *= s1[k]; mbar[1][k + 4] *= s1[k];
+        }
+      }
+      PT(4);
       // ---- mbar[hd][f] += sum_pairs p[pair][hd] * mem[pair][f]  (V projection folded out),
       //      transposing mem through the staging buffer one 64-feature half at a time
 #pragma unroll
@@ -414,20 +447,26 @@ __global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ job
         LDS_FENCE();
       }
 
+      PT(7);
     }  // tiles
 
     // ---- column partial: m[8], l[8], mbar[8][128]
     float *po = part + (size_t)J.slot * PART_STRIDE;
 #pragma unroll
-    for (int hd = 0; hd < 8; ++hd) {
-      const float l = red_sum16(l_part[hd]);
-      if (lane == 0) { po[hd] = m_run[hd]; po[8 + hd] = l; }
+    for (int r = 0; r < 4; ++r) {
+      const float l = red_sum16(l_part[r]);
+      if (p == 0 && q < 2) { po[4 * q + r] = m_run[r]; po[8 + 4 * q + r] = l; }
     }
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
       for (int hd = 0; hd < 8; ++hd) po[16 + hd * 128 + hf * 64 + lane] = mbar[hf][hd];
   }
+#ifdef MIND_PAIR_TRACE
+  if (blockIdx.x == 0 && tid == 0)
+    printf("[k_pair<%d> um=%d] cycles: load %lld gemm1 %lld T+LN1 %lld scores %lld softmax %lld mbar %lld gemm2 %lld LN23+store %lld\n", MODE,
+           update_mode, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[5], pt_[6], pt_[7]);
+#endif
 }
 
 template __global__ void k_pair<0>(const PairJob *, int, float *, const float *, const float *, float *,
@@ -479,42 +518,6 @@ __device__ __forceinline__ float block_sum128(float v, float *red, int tid) {
   return red[0] + red[1];
 }
 
-__device__ __forceinline__ float wsum64(float v) {
-  v += __shfl_xor(v, 32, 64);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 8, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 1, 64);
-  return v;
-}
-
-// LayerNorm statistics of TPW token rows at once (128 threads = one feature each): 4 barriers per
-// LayerNorm instead of 4 per token.  On exit pre[t] = (pre[t] - mean_t) and rstd[t] is set.
-__device__ __forceinline__ void ln_stats_multi(float (&pre)[TPW], float (&rstd)[TPW], float *red2, int tid) {
-  float s[TPW];
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) s[t] = wsum64(pre[t]);
-  __syncthreads();
-  if ((tid & 63) == 0)
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) red2[(tid >> 6) * TPW + t] = s[t];
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    const float mean = (red2[t] + red2[TPW + t]) * (1.0f / 128.0f);
-    pre[t] -= mean;
-    s[t] = wsum64(pre[t] * pre[t]);
-  }
-  __syncthreads();
-  if ((tid & 63) == 0)
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) red2[(tid >> 6) * TPW + t] = s[t];
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) rstd[t] = 1.0f / sqrtf((red2[t] + red2[TPW + t]) * (1.0f / 128.0f) + 1e-5f);
-}
-
 // y[t][tid] = sum_k WT[k*ldo + tid] * xin[t][k]  for t < TPW   (xin in LDS, row stride ldx)
 template <int K>
 __device__ __forceinline__ void matvec(float (&acc)[TPW], const float *__restrict__ WT, int ldo, int col,
@@ -537,7 +540,6 @@ __global__ __launch_bounds__(128) void k_token(const TokMeta *__restrict__ meta,
   __shared__ float tmp[TPW][260];       // scratch (o / h1 up to 256 wide)
   __shared__ float mb[TPW][8][132];     // normalised sum p*mem per head
   __shared__ float red[2];
-  __shared__ float red2[2 * TPW];
   __shared__ float cw[TPW][8][8];       // combine weights per (token, head, split<=8)
   const int tid = threadIdx.x;
   const int tok0 = blockIdx.x * TPW;
@@ -561,22 +563,19 @@ __global__ __launch_bounds__(128) void k_token(const TokMeta *__restrict__ meta,
     for (int t = 0; t < TPW; ++t) { aa[t] = W.bpa[tid]; al[t] = W.bpl[tid]; }
     matvec<128>(aa, W.WpaT, 128, tid, &tmp[0][0], 260);
     matvec<128>(al, W.WplT, 128, tid, &tmp[0][0], 260);
-    {
-      int types[TPW];
-      float pre[TPW], rs[TPW];
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) {
-        types[t] = (t < nt) ? meta[tok0 + t].type : 2;
-        pre[t] = types[t] == 0 ? aa[t] : al[t];
-      }
-      ln_stats_multi(pre, rs, red2, tid);
-      const float ga = W.gpa[tid], ba = W.bepa[tid], gl = W.gpl[tid], bl = W.bepl[tid];
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) {
-        float y = fmaxf(pre[t] * rs[t] * (types[t] == 0 ? ga : gl) + (types[t] == 0 ? ba : bl), 0.f);
-        if (types[t] == 2) y = 0.f;
-        xs[t][tid] = y;
-      }
+    for (int t = 0; t < TPW; ++t) {
+      int type = 2;
+      if (t < nt) type = meta[tok0 + t].type;
+      const float pre = type == 0 ? aa[t] : al[t];
+      const float mean = block_sum128(pre, red, tid) * (1.0f / 128.0f);
+      const float d = pre - mean;
+      const float var = block_sum128(d * d, red, tid) * (1.0f / 128.0f);
+      const float rstd = 1.0f / sqrtf(var + 1e-5f);
+      const float g = type == 0 ? W.gpa[tid] : W.gpl[tid];
+      const float b = type == 0 ? W.bepa[tid] : W.bepl[tid];
+      float y = fmaxf(d * rstd * g + b, 0.f);
+      if (type == 2) y = 0.f;
+      xs[t][tid] = y;
     }
     __syncthreads();
   } else {
@@ -611,43 +610,19 @@ __global__ __launch_bounds__(128) void k_token(const TokMeta *__restrict__ meta,
       for (int s = 0; s < 8; ++s) cw[t][hd][s] = wgt[s];
     }
     __syncthreads();
-    {
-      // all (token, head) accumulators advance together over the split index, so that up to 64
-      // independent loads are in flight per thread (the serial version was latency-bound)
-      __shared__ int s_ns[TPW], s_slot0[TPW];
-      if (tid < TPW) {
-        int ns = 0, slot0 = 0;
-        if (tid < nt) {
-          const TokMeta m = meta[tok0 + tid];
-          ns = ((mode & 8) && !(m.flags & 1)) ? 0 : m.nsplit;
-          slot0 = m.slot0;
-        }
-        s_ns[tid] = ns;
-        s_slot0[tid] = slot0;
+    for (int t = 0; t < TPW; ++t) {
+      int ns = 0, slot0 = 0;
+      if (t < nt) {
+        const TokMeta m = meta[tok0 + t];
+        ns = ((mode & 8) && !(m.flags & 1)) ? 0 : m.nsplit;
+        slot0 = m.slot0;
       }
-      __syncthreads();
-      float v[TPW][8];
-#pragma unroll
-      for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int hd = 0; hd < 8; ++hd) v[t][hd] = 0.f;
-      int nsmax = 0;
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) nsmax = max(nsmax, s_ns[t]);
-      for (int sp = 0; sp < nsmax; ++sp) {
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-          if (sp < s_ns[t]) {
-            const float *ps = part + (size_t)(s_slot0[t] + sp) * PART_STRIDE + 16 + tid;
-#pragma unroll
-            for (int hd = 0; hd < 8; ++hd) v[t][hd] = fmaf(cw[t][hd][sp], ps[hd * 128], v[t][hd]);
-          }
-        }
+      for (int hd = 0; hd < 8; ++hd) {
+        float v = 0.f;
+        for (int s = 0; s < ns; ++s)
+          v = fmaf(cw[t][hd][s], part[(size_t)(slot0 + s) * PART_STRIDE + 16 + hd * 128 + tid], v);
+        mb[t][hd][tid] = v;
       }
-#pragma unroll
-      for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int hd = 0; hd < 8; ++hd) mb[t][hd][tid] = v[t][hd];
     }
     __syncthreads();
     // ---- o = W_v,h mbar_h + b_v  (thread f = hd*16+d uses head hd = f>>4)
@@ -675,12 +650,13 @@ __global__ __launch_bounds__(128) void k_token(const TokMeta *__restrict__ meta,
       for (int t = 0; t < TPW; ++t) acc[t] = b;
       matvec<128>(acc, W.WoT, 128, tid, &tmp[0][0], 260);
       const float g = W.g2[tid], be = W.b2[tid];
-      float pre[TPW], rs[TPW];
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) pre[t] = xs[t][tid] + acc[t];
-      ln_stats_multi(pre, rs, red2, tid);
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) xs[t][tid] = pre[t] * rs[t] * g + be;
+      for (int t = 0; t < TPW; ++t) {
+        const float pre = xs[t][tid] + acc[t];
+        const float mean = block_sum128(pre, red, tid) * (1.0f / 128.0f);
+        const float d = pre - mean;
+        const float var = block_sum128(d * d, red, tid) * (1.0f / 128.0f);
+        xs[t][tid] = d * (1.0f / sqrtf(var + 1e-5f)) * g + be;
+      }
       __syncthreads();
     }
     // ---- FFN 128 -> 256 -> 128, x2 = LN3(x1 + ff)
@@ -700,12 +676,13 @@ __global__ __launch_bounds__(128) void k_token(const TokMeta *__restrict__ meta,
       for (int t = 0; t < TPW; ++t) acc[t] = b;
       matvec<256>(acc, W.W2T, 128, tid, &tmp[0][0], 260);
       const float g = W.g3[tid], be = W.b3[tid];
-      float pre[TPW], rs[TPW];
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) pre[t] = xs[t][tid] + acc[t];
-      ln_stats_multi(pre, rs, red2, tid);
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) xs[t][tid] = pre[t] * rs[t] * g + be;
+      for (int t = 0; t < TPW; ++t) {
+        const float pre = xs[t][tid] + acc[t];
+        const float mean = block_sum128(pre, red, tid) * (1.0f / 128.0f);
+        const float d = pre - mean;
+        const float var = block_sum128(d * d, red, tid) * (1.0f / 128.0f);
+        xs[t][tid] = d * (1.0f / sqrtf(var + 1e-5f)) * g + be;
+      }
       __syncthreads();
     }
   }
