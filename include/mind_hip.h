@@ -106,6 +106,11 @@ typedef struct {
   int n_agents;             /* a (agent 0 = ego)                                                  */
   const float *agent_mean;  /* HOST [M, a, 2] predicted mean of every agent at the node's step    */
   const float *agent_cov;   /* HOST [M, a]    max-sigma                                           */
+  /* generic mode only (mind_ilqr_solve_fields / mind_cost_eval with a grid), NULL otherwise:        */
+  const double *field;      /* HOST [M, H, W] cost_field of each node's PotentialField             */
+  const double *node_w;     /* HOST [M, 32]  per node: diag w_des[6], diag w_con[6], lower[6],     */
+                            /*   upper[6], diag w_ctrl[2], des_state[6] (StatePotential,           */
+                            /*   StateConstraint, ControlPotential of ilqr/potential.py:4-59)      */
 } mind_cost_tree;
 
 typedef struct {
@@ -128,6 +133,39 @@ int mind_ilqr_solve_trees(mind_ctx *ctx, const mind_ilqr_cfg *cfg, const mind_co
                           int n_trees, const double *x0, const double *target_lane, int n_lane_pts,
                           double target_vel, int use_exo, const double *us_init, double *xs,
                           double *us, mind_ilqr_stats *stats);
+
+/* ------------------------------------------------------------------------------------------------
+ * planners/ilqr call surface (iLQR.fit over a TreeCost of arbitrary PotentialField / StatePotential /
+ * StateConstraint / ControlPotential objects; solver.py:80-167, cost.py:326-446, potential.py:62-264).
+ * The grid is what PotentialField.__init__ receives: field_offset, resolution, xx[0,:], yy[:,0].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int W, H;                 /* cost_field.shape = (H, W)                                          */
+  double res;               /* resolution                                                         */
+  double off_x, off_y;      /* field_offset                                                       */
+  const double *gx, *gy;    /* HOST [W] = xx[0,:], [H] = yy[:,0]                                  */
+} mind_field_grid;
+
+/* gen_dist_field (ilqr/utils.py:5-22): grid of W x H centroids centred on ego_xy, distance of each to
+ * the polyline `lane` [n_pts,2].  Outputs HOST offset[2] (field_offset), gx[W] (= xx[0,:]), gy[H]
+ * (= yy[:,0]), dist[H,W]. */
+int mind_lane_dist_field(mind_ctx *ctx, const double *ego_xy, const double *lane, int n_pts, int W, int H,
+                         double res, double *offset, double *gx, double *gy, double *dist);
+
+/* iLQR.fit on trees whose nodes carry materialised cost fields and their own quadratic potentials
+ * (tree[i].field / .node_w set; .prob / agents ignored).  cfg supplies dt, wheelbase, max_iter only. */
+int mind_ilqr_solve_fields(mind_ctx *ctx, const mind_ilqr_cfg *cfg, const mind_field_grid *grid,
+                           const mind_cost_tree *trees, int n_trees, const double *x0,
+                           const double *us_init, double *xs, double *us, mind_ilqr_stats *stats);
+
+/* TreeCost.l / l_x / l_u / l_xx / l_uu (cost.py:341-446) of ONE tree at arbitrary points:
+ * out HOST [n_query, 47] = { l, l_x[6], l_u[2], l_xx[36] row-major, diag l_uu[2] } for node[q] at
+ * (x[q], u[q]).  grid == NULL: planner mode (fields from prob / agents / target lane as in
+ * mind_ilqr_solve_trees); grid != NULL: generic mode (tree->field / node_w; lane arguments ignored). */
+int mind_cost_eval(mind_ctx *ctx, const mind_ilqr_cfg *cfg, const mind_field_grid *grid,
+                   const mind_cost_tree *tree, const double *x0, const double *target_lane,
+                   int n_lane_pts, double target_vel, int use_exo, int n_query,
+                   const int32_t *node, const double *x, const double *u, double *out);
 
 #ifdef __cplusplus
 }

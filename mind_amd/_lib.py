@@ -30,7 +30,13 @@ class PredOut(C.Structure):
 
 class CostTree(C.Structure):
     _fields_ = [("n_nodes", C.c_int), ("parent", C.POINTER(C.c_int32)), ("prob", C.POINTER(C.c_float)),
-                ("n_agents", C.c_int), ("agent_mean", C.POINTER(C.c_float)), ("agent_cov", C.POINTER(C.c_float))]
+                ("n_agents", C.c_int), ("agent_mean", C.POINTER(C.c_float)), ("agent_cov", C.POINTER(C.c_float)),
+                ("field", C.POINTER(C.c_double)), ("node_w", C.POINTER(C.c_double))]
+
+
+class FieldGrid(C.Structure):
+    _fields_ = [("W", C.c_int), ("H", C.c_int), ("res", C.c_double), ("off_x", C.c_double), ("off_y", C.c_double),
+                ("gx", C.POINTER(C.c_double)), ("gy", C.POINTER(C.c_double))]
 
 
 class IlqrCfg(C.Structure):
@@ -48,7 +54,8 @@ class IlqrStats(C.Structure):
 
 EXPORTS = ["mind_ctx_create", "mind_ctx_destroy", "mind_last_error_string", "mind_ctx_synchronize",
            "mind_weights_load", "mind_predict_batch", "mind_last_fusion_stats", "mind_set_profiling",
-           "mind_ilqr_solve_trees", "mind_debug_set_layers", "mind_debug_read"]
+           "mind_ilqr_solve_trees", "mind_ilqr_solve_fields", "mind_cost_eval", "mind_lane_dist_field", "mind_debug_set_layers",
+           "mind_debug_read"]
 
 _lib = None
 
@@ -75,6 +82,14 @@ def load():
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_double, C.c_int,
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.POINTER(IlqrStats)]
+    lib.mind_ilqr_solve_fields.argtypes = [C.c_void_p, C.POINTER(IlqrCfg), C.POINTER(FieldGrid), C.POINTER(CostTree), C.c_int,
+                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double), C.POINTER(IlqrStats)]
+    lib.mind_cost_eval.argtypes = [C.c_void_p, C.POINTER(IlqrCfg), C.POINTER(FieldGrid), C.POINTER(CostTree),
+                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_double, C.c_int, C.c_int,
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.mind_lane_dist_field.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int,
+                                         C.c_double] + [C.POINTER(C.c_double)] * 4
     lib.mind_debug_set_layers.argtypes = [C.c_void_p, C.c_int]
     lib.mind_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64]
     for n in EXPORTS:

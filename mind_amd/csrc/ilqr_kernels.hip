@@ -52,6 +52,9 @@ struct IlqrTreeDev {
   double *k, *K, *Vx, *Vxx;                                   // [IL_SPEC][M,*]  (one set per speculative mu)
   double *xs_new, *us_new, *L_new;                            // [IL_SPEC][NA,M,*]
   int *rel;                 // [M, IL_REL+1]: count (or -1 = overflow) + agent indices near the nominal state
+  // generic mode (planners/ilqr surface: arbitrary materialised fields + per-node diagonal weights)
+  const double *field;      // [M, H*W] cost_field of every node's PotentialField, or null
+  const double *node_w;     // [M, IL_NW]: w_des[6] w_con[6] lb[6] ub[6] w_ctrl[2] des[6], or null
   // outputs
   double *stats;            // [4]: iterations, converged, J, mu
 };
@@ -76,7 +79,7 @@ __device__ __forceinline__ double il_shfl_down(double v, int d) {
 
 // ---- lane distance field: d(c)^2 = min over segments (ilqr/utils.py:5-22, geometry.py:70-78) ----
 __global__ void k_lane_field(const double *__restrict__ gx, const double *__restrict__ gy, int W, int H,
-                             const double *__restrict__ lane, int P, double *__restrict__ quad) {
+                             const double *__restrict__ lane, int P, double *__restrict__ quad, int squared = 1) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= W * H) return;
   const double px = gx[idx % W], py = gy[idx / W];
@@ -91,7 +94,7 @@ __global__ void k_lane_field(const double *__restrict__ gx, const double *__rest
     const double dj = sqrt(dx * dx + dy * dy);
     d = dj < d ? dj : d;
   }
-  quad[idx] = d * d;
+  quad[idx] = squared ? d * d : d;
 }
 
 // ---- 3x3 window placement, reproducing potential.py:126-144 exactly (Q4: borders are NOT zero
@@ -112,6 +115,22 @@ __device__ __forceinline__ void il_window_src(int xi, int yi, int W, int H, int 
 
 struct FieldOut { double val, gx, gy, hxx, hyy, hxy; };
 
+// Quadratic-potential parameters of one trajectory node (potential.py:4-59).  GEN = false: the planner's
+// uniform structure, config weight x node probability (trajectory_tree.py:38-46, product in float64 as
+// numpy computes it); GEN = true: arbitrary diagonal weights per node, read from T.node_w.
+#define IL_NW 32
+template <bool GEN> struct IlNodeW {
+  const IlqrConst &C;
+  const double *w;
+  double p;
+  __device__ __forceinline__ double wdes(int k) const { return GEN ? w[k] : C.w_des[k] * p; }
+  __device__ __forceinline__ double wcon(int k) const { return GEN ? w[6 + k] : C.w_con[k] * p; }
+  __device__ __forceinline__ double lb(int k) const { return GEN ? w[12 + k] : C.lb[k]; }
+  __device__ __forceinline__ double ub(int k) const { return GEN ? w[18 + k] : C.ub[k]; }
+  __device__ __forceinline__ double wctrl(int k) const { return GEN ? w[24 + k] : C.w_ctrl[k] * p; }
+  __device__ __forceinline__ double des(int k) const { return GEN ? w[26 + k] : (k == 2 ? C.target_vel : 0.0); }
+};
+
 // Stage node i's agents into the wave's LDS table ag[e] = {mean_x, mean_y, sigma_e + offset (f32 add,
 // as the reference computes it), early-out threshold}: entry 0 = ego (offset w_ego_cov_offset).
 __device__ __forceinline__ void il_stage_agents(const IlqrConst &C, const IlqrTreeDev &T, int i, double *ag) {
@@ -131,6 +150,7 @@ __device__ __forceinline__ void il_stage_agents(const IlqrConst &C, const IlqrTr
 
 // Cooperative (one wave) evaluation of node `i`'s potential field at (px, py).
 // cells[9] (LDS, per wave) receives the raw window; every lane returns the same FieldOut.
+template <bool GEN>
 __device__ __forceinline__ void il_field(const IlqrConst &C, const IlqrTreeDev &T, int i, double px, double py,
                                          double *scr /* >= 64+9 doubles, per wave */, const double *ag, bool want_deriv, FieldOut &o) {
   const int lane = threadIdx.x & 63;
@@ -138,7 +158,7 @@ __device__ __forceinline__ void il_field(const IlqrConst &C, const IlqrTreeDev &
   long yi = (long)rint((py - C.off_y) / C.res);
   xi = xi < 0 ? 0 : (xi > C.W - 1 ? C.W - 1 : xi);
   yi = yi < 0 ? 0 : (yi > C.H - 1 ? C.H - 1 : yi);
-  const float pf = T.prob[i];
+  const float pf = GEN ? 0.f : T.prob[i];
   const double wp = (double)((float)C.w_tgt * pf);
   // lanes 0..62: cell = lane % 9, agent slot = lane / 9 (7 slots)
   const int cell = lane % 9, slot = lane / 9;
@@ -164,7 +184,9 @@ __device__ __forceinline__ void il_field(const IlqrConst &C, const IlqrTreeDev &
   if (lane < 9) {
     double cell_v = 0.0;
     il_window_src((int)xi, (int)yi, C.W, C.H, lane / 3, lane % 3, sy, sx);
-    if (sy >= 0) {
+    if (sy >= 0 && GEN) {
+      cell_v = T.field[((size_t)i * C.H + sy) * C.W + sx];
+    } else if (sy >= 0) {
       double covf = 0.0;
       for (int s = 0; s < 7; ++s) covf += scr[lane + 9 * s];
       const double q = C.quad[(size_t)sy * C.W + sx];
@@ -233,54 +255,28 @@ __device__ __forceinline__ void il_dyn(const IlqrConst &C, const double *x, cons
   o[5] = x[5] + u[1] * C.dt;
 }
 
-// quadratic potentials (potential.py:4-59) + field value; derivatives optional (lane 0 writes)
-__device__ __forceinline__ double il_node_cost(const IlqrConst &C, double p, const double *x, const double *u,
-                                               const FieldOut &fe, double *lx, double *lxx, double *lu_diag /*[4]: lu0, lu1, luu00, luu11*/) {
+// quadratic potentials (potential.py:4-59) + field value
+template <bool GEN>
+__device__ __forceinline__ double il_node_cost(const IlNodeW<GEN> &NW, const double *x, const double *u, const FieldOut &fe) {
   double cost = 0.0;
   cost += fe.val;
   double sp = 0.0, sc = 0.0, cp = 0.0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    const double xd = (k == 2) ? C.target_vel : 0.0;
-    const double w = C.w_des[k] * p, d = x[k] - xd;
+    const double w = NW.wdes(k), d = x[k] - NW.des(k);
     sp += d * w * d;
   }
   cost += sp;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    const double w = C.w_con[k] * p;
-    const double d = fmax(x[k] - C.ub[k], 0.0) + fmax(C.lb[k] - x[k], 0.0);
+    const double w = NW.wcon(k);
+    const double d = fmax(x[k] - NW.ub(k), 0.0) + fmax(NW.lb(k) - x[k], 0.0);
     sc += d * w * d;
   }
   cost += sc;
 #pragma unroll
-  for (int k = 0; k < 2; ++k) cp += u[k] * (C.w_ctrl[k] * p) * u[k];
+  for (int k = 0; k < 2; ++k) cp += u[k] * NW.wctrl(k) * u[k];
   cost += cp;
-  if (lx) {
-#pragma unroll
-    for (int k = 0; k < 36; ++k) lxx[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) lx[k] = 0.0;
-    lx[0] += fe.gx; lx[1] += fe.gy;
-    lxx[0] += fe.hxx; lxx[1] += fe.hxy; lxx[6] += fe.hxy; lxx[7] += fe.hyy;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const double xd = (k == 2) ? C.target_vel : 0.0;
-      const double w = C.w_des[k] * p;
-      lx[k] += 2.0 * (w * (x[k] - xd));
-      lxx[k * 6 + k] += 2.0 * w;
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const double w = C.w_con[k] * p;
-      if (x[k] > C.ub[k]) { lx[k] += 2.0 * w * (x[k] - C.ub[k]); lxx[k * 6 + k] += 2.0 * w; }
-      else if (x[k] < C.lb[k]) { lx[k] += 2.0 * w * (x[k] - C.lb[k]); lxx[k * 6 + k] += 2.0 * w; }
-    }
-    lu_diag[0] = 2.0 * ((C.w_ctrl[0] * p) * u[0]);
-    lu_diag[1] = 2.0 * ((C.w_ctrl[1] * p) * u[1]);
-    lu_diag[2] = 2.0 * (C.w_ctrl[0] * p);
-    lu_diag[3] = 2.0 * (C.w_ctrl[1] * p);
-  }
   return cost;
 }
 
@@ -309,10 +305,11 @@ __device__ double il_np_sum(const double *a, long n) {
 // children-summed value function (Vxx at scr+36, Vx at scr+176); on exit it holds this node's value
 // function in the same place (so a chain is walked without touching global memory for V).
 // Returns (wave-uniform) 1 if Q_uu is singular.
-// pre[0..2]: this node's Fx[lane], Lxx[lane] (lanes < 36), Lx[lane-36] (lanes 36..41), loaded by the caller
-// one node ahead so that the global-memory latency overlaps the previous node's algebra.
+// pre_*: this node's Fx[lane], Lxx[lane] (lanes < 36), Lx[lane-36] (lanes 36..41), controls and control
+// weights (w_ctrl x prob), loaded by the caller one node ahead so that the global-memory latency overlaps
+// the previous node's algebra.
 __device__ __forceinline__ int il_gains(const IlqrConst &C, const IlqrTreeDev &T, int key, double mu, double *scr,
-                                        double pre_fx, double pre_lxx, double pre_lx, double pre_u0, double pre_u1, double pre_p) {
+                                        double pre_fx, double pre_lxx, double pre_lx, double pre_u0, double pre_u1, double pre_wc0, double pre_wc1) {
   const int lane = threadIdx.x & 63;
   const int i = lane / 6, j = lane % 6;   // lanes 0..35 <-> (i,j)
   double *fx = scr, *Vxx = scr + 36, *Tm = scr + 72, *Qxx = scr + 108, *Qux = scr + 144, *Kk = scr + 156;
@@ -346,12 +343,12 @@ __device__ __forceinline__ int il_gains(const IlqrConst &C, const IlqrTreeDev &T
   if (lane >= 54 && lane < 58) {  // Q_uu
     const int a = (lane - 54) / 2, b = (lane - 54) % 2;
     const double R = dt * (Vxx[(4 + a) * 6 + 4 + b] + ((a == b) ? mu : 0.0));
-    const double luu = (a == b) ? 2.0 * (C.w_ctrl[a] * pre_p) : 0.0;
+    const double luu = (a == b) ? 2.0 * (a == 0 ? pre_wc0 : pre_wc1) : 0.0;
     misc[2 + a * 2 + b] = luu + R * dt;
   }
   if (lane >= 58 && lane < 60) {  // Q_u
     const int a = lane - 58;
-    const double lu = 2.0 * ((C.w_ctrl[a] * pre_p) * (a == 0 ? pre_u0 : pre_u1));
+    const double lu = 2.0 * ((a == 0 ? pre_wc0 : pre_wc1) * (a == 0 ? pre_u0 : pre_u1));
     misc[a] = lu + dt * Vx[4 + a];
   }
   IL_WFENCE();
@@ -427,7 +424,8 @@ __device__ __forceinline__ void il_dyn_sc(const IlqrConst &C, const double *x, c
 // the group's 9 window cells are split over the sub-lanes, the exo sum runs over all agents in
 // ascending order (the oracle's order) with an exact squared-distance early-out before each sqrt.
 // cells: LDS scratch of 9 doubles owned by the group.
-__device__ __forceinline__ double il_field_val_group(const IlqrConst &C, const IlqrTreeDev &T, float pf, double px, double py,
+template <bool GEN>
+__device__ __forceinline__ double il_field_val_group(const IlqrConst &C, const IlqrTreeDev &T, int node, float pf, double px, double py,
                                                      int r, double *cells, const double *ag, const int *rel, int nrel) {
   long xi = (long)rint((px - C.off_x) / C.res);
   long yi = (long)rint((py - C.off_y) / C.res);
@@ -438,7 +436,9 @@ __device__ __forceinline__ double il_field_val_group(const IlqrConst &C, const I
     int sy, sx;
     il_window_src((int)xi, (int)yi, C.W, C.H, cell / 3, cell % 3, sy, sx);
     double cell_v = 0.0;
-    if (sy >= 0) {
+    if (sy >= 0 && GEN) {
+      cell_v = T.field[((size_t)node * C.H + sy) * C.W + sx];
+    } else if (sy >= 0) {
       const double q = C.quad[(size_t)sy * C.W + sx];
       if (C.use_exo) {
         const double cx = C.gx[sx], cy = C.gy[sy];
@@ -533,6 +533,7 @@ __device__ __forceinline__ void il_commit_node(const IlqrConst &C, const IlqrTre
 // Roll ALL 10 line-search candidates along one chain segment in one wave (solver.py:202-240): lane
 // group a = lane/6 carries candidate a (its running state lives in registers), sub-lane r = lane%6
 // shares the group's field evaluation.  init != 0: nominal rollout (alpha = 0 for every group).
+template <bool GEN>
 __device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const IlqrTreeDev &T, int seg, int init, double *scr,
                                                    double *ag) {
   const int lane = threadIdx.x & 63;
@@ -593,9 +594,10 @@ __device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const Ilq
       if (cnt >= 0 && !init && inside && ddx * ddx + ddy * ddy < IL_RMARGIN * IL_RMARGIN) nrel = cnt;
     }
     FieldOut fe;
-    fe.val = il_field_val_group(C, T, Pc.prob, x[0], x[1], r, cells, ag, rel, nrel);
+    fe.val = il_field_val_group<GEN>(C, T, c, Pc.prob, x[0], x[1], r, cells, ag, rel, nrel);
     if (writer) {
-      T.L_new[(size_t)a * M + c] = il_node_cost(C, (double)Pc.prob, x, u, fe, nullptr, nullptr, nullptr);
+      const IlNodeW<GEN> NW{C, GEN ? T.node_w + (size_t)c * IL_NW : nullptr, (double)Pc.prob};
+      T.L_new[(size_t)a * M + c] = il_node_cost<GEN>(NW, x, u, fe);
       double *xn = T.xs_new + ((size_t)a * M + c) * 6, *un = T.us_new + ((size_t)a * M + c) * 2;
 #pragma unroll
       for (int k = 0; k < 6; ++k) xn[k] = x[k];
@@ -608,17 +610,66 @@ __device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const Ilq
   }
 }
 
+// Cost value / gradient / Hessian and the dynamics Jacobian of node c at (x, u), one matrix entry per
+// lane (cost.py:341-446 over the node's potentials; f_x at the POST state, Q1).  Every destination is
+// optional.  One wave; `ag` must already hold the node's agents when C.use_exo.
+template <bool GEN>
+__device__ __forceinline__ void il_node_derivs(const IlqrConst &C, const IlqrTreeDev &T, int c, const double *x, const double *u,
+                                               double *scr, const double *ag, double *dLxx, double *dFx, double *dLx, double *dL) {
+  const int lane = threadIdx.x & 63;
+  const IlNodeW<GEN> NW{C, GEN ? T.node_w + (size_t)c * IL_NW : nullptr, GEN ? 0.0 : (double)T.prob[c]};
+  FieldOut fe;
+  il_field<GEN>(C, T, c, x[0], x[1], scr, ag, true, fe);
+  double s3, c3;
+  sincos(x[3], &s3, &c3);
+  const double c5 = cos(x[5]);
+  const double t5 = tan(x[5]);
+  if (lane < 36) {
+    const int i = lane / 6, j = lane % 6;
+    // l_xx = field Hessian (xy block) + 2 W_des + 2 W_con on violated bounds
+    double h = 0.0;
+    if (i == 0 && j == 0) h += fe.hxx;
+    if ((i == 0 && j == 1) || (i == 1 && j == 0)) h += fe.hxy;
+    if (i == 1 && j == 1) h += fe.hyy;
+    if (i == j) {
+      h += 2.0 * NW.wdes(i);
+      if (x[i] > NW.ub(i) || x[i] < NW.lb(i)) h += 2.0 * NW.wcon(i);
+    }
+    if (dLxx) dLxx[lane] = h;
+    double J = i == j ? 1.0 : 0.0;
+    if (i == 0 && j == 2) J = c3 * C.dt;
+    if (i == 0 && j == 3) J = -x[2] * s3 * C.dt;
+    if (i == 1 && j == 2) J = s3 * C.dt;
+    if (i == 1 && j == 3) J = x[2] * c3 * C.dt;
+    if (i == 2 && j == 4) J = C.dt;
+    if (i == 3 && j == 2) J = t5 / C.wb * C.dt;
+    if (i == 3 && j == 5) J = x[2] / C.wb / (c5 * c5) * C.dt;
+    if (dFx) dFx[lane] = J;
+  } else if (lane < 42) {
+    const int k = lane - 36;
+    double g = 0.0;
+    if (k == 0) g += fe.gx;
+    if (k == 1) g += fe.gy;
+    g += 2.0 * (NW.wdes(k) * (x[k] - NW.des(k)));
+    const double w = NW.wcon(k);
+    if (x[k] > NW.ub(k)) g += 2.0 * w * (x[k] - NW.ub(k));
+    else if (x[k] < NW.lb(k)) g += 2.0 * w * (x[k] - NW.lb(k));
+    if (dLx) dLx[k] = g;
+  } else if (lane == 42) {
+    if (dL) *dL = il_node_cost<GEN>(NW, x, u, fe);
+  }
+}
+
 // Derivatives at the accepted iterate (solver.py:285-294,308-320): embarrassingly parallel over nodes
 // because xs/us are already known (the accepted line-search candidate IS the next nominal rollout).
 // One wave per node, one matrix entry per lane (no private arrays: they would live in scratch memory).
+template <bool GEN>
 __device__ __forceinline__ void il_derivatives(const IlqrConst &C, const IlqrTreeDev &T, int c, double *scr, double *ag) {
   const int lane = threadIdx.x & 63;
   double x[6], u[2];
 #pragma unroll
   for (int k = 0; k < 6; ++k) x[k] = T.xs[(size_t)c * 6 + k];
   u[0] = T.us[(size_t)c * 2]; u[1] = T.us[(size_t)c * 2 + 1];
-  const double p = (double)T.prob[c];
-  FieldOut fe;
   if (C.use_exo) {
     il_stage_agents(C, T, c, ag);
     // relevant agents for the next line search: |mu_e - x| < (sigma_e + offset) + margin + window reach,
@@ -641,47 +692,7 @@ __device__ __forceinline__ void il_derivatives(const IlqrConst &C, const IlqrTre
     }
     if (lane == 0) rl[0] = cnt;
   }
-  il_field(C, T, c, x[0], x[1], scr, ag, true, fe);
-  double s3, c3;
-  sincos(x[3], &s3, &c3);
-  const double c5 = cos(x[5]);
-  const double t5 = tan(x[5]);
-  if (lane < 36) {
-    const int i = lane / 6, j = lane % 6;
-    // l_xx = field Hessian (xy block) + 2 W_des p + 2 W_con p on violated bounds
-    double h = 0.0;
-    if (i == 0 && j == 0) h += fe.hxx;
-    if ((i == 0 && j == 1) || (i == 1 && j == 0)) h += fe.hxy;
-    if (i == 1 && j == 1) h += fe.hyy;
-    if (i == j) {
-      h += 2.0 * (C.w_des[i] * p);
-      if (x[i] > C.ub[i] || x[i] < C.lb[i]) h += 2.0 * (C.w_con[i] * p);
-    }
-    T.Lxx[(size_t)c * 36 + lane] = h;
-    // f_x at the POST state (Q1)
-    double J = i == j ? 1.0 : 0.0;
-    if (i == 0 && j == 2) J = c3 * C.dt;
-    if (i == 0 && j == 3) J = -x[2] * s3 * C.dt;
-    if (i == 1 && j == 2) J = s3 * C.dt;
-    if (i == 1 && j == 3) J = x[2] * c3 * C.dt;
-    if (i == 2 && j == 4) J = C.dt;
-    if (i == 3 && j == 2) J = t5 / C.wb * C.dt;
-    if (i == 3 && j == 5) J = x[2] / C.wb / (c5 * c5) * C.dt;
-    T.Fx[(size_t)c * 36 + lane] = J;
-  } else if (lane < 42) {
-    const int k = lane - 36;
-    double g = 0.0;
-    if (k == 0) g += fe.gx;
-    if (k == 1) g += fe.gy;
-    const double xd = (k == 2) ? C.target_vel : 0.0;
-    g += 2.0 * ((C.w_des[k] * p) * (x[k] - xd));
-    const double w = C.w_con[k] * p;
-    if (x[k] > C.ub[k]) g += 2.0 * w * (x[k] - C.ub[k]);
-    else if (x[k] < C.lb[k]) g += 2.0 * w * (x[k] - C.lb[k]);
-    T.Lx[(size_t)c * 6 + k] = g;
-  } else if (lane == 42) {
-    T.L[c] = il_node_cost(C, p, x, u, fe, nullptr, nullptr, nullptr);
-  }
+  il_node_derivs<GEN>(C, T, c, x, u, scr, ag, T.Lxx + (size_t)c * 36, T.Fx + (size_t)c * 36, T.Lx + (size_t)c * 6, T.L + c);
 }
 
 // LM schedule after one rejection (solver.py:153-158)
@@ -690,6 +701,7 @@ __device__ __forceinline__ void il_reject_update(double &mu, double &delta) {
   mu = fmax(1e-6, mu * delta);
 }
 
+template <bool GEN>
 __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restrict__ trees, IlqrConst C) {
   const IlqrTreeDev T = trees[blockIdx.x];
   extern __shared__ double il_dsm[];
@@ -712,7 +724,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
   __syncthreads();
   for (int d = 0; d < T.n_slevels; ++d) {
     for (int q = T.slevel_start[d] + wave; q < T.slevel_start[d + 1]; q += IL_WAVES)
-      il_rollout_segment(C, T, T.slevel_segs[q], 1, scr, ag);
+      il_rollout_segment<GEN>(C, T, T.slevel_segs[q], 1, scr, ag);
     __threadfence_block();
     __syncthreads();
   }
@@ -731,7 +743,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
       for (int q = tid; q < M * 2; q += IL_THREADS) T.us[q] = un[q];
       __threadfence_block();
       __syncthreads();
-      for (int c = wave; c < M; c += IL_WAVES) il_derivatives(C, T, c, scr, ag);
+      for (int c = wave; c < M; c += IL_WAVES) il_derivatives<GEN>(C, T, c, scr, ag);
       __threadfence_block();
       __syncthreads();
       if (M <= IL_LSUM) {
@@ -781,23 +793,27 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
           IL_WFENCE();
         }
         int sing = 0;
-        double pfx = 0.0, plxx = 0.0, plx = 0.0, pu0, pu1, pp;
+        double pfx = 0.0, plxx = 0.0, plx = 0.0, pu0, pu1, pw0, pw1;
         {
           const int c = T.seg_nodes[s1 - 1];
           if (lane < 36) { pfx = T.Fx[(size_t)c * 36 + lane]; plxx = T.Lxx[(size_t)c * 36 + lane]; }
           else if (lane < 42) plx = T.Lx[(size_t)c * 6 + lane - 36];
-          pu0 = T.us[(size_t)c * 2]; pu1 = T.us[(size_t)c * 2 + 1]; pp = (double)T.prob[c];
+          pu0 = T.us[(size_t)c * 2]; pu1 = T.us[(size_t)c * 2 + 1];
+          if (GEN) { pw0 = T.node_w[(size_t)c * IL_NW + 24]; pw1 = T.node_w[(size_t)c * IL_NW + 25]; }
+          else { const double pp = (double)T.prob[c]; pw0 = C.w_ctrl[0] * pp; pw1 = C.w_ctrl[1] * pp; }
         }
         for (int r = s1 - 1; r >= s0 && !sing; --r) {
-          double nfx = 0.0, nlxx = 0.0, nlx = 0.0, nu0 = 0.0, nu1 = 0.0, np_ = 0.0;
+          double nfx = 0.0, nlxx = 0.0, nlx = 0.0, nu0 = 0.0, nu1 = 0.0, nw0 = 0.0, nw1 = 0.0;
           if (r > s0) {
             const int cn = T.seg_nodes[r - 1];
             if (lane < 36) { nfx = T.Fx[(size_t)cn * 36 + lane]; nlxx = T.Lxx[(size_t)cn * 36 + lane]; }
             else if (lane < 42) nlx = T.Lx[(size_t)cn * 6 + lane - 36];
-            nu0 = T.us[(size_t)cn * 2]; nu1 = T.us[(size_t)cn * 2 + 1]; np_ = (double)T.prob[cn];
+            nu0 = T.us[(size_t)cn * 2]; nu1 = T.us[(size_t)cn * 2 + 1];
+            if (GEN) { nw0 = T.node_w[(size_t)cn * IL_NW + 24]; nw1 = T.node_w[(size_t)cn * IL_NW + 25]; }
+            else { const double np_ = (double)T.prob[cn]; nw0 = C.w_ctrl[0] * np_; nw1 = C.w_ctrl[1] * np_; }
           }
-          sing = il_gains(C, Ts, T.seg_nodes[r], mu, scr, pfx, plxx, plx, pu0, pu1, pp);
-          pfx = nfx; plxx = nlxx; plx = nlx; pu0 = nu0; pu1 = nu1; pp = np_;
+          sing = il_gains(C, Ts, T.seg_nodes[r], mu, scr, pfx, plxx, plx, pu0, pu1, pw0, pw1);
+          pfx = nfx; plxx = nlxx; plx = nlx; pu0 = nu0; pu1 = nu1; pw0 = nw0; pw1 = nw1;
         }
         if (sing) { if (lane == 0) atomicOr(&sh_sing, 1 << slot); }
         else {
@@ -826,7 +842,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
         IlqrTreeDev Ts = T;
         Ts.k += (size_t)slot * M * 2; Ts.K += (size_t)slot * M * 12;
         Ts.xs_new += (size_t)slot * IL_NA * M * 6; Ts.us_new += (size_t)slot * IL_NA * M * 2; Ts.L_new += (size_t)slot * IL_NA * M;
-        il_rollout_segment(C, Ts, seg, 0, scr, ag);
+        il_rollout_segment<GEN>(C, Ts, seg, 0, scr, ag);
       }
       __threadfence_block();
       __syncthreads();
@@ -889,3 +905,30 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
 }
 
 static inline size_t il_lds_bytes(int amax) { return ((size_t)IL_WAVES * 192 + (size_t)IL_WAVES * 4 * amax + IL_LSUM) * sizeof(double); }
+
+// TreeCost.l / l_x / l_u / l_xx / l_uu (cost.py:341-446) at arbitrary (x, u) of given nodes: one wave per
+// query.  out[q] = { l, l_x[6], l_u[2], l_xx[36], l_uu diag[2] } (47 doubles).
+#define IL_EVAL_OUT 47
+template <bool GEN>
+__global__ __launch_bounds__(64) void k_cost_eval(const IlqrTreeDev *__restrict__ trees, IlqrConst C, int nq,
+                                                  const int *__restrict__ node, const double *__restrict__ xq,
+                                                  const double *__restrict__ uq, double *__restrict__ out) {
+  const IlqrTreeDev T = trees[0];
+  extern __shared__ double il_dsm[];
+  double *scr = il_dsm, *ag = il_dsm + 192;
+  const int q = blockIdx.x, lane = threadIdx.x;
+  if (q >= nq) return;
+  const int c = node[q];
+  double x[6], u[2];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) x[k] = xq[(size_t)q * 6 + k];
+  u[0] = uq[(size_t)q * 2]; u[1] = uq[(size_t)q * 2 + 1];
+  if (C.use_exo) il_stage_agents(C, T, c, ag);
+  double *o = out + (size_t)q * IL_EVAL_OUT;
+  il_node_derivs<GEN>(C, T, c, x, u, scr, ag, o + 9, nullptr, o + 1, o);
+  if (lane < 2) {
+    const IlNodeW<GEN> NW{C, GEN ? T.node_w + (size_t)c * IL_NW : nullptr, GEN ? 0.0 : (double)T.prob[c]};
+    o[7 + lane] = 2.0 * (NW.wctrl(lane) * u[lane]);
+    o[45 + lane] = 2.0 * NW.wctrl(lane);
+  }
+}

@@ -670,50 +670,100 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
 // -------------------------------------------------------------------------------------------------
 // tree-iLQR host side
 // -------------------------------------------------------------------------------------------------
-extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_cost_tree *trees, int n_trees,
-                                     const double *x0, const double *target_lane, int n_lane_pts, double target_vel,
-                                     int use_exo, const double *us_init, double *xs, double *us,
-                                     mind_ilqr_stats *stats) {
-  if (!c || !cfg || !trees || n_trees <= 0 || !x0 || !target_lane || n_lane_pts < 2 || !xs || !us)
-    return fail(c, MIND_EINVAL, "mind_ilqr_solve_trees: bad argument");
-  if (cfg->grid_w < 3 || cfg->grid_h < 3 || cfg->max_iter < 0) return fail(c, MIND_EINVAL, "bad grid / max_iter");
+// grid coordinates exactly as numpy builds them (ilqr/utils.py:7-13): linspace(0, size, n) + offset
+static void il_make_grid(int W, int H, double res, const double *ego_xy, double *gx, double *gy, double &offx, double &offy) {
+  const double fsx = (double)(W - 1) * res, fsy = (double)(H - 1) * res;
+  offx = ego_xy[0] - 0.5 * fsx; offy = ego_xy[1] - 0.5 * fsy;
+  const double sx = fsx / (double)(W - 1), sy = fsy / (double)(H - 1);
+  for (int i = 0; i < W; ++i) gx[i] = (double)i * sx + 0.0;
+  gx[W - 1] = fsx;
+  for (int i = 0; i < H; ++i) gy[i] = (double)i * sy + 0.0;
+  gy[H - 1] = fsy;
+  for (int i = 0; i < W; ++i) gx[i] += offx;
+  for (int i = 0; i < H; ++i) gy[i] += offy;
+}
+
+// gen_dist_field (ilqr/utils.py:5-22): distance of every grid centroid to the polyline
+extern "C" int mind_lane_dist_field(mind_ctx *c, const double *ego_xy, const double *lane, int n_pts, int W, int H,
+                                    double res, double *offset, double *gx, double *gy, double *dist) {
+  if (!c || !ego_xy || !lane || n_pts < 2 || W < 2 || H < 2 || !(res > 0) || !offset || !gx || !gy || !dist)
+    return fail(c, MIND_EINVAL, "mind_lane_dist_field: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = c->stream;
-  const int W = cfg->grid_w, H = cfg->grid_h;
+  il_make_grid(W, H, res, ego_xy, gx, gy, offset[0], offset[1]);
+  const size_t nd = (size_t)W + H + 2 * (size_t)n_pts + (size_t)W * H;
+  int rc;
+  if ((rc = ensure(c, c->ilqr_dev, nd * sizeof(double)))) return rc;
+  double *d = (double *)c->ilqr_dev.p;
+  HIPCHK(c, hipMemcpyAsync(d, gx, W * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d + W, gy, H * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d + W + H, lane, 2 * (size_t)n_pts * sizeof(double), hipMemcpyHostToDevice, st));
+  double *out = d + W + H + 2 * (size_t)n_pts;
+  hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, d, d + W, W, H, d + W + H, n_pts, out, 0);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(dist, out, (size_t)W * H * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return MIND_OK;
+}
+
+struct IlqrEvalReq { int nq; const int32_t *node; const double *x, *u; double *out; };
+
+// Shared host side of mind_ilqr_solve_trees / mind_ilqr_solve_fields / mind_cost_eval: build the device
+// arena, then either run the solver (ev == nullptr) or evaluate node costs at the requested points.
+// grid != nullptr selects the generic mode (materialised per-node fields + per-node weights).
+static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_grid *grid, const mind_cost_tree *trees, int n_trees,
+                     const double *x0, const double *target_lane, int n_lane_pts, double target_vel,
+                     int use_exo, const double *us_init, double *xs, double *us,
+                     mind_ilqr_stats *stats, const IlqrEvalReq *ev) {
+  const bool gen = grid != nullptr;
+  if (!c || !cfg || !trees || n_trees <= 0 || !x0) return fail(c, MIND_EINVAL, "iLQR: bad argument");
+  if (!ev && (!xs || !us)) return fail(c, MIND_EINVAL, "iLQR: null output");
+  if (!gen && (!target_lane || n_lane_pts < 2)) return fail(c, MIND_EINVAL, "iLQR: target lane needs >= 2 points");
+  if (gen) { use_exo = 0; n_lane_pts = 0; }
+  const int W = gen ? grid->W : cfg->grid_w, H = gen ? grid->H : cfg->grid_h;
+  if (W < 3 || H < 3 || cfg->max_iter < 0) return fail(c, MIND_EINVAL, "bad grid / max_iter");
+  if (gen && (!grid->gx || !grid->gy || !(grid->res > 0))) return fail(c, MIND_EINVAL, "bad field grid");
+  for (int t = 0; t < n_trees; ++t)
+    if (gen != (trees[t].field != nullptr) || gen != (trees[t].node_w != nullptr))
+      return fail(c, MIND_EINVAL, "tree %d: field / node_w must be given exactly in the generic (grid) mode", t);
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const double grid_res = gen ? grid->res : cfg->grid_res;
   // ---- grid coordinates exactly as numpy builds them (ilqr/utils.py:7-13)
   std::vector<double> gx(W), gy(H);
-  const double fsx = (double)(W - 1) * cfg->grid_res, fsy = (double)(H - 1) * cfg->grid_res;
-  const double offx = x0[0] - 0.5 * fsx, offy = x0[1] - 0.5 * fsy;
-  {
-    const double sx = fsx / (double)(W - 1), sy = fsy / (double)(H - 1);
-    for (int i = 0; i < W; ++i) gx[i] = (double)i * sx + 0.0;
-    gx[W - 1] = fsx;
-    for (int i = 0; i < H; ++i) gy[i] = (double)i * sy + 0.0;
-    gy[H - 1] = fsy;
-    for (int i = 0; i < W; ++i) gx[i] += offx;
-    for (int i = 0; i < H; ++i) gy[i] += offy;
+  const double fsx = (double)(W - 1) * grid_res, fsy = (double)(H - 1) * grid_res;
+  const double offx = gen ? grid->off_x : x0[0] - 0.5 * fsx, offy = gen ? grid->off_y : x0[1] - 0.5 * fsy;
+  if (gen) {
+    memcpy(gx.data(), grid->gx, W * sizeof(double));
+    memcpy(gy.data(), grid->gy, H * sizeof(double));
+  } else {
+    double ox, oy;
+    il_make_grid(W, H, grid_res, x0, gx.data(), gy.data(), ox, oy);
   }
   // ---- layout of one device arena: [doubles | floats | ints | tree structs]
   size_t nd = 0, nf = 0, ni = 0;
   auto takeD = [&](size_t n) { size_t o = nd; nd += (n + 1) & ~(size_t)1; return o; };
   auto takeF = [&](size_t n) { size_t o = nf; nf += (n + 3) & ~(size_t)3; return o; };
   auto takeI = [&](size_t n) { size_t o = ni; ni += (n + 3) & ~(size_t)3; return o; };
-  const size_t o_gx = takeD(W), o_gy = takeD(H), o_lane = takeD((size_t)n_lane_pts * 2), o_quad = takeD((size_t)W * H);
-  struct TL { size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel; int M, a, nl, nseg, nsl, maxls; };
+  const size_t o_gx = takeD(W), o_gy = takeD(H), o_lane = takeD((size_t)n_lane_pts * 2 + 2), o_quad = takeD(gen ? 2 : (size_t)W * H);
+  const size_t o_evx = takeD(ev ? (size_t)ev->nq * 6 : 0), o_evu = takeD(ev ? (size_t)ev->nq * 2 : 0), o_evo = takeD(ev ? (size_t)ev->nq * IL_EVAL_OUT : 0);
+  const size_t o_evn = takeI(ev ? ev->nq : 0);
+  struct TL { size_t nodew, field; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel; int M, a, nl, nseg, nsl, maxls; };
   std::vector<TL> tl(n_trees);
   long Mtot = 0;
   for (int t = 0; t < n_trees; ++t) {
     const mind_cost_tree &tr = trees[t];
-    if (tr.n_nodes <= 0 || !tr.parent || !tr.prob || tr.n_agents <= 0 || (use_exo && (!tr.agent_mean || !tr.agent_cov)))
+    if (tr.n_nodes <= 0 || !tr.parent || (!gen && (!tr.prob || tr.n_agents <= 0)) || (use_exo && (!tr.agent_mean || !tr.agent_cov)))
       return fail(c, MIND_EINVAL, "tree %d: bad arrays", t);
     if (tr.n_agents > IL_MAXA) return fail(c, MIND_EINVAL, "tree %d: %d agents > %d supported", t, tr.n_agents, IL_MAXA);
     const size_t M = tr.n_nodes;
     TL &L = tl[t];
-    L.M = (int)M; L.a = tr.n_agents;
+    L.M = (int)M; L.a = gen ? 1 : tr.n_agents;
+    L.nodew = takeD(gen ? M * IL_NW : 0);
     L.xs = takeD(6 * M); L.us = takeD(2 * M); L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M);
     L.Lxx = takeD(36 * M); L.k = takeD(IL_SPEC * 2 * M); L.K = takeD(IL_SPEC * 12 * M); L.Vx = takeD(IL_SPEC * 6 * M); L.Vxx = takeD(IL_SPEC * 36 * M);
     L.xsn = takeD(IL_SPEC * 60 * M); L.usn = takeD(IL_SPEC * 20 * M); L.Ln = takeD(IL_SPEC * 10 * M); L.stats = takeD(8);
-    L.prob = takeF(M); L.mean = takeF(M * tr.n_agents * 2); L.cov = takeF(M * tr.n_agents);
+    L.prob = takeF(M); L.mean = takeF(M * L.a * 2); L.cov = takeF(M * L.a);
     L.parent = takeI(M); L.lnodes = takeI(M); L.cstart = takeI(M + 1); L.clist = takeI(M); L.rel = takeI(M * (IL_REL + 1));
     Mtot += (long)M;
   }
@@ -779,7 +829,9 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
   }
   const size_t bytesD = nd * sizeof(double), bytesF = nf * sizeof(float), bytesI = ni * sizeof(int);
   const size_t o_structs = bytesD + bytesF + bytesI;
-  const size_t total = o_structs + (size_t)n_trees * sizeof(IlqrTreeDev);
+  // generic mode: the materialised fields go behind the structs, copied straight from the caller's arrays
+  size_t total = (o_structs + (size_t)n_trees * sizeof(IlqrTreeDev) + 15) & ~(size_t)15;
+  for (int t = 0; t < n_trees && gen; ++t) { tl[t].field = total; total += (size_t)tl[t].M * W * H * sizeof(double); }
   int rc;
   if ((rc = ensure(c, c->ilqr_dev, total))) return rc;
   char *base = (char *)c->ilqr_dev.p;
@@ -792,7 +844,14 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
   std::vector<int> hI(ni, 0);
   memcpy(hD.data() + o_gx, gx.data(), W * sizeof(double));
   memcpy(hD.data() + o_gy, gy.data(), H * sizeof(double));
-  memcpy(hD.data() + o_lane, target_lane, (size_t)n_lane_pts * 2 * sizeof(double));
+  if (n_lane_pts) memcpy(hD.data() + o_lane, target_lane, (size_t)n_lane_pts * 2 * sizeof(double));
+  if (ev) {
+    memcpy(hD.data() + o_evx, ev->x, (size_t)ev->nq * 6 * sizeof(double));
+    memcpy(hD.data() + o_evu, ev->u, (size_t)ev->nq * 2 * sizeof(double));
+    memcpy(hI.data() + o_evn, ev->node, (size_t)ev->nq * sizeof(int));
+    for (int q = 0; q < ev->nq; ++q)
+      if (ev->node[q] < 0 || ev->node[q] >= trees[0].n_nodes) return fail(c, MIND_EINVAL, "mind_cost_eval: node %d out of range", ev->node[q]);
+  }
   std::vector<IlqrTreeDev> hT(n_trees);
   long moff = 0;
   for (int t = 0; t < n_trees; ++t) {
@@ -800,9 +859,10 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
     const TL &L = tl[t];
     const size_t M = L.M;
     if (us_init) memcpy(hD.data() + L.us, us_init + moff * 2, 2 * M * sizeof(double));
-    memcpy(hF.data() + L.prob, tr.prob, M * sizeof(float));
-    if (tr.agent_mean) memcpy(hF.data() + L.mean, tr.agent_mean, M * L.a * 2 * sizeof(float));
-    if (tr.agent_cov) memcpy(hF.data() + L.cov, tr.agent_cov, M * L.a * sizeof(float));
+    if (tr.prob) memcpy(hF.data() + L.prob, tr.prob, M * sizeof(float));
+    if (gen) memcpy(hD.data() + L.nodew, tr.node_w, M * IL_NW * sizeof(double));
+    if (tr.agent_mean && !gen) memcpy(hF.data() + L.mean, tr.agent_mean, M * L.a * 2 * sizeof(float));
+    if (tr.agent_cov && !gen) memcpy(hF.data() + L.cov, tr.agent_cov, M * L.a * sizeof(float));
     memcpy(hI.data() + L.parent, tr.parent, M * sizeof(int));
     memcpy(hI.data() + L.lstart, lvl_start[t].data(), lvl_start[t].size() * sizeof(int));
     memcpy(hI.data() + L.lnodes, lvl_nodes[t].data(), M * sizeof(int));
@@ -817,6 +877,8 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
     D.parent = dI + L.parent; D.level_start = dI + L.lstart; D.level_nodes = dI + L.lnodes;
     D.child_start = dI + L.cstart; D.child_list = dI + L.clist;
     D.rel = dI + L.rel;
+    D.field = gen ? (const double *)(base + L.field) : nullptr;
+    D.node_w = gen ? dD + L.nodew : nullptr;
     D.n_segs = L.nseg; D.n_slevels = L.nsl; D.max_level_segs = L.maxls; D.pad2 = 0;
     D.seg_start = dI + L.sstart; D.seg_nodes = dI + L.snodes; D.slevel_start = dI + L.slstart; D.slevel_segs = dI + L.slsegs;
     D.prob = dF + L.prob; D.mean = dF + L.mean; D.cov = dF + L.cov;
@@ -829,6 +891,8 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
   HIPCHK(c, hipMemcpyAsync(dF, hF.data(), bytesF, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(dI, hI.data(), bytesI, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(base + o_structs, hT.data(), (size_t)n_trees * sizeof(IlqrTreeDev), hipMemcpyHostToDevice, st));
+  for (int t = 0; t < n_trees && gen; ++t)
+    HIPCHK(c, hipMemcpyAsync(base + tl[t].field, trees[t].field, (size_t)tl[t].M * W * H * sizeof(double), hipMemcpyHostToDevice, st));
   IlqrConst K;
   memset(&K, 0, sizeof(K));
   K.dt = cfg->dt; K.wb = cfg->wheelbase;
@@ -836,16 +900,31 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
   K.w_ctrl[0] = cfg->w_ctrl[0]; K.w_ctrl[1] = cfg->w_ctrl[1];
   K.w_tgt = cfg->w_tgt; K.w_ego = cfg->w_ego; K.w_ego_off = cfg->w_ego_cov_offset; K.w_exo = cfg->w_exo;
   K.w_exo_off = cfg->w_exo_cov_offset; K.w_exo_cost = cfg->w_exo_cost_offset;
-  K.res = cfg->grid_res; K.off_x = offx; K.off_y = offy; K.target_vel = target_vel;
+  K.res = grid_res; K.off_x = offx; K.off_y = offy; K.target_vel = target_vel;
   K.W = W; K.H = H; K.max_iter = cfg->max_iter; K.use_exo = use_exo;
   for (int j = 0; j < IL_NA; ++j) K.alphas[j] = std::pow(1.1, -(double)(j * j));
   K.gx = dD + o_gx; K.gy = dD + o_gy; K.quad = dD + o_quad;
-  hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, K.gx, K.gy, W, H, dD + o_lane, n_lane_pts, dD + o_quad);
+  if (!gen) hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, K.gx, K.gy, W, H, dD + o_lane, n_lane_pts, dD + o_quad);
   int amax = 1;
-  for (int t = 0; t < n_trees; ++t) amax = trees[t].n_agents > amax ? trees[t].n_agents : amax;
+  for (int t = 0; t < n_trees; ++t) amax = tl[t].a > amax ? tl[t].a : amax;
+  const IlqrTreeDev *dT = (const IlqrTreeDev *)(base + o_structs);
+  if (ev) {
+    const size_t lds = (192 + (size_t)4 * amax) * sizeof(double);
+    if (gen) hipLaunchKernelGGL(k_cost_eval<true>, dim3(ev->nq), dim3(64), lds, st, dT, K, ev->nq, dI + o_evn, dD + o_evx, dD + o_evu, dD + o_evo);
+    else hipLaunchKernelGGL(k_cost_eval<false>, dim3(ev->nq), dim3(64), lds, st, dT, K, ev->nq, dI + o_evn, dD + o_evx, dD + o_evu, dD + o_evo);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(ev->out, dD + o_evo, (size_t)ev->nq * IL_EVAL_OUT * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return MIND_OK;
+  }
   const size_t il_lds = il_lds_bytes(amax);
-  (void)hipFuncSetAttribute((const void *)k_ilqr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
-  hipLaunchKernelGGL(k_ilqr, dim3(n_trees), dim3(IL_THREADS), il_lds, st, (const IlqrTreeDev *)(base + o_structs), K);
+  if (gen) {
+    (void)hipFuncSetAttribute((const void *)k_ilqr<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
+    hipLaunchKernelGGL(k_ilqr<true>, dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, K);
+  } else {
+    (void)hipFuncSetAttribute((const void *)k_ilqr<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
+    hipLaunchKernelGGL(k_ilqr<false>, dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, K);
+  }
   HIPCHK(c, hipGetLastError());
   moff = 0;
   std::vector<double> hs(8 * n_trees);
@@ -862,10 +941,32 @@ extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, cons
       stats[t].iterations = (int)hs[8 * t]; stats[t].converged = (int)hs[8 * t + 1];
       stats[t].J = hs[8 * t + 2]; stats[t].mu = hs[8 * t + 3];
       if (getenv("MIND_ILQR_TRACE"))
-        fprintf(stderr, "[k_ilqr] tree %d it %d: cycles derivatives %.0f backward %.0f linesearch %.0f select %.0f\n", t,
-                stats[t].iterations, hs[8 * t + 4], hs[8 * t + 5], hs[8 * t + 6], hs[8 * t + 7]);
+        fprintf(stderr, "[k_ilqr] tree %d exo %d M %d segs %d seg-levels %d widest %d agents %d it %d: cycles derivatives %.0f backward %.0f linesearch %.0f select %.0f\n", t,
+                use_exo, tl[t].M, tl[t].nseg, tl[t].nsl, tl[t].maxls, tl[t].a, stats[t].iterations, hs[8 * t + 4], hs[8 * t + 5], hs[8 * t + 6], hs[8 * t + 7]);
     }
   return MIND_OK;
+}
+
+extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_cost_tree *trees, int n_trees,
+                                     const double *x0, const double *target_lane, int n_lane_pts, double target_vel,
+                                     int use_exo, const double *us_init, double *xs, double *us,
+                                     mind_ilqr_stats *stats) {
+  return ilqr_impl(c, cfg, nullptr, trees, n_trees, x0, target_lane, n_lane_pts, target_vel, use_exo, us_init, xs, us, stats, nullptr);
+}
+
+extern "C" int mind_ilqr_solve_fields(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_grid *grid,
+                                      const mind_cost_tree *trees, int n_trees, const double *x0,
+                                      const double *us_init, double *xs, double *us, mind_ilqr_stats *stats) {
+  if (!grid) return fail(c, MIND_EINVAL, "mind_ilqr_solve_fields: null grid");
+  return ilqr_impl(c, cfg, grid, trees, n_trees, x0, nullptr, 0, 0.0, 0, us_init, xs, us, stats, nullptr);
+}
+
+extern "C" int mind_cost_eval(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_grid *grid, const mind_cost_tree *tree,
+                              const double *x0, const double *target_lane, int n_lane_pts, double target_vel, int use_exo,
+                              int n_query, const int32_t *node, const double *x, const double *u, double *out) {
+  if (n_query <= 0 || !node || !x || !u || !out) return fail(c, MIND_EINVAL, "mind_cost_eval: bad argument");
+  IlqrEvalReq ev{n_query, node, x, u, out};
+  return ilqr_impl(c, cfg, grid, tree, 1, x0, target_lane, n_lane_pts, target_vel, use_exo, nullptr, nullptr, nullptr, nullptr, &ev);
 }
 
 // ---- debug taps (tests only): run only the first n fusion layers; read back internal buffers

@@ -160,6 +160,100 @@ class HipPredictor:
         return ([xs[offs[i]:offs[i + 1]] for i in range(n)], [us[offs[i]:offs[i + 1]] for i in range(n)],
                 [dict(iterations=st[i].iterations, converged=st[i].converged, J=st[i].J, mu=st[i].mu) for i in range(n)])
 
+    # ---- planners/ilqr surface: arbitrary materialised fields + per-node quadratic potentials -------------
+    @staticmethod
+    def _generic_tree(tree, keep):
+        """tree: dict(parent int32 [M], field f64 [M,H,W], node_w f64 [M,32]) -> CostTree."""
+        ct = _lib.CostTree()
+        par = np.ascontiguousarray(tree["parent"], np.int32)
+        fld = np.ascontiguousarray(tree["field"], np.float64)
+        nw = np.ascontiguousarray(tree["node_w"], np.float64)
+        if fld.ndim != 3 or fld.shape[0] != len(par) or nw.shape != (len(par), 32):
+            raise ValueError("generic cost tree: field [M,H,W] / node_w [M,32] do not match parent [M]")
+        keep += [par, fld, nw]
+        ct.n_nodes, ct.n_agents = len(par), 0
+        ct.parent = par.ctypes.data_as(C.POINTER(C.c_int32))
+        ct.field = fld.ctypes.data_as(C.POINTER(C.c_double))
+        ct.node_w = nw.ctypes.data_as(C.POINTER(C.c_double))
+        return ct
+
+    @staticmethod
+    def _grid(grid, keep):
+        """grid: dict(offset [2], res, gx [W], gy [H]) as PotentialField receives them."""
+        g = _lib.FieldGrid()
+        gx = np.ascontiguousarray(grid["gx"], np.float64)
+        gy = np.ascontiguousarray(grid["gy"], np.float64)
+        keep += [gx, gy]
+        g.W, g.H, g.res = len(gx), len(gy), float(grid["res"])
+        g.off_x, g.off_y = float(grid["offset"][0]), float(grid["offset"][1])
+        g.gx = gx.ctypes.data_as(C.POINTER(C.c_double))
+        g.gy = gy.ctypes.data_as(C.POINTER(C.c_double))
+        return g
+
+    def ilqr_solve_fields(self, cfg, grid, tree, x0, us_init=None):
+        """iLQR.fit on ONE tree with materialised fields (mind_ilqr_solve_fields).  Returns (xs [M,6], us [M,2], stats)."""
+        keep = []
+        ct = self._generic_tree(tree, keep)
+        g = self._grid(grid, keep)
+        M = ct.n_nodes
+        x0 = np.ascontiguousarray(x0, np.float64)
+        xs, us = np.zeros((M, 6)), np.zeros((M, 2))
+        st = _lib.IlqrStats()
+        ui = None if us_init is None else np.ascontiguousarray(us_init, np.float64)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+        rc = self.lib.mind_ilqr_solve_fields(self.ctx, C.byref(cfg), C.byref(g), C.byref(ct), 1, dp(x0), dp(ui), dp(xs), dp(us),
+                                             C.byref(st))
+        _lib.check(self.lib, self.ctx, rc, "mind_ilqr_solve_fields")
+        return xs, us, dict(iterations=st.iterations, converged=st.converged, J=st.J, mu=st.mu)
+
+    def cost_eval(self, cfg, node, x, u, tree, grid=None, x0=None, lane=None, target_vel=0.0, use_exo=0):
+        """TreeCost.l/l_x/l_u/l_xx/l_uu of ``tree`` at (x[q], u[q]) for node[q] (mind_cost_eval).
+        grid given: generic tree dict; grid None: planner-mode flat dict (parent, prob, mean, cov) + x0, lane.
+        Returns dict(l [Q], l_x [Q,6], l_u [Q,2], l_xx [Q,6,6], l_uu [Q,2,2])."""
+        keep = []
+        if grid is not None:
+            ct = self._generic_tree(tree, keep)
+            g = C.byref(self._grid(grid, keep))
+            x0 = np.zeros(6) if x0 is None else x0
+        else:
+            ct = _lib.CostTree()
+            par = np.ascontiguousarray(tree["parent"], np.int32)
+            prob = np.ascontiguousarray(tree["prob"], np.float32)
+            mean = np.ascontiguousarray(tree["mean"], np.float32)
+            cov = np.ascontiguousarray(tree["cov"], np.float32)
+            keep += [par, prob, mean, cov]
+            ct.n_nodes, ct.n_agents = len(par), mean.shape[1]
+            ct.parent = par.ctypes.data_as(C.POINTER(C.c_int32))
+            ct.prob = prob.ctypes.data_as(C.POINTER(C.c_float))
+            ct.agent_mean = mean.ctypes.data_as(C.POINTER(C.c_float))
+            ct.agent_cov = cov.ctypes.data_as(C.POINTER(C.c_float))
+            g = None
+        node = np.ascontiguousarray(node, np.int32)
+        x = np.ascontiguousarray(x, np.float64).reshape(len(node), 6)
+        u = np.ascontiguousarray(u, np.float64).reshape(len(node), 2)
+        x0 = np.ascontiguousarray(x0, np.float64)
+        lane_a = None if lane is None else np.ascontiguousarray(lane, np.float64)
+        out = np.zeros((len(node), 47))
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+        rc = self.lib.mind_cost_eval(self.ctx, C.byref(cfg), g, C.byref(ct), dp(x0), dp(lane_a), 0 if lane_a is None else len(lane_a),
+                                     C.c_double(float(target_vel)), int(use_exo), len(node),
+                                     node.ctypes.data_as(C.POINTER(C.c_int32)), dp(x), dp(u), dp(out))
+        _lib.check(self.lib, self.ctx, rc, "mind_cost_eval")
+        luu = np.zeros((len(node), 2, 2))
+        luu[:, 0, 0], luu[:, 1, 1] = out[:, 45], out[:, 46]
+        return dict(l=out[:, 0].copy(), l_x=out[:, 1:7].copy(), l_u=out[:, 7:9].copy(), l_xx=out[:, 9:45].reshape(-1, 6, 6).copy(), l_uu=luu)
+
+    def lane_dist_field(self, ego_xy, lane, W, H, res):
+        """gen_dist_field (ilqr/utils.py:5-22) -> (offset [2], gx [W], gy [H], dist [H,W])."""
+        ego = np.ascontiguousarray(np.asarray(ego_xy, np.float64)[:2])
+        lane = np.ascontiguousarray(lane, np.float64)
+        off, gx, gy, dist = np.zeros(2), np.zeros(W), np.zeros(H), np.zeros((H, W))
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        rc = self.lib.mind_lane_dist_field(self.ctx, dp(ego), dp(lane), len(lane), int(W), int(H), C.c_double(float(res)),
+                                           dp(off), dp(gx), dp(gy), dp(dist))
+        _lib.check(self.lib, self.ctx, rc, "mind_lane_dist_field")
+        return off, gx, gy, dist
+
     def predict_numpy_batch(self, pb, use_rpe=False, **kw):
         """Convenience for tests: ``pb`` as produced by ``mind_amd.synth.predictor_batch`` (numpy)."""
         dev = self.device

@@ -129,3 +129,36 @@ def field_eval(F, res, origin, px, py):
                             C.c_double(res), o.ctypes.data_as(C.POINTER(C.c_double)), C.c_double(px), C.c_double(py),
                             out.ctypes.data_as(C.POINTER(C.c_double)))
     return out
+
+
+def node_fields(cfg, flat, x0, lane, use_exo):
+    """Materialised cost field of every trajectory node + the grid (field_offset, xx[0,:], yy[:,0]) exactly as
+    trajectory_tree.py builds them for PotentialField.  -> (fields [M,H,W], gx [W], gy [H], off [2])."""
+    M, W, H = len(flat["parent"]), cfg.grid_w, cfg.grid_h
+    x0 = np.ascontiguousarray(x0, np.float64)
+    lane = np.ascontiguousarray(lane, np.float64)
+    fields, gx, gy, off = np.zeros((M, H, W)), np.zeros(W), np.zeros(H), np.zeros(2)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    t = _ct(flat)
+    rc = lib().oracle_node_fields(C.byref(cfg), C.byref(t), dp(x0), dp(lane), C.c_int(len(lane)), C.c_int(use_exo),
+                                  dp(fields), dp(gx), dp(gy), dp(off))
+    assert rc == 0
+    return fields, gx, gy, off
+
+
+def node_derivs(cfg, flat, x0, lane, target_vel, use_exo, xs, us):
+    """l, l_x, l_u, l_xx, l_uu of every node i at (xs[i], us[i]) -> dict of arrays."""
+    M = len(flat["parent"])
+    x0 = np.ascontiguousarray(x0, np.float64)
+    lane = np.ascontiguousarray(lane, np.float64)
+    xs = np.ascontiguousarray(xs, np.float64)
+    us = np.ascontiguousarray(us, np.float64)
+    out = np.zeros((M, 47))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    t = _ct(flat)
+    rc = lib().oracle_node_derivs(C.byref(cfg), C.byref(t), dp(x0), dp(lane), C.c_int(len(lane)), C.c_double(target_vel),
+                                  C.c_int(use_exo), dp(xs), dp(us), dp(out))
+    assert rc == 0
+    luu = np.zeros((M, 2, 2))
+    luu[:, 0, 0], luu[:, 1, 1] = out[:, 45], out[:, 46]
+    return dict(l=out[:, 0], l_x=out[:, 1:7], l_u=out[:, 7:9], l_xx=out[:, 9:45].reshape(M, 6, 6), l_uu=luu)

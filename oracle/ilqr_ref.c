@@ -578,3 +578,52 @@ int oracle_node_costs(const mind_ilqr_cfg *cfg, const mind_cost_tree *t, const d
   free(S.field); free(S.prob); free(quad); free(S.gx); free(S.gy);
   return 0;
 }
+
+/* the materialised per-node cost fields alone (what trajectory_tree.py:41-42 / :78-108 hands to
+ * PotentialField), for tests of the generic planners/ilqr surface: fields [M,H,W], gx [W], gy [H], off [2] */
+int oracle_node_fields(const mind_ilqr_cfg *cfg, const mind_cost_tree *t, const double *x0, const double *lane, int P,
+                       int use_exo, double *fields, double *gx, double *gy, double *off) {
+  solver_t S;
+  memset(&S, 0, sizeof(S));
+  S.cfg = cfg; S.M = t->n_nodes; S.parent = t->parent; S.W = cfg->grid_w; S.H = cfg->grid_h;
+  S.gx = gx; S.gy = gy;
+  make_grid(cfg, x0, S.gx, S.gy, S.off);
+  off[0] = S.off[0]; off[1] = S.off[1];
+  double *quad = (double *)malloc((size_t)S.W * S.H * sizeof(double));
+  lane_dist_field(S.gx, S.gy, S.W, S.H, lane, P, quad);
+  S.field = (double **)calloc(S.M, sizeof(double *));
+  build_fields(&S, t, quad, use_exo);
+  for (int i = 0; i < S.M; i++) {
+    memcpy(fields + (size_t)i * S.W * S.H, S.field[i], (size_t)S.W * S.H * sizeof(double));
+    free(S.field[i]);
+  }
+  free(S.field); free(quad);
+  return 0;
+}
+
+/* per-node cost AND derivatives at given xs/us (cost.py:341-446):
+ * out [M, 47] = { l, l_x[6], l_u[2], l_xx[36], diag l_uu[2] } */
+int oracle_node_derivs(const mind_ilqr_cfg *cfg, const mind_cost_tree *t, const double *x0, const double *lane, int P,
+                       double target_vel, int use_exo, const double *xs, const double *us, double *out) {
+  solver_t S;
+  memset(&S, 0, sizeof(S));
+  S.cfg = cfg; S.M = t->n_nodes; S.parent = t->parent; S.W = cfg->grid_w; S.H = cfg->grid_h; S.target_vel = target_vel;
+  memcpy(S.x0, x0, sizeof(S.x0));
+  S.gx = (double *)malloc(S.W * sizeof(double));
+  S.gy = (double *)malloc(S.H * sizeof(double));
+  make_grid(cfg, x0, S.gx, S.gy, S.off);
+  double *quad = (double *)malloc((size_t)S.W * S.H * sizeof(double));
+  lane_dist_field(S.gx, S.gy, S.W, S.H, lane, P, quad);
+  S.prob = (double *)malloc(S.M * sizeof(double));
+  for (int i = 0; i < S.M; i++) S.prob[i] = (double)t->prob[i];
+  S.field = (double **)calloc(S.M, sizeof(double *));
+  build_fields(&S, t, quad, use_exo);
+  for (int i = 0; i < S.M; i++) {
+    double *o = out + (size_t)i * 47, luu[4];
+    o[0] = node_cost(&S, i, xs + i * NS, us + i * NU, o + 1, o + 9, o + 7, luu);
+    o[45] = luu[0]; o[46] = luu[3];
+  }
+  for (int i = 0; i < S.M; i++) free(S.field[i]);
+  free(S.field); free(S.prob); free(quad); free(S.gx); free(S.gy);
+  return 0;
+}
