@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmind_hip.so")
+LIB_PATH = os.environ.get("MIND_HIP_LIB", os.path.join(_HERE, "libmind_hip.so"))   # override: diagnostic builds only
 
 MIND_OK = 0
 

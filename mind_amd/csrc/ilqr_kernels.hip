@@ -28,6 +28,9 @@
 #define IL_SPEC 4     // Levenberg-Marquardt values evaluated speculatively per step (see k_ilqr)
 #define IL_MAXA 128   // agents per scene staged in LDS (cfg4: 64, stress: 128)
 #define IL_REL 15     // relevant-agent list length per node
+#define IL_RA 64      // doubles per node in T.relag: (1 + IL_REL) records x 4
+#define IL_SCR 208    // doubles of per-wave LDS scratch (Riccati operands 0..190, constants 192..204)
+#define IL_CST 192    // scr[IL_CST..+6) = {1,0,0,0,0,0}, scr[IL_CST+6..+12) = {dt,0,0,0,0,0}
 #define IL_LSUM 2048   // doubles of LDS used to stage the cost sums
 #define IL_RMARGIN 3.0  // [m] the list is exact for queries within this distance of the nominal state
 
@@ -51,12 +54,14 @@ struct IlqrTreeDev {
   double *xs, *us, *Fx, *L, *Lx, *Lxx;                        // [M,*]
   double *k, *K, *Vx, *Vxx;                                   // [IL_SPEC][M,*]  (one set per speculative mu)
   double *xs_new, *us_new, *L_new;                            // [IL_SPEC][NA,M,*]
-  int *rel;                 // [M, IL_REL+1]: count (or -1 = overflow) + agent indices near the nominal state
+  int *rel;                 // [M] number of exo agents near the nominal state (<= IL_REL), or -1 = overflow
+  double *relag;            // [M, IL_RA] compact staged records {mean_x, mean_y, sigma+offset, threshold}: entry 0 =
+                            //   ego, entries 1..rel[c] = the relevant exo agents in ascending agent order
   // generic mode (planners/ilqr surface: arbitrary materialised fields + per-node diagonal weights)
   const double *field;      // [M, H*W] cost_field of every node's PotentialField, or null
   const double *node_w;     // [M, IL_NW]: w_des[6] w_con[6] lb[6] ub[6] w_ctrl[2] des[6], or null
   // outputs
-  double *stats;            // [4]: iterations, converged, J, mu
+  double *stats;            // [IL_NSTAT]: iterations, converged, J, mu, phase cycles, profile slots
 };
 
 struct IlqrConst {
@@ -68,13 +73,43 @@ struct IlqrConst {
   int W, H, max_iter, use_exo;
   double alphas[IL_NA];     // 1.1 ** (-j*j), j = 0..9 (solver.py:125), computed on the host
   const double *gx, *gy;    // [W], [H] grid coordinates (numpy linspace + offset, built on the host)
+  // lin != 0: gx[i] == ((i == W-1 ? fsx : i * stepx) + off_x) bit for bit (checked on the host), so the kernels
+  // compute cell centres instead of loading them
+  int lin, pad_;
+  double stepx, stepy, fsx, fsy;
+  double in_x0, in_x1, in_y0, in_y1;   // conservative "window fully inside the grid" box for the list fast path
   const double *quad;       // [H*W] squared distance to the target lane
 };
 
 #define IL_WFENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define IL_NSTAT 24   // doubles per tree in T.stats: 4 results + 4 phase cycle counters + 16 profile slots
+
+// fine-grained cycle attribution (diagnostic build only: -DIL_PROFILE); slots: 0-1 chain-rollout node (stage,
+// u+dynamics+store), 5 nodes; 2-4 cost-pass chunk (stage+loads, field, cost+store), 15 chunks; 6-9 Riccati
+// node (products, Qxx, solve, value update), 10 nodes; 11-12 derivative node (stage+lists, field+trig), 14 nodes
+#ifdef IL_PROFILE
+#define IL_PROF_ARG , long long *prof
+#define IL_PROF_PASS , prof
+#define IL_PT0() long long tp_ = clock64()
+#define IL_PT(i) do { const long long n_ = clock64(); prof[i] += n_ - tp_; tp_ = n_; } while (0)
+#define IL_PCNT(i) prof[i] += 1
+#else
+#define IL_PROF_ARG
+#define IL_PROF_PASS
+#define IL_PT0() do {} while (0)
+#define IL_PT(i) do {} while (0)
+#define IL_PCNT(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ double il_shfl_down(double v, int d) {
   return __shfl_down(v, d, 64);
+}
+
+__device__ __forceinline__ double il_gx(const IlqrConst &C, int i) {
+  return C.lin ? (i == C.W - 1 ? C.fsx : (double)i * C.stepx) + C.off_x : C.gx[i];
+}
+__device__ __forceinline__ double il_gy(const IlqrConst &C, int i) {
+  return C.lin ? (i == C.H - 1 ? C.fsy : (double)i * C.stepy) + C.off_y : C.gy[i];
 }
 
 // ---- lane distance field: d(c)^2 = min over segments (ilqr/utils.py:5-22, geometry.py:70-78) ----
@@ -114,6 +149,9 @@ __device__ __forceinline__ void il_window_src(int xi, int yi, int W, int H, int 
 }
 
 struct FieldOut { double val, gx, gy, hxx, hyy, hxy; };
+
+// doubles of the per-wave agent table (derivative pass): all agents x 4
+__host__ __device__ static inline int il_ag_doubles(int n_agents) { return 4 * n_agents; }
 
 // Quadratic-potential parameters of one trajectory node (potential.py:4-59).  GEN = false: the planner's
 // uniform structure, config weight x node probability (trajectory_tree.py:38-46, product in float64 as
@@ -308,56 +346,61 @@ __device__ double il_np_sum(const double *a, long n) {
 // pre_*: this node's Fx[lane], Lxx[lane] (lanes < 36), Lx[lane-36] (lanes 36..41), controls and control
 // weights (w_ctrl x prob), loaded by the caller one node ahead so that the global-memory latency overlaps
 // the previous node's algebra.
+// All first-stage products (F_x^T V_xx, Q_x, Q_ux, Q_uu, Q_u) are ONE instruction stream: every lane runs the
+// same six-term sum  s += (sc * (A[r] + add_r)) * B[r]  over its own LDS operands (role-dependent code would be
+// serialised by the SIMT hardware); sc = 1 / add = 0 / B = {c,0,0,0,0,0} reproduce the shorter expressions bit for bit.
 __device__ __forceinline__ int il_gains(const IlqrConst &C, const IlqrTreeDev &T, int key, double mu, double *scr,
-                                        double pre_fx, double pre_lxx, double pre_lx, double pre_u0, double pre_u1, double pre_wc0, double pre_wc1) {
+                                        double pre_fx, double pre_lxx, double pre_lx, double pre_u0, double pre_u1, double pre_wc0, double pre_wc1 IL_PROF_ARG) {
   const int lane = threadIdx.x & 63;
+  IL_PT0();
   const int i = lane / 6, j = lane % 6;   // lanes 0..35 <-> (i,j)
+  // scr offsets: fx 0, Vxx 36, Tm 72, Qxx 108, Qux 144, Kk 156, Qx 170, Vx 176, misc 182 (Qu[2], Quu[4], k[2])
   double *fx = scr, *Vxx = scr + 36, *Tm = scr + 72, *Qxx = scr + 108, *Qux = scr + 144, *Kk = scr + 156;
-  double *Qx = scr + 170, *Vx = scr + 176, *misc = scr + 182;   // misc: Qu[2], Quu[4], k[2]
+  double *Vx = scr + 176, *misc = scr + 182;
+  const double dt = C.dt;
+  // ---- per-lane operand description of the first stage
+  int ao, as, bo, bs, radd = -1, dst;
+  double sc = 1.0, addend = 0.0;
+  if (lane < 36) {                    // T = F_x^T V_xx
+    ao = i; as = 6; bo = 36 + j; bs = 6; dst = 72 + lane;
+  } else if (lane < 42) {             // Q_x = l_x + F_x^T V_x
+    ao = lane - 36; as = 6; bo = 176; bs = 1; dst = 170 + (lane - 36); addend = pre_lx;
+  } else if (lane < 54) {             // Q_ux = f_u^T (V_xx + mu I) f_x ; f_u^T picks rows 4,5 scaled by dt
+    const int a = (lane - 42) / 6, jj = (lane - 42) % 6;
+    ao = 36 + (4 + a) * 6; as = 1; bo = jj; bs = 6; dst = 144 + (lane - 42); sc = dt; radd = 4 + a;
+  } else if (lane < 58) {             // Q_uu = l_uu + f_u^T (V_xx + mu I) f_u
+    const int a = (lane - 54) / 2, b = (lane - 54) % 2;
+    ao = 36 + (4 + a) * 6 + 4 + b; as = 0; bo = IL_CST + 6; bs = 1; dst = 182 + 2 + (lane - 54); sc = dt;
+    radd = a == b ? 0 : -1;
+    addend = a == b ? 2.0 * (a == 0 ? pre_wc0 : pre_wc1) : 0.0;
+  } else if (lane < 60) {             // Q_u = l_u + f_u^T V_x
+    const int a = lane - 58;
+    ao = 176 + 4 + a; as = 0; bo = IL_CST; bs = 1; dst = 182 + a; sc = dt;
+    addend = 2.0 * ((a == 0 ? pre_wc0 : pre_wc1) * (a == 0 ? pre_u0 : pre_u1));
+  } else {
+    ao = 0; as = 0; bo = IL_CST + 1; bs = 0; dst = 0;
+  }
   if (lane < 36) fx[lane] = pre_fx;
   IL_WFENCE();
-  const double dt = C.dt;
-  if (lane < 36) {
-    double s = 0.0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) s += fx[r * 6 + i] * Vxx[r * 6 + j];
-    Tm[lane] = s;
-  }
-  if (lane >= 36 && lane < 42) {  // Q_x
-    const int a = lane - 36;
-    double s = 0.0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) s += fx[r * 6 + a] * Vx[r];
-    Qx[a] = pre_lx + s;
-  }
-  if (lane >= 42 && lane < 54) {  // Q_ux = f_u^T (V_xx + mu I) f_x ; f_u^T picks rows 4,5 scaled by dt
-    const int a = (lane - 42) / 6, jj = (lane - 42) % 6;
+  {
     double s = 0.0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      const double R = dt * (Vxx[(4 + a) * 6 + r] + ((r == 4 + a) ? mu : 0.0));
-      s += R * fx[r * 6 + jj];
+      const double R = sc * (scr[ao + r * as] + (r == radd ? mu : 0.0));
+      s += R * scr[bo + r * bs];
     }
-    Qux[a * 6 + jj] = 0.0 + s;
-  }
-  if (lane >= 54 && lane < 58) {  // Q_uu
-    const int a = (lane - 54) / 2, b = (lane - 54) % 2;
-    const double R = dt * (Vxx[(4 + a) * 6 + 4 + b] + ((a == b) ? mu : 0.0));
-    const double luu = (a == b) ? 2.0 * (a == 0 ? pre_wc0 : pre_wc1) : 0.0;
-    misc[2 + a * 2 + b] = luu + R * dt;
-  }
-  if (lane >= 58 && lane < 60) {  // Q_u
-    const int a = lane - 58;
-    const double lu = 2.0 * ((a == 0 ? pre_wc0 : pre_wc1) * (a == 0 ? pre_u0 : pre_u1));
-    misc[a] = lu + dt * Vx[4 + a];
+    IL_WFENCE();                      // all operands read before the results overwrite Tm / Qux / misc
+    if (lane < 60) scr[dst] = addend + s;
   }
   IL_WFENCE();
+  IL_PT(6);
   if (lane < 36) {
     double s = 0.0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) s += Tm[i * 6 + r] * fx[r * 6 + j];
     Qxx[lane] = pre_lxx + s;
   }
+  IL_PT(7);
   // 2x2 solves with partial pivoting (LAPACK dgesv order): lanes 0..6 each own one right-hand side
   int singular = 0;
   {
@@ -379,32 +422,37 @@ __device__ __forceinline__ int il_gains(const IlqrConst &C, const IlqrTreeDev &T
     }
   }
   IL_WFENCE();
+  IL_PT(8);
   if (singular) return 1;
-  const double k0 = misc[6], k1 = misc[7];
+  // ---- value update, V_xx (lanes < 36) and V_x (lanes 36..41, the "k column") in one stream:
+  //      V = Q + K^T Q_uu K + K^T Q_u. + Q_.u K   with (K_j, Q_ux_j, Q) -> (k, Q_u, Q_x) for the V_x lanes
   const double q00 = misc[2], q01 = misc[3], q10 = misc[4], q11 = misc[5];
-  double vnew = 0.0, vxnew = 0.0;
-  if (lane < 36) {
-    const double QuuK0j = q00 * Kk[j] + q01 * Kk[6 + j];
-    const double QuuK1j = q10 * Kk[j] + q11 * Kk[6 + j];
-    double v = Qxx[lane] + (Kk[i] * QuuK0j + Kk[6 + i] * QuuK1j);
-    v += (Kk[i] * Qux[j] + Kk[6 + i] * Qux[6 + j]) + (Qux[i] * Kk[j] + Qux[6 + i] * Kk[6 + j]);
-    Tm[lane] = v;
+  double vnew = 0.0;
+  {
+    const bool mat = lane < 36;
+    const int ii = mat ? i : (lane < 42 ? lane - 36 : 0);
+    const double Kj0 = scr[mat ? 156 + j : 182 + 6], Kj1 = scr[mat ? 156 + 6 + j : 182 + 7];
+    const double Uj0 = scr[mat ? 144 + j : 182 + 0], Uj1 = scr[mat ? 144 + 6 + j : 182 + 1];
+    const double Qb = scr[mat ? 108 + lane : 170 + ii];
+    const double Ki0 = Kk[ii], Ki1 = Kk[6 + ii], Ui0 = Qux[ii], Ui1 = Qux[6 + ii];
+    const double QuuK0 = q00 * Kj0 + q01 * Kj1;
+    const double QuuK1 = q10 * Kj0 + q11 * Kj1;
+    double v = Qb + (Ki0 * QuuK0 + Ki1 * QuuK1);
+    v += (Ki0 * Uj0 + Ki1 * Uj1) + (Ui0 * Kj0 + Ui1 * Kj1);
+    vnew = v;                          // lanes 36..41: the new V_x entry
+    if (mat) Tm[lane] = v;
   }
-  if (lane >= 36 && lane < 42) {
-    const int a = lane - 36;
-    const double Quuk0 = q00 * k0 + q01 * k1, Quuk1 = q10 * k0 + q11 * k1;
-    double v = Qx[a] + (Kk[a] * Quuk0 + Kk[6 + a] * Quuk1);
-    v += (Kk[a] * misc[0] + Kk[6 + a] * misc[1]) + (Qux[a] * k0 + Qux[6 + a] * k1);
-    vxnew = v;
+  if (lane >= 42 && lane < 56) {       // gains to global memory: K (12) then k (2)
+    double *dstg = lane < 54 ? T.K + (size_t)key * 12 + (lane - 42) : T.k + (size_t)key * 2 + (lane - 54);
+    *dstg = lane < 54 ? Kk[lane - 42] : misc[6 + (lane - 54)];
   }
-  if (lane >= 42 && lane < 54) T.K[(size_t)key * 12 + (lane - 42)] = Kk[lane - 42];
-  if (lane == 54) { T.k[(size_t)key * 2] = k0; T.k[(size_t)key * 2 + 1] = k1; }
   IL_WFENCE();
   if (lane < 36) vnew = 0.5 * (Tm[i * 6 + j] + Tm[j * 6 + i]);
   IL_WFENCE();
   if (lane < 36) Vxx[lane] = 0.0 + vnew;            // parent accumulates 0 + V[child] (solver.py:349-350)
-  if (lane >= 36 && lane < 42) Vx[lane - 36] = 0.0 + vxnew;
+  if (lane >= 36 && lane < 42) Vx[lane - 36] = 0.0 + vnew;
   IL_WFENCE();
+  IL_PT(9); IL_PCNT(10);
   return 0;
 }
 
@@ -420,131 +468,39 @@ __device__ __forceinline__ void il_dyn_sc(const IlqrConst &C, const double *x, c
   o[5] = x[5] + u[1] * C.dt;
 }
 
-// Value of node i's potential field at (px,py) for ONE lane group of 6 lanes (sub-lane r = 0..5):
-// the group's 9 window cells are split over the sub-lanes, the exo sum runs over all agents in
-// ascending order (the oracle's order) with an exact squared-distance early-out before each sqrt.
-// cells: LDS scratch of 9 doubles owned by the group.
-template <bool GEN>
-__device__ __forceinline__ double il_field_val_group(const IlqrConst &C, const IlqrTreeDev &T, int node, float pf, double px, double py,
-                                                     int r, double *cells, const double *ag, const int *rel, int nrel) {
-  long xi = (long)rint((px - C.off_x) / C.res);
-  long yi = (long)rint((py - C.off_y) / C.res);
-  xi = xi < 0 ? 0 : (xi > C.W - 1 ? C.W - 1 : xi);
-  yi = yi < 0 ? 0 : (yi > C.H - 1 ? C.H - 1 : yi);
-  const double wp = (double)((float)C.w_tgt * pf);
-  for (int cell = r; cell < 9; cell += 6) {
-    int sy, sx;
-    il_window_src((int)xi, (int)yi, C.W, C.H, cell / 3, cell % 3, sy, sx);
-    double cell_v = 0.0;
-    if (sy >= 0 && GEN) {
-      cell_v = T.field[((size_t)node * C.H + sy) * C.W + sx];
-    } else if (sy >= 0) {
-      const double q = C.quad[(size_t)sy * C.W + sx];
-      if (C.use_exo) {
-        const double cx = C.gx[sx], cy = C.gy[sy];
-        double covf = 0.0;
-        // nrel >= 0: only the listed agents can reach this window (ascending order = the oracle's
-        // summation order with the zero terms dropped); nrel < 0: all agents
-        const int cnt = nrel >= 0 ? nrel : T.n_agents - 1;
-        for (int t = 0; t < cnt; ++t) {
-          const int e = nrel >= 0 ? rel[t] : t + 1;
-          const double dx = cx - ag[4 * e], dy = cy - ag[4 * e + 1];
-          const double d2 = dx * dx + dy * dy;
-          if (d2 > ag[4 * e + 3]) continue;              // max(ec - sqrt(d2), 0) == 0 exactly
-          double v = ag[4 * e + 2] - sqrt(d2);
-          v = v > 0.0 ? v : 0.0;
-          if (v > 0.0) v += C.w_exo_cost;
-          covf += v;
-        }
-        const double ego_cov = ag[2];
-        const double dx = cx - ag[0], dy = cy - ag[1];
-        double ego = sqrt(dx * dx + dy * dy) - ego_cov;
-        ego = ego > 0.0 ? ego : 0.0;
-        cell_v = (wp * q + C.w_exo * covf) + C.w_ego * ego;
-      } else {
-        cell_v = wp * q;
-      }
-    }
-    cells[cell] = cell_v;
-  }
-  IL_WFENCE();
-  double g[3][3], s[3][3];
+// ---- line search (solver.py:202-240), two phases ---------------------------------------------------------
+// Only the state recursion x_c = f(x_parent, u_c(x_parent)) is serial along a chain; the cost of a candidate
+// node depends on nothing but its own (x, u).  Phase 1 rolls the states of all 10 step sizes down the chain
+// segments (cheap per node), phase 2 evaluates the M x 10 x slots node costs with one LANE per (node, alpha).
+
+// Per-node operands of the chain rollout (gains, nominal control and state), loaded one node ahead into
+// registers: the addresses are wave-uniform, every lane holds the full set.
+struct IlKv { double K[12], k[2], us[2], xs[6]; };
+
+__device__ __forceinline__ void il_prefetch_kv(const IlqrTreeDev &T, int c, IlKv &P) {
+  const double2 *pK = reinterpret_cast<const double2 *>(T.K + (size_t)c * 12);
+  const double2 *px = reinterpret_cast<const double2 *>(T.xs + (size_t)c * 6);
 #pragma unroll
-  for (int rr = 0; rr < 3; ++rr)
+  for (int q = 0; q < 6; ++q) { const double2 v = pK[q]; P.K[2 * q] = v.x; P.K[2 * q + 1] = v.y; }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) g[rr][c] = cells[rr * 3 + c];
-  IL_WFENCE();
-  s[0][0] = (((g[0][0] + g[0][1]) + g[1][0]) + g[1][1]) / 4.0;
-  s[0][2] = (((g[0][1] + g[0][2]) + g[1][1]) + g[1][2]) / 4.0;
-  s[2][0] = (((g[1][0] + g[1][1]) + g[2][0]) + g[2][1]) / 4.0;
-  s[2][2] = (((g[1][1] + g[1][2]) + g[2][1]) + g[2][2]) / 4.0;
-  s[0][1] = (g[0][1] + g[1][1]) / 2.0;
-  s[1][0] = (g[1][0] + g[1][1]) / 2.0;
-  s[1][2] = (g[1][1] + g[1][2]) / 2.0;
-  s[2][1] = (g[1][1] + g[2][1]) / 2.0;
-  s[1][1] = g[1][1];
-  const double u = (px - C.gx[xi]) / C.res + 0.5;
-  const double v = (py - C.gy[yi]) / C.res + 0.5;
-  const double u1 = 1 - u, v1 = 1 - v;
-  return u1 * u1 * v1 * v1 * s[0][0] + u1 * u1 * 2.0 * v1 * v * s[1][0] + u1 * u1 * v * v * s[2][0] +
-         2.0 * u1 * u * v1 * v1 * s[0][1] + 2.0 * u1 * u * 2.0 * v1 * v * s[1][1] + 2.0 * u1 * u * v * v * s[2][1] +
-         u * u * v1 * v1 * s[0][2] + u * u * 2.0 * v1 * v * s[1][2] + u * u * v * v * s[2][2];
+  for (int q = 0; q < 3; ++q) { const double2 v = px[q]; P.xs[2 * q] = v.x; P.xs[2 * q + 1] = v.y; }
+  const double2 vk = *reinterpret_cast<const double2 *>(T.k + (size_t)c * 2);
+  const double2 vu = *reinterpret_cast<const double2 *>(T.us + (size_t)c * 2);
+  P.k[0] = vk.x; P.k[1] = vk.y; P.us[0] = vu.x; P.us[1] = vu.y;
 }
 
-// Prefetched per-node operands (loaded one chain node ahead, written to LDS when the node is reached)
-struct IlNodePre { float mx[2], my[2], cv[2]; int relv; float prob; };
-
-__device__ __forceinline__ void il_prefetch_node(const IlqrConst &C, const IlqrTreeDev &T, int c, IlNodePre &P) {
-  const int lane = threadIdx.x & 63;
-  P.prob = T.prob[c];
-  P.relv = lane <= IL_REL ? T.rel[(size_t)c * (IL_REL + 1) + lane] : 0;
-  if (C.use_exo) {
-    const float *mean = T.mean + (size_t)c * T.n_agents * 2;
-    const float *cov = T.cov + (size_t)c * T.n_agents;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int e = lane + 64 * h;
-      if (e < T.n_agents) { P.mx[h] = mean[2 * e]; P.my[h] = mean[2 * e + 1]; P.cv[h] = cov[e]; }
-    }
-  }
-}
-
-// ag[e] = {mean, sigma + offset, threshold}; irel[0] = count, irel[1..] = relevant agent indices (LDS)
-__device__ __forceinline__ void il_commit_node(const IlqrConst &C, const IlqrTreeDev &T, const IlNodePre &P, double *ag, int *irel) {
-  const int lane = threadIdx.x & 63;
-  IL_WFENCE();
-  if (lane <= IL_REL) irel[lane] = P.relv;
-  if (C.use_exo) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int e = lane + 64 * h;
-      if (e < T.n_agents) {
-        const double ec = (double)(P.cv[h] + (float)(e == 0 ? C.w_ego_off : C.w_exo_off));
-        ag[4 * e + 0] = (double)P.mx[h];
-        ag[4 * e + 1] = (double)P.my[h];
-        ag[4 * e + 2] = ec;
-        ag[4 * e + 3] = ec * ec * 1.000000001;
-      }
-    }
-  }
-  IL_WFENCE();
-}
-
-// Roll ALL 10 line-search candidates along one chain segment in one wave (solver.py:202-240): lane
-// group a = lane/6 carries candidate a (its running state lives in registers), sub-lane r = lane%6
-// shares the group's field evaluation.  init != 0: nominal rollout (alpha = 0 for every group).
-template <bool GEN>
-__device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const IlqrTreeDev &T, int seg, int init, double *scr,
-                                                   double *ag) {
+// Phase 1: states/controls of ALL 10 line-search candidates along one chain segment, one wave, candidate
+// a = lane % 10 (lanes >= 10 mirror lanes < 10 and do not store).  init != 0: nominal rollout (alpha = 0,
+// gains are zero).  Writes T.xs_new / T.us_new.
+__device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const IlqrTreeDev &T, int seg, int init IL_PROF_ARG) {
   const int lane = threadIdx.x & 63;
   const int M = T.M;
-  const int a = lane / 6 < IL_NA ? lane / 6 : IL_NA - 1;
-  const int r = lane % 6;
-  const bool writer = (lane < 6 * IL_NA) && r == 0;
+  const int a = lane % IL_NA;
+  const bool writer = lane < IL_NA;
   const double alpha = init ? 0.0 : C.alphas[a];
-  double *cells = scr + 9 * (lane / 6);          // 11 groups x 9 doubles <= 192
   const int s0 = T.seg_start[seg], s1 = T.seg_start[seg + 1];
-  const int p0 = T.parent[T.seg_nodes[s0]];
+  int c = T.seg_nodes[s0];
+  const int p0 = c == 0 ? -1 : T.parent[c];      // node 0 is the only child of the x0 root (checked on the host)
   double xp[6], xo[6];
   if (p0 < 0) {
 #pragma unroll
@@ -553,60 +509,216 @@ __device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const Ilq
 #pragma unroll
     for (int k = 0; k < 6; ++k) { xp[k] = T.xs_new[((size_t)a * M + p0) * 6 + k]; xo[k] = T.xs[(size_t)p0 * 6 + k]; }
   }
-  int c = T.seg_nodes[s0];
-  int *irel = (int *)(scr + 160);          // 16 ints inside the wave scratch (cells use scr[0..99))
-  IlNodePre Pc, Pn;
-  il_prefetch_node(C, T, c, Pc);
+  IlKv Pc, Pn;
+  il_prefetch_kv(T, c, Pc);
   for (int q = s0; q < s1; ++q) {
+    IL_PT0();
     const int cn = q + 1 < s1 ? T.seg_nodes[q + 1] : c;
-    il_prefetch_node(C, T, cn, Pn);
-    double Kc[12], kc[2], uc[2], xoc[6];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Kc[k] = T.K[(size_t)c * 12 + k];
-    kc[0] = T.k[(size_t)c * 2]; kc[1] = T.k[(size_t)c * 2 + 1];
-    uc[0] = T.us[(size_t)c * 2]; uc[1] = T.us[(size_t)c * 2 + 1];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) xoc[k] = T.xs[(size_t)c * 6 + k];
+    il_prefetch_kv(T, cn, Pn);
+    IL_PT(0);
     double u[2], x[6];
-    if (T.parent[c] < 0) {
-      u[0] = uc[0] + alpha * kc[0];
-      u[1] = uc[1] + alpha * kc[1];
+    if (c == 0) {
+      u[0] = Pc.us[0] + alpha * Pc.k[0];
+      u[1] = Pc.us[1] + alpha * Pc.k[1];
     } else {
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         double sm = 0.0;
 #pragma unroll
-        for (int jj = 0; jj < 6; ++jj) sm += Kc[b * 6 + jj] * (xp[jj] - xo[jj]);
-        u[b] = uc[b] + alpha * kc[b] + sm;
+        for (int jj = 0; jj < 6; ++jj) sm += Pc.K[b * 6 + jj] * (xp[jj] - xo[jj]);
+        u[b] = Pc.us[b] + alpha * Pc.k[b] + sm;
       }
     }
     il_dyn_sc(C, xp, u, x);
-    int nrel = -1;
-    const int *rel = irel + 1;
-    il_commit_node(C, T, Pc, ag, irel);
-    if (C.use_exo) {
-      // the list was built around the nominal state xoc; it is exact while the query stays within
-      // IL_RMARGIN of it and inside the grid (no index clamping)
-      const int cnt = irel[0];
-      const double ddx = x[0] - xoc[0], ddy = x[1] - xoc[1];
-      const double fx_ = (x[0] - C.off_x) / C.res, fy_ = (x[1] - C.off_y) / C.res;
-      const bool inside = fx_ > 1.0 && fx_ < (double)(C.W - 2) && fy_ > 1.0 && fy_ < (double)(C.H - 2);
-      if (cnt >= 0 && !init && inside && ddx * ddx + ddy * ddy < IL_RMARGIN * IL_RMARGIN) nrel = cnt;
-    }
-    FieldOut fe;
-    fe.val = il_field_val_group<GEN>(C, T, c, Pc.prob, x[0], x[1], r, cells, ag, rel, nrel);
     if (writer) {
-      const IlNodeW<GEN> NW{C, GEN ? T.node_w + (size_t)c * IL_NW : nullptr, (double)Pc.prob};
-      T.L_new[(size_t)a * M + c] = il_node_cost<GEN>(NW, x, u, fe);
-      double *xn = T.xs_new + ((size_t)a * M + c) * 6, *un = T.us_new + ((size_t)a * M + c) * 2;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) xn[k] = x[k];
-      un[0] = u[0]; un[1] = u[1];
+      double2 *xn = reinterpret_cast<double2 *>(T.xs_new + ((size_t)a * M + c) * 6);
+      xn[0] = make_double2(x[0], x[1]); xn[1] = make_double2(x[2], x[3]); xn[2] = make_double2(x[4], x[5]);
+      *reinterpret_cast<double2 *>(T.us_new + ((size_t)a * M + c) * 2) = make_double2(u[0], u[1]);
     }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { xp[k] = x[k]; xo[k] = xoc[k]; }
+    for (int k = 0; k < 6; ++k) { xp[k] = x[k]; xo[k] = Pc.xs[k]; }
     Pc = Pn;
     c = cn;
+    IL_PT(1); IL_PCNT(5);
+  }
+}
+
+// 3x3 window as separable axes: source column of window column c, source row of window row r, -1 = the
+// cell stays zero (every case of il_window_src is a product of a row and a column condition).
+__device__ __forceinline__ void il_window_axes(int xi, int yi, int W, int H, int *sxc, int *syr) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { sxc[k] = -1; syr[k] = -1; }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      int sy, sx;
+      il_window_src(xi, yi, W, H, r, c, sy, sx);
+      if (sy >= 0) { syr[r] = sy; sxc[c] = sx; }
+    }
+}
+
+// one exo agent's contribution to the 9 window cells (trajectory_tree.py:94-101), accumulated in agent order
+#define IL_EXO_TERM(AX, AY, EC, TH)                                                             \
+  do {                                                                                          \
+    double dx2_[3], dy2_[3];                                                                    \
+    _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                                          \
+      const double dx_ = colx[k_] - (AX), dy_ = rowy[k_] - (AY);                                \
+      dx2_[k_] = dx_ * dx_; dy2_[k_] = dy_ * dy_;                                               \
+    }                                                                                           \
+    /* the smallest of the 9 squared distances decides whether ANY cell can be reached */       \
+    const double mx_ = fmin(dx2_[0], fmin(dx2_[1], dx2_[2])), my_ = fmin(dy2_[0], fmin(dy2_[1], dy2_[2])); \
+    if (!__any(mx_ + my_ <= (TH))) break;                                                        \
+    _Pragma("unroll") for (int r_ = 0; r_ < 3; ++r_)                                            \
+      _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_) {                                        \
+        const double d2_ = dx2_[c_] + dy2_[r_];                                                 \
+        if (d2_ <= (TH)) {                      /* else max(ec - sqrt(d2), 0) == 0 exactly */   \
+          double v_ = (EC) - sqrt(d2_);                                                         \
+          v_ = v_ > 0.0 ? v_ : 0.0;                                                             \
+          if (v_ > 0.0) v_ += C.w_exo_cost;                                                     \
+          cov[r_ * 3 + c_] += v_;                                                               \
+        }                                                                                       \
+      }                                                                                         \
+  } while (0)
+
+// Phase 2: node costs of all candidates, one lane per (slot, node, alpha); a wave takes chunks of 6 nodes
+// x 10 alphas and stages the 6 nodes' compact agent records (T.relag) in its LDS.  The exo sum runs over
+// the records in ascending agent order (the oracle's summation order with provably-zero terms dropped).
+// A candidate outside the validity region of its node's list (or a node whose list overflowed) walks all
+// agents from global memory instead.
+template <bool GEN>
+__device__ __forceinline__ void il_cost_pass(const IlqrConst &C, const IlqrTreeDev &T, int nuse, double *recs IL_PROF_ARG) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int M = T.M, P = nuse * M;
+  const int nchunk = (P + 5) / 6;
+  const int a = lane % IL_NA, pl = lane / IL_NA;
+  for (int ch = wave; ch < nchunk; ch += IL_WAVES) {
+    IL_PT0();
+    const int pi = ch * 6 + pl;
+    const bool valid = lane < 60 && pi < P;
+    const int pic = pi < P ? pi : P - 1;
+    const int slot = pic / M, c = pic % M;
+    // issue every independent load first: the records of the chunk's 6 nodes, the candidate's state/control,
+    // the node's probability / list length / nominal position
+    double rr[6];
+    if (C.use_exo) {
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const int pp = ch * 6 + p < P ? ch * 6 + p : P - 1;
+        rr[p] = T.relag[(size_t)(pp % M) * IL_RA + lane];
+      }
+    }
+    const size_t eo = (size_t)(slot * IL_NA + a) * M + c;
+    double x[6], u[2];
+    {
+      const double2 *px = reinterpret_cast<const double2 *>(T.xs_new + eo * 6);
+      const double2 v0 = px[0], v1 = px[1], v2 = px[2], vu = *reinterpret_cast<const double2 *>(T.us_new + eo * 2);
+      x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y; u[0] = vu.x; u[1] = vu.y;
+    }
+    const float pf = GEN ? 0.f : T.prob[c];
+    int cnt = 0;
+    bool full = false;
+    double nx = 0.0, ny = 0.0;
+    if (C.use_exo) {
+      cnt = T.rel[c];
+      const double2 vn = *reinterpret_cast<const double2 *>(T.xs + (size_t)c * 6);
+      nx = vn.x; ny = vn.y;
+      IL_WFENCE();
+#pragma unroll
+      for (int p = 0; p < 6; ++p) recs[p * IL_RA + lane] = rr[p];
+      IL_WFENCE();
+    }
+    if (C.use_exo) {
+      // the list was built around the nominal state; it is exact while the query stays within IL_RMARGIN of
+      // it and its window inside the grid (no index clamping)
+      const double ddx = x[0] - nx, ddy = x[1] - ny;
+      const bool ok = x[0] > C.in_x0 && x[0] < C.in_x1 && x[1] > C.in_y0 && x[1] < C.in_y1 &&
+                      ddx * ddx + ddy * ddy < IL_RMARGIN * IL_RMARGIN;
+      full = cnt < 0 || !ok;
+    }
+    long xi = (long)rint((x[0] - C.off_x) / C.res);
+    long yi = (long)rint((x[1] - C.off_y) / C.res);
+    xi = xi < 0 ? 0 : (xi > C.W - 1 ? C.W - 1 : xi);
+    yi = yi < 0 ? 0 : (yi > C.H - 1 ? C.H - 1 : yi);
+    int sxc[3], syr[3];
+    il_window_axes((int)xi, (int)yi, C.W, C.H, sxc, syr);
+    double g[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        const int sy = syr[r] < 0 ? 0 : syr[r], sx = sxc[cc] < 0 ? 0 : sxc[cc];
+        g[r * 3 + cc] = GEN ? T.field[((size_t)c * C.H + sy) * C.W + sx] : C.quad[(size_t)sy * C.W + sx];
+      }
+    IL_PT(2);
+    if (!GEN) {
+      const double wp = (double)((float)C.w_tgt * pf);
+      if (C.use_exo) {
+        double colx[3], rowy[3], cov[9];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { colx[k] = il_gx(C, sxc[k] < 0 ? 0 : sxc[k]); rowy[k] = il_gy(C, syr[k] < 0 ? 0 : syr[k]); }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cov[k] = 0.0;
+        const double *rec = recs + pl * IL_RA;
+        double ex, ey, ego_cov;
+        if (!full) {
+          for (int e = 1; e <= cnt; ++e) {
+            const double ax = rec[4 * e], ay = rec[4 * e + 1], ec = rec[4 * e + 2], th = rec[4 * e + 3];
+            IL_EXO_TERM(ax, ay, ec, th);
+          }
+          ex = rec[0]; ey = rec[1]; ego_cov = rec[2];
+        } else {
+          const float *mean = T.mean + (size_t)c * T.n_agents * 2;
+          const float *cv = T.cov + (size_t)c * T.n_agents;
+          for (int e = 1; e < T.n_agents; ++e) {
+            const double ax = (double)mean[2 * e], ay = (double)mean[2 * e + 1];
+            const double ec = (double)(cv[e] + (float)C.w_exo_off), th = ec * ec * 1.000000001;
+            IL_EXO_TERM(ax, ay, ec, th);
+          }
+          ex = (double)mean[0]; ey = (double)mean[1]; ego_cov = (double)(cv[0] + (float)C.w_ego_off);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            const double dx = colx[cc] - ex, dy = rowy[r] - ey;
+            double ego = sqrt(dx * dx + dy * dy) - ego_cov;
+            ego = ego > 0.0 ? ego : 0.0;
+            g[r * 3 + cc] = (wp * g[r * 3 + cc] + C.w_exo * cov[r * 3 + cc]) + C.w_ego * ego;
+          }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) g[k] = wp * g[k];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+        if (syr[r] < 0 || sxc[cc] < 0) g[r * 3 + cc] = 0.0;
+    IL_PT(3);
+    double s00, s02, s20, s22, s01, s10, s12, s21, s11;
+    s00 = (((g[0] + g[1]) + g[3]) + g[4]) / 4.0;
+    s02 = (((g[1] + g[2]) + g[4]) + g[5]) / 4.0;
+    s20 = (((g[3] + g[4]) + g[6]) + g[7]) / 4.0;
+    s22 = (((g[4] + g[5]) + g[7]) + g[8]) / 4.0;
+    s01 = (g[1] + g[4]) / 2.0;
+    s10 = (g[3] + g[4]) / 2.0;
+    s12 = (g[4] + g[5]) / 2.0;
+    s21 = (g[4] + g[7]) / 2.0;
+    s11 = g[4];
+    const double uu = (x[0] - il_gx(C, (int)xi)) / C.res + 0.5;
+    const double vv = (x[1] - il_gy(C, (int)yi)) / C.res + 0.5;
+    const double u1 = 1 - uu, v1 = 1 - vv;
+    FieldOut fe;
+    fe.val = u1 * u1 * v1 * v1 * s00 + u1 * u1 * 2.0 * v1 * vv * s10 + u1 * u1 * vv * vv * s20 +
+             2.0 * u1 * uu * v1 * v1 * s01 + 2.0 * u1 * uu * 2.0 * v1 * vv * s11 + 2.0 * u1 * uu * vv * vv * s21 +
+             uu * uu * v1 * v1 * s02 + uu * uu * 2.0 * v1 * vv * s12 + uu * uu * vv * vv * s22;
+    if (valid) {
+      const IlNodeW<GEN> NW{C, GEN ? T.node_w + (size_t)c * IL_NW : nullptr, (double)pf};
+      T.L_new[eo] = il_node_cost<GEN>(NW, x, u, fe);
+    }
+    IL_PT(4); IL_PCNT(15);
   }
 }
 
@@ -664,8 +776,9 @@ __device__ __forceinline__ void il_node_derivs(const IlqrConst &C, const IlqrTre
 // because xs/us are already known (the accepted line-search candidate IS the next nominal rollout).
 // One wave per node, one matrix entry per lane (no private arrays: they would live in scratch memory).
 template <bool GEN>
-__device__ __forceinline__ void il_derivatives(const IlqrConst &C, const IlqrTreeDev &T, int c, double *scr, double *ag) {
+__device__ __forceinline__ void il_derivatives(const IlqrConst &C, const IlqrTreeDev &T, int c, double *scr, double *ag IL_PROF_ARG) {
   const int lane = threadIdx.x & 63;
+  IL_PT0();
   double x[6], u[2];
 #pragma unroll
   for (int k = 0; k < 6; ++k) x[k] = T.xs[(size_t)c * 6 + k];
@@ -674,7 +787,8 @@ __device__ __forceinline__ void il_derivatives(const IlqrConst &C, const IlqrTre
     il_stage_agents(C, T, c, ag);
     // relevant agents for the next line search: |mu_e - x| < (sigma_e + offset) + margin + window reach,
     // compacted in ascending agent order with wave ballots
-    int *rl = T.rel + (size_t)c * (IL_REL + 1);
+    double *ra = T.relag + (size_t)c * IL_RA;
+    if (lane < 4) ra[lane] = ag[lane];               // record 0 = ego
     int cnt = 0;
     for (int base = 1; base < T.n_agents; base += 64) {
       const int e = base + lane;
@@ -686,13 +800,18 @@ __device__ __forceinline__ void il_derivatives(const IlqrConst &C, const IlqrTre
       }
       const unsigned long long m = __ballot(hit);
       const int rank = __popcll(m & ((1ull << lane) - 1ull));
-      if (hit && cnt >= 0 && cnt + rank < IL_REL) rl[1 + cnt + rank] = e;
+      if (hit && cnt >= 0 && cnt + rank < IL_REL) {
+        double *dst = ra + 4 * (1 + cnt + rank);
+        dst[0] = ag[4 * e]; dst[1] = ag[4 * e + 1]; dst[2] = ag[4 * e + 2]; dst[3] = ag[4 * e + 3];
+      }
       const int tot = __popcll(m);
       cnt = (cnt < 0 || cnt + tot > IL_REL) ? -1 : cnt + tot;
     }
-    if (lane == 0) rl[0] = cnt;
+    if (lane == 0) T.rel[c] = cnt;
   }
+  IL_PT(11);
   il_node_derivs<GEN>(C, T, c, x, u, scr, ag, T.Lxx + (size_t)c * 36, T.Fx + (size_t)c * 36, T.Lx + (size_t)c * 6, T.L + c);
+  IL_PT(12); IL_PCNT(14);
 }
 
 // LM schedule after one rejection (solver.py:153-158)
@@ -705,16 +824,24 @@ template <bool GEN>
 __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restrict__ trees, IlqrConst C) {
   const IlqrTreeDev T = trees[blockIdx.x];
   extern __shared__ double il_dsm[];
-  // LDS carve: per-wave scratch [IL_WAVES][192] | per-wave agent table [IL_WAVES][4*amax] | cost sums [IL_LSUM]
-  const int amax = T.n_agents;
-  double *scr = il_dsm + (size_t)(threadIdx.x >> 6) * 192;
-  double *ag = il_dsm + (size_t)IL_WAVES * 192 + (size_t)(threadIdx.x >> 6) * 4 * amax;
-  double *lsum = il_dsm + (size_t)IL_WAVES * 192 + (size_t)IL_WAVES * 4 * amax;
+  // LDS carve: per-wave scratch [IL_WAVES][IL_SCR] | per-wave agent table [IL_WAVES][4*amax] | cost sums [IL_LSUM]
+  const int agw = il_ag_doubles(T.n_agents);
+  double *scr = il_dsm + (size_t)(threadIdx.x >> 6) * IL_SCR;
+  double *ag = il_dsm + (size_t)IL_WAVES * IL_SCR + (size_t)(threadIdx.x >> 6) * agw;
+  double *lsum = il_dsm + (size_t)IL_WAVES * IL_SCR + (size_t)IL_WAVES * agw;
+  double *recs = lsum + IL_LSUM + (size_t)(threadIdx.x >> 6) * 6 * IL_RA;   // cost pass: 6 nodes' records per wave
+  if ((threadIdx.x & 63) < 12) {
+    const int l = threadIdx.x & 63;
+    scr[IL_CST + l] = l == 0 ? 1.0 : (l == 6 ? C.dt : 0.0);
+  }
   __shared__ double Jnew[IL_SPEC][IL_NA];
   __shared__ double sh_mu, sh_delta, sh_J;
   __shared__ int sh_accepted, sh_converged, sh_stop, sh_sing, sh_pick, sh_slot, sh_it, sh_nspec;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = T.M;
+#ifdef IL_PROFILE
+  long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   if (tid == 0) { sh_mu = 1.0; sh_delta = 2.0; sh_accepted = 1; sh_converged = 0; sh_stop = 0; sh_J = 0.0; sh_pick = 0; sh_slot = 0; sh_it = 0; }
   // ---- initial nominal rollout (solver.py:255-330) = candidate slot 0 with k = K = 0, alpha = 0
   for (int q = tid; q < M * 2; q += IL_THREADS) T.k[q] = 0.0;
@@ -724,7 +851,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
   __syncthreads();
   for (int d = 0; d < T.n_slevels; ++d) {
     for (int q = T.slevel_start[d] + wave; q < T.slevel_start[d + 1]; q += IL_WAVES)
-      il_rollout_segment<GEN>(C, T, T.slevel_segs[q], 1, scr, ag);
+      il_rollout_segment(C, T, T.slevel_segs[q], 1 IL_PROF_PASS);
     __threadfence_block();
     __syncthreads();
   }
@@ -743,7 +870,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
       for (int q = tid; q < M * 2; q += IL_THREADS) T.us[q] = un[q];
       __threadfence_block();
       __syncthreads();
-      for (int c = wave; c < M; c += IL_WAVES) il_derivatives<GEN>(C, T, c, scr, ag);
+      for (int c = wave; c < M; c += IL_WAVES) il_derivatives<GEN>(C, T, c, scr, ag IL_PROF_PASS);
       __threadfence_block();
       __syncthreads();
       if (M <= IL_LSUM) {
@@ -812,7 +939,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
             if (GEN) { nw0 = T.node_w[(size_t)cn * IL_NW + 24]; nw1 = T.node_w[(size_t)cn * IL_NW + 25]; }
             else { const double np_ = (double)T.prob[cn]; nw0 = C.w_ctrl[0] * np_; nw1 = C.w_ctrl[1] * np_; }
           }
-          sing = il_gains(C, Ts, T.seg_nodes[r], mu, scr, pfx, plxx, plx, pu0, pu1, pw0, pw1);
+          sing = il_gains(C, Ts, T.seg_nodes[r], mu, scr, pfx, plxx, plx, pu0, pu1, pw0, pw1 IL_PROF_PASS);
           pfx = nfx; plxx = nlxx; plx = nlx; pu0 = nu0; pu1 = nu1; pw0 = nw0; pw1 = nw1;
         }
         if (sing) { if (lane == 0) atomicOr(&sh_sing, 1 << slot); }
@@ -842,11 +969,14 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
         IlqrTreeDev Ts = T;
         Ts.k += (size_t)slot * M * 2; Ts.K += (size_t)slot * M * 12;
         Ts.xs_new += (size_t)slot * IL_NA * M * 6; Ts.us_new += (size_t)slot * IL_NA * M * 2; Ts.L_new += (size_t)slot * IL_NA * M;
-        il_rollout_segment<GEN>(C, Ts, seg, 0, scr, ag);
+        il_rollout_segment(C, Ts, seg, 0 IL_PROF_PASS);
       }
       __threadfence_block();
       __syncthreads();
     }
+    il_cost_pass<GEN>(C, T, nuse, recs IL_PROF_PASS);
+    __threadfence_block();
+    __syncthreads();
     IL_MARK(t_ls);
     if (M * IL_NA * nuse <= IL_LSUM) {
       for (int q = tid; q < M * IL_NA * nuse; q += IL_THREADS) lsum[q] = T.L_new[q];
@@ -901,10 +1031,15 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
     T.stats[2] = sh_J;
     T.stats[3] = sh_mu;
     T.stats[4] = (double)t_der; T.stats[5] = (double)t_bw; T.stats[6] = (double)t_ls; T.stats[7] = (double)t_sel;
+#ifdef IL_PROFILE
+    for (int q = 0; q < 16; ++q) T.stats[8 + q] = (double)prof[q];
+#endif
   }
 }
 
-static inline size_t il_lds_bytes(int amax) { return ((size_t)IL_WAVES * 192 + (size_t)IL_WAVES * 4 * amax + IL_LSUM) * sizeof(double); }
+static inline size_t il_lds_bytes(int amax) {
+  return ((size_t)IL_WAVES * IL_SCR + (size_t)IL_WAVES * il_ag_doubles(amax) + IL_LSUM + (size_t)IL_WAVES * 6 * IL_RA) * sizeof(double);
+}
 
 // TreeCost.l / l_x / l_u / l_xx / l_uu (cost.py:341-446) at arbitrary (x, u) of given nodes: one wave per
 // query.  out[q] = { l, l_x[6], l_u[2], l_xx[36], l_uu diag[2] } (47 doubles).
@@ -915,7 +1050,7 @@ __global__ __launch_bounds__(64) void k_cost_eval(const IlqrTreeDev *__restrict_
                                                   const double *__restrict__ uq, double *__restrict__ out) {
   const IlqrTreeDev T = trees[0];
   extern __shared__ double il_dsm[];
-  double *scr = il_dsm, *ag = il_dsm + 192;
+  double *scr = il_dsm, *ag = il_dsm + IL_SCR;
   const int q = blockIdx.x, lane = threadIdx.x;
   if (q >= nq) return;
   const int c = node[q];

@@ -748,7 +748,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   const size_t o_gx = takeD(W), o_gy = takeD(H), o_lane = takeD((size_t)n_lane_pts * 2 + 2), o_quad = takeD(gen ? 2 : (size_t)W * H);
   const size_t o_evx = takeD(ev ? (size_t)ev->nq * 6 : 0), o_evu = takeD(ev ? (size_t)ev->nq * 2 : 0), o_evo = takeD(ev ? (size_t)ev->nq * IL_EVAL_OUT : 0);
   const size_t o_evn = takeI(ev ? ev->nq : 0);
-  struct TL { size_t nodew, field; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel; int M, a, nl, nseg, nsl, maxls; };
+  struct TL { size_t nodew, field, relag; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel; int M, a, nl, nseg, nsl, maxls; };
   std::vector<TL> tl(n_trees);
   long Mtot = 0;
   for (int t = 0; t < n_trees; ++t) {
@@ -760,11 +760,12 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     TL &L = tl[t];
     L.M = (int)M; L.a = gen ? 1 : tr.n_agents;
     L.nodew = takeD(gen ? M * IL_NW : 0);
+    L.relag = takeD(use_exo ? M * IL_RA : 0);
     L.xs = takeD(6 * M); L.us = takeD(2 * M); L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M);
     L.Lxx = takeD(36 * M); L.k = takeD(IL_SPEC * 2 * M); L.K = takeD(IL_SPEC * 12 * M); L.Vx = takeD(IL_SPEC * 6 * M); L.Vxx = takeD(IL_SPEC * 36 * M);
-    L.xsn = takeD(IL_SPEC * 60 * M); L.usn = takeD(IL_SPEC * 20 * M); L.Ln = takeD(IL_SPEC * 10 * M); L.stats = takeD(8);
+    L.xsn = takeD(IL_SPEC * 60 * M); L.usn = takeD(IL_SPEC * 20 * M); L.Ln = takeD(IL_SPEC * 10 * M); L.stats = takeD(IL_NSTAT);
     L.prob = takeF(M); L.mean = takeF(M * L.a * 2); L.cov = takeF(M * L.a);
-    L.parent = takeI(M); L.lnodes = takeI(M); L.cstart = takeI(M + 1); L.clist = takeI(M); L.rel = takeI(M * (IL_REL + 1));
+    L.parent = takeI(M); L.lnodes = takeI(M); L.cstart = takeI(M + 1); L.clist = takeI(M); L.rel = takeI(M);
     Mtot += (long)M;
   }
   // levels need the depth first
@@ -877,6 +878,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     D.parent = dI + L.parent; D.level_start = dI + L.lstart; D.level_nodes = dI + L.lnodes;
     D.child_start = dI + L.cstart; D.child_list = dI + L.clist;
     D.rel = dI + L.rel;
+    D.relag = dD + L.relag;
     D.field = gen ? (const double *)(base + L.field) : nullptr;
     D.node_w = gen ? dD + L.nodew : nullptr;
     D.n_segs = L.nseg; D.n_slevels = L.nsl; D.max_level_segs = L.maxls; D.pad2 = 0;
@@ -904,12 +906,19 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   K.W = W; K.H = H; K.max_iter = cfg->max_iter; K.use_exo = use_exo;
   for (int j = 0; j < IL_NA; ++j) K.alphas[j] = std::pow(1.1, -(double)(j * j));
   K.gx = dD + o_gx; K.gy = dD + o_gy; K.quad = dD + o_quad;
+  // cell centres are computed in the kernels when the grid is the numpy linspace (always in the planner mode)
+  K.stepx = fsx / (double)(W - 1); K.stepy = fsy / (double)(H - 1); K.fsx = fsx; K.fsy = fsy;
+  K.lin = 1;
+  for (int i = 0; i < W && K.lin; ++i) K.lin = gx[i] == ((i == W - 1 ? K.fsx : (double)i * K.stepx) + offx);
+  for (int i = 0; i < H && K.lin; ++i) K.lin = gy[i] == ((i == H - 1 ? K.fsy : (double)i * K.stepy) + offy);
+  K.in_x0 = offx + 1.5 * grid_res; K.in_x1 = offx + ((double)W - 2.5) * grid_res;
+  K.in_y0 = offy + 1.5 * grid_res; K.in_y1 = offy + ((double)H - 2.5) * grid_res;
   if (!gen) hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, K.gx, K.gy, W, H, dD + o_lane, n_lane_pts, dD + o_quad);
   int amax = 1;
   for (int t = 0; t < n_trees; ++t) amax = tl[t].a > amax ? tl[t].a : amax;
   const IlqrTreeDev *dT = (const IlqrTreeDev *)(base + o_structs);
   if (ev) {
-    const size_t lds = (192 + (size_t)4 * amax) * sizeof(double);
+    const size_t lds = (IL_SCR + (size_t)4 * amax) * sizeof(double);
     if (gen) hipLaunchKernelGGL(k_cost_eval<true>, dim3(ev->nq), dim3(64), lds, st, dT, K, ev->nq, dI + o_evn, dD + o_evx, dD + o_evu, dD + o_evo);
     else hipLaunchKernelGGL(k_cost_eval<false>, dim3(ev->nq), dim3(64), lds, st, dT, K, ev->nq, dI + o_evn, dD + o_evx, dD + o_evu, dD + o_evo);
     HIPCHK(c, hipGetLastError());
@@ -927,22 +936,32 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   }
   HIPCHK(c, hipGetLastError());
   moff = 0;
-  std::vector<double> hs(8 * n_trees);
+  std::vector<double> hs((size_t)IL_NSTAT * n_trees);
   for (int t = 0; t < n_trees; ++t) {
     const TL &L = tl[t];
     HIPCHK(c, hipMemcpyAsync(xs + moff * 6, dD + L.xs, (size_t)L.M * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(us + moff * 2, dD + L.us, (size_t)L.M * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(hs.data() + 8 * t, dD + L.stats, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hs.data() + (size_t)IL_NSTAT * t, dD + L.stats, IL_NSTAT * sizeof(double), hipMemcpyDeviceToHost, st));
     moff += L.M;
   }
   HIPCHK(c, hipStreamSynchronize(st));
   if (stats)
     for (int t = 0; t < n_trees; ++t) {
-      stats[t].iterations = (int)hs[8 * t]; stats[t].converged = (int)hs[8 * t + 1];
-      stats[t].J = hs[8 * t + 2]; stats[t].mu = hs[8 * t + 3];
+      const double *h = hs.data() + (size_t)IL_NSTAT * t;
+      stats[t].iterations = (int)h[0]; stats[t].converged = (int)h[1];
+      stats[t].J = h[2]; stats[t].mu = h[3];
       if (getenv("MIND_ILQR_TRACE"))
         fprintf(stderr, "[k_ilqr] tree %d exo %d M %d segs %d seg-levels %d widest %d agents %d it %d: cycles derivatives %.0f backward %.0f linesearch %.0f select %.0f\n", t,
-                use_exo, tl[t].M, tl[t].nseg, tl[t].nsl, tl[t].maxls, tl[t].a, stats[t].iterations, hs[8 * t + 4], hs[8 * t + 5], hs[8 * t + 6], hs[8 * t + 7]);
+                use_exo, tl[t].M, tl[t].nseg, tl[t].nsl, tl[t].maxls, tl[t].a, stats[t].iterations, h[4], h[5], h[6], h[7]);
+#ifdef IL_PROFILE
+      if (getenv("MIND_ILQR_TRACE")) {
+        fprintf(stderr, "[k_ilqr prof] wave0: chain node (n=%.0f): stage %.0f u+dyn+store %.0f | cost chunk (n=%.0f): stage+loads %.0f field %.0f cost+store %.0f | riccati node (n=%.0f): products %.0f Qxx %.0f solve %.0f update %.0f | deriv node (n=%.0f): stage %.0f field+trig %.0f\n",
+                h[13], h[8] / fmax(h[13], 1), h[9] / fmax(h[13], 1),
+                h[23], h[10] / fmax(h[23], 1), h[11] / fmax(h[23], 1), h[12] / fmax(h[23], 1),
+                h[18], h[14] / fmax(h[18], 1), h[15] / fmax(h[18], 1), h[16] / fmax(h[18], 1), h[17] / fmax(h[18], 1),
+                h[22], h[19] / fmax(h[22], 1), h[20] / fmax(h[22], 1));
+      }
+#endif
     }
   return MIND_OK;
 }
