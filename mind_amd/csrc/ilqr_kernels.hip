@@ -86,7 +86,7 @@ struct IlqrConst {
 
 // fine-grained cycle attribution (diagnostic build only: -DIL_PROFILE); slots: 0-1 chain-rollout node (stage,
 // u+dynamics+store), 5 nodes; 2-4 cost-pass chunk (stage+loads, field, cost+store), 15 chunks; 6-9 Riccati
-// node (products, Qxx, solve, value update), 10 nodes; 11-12 derivative node (stage+lists, field+trig), 14 nodes
+// node (products, Qxx, solve, value update), 10 nodes; 11-13 derivative block (setup, tasks, assemble), 14 blocks
 #ifdef IL_PROFILE
 #define IL_PROF_ARG , long long *prof
 #define IL_PROF_PASS , prof
@@ -772,46 +772,212 @@ __device__ __forceinline__ void il_node_derivs(const IlqrConst &C, const IlqrTre
   }
 }
 
-// Derivatives at the accepted iterate (solver.py:285-294,308-320): embarrassingly parallel over nodes
-// because xs/us are already known (the accepted line-search candidate IS the next nominal rollout).
-// One wave per node, one matrix entry per lane (no private arrays: they would live in scratch memory).
+// Derivatives at the accepted iterate (solver.py:285-294,308-320; xs/us are already known: the accepted
+// line-search candidate IS the next nominal rollout), one LANE per node, blocks of up to 64 nodes.  The block's
+// agent arrays are staged agent-major in LDS; eleven independent tasks are spread over the waves -- the nine
+// window cells (exo sum over ALL agents in ascending order, as the oracle), the relevant-agent records for
+// the next line search, the dynamics Jacobian -- then wave 0 assembles value / gradient / Hessian per node.
+// Only the entries of F_x / l_xx that ever change are written (the rest is set once at kernel start).
+#define IL_DSTG 12288   // floats of LDS staging: 3 x agents x (nodes per block + 1)
 template <bool GEN>
-__device__ __forceinline__ void il_derivatives(const IlqrConst &C, const IlqrTreeDev &T, int c, double *scr, double *ag IL_PROF_ARG) {
-  const int lane = threadIdx.x & 63;
-  IL_PT0();
-  double x[6], u[2];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) x[k] = T.xs[(size_t)c * 6 + k];
-  u[0] = T.us[(size_t)c * 2]; u[1] = T.us[(size_t)c * 2 + 1];
-  if (C.use_exo) {
-    il_stage_agents(C, T, c, ag);
-    // relevant agents for the next line search: |mu_e - x| < (sigma_e + offset) + margin + window reach,
-    // compacted in ascending agent order with wave ballots
-    double *ra = T.relag + (size_t)c * IL_RA;
-    if (lane < 4) ra[lane] = ag[lane];               // record 0 = ego
-    int cnt = 0;
-    for (int base = 1; base < T.n_agents; base += 64) {
-      const int e = base + lane;
-      bool hit = false;
-      if (e < T.n_agents) {
-        const double dx = ag[4 * e] - x[0], dy = ag[4 * e + 1] - x[1];
-        const double rr = ag[4 * e + 2] + IL_RMARGIN + 1.0;      // 1.0 > 1.5 cells * sqrt(2) * 0.4 m
-        hit = dx * dx + dy * dy < rr * rr;
+__device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTreeDev &T, double *gcell, float *stg IL_PROF_ARG) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = T.M, A = T.n_agents;
+  const bool exo = !GEN && C.use_exo;
+  int nb = 64;
+  if (exo && 3 * A * (nb + 1) > IL_DSTG) nb = IL_DSTG / (3 * A) - 1;
+  const int nbp = nb + 1;                       // padded row: conflict-free transposed writes
+  float *smx = stg, *smy = stg + A * nbp, *scv = stg + 2 * A * nbp;
+  for (int n0 = 0; n0 < M; n0 += nb) {
+    IL_PT0();
+    const int nn = M - n0 < nb ? M - n0 : nb;
+    if (exo) {
+      for (int q = tid; q < nn * A; q += IL_THREADS) {
+        const int n = q / A, e = q - n * A;
+        const float2 m = reinterpret_cast<const float2 *>(T.mean)[(size_t)(n0 + n) * A + e];
+        smx[e * nbp + n] = m.x; smy[e * nbp + n] = m.y; scv[e * nbp + n] = T.cov[(size_t)(n0 + n) * A + e];
       }
-      const unsigned long long m = __ballot(hit);
-      const int rank = __popcll(m & ((1ull << lane) - 1ull));
-      if (hit && cnt >= 0 && cnt + rank < IL_REL) {
-        double *dst = ra + 4 * (1 + cnt + rank);
-        dst[0] = ag[4 * e]; dst[1] = ag[4 * e + 1]; dst[2] = ag[4 * e + 2]; dst[3] = ag[4 * e + 3];
-      }
-      const int tot = __popcll(m);
-      cnt = (cnt < 0 || cnt + tot > IL_REL) ? -1 : cnt + tot;
+      __syncthreads();
     }
-    if (lane == 0) T.rel[c] = cnt;
+    const bool valid = lane < nn;
+    const int n = valid ? lane : nn - 1;
+    const int c = n0 + n;
+    double x[6], u[2];
+    {
+      const double2 *px = reinterpret_cast<const double2 *>(T.xs + (size_t)c * 6);
+      const double2 v0 = px[0], v1 = px[1], v2 = px[2], vu = *reinterpret_cast<const double2 *>(T.us + (size_t)c * 2);
+      x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y; u[0] = vu.x; u[1] = vu.y;
+    }
+    const float pf = GEN ? 0.f : T.prob[c];
+    long xi = (long)rint((x[0] - C.off_x) / C.res);
+    long yi = (long)rint((x[1] - C.off_y) / C.res);
+    xi = xi < 0 ? 0 : (xi > C.W - 1 ? C.W - 1 : xi);
+    yi = yi < 0 ? 0 : (yi > C.H - 1 ? C.H - 1 : yi);
+    int sxc[3], syr[3];
+    il_window_axes((int)xi, (int)yi, C.W, C.H, sxc, syr);
+    IL_PT(11);
+    for (int task = wave; task < 11; task += IL_WAVES) {
+      if (task < 9) {
+        // ---- one window cell of every node of the block (trajectory_tree.py:78-108)
+        const int r = task / 3, cc = task - 3 * r;
+        const int sy0 = r == 0 ? syr[0] : (r == 1 ? syr[1] : syr[2]);
+        const int sx0 = cc == 0 ? sxc[0] : (cc == 1 ? sxc[1] : sxc[2]);
+        const int sy = sy0 < 0 ? 0 : sy0, sx = sx0 < 0 ? 0 : sx0;
+        double v;
+        if (GEN) {
+          v = T.field[((size_t)c * C.H + sy) * C.W + sx];
+        } else {
+          const double q = C.quad[(size_t)sy * C.W + sx];
+          const double wp = (double)((float)C.w_tgt * pf);
+          if (exo) {
+            const double cx = il_gx(C, sx), cy = il_gy(C, sy);
+            double covf = 0.0;
+            for (int e0 = 1; e0 < A; e0 += 4) {
+              double ec[4], d2[4];
+              bool need = false;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k < A ? e0 + k : A - 1;
+                const double ax = (double)smx[e * nbp + n], ay = (double)smy[e * nbp + n];
+                ec[k] = (double)(scv[e * nbp + n] + (float)C.w_exo_off);
+                const double dx = cx - ax, dy = cy - ay;
+                d2[k] = dx * dx + dy * dy;
+                if (e0 + k >= A || d2[k] > ec[k] * ec[k] * 1.000000001) d2[k] = -1.0;   // max(ec - sqrt(d2), 0) == 0 exactly
+                need |= d2[k] >= 0.0;
+              }
+              if (__any(need)) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  double t = d2[k] >= 0.0 ? ec[k] - sqrt(d2[k]) : 0.0;
+                  t = t > 0.0 ? t : 0.0;
+                  if (t > 0.0) t += C.w_exo_cost;
+                  covf += t;
+                }
+              }
+            }
+            const double ego_cov = (double)(scv[n] + (float)C.w_ego_off);
+            const double dx = cx - (double)smx[n], dy = cy - (double)smy[n];
+            double ego = sqrt(dx * dx + dy * dy) - ego_cov;
+            ego = ego > 0.0 ? ego : 0.0;
+            v = (wp * q + C.w_exo * covf) + C.w_ego * ego;
+          } else {
+            v = wp * q;
+          }
+        }
+        gcell[n * 9 + task] = (sy0 >= 0 && sx0 >= 0) ? v : 0.0;
+      } else if (task == 9) {
+        // ---- compact records of the agents near the nominal state, for the next line search:
+        //      |mu_e - x| < (sigma_e + offset) + margin + window reach, ascending agent order
+        if (exo) {
+          double *ra = T.relag + (size_t)c * IL_RA;
+          int cnt = 0;
+          if (valid) {
+            const double ec0 = (double)(scv[n] + (float)C.w_ego_off);
+            ra[0] = (double)smx[n]; ra[1] = (double)smy[n]; ra[2] = ec0; ra[3] = ec0 * ec0 * 1.000000001;
+          }
+          for (int e = 1; e < A; ++e) {
+            const double ax = (double)smx[e * nbp + n], ay = (double)smy[e * nbp + n];
+            const double ec = (double)(scv[e * nbp + n] + (float)C.w_exo_off);
+            const double dx = ax - x[0], dy = ay - x[1];
+            const double rr = ec + IL_RMARGIN + 1.0;      // 1.0 > 1.5 cells * sqrt(2) * 0.4 m
+            if (dx * dx + dy * dy < rr * rr) {
+              if (cnt >= 0 && cnt < IL_REL) {
+                if (valid) {
+                  double *dst = ra + 4 * (1 + cnt);
+                  dst[0] = ax; dst[1] = ay; dst[2] = ec; dst[3] = ec * ec * 1.000000001;
+                }
+                ++cnt;
+              } else {
+                cnt = -1;
+              }
+            }
+          }
+          if (valid) T.rel[c] = cnt;
+        }
+      } else {
+        // ---- f_x at the POST state (Q1); constant entries were written at kernel start
+        double s3, c3;
+        sincos(x[3], &s3, &c3);
+        const double c5 = cos(x[5]);
+        const double t5 = tan(x[5]);
+        if (valid) {
+          double *F = T.Fx + (size_t)c * 36;
+          F[2] = c3 * C.dt;
+          F[3] = -x[2] * s3 * C.dt;
+          F[8] = s3 * C.dt;
+          F[9] = x[2] * c3 * C.dt;
+          F[20] = t5 / C.wb * C.dt;
+          F[23] = x[2] / C.wb / (c5 * c5) * C.dt;
+        }
+      }
+    }
+    __syncthreads();
+    IL_PT(12);
+    if (wave == 0) {
+      // ---- PotentialField value / gradient / Hessian (potential.py:146-260) and the node's cost derivatives
+      double g[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) g[k] = gcell[n * 9 + k];
+      const double s00 = (((g[0] + g[1]) + g[3]) + g[4]) / 4.0;
+      const double s02 = (((g[1] + g[2]) + g[4]) + g[5]) / 4.0;
+      const double s20 = (((g[3] + g[4]) + g[6]) + g[7]) / 4.0;
+      const double s22 = (((g[4] + g[5]) + g[7]) + g[8]) / 4.0;
+      const double s01 = (g[1] + g[4]) / 2.0;
+      const double s10 = (g[3] + g[4]) / 2.0;
+      const double s12 = (g[4] + g[5]) / 2.0;
+      const double s21 = (g[4] + g[7]) / 2.0;
+      const double s11 = g[4];
+      const double res = C.res;
+      const double uu = (x[0] - il_gx(C, (int)xi)) / res + 0.5;
+      const double vv = (x[1] - il_gy(C, (int)yi)) / res + 0.5;
+      const double u1 = 1 - uu, v1 = 1 - vv;
+      FieldOut fe;
+      fe.val = u1 * u1 * v1 * v1 * s00 + u1 * u1 * 2.0 * v1 * vv * s10 + u1 * u1 * vv * vv * s20 +
+               2.0 * u1 * uu * v1 * v1 * s01 + 2.0 * u1 * uu * 2.0 * v1 * vv * s11 + 2.0 * u1 * uu * vv * vv * s21 +
+               uu * uu * v1 * v1 * s02 + uu * uu * 2.0 * v1 * vv * s12 + uu * uu * vv * vv * s22;
+      const double a = -2.0 + 2.0 * uu, b = 2.0 * (1.0 - 2.0 * uu), cq = uu * 2.0;
+      fe.gx = 1.0 / res * (a * v1 * v1 * s00 + a * 2.0 * v1 * vv * s10 + a * vv * vv * s20 +
+                           b * v1 * v1 * s01 + b * 2.0 * v1 * vv * s11 + b * vv * vv * s21 +
+                           cq * v1 * v1 * s02 + cq * 2.0 * v1 * vv * s12 + cq * vv * vv * s22);
+      const double av = -2.0 + 2.0 * vv, bv = 2.0 * (1.0 - 2.0 * vv), cv = 2.0 * vv;
+      fe.gy = 1.0 / res * (u1 * u1 * av * s00 + u1 * u1 * bv * s10 + u1 * u1 * cv * s20 +
+                           2.0 * u1 * uu * av * s01 + 2.0 * u1 * uu * bv * s11 + 2.0 * u1 * uu * cv * s21 +
+                           uu * uu * av * s02 + uu * uu * bv * s12 + uu * uu * cv * s22);
+      const double r2 = 1.0 / (res * res);
+      fe.hxx = r2 * (2.0 * v1 * v1 * s00 + 2.0 * v1 * 2.0 * vv * s10 + 2.0 * vv * vv * s20 +
+                     -4.0 * v1 * v1 * s01 + -4.0 * v1 * 2.0 * vv * s11 + -4.0 * vv * vv * s21 +
+                     2.0 * v1 * v1 * s02 + 2.0 * v1 * 2.0 * vv * s12 + 2.0 * vv * vv * s22);
+      fe.hyy = r2 * (2.0 * u1 * u1 * s00 + -4.0 * u1 * u1 * s10 + 2.0 * u1 * u1 * s20 +
+                     2.0 * u1 * 2.0 * uu * s01 + -4.0 * u1 * 2.0 * uu * s11 + 2.0 * u1 * 2.0 * uu * s21 +
+                     2.0 * uu * uu * s02 + -4.0 * uu * uu * s12 + 2.0 * uu * uu * s22);
+      fe.hxy = r2 * (a * av * s00 + a * bv * s10 + a * cv * s20 +
+                     b * av * s01 + b * bv * s11 + b * cv * s21 +
+                     2.0 * uu * av * s02 + 2.0 * uu * bv * s12 + 2.0 * uu * cv * s22);
+      const IlNodeW<GEN> NW{C, GEN ? T.node_w + (size_t)c * IL_NW : nullptr, (double)pf};
+      const double Lc = il_node_cost<GEN>(NW, x, u, fe);
+      if (valid) {
+        double *Lxx = T.Lxx + (size_t)c * 36, *Lx = T.Lx + (size_t)c * 6;
+        T.L[c] = Lc;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          double h = 0.0, gk = 0.0;
+          if (k == 0) { h += fe.hxx; gk += fe.gx; }
+          if (k == 1) { h += fe.hyy; gk += fe.gy; }
+          h += 2.0 * NW.wdes(k);
+          gk += 2.0 * (NW.wdes(k) * (x[k] - NW.des(k)));
+          const double w = NW.wcon(k);
+          if (x[k] > NW.ub(k) || x[k] < NW.lb(k)) h += 2.0 * w;
+          if (x[k] > NW.ub(k)) gk += 2.0 * w * (x[k] - NW.ub(k));
+          else if (x[k] < NW.lb(k)) gk += 2.0 * w * (x[k] - NW.lb(k));
+          Lxx[k * 7] = h;
+          Lx[k] = gk;
+        }
+        { double h = 0.0; h += fe.hxy; Lxx[1] = h; Lxx[6] = h; }
+      }
+    }
+    IL_PT(13); IL_PCNT(14);
+    __syncthreads();
   }
-  IL_PT(11);
-  il_node_derivs<GEN>(C, T, c, x, u, scr, ag, T.Lxx + (size_t)c * 36, T.Fx + (size_t)c * 36, T.Lx + (size_t)c * 6, T.L + c);
-  IL_PT(12); IL_PCNT(14);
 }
 
 // LM schedule after one rejection (solver.py:153-158)
@@ -824,12 +990,11 @@ template <bool GEN>
 __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restrict__ trees, IlqrConst C) {
   const IlqrTreeDev T = trees[blockIdx.x];
   extern __shared__ double il_dsm[];
-  // LDS carve: per-wave scratch [IL_WAVES][IL_SCR] | per-wave agent table [IL_WAVES][4*amax] | cost sums [IL_LSUM]
-  const int agw = il_ag_doubles(T.n_agents);
+  // LDS carve: per-wave scratch [IL_WAVES][IL_SCR] | cost sums [IL_LSUM] | cost-pass records [IL_WAVES][6][IL_RA] | staging [IL_DSTG] floats
   double *scr = il_dsm + (size_t)(threadIdx.x >> 6) * IL_SCR;
-  double *ag = il_dsm + (size_t)IL_WAVES * IL_SCR + (size_t)(threadIdx.x >> 6) * agw;
-  double *lsum = il_dsm + (size_t)IL_WAVES * IL_SCR + (size_t)IL_WAVES * agw;
+  double *lsum = il_dsm + (size_t)IL_WAVES * IL_SCR;
   double *recs = lsum + IL_LSUM + (size_t)(threadIdx.x >> 6) * 6 * IL_RA;   // cost pass: 6 nodes' records per wave
+  float *dstg = reinterpret_cast<float *>(lsum + IL_LSUM + (size_t)IL_WAVES * 6 * IL_RA);   // derivative pass staging
   if ((threadIdx.x & 63) < 12) {
     const int l = threadIdx.x & 63;
     scr[IL_CST + l] = l == 0 ? 1.0 : (l == 6 ? C.dt : 0.0);
@@ -847,6 +1012,12 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
   for (int q = tid; q < M * 2; q += IL_THREADS) T.k[q] = 0.0;
   for (int q = tid; q < M * 12; q += IL_THREADS) T.K[q] = 0.0;
   for (int q = tid; q < M * 6; q += IL_THREADS) T.xs[q] = 0.0;
+  // constant entries of F_x (identity, [2][4] = dt) and l_xx (zeros); the derivative pass only rewrites the rest
+  for (int q = tid; q < M * 36; q += IL_THREADS) {
+    const int e = q % 36;
+    T.Fx[q] = (e % 7 == 0) ? 1.0 : (e == 16 ? C.dt : 0.0);
+    T.Lxx[q] = 0.0;
+  }
   __threadfence_block();
   __syncthreads();
   for (int d = 0; d < T.n_slevels; ++d) {
@@ -870,7 +1041,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
       for (int q = tid; q < M * 2; q += IL_THREADS) T.us[q] = un[q];
       __threadfence_block();
       __syncthreads();
-      for (int c = wave; c < M; c += IL_WAVES) il_derivatives<GEN>(C, T, c, scr, ag IL_PROF_PASS);
+      il_deriv_pass<GEN>(C, T, lsum, dstg IL_PROF_PASS);
       __threadfence_block();
       __syncthreads();
       if (M <= IL_LSUM) {
@@ -1037,8 +1208,8 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
   }
 }
 
-static inline size_t il_lds_bytes(int amax) {
-  return ((size_t)IL_WAVES * IL_SCR + (size_t)IL_WAVES * il_ag_doubles(amax) + IL_LSUM + (size_t)IL_WAVES * 6 * IL_RA) * sizeof(double);
+static inline size_t il_lds_bytes(int /*amax*/) {
+  return ((size_t)IL_WAVES * IL_SCR + IL_LSUM + (size_t)IL_WAVES * 6 * IL_RA) * sizeof(double) + (size_t)IL_DSTG * sizeof(float);
 }
 
 // TreeCost.l / l_x / l_u / l_xx / l_uu (cost.py:341-446) at arbitrary (x, u) of given nodes: one wave per

@@ -955,11 +955,11 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
                 use_exo, tl[t].M, tl[t].nseg, tl[t].nsl, tl[t].maxls, tl[t].a, stats[t].iterations, h[4], h[5], h[6], h[7]);
 #ifdef IL_PROFILE
       if (getenv("MIND_ILQR_TRACE")) {
-        fprintf(stderr, "[k_ilqr prof] wave0: chain node (n=%.0f): stage %.0f u+dyn+store %.0f | cost chunk (n=%.0f): stage+loads %.0f field %.0f cost+store %.0f | riccati node (n=%.0f): products %.0f Qxx %.0f solve %.0f update %.0f | deriv node (n=%.0f): stage %.0f field+trig %.0f\n",
+        fprintf(stderr, "[k_ilqr prof] wave0: chain node (n=%.0f): stage %.0f u+dyn+store %.0f | cost chunk (n=%.0f): stage+loads %.0f field %.0f cost+store %.0f | riccati node (n=%.0f): products %.0f Qxx %.0f solve %.0f update %.0f | deriv block (n=%.0f): setup %.0f tasks %.0f assemble %.0f\n",
                 h[13], h[8] / fmax(h[13], 1), h[9] / fmax(h[13], 1),
                 h[23], h[10] / fmax(h[23], 1), h[11] / fmax(h[23], 1), h[12] / fmax(h[23], 1),
                 h[18], h[14] / fmax(h[18], 1), h[15] / fmax(h[18], 1), h[16] / fmax(h[18], 1), h[17] / fmax(h[18], 1),
-                h[22], h[19] / fmax(h[22], 1), h[20] / fmax(h[22], 1));
+                h[22], h[19] / fmax(h[22], 1), h[20] / fmax(h[22], 1), h[21] / fmax(h[22], 1));
       }
 #endif
     }
