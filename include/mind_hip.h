@@ -135,6 +135,31 @@ int mind_ilqr_solve_trees(mind_ctx *ctx, const mind_ilqr_cfg *cfg, const mind_co
                           double *us, mind_ilqr_stats *stats);
 
 /* ------------------------------------------------------------------------------------------------
+ * AIME glue (k7): the arithmetic of ScenarioTreeGenerator.prune_merge (planners/mind/scenario_tree.py:
+ * 281-412) that touches every (agent, mode, step) -- world-frame positions / velocities / headings,
+ * max-sigma covariances and the topology signatures -- for all scenes of one AIME round, reading the
+ * predictor outputs where they already are (device).  The pruning decisions stay on the host.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int n_scenes;
+  const int32_t *actor_off;   /* HOST [n+1]                                                        */
+  const float *reg, *vel;     /* DEVICE [A,6,60,5], [A,6,60,2]: mind_pred_out.reg / .vel            */
+  const float *actor_ctrs, *actor_vecs; /* DEVICE [A,2] agent frames (as in mind_scene_batch)      */
+  const float *rot, *orig;    /* HOST [n,2,2], [n,2]: scene frames ROT / ORIG                       */
+  const float *cov_last;      /* HOST [A] last history covariance TRAJS_COV_HIST[:, -1, 0]          */
+  const int32_t *last;        /* HOST [n] index of the last predicted step kept by seq_len (or < 0) */
+} mind_world_in;
+
+typedef struct {
+  float *world;               /* DEVICE [A,6,60,6]: x, y, vx, vy, heading, max-sigma (world frame)  */
+  float *topo;                /* DEVICE [A,6] winding of (agent - ego of its scene); ego rows = 0   */
+  float *ego_end;             /* DEVICE [n,6,3]: ego x, y, max-sigma at step `last` (if last >= 0)  */
+} mind_world_out;
+
+/* asynchronous on the context stream (read the outputs after mind_ctx_synchronize or a stream-ordered copy) */
+int mind_aime_world(mind_ctx *ctx, const mind_world_in *in, const mind_world_out *out);
+
+/* ------------------------------------------------------------------------------------------------
  * planners/ilqr call surface (iLQR.fit over a TreeCost of arbitrary PotentialField / StatePotential /
  * StateConstraint / ControlPotential objects; solver.py:80-167, cost.py:326-446, potential.py:62-264).
  * The grid is what PotentialField.__init__ receives: field_offset, resolution, xx[0,:], yy[:,0].

@@ -39,6 +39,16 @@ class FieldGrid(C.Structure):
                 ("gx", C.POINTER(C.c_double)), ("gy", C.POINTER(C.c_double))]
 
 
+class WorldIn(C.Structure):
+    _fields_ = [("n_scenes", C.c_int), ("actor_off", C.POINTER(C.c_int32)), ("reg", C.c_void_p), ("vel", C.c_void_p),
+                ("actor_ctrs", C.c_void_p), ("actor_vecs", C.c_void_p), ("rot", C.POINTER(C.c_float)),
+                ("orig", C.POINTER(C.c_float)), ("cov_last", C.POINTER(C.c_float)), ("last", C.POINTER(C.c_int32))]
+
+
+class WorldOut(C.Structure):
+    _fields_ = [("world", C.c_void_p), ("topo", C.c_void_p), ("ego_end", C.c_void_p)]
+
+
 class IlqrCfg(C.Structure):
     _fields_ = [("dt", C.c_double), ("wheelbase", C.c_double), ("w_des_state", C.c_double * 6),
                 ("w_state_con", C.c_double * 6), ("state_lower", C.c_double * 6), ("state_upper", C.c_double * 6),
@@ -54,7 +64,7 @@ class IlqrStats(C.Structure):
 
 EXPORTS = ["mind_ctx_create", "mind_ctx_destroy", "mind_last_error_string", "mind_ctx_synchronize",
            "mind_weights_load", "mind_predict_batch", "mind_last_fusion_stats", "mind_set_profiling",
-           "mind_ilqr_solve_trees", "mind_ilqr_solve_fields", "mind_cost_eval", "mind_lane_dist_field", "mind_debug_set_layers",
+           "mind_ilqr_solve_trees", "mind_ilqr_solve_fields", "mind_cost_eval", "mind_lane_dist_field", "mind_aime_world", "mind_debug_set_layers",
            "mind_debug_read"]
 
 _lib = None
@@ -90,6 +100,7 @@ def load():
                                    C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.mind_lane_dist_field.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int,
                                          C.c_double] + [C.POINTER(C.c_double)] * 4
+    lib.mind_aime_world.argtypes = [C.c_void_p, C.POINTER(WorldIn), C.POINTER(WorldOut)]
     lib.mind_debug_set_layers.argtypes = [C.c_void_p, C.c_int]
     lib.mind_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64]
     for n in EXPORTS:

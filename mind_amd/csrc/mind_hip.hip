@@ -16,6 +16,7 @@
 #include "encdec_kernels.hip"
 #include "fusion_kernels.hip"
 #include "ilqr_kernels.hip"
+#include "aime_kernels.hip"
 
 namespace {
 
@@ -56,7 +57,7 @@ struct mind_ctx {
   DevBuf edge, x, ST, QK, part, tokpos, meta, jobs, actor_feat, lane_feat, tgt_feat, cmode, tgt_emb,
       rows, rpe_ptrs;
   // ilqr workspaces
-  DevBuf ilqr_dev;
+  DevBuf ilqr_dev, aime_dev;
   // profiling
   bool profiling = false;
   int n_pair_launch = 0;
@@ -986,6 +987,42 @@ extern "C" int mind_cost_eval(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_
   if (n_query <= 0 || !node || !x || !u || !out) return fail(c, MIND_EINVAL, "mind_cost_eval: bad argument");
   IlqrEvalReq ev{n_query, node, x, u, out};
   return ilqr_impl(c, cfg, grid, tree, 1, x0, target_lane, n_lane_pts, target_vel, use_exo, nullptr, nullptr, nullptr, nullptr, &ev);
+}
+
+// -------------------------------------------------------------------------------------------------
+// AIME glue (k7): world-frame modes + topology signatures of a round's scenes
+// -------------------------------------------------------------------------------------------------
+extern "C" int mind_aime_world(mind_ctx *c, const mind_world_in *in, const mind_world_out *out) {
+  if (!c || !in || !out || in->n_scenes <= 0 || !in->actor_off || !in->reg || !in->vel || !in->actor_ctrs || !in->actor_vecs ||
+      !in->rot || !in->orig || !in->cov_last || !in->last || !out->world || !out->topo || !out->ego_end)
+    return fail(c, MIND_EINVAL, "mind_aime_world: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const int B = in->n_scenes, A = in->actor_off[B];
+  if (A <= 0) return fail(c, MIND_EINVAL, "mind_aime_world: no agents");
+  std::vector<AimeScene> hs(B);
+  std::vector<int> ascene(A);
+  for (int b = 0; b < B; ++b) {
+    AimeScene &S = hs[b];
+    S.a0 = in->actor_off[b]; S.a1 = in->actor_off[b + 1]; S.last = in->last[b]; S.pad = 0; S.pad2 = 0.f;
+    if (S.a1 <= S.a0) return fail(c, MIND_EINVAL, "mind_aime_world: scene %d has no agents", b);
+    S.r00 = in->rot[4 * b]; S.r01 = in->rot[4 * b + 1]; S.r10 = in->rot[4 * b + 2]; S.r11 = in->rot[4 * b + 3];
+    S.ox = in->orig[2 * b]; S.oy = in->orig[2 * b + 1];
+    S.theta_g = atan2f(S.r10, S.r00);
+    for (int i = S.a0; i < S.a1; ++i) ascene[i] = b;
+  }
+  const size_t bS = ((size_t)B * sizeof(AimeScene) + 15) & ~(size_t)15, bI = ((size_t)A * sizeof(int) + 15) & ~(size_t)15;
+  int rc;
+  if ((rc = ensure(c, c->aime_dev, bS + bI + (size_t)A * sizeof(float)))) return rc;
+  char *base = (char *)c->aime_dev.p;
+  HIPCHK(c, hipMemcpyAsync(base, hs.data(), (size_t)B * sizeof(AimeScene), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(base + bS, ascene.data(), (size_t)A * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(base + bS + bI, in->cov_last, (size_t)A * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipStreamSynchronize(st));     // the staging vectors go out of scope
+  hipLaunchKernelGGL(k_aime_world, dim3(A * AIME_K), dim3(64), 0, st, (const AimeScene *)base, (const int *)(base + bS), in->reg, in->vel,
+                     in->actor_ctrs, in->actor_vecs, (const float *)(base + bS + bI), out->world, out->topo, out->ego_end);
+  HIPCHK(c, hipGetLastError());
+  return MIND_OK;
 }
 
 // ---- debug taps (tests only): run only the first n fusion layers; read back internal buffers

@@ -77,7 +77,8 @@ class ScenePredNet:
             self.last_lane_feat = d["lane_feat"][:d["l_off"][1]]
         else:
             self.last_lane_feat = None
-        self.last_packed = {"n": B, "cls": o["cls"], "reg": o["reg"], "vel": o["vel"], "a_off": d["a_off"]}
+        self.last_packed = {"n": B, "cls": o["cls"], "reg": o["reg"], "vel": o["vel"], "a_off": d["a_off"],
+                            "actor_ctrs": d["actor_ctrs"], "actor_vecs": d["actor_vecs"], "rt": self.rt}
         res_cls = [o["cls"][b:b + 1] for b in range(B)]
         res_reg = [o["reg"][d["a_off"][b]:d["a_off"][b + 1]] for b in range(B)]
         res_aux = [(o["vel"][d["a_off"][b]:d["a_off"][b + 1]], None, None) for b in range(B)]

@@ -51,6 +51,7 @@ class ScenarioTreeGenerator:
         self.target_lane = None
         self.target_lane_info = None
         self.ego_idx = 0
+        self.device_glue = True     # prune_merge arithmetic on the device when the network leaves its outputs there
         self.branch_depth = 0
         self.n_expanded = 0           # scenes pushed through the predictor (metric: nodes expanded)
         self.shard = None             # mind_amd.parallel.Shard: block-distribute each round's scenes over ranks
@@ -252,9 +253,89 @@ class ScenarioTreeGenerator:
         root["END_T"] = self.pred_len
         return root
 
+    def _select_modes(self, sc, cls_row, topo_all, ego_end):
+        """Pruning decisions of one scene (scenario_tree.py:293-327, 361-395): probability floor, distance of the
+        ego end point to the target lane, greedy merge of modes with the same topology.  cls_row [K] f32,
+        topo_all [a-1,K], ego_end(k) -> (mean [2], cov [1]).  -> [(k, prob)] in visiting order."""
+        order = np.argsort(-cls_row, kind="stable")
+        cands = []
+        for k in order:
+            prob = F32(cls_row[k] * sc["SCEN_PROB"])
+            if prob < F32(0.001):
+                continue
+            if self.target_lane is not None and self.ego_idx is not None:
+                ego_mean, ego_cov = ego_end(int(k))
+                dis = U.get_distance_to_polyline(self.target_lane, ego_mean)
+                if (dis - ego_cov > self.config.tar_dist_thres).any():
+                    continue
+            cands.append((int(k), prob, topo_all[:, k] if len(topo_all) else np.zeros(0, F32)))
+        # greedy merge of modes whose signatures differ by <= pi/6 for every exo agent
+        thr = F32(np.pi / 6)
+        selected = []
+        while cands:
+            sel = cands[0]
+            selected.append(sel[:2])
+            rest = []
+            for cd in cands[1:]:
+                diff = sel[2] - cd[2]
+                diff = np.arctan2(np.sin(diff), np.cos(diff))
+                if ((np.abs(diff) - thr) > 0).sum() > 0:
+                    rest.append(cd)
+            cands = rest
+        return selected
+
+    def _prune_merge_device(self, scenes, packed, idx_offset):
+        """prune_merge with the per-(agent, mode, step) arithmetic on the MI355X (mind_aime_world): the predictor
+        outputs never leave the device; the host reads cls / topology signatures / ego end points (one small
+        copy), decides, and fetches the world-frame histories of the SURVIVING modes only (second copy)."""
+        rt, a_off = packed["rt"], packed["a_off"]
+        B, A, L = len(scenes), int(packed["a_off"][-1]), self.seq_len
+        lasts = [L - 1 - sc["TRAJS_POS_HIST"].shape[1] for sc in scenes]
+        w = rt.aime_world(packed["reg"], packed["vel"], packed["actor_ctrs"], packed["actor_vecs"], a_off,
+                          np.stack([sc["ROT"] for sc in scenes]), np.stack([sc["ORIG"] for sc in scenes]),
+                          np.concatenate([sc["TRAJS_COV_HIST"][:, -1, 0] for sc in scenes]), [max(l, -1) for l in lasts])
+        small = torch.cat([packed["cls"].reshape(-1), w["topo"].reshape(-1), w["ego_end"].reshape(-1)]).cpu().numpy()
+        cls_all = small[:B * 6].reshape(B, 6)
+        topo = small[B * 6:B * 6 + A * 6].reshape(A, 6)
+        ego_all = small[B * 6 + A * 6:].reshape(B, 6, 3)
+        picks = []
+        for lidx, sc in enumerate(scenes):
+            def ego_end(k, lidx=lidx, sc=sc):
+                if lasts[lidx] >= 0:
+                    return ego_all[lidx, k, :2], ego_all[lidx, k, 2:3]
+                return sc["TRAJS_POS_HIST"][self.ego_idx][L - 1], sc["TRAJS_COV_HIST"][self.ego_idx][L - 1]
+            for k, prob in self._select_modes(sc, cls_all[lidx], topo[a_off[lidx] + 1:a_off[lidx + 1]], ego_end):
+                picks.append((lidx, k, prob))
+        if not picks:
+            return []
+        rows = np.concatenate([np.arange(a_off[l], a_off[l + 1]) for l, _, _ in picks])
+        ks = np.concatenate([np.full(a_off[l + 1] - a_off[l], k) for l, k, _ in picks])
+        dev = w["world"].device
+        sel = w["world"][torch.from_numpy(rows).to(dev), torch.from_numpy(ks).to(dev)].cpu().numpy()   # [R,60,6]
+        kept, r0 = [], 0
+        for lidx, k, prob in picks:
+            sc = scenes[lidx]
+            a = a_off[lidx + 1] - a_off[lidx]
+            m = sel[r0:r0 + a]
+            r0 += a
+            kept.append({
+                "SCEN_PROB": prob, "CUR_T": sc["CUR_T"], "END_T": sc["END_T"],
+                "PARENT_ID": sc["SCEN_ID"], "SCEN_ID": "{}_{}_{}".format(self.branch_depth, lidx + idx_offset, k),
+                "TRAJS_TYPE": sc["TRAJS_TYPE"], "TRAJS_TID": sc["TRAJS_TID"], "TRAJS_CAT": sc["TRAJS_CAT"],
+                "TRAJS_POS_HIST": np.concatenate([sc["TRAJS_POS_HIST"], m[:, :, 0:2]], axis=1)[:, :L],
+                "TRAJS_COV_HIST": np.concatenate([sc["TRAJS_COV_HIST"], m[:, :, 5:6]], axis=1)[:, :L],
+                "TRAJS_ANG_HIST": np.concatenate([sc["TRAJS_ANG_HIST"], m[:, :, 4]], axis=1)[:, :L],
+                "TRAJS_VEL_HIST": np.concatenate([sc["TRAJS_VEL_HIST"], m[:, :, 2:4]], axis=1)[:, :L],
+                "TGT_PTS": sc["TGT_PTS"],
+            })
+        return kept
+
     def prune_merge(self, scenes, out, idx_offset=0):
         res_cls_b, res_reg_b, res_aux_b = out
         packed = getattr(self.network, "last_packed", None)
+        if (self.device_glue and packed is not None and packed["n"] == len(scenes) and packed.get("rt") is not None
+                and packed.get("actor_ctrs") is not None and self.ego_idx == 0):
+            return self._prune_merge_device(scenes, packed, idx_offset)
         if packed is not None and packed["n"] == len(scenes):
             # one device->host copy per tensor for the whole round instead of three per scene
             cls_all, reg_all, vel_all = (_np(packed[k]) for k in ("cls", "reg", "vel"))
@@ -272,7 +353,6 @@ class ScenarioTreeGenerator:
             cls = _np(res_cls_b[lidx]).astype(F32, copy=False)      # [1,6]
             vel = _np(res_aux_b[lidx][0]).astype(F32, copy=False)   # [a,6,60,2]
             ang_loc = U.get_angle(vel)                               # from the un-rotated velocity
-            order = np.argsort(-cls[0], kind="stable")
             a_, K_, T_ = reg.shape[:3]
             # all K modes at once: [a, K*T, 2] through the same per-agent / global rotations
             pos_all, th = self._to_world(reg[..., :2].reshape(a_, K_ * T_, 2), ctrs, vecs, rot, orig)
@@ -290,35 +370,13 @@ class ScenarioTreeGenerator:
             L = self.seq_len
             n_hist = sc["TRAJS_POS_HIST"].shape[1]
             last = L - 1 - n_hist                                            # index of the last kept predicted step
-            cands = []
-            for k in order:
-                prob = F32(cls[0, k] * sc["SCEN_PROB"])
-                if prob < F32(0.001):
-                    continue
-                if self.target_lane is not None and self.ego_idx is not None:
-                    if last >= 0:
-                        ego_mean, ego_cov = pos_all[self.ego_idx, k, last], cov_all[self.ego_idx, k, last]
-                    else:
-                        ego_mean, ego_cov = sc["TRAJS_POS_HIST"][self.ego_idx][L - 1], sc["TRAJS_COV_HIST"][self.ego_idx][L - 1]
-                    dis = U.get_distance_to_polyline(self.target_lane, ego_mean)
-                    if (dis - ego_cov > self.config.tar_dist_thres).any():
-                        continue
-                cands.append((int(k), prob, topo_all[:, k] if len(topo_all) else np.zeros(0, F32)))
-            # greedy merge of modes whose signatures differ by <= pi/6 for every exo agent
-            thr = F32(np.pi / 6)
-            selected = []
-            while cands:
-                sel = cands[0]
-                selected.append(sel)
-                rest = []
-                for cd in cands[1:]:
-                    diff = sel[2] - cd[2]
-                    diff = np.arctan2(np.sin(diff), np.cos(diff))
-                    if ((np.abs(diff) - thr) > 0).sum() > 0:
-                        rest.append(cd)
-                cands = rest
+            def ego_end(k):
+                if last >= 0:
+                    return pos_all[self.ego_idx, k, last], cov_all[self.ego_idx, k, last]
+                return sc["TRAJS_POS_HIST"][self.ego_idx][L - 1], sc["TRAJS_COV_HIST"][self.ego_idx][L - 1]
+            selected = self._select_modes(sc, cls[0], topo_all, ego_end)
             # only the surviving modes get their histories extended (world frame, truncated to seq_len, Q8)
-            for k, prob, _ in selected:
+            for k, prob in selected:
                 kept.append({
                     "SCEN_PROB": prob, "CUR_T": sc["CUR_T"], "END_T": sc["END_T"],
                     "PARENT_ID": sc["SCEN_ID"], "SCEN_ID": "{}_{}_{}".format(self.branch_depth, idx, k),

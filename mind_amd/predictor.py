@@ -243,6 +243,34 @@ class HipPredictor:
         luu[:, 0, 0], luu[:, 1, 1] = out[:, 45], out[:, 46]
         return dict(l=out[:, 0].copy(), l_x=out[:, 1:7].copy(), l_u=out[:, 7:9].copy(), l_xx=out[:, 9:45].reshape(-1, 6, 6).copy(), l_uu=luu)
 
+    def aime_world(self, reg, vel, actor_ctrs, actor_vecs, a_off, rots, origs, cov_last, last):
+        """k7 on the device (mind_aime_world): reg [A,6,60,5] / vel [A,6,60,2] / actor_ctrs, actor_vecs [A,2] device
+        tensors; a_off [B+1]; rots [B,2,2], origs [B,2], cov_last [A] host float32; last [B] int.
+        Returns device tensors world [A,6,60,6] (x,y,vx,vy,heading,max-sigma), topo [A,6], ego_end [B,6,3]."""
+        dev = self.device
+        B, A = len(a_off) - 1, int(a_off[-1])
+        for t_ in (reg, vel, actor_ctrs, actor_vecs):
+            assert t_.device == dev and t_.dtype == torch.float32 and t_.is_contiguous()
+        assert reg.shape == (A, 6, 60, 5) and vel.shape == (A, 6, 60, 2) and actor_ctrs.shape == (A, 2)
+        wi, wo = _lib.WorldIn(), _lib.WorldOut()
+        ao = (C.c_int32 * (B + 1))(*[int(v) for v in a_off])
+        rot = np.ascontiguousarray(rots, np.float32).reshape(B, 4)
+        org = np.ascontiguousarray(origs, np.float32).reshape(B, 2)
+        cvl = np.ascontiguousarray(cov_last, np.float32).reshape(A)
+        lst = np.ascontiguousarray(last, np.int32).reshape(B)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        wi.n_scenes, wi.actor_off = B, ao
+        wi.reg, wi.vel = C.c_void_p(reg.data_ptr()), C.c_void_p(vel.data_ptr())
+        wi.actor_ctrs, wi.actor_vecs = C.c_void_p(actor_ctrs.data_ptr()), C.c_void_p(actor_vecs.data_ptr())
+        wi.rot, wi.orig, wi.cov_last = fp(rot), fp(org), fp(cvl)
+        wi.last = lst.ctypes.data_as(C.POINTER(C.c_int32))
+        out = dict(world=torch.empty(A, 6, 60, 6, device=dev), topo=torch.empty(A, 6, device=dev),
+                   ego_end=torch.zeros(B, 6, 3, device=dev))
+        wo.world, wo.topo, wo.ego_end = (C.c_void_p(out[k].data_ptr()) for k in ("world", "topo", "ego_end"))
+        rc = self.lib.mind_aime_world(self.ctx, C.byref(wi), C.byref(wo))
+        _lib.check(self.lib, self.ctx, rc, "mind_aime_world")
+        return out
+
     def lane_dist_field(self, ego_xy, lane, W, H, res):
         """gen_dist_field (ilqr/utils.py:5-22) -> (offset [2], gx [W], gy [H], dist [H,W])."""
         ego = np.ascontiguousarray(np.asarray(ego_xy, np.float64)[:2])

@@ -1,0 +1,96 @@
+"""GPU parity of the AIME glue kernel (mind_aime_world, k7) against the host restatement of prune_merge's
+arithmetic (scenario_tree.py:281-412), and of the device prune_merge path against the host path end to end."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from mind_amd.planners.mind import utils as U
+from mind_amd.planners.mind.scenario_tree import ScenarioTreeGenerator as STG
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F32 = np.float32
+
+
+def _host_world(reg, vel, ctrs, vecs, rot, orig, cov_last):
+    a, K, T = reg.shape[:3]
+    theta_g = np.arctan2(rot[1, 0], rot[0, 0])
+    pos, th = STG._to_world(reg[..., :2].reshape(a, K * T, 2), ctrs, vecs, rot, orig)
+    v, _ = STG._to_world(vel.reshape(a, K * T, 2), ctrs, vecs, rot, orig, False)
+    pos, v = pos.reshape(a, K, T, 2), v.reshape(a, K, T, 2)
+    ang = (U.get_angle(vel) + th[:, None, None] + theta_g).astype(F32)
+    cov = U.get_max_covariance(reg[..., 2:])[..., 0] + cov_last[:, None, None]
+    rel = pos[1:] - pos[0:1]
+    rel = rel / np.sqrt((rel * rel).sum(-1, keepdims=True))
+    phi = np.arctan2(rel[..., 1], rel[..., 0])
+    dphi = phi[..., 1:] - phi[..., :-1]
+    dphi = np.arctan2(np.sin(dphi), np.cos(dphi))
+    return pos, v, ang, cov, dphi.sum(axis=-1, dtype=F32)
+
+
+def test_world_kernel_matches_host_arithmetic(hip_predictor):
+    rng = np.random.default_rng(3)
+    counts = [7, 1, 12]                       # ragged scenes incl. an ego-only one
+    a_off = np.concatenate([[0], np.cumsum(counts)])
+    A = int(a_off[-1])
+    t = np.arange(1, 61, dtype=F32) * F32(0.1)
+    reg = np.zeros((A, 6, 60, 5), F32)
+    reg[..., 0] = rng.uniform(2, 9, (A, 6, 1)).astype(F32) * t
+    reg[..., 1] = rng.normal(0, 2.0, (A, 6, 1)).astype(F32) * (t / 6) ** 2
+    reg[..., 2:4] = rng.uniform(0.1, 3.0, (A, 6, 60, 2))
+    vel = rng.normal(0, 3.0, (A, 6, 60, 2)).astype(F32)
+    ctrs = rng.uniform(-40, 40, (A, 2)).astype(F32)
+    th = rng.uniform(-np.pi, np.pi, A)
+    vecs = np.stack([np.cos(th), np.sin(th)], -1).astype(F32)
+    rots = np.stack([U.rot2(F32(x)) for x in (0.3, -2.0, 1.1)])
+    origs = rng.uniform(-500, 500, (3, 2)).astype(F32)
+    cov_last = rng.uniform(1e-5, 0.5, A).astype(F32)
+    last = [59, 12, -1]
+    dev = hip_predictor.device
+    g = lambda x: torch.from_numpy(x).to(dev)
+    w = hip_predictor.aime_world(g(reg), g(vel), g(ctrs), g(vecs), a_off, rots, origs, cov_last, last)
+    world, topo, ego_end = (w[k].cpu().numpy() for k in ("world", "topo", "ego_end"))
+    for b in range(3):
+        sl = slice(a_off[b], a_off[b + 1])
+        pos, v, ang, cov, tp = _host_world(reg[sl], vel[sl], ctrs[sl], vecs[sl], rots[b], origs[b], cov_last[sl])
+        # float32 arithmetic at coordinates of a few hundred metres: a handful of ulps (3e-5 m each)
+        assert np.abs(world[sl, ..., 0:2] - pos).max() < 3e-4
+        assert np.abs(world[sl, ..., 2:4] - v).max() < 2e-5
+        dang = world[sl, ..., 4] - ang
+        assert np.abs(dang).max() < 5e-6
+        assert np.array_equal(world[sl, ..., 5], cov)
+        assert not topo[a_off[b]].any()
+        if counts[b] > 1:
+            assert np.abs(topo[a_off[b] + 1:a_off[b + 1]] - tp).max() < 2e-4
+        if last[b] >= 0:
+            assert np.abs(ego_end[b, :, :2] - pos[0, :, last[b]]).max() < 3e-4
+            assert np.array_equal(ego_end[b, :, 2], cov[0, :, last[b]])
+
+
+def test_device_prune_merge_equals_host_path_in_closed_loop():
+    """Scripted-branching closed loop, same planner state: the scenario trees handed to the contingency planner
+    (node ids, probabilities, world-frame trajectories, covariances) are the same whether prune_merge runs its
+    arithmetic on the device or on the host -- float32 rounding apart (coordinates of ~100 m: 1e-4 m)."""
+    sys.path.insert(0, ROOT)
+    from bench import WORKLOADS, make_closed_loop
+    runs = {}
+    for glue in (True, False):
+        pl, sim, w = make_closed_loop(dict(WORKLOADS["demo1"]))
+        pl.scen_tree_gen.device_glue = glue
+        sim.run_plans(1)
+        runs[glue] = (pl.scen_tree_gen.get_scenario_tree(), np.array(pl.ctrl, dtype=np.float64), pl.timing["best_traj_idx"])
+    (td, ctrl_d, best_d), (th_, ctrl_h, best_h) = runs[True], runs[False]
+    assert len(td) == len(th_) and len(td) >= 2
+    for a, b in zip(td, th_):
+        assert list(a.nodes.keys()) == list(b.nodes.keys())
+        for k in a.nodes:
+            da, db = a.nodes[k].data, b.nodes[k].data
+            assert np.allclose(da[0], db[0], rtol=1e-6)
+            assert da[1].shape == db[1].shape and np.abs(da[1] - db[1]).max() < 2e-4       # trajectories [a,dur,2]
+            assert np.abs(da[2] - db[2]).max() < 1e-6                                      # max-sigma
+    # the tree-iLQR runs tens of Levenberg-Marquardt iterations on these trees and amplifies input rounding;
+    # the selected branch is the same and the control agrees to ~1e-2
+    assert best_d == best_h and np.abs(ctrl_d - ctrl_h).max() < 5e-2
