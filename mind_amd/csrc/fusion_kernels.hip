@@ -481,7 +481,7 @@ extern "C" size_t mind_pair_lds_bytes() { return (size_t)LDS_TOTAL * sizeof(floa
 // =================================================================================================
 // k_token: per-token epilogue of layer L (combine column partials, V/out projections, LN, FFN, LN;
 // network.py:177-179,222-232) and prologue of layer L+1 (S, T, q, qk).  TPW tokens per workgroup,
-// 128 threads, thread t owns output feature t; weights are stored transposed [in][out] so that a
+// 512 threads = 4 k-groups x 128 output features; weights are stored transposed [in][out] so that a
 // wave reads 64 consecutive floats per k.
 // =================================================================================================
 #define TPW 8
@@ -504,85 +504,143 @@ struct TokWeights {
   const float *WpaT, *bpa, *gpa, *bepa, *WplT, *bpl, *gpl, *bepl;
 };
 
-__device__ __forceinline__ float block_sum128(float v, float *red, int tid) {
-  // 128 threads = 2 waves
-  v += __shfl_xor(v, 32, 64);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 8, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 1, 64);
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  return red[0] + red[1];
+// ---- k_token building blocks.  512 threads = 4 k-groups x 128 output features: a projection's reduction
+// dimension is split four ways so that all of its weight loads are in flight at once (the kernel runs a few
+// dozen workgroups whose weights arrive cold from the Infinity Cache: it is bound by those round trips, not
+// by FLOPs); the partial sums meet in LDS, after which thread (kg, col) owns tokens 2kg, 2kg+1 of feature col.
+#define TKG 4
+#define TT_THREADS (TKG * 128)
+
+// partial y[t] = sum_{k in this group's quarter} WT[k*ldo + col] * xin[t][k]   (K/4 <= 64 weights in registers)
+template <int K>
+__device__ __forceinline__ void matvec_part(float (&acc)[TPW], const float *__restrict__ WT, int ldo, int col,
+                                            const float *xin, int ldx, int kg) {
+  constexpr int KQ = K / TKG;
+  const int k0 = kg * KQ;
+  float w[KQ];
+#pragma unroll
+  for (int k = 0; k < KQ; ++k) w[k] = WT[(size_t)(k0 + k) * ldo + col];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) acc[t] = 0.f;
+#pragma unroll
+  for (int k = 0; k < KQ; k += 4)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const float4 xv = *reinterpret_cast<const float4 *>(xin + t * ldx + k0 + k);
+      acc[t] = fmaf(w[k], xv.x, acc[t]);
+      acc[t] = fmaf(w[k + 1], xv.y, acc[t]);
+      acc[t] = fmaf(w[k + 2], xv.z, acc[t]);
+      acc[t] = fmaf(w[k + 3], xv.w, acc[t]);
+    }
 }
 
-// y[t][tid] = sum_k WT[k*ldo + tid] * xin[t][k]  for t < TPW   (xin in LDS, row stride ldx)
-template <int K>
-__device__ __forceinline__ void matvec(float (&acc)[TPW], const float *__restrict__ WT, int ldo, int col,
-                                       const float *xin, int ldx) {
-#pragma unroll 16
-  for (int k = 0; k < K; ++k) {
-    const float w = WT[(size_t)k * ldo + col];
+// meet the four partials: on return r0/r1 = bias + full sums for this thread's tokens 2kg, 2kg+1 (fixed order).
+// Contains two barriers; rk is [TKG][TPW][128].
+__device__ __forceinline__ void ksum(const float (&acc)[TPW], float bias, float *rk, int kg, int col, float &r0, float &r1) {
+  __syncthreads();                      // previous users of rk are done
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = fmaf(w, xin[t * ldx + k], acc[t]);
-  }
+  for (int t = 0; t < TPW; ++t) rk[(kg * TPW + t) * 128 + col] = acc[t];
+  __syncthreads();
+  const int t0 = 2 * kg;
+  r0 = ((rk[(0 * TPW + t0) * 128 + col] + rk[(1 * TPW + t0) * 128 + col]) +
+        (rk[(2 * TPW + t0) * 128 + col] + rk[(3 * TPW + t0) * 128 + col])) + bias;
+  r1 = ((rk[(0 * TPW + t0 + 1) * 128 + col] + rk[(1 * TPW + t0 + 1) * 128 + col]) +
+        (rk[(2 * TPW + t0 + 1) * 128 + col] + rk[(3 * TPW + t0 + 1) * 128 + col])) + bias;
+}
+
+// sum over the 128 features of this k-group's two tokens (two waves per group); rd is [TKG][2][2]
+__device__ __forceinline__ void gsum2(float &a, float &b, float *rd, int kg, int tid) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+  const int wv = (tid >> 6) & 1;
+  __syncthreads();
+  if ((tid & 63) == 0) { rd[(kg * 2 + wv) * 2] = a; rd[(kg * 2 + wv) * 2 + 1] = b; }
+  __syncthreads();
+  a = rd[(kg * 2) * 2] + rd[(kg * 2 + 1) * 2];
+  b = rd[(kg * 2) * 2 + 1] + rd[(kg * 2 + 1) * 2 + 1];
+}
+
+// LayerNorm over the 128 features of the group's two tokens (eps 1e-5), in place
+__device__ __forceinline__ void ln2tok(float &p0, float &p1, float g, float be, float *rd, int kg, int tid) {
+  float s0 = p0, s1 = p1;
+  gsum2(s0, s1, rd, kg, tid);
+  const float d0 = p0 - s0 * (1.0f / 128.0f), d1 = p1 - s1 * (1.0f / 128.0f);
+  s0 = d0 * d0; s1 = d1 * d1;
+  gsum2(s0, s1, rd, kg, tid);
+  p0 = d0 * (1.0f / sqrtf(s0 * (1.0f / 128.0f) + 1e-5f)) * g + be;
+  p1 = d1 * (1.0f / sqrtf(s1 * (1.0f / 128.0f) + 1e-5f)) * g + be;
 }
 
 // mode bits: 1 = init (x0 from actor/lane features), 2 = has epilogue, 4 = has prologue, 8 = only flagged
-__global__ __launch_bounds__(128) void k_token(const TokMeta *__restrict__ meta, int n_tok, int mode,
-                                               const float *__restrict__ actor_feat,
-                                               const float *__restrict__ lane_feat, float *__restrict__ x,
-                                               const float *__restrict__ part, float *__restrict__ ST,
-                                               float *__restrict__ QK, TokWeights W) {
-  __shared__ float xs[TPW][132];        // current token vectors
-  __shared__ float tmp[TPW][260];       // scratch (o / h1 up to 256 wide)
-  __shared__ float mb[TPW][8][132];     // normalised sum p*mem per head
-  __shared__ float red[2];
+__global__ __launch_bounds__(TT_THREADS) void k_token(const TokMeta *__restrict__ meta, int n_tok, int mode,
+                                                      const float *__restrict__ actor_feat,
+                                                      const float *__restrict__ lane_feat, float *__restrict__ x,
+                                                      const float *__restrict__ part, float *__restrict__ ST,
+                                                      float *__restrict__ QK, TokWeights W) {
+  __shared__ __attribute__((aligned(16))) float xs[TPW][132];        // current token vectors
+  __shared__ __attribute__((aligned(16))) float tmp[TPW][260];       // scratch (o / h1 up to 256 wide)
+  __shared__ __attribute__((aligned(16))) float mb[TPW][8][132];     // normalised sum p*mem per head
+  __shared__ float rk[TKG * TPW * 128];                              // k-group partial sums
+  __shared__ float rd[TKG * 2 * 2];
   __shared__ float cw[TPW][8][8];       // combine weights per (token, head, split<=8)
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, kg = tid >> 7, col = tid & 127;
   const int tok0 = blockIdx.x * TPW;
   const int nt = min(TPW, n_tok - tok0);
+  const int ta = 2 * kg, tb = 2 * kg + 1;          // the two tokens this thread owns after a ksum
+  const bool va = ta < nt, vb = tb < nt;
+#ifdef MIND_TOKEN_TRACE
+  long long tt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq_ = clock64();
+#define TT(i) do { const long long n_ = clock64(); tt_[i] += n_ - tq_; tq_ = n_; } while (0)
+#else
+#define TT(i) do {} while (0)
+#endif
 
   // ---- load x (or build x0)
   if (mode & 1) {
     // FusionNet projections (network.py:313-314, 323-324): Linear + LN + ReLU, cls token = zeros
-    for (int t = 0; t < TPW; ++t) {
-      float v = 0.f;
-      if (t < nt) {
-        const TokMeta m = meta[tok0 + t];
-        if (m.type == 0) v = actor_feat[(size_t)m.src * 128 + tid];
-        else if (m.type == 1) v = lane_feat[(size_t)m.src * 128 + tid];
-      }
-      tmp[t][tid] = v;
+    int tya = 2, tyb = 2;
+    float fa = 0.f, fb = 0.f;
+    if (va) {
+      const TokMeta m = meta[tok0 + ta];
+      tya = m.type;
+      if (m.type == 0) fa = actor_feat[(size_t)m.src * 128 + col];
+      else if (m.type == 1) fa = lane_feat[(size_t)m.src * 128 + col];
     }
+    if (vb) {
+      const TokMeta m = meta[tok0 + tb];
+      tyb = m.type;
+      if (m.type == 0) fb = actor_feat[(size_t)m.src * 128 + col];
+      else if (m.type == 1) fb = lane_feat[(size_t)m.src * 128 + col];
+    }
+    tmp[ta][col] = fa; tmp[tb][col] = fb;
     __syncthreads();
-    float aa[TPW], al[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) { aa[t] = W.bpa[tid]; al[t] = W.bpl[tid]; }
-    matvec<128>(aa, W.WpaT, 128, tid, &tmp[0][0], 260);
-    matvec<128>(al, W.WplT, 128, tid, &tmp[0][0], 260);
-    for (int t = 0; t < TPW; ++t) {
-      int type = 2;
-      if (t < nt) type = meta[tok0 + t].type;
-      const float pre = type == 0 ? aa[t] : al[t];
-      const float mean = block_sum128(pre, red, tid) * (1.0f / 128.0f);
-      const float d = pre - mean;
-      const float var = block_sum128(d * d, red, tid) * (1.0f / 128.0f);
-      const float rstd = 1.0f / sqrtf(var + 1e-5f);
-      const float g = type == 0 ? W.gpa[tid] : W.gpl[tid];
-      const float b = type == 0 ? W.bepa[tid] : W.bepl[tid];
-      float y = fmaxf(d * rstd * g + b, 0.f);
-      if (type == 2) y = 0.f;
-      xs[t][tid] = y;
+    float acc[TPW], a0, a1, l0, l1;
+    matvec_part<128>(acc, W.WpaT, 128, col, &tmp[0][0], 260, kg);
+    ksum(acc, W.bpa[col], rk, kg, col, a0, a1);
+    matvec_part<128>(acc, W.WplT, 128, col, &tmp[0][0], 260, kg);
+    ksum(acc, W.bpl[col], rk, kg, col, l0, l1);
+    float p0 = tya == 0 ? a0 : l0, p1 = tyb == 0 ? a1 : l1;
+    {
+      // LN with per-token (type-dependent) affine: normalise first, then scale
+      float s0 = p0, s1 = p1;
+      gsum2(s0, s1, rd, kg, tid);
+      const float d0 = p0 - s0 * (1.0f / 128.0f), d1 = p1 - s1 * (1.0f / 128.0f);
+      s0 = d0 * d0; s1 = d1 * d1;
+      gsum2(s0, s1, rd, kg, tid);
+      const float ga = W.gpa[col], gl = W.gpl[col], ba = W.bepa[col], bl = W.bepl[col];
+      p0 = fmaxf(d0 * (1.0f / sqrtf(s0 * (1.0f / 128.0f) + 1e-5f)) * (tya == 0 ? ga : gl) + (tya == 0 ? ba : bl), 0.f);
+      p1 = fmaxf(d1 * (1.0f / sqrtf(s1 * (1.0f / 128.0f) + 1e-5f)) * (tyb == 0 ? ga : gl) + (tyb == 0 ? ba : bl), 0.f);
+      if (tya == 2) p0 = 0.f;
+      if (tyb == 2) p1 = 0.f;
     }
+    xs[ta][col] = p0; xs[tb][col] = p1;
     __syncthreads();
   } else {
-    for (int t = 0; t < TPW; ++t) xs[t][tid] = (t < nt) ? x[(size_t)(tok0 + t) * 128 + tid] : 0.f;
+    xs[ta][col] = va ? x[(size_t)(tok0 + ta) * 128 + col] : 0.f;
+    xs[tb][col] = vb ? x[(size_t)(tok0 + tb) * 128 + col] : 0.f;
     __syncthreads();
   }
-
+  TT(0);
   if (mode & 2) {
     // ---- combine split partials: weights exp(m_s - M) / L  (softmax over i finished here)
     if (tid < TPW * 8) {
@@ -610,114 +668,122 @@ __global__ __launch_bounds__(128) void k_token(const TokMeta *__restrict__ meta,
       for (int s = 0; s < 8; ++s) cw[t][hd][s] = wgt[s];
     }
     __syncthreads();
-    for (int t = 0; t < TPW; ++t) {
+    TT(1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int t = ta + q;
       int ns = 0, slot0 = 0;
       if (t < nt) {
         const TokMeta m = meta[tok0 + t];
         ns = ((mode & 8) && !(m.flags & 1)) ? 0 : m.nsplit;
         slot0 = m.slot0;
       }
-      for (int hd = 0; hd < 8; ++hd) {
-        float v = 0.f;
-        for (int s = 0; s < ns; ++s)
-          v = fmaf(cw[t][hd][s], part[(size_t)(slot0 + s) * PART_STRIDE + 16 + hd * 128 + tid], v);
-        mb[t][hd][tid] = v;
+      // all 8 heads' loads of a split are issued together (the split loop has a run-time trip count)
+      float v[8];
+#pragma unroll
+      for (int hd = 0; hd < 8; ++hd) v[hd] = 0.f;
+      for (int s = 0; s < ns; ++s) {
+        const float *ps = part + (size_t)(slot0 + s) * PART_STRIDE + 16 + col;
+        float pv[8];
+#pragma unroll
+        for (int hd = 0; hd < 8; ++hd) pv[hd] = ps[hd * 128];
+#pragma unroll
+        for (int hd = 0; hd < 8; ++hd) v[hd] = fmaf(cw[t][hd][s], pv[hd], v[hd]);
       }
+#pragma unroll
+      for (int hd = 0; hd < 8; ++hd) mb[t][hd][col] = v[hd];
     }
     __syncthreads();
-    // ---- o = W_v,h mbar_h + b_v  (thread f = hd*16+d uses head hd = f>>4)
+    TT(2);
+    // ---- o = W_v,h mbar_h + b_v  (output feature f = hd*16+d uses head hd = f>>4)
     {
-      float acc[TPW];
-      const float bvv = W.bv[tid];
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) acc[t] = bvv;
-      const int hd = tid >> 4;
-#pragma unroll 16
-      for (int k = 0; k < 128; ++k) {
-        const float w = W.WvT[k * 128 + tid];
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = fmaf(w, mb[t][hd][k], acc[t]);
-      }
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) tmp[t][tid] = acc[t];
+      float acc[TPW], o0, o1;
+      matvec_part<128>(acc, W.WvT, 128, col, &mb[0][col >> 4][0], 8 * 132, kg);
+      ksum(acc, W.bv[col], rk, kg, col, o0, o1);
+      tmp[ta][col] = o0; tmp[tb][col] = o1;
+      __syncthreads();
     }
-    __syncthreads();
+    TT(3);
     // ---- att = W_o o + b_o ; x1 = LN2(x + att)
     {
-      float acc[TPW];
-      const float b = W.bo[tid];
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) acc[t] = b;
-      matvec<128>(acc, W.WoT, 128, tid, &tmp[0][0], 260);
-      const float g = W.g2[tid], be = W.b2[tid];
-      for (int t = 0; t < TPW; ++t) {
-        const float pre = xs[t][tid] + acc[t];
-        const float mean = block_sum128(pre, red, tid) * (1.0f / 128.0f);
-        const float d = pre - mean;
-        const float var = block_sum128(d * d, red, tid) * (1.0f / 128.0f);
-        xs[t][tid] = d * (1.0f / sqrtf(var + 1e-5f)) * g + be;
-      }
+      float acc[TPW], p0, p1;
+      matvec_part<128>(acc, W.WoT, 128, col, &tmp[0][0], 260, kg);
+      ksum(acc, W.bo[col], rk, kg, col, p0, p1);
+      p0 += xs[ta][col]; p1 += xs[tb][col];
+      ln2tok(p0, p1, W.g2[col], W.b2[col], rd, kg, tid);
+      __syncthreads();                  // every k-group has finished reading xs
+      xs[ta][col] = p0; xs[tb][col] = p1;
       __syncthreads();
     }
+    TT(4);
     // ---- FFN 128 -> 256 -> 128, x2 = LN3(x1 + ff)
     {
-      float a0[TPW], a1[TPW];
-      const float b0 = W.b1[tid], b1v = W.b1[128 + tid];
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) { a0[t] = b0; a1[t] = b1v; }
-      matvec<128>(a0, W.W1T, 256, tid, &xs[0][0], 132);
-      matvec<128>(a1, W.W1T, 256, 128 + tid, &xs[0][0], 132);
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) { tmp[t][tid] = fmaxf(a0[t], 0.f); tmp[t][128 + tid] = fmaxf(a1[t], 0.f); }
+      float acc[TPW], h0, h1;
+      matvec_part<128>(acc, W.W1T, 256, col, &xs[0][0], 132, kg);
+      ksum(acc, W.b1[col], rk, kg, col, h0, h1);
+      tmp[ta][col] = fmaxf(h0, 0.f); tmp[tb][col] = fmaxf(h1, 0.f);
+      matvec_part<128>(acc, W.W1T, 256, 128 + col, &xs[0][0], 132, kg);
+      ksum(acc, W.b1[128 + col], rk, kg, col, h0, h1);
+      tmp[ta][128 + col] = fmaxf(h0, 0.f); tmp[tb][128 + col] = fmaxf(h1, 0.f);
       __syncthreads();
-      float acc[TPW];
-      const float b = W.bb2[tid];
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) acc[t] = b;
-      matvec<256>(acc, W.W2T, 128, tid, &tmp[0][0], 260);
-      const float g = W.g3[tid], be = W.b3[tid];
-      for (int t = 0; t < TPW; ++t) {
-        const float pre = xs[t][tid] + acc[t];
-        const float mean = block_sum128(pre, red, tid) * (1.0f / 128.0f);
-        const float d = pre - mean;
-        const float var = block_sum128(d * d, red, tid) * (1.0f / 128.0f);
-        xs[t][tid] = d * (1.0f / sqrtf(var + 1e-5f)) * g + be;
-      }
+      float p0, p1;
+      matvec_part<256>(acc, W.W2T, 128, col, &tmp[0][0], 260, kg);
+      ksum(acc, W.bb2[col], rk, kg, col, p0, p1);
+      p0 += xs[ta][col]; p1 += xs[tb][col];
+      ln2tok(p0, p1, W.g3[col], W.b3[col], rd, kg, tid);
+      __syncthreads();
+      xs[ta][col] = p0; xs[tb][col] = p1;
       __syncthreads();
     }
   }
+  TT(5);
   // ---- write x
-  for (int t = 0; t < nt; ++t) x[(size_t)(tok0 + t) * 128 + tid] = xs[t][tid];
+  if (va) x[(size_t)(tok0 + ta) * 128 + col] = xs[ta][col];
+  if (vb) x[(size_t)(tok0 + tb) * 128 + col] = xs[tb][col];
 
   if (mode & 4) {
     // ---- prologue of the next layer: S = W_s x, T = W_t x + b_m, q = W_q x + b_q,
     //      qk[hd][f] = sum_d q[hd*16+d] W_k[hd*16+d][f] / 4      (scale 1/sqrt(16))
-    float as[TPW], at[TPW], aq[TPW];
-    const float bmv = W.bm[tid], bqv = W.bq[tid];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) { as[t] = 0.f; at[t] = bmv; aq[t] = bqv; }
-    matvec<128>(as, W.WsT, 128, tid, &xs[0][0], 132);
-    matvec<128>(at, W.WtT, 128, tid, &xs[0][0], 132);
-    matvec<128>(aq, W.WqT, 128, tid, &xs[0][0], 132);
-    for (int t = 0; t < nt; ++t) {
-      ST[(size_t)(tok0 + t) * 256 + tid] = as[t];
-      ST[(size_t)(tok0 + t) * 256 + 128 + tid] = at[t];
-    }
+    float acc[TPW], r0, r1;
+    matvec_part<128>(acc, W.WsT, 128, col, &xs[0][0], 132, kg);
+    ksum(acc, 0.f, rk, kg, col, r0, r1);
+    if (va) ST[(size_t)(tok0 + ta) * 256 + col] = r0;
+    if (vb) ST[(size_t)(tok0 + tb) * 256 + col] = r1;
+    matvec_part<128>(acc, W.WtT, 128, col, &xs[0][0], 132, kg);
+    ksum(acc, W.bm[col], rk, kg, col, r0, r1);
+    if (va) ST[(size_t)(tok0 + ta) * 256 + 128 + col] = r0;
+    if (vb) ST[(size_t)(tok0 + tb) * 256 + 128 + col] = r1;
+    matvec_part<128>(acc, W.WqT, 128, col, &xs[0][0], 132, kg);
+    ksum(acc, W.bq[col], rk, kg, col, r0, r1);
+    tmp[ta][col] = r0; tmp[tb][col] = r1;
     __syncthreads();
+    TT(6);
+    // each k-group takes two of the eight heads, all tokens
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) tmp[t][tid] = aq[t];
-    __syncthreads();
-    for (int hd = 0; hd < 8; ++hd) {
-      float acc[TPW];
+    for (int hh = 0; hh < 2; ++hh) {
+      const int hd = 2 * kg + hh;
+      float w[16];
+#pragma unroll
+      for (int d = 0; d < 16; ++d) w[d] = W.Wk[(size_t)(hd * 16 + d) * 128 + col];
 #pragma unroll
       for (int t = 0; t < TPW; ++t) acc[t] = 0.f;
 #pragma unroll
-      for (int d = 0; d < 16; ++d) {
-        const float w = W.Wk[(size_t)(hd * 16 + d) * 128 + tid];
+      for (int d = 0; d < 16; d += 4)
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = fmaf(w, tmp[t][hd * 16 + d], acc[t]);
-      }
-      for (int t = 0; t < nt; ++t) QK[(size_t)(tok0 + t) * 1024 + hd * 128 + tid] = acc[t] * 0.25f;
+        for (int t = 0; t < TPW; ++t) {
+          const float4 xv = *reinterpret_cast<const float4 *>(&tmp[t][hd * 16 + d]);
+          acc[t] = fmaf(w[d], xv.x, acc[t]);
+          acc[t] = fmaf(w[d + 1], xv.y, acc[t]);
+          acc[t] = fmaf(w[d + 2], xv.z, acc[t]);
+          acc[t] = fmaf(w[d + 3], xv.w, acc[t]);
+        }
+      for (int t = 0; t < nt; ++t) QK[(size_t)(tok0 + t) * 1024 + hd * 128 + col] = acc[t] * 0.25f;
     }
   }
+  TT(7);
+#ifdef MIND_TOKEN_TRACE
+  if (blockIdx.x == 0 && tid == 0)
+    printf("[k_token mode %d ntok %d] cycles: load %lld cw %lld combine %lld Wv %lld Wo+LN2 %lld FFN+LN3 %lld S,T,q %lld QK %lld\n", mode, n_tok,
+           tt_[0], tt_[1], tt_[2], tt_[3], tt_[4], tt_[5], tt_[6], tt_[7]);
+#endif
 }

@@ -607,7 +607,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
 
   // ---- fusion: init tokens + 6 x (pair kernel, token kernel)
   const int tok_blocks = (ntok + TPW - 1) / TPW;
-  hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(128), 0, st, dmeta, ntok, 1 | 4, actor_feat, lane_feat, x, part, ST, QK,
+  hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok, 1 | 4, actor_feat, lane_feat, x, part, ST, QK,
                      c->tokW[0]);
   int grid = (njobs + 3) / 4;
   if (grid > c->n_cu) grid = c->n_cu;
@@ -635,7 +635,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
     c->n_pair_launch++;
     c->pairs_done += (L == 5) ? pairs_l5 : pairs_full;
     const int mode = 2 | (L < 5 ? 4 : 8);
-    hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(128), 0, st, dmeta, ntok, mode, actor_feat, lane_feat, x, part, ST, QK,
+    hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok, mode, actor_feat, lane_feat, x, part, ST, QK,
                        c->tokW[L + 1]);
   }
   // ---- decoder
