@@ -39,6 +39,9 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 // weights from L2, so when NOUT < blockDim the K range is split over KP thread groups (partials
 // reduced through the LDS scratch `part`, >= part_floats floats) and every thread keeps 16 weight
 // loads in flight.  Contains __syncthreads(): call from uniform control flow; caller syncs after.
+#ifndef DB
+#define DB 16   // weight loads in flight per thread (32 was measured slower: register pressure at 1024 threads)
+#endif
 template <int R>
 __device__ __forceinline__ void dense(const float *in, int ldi, int K, const float *__restrict__ WT,
                                       const float *__restrict__ b, int NOUT, float *out, int ldo,
@@ -60,14 +63,14 @@ __device__ __forceinline__ void dense(const float *in, int ldi, int K, const flo
 #pragma unroll
       for (int r = 0; r < R; ++r) acc[r] = bv;
       int k = 0;
-      for (; k + 16 <= K; k += 16) {
-        float w[16];
+      for (; k + DB <= K; k += DB) {
+        float w[DB];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) w[q] = WT[(size_t)(k + q) * NOUT + o];
+        for (int q = 0; q < DB; ++q) w[q] = WT[(size_t)(k + q) * NOUT + o];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
+          for (int q4 = 0; q4 < DB / 4; ++q4) {
             const f32x4 x = *(const f32x4 *)(in + r * ldi + k + 4 * q4);
             acc[r] = fmaf(w[4 * q4 + 0], x[0], acc[r]);
             acc[r] = fmaf(w[4 * q4 + 1], x[1], acc[r]);
@@ -97,14 +100,14 @@ __device__ __forceinline__ void dense(const float *in, int ldi, int K, const flo
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
     const int k0 = kp * Kc, k1 = min(K, k0 + Kc);
     int k = k0;
-    for (; k + 16 <= k1; k += 16) {
-      float w[16];
+    for (; k + DB <= k1; k += DB) {
+      float w[DB];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) w[q] = WT[(size_t)(k + q) * NOUT + o];
+      for (int q = 0; q < DB; ++q) w[q] = WT[(size_t)(k + q) * NOUT + o];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
+        for (int q4 = 0; q4 < DB / 4; ++q4) {
           const f32x4 x = *(const f32x4 *)(in + r * ldi + k + 4 * q4);
           acc[r] = fmaf(w[4 * q4 + 0], x[0], acc[r]);
           acc[r] = fmaf(w[4 * q4 + 1], x[1], acc[r]);
@@ -168,7 +171,9 @@ struct LaneW {
 #define PL 2
 #define LR (PL * 10)
 
+#ifndef DT
 #define DT 1024   // threads of the latency-bound dense kernels (K-split over thread groups)
+#endif
 __global__ __launch_bounds__(DT) void k_lane_net(const float *__restrict__ feats, int n_poly,
                                                  float *__restrict__ out, LaneW W) {
   __shared__ __attribute__((aligned(16))) float xin[LR][16];
@@ -239,7 +244,9 @@ struct ActorW {
   const float *latW[4], *latG[4], *latB[4];
 };
 
+#ifndef AT
 #define AT 1024   // threads of k_actor_net
+#endif
 
 // out[co][t] = sum_ci sum_dk W[ci][dk][co] * in[ci][t*stride + dk - pad], raw (no norm).
 // thread = (co, time chunk of TCH outputs, K part): the Cin range is split over KP thread groups and the
@@ -260,7 +267,10 @@ __device__ __forceinline__ void conv_chunk(const float *in, int Cin, int Tin, co
 #pragma unroll
     for (int i = 0; i < TCH; ++i) acc[i] = 0.f;
     const int c0 = kp * cpk, c1 = min(Cin, c0 + cpk);
-#pragma unroll 4
+#ifndef CONV_UNROLL
+#define CONV_UNROLL 4
+#endif
+#pragma unroll CONV_UNROLL
     for (int ci = c0; ci < c1; ++ci) {
 #pragma unroll 3
       for (int dk = 0; dk < ksz; ++dk) {
