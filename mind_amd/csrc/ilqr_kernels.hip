@@ -25,6 +25,9 @@
 #define IL_NA 10      // line-search candidates
 #define IL_THREADS 512
 #define IL_WAVES (IL_THREADS / 64)
+#ifndef IL_SPEC_OVERSUB
+#define IL_SPEC_OVERSUB 1   // (slot, segment) items per wave tolerated at the widest segment level
+#endif
 #define IL_SPEC 4     // Levenberg-Marquardt values evaluated speculatively per step (see k_ilqr)
 #define IL_MAXA 128   // agents per scene staged in LDS (cfg4: 64, stress: 128)
 #define IL_REL 15     // relevant-agent list length per node
@@ -82,7 +85,7 @@ struct IlqrConst {
 };
 
 #define IL_WFENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define IL_NSTAT 24   // doubles per tree in T.stats: 4 results + 4 phase cycle counters + 16 profile slots
+#define IL_NSTAT 25   // doubles per tree in T.stats: 4 results + 4 phase cycle counters + 16 profile slots + passes
 
 // fine-grained cycle attribution (diagnostic build only: -DIL_PROFILE); slots: 0-1 chain-rollout node (stage,
 // u+dynamics+store), 5 nodes; 2-4 cost-pass chunk (stage+loads, field, cost+store), 15 chunks; 6-9 Riccati
@@ -1001,13 +1004,13 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
   }
   __shared__ double Jnew[IL_SPEC][IL_NA];
   __shared__ double sh_mu, sh_delta, sh_J;
-  __shared__ int sh_accepted, sh_converged, sh_stop, sh_sing, sh_pick, sh_slot, sh_it, sh_nspec;
+  __shared__ int sh_accepted, sh_converged, sh_stop, sh_sing, sh_pick, sh_slot, sh_it, sh_nspec, sh_hint;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = T.M;
 #ifdef IL_PROFILE
   long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  if (tid == 0) { sh_mu = 1.0; sh_delta = 2.0; sh_accepted = 1; sh_converged = 0; sh_stop = 0; sh_J = 0.0; sh_pick = 0; sh_slot = 0; sh_it = 0; }
+  if (tid == 0) { sh_mu = 1.0; sh_delta = 2.0; sh_accepted = 1; sh_converged = 0; sh_stop = 0; sh_J = 0.0; sh_pick = 0; sh_slot = 0; sh_it = 0; sh_hint = 1; }
   // ---- initial nominal rollout (solver.py:255-330) = candidate slot 0 with k = K = 0, alpha = 0
   for (int q = tid; q < M * 2; q += IL_THREADS) T.k[q] = 0.0;
   for (int q = tid; q < M * 12; q += IL_THREADS) T.K[q] = 0.0;
@@ -1032,7 +1035,9 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
   // evaluated for the current mu AND for the next mu values the LM schedule would visit if the step keeps
   // being rejected (a deterministic sequence); the first slot with an improving step is taken, exactly
   // what the sequential loop of solver.py:133-158 would have reached.
+  int n_pass = 0;
   while (sh_it < C.max_iter) {
+    ++n_pass;
     if (sh_accepted) {
       // adopt the accepted candidate as the nominal trajectory, then derivatives for all nodes in parallel
       const size_t off = ((size_t)sh_slot * IL_NA + sh_pick) * M;
@@ -1054,9 +1059,11 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
     IL_MARK(t_der);
     // number of speculative slots this pass: bounded by waves, remaining iterations and the mu >= 1e10 stop
     if (tid == 0) {
-      int ns = IL_SPEC;
+      // speculate only while the LM schedule is in a run of rejections (the previous pass saw one): when every
+      // step is accepted the extra slots would only add work to the cost pass
+      int ns = sh_hint;
       const int maxseg = T.max_level_segs > 0 ? T.max_level_segs : 1;   // widest segment level
-      while (ns > 1 && ns * maxseg > IL_WAVES) --ns;
+      while (ns > 1 && ns * maxseg > IL_SPEC_OVERSUB * IL_WAVES) --ns;
       if (ns > C.max_iter - sh_it) ns = C.max_iter - sh_it;
       double mu = sh_mu, de = sh_delta;
       int cnt = 1;
@@ -1184,6 +1191,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
         }
       }
       sh_mu = mu; sh_delta = de; sh_it = it;
+      sh_hint = (sh_accepted && sh_slot == 0) ? 1 : IL_SPEC;
     }
     __syncthreads();
     IL_MARK(t_sel);
@@ -1205,6 +1213,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
 #ifdef IL_PROFILE
     for (int q = 0; q < 16; ++q) T.stats[8 + q] = (double)prof[q];
 #endif
+    T.stats[IL_NSTAT - 1] = (double)n_pass;
   }
 }
 

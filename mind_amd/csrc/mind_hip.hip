@@ -952,8 +952,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
       stats[t].iterations = (int)h[0]; stats[t].converged = (int)h[1];
       stats[t].J = h[2]; stats[t].mu = h[3];
       if (getenv("MIND_ILQR_TRACE"))
-        fprintf(stderr, "[k_ilqr] tree %d exo %d M %d segs %d seg-levels %d widest %d agents %d it %d: cycles derivatives %.0f backward %.0f linesearch %.0f select %.0f\n", t,
-                use_exo, tl[t].M, tl[t].nseg, tl[t].nsl, tl[t].maxls, tl[t].a, stats[t].iterations, h[4], h[5], h[6], h[7]);
+        fprintf(stderr, "[k_ilqr] tree %d exo %d M %d segs %d seg-levels %d widest %d agents %d it %d passes %.0f: cycles derivatives %.0f backward %.0f linesearch %.0f select %.0f\n", t,
+                use_exo, tl[t].M, tl[t].nseg, tl[t].nsl, tl[t].maxls, tl[t].a, stats[t].iterations, h[IL_NSTAT - 1], h[4], h[5], h[6], h[7]);
 #ifdef IL_PROFILE
       if (getenv("MIND_ILQR_TRACE")) {
         fprintf(stderr, "[k_ilqr prof] wave0: chain node (n=%.0f): stage %.0f u+dyn+store %.0f | cost chunk (n=%.0f): stage+loads %.0f field %.0f cost+store %.0f | riccati node (n=%.0f): products %.0f Qxx %.0f solve %.0f update %.0f | deriv block (n=%.0f): setup %.0f tasks %.0f assemble %.0f\n",
