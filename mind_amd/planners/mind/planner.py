@@ -187,8 +187,12 @@ class MINDPlanner:
         """mean over nodes of .1 jerk^2 + 5 steer_rate^2 + .01 (v_tgt - v)^2 + .01 dist(target lane) (:180-198),
         all nodes at once."""
         nodes = list(traj_tree.nodes.values())
-        st = np.array([n.data[0] for n in nodes], dtype=np.float64)
-        ct = np.array([n.data[1] for n in nodes], dtype=np.float64)
+        packed = getattr(traj_tree, "_arrays", None)        # (states, controls) the solver already holds as arrays
+        if packed is not None and len(packed[0]) == len(nodes):
+            st, ct = packed
+        else:
+            st = np.array([n.data[0] for n in nodes], dtype=np.float64)
+            ct = np.array([n.data[1] for n in nodes], dtype=np.float64)
         comfort = (0.1 * ct[:, 0] ** 2 + 5.0 * ct[:, 1] ** 2).sum()
         eff = (0.01 * (lcl_smp.target_velocity - st[:, 2]) ** 2).sum()
         lane = np.asarray(lcl_smp.target_lane)

@@ -259,14 +259,16 @@ class ScenarioTreeGenerator:
         topo_all [a-1,K], ego_end(k) -> (mean [2], cov [1]).  -> [(k, prob)] in visiting order."""
         order = np.argsort(-cls_row, kind="stable")
         cands = []
+        lane_check = self.target_lane is not None and self.ego_idx is not None
+        if lane_check:       # ego end point of every mode against the target lane, all modes at once
+            ends = [ego_end(int(k)) for k in range(len(cls_row))]
+            dis_all = U.get_distances_to_polyline(self.target_lane, np.stack([e[0] for e in ends]).astype(F32, copy=False))
         for k in order:
             prob = F32(cls_row[k] * sc["SCEN_PROB"])
             if prob < F32(0.001):
                 continue
-            if self.target_lane is not None and self.ego_idx is not None:
-                ego_mean, ego_cov = ego_end(int(k))
-                dis = U.get_distance_to_polyline(self.target_lane, ego_mean)
-                if (dis - ego_cov > self.config.tar_dist_thres).any():
+            if lane_check:
+                if (dis_all[k] - ends[k][1] > self.config.tar_dist_thres).any():
                     continue
             cands.append((int(k), prob, topo_all[:, k] if len(topo_all) else np.zeros(0, F32)))
         # greedy merge of modes whose signatures differ by <= pi/6 for every exo agent

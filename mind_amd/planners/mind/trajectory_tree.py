@@ -62,8 +62,11 @@ def to_traj_tree(flat, x0, xs, us, action_size=2):
     """root key -1 holds [x0, 0]; node k holds [xs[k], us[k]] (trajectory_tree.py:140-146)."""
     t = Tree()
     t.add_node(Node(-1, None, [x0, np.zeros(action_size)]))
-    for k in range(len(flat["parent"])):
-        t.add_node(Node(k, int(flat["parent"][k]), [xs[k], us[k]]))
+    par = flat["parent"].tolist()
+    for k in range(len(par)):
+        t.add_node(Node(k, par[k], [xs[k], us[k]]))
+    # node-order arrays for evaluate_traj_tree (root first), so that it does not rebuild them from the nodes
+    t._arrays = (np.concatenate([np.asarray(x0, np.float64)[None], xs]), np.concatenate([np.zeros((1, action_size)), us]))
     return t
 
 

@@ -61,11 +61,46 @@ def _nn_fill(vals, have):
     return vals[fwd]
 
 
+def _agent_trajectories_full_windows(agent_obs, keys, order):
+    """Same result as the per-agent loop of get_agent_trajectories when every kept track carries a full
+    OBS_LEN-row array mirror (the steady state of the closed loop): all agents in one set of array ops."""
+    sel, raws = [], []
+    for rank, ki in enumerate(order):
+        tr = agent_obs[keys[ki]]
+        if tr.object_states[-1].observed is False:
+            continue
+        raw = getattr(tr, "_arr", None)
+        if raw is None or len(raw) != OBS_LEN or len(tr.object_states) != OBS_LEN:
+            return None
+        sel.append((rank, keys[ki], tr))
+        raws.append(raw)
+    raw = np.stack(raws)                                   # [a,50,6] float64
+    a = len(sel)
+    have = raw[..., 0] != 0
+    pos = np.where(have[..., None], raw[..., 1:3], 0.0)
+    ang = np.where(have, raw[..., 3], 0.0)
+    vel = np.where(have[..., None], raw[..., 4:6], 0.0)
+    idx = np.where(have, np.arange(OBS_LEN)[None, :], -1)
+    fwd = np.maximum.accumulate(idx, axis=1)
+    first = np.argmax(have, axis=1)
+    fwd = np.where(fwd < 0, first[:, None], fwd)
+    rows = np.arange(a)[:, None]
+    pos, ang = pos[rows, fwd], ang[rows, fwd]
+    slot = np.array([_TYPE_SLOT.get(_name(tr.object_type), 6) for _, _, tr in sel])
+    typ = np.zeros((a, OBS_LEN, 7), np.int16)
+    typ[rows, np.arange(OBS_LEN)[None, :], slot[:, None]] = have
+    return (pos.astype(F32), ang.astype(F32), vel.astype(F32), typ, have.astype(np.int16),
+            [k for _, k, _ in sel], ["av" if r == 0 else "exo" for r, _, _ in sel])
+
+
 def get_agent_trajectories(agent_obs):
     """agent_obs: {id: Track(track_id, object_states, object_type, category)}; 'AV' is moved first.
     Returns pos [a,50,2] f32, ang [a,50] f32, vel [a,50,2] f32, type [a,50,7] i16, flags [a,50] i16, tids, cats."""
     keys = list(agent_obs.keys())
     order = [keys.index("AV")] + [i for i, k in enumerate(keys) if k != "AV"]
+    fast = _agent_trajectories_full_windows(agent_obs, keys, order)
+    if fast is not None:
+        return fast
     P, A, V, T, Fl, tids, cats = [], [], [], [], [], [], []
     for rank, ki in enumerate(order):
         key = keys[ki]
@@ -151,6 +186,18 @@ def get_distance_to_polyline(polyline, point):
     closest = p1 + t[:, None] * seg
     d = closest - point
     return np.sqrt((d * d).sum(-1)).min()
+
+
+def get_distances_to_polyline(polyline, points):
+    """get_distance_to_polyline for several points [m,2] at once (same float32 arithmetic per point) -> [m]."""
+    p1, p2 = polyline[:-1], polyline[1:]
+    seg = p2 - p1
+    rel = points[:, None, :] - p1[None]
+    t = (rel * seg[None]).sum(-1) / (seg * seg).sum(-1)[None]
+    t = np.clip(t, 0, 1)
+    closest = p1[None] + t[..., None] * seg[None]
+    d = closest - points[:, None, :]
+    return np.sqrt((d * d).sum(-1)).min(axis=1)
 
 
 # ---------------------------------------------------------------------------------------------

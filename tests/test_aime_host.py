@@ -106,3 +106,37 @@ def test_tree_container_contract():
         t.add_node(Node("a", "r", 0))
     with pytest.raises(KeyError):
         t.get_node("zz")
+
+
+def test_agent_trajectories_vectorised_path_equals_per_agent_loop(monkeypatch):
+    """full-window fast path of get_agent_trajectories (all agents at once) == the per-agent loop, incl. unobserved gaps."""
+    from types import SimpleNamespace
+    from mind_amd.planners.mind import utils as U
+    rng = np.random.default_rng(0)
+    agent_obs = {}
+    for i, key in enumerate(["x3", "AV", "x1", "x2", "x7"]):
+        states, rows = [], []
+        for t in range(50):
+            seen = not (key == "x1" and t < 7) and not (key == "x2" and 20 <= t < 26) and not (key == "x7" and t == 49)
+            p, h, v = rng.normal(size=2) * 30, rng.uniform(-3, 3), rng.normal(size=2) * 4
+            states.append(SimpleNamespace(observed=seen, timestep=t, position=(p[0], p[1]), heading=h, velocity=(v[0], v[1])))
+            rows.append([float(seen), p[0], p[1], h, v[0], v[1]])
+        agent_obs[key] = SimpleNamespace(track_id=key, object_states=states, object_type=["vehicle", "pedestrian", "bus"][i % 3],
+                                         category=None, _arr=np.array(rows))
+    fast = U.get_agent_trajectories(agent_obs)
+    monkeypatch.setattr(U, "_agent_trajectories_full_windows", lambda *a: None)
+    slow = U.get_agent_trajectories(agent_obs)
+    assert fast[5] == slow[5] == ["AV", "x3", "x1", "x2"] and fast[6] == slow[6]      # x7 unobserved now: skipped; AV first
+    for f, s_ in zip(fast[:5], slow[:5]):
+        assert f.dtype == s_.dtype and np.array_equal(f, s_)
+
+
+def test_distances_to_polyline_batched_equals_single():
+    from mind_amd.planners.mind import utils as U
+    rng = np.random.default_rng(1)
+    lane = np.cumsum(rng.uniform(0.5, 2.0, (30, 2)), axis=0).astype(np.float32)
+    pts = (rng.uniform(0, 40, (6, 2))).astype(np.float32)
+    d = U.get_distances_to_polyline(lane, pts)
+    assert d.dtype == np.float32
+    for i in range(6):
+        assert d[i] == U.get_distance_to_polyline(lane, pts[i])
