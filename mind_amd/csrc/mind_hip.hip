@@ -746,12 +746,21 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   auto takeD = [&](size_t n) { size_t o = nd; nd += (n + 1) & ~(size_t)1; return o; };
   auto takeF = [&](size_t n) { size_t o = nf; nf += (n + 3) & ~(size_t)3; return o; };
   auto takeI = [&](size_t n) { size_t o = ni; ni += (n + 3) & ~(size_t)3; return o; };
-  const size_t o_gx = takeD(W), o_gy = takeD(H), o_lane = takeD((size_t)n_lane_pts * 2 + 2), o_quad = takeD(gen ? 2 : (size_t)W * H);
-  const size_t o_evx = takeD(ev ? (size_t)ev->nq * 6 : 0), o_evu = takeD(ev ? (size_t)ev->nq * 2 : 0), o_evo = takeD(ev ? (size_t)ev->nq * IL_EVAL_OUT : 0);
+  // the doubles region starts with everything the host uploads (grid, lane, queries, initial controls, per-node
+  // weights); the workspace behind `nd_in` is produced by the kernels and never copied from the host
+  const size_t o_gx = takeD(W), o_gy = takeD(H), o_lane = takeD((size_t)n_lane_pts * 2 + 2);
+  const size_t o_evx = takeD(ev ? (size_t)ev->nq * 6 : 0), o_evu = takeD(ev ? (size_t)ev->nq * 2 : 0);
   const size_t o_evn = takeI(ev ? ev->nq : 0);
   struct TL { size_t nodew, field, relag; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel; int M, a, nl, nseg, nsl, maxls; };
   std::vector<TL> tl(n_trees);
   long Mtot = 0;
+  for (int t = 0; t < n_trees; ++t) {
+    const size_t M = trees[t].n_nodes > 0 ? trees[t].n_nodes : 0;
+    tl[t].us = takeD(2 * M);
+    tl[t].nodew = takeD(gen ? M * IL_NW : 0);
+  }
+  const size_t nd_in = nd;
+  const size_t o_quad = takeD(gen ? 2 : (size_t)W * H), o_evo = takeD(ev ? (size_t)ev->nq * IL_EVAL_OUT : 0);
   for (int t = 0; t < n_trees; ++t) {
     const mind_cost_tree &tr = trees[t];
     if (tr.n_nodes <= 0 || !tr.parent || (!gen && (!tr.prob || tr.n_agents <= 0)) || (use_exo && (!tr.agent_mean || !tr.agent_cov)))
@@ -760,9 +769,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     const size_t M = tr.n_nodes;
     TL &L = tl[t];
     L.M = (int)M; L.a = gen ? 1 : tr.n_agents;
-    L.nodew = takeD(gen ? M * IL_NW : 0);
     L.relag = takeD(use_exo ? M * IL_RA : 0);
-    L.xs = takeD(6 * M); L.us = takeD(2 * M); L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M);
+    L.xs = takeD(6 * M); L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M);
     L.Lxx = takeD(36 * M); L.k = takeD(IL_SPEC * 2 * M); L.K = takeD(IL_SPEC * 12 * M); L.Vx = takeD(IL_SPEC * 6 * M); L.Vxx = takeD(IL_SPEC * 36 * M);
     L.xsn = takeD(IL_SPEC * 60 * M); L.usn = takeD(IL_SPEC * 20 * M); L.Ln = takeD(IL_SPEC * 10 * M); L.stats = takeD(IL_NSTAT);
     L.prob = takeF(M); L.mean = takeF(M * L.a * 2); L.cov = takeF(M * L.a);
@@ -841,7 +849,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   float *dF = (float *)(base + bytesD);
   int *dI = (int *)(base + bytesD + bytesF);
   // host staging of the read-only part
-  std::vector<double> hD(nd, 0.0);
+  std::vector<double> hD(nd_in, 0.0);
   std::vector<float> hF(nf, 0.f);
   std::vector<int> hI(ni, 0);
   memcpy(hD.data() + o_gx, gx.data(), W * sizeof(double));
@@ -890,7 +898,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     D.xs_new = dD + L.xsn; D.us_new = dD + L.usn; D.L_new = dD + L.Ln; D.stats = dD + L.stats;
     moff += (long)M;
   }
-  HIPCHK(c, hipMemcpyAsync(dD, hD.data(), bytesD, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dD, hD.data(), nd_in * sizeof(double), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(dF, hF.data(), bytesF, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(dI, hI.data(), bytesI, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(base + o_structs, hT.data(), (size_t)n_trees * sizeof(IlqrTreeDev), hipMemcpyHostToDevice, st));
