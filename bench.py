@@ -24,6 +24,8 @@ WORKLOADS = {
     "demo1": dict(n_agents=40, n_lanes=5, n_segs=11, seed=3),
     # cfg4: 64 agents x 256 lane polylines
     "cfg4": dict(n_agents=64, n_lanes=8, n_segs=32, seed=4),
+    # cfg4 with the full scripted 6-ary depth-4 AIME tree (259 expansions / plan; BASELINE config 4)
+    "cfg4tree": dict(n_agents=64, n_lanes=8, n_segs=32, seed=4),
 }
 F_MIN_N2 = 754944.0   # minimal-algorithm FLOPs per expansion, N^2 coefficient (6 layers)
 PEAK_F32_MFMA = 157.3e12
@@ -45,16 +47,16 @@ def make_planner(wkw, scripted=True):
     return pl, lcl, w
 
 
-def make_closed_loop(wkw, scripted=True):
+def make_closed_loop(wkw, scripted=True, full_tree=False):
     """planner + closed-loop simulator advanced to the enable time (t = 4.0 s: 40 observation updates)."""
     from mind_amd.closed_loop import ClosedLoopSim
     from mind_amd.planners.mind.planner import MINDPlanner
-    from mind_amd.synth import ScriptedBranching, SynthWorld
+    from mind_amd.synth import ScriptedBranching, ScriptedFullTree, SynthWorld
     cfg = os.path.join(ROOT, "mind_amd", "planners", "mind", "configs", "synthetic.json")
     w = SynthWorld(**wkw)
     pl = MINDPlanner(cfg)
     if scripted:
-        pl.scen_tree_gen.network = ScriptedBranching(pl.network)
+        pl.scen_tree_gen.network = (ScriptedFullTree if full_tree else ScriptedBranching)(pl.network)
     sim = ClosedLoopSim(w, pl)
     sim.run_until(4.0)
     return pl, sim, w
@@ -116,7 +118,7 @@ def main():
     wkw = dict(WORKLOADS[args.workload])
     if not args.shard:
         wkw["seed"] = wkw["seed"] + rank      # every rank plans its own scene (weak scaling)
-    pl, sim, w = make_closed_loop(wkw)
+    pl, sim, w = make_closed_loop(wkw, full_tree=args.workload == "cfg4tree")
     if args.shard and dist is not None:
         pl.enable_sharding()
     rt = pl.network.rt
