@@ -146,6 +146,9 @@ class ScenarioTreeGenerator:
             self.tree.add_node(Node(pred["SCEN_ID"], pred["PARENT_ID"], ScenarioData(pred, None)))
 
     def decide_branch(self):
+        """scenario_tree.py:82-100; the per-leaf work (branch time, re-basing of the observation) is done for all
+        candidate leaves of the round at once."""
+        cand = []
         for l in self.tree.get_leaf_nodes():
             d = l.data
             if d.branch_flag:
@@ -155,12 +158,20 @@ class ScenarioTreeGenerator:
                 if l.depth >= self.config.max_depth:
                     d.terminate_flag = True
                 else:
-                    t_b = self.get_branch_time(d.data)
-                    if t_b < self.pred_len:
-                        d.obs_data, d.data = self.update_obser(d.data)
-                        d.branch_flag = True
-                    else:
-                        d.end_flag = True
+                    cand.append(l)
+        if not cand:
+            return
+        tbs = self.get_branch_times([l.data.data for l in cand])
+        todo = []
+        for l, t_b in zip(cand, tbs):
+            if t_b < self.pred_len:
+                todo.append(l)
+            else:
+                l.data.end_flag = True
+        if todo:
+            for l, (obs, cur) in zip(todo, self.update_obser_batch([l.data.data for l in todo])):
+                l.data.obs_data, l.data.data = obs, cur
+                l.data.branch_flag = True
 
     def get_branch_set(self):
         out = [l for l in self.tree.get_leaf_nodes() if l.data.branch_flag]
@@ -253,7 +264,7 @@ class ScenarioTreeGenerator:
         root["END_T"] = self.pred_len
         return root
 
-    def _select_modes(self, sc, cls_row, topo_all, ego_end):
+    def _select_modes(self, sc, cls_row, topo_all, ego_end, dis_all=None):
         """Pruning decisions of one scene (scenario_tree.py:293-327, 361-395): probability floor, distance of the
         ego end point to the target lane, greedy merge of modes with the same topology.  cls_row [K] f32,
         topo_all [a-1,K], ego_end(k) -> (mean [2], cov [1]).  -> [(k, prob)] in visiting order."""
@@ -262,7 +273,8 @@ class ScenarioTreeGenerator:
         lane_check = self.target_lane is not None and self.ego_idx is not None
         if lane_check:       # ego end point of every mode against the target lane, all modes at once
             ends = [ego_end(int(k)) for k in range(len(cls_row))]
-            dis_all = U.get_distances_to_polyline(self.target_lane, np.stack([e[0] for e in ends]).astype(F32, copy=False))
+            if dis_all is None:
+                dis_all = U.get_distances_to_polyline(self.target_lane, np.stack([e[0] for e in ends]).astype(F32, copy=False))
         for k in order:
             prob = F32(cls_row[k] * sc["SCEN_PROB"])
             if prob < F32(0.001):
@@ -301,12 +313,17 @@ class ScenarioTreeGenerator:
         topo = small[B * 6:B * 6 + A * 6].reshape(A, 6)
         ego_all = small[B * 6 + A * 6:].reshape(B, 6, 3)
         picks = []
+        dis_round = None
+        if self.target_lane is not None and self.ego_idx is not None and all(l >= 0 for l in lasts):
+            # ego end points of every (scene, mode) of the round against the target lane in one call
+            dis_round = U.get_distances_to_polyline(self.target_lane, np.ascontiguousarray(ego_all[:, :, :2].reshape(B * 6, 2))).reshape(B, 6)
         for lidx, sc in enumerate(scenes):
             def ego_end(k, lidx=lidx, sc=sc):
                 if lasts[lidx] >= 0:
                     return ego_all[lidx, k, :2], ego_all[lidx, k, 2:3]
                 return sc["TRAJS_POS_HIST"][self.ego_idx][L - 1], sc["TRAJS_COV_HIST"][self.ego_idx][L - 1]
-            for k, prob in self._select_modes(sc, cls_all[lidx], topo[a_off[lidx] + 1:a_off[lidx + 1]], ego_end):
+            for k, prob in self._select_modes(sc, cls_all[lidx], topo[a_off[lidx] + 1:a_off[lidx + 1]], ego_end,
+                                              None if dis_round is None else dis_round[lidx]):
                 picks.append((lidx, k, prob))
         if not picks:
             return []
@@ -403,6 +420,120 @@ class ScenarioTreeGenerator:
                 d["END_T"] = t
                 return t
         return end_t
+
+    def get_branch_times(self, datas):
+        """get_branch_time for several nodes; nodes with equally shaped covariance histories share one array pass."""
+        out = [None] * len(datas)
+        groups = {}
+        for i, d in enumerate(datas):
+            groups.setdefault(d["TRAJS_COV_HIST"].shape, []).append(i)
+        for shape, idx in groups.items():
+            T = shape[1]
+            if len(idx) == 1 or T <= self.obs_len:
+                for i in idx:
+                    out[i] = self.get_branch_time(datas[i])
+                continue
+            cov = np.stack([datas[i]["TRAJS_COV_HIST"][:, :, 0] for i in idx])          # [G,a,T]
+            cur = np.array([datas[i]["CUR_T"] for i in idx])
+            end = np.array([datas[i]["END_T"] for i in idx])
+            cmp_t = self.obs_len + cur + (cur == 0)
+            if (end > T - self.obs_len).any() or (cmp_t >= T).any():
+                for i in idx:                                   # would index past the history: per-node semantics
+                    out[i] = self.get_branch_time(datas[i])
+                continue
+            ts = np.arange(0, T - self.obs_len)
+            ratio = cov[:, :, self.obs_len:] / np.take_along_axis(cov, cmp_t[:, None, None], axis=2)
+            hit = (ratio > 9).any(axis=1)                                                   # [G, T-obs]
+            hit &= (ts[None, :] > cur[:, None]) & (ts[None, :] < end[:, None]) & (ts[None, :] % 2 == 0)
+            anyhit = hit.any(axis=1)
+            first = np.argmax(hit, axis=1)
+            for g, i in enumerate(idx):
+                if anyhit[g]:
+                    datas[i]["END_T"] = int(first[g])
+                    out[i] = int(first[g])
+                else:
+                    out[i] = datas[i]["END_T"]
+        return out
+
+    def high_level_command_batch(self, origs, rots, cur_vels, min_vel=0.5):
+        """get_high_level_command for G frames at once (same float32 arithmetic per frame): the running ``travel``
+        subtraction of the reference's while-loop is a float32 cumulative sum of [travel0, -seg, -seg, ...]."""
+        lane = self.target_lane
+        n, G = len(lane), len(origs)
+        d = lane[None] - origs[:, None, :]
+        closest = np.argmin(np.sqrt((d * d).sum(-1)), axis=1)
+        seg = self._lane_seg_f32()                                                          # [n-1] |lane[i+1]-lane[i]|
+        travel0 = np.array([max(v, min_vel) * self.config.tar_time_ahead for v in cur_vels]).astype(F32)
+        steps = np.zeros((G, n), F32)
+        steps[:, 0] = travel0
+        j = np.arange(1, n)
+        src = closest[:, None] + j[None, :] - 1                                             # seg index used at step j
+        ok = src < n - 1
+        steps[:, 1:] = np.where(ok, -seg[np.minimum(src, n - 2)], F32(0))
+        trav = np.cumsum(steps, axis=1, dtype=F32)                                          # trav[:, j] after j steps
+        done = (trav[:, 1:] <= 0) & ok                                                      # loop stops after this step
+        nstep = np.where(done.any(axis=1), np.argmax(done, axis=1) + 1, (n - 1) - closest)
+        idx = closest + nstep
+        idx = np.where(idx == n - 1, idx - 1, idx)
+        idx = np.maximum(5, np.minimum(idx, n - 6))
+        sel = idx[:, None] + np.arange(-5, 6)[None, :]                                      # [G,11]
+        pts = lane[sel]                                                                     # [G,11,2]
+        info = self.target_lane_info[sel][:, 1:]                                            # [G,10,12]
+        ctrln = np.matmul(pts - origs[:, None, :], rots)
+        anch_pos = ctrln.mean(axis=1, dtype=F32)
+        dv = ctrln[:, -1] - ctrln[:, 0]
+        anch_vec = dv / np.sqrt((dv * dv).sum(-1), dtype=F32)[:, None]
+        anch_rot = np.stack([np.stack([anch_vec[:, 0], -anch_vec[:, 1]], -1), np.stack([anch_vec[:, 1], anch_vec[:, 0]], -1)], -2).astype(F32)
+        ctrln = np.matmul(ctrln - anch_pos[:, None, :], anch_rot)
+        ctrs = (ctrln[:, :-1] + ctrln[:, 1:]) / F32(2.0)
+        vecs = ctrln[:, 1:] - ctrln[:, :-1]
+        tgt_nodes = np.concatenate([ctrs, vecs, info], axis=-1).astype(F32)
+        return pts.copy(), tgt_nodes, anch_pos.astype(F32), anch_vec.astype(F32)
+
+    def _lane_seg_f32(self):
+        lane = self.target_lane
+        hit = getattr(self, "_seg_cache", None)
+        if hit is None or hit[0] is not lane:
+            dl = lane[1:] - lane[:-1]
+            self._seg_cache = (lane, np.sqrt((dl * dl).sum(-1), dtype=F32))
+        return self._seg_cache[1]
+
+    def update_obser_batch(self, curs):
+        """update_obser (scenario_tree.py:467-567) for all branching nodes of a round at once; nodes must share the
+        agent set (they are children of one plan).  Returns [(obs_data, cur)] in order."""
+        a_counts = {c["TRAJS_POS_HIST"].shape[0] for c in curs}
+        if len(curs) < 2 or len(a_counts) != 1:
+            return [self.update_obser(c) for c in curs]
+        o = self.obs_len
+        G = len(curs)
+        wins = {}
+        for c in curs:
+            keep = o + (c["END_T"] - c["CUR_T"])
+            for k in ("TRAJS_POS_HIST", "TRAJS_COV_HIST", "TRAJS_ANG_HIST", "TRAJS_VEL_HIST"):
+                c[k] = c[k][:, :keep]
+                wins.setdefault(k, []).append(c[k][:, -o:])
+        pos, cov = np.stack(wins["TRAJS_POS_HIST"]), np.stack(wins["TRAJS_COV_HIST"])
+        ang, vel = np.stack(wins["TRAJS_ANG_HIST"]), np.stack(wins["TRAJS_VEL_HIST"])
+        orig, rot, theta, pos_n, ang_n, vel_n, ctrs, vecs = U.normalize_agents_batch(pos, ang, vel)
+        lane_ctrs = np.ascontiguousarray(np.matmul(self.lane_graph["lane_ctrs"][None] - orig[:, None, :], rot), F32)
+        lane_vecs = np.ascontiguousarray(np.matmul(self.lane_graph["lane_vecs"][None], rot), F32)
+        cur_vel = np.sqrt((vel_n[:, 0, -1] * vel_n[:, 0, -1]).sum(-1), dtype=F32)
+        pad = np.ones(ang.shape, F32)
+        types = np.stack([c["TRAJS_TYPE"] for c in curs])
+        tgt_pts, tgt_nodes, tgt_ctr, tgt_vec = self.high_level_command_batch(orig, rot, cur_vel)
+        tgt_rpe = U.get_rpe_batch(np.stack([tgt_ctr, ctrs[:, 0]], 1), np.stack([tgt_vec, vecs[:, 0]], 1)).reshape(G, -1)
+        actors = U.actor_features_batch(pos_n, ang_n, vel_n, types, pad)
+        out = []
+        for g, c in enumerate(curs):
+            s = {"ORIG": orig[g], "ROT": rot[g], "TRAJS_POS_OBS": pos_n[g], "TRAJS_ANG_OBS": ang_n[g], "TRAJS_VEL_OBS": vel_n[g],
+                 "TRAJS_TYPE": c["TRAJS_TYPE"], "PAD_OBS": pad[g], "TRAJS_CTRS": ctrs[g], "TRAJS_VECS": vecs[g],
+                 "ACTORS": actors[g], "LANES": self.lane_feat_in, "LANE_CTRS": lane_ctrs[g], "LANE_VECS": lane_vecs[g],
+                 "TGT_PTS": tgt_pts[g], "TGT_NODES": tgt_nodes[g], "TGT_RPE": tgt_rpe[g],
+                 "SCEN_PROB": c["SCEN_PROB"], "SCEN_ID": c["SCEN_ID"], "PARENT_ID": c["PARENT_ID"],
+                 "CUR_T": c["END_T"], "END_T": self.pred_len, "TRAJS_TID": c["TRAJS_TID"], "TRAJS_CAT": c["TRAJS_CAT"],
+                 "TRAJS_POS_HIST": pos[g], "TRAJS_COV_HIST": cov[g], "TRAJS_ANG_HIST": ang[g], "TRAJS_VEL_HIST": vel[g]}
+            out.append((s, c))
+        return out
 
     def update_obser(self, cur):
         end_t, cur_t = cur["END_T"], cur["CUR_T"]

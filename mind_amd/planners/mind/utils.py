@@ -177,6 +177,52 @@ def get_rpe(ctrs, vecs, radius=100.0):
     return np.stack([c1, s1, c2, s2, dist * F32(2) / F32(radius)]).astype(F32)
 
 
+def get_rpe_batch(ctrs, vecs, radius=100.0):
+    """get_rpe for G independent point sets at once: ctrs, vecs [G,n,2] -> [G,5,n,n] (same float32 arithmetic)."""
+    d = ctrs[:, None, :, :] - ctrs[:, :, None, :]
+    dist = np.sqrt((d * d).sum(-1))
+    v1 = np.broadcast_to(vecs[:, None, :, :], d.shape)
+    v2 = np.broadcast_to(vecs[:, :, None, :], d.shape)
+
+    def cs(a, b):
+        den = np.sqrt((a * a).sum(-1)) * np.sqrt((b * b).sum(-1)) + F32(1e-10)
+        return (a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) / den, (a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]) / den
+
+    c1, s1 = cs(v1, v2)
+    c2, s2 = cs(v1, d)
+    return np.stack([c1, s1, c2, s2, dist * F32(2) / F32(radius)], axis=1).astype(F32)
+
+
+def normalize_agents_batch(pos, ang, vel):
+    """normalize_agents for G scenes with the same agent count at once: pos [G,a,50,2], ang [G,a,50], vel [G,a,50,2].
+    Returns orig [G,2], rot [G,2,2], theta [G], pos_n, ang_n, vel_n, ctrs [G,a,2], vecs [G,a,2]."""
+    orig = pos[:, 0, OBS_LEN - 1]
+    theta = ang[:, 0, OBS_LEN - 1]
+    c0, s0 = np.cos(theta, dtype=F32), np.sin(theta, dtype=F32)
+    rot = np.stack([np.stack([c0, -s0], -1), np.stack([s0, c0], -1)], -2).astype(F32)      # [G,2,2]
+    pos = np.matmul(pos - orig[:, None, None, :], rot[:, None])
+    ang = ang - theta[:, None, None]
+    vel = np.matmul(vel, rot[:, None])
+    ctrs = pos[:, :, OBS_LEN - 1].copy()
+    th = ang[:, :, OBS_LEN - 1].copy()
+    c, s_ = np.cos(th), np.sin(th)
+    R = np.stack([np.stack([c, -s_], -1), np.stack([s_, c], -1)], -2).astype(F32)          # [G,a,2,2]
+    pos_n = np.matmul(pos - ctrs[:, :, None, :], R)
+    ang_n = ang - th[..., None]
+    vel_n = np.matmul(vel, R)
+    vecs = np.stack([c, s_], -1).astype(F32)
+    return orig, rot, theta, pos_n.astype(F32), ang_n.astype(F32), vel_n.astype(F32), ctrs.astype(F32), vecs
+
+
+def actor_features_batch(pos_n, ang_n, vel_n, types, pad):
+    """actor_features with a leading scene axis: -> [G,a,14,48]; types [G,a,50,7] (or broadcastable), pad [G,a,50]."""
+    disp = np.zeros_like(pos_n)
+    disp[:, :, 1:] = pos_n[:, :, 1:] - pos_n[:, :, :-1]
+    feat = np.concatenate([disp, np.stack([np.cos(ang_n), np.sin(ang_n)], -1), vel_n, types.astype(F32),
+                           pad.astype(F32)[..., None]], axis=-1)
+    return np.ascontiguousarray(np.transpose(feat, (0, 1, 3, 2))[..., 2:], dtype=F32)
+
+
 def get_distance_to_polyline(polyline, point):
     """min over segments of |closest point - point| (float32, :486-513), vectorised."""
     p1, p2 = polyline[:-1], polyline[1:]

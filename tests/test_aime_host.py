@@ -140,3 +140,62 @@ def test_distances_to_polyline_batched_equals_single():
     assert d.dtype == np.float32
     for i in range(6):
         assert d[i] == U.get_distance_to_polyline(lane, pts[i])
+
+
+def _full_tree_run(batched):
+    """CPU run of the scripted 6-ary tree (16 agents) through the AIME bookkeeping with a stub network."""
+    from mind_amd.synth import ScriptedFullTree
+
+    class Stub:
+        computes_rpe_in_kernel = True
+        last_packed = None
+        last_lane_feat = None
+
+    class CpuFull(ScriptedFullTree):
+        def pre_process(self, d):
+            return d
+
+        def __call__(self, d):
+            cls, reg, aux = [], [], []
+            for ii in d["ACTOR_IDCS"]:
+                c, r, v = self._modes(len(ii), "cpu")
+                cls.append(c); reg.append(r); aux.append((v, None, None))
+            return cls, reg, aux
+
+    w = SynthWorld(n_agents=16, n_lanes=8, n_segs=32, seed=4)
+    lcl = w.local_semantic_map(4.9)
+    obs = w.tracks(4.9)
+    lane, info = MINDPlanner.resample_target_lane(MINDPlanner.__new__(MINDPlanner), lcl)
+    g = ScenarioTreeGenerator(torch.device("cpu"), CpuFull(Stub()), 50, 50, ScenTreeCfg())
+    if not batched:
+        g.update_obser_batch = lambda curs: [g.update_obser(c) for c in curs]
+        g.get_branch_times = lambda datas: [g.get_branch_time(d) for d in datas]
+    g.reset()
+    g.set_target_lane(lane, info)
+    trees = g.branch_aime(lcl, obs)
+    return g, trees
+
+
+def test_batched_round_bookkeeping_equals_per_node_path():
+    """decide_branch's batched branch-time search and observation re-basing (all branching nodes of a round in one
+    set of array ops) give bit-identical node data and scene inputs to the per-node functions, on the scripted
+    6-ary depth-4 tree (253 expansions)."""
+    gb, tb = _full_tree_run(True)
+    gl, tl = _full_tree_run(False)
+    assert gb.n_expanded == gl.n_expanded > 200
+    assert list(gb.tree.nodes.keys()) == list(gl.tree.nodes.keys())
+    for k in gb.tree.nodes:
+        db, dl = gb.tree.nodes[k].data, gl.tree.nodes[k].data
+        assert (db.branch_flag, db.end_flag, db.terminate_flag) == (dl.branch_flag, dl.end_flag, dl.terminate_flag)
+        for part_b, part_l in ((db.data, dl.data), (db.obs_data, dl.obs_data)):
+            assert (part_b is None) == (part_l is None)
+            if part_b is None:
+                continue
+            assert set(part_b.keys()) == set(part_l.keys())
+            for f in part_b:
+                vb, vl = part_b[f], part_l[f]
+                if isinstance(vb, np.ndarray):
+                    assert vb.dtype == vl.dtype and vb.shape == vl.shape and np.array_equal(vb, vl), (k, f)
+                elif not isinstance(vb, (list, str, type(None))):
+                    assert vb == vl, (k, f)
+    assert [len(t.nodes) for t in tb] == [len(t.nodes) for t in tl]
