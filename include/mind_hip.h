@@ -148,12 +148,15 @@ typedef struct {
   const float *rot, *orig;    /* HOST [n,2,2], [n,2]: scene frames ROT / ORIG                       */
   const float *cov_last;      /* HOST [A] last history covariance TRAJS_COV_HIST[:, -1, 0]          */
   const int32_t *last;        /* HOST [n] index of the last predicted step kept by seq_len (or < 0) */
+  const float *target_lane;   /* HOST [n_lane_pts,2] target lane polyline (float32), or NULL            */
+  int n_lane_pts;
 } mind_world_in;
 
 typedef struct {
   float *world;               /* DEVICE [A,6,60,6]: x, y, vx, vy, heading, max-sigma (world frame)  */
   float *topo;                /* DEVICE [A,6] winding of (agent - ego of its scene); ego rows = 0   */
-  float *ego_end;             /* DEVICE [n,6,3]: ego x, y, max-sigma at step `last` (if last >= 0)  */
+  float *ego_end;             /* DEVICE [n,6,4]: ego x, y, max-sigma at step `last` and the distance */
+                              /*   of that point to the target lane (if last >= 0; inf without lane) */
 } mind_world_out;
 
 /* asynchronous on the context stream (read the outputs after mind_ctx_synchronize or a stream-ordered copy) */

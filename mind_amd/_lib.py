@@ -42,7 +42,8 @@ class FieldGrid(C.Structure):
 class WorldIn(C.Structure):
     _fields_ = [("n_scenes", C.c_int), ("actor_off", C.POINTER(C.c_int32)), ("reg", C.c_void_p), ("vel", C.c_void_p),
                 ("actor_ctrs", C.c_void_p), ("actor_vecs", C.c_void_p), ("rot", C.POINTER(C.c_float)),
-                ("orig", C.POINTER(C.c_float)), ("cov_last", C.POINTER(C.c_float)), ("last", C.POINTER(C.c_int32))]
+                ("orig", C.POINTER(C.c_float)), ("cov_last", C.POINTER(C.c_float)), ("last", C.POINTER(C.c_int32)),
+                ("target_lane", C.POINTER(C.c_float)), ("n_lane_pts", C.c_int)]
 
 
 class WorldOut(C.Structure):

@@ -34,7 +34,8 @@ __global__ __launch_bounds__(64) void k_aime_world(const AimeScene *__restrict__
                                                    const float *__restrict__ reg, const float *__restrict__ vel,
                                                    const float *__restrict__ ctrs, const float *__restrict__ vecs,
                                                    const float *__restrict__ cov_last, float *__restrict__ world,
-                                                   float *__restrict__ topo, float *__restrict__ ego_end) {
+                                                   float *__restrict__ topo, float *__restrict__ ego_end,
+                                                   const float *__restrict__ lane, int n_lane) {
   const int i = blockIdx.x / AIME_K, k = blockIdx.x % AIME_K, t = threadIdx.x;
   const int b = agent_scene[i];
   const AimeScene S = scenes[b];
@@ -54,9 +55,25 @@ __global__ __launch_bounds__(64) void k_aime_world(const AimeScene *__restrict__
     float *w = world + e * AIME_PK;
     w[0] = wx; w[1] = wy; w[2] = wvx; w[3] = wvy; w[4] = ang; w[5] = cv;
   }
-  if (i == S.a0 && live && t == S.last) {
-    float *o = ego_end + ((size_t)b * AIME_K + k) * 3;
-    o[0] = wx; o[1] = wy; o[2] = cv;
+  if (i == S.a0 && S.last >= 0) {
+    // ego end point of this mode (step `last`) and its distance to the target lane (min over segments of the
+    // distance to the clamped projection, utils.py:486-513), the quantity prune_merge thresholds (:300-306)
+    const float px = __shfl(wx, S.last, 64), py = __shfl(wy, S.last, 64), pc = __shfl(cv, S.last, 64);
+    float dmin = INFINITY;
+    for (int sgi = t; sgi < n_lane - 1; sgi += 64) {
+      const float ax = lane[2 * sgi], ay = lane[2 * sgi + 1];
+      const float sx = lane[2 * sgi + 2] - ax, sy = lane[2 * sgi + 3] - ay;
+      float tt = ((px - ax) * sx + (py - ay) * sy) / (sx * sx + sy * sy);
+      tt = fminf(fmaxf(tt, 0.f), 1.f);
+      const float dx = (ax + tt * sx) - px, dy = (ay + tt * sy) - py;
+      dmin = fminf(dmin, sqrtf(dx * dx + dy * dy));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
+    if (t == 0) {
+      float *o = ego_end + ((size_t)b * AIME_K + k) * 4;
+      o[0] = px; o[1] = py; o[2] = pc; o[3] = dmin;
+    }
   }
   // ---- topology signature against the scene's ego (same mode, same step)
   float sig = 0.f;

@@ -1020,15 +1020,20 @@ extern "C" int mind_aime_world(mind_ctx *c, const mind_world_in *in, const mind_
     for (int i = S.a0; i < S.a1; ++i) ascene[i] = b;
   }
   const size_t bS = ((size_t)B * sizeof(AimeScene) + 15) & ~(size_t)15, bI = ((size_t)A * sizeof(int) + 15) & ~(size_t)15;
+  const size_t bC = ((size_t)A * sizeof(float) + 15) & ~(size_t)15;
+  const int n_lane = in->target_lane ? in->n_lane_pts : 0;
+  if (in->target_lane && n_lane < 2) return fail(c, MIND_EINVAL, "mind_aime_world: target lane needs >= 2 points");
   int rc;
-  if ((rc = ensure(c, c->aime_dev, bS + bI + (size_t)A * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->aime_dev, bS + bI + bC + (size_t)(n_lane > 0 ? n_lane : 1) * 2 * sizeof(float)))) return rc;
   char *base = (char *)c->aime_dev.p;
   HIPCHK(c, hipMemcpyAsync(base, hs.data(), (size_t)B * sizeof(AimeScene), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(base + bS, ascene.data(), (size_t)A * sizeof(int), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(base + bS + bI, in->cov_last, (size_t)A * sizeof(float), hipMemcpyHostToDevice, st));
+  if (n_lane) HIPCHK(c, hipMemcpyAsync(base + bS + bI + bC, in->target_lane, (size_t)n_lane * 2 * sizeof(float), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipStreamSynchronize(st));     // the staging vectors go out of scope
   hipLaunchKernelGGL(k_aime_world, dim3(A * AIME_K), dim3(64), 0, st, (const AimeScene *)base, (const int *)(base + bS), in->reg, in->vel,
-                     in->actor_ctrs, in->actor_vecs, (const float *)(base + bS + bI), out->world, out->topo, out->ego_end);
+                     in->actor_ctrs, in->actor_vecs, (const float *)(base + bS + bI), out->world, out->topo, out->ego_end,
+                     (const float *)(base + bS + bI + bC), n_lane);
   HIPCHK(c, hipGetLastError());
   return MIND_OK;
 }

@@ -307,16 +307,17 @@ class ScenarioTreeGenerator:
         lasts = [L - 1 - sc["TRAJS_POS_HIST"].shape[1] for sc in scenes]
         w = rt.aime_world(packed["reg"], packed["vel"], packed["actor_ctrs"], packed["actor_vecs"], a_off,
                           np.stack([sc["ROT"] for sc in scenes]), np.stack([sc["ORIG"] for sc in scenes]),
-                          np.concatenate([sc["TRAJS_COV_HIST"][:, -1, 0] for sc in scenes]), [max(l, -1) for l in lasts])
+                          np.concatenate([sc["TRAJS_COV_HIST"][:, -1, 0] for sc in scenes]), [max(l, -1) for l in lasts],
+                          target_lane=self.target_lane)
         small = torch.cat([packed["cls"].reshape(-1), w["topo"].reshape(-1), w["ego_end"].reshape(-1)]).cpu().numpy()
         cls_all = small[:B * 6].reshape(B, 6)
         topo = small[B * 6:B * 6 + A * 6].reshape(A, 6)
-        ego_all = small[B * 6 + A * 6:].reshape(B, 6, 3)
+        ego_all = small[B * 6 + A * 6:].reshape(B, 6, 4)
         picks = []
         dis_round = None
         if self.target_lane is not None and self.ego_idx is not None and all(l >= 0 for l in lasts):
             # ego end points of every (scene, mode) of the round against the target lane in one call
-            dis_round = U.get_distances_to_polyline(self.target_lane, np.ascontiguousarray(ego_all[:, :, :2].reshape(B * 6, 2))).reshape(B, 6)
+            dis_round = ego_all[:, :, 3]        # distance of every ego end point to the target lane, from the kernel
         for lidx, sc in enumerate(scenes):
             def ego_end(k, lidx=lidx, sc=sc):
                 if lasts[lidx] >= 0:

@@ -51,7 +51,8 @@ def test_world_kernel_matches_host_arithmetic(hip_predictor):
     last = [59, 12, -1]
     dev = hip_predictor.device
     g = lambda x: torch.from_numpy(x).to(dev)
-    w = hip_predictor.aime_world(g(reg), g(vel), g(ctrs), g(vecs), a_off, rots, origs, cov_last, last)
+    lane = (np.cumsum(rng.uniform(0.5, 1.5, (300, 2)), axis=0) + origs[0] - 150.0).astype(F32)
+    w = hip_predictor.aime_world(g(reg), g(vel), g(ctrs), g(vecs), a_off, rots, origs, cov_last, last, target_lane=lane)
     world, topo, ego_end = (w[k].cpu().numpy() for k in ("world", "topo", "ego_end"))
     for b in range(3):
         sl = slice(a_off[b], a_off[b + 1])
@@ -68,6 +69,8 @@ def test_world_kernel_matches_host_arithmetic(hip_predictor):
         if last[b] >= 0:
             assert np.abs(ego_end[b, :, :2] - pos[0, :, last[b]]).max() < 3e-4
             assert np.array_equal(ego_end[b, :, 2], cov[0, :, last[b]])
+            want = U.get_distances_to_polyline(lane, np.ascontiguousarray(ego_end[b, :, :2]))
+            assert np.abs(ego_end[b, :, 3] - want).max() < 1e-3 * max(1.0, want.max())
 
 
 def test_device_prune_merge_equals_host_path_in_closed_loop():
