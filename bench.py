@@ -95,6 +95,101 @@ def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees):
             "plan_ms": plan_s * 1e3}
 
 
+def _proc_scene(i, workload, steps, warmup, ready, go, q):
+    """One scene in its own process (own HIP context): signals ready, waits for the common start, reports back."""
+    import torch as th
+    wkw = dict(WORKLOADS[workload])
+    wkw["seed"] = wkw["seed"] + i
+    pl, sim, w = make_closed_loop(wkw, full_tree=workload == "cfg4tree")
+    sim.run_plans(max(warmup, 1))
+    th.cuda.synchronize()
+    ready.wait()
+    go.wait()
+    t0 = time.time()
+    n = sim.run_plans(steps)
+    th.cuda.synchronize()
+    q.put((i, n, t0, time.time(), pl.scen_tree_gen.n_expanded))
+
+
+def run_concurrent_processes(args):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    P = args.concurrent
+    ready, go, q = ctx.Barrier(P + 1), ctx.Barrier(P + 1), ctx.Queue()
+    procs = [ctx.Process(target=_proc_scene, args=(i, args.workload, args.steps, args.warmup, ready, go, q)) for i in range(P)]
+    for p_ in procs:
+        p_.start()
+    ready.wait(timeout=600)
+    go.wait(timeout=60)
+    res = [q.get(timeout=600) for _ in range(P)]
+    for p_ in procs:
+        p_.join(timeout=60)
+    dt = max(r[3] for r in res) - min(r[2] for r in res)       # same host clock: first start to last finish
+    steps = sum(r[1] for r in res)
+    print(json.dumps({
+        "metric": "sim steps/sec (whole node) + scenario-tree nodes expanded/sec, AV2 demo scenes",
+        "value": steps / dt, "unit": "sim steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 predictor / f64 iLQR", "data": "synthetic",
+        "config": {"workload": f"{P} {args.workload}-like synthetic scenes planned concurrently on one GPU (one host process + HIP "
+                               f"context per scene), {args.steps} planning cycles each", "concurrent_scenes": P,
+                   "sim_steps_timed": steps},
+        "ms_per_plan_aggregate": dt / (args.steps * P) * 1e3}))
+
+
+def run_concurrent(args):
+    """P closed loops (different scenes) in P host threads, each with its own HIP context on its own stream: the
+    GPU work of one scene overlaps the host bookkeeping and the GPU work of the others."""
+    import threading
+    P = args.concurrent
+    loops, errs = [None] * P, []
+    ready, go = threading.Barrier(P + 1), threading.Barrier(P + 1)
+    done_steps = [0] * P
+
+    def worker(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                wkw = dict(WORKLOADS[args.workload])
+                wkw["seed"] = wkw["seed"] + i
+                pl, sim, w = make_closed_loop(wkw, full_tree=args.workload == "cfg4tree")
+                sim.run_plans(max(args.warmup, 1))
+                torch.cuda.current_stream().synchronize()
+                loops[i] = (pl, sim)
+                ready.wait()
+                go.wait()
+                done_steps[i] = sim.run_plans(args.steps)
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:           # surface the failure instead of dead-locking the barriers
+            errs.append(e)
+            for b in (ready, go):
+                b.abort()
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(P)]
+    for t in ths:
+        t.start()
+    ready.wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    go.wait()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if errs:
+        raise errs[0]
+    steps = sum(done_steps)
+    exp = sum(pl.scen_tree_gen.n_expanded for pl, _ in loops)
+    print(json.dumps({
+        "metric": "sim steps/sec (whole node) + scenario-tree nodes expanded/sec, AV2 demo scenes",
+        "value": steps / dt, "unit": "sim steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 predictor / f64 iLQR", "data": "synthetic",
+        "config": {"workload": f"{P} {args.workload}-like synthetic scenes planned concurrently on one GPU (one host thread + HIP "
+                               f"context + stream per scene), {args.steps} planning cycles each", "concurrent_scenes": P,
+                   "sim_steps_timed": steps},
+        "ms_per_plan_aggregate": dt / (args.steps * P) * 1e3}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +197,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="demo1", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--concurrent", type=int, default=0,
+                    help="BASELINE config 3: plan this many independent scenes concurrently on the GPU (one host thread, "
+                         "HIP context and stream per scene); prints the aggregate rate")
+    ap.add_argument("--processes", action="store_true",
+                    help="with --concurrent: one host PROCESS per scene instead of one thread (host bookkeeping in parallel too)")
     ap.add_argument("--shard", action="store_true",
                     help="strong scaling: all ranks plan the SAME scene, AIME rounds and contingency solves sharded over ranks")
     args = ap.parse_args()
@@ -115,6 +215,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.concurrent > 1:
+        return run_concurrent_processes(args) if args.processes else run_concurrent(args)
     wkw = dict(WORKLOADS[args.workload])
     if not args.shard:
         wkw["seed"] = wkw["seed"] + rank      # every rank plans its own scene (weak scaling)

@@ -1,23 +1,28 @@
-"""Process-wide handle on the HIP context (one ``mind_ctx`` per process / GPU)."""
-import os
+"""Handle on the HIP context: one ``mind_ctx`` per (process, thread).
 
-_default = None
+A planner uses the runtime of the thread that built it.  One thread per scene, each under its own
+``torch.cuda.stream``, gives independent contexts/streams whose kernels overlap on the device (BASELINE config 3:
+several scenes planned concurrently on one MI355X); the common single-threaded case sees one runtime per process."""
+import os
+import threading
+
+_local = threading.local()
 
 
 def get_runtime(device=None):
-    """The shared ``HipPredictor`` (predictor + tree-iLQR entry points).  Raises without a GPU / library:
-    the product path has no CPU fallback."""
-    global _default
-    if _default is None:
+    """This thread's ``HipPredictor`` (predictor + tree-iLQR entry points), bound to the thread's current torch
+    stream when first requested.  Raises without a GPU / library: the product path has no CPU fallback."""
+    rt = getattr(_local, "rt", None)
+    if rt is None:
         from .predictor import HipPredictor
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
-        _default = HipPredictor(device)
-    return _default
+        rt = _local.rt = HipPredictor(device)
+    return rt
 
 
 def reset_runtime():
-    global _default
-    if _default is not None:
-        _default.close()
-    _default = None
+    rt = getattr(_local, "rt", None)
+    if rt is not None:
+        rt.close()
+    _local.rt = None

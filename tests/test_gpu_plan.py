@@ -51,3 +51,42 @@ def test_plan_repeatable_and_timed(hip_predictor):
     r2 = pl.plan(lcl)
     assert np.array_equal(r1[1], r2[1])
     assert pl.timing["nodes_expanded"] >= 1 and pl.timing["total_s"] < 5.0
+
+
+def test_concurrent_scenes_equal_sequential_runs():
+    """BASELINE config 3: scenes planned concurrently (one host thread + HIP context + stream per scene) give exactly
+    the controls they give when planned alone."""
+    import sys
+    import threading
+    import torch
+    sys.path.insert(0, ROOT)
+    from bench import WORKLOADS, make_closed_loop
+
+    def run(seed_off, out, key, in_stream):
+        def body():
+            wkw = dict(WORKLOADS["demo1"])
+            wkw["seed"] += seed_off
+            pl, sim, w = make_closed_loop(wkw)
+            ctrls = []
+            for _ in range(3):
+                sim.run_plans(1)
+                ctrls.append(np.array(pl.ctrl, dtype=np.float64))
+            out[key] = np.stack(ctrls)
+        if in_stream:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                body()
+                torch.cuda.current_stream().synchronize()
+        else:
+            body()
+
+    alone, conc = {}, {}
+    for i in range(2):
+        run(i, alone, i, False)
+    ths = [threading.Thread(target=run, args=(i, conc, i, True)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for i in range(2):
+        assert np.array_equal(alone[i], conc[i]), i
+    assert not np.array_equal(alone[0], alone[1])
