@@ -230,7 +230,7 @@ def main():
     ilqr = {"trees": 0, "iterations": 0, "calls": 0}
     expansions = 0
     gen = pl.scen_tree_gen
-    orig_predict, orig_solve = rt.predict, rt.ilqr_solve
+    orig_predict, orig_solve, orig_cont = rt.predict, rt.ilqr_solve, rt.ilqr_contingency
 
     # live accounting inside the timed region: k_pair launch durations come from HIP events recorded on the
     # context stream around every launch (read back after the forward's own synchronisation point)
@@ -252,7 +252,14 @@ def main():
         ilqr["iterations"] += sum(s_["iterations"] for s_ in st)
         return xs, us, st
 
-    rt.predict, rt.ilqr_solve = prof_predict, prof_solve
+    def prof_cont(*a, **k):
+        xs, us, sw, sf = orig_cont(*a, **k)
+        ilqr["calls"] += 1
+        ilqr["trees"] += 2 * len(sf)                      # two fits per tree: warm start, full cost
+        ilqr["iterations"] += sum(s_["iterations"] for s_ in sw) + sum(s_["iterations"] for s_ in sf)
+        return xs, us, sw, sf
+
+    rt.predict, rt.ilqr_solve, rt.ilqr_contingency = prof_predict, prof_solve, prof_cont
 
     def barrier():
         torch.cuda.synchronize()
@@ -267,7 +274,7 @@ def main():
     expansions = pl.scen_tree_gen.n_expanded - n0
     barrier()
     dt = time.perf_counter() - t0
-    rt.predict, rt.ilqr_solve = orig_predict, orig_solve
+    rt.predict, rt.ilqr_solve, rt.ilqr_contingency = orig_predict, orig_solve, orig_cont
     rt.set_profiling(False)
     lcl = sim._observation()
     if dist is not None:

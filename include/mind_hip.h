@@ -134,6 +134,15 @@ int mind_ilqr_solve_trees(mind_ctx *ctx, const mind_ilqr_cfg *cfg, const mind_co
                           double target_vel, int use_exo, const double *us_init, double *xs,
                           double *us, mind_ilqr_stats *stats);
 
+/* MINDPlanner.get_traj_tree (planner.py:174-178) for every scenario tree of a plan in ONE launch: the warm-start
+ * fit (init_warm_start_cost_tree + warm_start_solve: lane term only, cfg_warm = w_opt_cfg, zero initial controls)
+ * followed, from its controls, by the full fit (init_cost_tree + solve, cfg_full = opt_cfg).  xs / us are the
+ * full fit's; both configurations must share dt, wheelbase and the grid. */
+int mind_ilqr_contingency(mind_ctx *ctx, const mind_ilqr_cfg *cfg_warm, const mind_ilqr_cfg *cfg_full,
+                          const mind_cost_tree *trees, int n_trees, const double *x0,
+                          const double *target_lane, int n_lane_pts, double target_vel, double *xs,
+                          double *us, mind_ilqr_stats *stats_warm, mind_ilqr_stats *stats_full);
+
 /* ------------------------------------------------------------------------------------------------
  * AIME glue (k7): the arithmetic of ScenarioTreeGenerator.prune_merge (planners/mind/scenario_tree.py:
  * 281-412) that touches every (agent, mode, step) -- world-frame positions / velocities / headings,

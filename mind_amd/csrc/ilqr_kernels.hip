@@ -989,9 +989,9 @@ __device__ __forceinline__ void il_reject_update(double &mu, double &delta) {
   mu = fmax(1e-6, mu * delta);
 }
 
+// One iLQR.fit (solver.py:80-167) of one cost tree by one workgroup; starts from the controls in T.us.
 template <bool GEN>
-__global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restrict__ trees, IlqrConst C) {
-  const IlqrTreeDev T = trees[blockIdx.x];
+__device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C, double *stats) {
   extern __shared__ double il_dsm[];
   // LDS carve: per-wave scratch [IL_WAVES][IL_SCR] | cost sums [IL_LSUM] | cost-pass records [IL_WAVES][6][IL_RA] | staging [IL_DSTG] floats
   double *scr = il_dsm + (size_t)(threadIdx.x >> 6) * IL_SCR;
@@ -1205,16 +1205,28 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
     for (int q = tid; q < M * 2; q += IL_THREADS) T.us[q] = un[q];
   }
   if (tid == 0) {
-    T.stats[0] = (double)sh_it;
-    T.stats[1] = (double)sh_converged;
-    T.stats[2] = sh_J;
-    T.stats[3] = sh_mu;
-    T.stats[4] = (double)t_der; T.stats[5] = (double)t_bw; T.stats[6] = (double)t_ls; T.stats[7] = (double)t_sel;
+    stats[0] = (double)sh_it;
+    stats[1] = (double)sh_converged;
+    stats[2] = sh_J;
+    stats[3] = sh_mu;
+    stats[4] = (double)t_der; stats[5] = (double)t_bw; stats[6] = (double)t_ls; stats[7] = (double)t_sel;
 #ifdef IL_PROFILE
-    for (int q = 0; q < 16; ++q) T.stats[8 + q] = (double)prof[q];
+    for (int q = 0; q < 16; ++q) stats[8 + q] = (double)prof[q];
 #endif
-    T.stats[IL_NSTAT - 1] = (double)n_pass;
+    stats[IL_NSTAT - 1] = (double)n_pass;
   }
+  __threadfence_block();
+  __syncthreads();
+}
+
+// n_phases == 1: one fit with consts[0].  n_phases == 2: the contingency planner's sequence (planner.py:174-178) in
+// one launch -- the warm-start fit (consts[0]: lane term only) and then, from its controls, the full fit (consts[1]).
+// T.stats receives IL_NSTAT doubles per phase.
+template <bool GEN>
+__global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restrict__ trees, const IlqrConst *__restrict__ consts,
+                                                     int n_phases) {
+  const IlqrTreeDev T = trees[blockIdx.x];
+  for (int ph = 0; ph < n_phases; ++ph) il_fit<GEN>(T, consts[ph], T.stats + (size_t)ph * IL_NSTAT);
 }
 
 static inline size_t il_lds_bytes(int /*amax*/) {

@@ -715,8 +715,13 @@ struct IlqrEvalReq { int nq; const int32_t *node; const double *x, *u; double *o
 static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_grid *grid, const mind_cost_tree *trees, int n_trees,
                      const double *x0, const double *target_lane, int n_lane_pts, double target_vel,
                      int use_exo, const double *us_init, double *xs, double *us,
-                     mind_ilqr_stats *stats, const IlqrEvalReq *ev) {
+                     mind_ilqr_stats *stats, const IlqrEvalReq *ev,
+                     const mind_ilqr_cfg *cfg2 = nullptr, mind_ilqr_stats *stats2 = nullptr) {
+  // cfg2 != nullptr: two fits in one launch -- (cfg, lane term only) then, from its controls, (cfg2, full cost)
   const bool gen = grid != nullptr;
+  const int n_phases = cfg2 ? 2 : 1;
+  const int use_exo_first = cfg2 ? 0 : use_exo;
+  if (cfg2) use_exo = 1;
   if (!c || !cfg || !trees || n_trees <= 0 || !x0) return fail(c, MIND_EINVAL, "iLQR: bad argument");
   if (!ev && (!xs || !us)) return fail(c, MIND_EINVAL, "iLQR: null output");
   if (!gen && (!target_lane || n_lane_pts < 2)) return fail(c, MIND_EINVAL, "iLQR: target lane needs >= 2 points");
@@ -772,7 +777,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     L.relag = takeD(use_exo ? M * IL_RA : 0);
     L.xs = takeD(6 * M); L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M);
     L.Lxx = takeD(36 * M); L.k = takeD(IL_SPEC * 2 * M); L.K = takeD(IL_SPEC * 12 * M); L.Vx = takeD(IL_SPEC * 6 * M); L.Vxx = takeD(IL_SPEC * 36 * M);
-    L.xsn = takeD(IL_SPEC * 60 * M); L.usn = takeD(IL_SPEC * 20 * M); L.Ln = takeD(IL_SPEC * 10 * M); L.stats = takeD(IL_NSTAT);
+    L.xsn = takeD(IL_SPEC * 60 * M); L.usn = takeD(IL_SPEC * 20 * M); L.Ln = takeD(IL_SPEC * 10 * M); L.stats = takeD(2 * IL_NSTAT);
     L.prob = takeF(M); L.mean = takeF(M * L.a * 2); L.cov = takeF(M * L.a);
     L.parent = takeI(M); L.lnodes = takeI(M); L.cstart = takeI(M + 1); L.clist = takeI(M); L.rel = takeI(M);
     Mtot += (long)M;
@@ -840,7 +845,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   const size_t bytesD = nd * sizeof(double), bytesF = nf * sizeof(float), bytesI = ni * sizeof(int);
   const size_t o_structs = bytesD + bytesF + bytesI;
   // generic mode: the materialised fields go behind the structs, copied straight from the caller's arrays
-  size_t total = (o_structs + (size_t)n_trees * sizeof(IlqrTreeDev) + 15) & ~(size_t)15;
+  const size_t o_consts = (o_structs + (size_t)n_trees * sizeof(IlqrTreeDev) + 15) & ~(size_t)15;
+  size_t total = (o_consts + 2 * sizeof(IlqrConst) + 15) & ~(size_t)15;
   for (int t = 0; t < n_trees && gen; ++t) { tl[t].field = total; total += (size_t)tl[t].M * W * H * sizeof(double); }
   int rc;
   if ((rc = ensure(c, c->ilqr_dev, total))) return rc;
@@ -912,7 +918,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   K.w_tgt = cfg->w_tgt; K.w_ego = cfg->w_ego; K.w_ego_off = cfg->w_ego_cov_offset; K.w_exo = cfg->w_exo;
   K.w_exo_off = cfg->w_exo_cov_offset; K.w_exo_cost = cfg->w_exo_cost_offset;
   K.res = grid_res; K.off_x = offx; K.off_y = offy; K.target_vel = target_vel;
-  K.W = W; K.H = H; K.max_iter = cfg->max_iter; K.use_exo = use_exo;
+  K.W = W; K.H = H; K.max_iter = cfg->max_iter; K.use_exo = use_exo_first;
   for (int j = 0; j < IL_NA; ++j) K.alphas[j] = std::pow(1.1, -(double)(j * j));
   K.gx = dD + o_gx; K.gy = dD + o_gy; K.quad = dD + o_quad;
   // cell centres are computed in the kernels when the grid is the numpy linspace (always in the planner mode)
@@ -922,6 +928,22 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   for (int i = 0; i < H && K.lin; ++i) K.lin = gy[i] == ((i == H - 1 ? K.fsy : (double)i * K.stepy) + offy);
   K.in_x0 = offx + 1.5 * grid_res; K.in_x1 = offx + ((double)W - 2.5) * grid_res;
   K.in_y0 = offy + 1.5 * grid_res; K.in_y1 = offy + ((double)H - 2.5) * grid_res;
+  IlqrConst K2[2];
+  K2[0] = K;
+  K2[1] = K;
+  if (cfg2) {      // the full-cost fit: same grid / state / lane field, its own weights
+    IlqrConst &F = K2[1];
+    for (int i = 0; i < 6; ++i) { F.w_des[i] = cfg2->w_des_state[i]; F.w_con[i] = cfg2->w_state_con[i]; F.lb[i] = cfg2->state_lower[i]; F.ub[i] = cfg2->state_upper[i]; }
+    F.w_ctrl[0] = cfg2->w_ctrl[0]; F.w_ctrl[1] = cfg2->w_ctrl[1];
+    F.w_tgt = cfg2->w_tgt; F.w_ego = cfg2->w_ego; F.w_ego_off = cfg2->w_ego_cov_offset; F.w_exo = cfg2->w_exo;
+    F.w_exo_off = cfg2->w_exo_cov_offset; F.w_exo_cost = cfg2->w_exo_cost_offset;
+    F.max_iter = cfg2->max_iter; F.use_exo = 1;
+    if (cfg2->dt != cfg->dt || cfg2->wheelbase != cfg->wheelbase || cfg2->grid_res != cfg->grid_res || cfg2->grid_w != cfg->grid_w ||
+        cfg2->grid_h != cfg->grid_h)
+      return fail(c, MIND_EINVAL, "mind_ilqr_contingency: both configurations must share dt / wheelbase / grid");
+  }
+  HIPCHK(c, hipMemcpyAsync(base + o_consts, K2, 2 * sizeof(IlqrConst), hipMemcpyHostToDevice, st));
+  const IlqrConst *dK = (const IlqrConst *)(base + o_consts);
   if (!gen) hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, K.gx, K.gy, W, H, dD + o_lane, n_lane_pts, dD + o_quad);
   int amax = 1;
   for (int t = 0; t < n_trees; ++t) amax = tl[t].a > amax ? tl[t].a : amax;
@@ -938,30 +960,33 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   const size_t il_lds = il_lds_bytes(amax);
   if (gen) {
     (void)hipFuncSetAttribute((const void *)k_ilqr<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
-    hipLaunchKernelGGL(k_ilqr<true>, dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, K);
+    hipLaunchKernelGGL(k_ilqr<true>, dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases);
   } else {
     (void)hipFuncSetAttribute((const void *)k_ilqr<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
-    hipLaunchKernelGGL(k_ilqr<false>, dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, K);
+    hipLaunchKernelGGL(k_ilqr<false>, dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases);
   }
   HIPCHK(c, hipGetLastError());
   moff = 0;
-  std::vector<double> hs((size_t)IL_NSTAT * n_trees);
+  std::vector<double> hs((size_t)2 * IL_NSTAT * n_trees);
   for (int t = 0; t < n_trees; ++t) {
     const TL &L = tl[t];
     HIPCHK(c, hipMemcpyAsync(xs + moff * 6, dD + L.xs, (size_t)L.M * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(us + moff * 2, dD + L.us, (size_t)L.M * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(hs.data() + (size_t)IL_NSTAT * t, dD + L.stats, IL_NSTAT * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hs.data() + (size_t)2 * IL_NSTAT * t, dD + L.stats, (size_t)n_phases * IL_NSTAT * sizeof(double), hipMemcpyDeviceToHost, st));
     moff += L.M;
   }
   HIPCHK(c, hipStreamSynchronize(st));
-  if (stats)
+  for (int ph = 0; ph < n_phases; ++ph) {
+    mind_ilqr_stats *so = ph == 0 ? stats : stats2;
+    if (!so) continue;
     for (int t = 0; t < n_trees; ++t) {
-      const double *h = hs.data() + (size_t)IL_NSTAT * t;
+      const double *h = hs.data() + (size_t)2 * IL_NSTAT * t + (size_t)ph * IL_NSTAT;
+      mind_ilqr_stats *stats = so;      // (shadows the parameter inside this loop body)
       stats[t].iterations = (int)h[0]; stats[t].converged = (int)h[1];
       stats[t].J = h[2]; stats[t].mu = h[3];
       if (getenv("MIND_ILQR_TRACE"))
         fprintf(stderr, "[k_ilqr] tree %d exo %d M %d segs %d seg-levels %d widest %d agents %d it %d passes %.0f: cycles derivatives %.0f backward %.0f linesearch %.0f select %.0f\n", t,
-                use_exo, tl[t].M, tl[t].nseg, tl[t].nsl, tl[t].maxls, tl[t].a, stats[t].iterations, h[IL_NSTAT - 1], h[4], h[5], h[6], h[7]);
+                n_phases == 2 ? ph : use_exo, tl[t].M, tl[t].nseg, tl[t].nsl, tl[t].maxls, tl[t].a, stats[t].iterations, h[IL_NSTAT - 1], h[4], h[5], h[6], h[7]);
 #ifdef IL_PROFILE
       if (getenv("MIND_ILQR_TRACE")) {
         fprintf(stderr, "[k_ilqr prof] wave0: chain node (n=%.0f): stage %.0f u+dyn+store %.0f | cost chunk (n=%.0f): stage+loads %.0f field %.0f cost+store %.0f | riccati node (n=%.0f): products %.0f Qxx %.0f solve %.0f update %.0f | deriv block (n=%.0f): setup %.0f tasks %.0f assemble %.0f\n",
@@ -972,7 +997,17 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
       }
 #endif
     }
+  }
   return MIND_OK;
+}
+
+extern "C" int mind_ilqr_contingency(mind_ctx *c, const mind_ilqr_cfg *cfg_warm, const mind_ilqr_cfg *cfg_full,
+                                     const mind_cost_tree *trees, int n_trees, const double *x0, const double *target_lane,
+                                     int n_lane_pts, double target_vel, double *xs, double *us,
+                                     mind_ilqr_stats *stats_warm, mind_ilqr_stats *stats_full) {
+  if (!cfg_full) return fail(c, MIND_EINVAL, "mind_ilqr_contingency: null configuration");
+  return ilqr_impl(c, cfg_warm, nullptr, trees, n_trees, x0, target_lane, n_lane_pts, target_vel, 0, nullptr, xs, us, stats_warm, nullptr,
+                   cfg_full, stats_full);
 }
 
 extern "C" int mind_ilqr_solve_trees(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_cost_tree *trees, int n_trees,

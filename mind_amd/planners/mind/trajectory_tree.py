@@ -125,8 +125,12 @@ class TrajectoryTreeOptimizer:
         xs, us, st_w, st = [], [], [], []
         if mine:
             sub = [flats[i] for i in mine]
-            _, us_w, st_w = solve(ilqr_cfg_from(self.config, "w_opt_cfg"), sub, x0, lane, target_vel, 0, None)
-            xs, us, st = solve(ilqr_cfg_from(self.config, "opt_cfg"), sub, x0, lane, target_vel, 1, us_w)
+            if self.solver is None:      # warm start + full solve in one launch
+                xs, us, st_w, st = self._runtime().ilqr_contingency(ilqr_cfg_from(self.config, "w_opt_cfg"),
+                                                                    ilqr_cfg_from(self.config, "opt_cfg"), sub, x0, lane, target_vel)
+            else:
+                _, us_w, st_w = solve(ilqr_cfg_from(self.config, "w_opt_cfg"), sub, x0, lane, target_vel, 0, None)
+                xs, us, st = solve(ilqr_cfg_from(self.config, "opt_cfg"), sub, x0, lane, target_vel, 1, us_w)
         if self.shard is not None and self.shard.world > 1:
             from ...parallel import gather_round_robin
             res = gather_round_robin(self.shard, len(flats), list(zip(xs, us)))

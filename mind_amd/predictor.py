@@ -124,6 +124,43 @@ class HipPredictor:
         return out
 
     # ------------------------------------------------------------------------------------------
+    def _cost_trees(self, flats, keep):
+        n = len(flats)
+        trees = (_lib.CostTree * n)()
+        Ms = []
+        for i, f in enumerate(flats):
+            par = np.ascontiguousarray(f["parent"], np.int32)
+            prob = np.ascontiguousarray(f["prob"], np.float32)
+            mean = np.ascontiguousarray(f["mean"], np.float32)
+            cov = np.ascontiguousarray(f["cov"], np.float32)
+            keep += [par, prob, mean, cov]
+            trees[i].n_nodes = len(par)
+            trees[i].parent = par.ctypes.data_as(C.POINTER(C.c_int32))
+            trees[i].prob = prob.ctypes.data_as(C.POINTER(C.c_float))
+            trees[i].n_agents = mean.shape[1]
+            trees[i].agent_mean = mean.ctypes.data_as(C.POINTER(C.c_float))
+            trees[i].agent_cov = cov.ctypes.data_as(C.POINTER(C.c_float))
+            Ms.append(len(par))
+        return trees, Ms
+
+    def ilqr_contingency(self, cfg_warm, cfg_full, flats, x0, lane, target_vel):
+        """Warm-start fit + full fit of all cost trees of a plan in one launch (mind_ilqr_contingency).
+        Returns (xs list[[M,6]], us list[[M,2]], stats_warm list[dict], stats_full list[dict])."""
+        keep = []
+        trees, Ms = self._cost_trees(flats, keep)
+        n, Mt = len(flats), int(sum(Ms))
+        x0 = np.ascontiguousarray(x0, np.float64)
+        lane = np.ascontiguousarray(lane, np.float64)
+        xs, us = np.zeros((Mt, 6)), np.zeros((Mt, 2))
+        sw, sf = (_lib.IlqrStats * n)(), (_lib.IlqrStats * n)()
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        rc = self.lib.mind_ilqr_contingency(self.ctx, C.byref(cfg_warm), C.byref(cfg_full), trees, n, dp(x0), dp(lane), len(lane),
+                                            C.c_double(float(target_vel)), dp(xs), dp(us), sw, sf)
+        _lib.check(self.lib, self.ctx, rc, "mind_ilqr_contingency")
+        offs = np.cumsum([0] + Ms)
+        st = lambda s_: [dict(iterations=s_[i].iterations, converged=s_[i].converged, J=s_[i].J, mu=s_[i].mu) for i in range(n)]
+        return ([xs[offs[i]:offs[i + 1]] for i in range(n)], [us[offs[i]:offs[i + 1]] for i in range(n)], st(sw), st(sf))
+
     def ilqr_solve(self, cfg, flats, x0, lane, target_vel, use_exo, us_init=None):
         """Solve all cost trees of a plan in one launch.  ``flats``: list of dicts with parent int32 [M],
         prob f32 [M], mean f32 [M,a,2], cov f32 [M,a] (trajectory-node arrays in creation order);

@@ -57,3 +57,20 @@ def test_hip_ilqr_grid_border_and_outside(hip_predictor):
     ref = oi.solve(cfg, flat, x0, lane, sst["target_vel"], 1)
     xs, us, st = hip_predictor.ilqr_solve(cfg, [flat], x0, lane, sst["target_vel"], 1)
     assert np.abs(xs[0] - ref["xs"]).max() < 1e-7
+
+
+@pytest.mark.parametrize("kind,a", [("lead", 4), ("branch3", 40)])
+def test_contingency_in_one_launch_equals_two_solves(kind, a, hip_predictor):
+    """mind_ilqr_contingency (warm-start fit + full fit in one persistent launch) == the two separate calls, bit for bit."""
+    sst = scripted_scenario_tree(kind, a)
+    cfg_w, cfg_f = oi.default_cfg(max_iter=100), oi.default_cfg(max_iter=100)
+    cfg_w.w_ego = cfg_w.w_exo = 0.0                          # w_opt_cfg carries no exo weights (unused by the lane-only fit)
+    flat = oi.flatten(sst["nodes"])
+    flat2 = oi.flatten(scripted_scenario_tree("straight", a, seed=2)["nodes"])
+    x0 = oi.init_state(sst["state"], sst["ctrl"])
+    xs_w, us_w, st_w = hip_predictor.ilqr_solve(cfg_w, [flat, flat2], x0, sst["target_lane"], sst["target_vel"], 0)
+    xs_f, us_f, st_f = hip_predictor.ilqr_solve(cfg_f, [flat, flat2], x0, sst["target_lane"], sst["target_vel"], 1, us_init=us_w)
+    xs, us, sw, sf = hip_predictor.ilqr_contingency(cfg_w, cfg_f, [flat, flat2], x0, sst["target_lane"], sst["target_vel"])
+    for t in range(2):
+        assert np.array_equal(xs[t], xs_f[t]) and np.array_equal(us[t], us_f[t])
+        assert sw[t] == st_w[t] and sf[t] == st_f[t]
