@@ -84,7 +84,15 @@ struct IlqrConst {
   const double *quad;       // [H*W] squared distance to the target lane
 };
 
+// Ordering point for lane-to-lane exchange through LDS inside ONE wave.  The LDS pipeline executes a wave's DS
+// instructions in order, so a ds_read issued after a ds_write sees the written data without waiting for the
+// write to retire; only the compiler must be kept from reordering the accesses (it inserts the s_waitcnt a
+// register use needs by itself).  -DIL_HW_FENCE restores the explicit wait.
+#ifdef IL_HW_FENCE
 #define IL_WFENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define IL_WFENCE() asm volatile("" ::: "memory")
+#endif
 #define IL_NSTAT 25   // doubles per tree in T.stats: 4 results + 4 phase cycle counters + 16 profile slots + passes
 
 // fine-grained cycle attribution (diagnostic build only: -DIL_PROFILE); slots: 0-1 chain-rollout node (stage,
@@ -782,8 +790,10 @@ __device__ __forceinline__ void il_node_derivs(const IlqrConst &C, const IlqrTre
 // the next line search, the dynamics Jacobian -- then wave 0 assembles value / gradient / Hessian per node.
 // Only the entries of F_x / l_xx that ever change are written (the rest is set once at kernel start).
 #define IL_DSTG 12288   // floats of LDS staging: 3 x agents x (nodes per block + 1)
+#define IL_RECS (64 * IL_RA)   // doubles of LDS for compact records: 64 nodes (derivative pass) >= 8 waves x 6 nodes (cost pass)
 template <bool GEN>
-__device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTreeDev &T, double *gcell, float *stg IL_PROF_ARG) {
+__device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTreeDev &T, double *gcell, float *stg, double *drec,
+                                              unsigned *dmask IL_PROF_ARG) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = T.M, A = T.n_agents;
   const bool exo = !GEN && C.use_exo;
@@ -819,7 +829,54 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
     int sxc[3], syr[3];
     il_window_axes((int)xi, (int)yi, C.W, C.H, sxc, syr);
     IL_PT(11);
-    for (int task = wave; task < 11; task += IL_WAVES) {
+    // ---- compact records of the agents near the nominal state (for the next line search AND for this pass's
+    //      window cells): |mu_e - x| < (sigma_e + offset) + margin + window reach, ascending agent order.
+    //      The waves share the agents: hit bits meet in an LDS mask per node, a hit's slot is the number of
+    //      lower set bits.
+    int cnt = 0;
+    bool full = false;
+    if (exo) {
+      if (wave < 4) dmask[n * 4 + wave] = 0u;
+      __syncthreads();
+      for (int e = 1 + wave; e < A; e += IL_WAVES) {
+        const double ax = (double)smx[e * nbp + n], ay = (double)smy[e * nbp + n];
+        const double ec = (double)(scv[e * nbp + n] + (float)C.w_exo_off);
+        const double dx = ax - x[0], dy = ay - x[1];
+        const double rr = ec + IL_RMARGIN + 1.0;      // 1.0 > 1.5 cells * sqrt(2) * 0.4 m
+        if (valid && dx * dx + dy * dy < rr * rr) atomicOr(&dmask[n * 4 + (e >> 5)], 1u << (e & 31));
+      }
+      __syncthreads();
+      const unsigned m0 = dmask[n * 4], m1 = dmask[n * 4 + 1], m2 = dmask[n * 4 + 2], m3 = dmask[n * 4 + 3];
+      cnt = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
+      if (cnt > IL_REL) cnt = -1;
+      double *ra = T.relag + (size_t)c * IL_RA;
+      double *rl = drec + (size_t)n * IL_RA;
+      for (int e = 1 + wave; e < A; e += IL_WAVES) {
+        const unsigned w_ = e >> 5, bit = 1u << (e & 31);
+        const unsigned mw = w_ == 0 ? m0 : (w_ == 1 ? m1 : (w_ == 2 ? m2 : m3));
+        if (cnt >= 0 && (mw & bit)) {
+          const int slot = (w_ > 0 ? __popc(m0) : 0) + (w_ > 1 ? __popc(m1) : 0) + (w_ > 2 ? __popc(m2) : 0) + __popc(mw & (bit - 1u));
+          const double ax = (double)smx[e * nbp + n], ay = (double)smy[e * nbp + n];
+          const double ec = (double)(scv[e * nbp + n] + (float)C.w_exo_off);
+          const double th = ec * ec * 1.000000001;
+          double *dl = rl + 4 * (1 + slot);
+          dl[0] = ax; dl[1] = ay; dl[2] = ec; dl[3] = th;
+          if (valid) { double *dg = ra + 4 * (1 + slot); dg[0] = ax; dg[1] = ay; dg[2] = ec; dg[3] = th; }
+        }
+      }
+      if (wave == 0) {
+        const double ec0 = (double)(scv[n] + (float)C.w_ego_off);
+        rl[0] = (double)smx[n]; rl[1] = (double)smy[n]; rl[2] = ec0; rl[3] = ec0 * ec0 * 1.000000001;
+        if (valid) {
+          ra[0] = rl[0]; ra[1] = rl[1]; ra[2] = rl[2]; ra[3] = rl[3];
+          T.rel[c] = cnt;
+        }
+      }
+      // the list covers the window only when the window sits around x (no index clamping)
+      full = cnt < 0 || !(x[0] > C.in_x0 && x[0] < C.in_x1 && x[1] > C.in_y0 && x[1] < C.in_y1);
+      __syncthreads();
+    }
+    for (int task = wave; task < 10; task += IL_WAVES) {
       if (task < 9) {
         // ---- one window cell of every node of the block (trajectory_tree.py:78-108)
         const int r = task / 3, cc = task - 3 * r;
@@ -835,17 +892,26 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
           if (exo) {
             const double cx = il_gx(C, sx), cy = il_gy(C, sy);
             double covf = 0.0;
-            for (int e0 = 1; e0 < A; e0 += 4) {
+            // exo sum in ascending agent order (the oracle's order; provably-zero terms dropped): over the node's
+            // records, or over all agents when the list overflowed / the window was clamped to the grid border
+            const int ne = full ? A - 1 : cnt;
+            const double *rl = drec + (size_t)n * IL_RA;
+            for (int e0 = 1; e0 <= ne; e0 += 4) {
               double ec[4], d2[4];
               bool need = false;
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
-                const int e = e0 + k < A ? e0 + k : A - 1;
-                const double ax = (double)smx[e * nbp + n], ay = (double)smy[e * nbp + n];
-                ec[k] = (double)(scv[e * nbp + n] + (float)C.w_exo_off);
+                const int e = e0 + k <= ne ? e0 + k : (ne > 0 ? ne : 1);
+                double ax, ay;
+                if (full) {
+                  ax = (double)smx[e * nbp + n]; ay = (double)smy[e * nbp + n];
+                  ec[k] = (double)(scv[e * nbp + n] + (float)C.w_exo_off);
+                } else {
+                  ax = rl[4 * e]; ay = rl[4 * e + 1]; ec[k] = rl[4 * e + 2];
+                }
                 const double dx = cx - ax, dy = cy - ay;
                 d2[k] = dx * dx + dy * dy;
-                if (e0 + k >= A || d2[k] > ec[k] * ec[k] * 1.000000001) d2[k] = -1.0;   // max(ec - sqrt(d2), 0) == 0 exactly
+                if (e0 + k > ne || d2[k] > ec[k] * ec[k] * 1.000000001) d2[k] = -1.0;   // max(ec - sqrt(d2), 0) == 0 exactly
                 need |= d2[k] >= 0.0;
               }
               if (__any(need)) {
@@ -868,35 +934,6 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
           }
         }
         gcell[n * 9 + task] = (sy0 >= 0 && sx0 >= 0) ? v : 0.0;
-      } else if (task == 9) {
-        // ---- compact records of the agents near the nominal state, for the next line search:
-        //      |mu_e - x| < (sigma_e + offset) + margin + window reach, ascending agent order
-        if (exo) {
-          double *ra = T.relag + (size_t)c * IL_RA;
-          int cnt = 0;
-          if (valid) {
-            const double ec0 = (double)(scv[n] + (float)C.w_ego_off);
-            ra[0] = (double)smx[n]; ra[1] = (double)smy[n]; ra[2] = ec0; ra[3] = ec0 * ec0 * 1.000000001;
-          }
-          for (int e = 1; e < A; ++e) {
-            const double ax = (double)smx[e * nbp + n], ay = (double)smy[e * nbp + n];
-            const double ec = (double)(scv[e * nbp + n] + (float)C.w_exo_off);
-            const double dx = ax - x[0], dy = ay - x[1];
-            const double rr = ec + IL_RMARGIN + 1.0;      // 1.0 > 1.5 cells * sqrt(2) * 0.4 m
-            if (dx * dx + dy * dy < rr * rr) {
-              if (cnt >= 0 && cnt < IL_REL) {
-                if (valid) {
-                  double *dst = ra + 4 * (1 + cnt);
-                  dst[0] = ax; dst[1] = ay; dst[2] = ec; dst[3] = ec * ec * 1.000000001;
-                }
-                ++cnt;
-              } else {
-                cnt = -1;
-              }
-            }
-          }
-          if (valid) T.rel[c] = cnt;
-        }
       } else {
         // ---- f_x at the POST state (Q1); constant entries were written at kernel start
         double s3, c3;
@@ -993,11 +1030,12 @@ __device__ __forceinline__ void il_reject_update(double &mu, double &delta) {
 template <bool GEN>
 __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C, double *stats) {
   extern __shared__ double il_dsm[];
-  // LDS carve: per-wave scratch [IL_WAVES][IL_SCR] | cost sums [IL_LSUM] | cost-pass records [IL_WAVES][6][IL_RA] | staging [IL_DSTG] floats
+  // LDS carve: per-wave scratch [IL_WAVES][IL_SCR] | cost sums [IL_LSUM] | compact records [IL_RECS] | staging [IL_DSTG] floats
   double *scr = il_dsm + (size_t)(threadIdx.x >> 6) * IL_SCR;
   double *lsum = il_dsm + (size_t)IL_WAVES * IL_SCR;
-  double *recs = lsum + IL_LSUM + (size_t)(threadIdx.x >> 6) * 6 * IL_RA;   // cost pass: 6 nodes' records per wave
-  float *dstg = reinterpret_cast<float *>(lsum + IL_LSUM + (size_t)IL_WAVES * 6 * IL_RA);   // derivative pass staging
+  double *recs0 = lsum + IL_LSUM;                                            // records region: IL_RECS doubles
+  double *recs = recs0 + (size_t)(threadIdx.x >> 6) * 6 * IL_RA;            // cost pass: 6 nodes' records per wave
+  float *dstg = reinterpret_cast<float *>(recs0 + IL_RECS);                  // derivative pass staging
   if ((threadIdx.x & 63) < 12) {
     const int l = threadIdx.x & 63;
     scr[IL_CST + l] = l == 0 ? 1.0 : (l == 6 ? C.dt : 0.0);
@@ -1046,7 +1084,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       for (int q = tid; q < M * 2; q += IL_THREADS) T.us[q] = un[q];
       __threadfence_block();
       __syncthreads();
-      il_deriv_pass<GEN>(C, T, lsum, dstg IL_PROF_PASS);
+      il_deriv_pass<GEN>(C, T, lsum, dstg, recs0, reinterpret_cast<unsigned *>(lsum + 9 * 64) IL_PROF_PASS);
       __threadfence_block();
       __syncthreads();
       if (M <= IL_LSUM) {
@@ -1230,7 +1268,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
 }
 
 static inline size_t il_lds_bytes(int /*amax*/) {
-  return ((size_t)IL_WAVES * IL_SCR + IL_LSUM + (size_t)IL_WAVES * 6 * IL_RA) * sizeof(double) + (size_t)IL_DSTG * sizeof(float);
+  return ((size_t)IL_WAVES * IL_SCR + IL_LSUM + (size_t)IL_RECS) * sizeof(double) + (size_t)IL_DSTG * sizeof(float);
 }
 
 // TreeCost.l / l_x / l_u / l_xx / l_uu (cost.py:341-446) at arbitrary (x, u) of given nodes: one wave per
