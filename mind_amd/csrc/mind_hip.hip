@@ -67,6 +67,7 @@ struct mind_ctx {
   int n_cu = 256;
   int debug_layers = 6;
   int last_ntok = 0;
+  size_t il_dbg[6] = {0, 0, 0, 0, 0, 0};   // tree 0 of the last iLQR call: byte offsets of L, Lx, Lxx, Fx, xs in ilqr_dev; M
   long long last_edge_pairs = 0;
   int last_slots = 0, last_A = 0, last_B = 0;
 };
@@ -948,6 +949,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   int amax = 1;
   for (int t = 0; t < n_trees; ++t) amax = tl[t].a > amax ? tl[t].a : amax;
   const IlqrTreeDev *dT = (const IlqrTreeDev *)(base + o_structs);
+  c->il_dbg[0] = tl[0].L * 8; c->il_dbg[1] = tl[0].Lx * 8; c->il_dbg[2] = tl[0].Lxx * 8; c->il_dbg[3] = tl[0].Fx * 8; c->il_dbg[4] = tl[0].xs * 8;
+  c->il_dbg[5] = (size_t)tl[0].M;
   if (ev) {
     const size_t lds = (IL_SCR + (size_t)4 * amax) * sizeof(double);
     if (gen) hipLaunchKernelGGL(k_cost_eval<true>, dim3(ev->nq), dim3(64), lds, st, dT, K, ev->nq, dI + o_evn, dD + o_evx, dD + o_evu, dD + o_evo);
@@ -1094,6 +1097,16 @@ extern "C" int64_t mind_debug_read(mind_ctx *c, const char *name, float *host, i
   else if (k == "cmode") { src = c->cmode.p; n = (int64_t)c->last_B * 768; }
   else if (k == "tgt_emb") { src = c->tgt_emb.p; n = (int64_t)c->last_B * 128; }
   else if (k == "tgt_feat") { src = c->tgt_feat.p; n = (int64_t)c->last_B * 128; }
+  else if (k.rfind("il_", 0) == 0 && c->il_dbg[5]) {
+    // float64 arrays of tree 0 of the last tree-iLQR call, returned as raw bytes (2 floats per double)
+    const size_t M = c->il_dbg[5];
+    int w = -1; size_t per = 0;
+    if (k == "il_L") { w = 0; per = 1; } else if (k == "il_Lx") { w = 1; per = 6; } else if (k == "il_Lxx") { w = 2; per = 36; }
+    else if (k == "il_Fx") { w = 3; per = 36; } else if (k == "il_xs") { w = 4; per = 6; }
+    if (w < 0) return MIND_EINVAL;
+    src = (const char *)c->ilqr_dev.p + c->il_dbg[w];
+    n = (int64_t)(M * per * 2);
+  }
   else return MIND_EINVAL;
   if (!host) return n;
   if (n > max_floats) n = max_floats;

@@ -30,7 +30,7 @@ def test_hip_ilqr_matches_reference_golden(kind, a, max_iter, hip_predictor):
     assert abs(st_f[0]["J"] - G[key + "_Jf"][0]) < 1e-8 * max(1.0, abs(st_f[0]["J"]))
 
 
-@pytest.mark.parametrize("kind,a", [("lead", 5), ("branch3", 12), ("deep", 4)])
+@pytest.mark.parametrize("kind,a", [("lead", 5), ("branch3", 12), ("deep", 4), ("branch3", 128)])
 def test_hip_ilqr_matches_oracle_and_batches(kind, a, hip_predictor):
     """several trees in one launch give the same result as one by one; compared with the C oracle."""
     sst = scripted_scenario_tree(kind, a, seed=2)
@@ -74,3 +74,47 @@ def test_contingency_in_one_launch_equals_two_solves(kind, a, hip_predictor):
     for t in range(2):
         assert np.array_equal(xs[t], xs_f[t]) and np.array_equal(us[t], us_f[t])
         assert sw[t] == st_w[t] and sf[t] == st_f[t]
+
+
+def test_wide_cost_tree_matches_oracle(hip_predictor):
+    """The biggest scenario tree of the scripted 6-ary depth-4 AIME tree (16 agents): hundreds of trajectory nodes,
+    dozens of chain segments per level (several rounds of waves per level).  The lane-only fit is exact after one
+    iteration; afterwards the only deviations from the C oracle are last-bit differences between the device math
+    library and glibc (sincos / tan) amplified by the iteration: <= 6e-14 after three iterations -- the same
+    numbers, bit for bit, that the first (wave-per-node) version of the kernel produced on this tree."""
+    from test_aime_host import _full_tree_run
+    g, trees = _full_tree_run(True)
+    st = max(trees, key=lambda t: len(t.nodes))
+    nodes = [(k, n.parent_key, n.data) for k, n in st.nodes.items()]
+    flat = oi.flatten(nodes)
+    assert len(flat["parent"]) > 300
+    lane = np.asarray(g.target_lane[::2], np.float64)
+    d0 = nodes[0][2][1][0, 0]                                   # ego position at the first step
+    state = np.array([float(d0[0]), float(d0[1]), 4.0, 0.0])
+    x0 = oi.init_state(state, np.array([0.0, 0.0]))
+    cfg = oi.default_cfg(max_iter=3)
+    for use_exo in (0, 1):
+        ref = oi.solve(cfg, flat, x0, lane, 4.0, use_exo)
+        xs, us, stt = hip_predictor.ilqr_solve(cfg, [flat], x0, lane, 4.0, use_exo)
+        assert np.abs(xs[0] - ref["xs"]).max() < 1e-12 and np.abs(us[0] - ref["us"]).max() < 1e-12
+        assert stt[0]["iterations"] == ref["iterations"] and stt[0]["mu"] == ref["mu"] and stt[0]["J"] == ref["J"]
+    cfg1 = oi.default_cfg(max_iter=1)
+    ref = oi.solve(cfg1, flat, x0, lane, 4.0, 0)
+    xs, us, _ = hip_predictor.ilqr_solve(cfg1, [flat], x0, lane, 4.0, 0)
+    assert np.array_equal(xs[0], ref["xs"]) and np.array_equal(us[0], ref["us"])
+
+
+@pytest.mark.parametrize("n_agents", [1, 2])
+def test_tiny_trees_and_ego_only(n_agents, hip_predictor):
+    """one- and two-node cost trees, a scene with the ego alone (no exo term at all)."""
+    sst = scripted_scenario_tree("straight", n_agents)
+    cfg = oi.default_cfg(max_iter=8)
+    x0 = oi.init_state(sst["state"], sst["ctrl"])
+    for keep in (1, 3):
+        key, parent, data = sst["nodes"][0]
+        short = [(key, parent, [data[0], data[1][:, :keep], data[2][:, :keep], data[3]])]
+        flat = oi.flatten(short)
+        assert len(flat["parent"]) == (keep + 1) // 2
+        ref = oi.solve(cfg, flat, x0, sst["target_lane"], sst["target_vel"], 1)
+        xs, us, stt = hip_predictor.ilqr_solve(cfg, [flat], x0, sst["target_lane"], sst["target_vel"], 1)
+        assert np.array_equal(xs[0], ref["xs"]) and np.array_equal(us[0], ref["us"]) and stt[0]["iterations"] == ref["iterations"]
