@@ -43,6 +43,10 @@ struct mind_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // internal side stream: the lane encoders run beside the actor encoder; always fenced against `stream` with
+  // events on both sides, so callers only ever see work ordered on `stream`
+  hipStream_t side = nullptr;
+  hipEvent_t ev_side = nullptr;
   std::string err;
   // weights
   float *wdev = nullptr;
@@ -115,8 +119,10 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   c->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete c; return MIND_EHIP; }
   // NULL = the device's default (null) stream, which is what torch.cuda.current_stream() is unless the
-  // caller switched streams; the library never creates a stream behind the caller's back.
+  // caller switched streams; everything the caller can observe is ordered on this stream.
   c->stream = (hipStream_t)stream;
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
+  if (c->side && hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   (void)hipFuncSetAttribute((const void *)k_pair<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_lds_bytes());
@@ -133,11 +139,13 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf *bufs[] = {&c->edge, &c->x, &c->ST, &c->QK, &c->part, &c->tokpos, &c->meta, &c->jobs, &c->actor_feat,
-                    &c->lane_feat, &c->tgt_feat, &c->cmode, &c->tgt_emb, &c->rows, &c->rpe_ptrs, &c->ilqr_dev};
+                    &c->lane_feat, &c->tgt_feat, &c->cmode, &c->tgt_emb, &c->rows, &c->rpe_ptrs, &c->ilqr_dev, &c->aime_dev};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->wdev) (void)hipFree(c->wdev);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  if (c->ev_side) (void)hipEventDestroy(c->ev_side);
+  if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return MIND_OK;
@@ -592,19 +600,25 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   float *actor_feat = (float *)c->actor_feat.p;
   const float *lane_feat = in->lane_feat;
 
-  // ---- encoders
+  // ---- encoders: ActorNet on the context stream, the (independent) lane encoders and token positions beside it on
+  //      the side stream (everything they read was complete at the synchronisation point above)
+  hipStream_t ss = c->side ? c->side : st;
   hipLaunchKernelGGL(k_actor_net, dim3(A), dim3(AT), mind_actor_lds_bytes(), st, in->actors, A, actor_feat, c->actorW);
   if (!lane_feat) {
     float *lf = out->lane_feat ? out->lane_feat : (float *)c->lane_feat.p;
     if (Ltot > 0)
-      hipLaunchKernelGGL(k_lane_net, dim3((Ltot + PL - 1) / PL), dim3(DT), 0, st, in->lanes, Ltot, lf, c->laneW);
+      hipLaunchKernelGGL(k_lane_net, dim3((Ltot + PL - 1) / PL), dim3(DT), 0, ss, in->lanes, Ltot, lf, c->laneW);
     lane_feat = lf;
   } else if (out->lane_feat && out->lane_feat != in->lane_feat && Ltot > 0) {
-    HIPCHK(c, hipMemcpyAsync(out->lane_feat, in->lane_feat, (size_t)Ltot * 128 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(out->lane_feat, in->lane_feat, (size_t)Ltot * 128 * sizeof(float), hipMemcpyDeviceToDevice, ss));
   }
-  hipLaunchKernelGGL(k_lane_net, dim3((Bn + PL - 1) / PL), dim3(DT), 0, st, in->tgt_nodes, Bn, (float *)c->tgt_feat.p, c->laneW);
-  hipLaunchKernelGGL(k_tokpos, dim3((ntok + 255) / 256), dim3(256), 0, st, dmeta, ntok, in->actor_ctrs, in->actor_vecs,
+  hipLaunchKernelGGL(k_lane_net, dim3((Bn + PL - 1) / PL), dim3(DT), 0, ss, in->tgt_nodes, Bn, (float *)c->tgt_feat.p, c->laneW);
+  hipLaunchKernelGGL(k_tokpos, dim3((ntok + 255) / 256), dim3(256), 0, ss, dmeta, ntok, in->actor_ctrs, in->actor_vecs,
                      in->lane_ctrs, in->lane_vecs, tokpos);
+  if (c->side) {
+    HIPCHK(c, hipEventRecord(c->ev_side, c->side));
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_side, 0));
+  }
 
   // ---- fusion: init tokens + 6 x (pair kernel, token kernel)
   const int tok_blocks = (ntok + TPW - 1) / TPW;
