@@ -128,8 +128,11 @@ __device__ __forceinline__ void ln_pairs(frag8 &a, const float *vtq, int off_g, 
 // MFMAs are 64 cycles apart > the 40-cycle latency); the two A fragments of the next step are
 // prefetched from LDS during the current one.  Scheduling fences bound the live ranges.
 __device__ __forceinline__ void gemm128(frag8 &acc, const float *wa, const frag8 &bsrc, int lane) {
-  const float *wl = wa + lane * 4;
-  OPAQUE(wl);
+  // the lane offset is hidden as an INTEGER (not the pointer): the address space of `wa` (LDS) stays visible, so
+  // the fragment reads are ds_read_b128 base+immediate instead of flat loads
+  int lo = lane * 4;
+  OPAQUE(lo);
+  const float *wl = wa + lo;
   f32x4 c0 = *(const f32x4 *)(wl + (0 * 8 + 0) * 256);
   f32x4 c1 = *(const f32x4 *)(wl + (1 * 8 + 0) * 256);
 #pragma unroll
