@@ -47,14 +47,20 @@ struct PairJob {
 #define VT_BE 768
 #define VT_SIZE 896
 
+// Eight waves (two per SIMD) share the two weight matrices: while one wave of a SIMD is in its LayerNorm / softmax /
+// staging phases the other one keeps the MFMA busy.  Everything per-wave is sized so that the workgroup fits
+// the 160 KB of LDS: the staging buffer holds a QUARTER tile (16 pairs x 32 features).
+#define PAIR_WAVES 8
+#define PAIR_THREADS (PAIR_WAVES * 64)
+#define STAGE_FLOATS 512              // 16 rows x 8 chunks of 16 bytes
 #define LDS_WAE 0
 #define LDS_WAP 16384
-#define LDS_STAGE 32768               // 4 waves x 1024 floats
-#define LDS_PTAB (LDS_STAGE + 4096)   // 4 waves x 128 floats
-#define LDS_SVEC (LDS_PTAB + 512)     // 4 waves x 136 floats (S[j] + 8 softmax rescale factors)
-#define LDS_VT (LDS_SVEC + 544)       // 896 floats
-#define LDS_RT (LDS_VT + VT_SIZE)     // rpe table 32 chunks x 8 x 4 = 1024 floats
-#define LDS_TOTAL (LDS_RT + 1024)     // 39808 floats = 159232 bytes (<= 163840)
+#define LDS_STAGE 32768                               // 8 waves x 512 floats
+#define LDS_PTAB (LDS_STAGE + PAIR_WAVES * STAGE_FLOATS)   // 8 waves x 128 floats
+#define LDS_SVEC (LDS_PTAB + PAIR_WAVES * 128)        // 8 waves x 136 floats (S[j] + 8 softmax rescale factors)
+#define LDS_VT (LDS_SVEC + PAIR_WAVES * 136)          // 896 floats
+#define LDS_RT (LDS_VT + VT_SIZE)                     // rpe table 32 chunks x 8 x 4 = 1024 floats
+#define LDS_TOTAL (LDS_RT + 1024)                     // 40896 floats = 163584 bytes (<= 163840)
 
 #define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -155,8 +161,10 @@ __device__ __forceinline__ void gemm128(frag8 &acc, const float *wa, const frag8
   }
 }
 
-// swizzled float offset of 16-byte chunk c (0..15) in a 256-byte staging row r (0..15)
-__device__ __forceinline__ int sw_pos(int r, int c) { return (r * 16 + (c ^ (r & 15))) * 4; }
+// swizzled float offset of 16-byte chunk c (0..7) in a 128-byte staging row r (0..15): the 16 lanes of a
+// ds_read_b128 pass (rows 0..15, one chunk each) and of a ds_write_b128 pass (2 rows x 8 chunks) hit 16
+// distinct 16-byte bank groups
+__device__ __forceinline__ int sw_pos(int r, int c) { return (r * 8 + (c ^ ((r >> 1) & 7))) * 4; }
 
 // MODE 0: layer 0, edge built in-kernel from the relative pose encoding (no edge read)
 // MODE 1: layers 1..5, edge read from HBM
@@ -171,7 +179,7 @@ __device__ __forceinline__ int sw_pos(int r, int c) { return (r * 16 + (c ^ (r &
 #endif
 
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ jobs, int n_jobs,
+__global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair(const PairJob *__restrict__ jobs, int n_jobs,
                                                  float *__restrict__ edge, const float *__restrict__ ST,
                                                  const float *__restrict__ QK, float *__restrict__ part,
                                                  const float *__restrict__ WAe, const float *__restrict__ WAp,
@@ -186,22 +194,22 @@ __global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ job
   const int q = lane >> 4;
 
   // ---- stage weights / tables (once per workgroup) ----
-  for (int i = tid; i < 4096; i += 256) {
+  for (int i = tid; i < 4096; i += PAIR_THREADS) {
     ((f32x4 *)(lds + LDS_WAE))[i] = ((const f32x4 *)WAe)[i];
     if (update_mode != 2) ((f32x4 *)(lds + LDS_WAP))[i] = ((const f32x4 *)WAp)[i];
   }
-  for (int i = tid; i < VT_SIZE; i += 256) lds[LDS_VT + i] = vtab[i];
+  for (int i = tid; i < VT_SIZE; i += PAIR_THREADS) lds[LDS_VT + i] = vtab[i];
   if (MODE == 0)
-    for (int i = tid; i < 1024; i += 256) lds[LDS_RT + i] = rtab[i];
+    for (int i = tid; i < 1024; i += PAIR_THREADS) lds[LDS_RT + i] = rtab[i];
   __syncthreads();
 
-  float *stage = lds + LDS_STAGE + wave * 1024;
+  float *stage = lds + LDS_STAGE + wave * STAGE_FLOATS;
   float *ptab = lds + LDS_PTAB + wave * 128;
   float *svec = lds + LDS_SVEC + wave * 136;
   const float *vt = lds + LDS_VT;
 
   PT_DECL
-  for (int job = blockIdx.x * 4 + wave; job < n_jobs; job += gridDim.x * 4) {
+  for (int job = blockIdx.x * PAIR_WAVES + wave; job < n_jobs; job += gridDim.x * PAIR_WAVES) {
     const PairJob J = jobs[job];
     if (update_mode == 2 && !(J.flags & 1)) continue;
     const bool do_update = (update_mode == 0) || (update_mode == 1 && (J.flags & 1));
@@ -247,22 +255,25 @@ __global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ job
       const int ic = valid ? i : (N - 1);
       frag8 ef;
       if (MODE == 1) {
-        // ---- edge tile -> registers through the swizzled staging buffer: 2 x (16 rows x 256 B),
-        //      every global access is a full 256-byte row segment (coalesced), LDS reads conflict-free
+        // ---- edge tile -> registers through the swizzled staging buffer: 4 x (16 rows x 128 B),
+        //      every global access is a full 128-byte row segment (coalesced), LDS accesses conflict-free
+        //      all eight global loads of the tile are issued before the first LDS pass (one HBM round trip per tile)
+        f32x4 raw[8];
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
+        for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
-          for (int n = 0; n < 4; ++n) {
-            const int r = 4 * n + (ll >> 4);
-            const int cp = ll & 15;
-            int irow = i0 + r;
+          for (int n = 0; n < 2; ++n) {
+            int irow = i0 + 8 * n + (ll >> 3);
             irow = irow < N ? irow : N - 1;
-            const f32x4 v = *(const f32x4 *)(edge + (((size_t)J.edge_base + (size_t)irow * N + j) << 7) + hf * 64 + cp * 4);
-            *(f32x4 *)(stage + sw_pos(r, cp)) = v;
+            raw[2 * qt + n] = *(const f32x4 *)(edge + (((size_t)J.edge_base + (size_t)irow * N + j) << 7) + qt * 32 + (ll & 7) * 4);
           }
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) *(f32x4 *)(stage + sw_pos(8 * n + (ll >> 3), ll & 7)) = raw[2 * qt + n];
           LDS_FENCE();
 #pragma unroll
-          for (int b2 = 0; b2 < 4; ++b2) ef[4 * hf + b2] = *(const f32x4 *)(stage + sw_pos(lp, 4 * b2 + lq));
+          for (int b2 = 0; b2 < 2; ++b2) ef[2 * qt + b2] = *(const f32x4 *)(stage + sw_pos(lp, 4 * b2 + lq));
           LDS_FENCE();
         }
       } else {
@@ -365,19 +376,19 @@ __global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ job
 #pragma unroll
         for (int b = 0; b < 8; ++b) up[b] += ef[b];
         ln_pairs(up, vtq, VT_GE, VT_BE, false);
-        // store through the staging buffer: full 256-byte row segments
+        // store through the staging buffer: full 128-byte row segments
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
+        for (int qt = 0; qt < 4; ++qt) {
 #pragma unroll
-          for (int b2 = 0; b2 < 4; ++b2) *(f32x4 *)(stage + sw_pos(lp, 4 * b2 + lq)) = up[4 * hf + b2];
+          for (int b2 = 0; b2 < 2; ++b2) *(f32x4 *)(stage + sw_pos(lp, 4 * b2 + lq)) = up[2 * qt + b2];
           LDS_FENCE();
 #pragma unroll
-          for (int n = 0; n < 4; ++n) {
-            const int r = 4 * n + (ll >> 4);
-            const int cp = ll & 15;
+          for (int n = 0; n < 2; ++n) {
+            const int r = 8 * n + (ll >> 3);
+            const int cp = ll & 7;
             const f32x4 v = *(const f32x4 *)(stage + sw_pos(r, cp));
             if (i0 + r < N)
-              *(f32x4 *)(edge + (((size_t)J.edge_base + (size_t)(i0 + r) * N + j) << 7) + hf * 64 + cp * 4) = v;
+              *(f32x4 *)(edge + (((size_t)J.edge_base + (size_t)(i0 + r) * N + j) << 7) + qt * 32 + cp * 4) = v;
           }
           LDS_FENCE();
         }
@@ -429,15 +440,20 @@ __global__ __launch_bounds__(256, 1) void k_pair(const PairJob *__restrict__ job
       }
       PT(4);
       // ---- mbar[hd][f] += sum_pairs p[pair][hd] * mem[pair][f]  (V projection folded out),
-      //      transposing mem through the staging buffer one 64-feature half at a time
+      //      transposing mem through the staging buffer one 32-feature quarter at a time: quarter qt holds the
+      //      features 64*(qt>>1) + lane of the lanes with (lane >> 5) == (qt & 1); the other half-wave adds zeros
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
+      for (int qt = 0; qt < 4; ++qt) {
+        const int hf = qt >> 1;
 #pragma unroll
-        for (int b2 = 0; b2 < 4; ++b2) *(f32x4 *)(stage + sw_pos(lp, 4 * b2 + lq)) = mem[4 * hf + b2];
+        for (int b2 = 0; b2 < 2; ++b2) *(f32x4 *)(stage + sw_pos(lp, 4 * b2 + lq)) = mem[2 * qt + b2];
         LDS_FENCE();
+        const bool mine = (ll >> 5) == (qt & 1);
+        const int fq = ll & 31;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-          const float val = stage[sw_pos(t, ll >> 2) + (ll & 3)];
+          float val = stage[sw_pos(t, fq >> 2) + (fq & 3)];
+          val = mine ? val : 0.f;
           const f32x4 pa = *(const f32x4 *)(ptab + t * 8);
           const f32x4 pb = *(const f32x4 *)(ptab + t * 8 + 4);
 #pragma unroll

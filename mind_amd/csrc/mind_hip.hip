@@ -624,7 +624,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   const int tok_blocks = (ntok + TPW - 1) / TPW;
   hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok, 1 | 4, actor_feat, lane_feat, x, part, ST, QK,
                      c->tokW[0]);
-  int grid = (njobs + 3) / 4;
+  int grid = (njobs + PAIR_WAVES - 1) / PAIR_WAVES;
   if (grid > c->n_cu) grid = c->n_cu;
   const size_t lds = mind_pair_lds_bytes();
   c->n_pair_launch = 0;
@@ -641,10 +641,10 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
     const int um = L < 4 ? 0 : (L == 4 ? 1 : 2);
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2 * L], st));
     if (L == 0)
-      hipLaunchKernelGGL(k_pair<0>, dim3(grid), dim3(256), lds, st, djobs, njobs, edge, ST, QK, part, c->WAe[L], c->WAp[L],
+      hipLaunchKernelGGL(k_pair<0>, dim3(grid), dim3(PAIR_THREADS), lds, st, djobs, njobs, edge, ST, QK, part, c->WAe[L], c->WAp[L],
                          c->vtab[L], c->rtab, tokpos, rpe_dev, um);
     else
-      hipLaunchKernelGGL(k_pair<1>, dim3(grid), dim3(256), lds, st, djobs, njobs, edge, ST, QK, part, c->WAe[L],
+      hipLaunchKernelGGL(k_pair<1>, dim3(grid), dim3(PAIR_THREADS), lds, st, djobs, njobs, edge, ST, QK, part, c->WAe[L],
                          L == 5 ? c->WAe[L] : c->WAp[L], c->vtab[L], c->rtab, tokpos, rpe_dev, um);
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2 * L + 1], st));
     c->n_pair_launch++;
