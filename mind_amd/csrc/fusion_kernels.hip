@@ -209,7 +209,9 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair(const PairJob *__restr
   const float *vt = lds + LDS_VT;
 
   PT_DECL
-  for (int job = blockIdx.x * PAIR_WAVES + wave; job < n_jobs; job += gridDim.x * PAIR_WAVES) {
+  // wave-major job order: a launch with fewer jobs than wave slots spreads over all compute units (one wave per SIMD
+  // first) instead of packing eight waves onto a few of them
+  for (int job = wave * gridDim.x + blockIdx.x; job < n_jobs; job += gridDim.x * PAIR_WAVES) {
     const PairJob J = jobs[job];
     if (update_mode == 2 && !(J.flags & 1)) continue;
     const bool do_update = (update_mode == 0) || (update_mode == 1 && (J.flags & 1));

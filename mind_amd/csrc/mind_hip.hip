@@ -624,8 +624,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   const int tok_blocks = (ntok + TPW - 1) / TPW;
   hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok, 1 | 4, actor_feat, lane_feat, x, part, ST, QK,
                      c->tokW[0]);
-  int grid = (njobs + PAIR_WAVES - 1) / PAIR_WAVES;
-  if (grid > c->n_cu) grid = c->n_cu;
+  int grid = njobs < c->n_cu ? njobs : c->n_cu;      // jobs are dealt wave-major over the workgroups
   const size_t lds = mind_pair_lds_bytes();
   c->n_pair_launch = 0;
   c->pairs_done = 0;
