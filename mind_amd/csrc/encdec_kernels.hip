@@ -382,16 +382,28 @@ __global__ __launch_bounds__(AT) void k_actor_net(const float *__restrict__ acto
   const int tid = threadIdx.x;
   const int a = blockIdx.x;
   if (a >= n_actors) return;
+#ifdef MIND_ENC_TRACE
+  long long at_[12], aq_ = clock64();
+  int an_ = 0;
+#define AT_MARK() do { const long long n_ = clock64(); at_[an_++] = n_ - aq_; aq_ = n_; } while (0)
+#else
+#define AT_MARK() do {} while (0)
+#endif
   for (int i = tid; i < 14 * 48; i += AT) xin[i] = actors[(size_t)a * 14 * 48 + i];
   __syncthreads();
+  AT_MARK();
   res1d(xin, 14, 48, W.res[0], 32, 1, ta, tb, tc, red, part, pf);
   res1d(ta, 32, 48, W.res[1], 32, 1, o0, tb, tc, red, part, pf);
+  AT_MARK();
   res1d(o0, 32, 48, W.res[2], 64, 2, ta, tb, tc, red, part, pf);
   res1d(ta, 64, 24, W.res[3], 64, 1, o1, tb, tc, red, part, pf);
+  AT_MARK();
   res1d(o1, 64, 24, W.res[4], 128, 2, ta, tb, tc, red, part, pf);
   res1d(ta, 128, 12, W.res[5], 128, 1, o2, tb, tc, red, part, pf);
+  AT_MARK();
   res1d(o2, 128, 12, W.res[6], 256, 2, ta, tb, tc, red, part, pf);
   res1d(ta, 256, 6, W.res[7], 256, 1, o3, tb, tc, red, part, pf);
+  AT_MARK();
   // FPN top-down (network.py:55-58): lateral = conv3 + GN, no activation
   conv(o3, 256, 6, W.latW[3], 128, 6, 1, 3, fa, part, pf);
   __syncthreads();
@@ -418,6 +430,7 @@ __global__ __launch_bounds__(AT) void k_actor_net(const float *__restrict__ acto
     __syncthreads();
     float *t = cur; cur = nxt; nxt = t;
   }
+  AT_MARK();
   // output Res1d(128,128) at T = 48 (network.py:60); only the last time column is kept
   {
     const ResW &w = W.res[8];
@@ -428,7 +441,13 @@ __global__ __launch_bounds__(AT) void k_actor_net(const float *__restrict__ acto
     __syncthreads();
     gn(fo, 128, 48, w.g2, w.b2, cur, true, red);
   }
+  AT_MARK();
   if (tid < 128) out[(size_t)a * 128 + tid] = fo[tid * 48 + 47];
+#ifdef MIND_ENC_TRACE
+  if (a == 0 && tid == 0)
+    printf("[k_actor_net n=%d] cycles: load %lld group0 %lld group1 %lld group2 %lld group3 %lld fpn %lld out-res %lld\n", n_actors, at_[0], at_[1], at_[2],
+           at_[3], at_[4], at_[5], at_[6]);
+#endif
 }
 extern "C" size_t mind_actor_lds_bytes() { return (size_t)ACT_LDS_FLOATS * sizeof(float); }
 
