@@ -150,8 +150,7 @@ class MINDPlanner:
                                                     lcl_smp.target_velocity)
         t2 = time.perf_counter()
         best, min_cost = None, np.inf
-        for i, tt in enumerate(traj_trees):
-            cost = self.evaluate_traj_tree(lcl_smp, tt)
+        for i, cost in enumerate(self.evaluate_traj_trees(lcl_smp, traj_trees)):
             if cost < min_cost:
                 min_cost, best = cost, i
         opt = traj_trees[best]
@@ -182,6 +181,28 @@ class MINDPlanner:
         xs, us = o.warm_start_solve()
         o.init_cost_tree(scen_tree, self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)
         return o.solve(us), o.debug
+
+    def evaluate_traj_trees(self, lcl_smp, traj_trees):
+        """evaluate_traj_tree for all candidate trees of a plan in one set of array ops (the per-tree sums are taken
+        over each tree's own node range); falls back to the per-tree function for trees without solver arrays."""
+        packs = [getattr(t, "_arrays", None) for t in traj_trees]
+        if len(traj_trees) < 2 or any(p is None or len(p[0]) != len(t.nodes) for p, t in zip(packs, traj_trees)):
+            return [self.evaluate_traj_tree(lcl_smp, t) for t in traj_trees]
+        st = np.concatenate([p[0] for p in packs])
+        ct = np.concatenate([p[1] for p in packs])
+        counts = np.array([len(p[0]) for p in packs])
+        starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        lane = np.asarray(lcl_smp.target_lane)
+        s, e = lane[:-1], lane[1:]
+        d = e - s
+        l2 = (d ** 2).sum(-1)
+        assert np.all(l2 != 0.0), "Polyline segments should not have zero lengths."
+        rel = st[:, None, :2] - s[None]
+        t = np.clip((rel * d[None]).sum(-1) / l2[None], 0, 1)
+        near = s[None] + t[..., None] * d[None]
+        dist = np.sqrt(((st[:, None, :2] - near) ** 2).sum(-1)).min(axis=1)
+        per_node = (0.1 * ct[:, 0] ** 2 + 5.0 * ct[:, 1] ** 2) + 0.01 * (lcl_smp.target_velocity - st[:, 2]) ** 2 + 0.01 * dist
+        return list(np.add.reduceat(per_node, starts) / counts)
 
     def evaluate_traj_tree(self, lcl_smp, traj_tree):
         """mean over nodes of .1 jerk^2 + 5 steer_rate^2 + .01 (v_tgt - v)^2 + .01 dist(target lane) (:180-198),

@@ -199,3 +199,24 @@ def test_batched_round_bookkeeping_equals_per_node_path():
                 elif not isinstance(vb, (list, str, type(None))):
                     assert vb == vl, (k, f)
     assert [len(t.nodes) for t in tb] == [len(t.nodes) for t in tl]
+
+
+def test_batched_tree_evaluation_equals_per_tree():
+    """evaluate_traj_trees (all candidate trees in one pass) == evaluate_traj_tree per tree (planner.py:180-198)."""
+    from types import SimpleNamespace
+    from mind_amd.planners.mind.trajectory_tree import to_traj_tree
+    rng = np.random.default_rng(2)
+    pl = MINDPlanner.__new__(MINDPlanner)
+    lane = np.cumsum(rng.uniform(0.5, 2.0, (40, 2)), axis=0)
+    lcl = SimpleNamespace(target_lane=lane, target_velocity=4.0)
+    trees = []
+    for M in (25, 40, 7):
+        par = np.concatenate([[-1], rng.integers(0, np.arange(1, M))]).astype(np.int32)
+        xs = rng.normal(size=(M, 6)) * np.array([20, 20, 2, 0.3, 1, 0.1]) + np.array([30, 30, 4, 0, 0, 0])
+        trees.append(to_traj_tree(dict(parent=par), xs[0] * 0.9, xs, rng.normal(size=(M, 2))))
+    got = pl.evaluate_traj_trees(lcl, trees)
+    want = [pl.evaluate_traj_tree(lcl, t) for t in trees]
+    assert np.allclose(got, want, rtol=1e-13, atol=0) and int(np.argmin(got)) == int(np.argmin(want))
+    for t in trees:
+        t._arrays = None
+    assert pl.evaluate_traj_trees(lcl, trees) == want

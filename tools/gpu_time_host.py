@@ -1,0 +1,36 @@
+"""GPU-box diagnostic: wall-clock of the host-side sections of a planning cycle (method-level timers, no profiler)."""
+import os, sys, time, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from bench import WORKLOADS, make_closed_loop
+
+acc = collections.OrderedDict()
+def wrap(obj, name, label=None, sync=False):
+    f = getattr(obj, name)
+    label = label or name
+    def g(*a, **k):
+        t0 = time.perf_counter()
+        r = f(*a, **k)
+        if sync:
+            torch.cuda.synchronize()
+        acc[label] = acc.get(label, 0.0) + time.perf_counter() - t0
+        return r
+    setattr(obj, name, g)
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "demo1"
+pl, sim, w = make_closed_loop(dict(WORKLOADS[wl]), full_tree=wl == "cfg4tree")
+gen, net, rt, opt = pl.scen_tree_gen, pl.scen_tree_gen.network, pl.network.rt, pl.traj_tree_opt
+sim.run_plans(3)
+wrap(pl, "plan"); wrap(gen, "branch_aime"); wrap(gen, "process_data"); wrap(gen, "collate"); wrap(net, "pre_process")
+wrap(rt, "predict", "rt.predict(launch)"); wrap(rt, "aime_world", "rt.aime_world(sync+launch)"); wrap(gen, "_prune_merge_device")
+wrap(gen, "create_nodes"); wrap(gen, "decide_branch"); wrap(gen, "update_obser_batch"); wrap(gen, "get_scenario_tree")
+wrap(rt, "ilqr_contingency"); wrap(opt, "solve_batch"); wrap(pl, "evaluate_traj_trees"); wrap(pl, "update_observation")
+wrap(sim, "_observation", "sim._observation"); wrap(gen, "prepare_root_data"); wrap(gen, "_select_modes")
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+t0 = time.perf_counter()
+sim.run_plans(n)
+tot = time.perf_counter() - t0
+print("cycle %.2f ms" % (tot / n * 1e3))
+for k, v in acc.items():
+    print("  %-34s %7.3f ms" % (k, v / n * 1e3))
