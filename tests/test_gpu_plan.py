@@ -90,3 +90,24 @@ def test_concurrent_scenes_equal_sequential_runs():
     for i in range(2):
         assert np.array_equal(alone[i], conc[i]), i
     assert not np.array_equal(alone[0], alone[1])
+
+
+def test_bench_prints_one_contract_json_line():
+    """bench.py contract: exactly one JSON line on stdout with the driver's keys, the roofline and cpu_baseline objects."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "sim steps/s" and d["value"] > 83.0 and "workload" in d["config"]
+    r, c = d["roofline"], d["cpu_baseline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] == "TFLOP/s"
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
