@@ -171,6 +171,33 @@ typedef struct {
 /* asynchronous on the context stream (read the outputs after mind_ctx_synchronize or a stream-ordered copy) */
 int mind_aime_world(mind_ctx *ctx, const mind_world_in *in, const mind_world_out *out);
 
+/* Re-basing of the observation at a branch point for all branching nodes of a round: update_obser
+ * (scenario_tree.py:467-567) = get_origin_rotation / normalisation into the AV and agent frames
+ * (utils.py:180-190, scenario_tree.py:128-158), actor features (utils.py:113-134), get_new_lane_graph
+ * (utils.py:171-177), get_high_level_command (scenario_tree.py:613-652) and the target RPE (utils.py:193-242).
+ * The outputs are the next round's mind_scene_batch tensors, written on the device. */
+typedef struct {
+  int n_scenes, n_agents, n_lanes;  /* S child scenes sharing one agent set (a) and one lane graph (l)   */
+  const float *pos, *ang, *vel;     /* HOST [S,a,50,2], [S,a,50], [S,a,50,2]: last 50 world-frame steps    */
+  const float *types;               /* HOST [a,50,7] TRAJS_TYPE                                            */
+  const float *pad;                 /* HOST [S,a,50] PAD_OBS or NULL (= ones, as update_obser sets it)     */
+  const float *lane_ctrs, *lane_vecs; /* HOST [l,2] lane_graph["lane_ctrs"/"lane_vecs"]                    */
+  const float *target_lane;         /* HOST [P,2]                                                          */
+  const float *target_lane_info;    /* HOST [P,12]                                                         */
+  int n_lane_pts;                   /* P >= 12                                                             */
+  float time_ahead, min_vel;        /* tar_time_ahead (5.0), 0.5                                           */
+} mind_rebase_in;
+
+typedef struct {
+  float *actors;                    /* DEVICE [S*a,14,48]                                                  */
+  float *actor_ctrs, *actor_vecs;   /* DEVICE [S*a,2]                                                      */
+  float *lane_ctrs, *lane_vecs;     /* DEVICE [S*l,2]                                                      */
+  float *tgt_nodes, *tgt_rpe;       /* DEVICE [S,10,16], [S,20]                                            */
+  float *frames;                    /* DEVICE [S,28]: ROT (4, row-major), ORIG (2), TGT_PTS (11 x 2)       */
+} mind_rebase_out;
+
+int mind_aime_rebase(mind_ctx *ctx, const mind_rebase_in *in, const mind_rebase_out *out);
+
 /* ------------------------------------------------------------------------------------------------
  * planners/ilqr call surface (iLQR.fit over a TreeCost of arbitrary PotentialField / StatePotential /
  * StateConstraint / ControlPotential objects; solver.py:80-167, cost.py:326-446, potential.py:62-264).

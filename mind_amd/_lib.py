@@ -50,6 +50,19 @@ class WorldOut(C.Structure):
     _fields_ = [("world", C.c_void_p), ("topo", C.c_void_p), ("ego_end", C.c_void_p)]
 
 
+class RebaseIn(C.Structure):
+    _fields_ = [("n_scenes", C.c_int), ("n_agents", C.c_int), ("n_lanes", C.c_int), ("pos", C.POINTER(C.c_float)),
+                ("ang", C.POINTER(C.c_float)), ("vel", C.POINTER(C.c_float)), ("types", C.POINTER(C.c_float)),
+                ("pad", C.POINTER(C.c_float)), ("lane_ctrs", C.POINTER(C.c_float)), ("lane_vecs", C.POINTER(C.c_float)),
+                ("target_lane", C.POINTER(C.c_float)), ("target_lane_info", C.POINTER(C.c_float)), ("n_lane_pts", C.c_int),
+                ("time_ahead", C.c_float), ("min_vel", C.c_float)]
+
+
+class RebaseOut(C.Structure):
+    _fields_ = [("actors", C.c_void_p), ("actor_ctrs", C.c_void_p), ("actor_vecs", C.c_void_p), ("lane_ctrs", C.c_void_p),
+                ("lane_vecs", C.c_void_p), ("tgt_nodes", C.c_void_p), ("tgt_rpe", C.c_void_p), ("frames", C.c_void_p)]
+
+
 class IlqrCfg(C.Structure):
     _fields_ = [("dt", C.c_double), ("wheelbase", C.c_double), ("w_des_state", C.c_double * 6),
                 ("w_state_con", C.c_double * 6), ("state_lower", C.c_double * 6), ("state_upper", C.c_double * 6),
@@ -65,7 +78,7 @@ class IlqrStats(C.Structure):
 
 EXPORTS = ["mind_ctx_create", "mind_ctx_destroy", "mind_last_error_string", "mind_ctx_synchronize",
            "mind_weights_load", "mind_predict_batch", "mind_last_fusion_stats", "mind_set_profiling",
-           "mind_ilqr_solve_trees", "mind_ilqr_contingency", "mind_ilqr_solve_fields", "mind_cost_eval", "mind_lane_dist_field", "mind_aime_world", "mind_debug_set_layers",
+           "mind_ilqr_solve_trees", "mind_ilqr_contingency", "mind_ilqr_solve_fields", "mind_cost_eval", "mind_lane_dist_field", "mind_aime_world", "mind_aime_rebase", "mind_debug_set_layers",
            "mind_debug_read"]
 
 _lib = None
@@ -105,6 +118,7 @@ def load():
     lib.mind_lane_dist_field.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int,
                                          C.c_double] + [C.POINTER(C.c_double)] * 4
     lib.mind_aime_world.argtypes = [C.c_void_p, C.POINTER(WorldIn), C.POINTER(WorldOut)]
+    lib.mind_aime_rebase.argtypes = [C.c_void_p, C.POINTER(RebaseIn), C.POINTER(RebaseOut)]
     lib.mind_debug_set_layers.argtypes = [C.c_void_p, C.c_int]
     lib.mind_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64]
     for n in EXPORTS:

@@ -97,3 +97,188 @@ __global__ __launch_bounds__(64) void k_aime_world(const AimeScene *__restrict__
   }
   if (t == 0) topo[(size_t)i * AIME_K + k] = sig;
 }
+
+// -------------------------------------------------------------------------------------------------
+// Re-basing of the observation at a branch point (scenario_tree.py:467-567 update_obser, with
+// utils.py:171-190 get_new_lane_graph / get_origin_rotation, :113-134 actor features, scenario_tree.py:
+// 613-652 get_high_level_command, utils.py:193-242 get_rpe): from the last 50 world-frame steps of every
+// agent of a child scene to the predictor inputs of the next AIME round, written where the predictor reads
+// them.  One workgroup per child scene; float32 like the reference.
+// -------------------------------------------------------------------------------------------------
+#define RB_THREADS 256
+#define RB_T 50
+
+struct RebaseArgs {
+  int a, l, n_lane, pad_ones;
+  const float *pos, *ang, *vel;       // [S,a,50,2], [S,a,50], [S,a,50,2]   world frame windows
+  const float *types;                 // [a,50,7]
+  const float *pad;                   // [S,a,50] or null (ones)
+  const float *lane_ctrs0, *lane_vecs0;   // [l,2] lane anchors as the lane graph holds them
+  const float *tlane, *tinfo;         // target lane [n_lane,2], per-point info [n_lane,12]
+  float time_ahead, min_vel;
+  float *actors, *actor_ctrs, *actor_vecs, *lane_ctrs, *lane_vecs, *tgt_nodes, *tgt_rpe, *frames;
+};
+
+__device__ __forceinline__ void rb_cs(float ax, float ay, float bx, float by, float &c, float &s) {
+  const float den = sqrtf(ax * ax + ay * ay) * sqrtf(bx * bx + by * by) + 1e-10f;
+  c = (ax * bx + ay * by) / den;
+  s = (ax * by - ay * bx) / den;
+}
+
+__global__ __launch_bounds__(RB_THREADS) void k_aime_rebase(RebaseArgs A) {
+  const int sc = blockIdx.x, tid = threadIdx.x;
+  const int a = A.a;
+  extern __shared__ float rb_sm[];          // per agent: ctr x, ctr y, th, cos, sin (5 floats)
+  __shared__ float fr[8];                   // orig x, y, theta, cos, sin, cur_vel
+  __shared__ float rdv[RB_THREADS];
+  __shared__ int rdi[RB_THREADS];
+  __shared__ int s_idx;
+  __shared__ float ctr[11][2];
+  const float *pos = A.pos + (size_t)sc * a * RB_T * 2;
+  const float *ang = A.ang + (size_t)sc * a * RB_T;
+  const float *vel = A.vel + (size_t)sc * a * RB_T * 2;
+  if (tid == 0) {
+    const float th = ang[RB_T - 1];
+    fr[0] = pos[(RB_T - 1) * 2]; fr[1] = pos[(RB_T - 1) * 2 + 1]; fr[2] = th; fr[3] = cosf(th); fr[4] = sinf(th);
+  }
+  __syncthreads();
+  const float ox = fr[0], oy = fr[1], th0 = fr[2], c0 = fr[3], s0 = fr[4];
+  // ---- per-agent frames (AV frame first, then the agent's own last pose)
+  for (int i = tid; i < a; i += RB_THREADS) {
+    const float dx = pos[(i * RB_T + RB_T - 1) * 2] - ox, dy = pos[(i * RB_T + RB_T - 1) * 2 + 1] - oy;
+    const float cx = dx * c0 + dy * s0, cy = dx * (-s0) + dy * c0;
+    const float thi = ang[i * RB_T + RB_T - 1] - th0;
+    const float ci = cosf(thi), si = sinf(thi);
+    float *o = rb_sm + 5 * i;
+    o[0] = cx; o[1] = cy; o[2] = thi; o[3] = ci; o[4] = si;
+    A.actor_ctrs[((size_t)sc * a + i) * 2] = cx; A.actor_ctrs[((size_t)sc * a + i) * 2 + 1] = cy;
+    A.actor_vecs[((size_t)sc * a + i) * 2] = ci; A.actor_vecs[((size_t)sc * a + i) * 2 + 1] = si;
+  }
+  __syncthreads();
+  // ---- actor features [a,14,48]: displacement, heading cos/sin, velocity, type one-hot, pad flag; steps 2..49
+  for (int e = tid; e < a * 48; e += RB_THREADS) {
+    const int i = e / 48, t = e % 48 + 2;
+    const float *f = rb_sm + 5 * i;
+    float pn[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int tt = t - 1 + q;
+      const float dx = pos[(i * RB_T + tt) * 2] - ox, dy = pos[(i * RB_T + tt) * 2 + 1] - oy;
+      const float x1 = (dx * c0 + dy * s0) - f[0], y1 = (dx * (-s0) + dy * c0) - f[1];
+      pn[q][0] = x1 * f[3] + y1 * f[4];
+      pn[q][1] = x1 * (-f[4]) + y1 * f[3];
+    }
+    const float an = (ang[i * RB_T + t] - th0) - f[2];
+    const float vx0 = vel[(i * RB_T + t) * 2], vy0 = vel[(i * RB_T + t) * 2 + 1];
+    const float vx1 = vx0 * c0 + vy0 * s0, vy1 = vx0 * (-s0) + vy0 * c0;
+    float *o = A.actors + ((size_t)sc * a + i) * 14 * 48 + (t - 2);
+    o[0 * 48] = pn[1][0] - pn[0][0];
+    o[1 * 48] = pn[1][1] - pn[0][1];
+    o[2 * 48] = cosf(an);
+    o[3 * 48] = sinf(an);
+    o[4 * 48] = vx1 * f[3] + vy1 * f[4];
+    o[5 * 48] = vx1 * (-f[4]) + vy1 * f[3];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) o[(6 + k) * 48] = A.types[(i * RB_T + t) * 7 + k];
+    o[13 * 48] = A.pad ? A.pad[((size_t)sc * a + i) * RB_T + t] : 1.0f;
+  }
+  // ---- lane anchors in the new frame (utils.py:171-177)
+  for (int q = tid; q < A.l; q += RB_THREADS) {
+    const float dx = A.lane_ctrs0[2 * q] - ox, dy = A.lane_ctrs0[2 * q + 1] - oy;
+    A.lane_ctrs[((size_t)sc * A.l + q) * 2] = dx * c0 + dy * s0;
+    A.lane_ctrs[((size_t)sc * A.l + q) * 2 + 1] = dx * (-s0) + dy * c0;
+    const float vx = A.lane_vecs0[2 * q], vy = A.lane_vecs0[2 * q + 1];
+    A.lane_vecs[((size_t)sc * A.l + q) * 2] = vx * c0 + vy * s0;
+    A.lane_vecs[((size_t)sc * A.l + q) * 2 + 1] = vx * (-s0) + vy * c0;
+  }
+  // ---- high-level command: target-lane window ahead of the ego (scenario_tree.py:613-652)
+  {
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int q = tid; q < A.n_lane; q += RB_THREADS) {
+      const float dx = A.tlane[2 * q] - ox, dy = A.tlane[2 * q + 1] - oy;
+      const float d = sqrtf(dx * dx + dy * dy);
+      if (d < best) { best = d; bi = q; }            // strided scan keeps the lowest index per thread
+    }
+    rdv[tid] = best; rdi[tid] = bi;
+    __syncthreads();
+    for (int o = RB_THREADS / 2; o > 0; o >>= 1) {
+      if (tid < o) {
+        const float v2 = rdv[tid + o];
+        const int i2 = rdi[tid + o];
+        if (v2 < rdv[tid] || (v2 == rdv[tid] && i2 < rdi[tid])) { rdv[tid] = v2; rdi[tid] = i2; }   // np.argmin: first minimum
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      // ego speed in its own frame = |vel_n[0, 49]|
+      const float *f = rb_sm;
+      const float vx0 = vel[(RB_T - 1) * 2], vy0 = vel[(RB_T - 1) * 2 + 1];
+      const float vx1 = vx0 * c0 + vy0 * s0, vy1 = vx0 * (-s0) + vy0 * c0;
+      const float vnx = vx1 * f[3] + vy1 * f[4], vny = vx1 * (-f[4]) + vy1 * f[3];
+      const float cur_vel = sqrtf(vnx * vnx + vny * vny);
+      float travel = fmaxf(cur_vel, A.min_vel) * A.time_ahead;
+      int idx = rdi[0];
+      const int n = A.n_lane;
+      while (idx < n - 1 && travel > 0.f) {
+        ++idx;
+        const float sx = A.tlane[2 * idx] - A.tlane[2 * idx - 2], sy = A.tlane[2 * idx + 1] - A.tlane[2 * idx - 1];
+        travel = travel - sqrtf(sx * sx + sy * sy);
+      }
+      if (idx == n - 1) --idx;
+      idx = idx < 5 ? 5 : idx;
+      idx = idx > n - 6 ? n - 6 : idx;
+      s_idx = idx;
+      fr[5] = cur_vel;
+    }
+    __syncthreads();
+    const int idx = s_idx;
+    float *frm = A.frames + (size_t)sc * 28;
+    if (tid < 11) {
+      const int q = idx - 5 + tid;
+      const float px = A.tlane[2 * q], py = A.tlane[2 * q + 1];
+      frm[6 + 2 * tid] = px; frm[6 + 2 * tid + 1] = py;                 // TGT_PTS (world frame)
+      const float dx = px - ox, dy = py - oy;
+      ctr[tid][0] = dx * c0 + dy * s0;
+      ctr[tid][1] = dx * (-s0) + dy * c0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      frm[0] = c0; frm[1] = -s0; frm[2] = s0; frm[3] = c0; frm[4] = ox; frm[5] = oy;      // ROT (row-major), ORIG
+      float mx = 0.f, my = 0.f;
+      for (int q = 0; q < 11; ++q) { mx += ctr[q][0]; my += ctr[q][1]; }
+      mx = mx / 11.0f; my = my / 11.0f;
+      const float dvx = ctr[10][0] - ctr[0][0], dvy = ctr[10][1] - ctr[0][1];
+      const float nrm = sqrtf(dvx * dvx + dvy * dvy);
+      const float ax = dvx / nrm, ay = dvy / nrm;
+      float ln[11][2];
+      for (int q = 0; q < 11; ++q) {
+        const float x1 = ctr[q][0] - mx, y1 = ctr[q][1] - my;
+        ln[q][0] = x1 * ax + y1 * ay;           // (x, y) @ [[ax, -ay], [ay, ax]]
+        ln[q][1] = x1 * (-ay) + y1 * ax;
+      }
+      float *tn = A.tgt_nodes + (size_t)sc * 160;
+      for (int q = 0; q < 10; ++q) {
+        tn[q * 16 + 0] = (ln[q][0] + ln[q + 1][0]) / 2.0f;
+        tn[q * 16 + 1] = (ln[q][1] + ln[q + 1][1]) / 2.0f;
+        tn[q * 16 + 2] = ln[q + 1][0] - ln[q][0];
+        tn[q * 16 + 3] = ln[q + 1][1] - ln[q][1];
+        for (int k = 0; k < 12; ++k) tn[q * 16 + 4 + k] = A.tinfo[(size_t)(idx - 5 + q + 1) * 12 + k];
+      }
+      // TGT_RPE = get_rpe([anchor, ego], [anchor direction, ego direction]) flattened [5][i][j]
+      const float cxs[2] = {mx, rb_sm[0]}, cys[2] = {my, rb_sm[1]};
+      const float vxs[2] = {ax, rb_sm[3]}, vys[2] = {ay, rb_sm[4]};
+      float *tr = A.tgt_rpe + (size_t)sc * 20;
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+          const float dx = cxs[j] - cxs[i], dy = cys[j] - cys[i];
+          const float dist = sqrtf(dx * dx + dy * dy);
+          float c1, s1, c2, s2;
+          rb_cs(vxs[j], vys[j], vxs[i], vys[i], c1, s1);
+          rb_cs(vxs[j], vys[j], dx, dy, c2, s2);
+          tr[0 * 4 + i * 2 + j] = c1; tr[1 * 4 + i * 2 + j] = s1; tr[2 * 4 + i * 2 + j] = c2; tr[3 * 4 + i * 2 + j] = s2;
+          tr[4 * 4 + i * 2 + j] = dist * 2.0f / 100.0f;
+        }
+    }
+  }
+}

@@ -61,7 +61,7 @@ struct mind_ctx {
   DevBuf edge, x, ST, QK, part, tokpos, meta, jobs, actor_feat, lane_feat, tgt_feat, cmode, tgt_emb,
       rows, rpe_ptrs;
   // ilqr workspaces
-  DevBuf ilqr_dev, aime_dev;
+  DevBuf ilqr_dev, aime_dev, rebase_dev;
   // profiling
   bool profiling = false;
   int n_pair_launch = 0;
@@ -139,7 +139,7 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf *bufs[] = {&c->edge, &c->x, &c->ST, &c->QK, &c->part, &c->tokpos, &c->meta, &c->jobs, &c->actor_feat,
-                    &c->lane_feat, &c->tgt_feat, &c->cmode, &c->tgt_emb, &c->rows, &c->rpe_ptrs, &c->ilqr_dev, &c->aime_dev};
+                    &c->lane_feat, &c->tgt_feat, &c->cmode, &c->tgt_emb, &c->rows, &c->rpe_ptrs, &c->ilqr_dev, &c->aime_dev, &c->rebase_dev};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->wdev) (void)hipFree(c->wdev);
@@ -1086,6 +1086,46 @@ extern "C" int mind_aime_world(mind_ctx *c, const mind_world_in *in, const mind_
                      in->actor_ctrs, in->actor_vecs, (const float *)(base + bS + bI), out->world, out->topo, out->ego_end,
                      (const float *)(base + bS + bI + bC), n_lane);
   HIPCHK(c, hipGetLastError());
+  return MIND_OK;
+}
+
+extern "C" int mind_aime_rebase(mind_ctx *c, const mind_rebase_in *in, const mind_rebase_out *out) {
+  if (!c || !in || !out || in->n_scenes <= 0 || in->n_agents <= 0 || in->n_lanes < 0 || !in->pos || !in->ang || !in->vel || !in->types ||
+      (in->n_lanes > 0 && (!in->lane_ctrs || !in->lane_vecs)) || !in->target_lane || !in->target_lane_info || in->n_lane_pts < 12 ||
+      !out->actors || !out->actor_ctrs || !out->actor_vecs || (in->n_lanes > 0 && (!out->lane_ctrs || !out->lane_vecs)) ||
+      !out->tgt_nodes || !out->tgt_rpe || !out->frames)
+    return fail(c, MIND_EINVAL, "mind_aime_rebase: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const size_t S = in->n_scenes, a = in->n_agents, l = in->n_lanes, P = in->n_lane_pts;
+  // staging layout (floats): pos | ang | vel | types | pad | lane_ctrs | lane_vecs | tlane | tinfo
+  const size_t n_pos = S * a * 50 * 2, n_ang = S * a * 50, n_types = a * 50 * 7, n_pad = in->pad ? S * a * 50 : 0;
+  const size_t o_pos = 0, o_ang = o_pos + n_pos, o_vel = o_ang + n_ang, o_types = o_vel + n_pos, o_pad = o_types + n_types;
+  const size_t o_lc = o_pad + n_pad, o_lv = o_lc + 2 * l, o_tl = o_lv + 2 * l, o_ti = o_tl + 2 * P, total = o_ti + 12 * P;
+  int rc;
+  if ((rc = ensure(c, c->rebase_dev, total * sizeof(float)))) return rc;
+  float *d = (float *)c->rebase_dev.p;
+  HIPCHK(c, hipMemcpyAsync(d + o_pos, in->pos, n_pos * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d + o_ang, in->ang, n_ang * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d + o_vel, in->vel, n_pos * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d + o_types, in->types, n_types * sizeof(float), hipMemcpyHostToDevice, st));
+  if (in->pad) HIPCHK(c, hipMemcpyAsync(d + o_pad, in->pad, n_pad * sizeof(float), hipMemcpyHostToDevice, st));
+  if (l) {
+    HIPCHK(c, hipMemcpyAsync(d + o_lc, in->lane_ctrs, 2 * l * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d + o_lv, in->lane_vecs, 2 * l * sizeof(float), hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(c, hipMemcpyAsync(d + o_tl, in->target_lane, 2 * P * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d + o_ti, in->target_lane_info, 12 * P * sizeof(float), hipMemcpyHostToDevice, st));
+  RebaseArgs A;
+  A.a = (int)a; A.l = (int)l; A.n_lane = (int)P; A.pad_ones = in->pad ? 0 : 1;
+  A.pos = d + o_pos; A.ang = d + o_ang; A.vel = d + o_vel; A.types = d + o_types; A.pad = in->pad ? d + o_pad : nullptr;
+  A.lane_ctrs0 = d + o_lc; A.lane_vecs0 = d + o_lv; A.tlane = d + o_tl; A.tinfo = d + o_ti;
+  A.time_ahead = in->time_ahead; A.min_vel = in->min_vel;
+  A.actors = out->actors; A.actor_ctrs = out->actor_ctrs; A.actor_vecs = out->actor_vecs; A.lane_ctrs = out->lane_ctrs;
+  A.lane_vecs = out->lane_vecs; A.tgt_nodes = out->tgt_nodes; A.tgt_rpe = out->tgt_rpe; A.frames = out->frames;
+  hipLaunchKernelGGL(k_aime_rebase, dim3((unsigned)S), dim3(RB_THREADS), 5 * a * sizeof(float), st, A);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(st));     // the caller's host arrays may be reused after return
   return MIND_OK;
 }
 

@@ -312,6 +312,40 @@ class HipPredictor:
         _lib.check(self.lib, self.ctx, rc, "mind_aime_world")
         return out
 
+    def aime_rebase(self, pos, ang, vel, types, lane_ctrs, lane_vecs, target_lane, target_lane_info, pad=None,
+                    time_ahead=5.0, min_vel=0.5):
+        """update_obser for S child scenes on the device (mind_aime_rebase).  pos [S,a,50,2], ang [S,a,50], vel [S,a,50,2]
+        (world-frame windows), types [a,50,7], lane_ctrs / lane_vecs [l,2], target_lane [P,2], target_lane_info [P,12]: host
+        float32.  Returns device tensors actors [S*a,14,48], actor_ctrs, actor_vecs [S*a,2], lane_ctrs, lane_vecs [S*l,2],
+        tgt_nodes [S,10,16], tgt_rpe [S,20], frames [S,28] (ROT, ORIG, TGT_PTS)."""
+        dev = self.device
+        f = lambda x: np.ascontiguousarray(x, np.float32)
+        pos, ang, vel, types = f(pos), f(ang), f(vel), f(types)
+        lane_ctrs, lane_vecs, tl, ti = f(lane_ctrs), f(lane_vecs), f(target_lane), f(target_lane_info)
+        S, a = pos.shape[:2]
+        l = lane_ctrs.shape[0]
+        assert pos.shape == (S, a, 50, 2) and ang.shape == (S, a, 50) and vel.shape == (S, a, 50, 2) and types.shape == (a, 50, 7)
+        assert tl.ndim == 2 and ti.shape == (len(tl), 12)
+        ri, ro = _lib.RebaseIn(), _lib.RebaseOut()
+        fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+        ri.n_scenes, ri.n_agents, ri.n_lanes = S, a, l
+        ri.pos, ri.ang, ri.vel, ri.types = fp(pos), fp(ang), fp(vel), fp(types)
+        padk = None
+        if pad is not None:
+            padk = f(pad)
+            ri.pad = fp(padk)
+        ri.lane_ctrs, ri.lane_vecs, ri.target_lane, ri.target_lane_info, ri.n_lane_pts = fp(lane_ctrs), fp(lane_vecs), fp(tl), fp(ti), len(tl)
+        ri.time_ahead, ri.min_vel = float(time_ahead), float(min_vel)
+        out = dict(actors=torch.empty(S * a, 14, 48, device=dev), actor_ctrs=torch.empty(S * a, 2, device=dev),
+                   actor_vecs=torch.empty(S * a, 2, device=dev), lane_ctrs=torch.empty(S * l, 2, device=dev),
+                   lane_vecs=torch.empty(S * l, 2, device=dev), tgt_nodes=torch.empty(S, 10, 16, device=dev),
+                   tgt_rpe=torch.empty(S, 20, device=dev), frames=torch.empty(S, 28, device=dev))
+        for k in out:
+            setattr(ro, k, C.c_void_p(out[k].data_ptr()))
+        rc = self.lib.mind_aime_rebase(self.ctx, C.byref(ri), C.byref(ro))
+        _lib.check(self.lib, self.ctx, rc, "mind_aime_rebase")
+        return out
+
     def lane_dist_field(self, ego_xy, lane, W, H, res):
         """gen_dist_field (ilqr/utils.py:5-22) -> (offset [2], gx [W], gy [H], dist [H,W])."""
         ego = np.ascontiguousarray(np.asarray(ego_xy, np.float64)[:2])

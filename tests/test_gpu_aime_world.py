@@ -97,3 +97,51 @@ def test_device_prune_merge_equals_host_path_in_closed_loop():
     # the tree-iLQR runs tens of Levenberg-Marquardt iterations on these trees and amplifies input rounding;
     # the selected branch is the same and the control agrees to ~1e-2
     assert best_d == best_h and np.abs(ctrl_d - ctrl_h).max() < 5e-2
+
+
+def test_rebase_kernel_matches_host_update_obser(hip_predictor):
+    """mind_aime_rebase (update_obser on the device) against the host functions it replaces: normalisation into the AV /
+    agent frames, actor features, lane anchors, high-level command, target RPE.  float32 on both sides; coordinates
+    of hundreds of metres give ~1e-4 m of rounding in the first subtraction, everything downstream is O(1e-5)."""
+    from mind_amd.planners.mind.configs.planning._base import ScenTreeCfg
+    rng = np.random.default_rng(11)
+    S, a, l, P = 5, 9, 23, 180
+    lane_xy = np.stack([np.linspace(100.0, 100.0 + 1.0 * (P - 1), P), 300.0 + 6.0 * np.sin(np.linspace(0, 3, P))], 1).astype(F32)
+    info = rng.integers(0, 2, (P, 12)).astype(F32)
+    gen = STG(torch.device("cpu"), None, 50, 50, ScenTreeCfg())
+    gen.target_lane, gen.target_lane_info = lane_xy, info
+    t = np.arange(50, dtype=F32) * F32(0.1)
+    pos = np.zeros((S, a, 50, 2), F32)
+    ang = np.zeros((S, a, 50), F32)
+    vel = np.zeros((S, a, 50, 2), F32)
+    for s_ in range(S):
+        for i in range(a):
+            p0 = np.array([110.0 + 12.0 * s_ + rng.uniform(-15, 25), 300.0 + rng.uniform(-6, 6)])
+            h = rng.uniform(-0.4, 0.4) + 0.05 * s_
+            v = rng.uniform(0.0, 9.0) if i else 0.3 + 2.0 * s_          # scene 0: ego slower than min_vel
+            ang[s_, i] = h + 0.02 * np.sin(t + i)
+            vel[s_, i, :, 0], vel[s_, i, :, 1] = v * np.cos(ang[s_, i]), v * np.sin(ang[s_, i])
+            pos[s_, i] = p0 + np.cumsum(vel[s_, i] * 0.1, axis=0)
+    types = np.zeros((a, 50, 7), F32)
+    types[np.arange(a), :, np.arange(a) % 7] = 1.0
+    types[2, :7] = 0.0                                                # an agent first seen 7 steps in
+    lane_c = rng.uniform(-50, 150, (l, 2)).astype(F32)
+    th = rng.uniform(-np.pi, np.pi, l)
+    lane_v = np.stack([np.cos(th), np.sin(th)], -1).astype(F32)
+    o = hip_predictor.aime_rebase(pos, ang, vel, types, lane_c, lane_v, lane_xy, info)
+    got = {k: v.cpu().numpy() for k, v in o.items()}
+    orig, rot, theta, pos_n, ang_n, vel_n, ctrs, vecs = U.normalize_agents_batch(pos, ang, vel)
+    pad = np.ones(ang.shape, F32)
+    actors = U.actor_features_batch(pos_n, ang_n, vel_n, np.broadcast_to(types, (S,) + types.shape), pad)
+    cur_vel = np.sqrt((vel_n[:, 0, -1] * vel_n[:, 0, -1]).sum(-1), dtype=F32)
+    tgt_pts, tgt_nodes, tgt_ctr, tgt_vec = gen.high_level_command_batch(orig, rot, cur_vel)
+    tgt_rpe = U.get_rpe_batch(np.stack([tgt_ctr, ctrs[:, 0]], 1), np.stack([tgt_vec, vecs[:, 0]], 1)).reshape(S, -1)
+    assert np.array_equal(got["frames"][:, 4:6], orig) and np.abs(got["frames"][:, :4] - rot.reshape(S, 4)).max() < 1e-6
+    assert np.array_equal(got["frames"][:, 6:].reshape(S, 11, 2), tgt_pts)           # same lane window chosen
+    assert np.abs(got["actor_ctrs"].reshape(S, a, 2) - ctrs).max() < 2e-4 and np.abs(got["actor_vecs"].reshape(S, a, 2) - vecs).max() < 1e-6
+    assert np.abs(got["actors"].reshape(S, a, 14, 48) - actors).max() < 2e-4
+    assert np.array_equal(got["actors"].reshape(S, a, 14, 48)[:, :, 6:], actors[:, :, 6:])     # one-hot + pad rows exact
+    assert np.abs(got["lane_ctrs"].reshape(S, l, 2) - np.matmul(lane_c[None] - orig[:, None, :], rot)).max() < 2e-4
+    assert np.abs(got["lane_vecs"].reshape(S, l, 2) - np.matmul(lane_v[None], rot)).max() < 1e-6
+    assert np.abs(got["tgt_nodes"] - tgt_nodes).max() < 2e-4 and np.array_equal(got["tgt_nodes"][:, :, 4:], tgt_nodes[:, :, 4:])
+    assert np.abs(got["tgt_rpe"] - tgt_rpe).max() < 2e-5
