@@ -30,6 +30,26 @@ class ScenarioData:
         self.terminate_flag = terminate_flag
 
 
+class DevScene(dict):
+    """Observation of a branch node whose predictor inputs were built on the device (mind_aime_rebase): holds the host
+    fields the AIME bookkeeping reads (frames, world-frame history windows, ids) plus a handle on the device batch.
+    The host-side predictor inputs (ACTORS, LANE_CTRS, TGT_NODES, ...) are only materialised if somebody asks."""
+    _HOST_KEYS = ("TRAJS_POS_OBS", "TRAJS_ANG_OBS", "TRAJS_VEL_OBS", "PAD_OBS", "TRAJS_CTRS", "TRAJS_VECS", "ACTORS",
+                  "LANES", "LANE_CTRS", "LANE_VECS", "TGT_NODES", "TGT_RPE")
+
+    def __init__(self, gen, dev, g, fields):
+        super().__init__(fields)
+        self.gen, self.dev, self.g = gen, dev, g
+
+    def __missing__(self, key):
+        if key not in self._HOST_KEYS:
+            raise KeyError(key)
+        full = self.gen._host_obs(self["TRAJS_POS_HIST"], self["TRAJS_ANG_HIST"], self["TRAJS_VEL_HIST"], self["TRAJS_TYPE"])
+        for k in self._HOST_KEYS:
+            dict.__setitem__(self, k, full[k])
+        return dict.__getitem__(self, key)
+
+
 def _np(x):
     if isinstance(x, torch.Tensor):
         return x.detach().cpu().numpy()
@@ -132,7 +152,30 @@ class ScenarioTreeGenerator:
                             "scene_mask": None} for s in scenes]
         return data
 
+    def _device_batch(self, scenes):
+        """If the scenes are a contiguous run of one mind_aime_rebase batch, the predictor input dict built from
+        its device tensors (what ScenePredNet.pre_process would return); else None."""
+        s0 = scenes[0]
+        if not isinstance(s0, DevScene) or self.lane_feat_cache is None:
+            return None
+        dev, g0 = s0.dev, s0.g
+        if any((not isinstance(sc, DevScene)) or sc.dev is not dev or sc.g != g0 + i for i, sc in enumerate(scenes)):
+            return None
+        B, a, l = len(scenes), dev["a"], dev["l"]
+        if self.lane_feat_cache.shape[0] != l:
+            return None
+        cache = self.lane_feat_cache
+        return {"actors": dev["actors"][g0 * a:(g0 + B) * a], "a_off": [a * i for i in range(B + 1)],
+                "l_off": [l * i for i in range(B + 1)], "tgt_nodes": dev["tgt_nodes"][g0:g0 + B], "tgt_rpe": dev["tgt_rpe"][g0:g0 + B],
+                "lanes": None, "lane_feat": cache.repeat(B, 1) if B > 1 else cache, "rpe": None, "lane_shared": True,
+                "actor_ctrs": dev["actor_ctrs"][g0 * a:(g0 + B) * a], "actor_vecs": dev["actor_vecs"][g0 * a:(g0 + B) * a],
+                "lane_ctrs": dev["lane_ctrs"][g0 * l:(g0 + B) * l], "lane_vecs": dev["lane_vecs"][g0 * l:(g0 + B) * l]}
+
     def predict_scenes(self, scenes):
+        d = self._device_batch(scenes) if self.device_glue else None
+        if d is not None:          # inputs already on the device: no collate, no host->device copies
+            self.n_expanded += len(scenes)
+            return self.network(d)
         data = self.collate(scenes)
         self.n_expanded += len(scenes)
         out = self.network(self.network.pre_process(data))
@@ -503,7 +546,10 @@ class ScenarioTreeGenerator:
         """update_obser (scenario_tree.py:467-567) for all branching nodes of a round at once; nodes must share the
         agent set (they are children of one plan).  Returns [(obs_data, cur)] in order."""
         a_counts = {c["TRAJS_POS_HIST"].shape[0] for c in curs}
-        if len(curs) < 2 or len(a_counts) != 1:
+        rt = getattr(self.network, "rt", None) if self.device_glue else None
+        on_dev = (rt is not None and len(a_counts) == 1 and self.target_lane is not None and len(self.target_lane) >= 12
+                  and all(c["TRAJS_TYPE"] is curs[0]["TRAJS_TYPE"] for c in curs))
+        if not on_dev and (len(curs) < 2 or len(a_counts) != 1):
             return [self.update_obser(c) for c in curs]
         o = self.obs_len
         G = len(curs)
@@ -515,6 +561,20 @@ class ScenarioTreeGenerator:
                 wins.setdefault(k, []).append(c[k][:, -o:])
         pos, cov = np.stack(wins["TRAJS_POS_HIST"]), np.stack(wins["TRAJS_COV_HIST"])
         ang, vel = np.stack(wins["TRAJS_ANG_HIST"]), np.stack(wins["TRAJS_VEL_HIST"])
+        if on_dev:
+            # the whole re-basing arithmetic on the device; the next round's predictor reads its outputs in place
+            dev = rt.aime_rebase(pos, ang, vel, curs[0]["TRAJS_TYPE"], self.lane_graph["lane_ctrs"], self.lane_graph["lane_vecs"],
+                                 self.target_lane, self.target_lane_info, time_ahead=self.config.tar_time_ahead)
+            dev["a"], dev["l"] = pos.shape[1], self.lane_graph["lane_ctrs"].shape[0]
+            fr = dev["frames"].cpu().numpy()
+            out = []
+            for g, c in enumerate(curs):
+                out.append((DevScene(self, dev, g, {
+                    "ORIG": fr[g, 4:6].copy(), "ROT": fr[g, :4].reshape(2, 2).copy(), "TGT_PTS": fr[g, 6:].reshape(11, 2).copy(),
+                    "TRAJS_TYPE": c["TRAJS_TYPE"], "SCEN_PROB": c["SCEN_PROB"], "SCEN_ID": c["SCEN_ID"], "PARENT_ID": c["PARENT_ID"],
+                    "CUR_T": c["END_T"], "END_T": self.pred_len, "TRAJS_TID": c["TRAJS_TID"], "TRAJS_CAT": c["TRAJS_CAT"],
+                    "TRAJS_POS_HIST": pos[g], "TRAJS_COV_HIST": cov[g], "TRAJS_ANG_HIST": ang[g], "TRAJS_VEL_HIST": vel[g]}), c))
+            return out
         orig, rot, theta, pos_n, ang_n, vel_n, ctrs, vecs = U.normalize_agents_batch(pos, ang, vel)
         lane_ctrs = np.ascontiguousarray(np.matmul(self.lane_graph["lane_ctrs"][None] - orig[:, None, :], rot), F32)
         lane_vecs = np.ascontiguousarray(np.matmul(self.lane_graph["lane_vecs"][None], rot), F32)
@@ -535,6 +595,16 @@ class ScenarioTreeGenerator:
                  "TRAJS_POS_HIST": pos[g], "TRAJS_COV_HIST": cov[g], "TRAJS_ANG_HIST": ang[g], "TRAJS_VEL_HIST": vel[g]}
             out.append((s, c))
         return out
+
+    def _host_obs(self, pos, ang, vel, types):
+        """Host restatement of the predictor inputs of one re-based scene (what update_obser computes), for consumers
+        of a DevScene that want the arrays on the host."""
+        orig, rot, theta, pos_n, ang_n, vel_n, ctrs, vecs = U.normalize_agents(pos, ang, vel)
+        lane_ctrs = np.matmul(self.lane_graph["lane_ctrs"] - orig, rot)
+        lane_vecs = np.matmul(self.lane_graph["lane_vecs"], rot)
+        cur_vel = np.sqrt((vel_n[0, -1] * vel_n[0, -1]).sum(), dtype=F32)
+        pad = np.ones(ang.shape, F32)[:, :self.obs_len]
+        return self._scene_inputs(orig, rot, pos_n, ang_n, vel_n, types, pad, ctrs, vecs, cur_vel, lane_ctrs, lane_vecs)
 
     def update_obser(self, cur):
         end_t, cur_t = cur["END_T"], cur["CUR_T"]
