@@ -351,8 +351,8 @@ class ScenarioTreeGenerator:
         w = rt.aime_world(packed["reg"], packed["vel"], packed["actor_ctrs"], packed["actor_vecs"], a_off,
                           np.stack([sc["ROT"] for sc in scenes]), np.stack([sc["ORIG"] for sc in scenes]),
                           np.concatenate([sc["TRAJS_COV_HIST"][:, -1, 0] for sc in scenes]), [max(l, -1) for l in lasts],
-                          target_lane=self.target_lane)
-        small = torch.cat([packed["cls"].reshape(-1), w["topo"].reshape(-1), w["ego_end"].reshape(-1)]).cpu().numpy()
+                          target_lane=self.target_lane, cls=packed["cls"])
+        small = w["small"].cpu().numpy()            # [cls | topology signatures | ego end points], one copy
         cls_all = small[:B * 6].reshape(B, 6)
         topo = small[B * 6:B * 6 + A * 6].reshape(A, 6)
         ego_all = small[B * 6 + A * 6:].reshape(B, 6, 4)
@@ -371,10 +371,9 @@ class ScenarioTreeGenerator:
                 picks.append((lidx, k, prob))
         if not picks:
             return []
-        rows = np.concatenate([np.arange(a_off[l], a_off[l + 1]) for l, _, _ in picks])
-        ks = np.concatenate([np.full(a_off[l + 1] - a_off[l], k) for l, k, _ in picks])
+        flat = np.concatenate([np.arange(a_off[l], a_off[l + 1]) * 6 + k for l, k, _ in picks])       # (agent row, mode) -> row of [A*6]
         dev = w["world"].device
-        sel = w["world"][torch.from_numpy(rows).to(dev), torch.from_numpy(ks).to(dev)].cpu().numpy()   # [R,60,6]
+        sel = w["world"].view(A * 6, 60, 6).index_select(0, torch.from_numpy(flat).to(dev)).cpu().numpy()   # [R,60,6]
         kept, r0 = [], 0
         for lidx, k, prob in picks:
             sc = scenes[lidx]

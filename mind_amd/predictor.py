@@ -280,7 +280,7 @@ class HipPredictor:
         luu[:, 0, 0], luu[:, 1, 1] = out[:, 45], out[:, 46]
         return dict(l=out[:, 0].copy(), l_x=out[:, 1:7].copy(), l_u=out[:, 7:9].copy(), l_xx=out[:, 9:45].reshape(-1, 6, 6).copy(), l_uu=luu)
 
-    def aime_world(self, reg, vel, actor_ctrs, actor_vecs, a_off, rots, origs, cov_last, last, target_lane=None):
+    def aime_world(self, reg, vel, actor_ctrs, actor_vecs, a_off, rots, origs, cov_last, last, target_lane=None, cls=None):
         """k7 on the device (mind_aime_world): reg [A,6,60,5] / vel [A,6,60,2] / actor_ctrs, actor_vecs [A,2] device
         tensors; a_off [B+1]; rots [B,2,2], origs [B,2], cov_last [A] host float32; last [B] int.
         target_lane [P,2] float32 (optional).  Returns device tensors world [A,6,60,6] (x,y,vx,vy,heading,max-sigma),
@@ -305,8 +305,12 @@ class HipPredictor:
         if target_lane is not None:
             tl = np.ascontiguousarray(target_lane, np.float32).reshape(-1, 2)
             wi.target_lane, wi.n_lane_pts = fp(tl), len(tl)
-        out = dict(world=torch.empty(A, 6, 60, 6, device=dev), topo=torch.empty(A, 6, device=dev),
-                   ego_end=torch.zeros(B, 6, 4, device=dev))
+        # topo and ego_end live in one buffer behind a copy of cls, so that the host fetches all three with one copy
+        small = torch.zeros(B * 6 + A * 6 + B * 24, device=dev)
+        if cls is not None:
+            small[:B * 6] = cls.reshape(-1)
+        out = dict(world=torch.empty(A, 6, 60, 6, device=dev), small=small, topo=small[B * 6:B * 6 + A * 6].view(A, 6),
+                   ego_end=small[B * 6 + A * 6:].view(B, 6, 4))
         wo.world, wo.topo, wo.ego_end = (C.c_void_p(out[k].data_ptr()) for k in ("world", "topo", "ego_end"))
         rc = self.lib.mind_aime_world(self.ctx, C.byref(wi), C.byref(wo))
         _lib.check(self.lib, self.ctx, rc, "mind_aime_world")
