@@ -193,14 +193,15 @@ class MINDPlanner:
         counts = np.array([len(p[0]) for p in packs])
         starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
         lane = np.asarray(lcl_smp.target_lane)
-        s, e = lane[:-1], lane[1:]
-        d = e - s
-        l2 = (d ** 2).sum(-1)
+        # x / y kept as separate [nodes, segments] arrays (same arithmetic per element as the [.., 2] form, a
+        # fraction of the numpy overhead)
+        sx, sy = lane[:-1, 0][None], lane[:-1, 1][None]
+        dx, dy = lane[1:, 0][None] - sx, lane[1:, 1][None] - sy
+        l2 = dx ** 2 + dy ** 2
         assert np.all(l2 != 0.0), "Polyline segments should not have zero lengths."
-        rel = st[:, None, :2] - s[None]
-        t = np.clip((rel * d[None]).sum(-1) / l2[None], 0, 1)
-        near = s[None] + t[..., None] * d[None]
-        dist = np.sqrt(((st[:, None, :2] - near) ** 2).sum(-1)).min(axis=1)
+        px, py = st[:, 0][:, None], st[:, 1][:, None]
+        t = np.clip(((px - sx) * dx + (py - sy) * dy) / l2, 0, 1)
+        dist = np.sqrt((px - (sx + t * dx)) ** 2 + (py - (sy + t * dy)) ** 2).min(axis=1)
         per_node = (0.1 * ct[:, 0] ** 2 + 5.0 * ct[:, 1] ** 2) + 0.01 * (lcl_smp.target_velocity - st[:, 2]) ** 2 + 0.01 * dist
         return list(np.add.reduceat(per_node, starts) / counts)
 
