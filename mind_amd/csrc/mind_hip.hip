@@ -773,13 +773,13 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   struct TL { size_t nodew, field, relag; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel; int M, a, nl, nseg, nsl, maxls; };
   std::vector<TL> tl(n_trees);
   long Mtot = 0;
-  for (int t = 0; t < n_trees; ++t) {
-    const size_t M = trees[t].n_nodes > 0 ? trees[t].n_nodes : 0;
-    tl[t].us = takeD(2 * M);
-    tl[t].nodew = takeD(gen ? M * IL_NW : 0);
-  }
+  for (int t = 0; t < n_trees; ++t) tl[t].us = takeD(2 * (size_t)(trees[t].n_nodes > 0 ? trees[t].n_nodes : 0));
+  for (int t = 0; t < n_trees; ++t) tl[t].nodew = takeD(gen ? (size_t)(trees[t].n_nodes > 0 ? trees[t].n_nodes : 0) * IL_NW : 0);
   const size_t nd_in = nd;
   const size_t o_quad = takeD(gen ? 2 : (size_t)W * H), o_evo = takeD(ev ? (size_t)ev->nq * IL_EVAL_OUT : 0);
+  // results of all trees are contiguous (us already is: it lives in the upload region), so they come back in three copies
+  for (int t = 0; t < n_trees; ++t) tl[t].xs = takeD(6 * (size_t)(trees[t].n_nodes > 0 ? trees[t].n_nodes : 0));
+  for (int t = 0; t < n_trees; ++t) tl[t].stats = takeD(2 * IL_NSTAT);
   for (int t = 0; t < n_trees; ++t) {
     const mind_cost_tree &tr = trees[t];
     if (tr.n_nodes <= 0 || !tr.parent || (!gen && (!tr.prob || tr.n_agents <= 0)) || (use_exo && (!tr.agent_mean || !tr.agent_cov)))
@@ -789,9 +789,9 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     TL &L = tl[t];
     L.M = (int)M; L.a = gen ? 1 : tr.n_agents;
     L.relag = takeD(use_exo ? M * IL_RA : 0);
-    L.xs = takeD(6 * M); L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M);
+    L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M);
     L.Lxx = takeD(36 * M); L.k = takeD(IL_SPEC * 2 * M); L.K = takeD(IL_SPEC * 12 * M); L.Vx = takeD(IL_SPEC * 6 * M); L.Vxx = takeD(IL_SPEC * 36 * M);
-    L.xsn = takeD(IL_SPEC * 60 * M); L.usn = takeD(IL_SPEC * 20 * M); L.Ln = takeD(IL_SPEC * 10 * M); L.stats = takeD(2 * IL_NSTAT);
+    L.xsn = takeD(IL_SPEC * 60 * M); L.usn = takeD(IL_SPEC * 20 * M); L.Ln = takeD(IL_SPEC * 10 * M);
     L.prob = takeF(M); L.mean = takeF(M * L.a * 2); L.cov = takeF(M * L.a);
     L.parent = takeI(M); L.lnodes = takeI(M); L.cstart = takeI(M + 1); L.clist = takeI(M); L.rel = takeI(M);
     Mtot += (long)M;
@@ -982,15 +982,10 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     hipLaunchKernelGGL(k_ilqr<false>, dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases);
   }
   HIPCHK(c, hipGetLastError());
-  moff = 0;
   std::vector<double> hs((size_t)2 * IL_NSTAT * n_trees);
-  for (int t = 0; t < n_trees; ++t) {
-    const TL &L = tl[t];
-    HIPCHK(c, hipMemcpyAsync(xs + moff * 6, dD + L.xs, (size_t)L.M * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(us + moff * 2, dD + L.us, (size_t)L.M * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(hs.data() + (size_t)2 * IL_NSTAT * t, dD + L.stats, (size_t)n_phases * IL_NSTAT * sizeof(double), hipMemcpyDeviceToHost, st));
-    moff += L.M;
-  }
+  HIPCHK(c, hipMemcpyAsync(xs, dD + tl[0].xs, (size_t)Mtot * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(us, dD + tl[0].us, (size_t)Mtot * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(hs.data(), dD + tl[0].stats, hs.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   for (int ph = 0; ph < n_phases; ++ph) {
     mind_ilqr_stats *so = ph == 0 ? stats : stats2;
