@@ -145,3 +145,25 @@ def test_rebase_kernel_matches_host_update_obser(hip_predictor):
     assert np.abs(got["lane_vecs"].reshape(S, l, 2) - np.matmul(lane_v[None], rot)).max() < 1e-6
     assert np.abs(got["tgt_nodes"] - tgt_nodes).max() < 2e-4 and np.array_equal(got["tgt_nodes"][:, :, 4:], tgt_nodes[:, :, 4:])
     assert np.abs(got["tgt_rpe"] - tgt_rpe).max() < 2e-5
+
+
+def test_devscene_lazily_materialises_host_inputs():
+    """A branch node re-based on the device still answers for the host-side predictor inputs (ACTORS, LANE_CTRS,
+    TGT_NODES, ...): they are computed on demand by the host restatement and agree with what the device wrote."""
+    sys.path.insert(0, ROOT)
+    from bench import WORKLOADS, make_closed_loop
+    from mind_amd.planners.mind.scenario_tree import DevScene
+    pl, sim, w = make_closed_loop(dict(WORKLOADS["demo1"]))
+    sim.run_plans(1)
+    gen = pl.scen_tree_gen
+    devs = [n.data.obs_data for n in gen.tree.nodes.values() if isinstance(n.data.obs_data, DevScene)]
+    assert devs, "no node was re-based on the device"
+    sc = devs[0]
+    assert "ACTORS" not in dict.keys(sc)
+    a, l = sc.dev["a"], sc.dev["l"]
+    got = sc.dev["actors"][sc.g * a:(sc.g + 1) * a].cpu().numpy()
+    assert np.abs(sc["ACTORS"] - got).max() < 2e-4 and "TGT_NODES" in dict.keys(sc)
+    assert np.abs(sc["LANE_CTRS"] - sc.dev["lane_ctrs"][sc.g * l:(sc.g + 1) * l].cpu().numpy()).max() < 2e-4
+    assert np.abs(sc["TGT_RPE"] - sc.dev["tgt_rpe"][sc.g].cpu().numpy()).max() < 2e-5
+    batch = gen.collate([sc])                                  # the host collate path accepts the scene
+    assert batch["ACTORS"].shape == (a, 14, 48) and batch["TGT_NODES"].shape == (1, 10, 16)
