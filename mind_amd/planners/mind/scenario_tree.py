@@ -547,7 +547,7 @@ class ScenarioTreeGenerator:
         a_counts = {c["TRAJS_POS_HIST"].shape[0] for c in curs}
         rt = getattr(self.network, "rt", None) if self.device_glue else None
         on_dev = (rt is not None and len(a_counts) == 1 and self.target_lane is not None and len(self.target_lane) >= 12
-                  and all(c["TRAJS_TYPE"] is curs[0]["TRAJS_TYPE"] for c in curs))
+                  and all(c["TRAJS_TYPE"] is curs[0]["TRAJS_TYPE"] or np.array_equal(c["TRAJS_TYPE"], curs[0]["TRAJS_TYPE"]) for c in curs))
         if not on_dev and (len(curs) < 2 or len(a_counts) != 1):
             return [self.update_obser(c) for c in curs]
         o = self.obs_len
