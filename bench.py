@@ -26,6 +26,8 @@ WORKLOADS = {
     "cfg4": dict(n_agents=64, n_lanes=8, n_segs=32, seed=4),
     # cfg4 with the full scripted 6-ary depth-4 AIME tree (259 expansions / plan; BASELINE config 4)
     "cfg4tree": dict(n_agents=64, n_lanes=8, n_segs=32, seed=4),
+    # the reference's four recorded AV2 demo scenes (compact fixtures derived from data/<seq_id>/, tests/golden/scenes)
+    "demo_1": dict(scene="demo_1"), "demo_2": dict(scene="demo_2"), "demo_3": dict(scene="demo_3"), "demo_4": dict(scene="demo_4"),
 }
 F_MIN_N2 = 754944.0   # minimal-algorithm FLOPs per expansion, N^2 coefficient (6 layers)
 PEAK_F32_MFMA = 157.3e12
@@ -53,12 +55,17 @@ def make_closed_loop(wkw, scripted=True, full_tree=False):
     from mind_amd.planners.mind.planner import MINDPlanner
     from mind_amd.synth import ScriptedBranching, ScriptedFullTree, SynthWorld
     cfg = os.path.join(ROOT, "mind_amd", "planners", "mind", "configs", "synthetic.json")
-    w = SynthWorld(**wkw)
+    if "scene" in wkw:
+        from mind_amd.scene_io import ReplayWorld, scene_fixture_path
+        w = ReplayWorld.from_scene_file(scene_fixture_path(wkw["scene"]))
+        cfg = dict(json.load(open(cfg)), planning_config="planners.mind.configs.planning." + wkw["scene"])
+    else:
+        w = SynthWorld(**wkw)
     pl = MINDPlanner(cfg)
     if scripted:
         pl.scen_tree_gen.network = (ScriptedFullTree if full_tree else ScriptedBranching)(pl.network)
     sim = ClosedLoopSim(w, pl)
-    sim.run_until(4.0)
+    sim.run_until(sim.enable_time)
     return pl, sim, w
 
 
@@ -218,8 +225,9 @@ def main():
     if args.concurrent > 1:
         return run_concurrent_processes(args) if args.processes else run_concurrent(args)
     wkw = dict(WORKLOADS[args.workload])
-    if not args.shard:
+    if not args.shard and "seed" in wkw:
         wkw["seed"] = wkw["seed"] + rank      # every rank plans its own scene (weak scaling)
+    real_scene = "scene" in wkw
     pl, sim, w = make_closed_loop(wkw, full_tree=args.workload == "cfg4tree")
     if args.shard and dist is not None:
         pl.enable_sharding()
@@ -309,9 +317,12 @@ def main():
         "metric": "sim steps/sec (whole node) + scenario-tree nodes expanded/sec, AV2 demo scenes",
         "value": value, "unit": "sim steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.shard else "weak", "vs_baseline": None,
-        "dtype": "f32 predictor / f64 iLQR", "data": "synthetic",
+        "dtype": "f32 predictor / f64 iLQR",
+        "data": ("recorded AV2 scene (map + tracks of the reference's %s, tests/golden/scenes) with synthetic formula-initialised "
+                 "weights" % args.workload) if real_scene else "synthetic",
         "nodes_expanded_per_s": expansions_all / dt,
-        "config": {"workload": f"{args.workload}-like synthetic scene: {a} agents x {l} lane polylines (N={a+l+1} tokens), "
+        "config": {"workload": (f"recorded scene {args.workload}" if real_scene else f"{args.workload}-like synthetic scene") +
+                               f": {a} agents x {l} lane polylines (N={a+l+1} tokens), "
                                f"one closed-loop planning cycle per step = AIME tree ({expansions // args.steps} node expansions, "
                                f"scripted mode branching on top of the real predictor forward: no trained checkpoint exists) + "
                                f"tree-iLQR warm+full solves of {pl.timing['n_scen_trees']} scenario trees; closed loop: {sim_steps} simulator steps "

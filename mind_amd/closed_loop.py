@@ -7,7 +7,9 @@ check_enable (agent.py:255-286; planner at 10 Hz with plan_step = 0.1 - 1e-4, en
 MINDAgent.plan / update_observation (agent.py:324-331) and the ego plant kine_propagate
 (common/kinematics.py:22-36 with the simulator's wheelbase 3.0, max speed 15 m/s, max steer 45 deg;
 agent.py:298-299 -- the planner itself uses wheelbase 2.5, Q16).
-Exo agents replay the synthetic world's trajectories (the reference replays recorded AV2 tracks).
+Exo agents replay the world's trajectories: a SynthWorld's formula tracks or a scene_io.ReplayWorld's recorded
+AV2 tracks (then only agents observed at the current step are reported, simulator.py:60-63, and the planner
+gets the 4 m-spaced target lane of MINDAgent.update_target_lane, agent.py:320-322).
 """
 from types import SimpleNamespace
 
@@ -29,10 +31,10 @@ class ClosedLoopSim:
     PLAN_STEP = 1.0 / 10 - 1e-4
     WB, MAX_SPD, MAX_STR = 3.0, 15.0, np.deg2rad(45.0)
 
-    def __init__(self, world, planner, enable_time=4.0):
+    def __init__(self, world, planner, enable_time=None):
         self.world = world
         self.planner = planner
-        self.enable_time = enable_time
+        self.enable_time = enable_time if enable_time is not None else getattr(world, "enable_time", 4.0)
         self.sim_time = 0.0
         self.n_steps = 0
         self.n_plans = 0
@@ -42,7 +44,9 @@ class ClosedLoopSim:
         self.ctrl = np.array([0.0, 0.0])
         self.timestep = 0.0
         self.last_result = None
-        planner.update_target_lane(np.asarray(world.target_lane[::2], dtype=np.float64))
+        gt_lane = getattr(world, "gt_tgt_lane", None)
+        planner.update_target_lane(np.asarray(world.target_lane[::2], dtype=np.float64) if gt_lane is None else gt_lane)
+        self._valid = getattr(world, "is_valid", None)
 
     def _observation(self):
         t = self.sim_time
@@ -50,7 +54,8 @@ class ClosedLoopSim:
         ego_state = self.state if self.enabled else w.agent_state(0, t)
         ego = SimpleNamespace(state=ego_state, type=w.object_type(0), id="AV", timestep=int(round(t / 0.1)))
         exo = [SimpleNamespace(state=w.agent_state(i, t), type=w.object_type(i), id=w.agent_ids[i],
-                               timestep=int(round(t / 0.1))) for i in range(1, w.n_agents)]
+                               timestep=int(round(t / 0.1))) for i in range(1, w.n_agents)
+               if self._valid is None or self._valid(i, t)]
         return SimpleNamespace(ego_agent=ego, exo_agents=exo, map_data=w, target_lane=w.target_lane,
                                target_lane_info=w.target_lane_info, target_velocity=w.target_velocity)
 

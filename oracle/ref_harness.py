@@ -182,8 +182,16 @@ def install():
     ls.LaneMarkType = LaneMarkType
     mapi = _mod("av2.map.map_api")
 
-    class ArgoverseStaticMap:
-        pass
+    # map / scenario file readers: av2 itself is absent, so the reference's scene I/O (common/semantic_map.py,
+    # loader.py, agent.py) runs on top of mind_amd.av2_lite's restatement of the two av2 readers, with the enum
+    # classes above injected.  This pins the reference's OWN logic on the demo scenes; the av2 layer underneath
+    # stays unpinned (see mind_amd/av2_lite.py).
+    from mind_amd import av2_lite
+
+    class ArgoverseStaticMap(av2_lite.StaticMap):
+        @classmethod
+        def from_json(cls, path):
+            return super().from_json(path, lane_type_cls=LaneType, lane_mark_cls=LaneMarkType)
 
     mapi.ArgoverseStaticMap = ArgoverseStaticMap
     ds = _mod("av2.datasets")
@@ -194,6 +202,8 @@ def install():
     sch.ObjectState = ObjectState
     sch.Track = Track
     ser = _mod("av2.datasets.motion_forecasting.scenario_serialization")
+    ser.load_argoverse_scenario_parquet = lambda path: av2_lite.load_argoverse_scenario_parquet(
+        path, object_type_cls=ObjectType, category_cls=TrackCategory)
     av2.map = av2map
     av2map.lane_segment = ls
     av2map.map_api = mapi

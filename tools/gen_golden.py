@@ -2,7 +2,7 @@
 
 The reference Python cannot travel to the GPU box; these small fixtures (inputs are formula
 generated, so only expected outputs are stored) can.  Re-run:  python tools/gen_golden.py [section ...]
-Sections: predictor rpe potential ilqr aime plan
+Sections: predictor rpe potential ilqr aime plan scenes demo_plans
 """
 import os
 import sys
@@ -230,7 +230,126 @@ def gen_plan():
     np.savez_compressed(os.path.join(GOLD, "plan.npz"), **out)
 
 
-SECTIONS = {"predictor": gen_predictor, "ilqr": gen_ilqr, "potential": gen_potential, "aime": gen_aime, "plan": gen_plan}
+def gen_scenes():
+    """G8: the four recorded demo scenes.
+    (1) tests/golden/scenes/demo_N.npz: compact array form of the scene (lane segments + 10 Hz tracks + the
+        closed-loop agent entry of configs/demo_N.json), derived with mind_amd.av2_lite from data/<seq_id>/.
+    (2) tests/golden/scene_io.npz: what the reference's own scene I/O (SemanticMap, ArgoAgentLoader,
+        MINDAgent target lane) produces on those scenes, running on top of the av2_lite readers."""
+    import importlib
+    import json
+    from mind_amd import av2_lite
+    from mind_amd.scene_io import DEMO_SCENES
+    rh.install()
+    SemanticMap = importlib.import_module("common.semantic_map").SemanticMap
+    Loader = importlib.import_module("loader").ArgoAgentLoader
+    agent_mod = importlib.import_module("agent")
+    geom = importlib.import_module("common.geometry")
+    os.makedirs(os.path.join(GOLD, "scenes"), exist_ok=True)
+    out = {}
+    for name, seq in DEMO_SCENES.items():
+        d = os.path.join(rh.REF_ROOT, "data", seq)
+        mp, sp = os.path.join(d, f"log_map_archive_{seq}.json"), os.path.join(d, f"scenario_{seq}.parquet")
+        cfg = json.load(open(os.path.join(rh.REF_ROOT, "configs", name + ".json")))
+        cl = {k: cfg["cl_agents"][0][k] for k in ("id", "enable_timestep", "semantic_lane", "target_velocity")}
+        av2_lite.save_scene(os.path.join(GOLD, "scenes", name + ".npz"), av2_lite.StaticMap.from_json(mp),
+                            av2_lite.load_argoverse_scenario_parquet(sp), meta=dict(cl_agent=json.dumps(cl), seq_id=seq))
+        from pathlib import Path
+        smp = SemanticMap()
+        smp.load_from_argo2(Path(mp))
+        out[name + "_n_sem"] = np.array(len(smp.semantic_lanes))
+        out[name + "_sem_len"] = np.array([len(v) for v in smp.semantic_lanes.values()])
+        out[name + "_sem_pts"] = np.concatenate(list(smp.semantic_lanes.values()))
+        for c, nm in enumerate(("intersect", "lane_type", "cross_left", "cross_right", "left", "right")):
+            out[f"{name}_sem_{nm}"] = np.concatenate([v[c] for v in smp.semantic_lanes_infos.values()]).astype(np.int8)
+        out[name + "_limits"] = np.array(smp.limits)
+        pos, ang, vel, types, tids, cats, flags = Loader(Path(sp)).get_trajs_info(smp)
+        out[name + "_tids"] = np.array(tids)
+        out[name + "_cats"] = np.array(cats)
+        out[name + "_types"] = np.array([t[0].name for t in types])
+        out[name + "_shape"] = np.array(pos.shape)
+        out[name + "_pos7"], out[name + "_ang7"], out[name + "_vel7"] = pos[:, ::7], ang[:, ::7], vel[:, ::7]
+        out[name + "_flags"] = np.packbits(flags.astype(bool), axis=1)
+        out[name + "_sums"] = np.array([pos.astype(np.float64).sum(), ang.astype(np.float64).sum(),
+                                        vel.astype(np.float64).sum(), flags.sum()])
+        k = tids.index("AV")
+        lane_id = None if cl["semantic_lane"] == -1 else cl["semantic_lane"]
+        tv = None if cl["target_velocity"] == -1 else cl["target_velocity"]
+        ag = agent_mod.MINDAgent()
+        ag.init("AV", types[k], cats[k], [pos[k], ang[k], vel[k], flags[k]], smp, None, semantic_lane_id=lane_id,
+                target_velocity=tv)
+        out[name + "_closest_lane"] = np.array(-1 if (c := ag.get_closest_semantic_lane(smp, pos[k], ang[k])) is None else c)
+        out[name + "_target_lane"] = np.asarray(ag.lcl_smp.target_lane)
+        out[name + "_target_velocity"] = np.array(float(ag.lcl_smp.target_velocity))
+        gt, _ = ag.get_target_lane(smp, True, lane_id)
+        out[name + "_gt_tgt_lane"] = geom.remove_close_points(gt, 4.0)
+        print(name, "sem lanes", len(smp.semantic_lanes), "tracks kept", len(tids), "of",
+              len(av2_lite.load_argoverse_scenario_parquet(sp).tracks), "closest lane", out[name + "_closest_lane"],
+              "gt lane pts", len(out[name + "_gt_tgt_lane"]))
+    np.savez_compressed(os.path.join(GOLD, "scene_io.npz"), **out)
+
+
+def gen_demo_plans(n_plans=4):
+    """G9: the reference's OWN closed loop (Simulator.run_sim, headless) on its four recorded demo scenes up to the
+    first `n_plans` planning cycles (t = 4.0 s, 4.1 s, ...), with the formula weights (the trained checkpoint is not in the
+    reference tree): control, chosen scenario/trajectory trees and the ego state after each cycle."""
+    import importlib
+    import json
+    import tempfile
+    from mind_amd.scene_io import DEMO_SCENES
+    rh.install()
+    os.chdir(rh.REF_ROOT)                       # the simulator opens 'data/<seq_id>/...' relative to its cwd (read only)
+    import types
+    vis = types.ModuleType("common.visualization")     # rendering (matplotlib + shapely polygons) is never reached headless
+    for fn in ("draw_map", "draw_agent", "draw_scen_trees", "reset_ax", "draw_traj_trees", "draw_traj"):
+        setattr(vis, fn, None)
+    sys.modules["common.visualization"] = vis
+    Simulator = importlib.import_module("simulator").Simulator
+    tmp = tempfile.mkdtemp()
+    ck = os.path.join(tmp, "formula.tar")
+    torch.save({"state_dict": formula_state_dict(as_torch=True)}, ck)
+    out = {}
+    for name in DEMO_SCENES:
+        cfg = json.load(open(os.path.join(rh.REF_ROOT, "configs", name + ".json")))
+        pcfg = json.load(open(os.path.join(rh.REF_ROOT, cfg["cl_agents"][0]["planner_config"])))
+        pcfg.update(use_cuda=False, ckpt_path=ck)
+        pp = os.path.join(tmp, name + "_planner.json")
+        json.dump(pcfg, open(pp, "w"))
+        cfg["cl_agents"][0]["planner_config"] = pp
+        cfg.update(render=False, output_dir=tmp)
+        cp = os.path.join(tmp, name + ".json")
+        json.dump(cfg, open(cp, "w"))
+        sim = Simulator(cp)
+        sim.init_sim()
+        sim.sim_horizon = 201 + 5 * (n_plans - 1)
+        sim.run_sim()
+        ego = [a for a in sim.agents if a.id == "AV"][0]
+        planned = [i for i, f in enumerate(sim.frames) if "scen_tree" in f]
+        assert len(planned) == n_plans, planned
+        out[name + "_plan_steps"] = np.array(planned)
+        out[name + "_final_state"] = np.array(ego.state, np.float64)
+        out[name + "_final_ctrl"] = np.array(ego.ctrl, np.float64)
+        out[name + "_n_tracked"] = np.array(len(ego.planner.agent_obs))
+        for pi, fi in enumerate(planned):
+            st, tt = sim.frames[fi]["scen_tree"][0], sim.frames[fi]["traj_tree"][0]
+            keys = list(st.nodes.keys())
+            out[f"{name}_p{pi}_scen_keys"] = np.array(keys)
+            out[f"{name}_p{pi}_scen_probs"] = np.array([float(np.ravel(st.nodes[k].data[0])[0]) for k in keys])
+            for k in keys:
+                out[f"{name}_p{pi}_scen_{k}_pos"] = st.nodes[k].data[1][:, ::5]
+                out[f"{name}_p{pi}_scen_{k}_cov"] = st.nodes[k].data[2][:, ::5]
+            tk = [k for k in tt.nodes.keys() if k != -1]
+            out[f"{name}_p{pi}_traj_xs"] = np.array([tt.nodes[k].data[0] for k in tk])
+            out[f"{name}_p{pi}_traj_us"] = np.array([tt.nodes[k].data[1] for k in tk])
+            out[f"{name}_p{pi}_traj_parent"] = np.array([tt.nodes[k].parent_key for k in tk])
+            out[f"{name}_p{pi}_n_scen_trees"] = np.array(len(sim.frames[fi]["scen_tree"]))
+            print(name, "plan", pi, "step", fi, "scen keys", keys, "traj nodes", len(tk), "agents",
+                  st.nodes[keys[0]].data[1].shape[0])
+        print(name, "final state", ego.state, "ctrl", ego.ctrl)
+    np.savez_compressed(os.path.join(GOLD, "demo_plans.npz"), **out)
+
+
+SECTIONS = {"demo_plans": gen_demo_plans, "scenes": gen_scenes, "predictor": gen_predictor, "ilqr": gen_ilqr, "potential": gen_potential, "aime": gen_aime, "plan": gen_plan}
 
 if __name__ == "__main__":
     torch.manual_seed(0)
