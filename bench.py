@@ -28,7 +28,28 @@ WORKLOADS = {
     "cfg4tree": dict(n_agents=64, n_lanes=8, n_segs=32, seed=4),
     # the reference's four recorded AV2 demo scenes (compact fixtures derived from data/<seq_id>/, tests/golden/scenes)
     "demo_1": dict(scene="demo_1"), "demo_2": dict(scene="demo_2"), "demo_3": dict(scene="demo_3"), "demo_4": dict(scene="demo_4"),
+    # BASELINE config 3: demo_{1,2,3,4} concurrently on one GPU (use with --concurrent P: scene i plans demo_(i mod 4 + 1))
+    "demo_all": dict(scene="demo_1"),
 }
+
+
+def scene_workload(workload, i):
+    """workload of the i-th concurrent scene: its own seed for the synthetic worlds, round-robin over the four recorded scenes
+    for demo_all."""
+    if workload == "demo_all":
+        return dict(scene="demo_%d" % (i % 4 + 1))
+    wkw = dict(WORKLOADS[workload])
+    if "seed" in wkw:
+        wkw["seed"] = wkw["seed"] + i
+    return wkw
+
+
+def _concurrent_label(workload, P):
+    if workload == "demo_all":
+        return f"the recorded scenes demo_1..4 ({P} closed loops, scene i = demo_(i mod 4 + 1))", "recorded AV2 scenes, formula-initialised weights"
+    if "scene" in WORKLOADS[workload]:
+        return f"{P} closed loops on the recorded scene {workload}", "recorded AV2 scene, formula-initialised weights"
+    return f"{P} {workload}-like synthetic scenes", "synthetic"
 F_MIN_N2 = 754944.0   # SURVEY 8(d): minimal-algorithm FLOPs per expansion, N^2 coefficient (6 layers)
 PEAK_F32_MFMA = 157.3e12
 
@@ -130,9 +151,7 @@ def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees):
 def _proc_scene(i, workload, steps, warmup, ready, go, q):
     """One scene in its own process (own HIP context): signals ready, waits for the common start, reports back."""
     import torch as th
-    wkw = dict(WORKLOADS[workload])
-    wkw["seed"] = wkw["seed"] + i
-    pl, sim, w = make_closed_loop(wkw, full_tree=workload == "cfg4tree")
+    pl, sim, w = make_closed_loop(scene_workload(workload, i), full_tree=workload == "cfg4tree")
     sim.run_plans(max(warmup, 1))
     th.cuda.synchronize()
     ready.wait()
@@ -162,8 +181,8 @@ def run_concurrent_processes(args):
         "metric": "sim steps/sec (whole node) + scenario-tree nodes expanded/sec, AV2 demo scenes",
         "value": steps / dt, "unit": "sim steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 predictor / f64 iLQR", "data": "synthetic",
-        "config": {"workload": f"{P} {args.workload}-like synthetic scenes planned concurrently on one GPU (one host process + HIP "
+        "dtype": "f32 predictor / f64 iLQR", "data": _concurrent_label(args.workload, P)[1],
+        "config": {"workload": f"{_concurrent_label(args.workload, P)[0]} planned concurrently on one GPU (one host process + HIP "
                                f"context per scene), {args.steps} planning cycles each", "concurrent_scenes": P,
                    "sim_steps_timed": steps},
         "ms_per_plan_aggregate": dt / (args.steps * P) * 1e3}))
@@ -181,9 +200,7 @@ def run_concurrent(args):
     def worker(i):
         try:
             with torch.cuda.stream(torch.cuda.Stream()):
-                wkw = dict(WORKLOADS[args.workload])
-                wkw["seed"] = wkw["seed"] + i
-                pl, sim, w = make_closed_loop(wkw, full_tree=args.workload == "cfg4tree")
+                pl, sim, w = make_closed_loop(scene_workload(args.workload, i), full_tree=args.workload == "cfg4tree")
                 sim.run_plans(max(args.warmup, 1))
                 torch.cuda.current_stream().synchronize()
                 loops[i] = (pl, sim)
@@ -215,8 +232,8 @@ def run_concurrent(args):
         "metric": "sim steps/sec (whole node) + scenario-tree nodes expanded/sec, AV2 demo scenes",
         "value": steps / dt, "unit": "sim steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 predictor / f64 iLQR", "data": "synthetic",
-        "config": {"workload": f"{P} {args.workload}-like synthetic scenes planned concurrently on one GPU (one host thread + HIP "
+        "dtype": "f32 predictor / f64 iLQR", "data": _concurrent_label(args.workload, P)[1],
+        "config": {"workload": f"{_concurrent_label(args.workload, P)[0]} planned concurrently on one GPU (one host thread + HIP "
                                f"context + stream per scene), {args.steps} planning cycles each", "concurrent_scenes": P,
                    "sim_steps_timed": steps},
         "ms_per_plan_aggregate": dt / (args.steps * P) * 1e3}))
