@@ -110,6 +110,18 @@ def recorded_scenes(plans=20, warmup=3):
         out[name] = {"sim_steps_per_s": steps / dt, "ms_per_plan": dt / plans * 1e3, "agents": len(pl.agent_obs),
                      "lane_polylines": int(pl.scen_tree_gen.lane_feat_in.shape[0]),
                      "expansions_per_plan": (pl.scen_tree_gen.n_expanded - n0) / plans}
+        if name == "demo_1":
+            # BASELINE configs[0]/[1]: the whole demo_1 closed loop = 500 simulator steps (10 s), 60 planning cycles
+            from mind_amd.closed_loop import ClosedLoopSim
+            from mind_amd.planners.mind.planner import MINDPlanner
+            sim = ClosedLoopSim(w, MINDPlanner(pl.planner_cfg))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(500):
+                sim.step()
+            torch.cuda.synchronize()
+            out[name]["whole_run_500_steps_s"] = time.perf_counter() - t0
+            out[name]["whole_run_plans"] = sim.n_plans
     out["note"] = ("recorded map + tracks, formula-initialised weights (the trained checkpoint is not in the reference tree); parity of "
                    "this loop against the reference's own simulator: tests/test_gpu_plan.py::test_recorded_demo_scenes_match_reference_closed_loop")
     return out

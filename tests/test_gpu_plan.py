@@ -156,3 +156,47 @@ def test_recorded_demo_scenes_match_reference_closed_loop(scene):
     assert len(pl.agent_obs) == int(D[scene + "_n_tracked"])
     assert np.abs(np.asarray(sim.ctrl) - D[scene + "_final_ctrl"]).max() < 2e-3
     assert np.abs(sim.state - D[scene + "_final_state"]).max() < tol
+
+
+@pytest.mark.parametrize("scene", ["demo_1", "demo_2", "demo_3", "demo_4"])
+def test_recorded_demo_scenes_whole_run_teacher_forced(scene):
+    """Every planning cycle of the reference's whole closed loop on the recorded scenes (t = 4.0 .. 9.9 s, 60 cycles,
+    tools/gen_golden.py demo_runs), teacher-forced: before each cycle the ego state / control are set to the ones the
+    reference planned from (free-running loops drift apart once a discrete branch decision flips), then branch ids,
+    tracked agents, probabilities, agent / ego trajectories and the control are compared cycle by cycle."""
+    sys.path.insert(0, ROOT)
+    from bench import WORKLOADS, make_closed_loop
+    D = np.load(os.path.join(ROOT, "tests", "golden", "demo_runs.npz"))
+    pl, sim, w = make_closed_loop(dict(WORKLOADS[scene]), scripted=False)
+    ulp = float(np.spacing(np.float32(np.abs(w.pos[0, 0]).max())))
+    tol = 1e-3 + 2 * ulp
+    state_in, ctrl_in, ctrl_out = D[scene + "_state_in"], D[scene + "_ctrl_in"], D[scene + "_ctrl_out"]
+    keys, n_agents, xs_all = D[scene + "_scen_keys"], D[scene + "_n_agents"], D[scene + "_traj_xs"]
+    n = len(state_in)
+    assert n == 60
+    worst = dict(ctrl=0.0, ego=0.0, agents=0.0)
+    for pi in range(n):
+        while True:
+            will_plan = sim.sim_time >= sim.enable_time and (sim.last_trigger is None or
+                                                             sim.sim_time - sim.last_trigger >= sim.PLAN_STEP)
+            if will_plan and pi > 0:
+                sim.state, sim.ctrl = state_in[pi].copy(), ctrl_in[pi].copy()
+            planned = sim.step()
+            if planned:
+                break
+        if pi == 0:
+            assert np.array_equal(pl.state, state_in[0])                      # the recording itself: identical by construction
+        st, tt = sim.last_result[0][0], sim.last_result[1][0]
+        assert len(sim.last_result[0]) == int(D[scene + "_n_scen_trees"][pi]), pi
+        assert "|".join(st.nodes.keys()) == str(keys[pi]), (pi, list(st.nodes.keys()), keys[pi])
+        root = next(iter(st.nodes.values())).data
+        assert root[1].shape[0] == int(n_agents[pi]), pi
+        assert abs(float(np.ravel(root[0])[0]) - float(D[scene + "_root_prob"][pi])) < 1e-5
+        if pi % 4 == 0:                                                       # agent trajectories: every 4th cycle is stored
+            worst["agents"] = max(worst["agents"], float(np.abs(root[1][:, ::10] - D[f"{scene}_p{pi}_pos"]).max()))
+            assert np.abs(root[2][:, ::10] - D[f"{scene}_p{pi}_cov"]).max() < 1e-3
+        tk = [k for k in tt.nodes.keys() if k != -1]
+        xs = np.array([tt.nodes[k].data[0] for k in tk])[:25]
+        worst["ego"] = max(worst["ego"], float(np.abs(xs[:, :2] - xs_all[pi][:, :2]).max()))
+        worst["ctrl"] = max(worst["ctrl"], float(np.abs(np.asarray(sim.ctrl) - ctrl_out[pi]).max()))
+    assert worst["agents"] < tol and worst["ego"] < tol and worst["ctrl"] < 2e-3, worst

@@ -2,7 +2,7 @@
 
 The reference Python cannot travel to the GPU box; these small fixtures (inputs are formula
 generated, so only expected outputs are stored) can.  Re-run:  python tools/gen_golden.py [section ...]
-Sections: predictor rpe potential ilqr aime plan scenes demo_plans
+Sections: predictor rpe potential ilqr aime plan scenes demo_plans demo_runs
 """
 import os
 import sys
@@ -349,7 +349,76 @@ def gen_demo_plans(n_plans=4):
     np.savez_compressed(os.path.join(GOLD, "demo_plans.npz"), **out)
 
 
-SECTIONS = {"demo_plans": gen_demo_plans, "scenes": gen_scenes, "predictor": gen_predictor, "ilqr": gen_ilqr, "potential": gen_potential, "aime": gen_aime, "plan": gen_plan}
+def gen_demo_runs(n_plans=60):
+    """G10: the reference's whole closed loop on the four recorded scenes (every planning cycle from t = 4.0 s to
+    t = 9.9 s), for TEACHER-FORCED comparison: per cycle the ego state and control the reference planned from, and
+    what it planned (branch ids, probabilities, ego trajectory, control, coarse agent trajectories)."""
+    import importlib
+    import json
+    import tempfile
+    import types
+    from mind_amd.scene_io import DEMO_SCENES
+    rh.install()
+    os.chdir(rh.REF_ROOT)
+    vis = types.ModuleType("common.visualization")
+    for fn in ("draw_map", "draw_agent", "draw_scen_trees", "reset_ax", "draw_traj_trees", "draw_traj"):
+        setattr(vis, fn, None)
+    sys.modules["common.visualization"] = vis
+    Simulator = importlib.import_module("simulator").Simulator
+    agent_mod = importlib.import_module("agent")
+    tmp = tempfile.mkdtemp()
+    ck = os.path.join(tmp, "formula.tar")
+    torch.save({"state_dict": formula_state_dict(as_torch=True)}, ck)
+    rec = []
+    orig_plan = agent_mod.MINDAgent.plan
+
+    def recording_plan(self):
+        before = (np.array(self.lcl_smp.ego_agent.state, np.float64), np.array(self.ctrl, np.float64))
+        ok, res = orig_plan(self)
+        rec.append((before, np.array(self.ctrl, np.float64), res))
+        return ok, res
+
+    agent_mod.MINDAgent.plan = recording_plan
+    out = {}
+    for name in DEMO_SCENES:
+        cfg = json.load(open(os.path.join(rh.REF_ROOT, "configs", name + ".json")))
+        pcfg = json.load(open(os.path.join(rh.REF_ROOT, cfg["cl_agents"][0]["planner_config"])))
+        pcfg.update(use_cuda=False, ckpt_path=ck)
+        pp = os.path.join(tmp, name + "_planner.json")
+        json.dump(pcfg, open(pp, "w"))
+        cfg["cl_agents"][0]["planner_config"] = pp
+        cfg.update(render=False, output_dir=tmp)
+        cp = os.path.join(tmp, name + ".json")
+        json.dump(cfg, open(cp, "w"))
+        del rec[:]
+        sim = Simulator(cp)
+        sim.init_sim()
+        sim.sim_horizon = 201 + 5 * (n_plans - 1)
+        sim.run_sim()
+        assert len(rec) == n_plans, len(rec)
+        out[name + "_state_in"] = np.array([r[0][0] for r in rec])
+        out[name + "_ctrl_in"] = np.array([r[0][1] for r in rec])
+        out[name + "_ctrl_out"] = np.array([r[1] for r in rec])
+        out[name + "_n_scen_trees"] = np.array([len(r[2][0]) for r in rec])
+        out[name + "_scen_keys"] = np.array(["|".join(r[2][0][0].nodes.keys()) for r in rec])
+        out[name + "_n_agents"] = np.array([next(iter(r[2][0][0].nodes.values())).data[1].shape[0] for r in rec])
+        out[name + "_root_prob"] = np.array([float(np.ravel(next(iter(r[2][0][0].nodes.values())).data[0])[0]) for r in rec])
+        xs = []
+        for pi, r in enumerate(rec):
+            st, tt = r[2][0][0], r[2][1][0]
+            tk = [k for k in tt.nodes.keys() if k != -1]
+            xs.append(np.array([tt.nodes[k].data[0] for k in tk])[:25])
+            root = next(iter(st.nodes.values())).data
+            if pi % 4 == 0:         # agent trajectories of every 4th cycle keep the fixture small
+                out[f"{name}_p{pi}_pos"] = root[1][:, ::10].astype(np.float32)
+                out[f"{name}_p{pi}_cov"] = root[2][:, ::10].astype(np.float32)
+        out[name + "_traj_xs"] = np.array(xs)
+        print(name, "plans", len(rec), "branch ids", sorted(set(out[name + "_scen_keys"])), "agents", out[name + "_n_agents"].min(),
+              out[name + "_n_agents"].max())
+    np.savez_compressed(os.path.join(GOLD, "demo_runs.npz"), **out)
+
+
+SECTIONS = {"demo_runs": gen_demo_runs, "demo_plans": gen_demo_plans, "scenes": gen_scenes, "predictor": gen_predictor, "ilqr": gen_ilqr, "potential": gen_potential, "aime": gen_aime, "plan": gen_plan}
 
 if __name__ == "__main__":
     torch.manual_seed(0)
