@@ -42,6 +42,9 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 #ifndef DB
 #define DB 16   // weight loads in flight per thread (32 was measured slower: register pressure at 1024 threads)
 #endif
+// Keeps the LDS reads of one input row next to the FMAs that consume them: without it the scheduler hoists the reads
+// of ALL R rows above the first FMA (R x DB live values) and spills hundreds of registers at 1024 threads per workgroup.
+#define DENSE_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
 template <int R>
 __device__ __forceinline__ void dense(const float *in, int ldi, int K, const float *__restrict__ WT,
                                       const float *__restrict__ b, int NOUT, float *out, int ldo,
@@ -77,6 +80,7 @@ __device__ __forceinline__ void dense(const float *in, int ldi, int K, const flo
             acc[r] = fmaf(w[4 * q4 + 2], x[2], acc[r]);
             acc[r] = fmaf(w[4 * q4 + 3], x[3], acc[r]);
           }
+        DENSE_ROW_FENCE();
         }
       }
       for (; k < K; k += 4) {
@@ -114,6 +118,7 @@ __device__ __forceinline__ void dense(const float *in, int ldi, int K, const flo
           acc[r] = fmaf(w[4 * q4 + 2], x[2], acc[r]);
           acc[r] = fmaf(w[4 * q4 + 3], x[3], acc[r]);
         }
+        DENSE_ROW_FENCE();
       }
     }
     for (; k < k1; k += 4) {
@@ -250,38 +255,44 @@ struct ActorW {
 
 // out[co][t] = sum_ci sum_dk W[ci][dk][co] * in[ci][t*stride + dk - pad], raw (no norm).
 // thread = (co, time chunk of TCH outputs, K part): the Cin range is split over KP thread groups and the
-// partials are reduced through `part` (LDS, KP*Cout*Tout floats) -- the conv is latency-bound on the
-// weight stream, not on FLOPs.  Contains __syncthreads().
-template <int TCH>
+// partials are reduced through `part` (LDS, KP*Cout*Tout floats).  Per input channel a thread reads the window
+// of (TCH-1)*STRIDE + KSZ inputs it needs ONCE into registers and reuses it for all taps: the layer is bound by
+// the LDS read rate (one read per FMA if every tap re-reads its inputs), not by FLOPs or by the weight stream.
+// Contains __syncthreads().
+template <int TCH, int STRIDE, int KSZ>
 __device__ __forceinline__ void conv_chunk(const float *in, int Cin, int Tin, const float *__restrict__ W,
-                                           int Cout, int Tout, int stride, int ksz, float *out, float *part, int KP) {
+                                           int Cout, int Tout, float *out, float *part, int KP) {
+  constexpr int SPAN = (TCH - 1) * STRIDE + KSZ, PAD = (KSZ - 1) / 2;
   const int tid = threadIdx.x;
   const int nch = (Tout + TCH - 1) / TCH;
   const int groups = Cout * nch;
   const int kp = tid / groups, g = tid % groups;
   const int co = g % Cout, t0 = (g / Cout) * TCH;
-  const int pad = (ksz - 1) / 2;
   const int cpk = (Cin + KP - 1) / KP;
   if (kp < KP) {
     float acc[TCH];
 #pragma unroll
     for (int i = 0; i < TCH; ++i) acc[i] = 0.f;
     const int c0 = kp * cpk, c1 = min(Cin, c0 + cpk);
+    const int base = t0 * STRIDE - PAD;
 #ifndef CONV_UNROLL
 #define CONV_UNROLL 4
 #endif
 #pragma unroll CONV_UNROLL
     for (int ci = c0; ci < c1; ++ci) {
-#pragma unroll 3
-      for (int dk = 0; dk < ksz; ++dk) {
-        const float w = W[((size_t)ci * ksz + dk) * Cout + co];
+      float w[KSZ], xw[SPAN];
 #pragma unroll
-        for (int i = 0; i < TCH; ++i) {
-          const int ti = (t0 + i) * stride + dk - pad;
-          const float xv = (ti >= 0 && ti < Tin) ? in[ci * Tin + ti] : 0.f;
-          acc[i] = fmaf(w, xv, acc[i]);
-        }
+      for (int dk = 0; dk < KSZ; ++dk) w[dk] = W[((size_t)ci * KSZ + dk) * Cout + co];
+#pragma unroll
+      for (int j = 0; j < SPAN; ++j) {
+        const int ti = base + j;
+        xw[j] = (ti >= 0 && ti < Tin) ? in[ci * Tin + ti] : 0.f;
       }
+#pragma unroll
+      for (int dk = 0; dk < KSZ; ++dk)        // tap-major: the accumulation order of the per-tap formulation
+#pragma unroll
+        for (int i = 0; i < TCH; ++i) acc[i] = fmaf(w[dk], xw[i * STRIDE + dk], acc[i]);
+      DENSE_ROW_FENCE();      // keep one channel's window next to its FMAs (see dense())
     }
     float *dst = KP > 1 ? part + (size_t)kp * Cout * Tout : out;
 #pragma unroll
@@ -298,19 +309,21 @@ __device__ __forceinline__ void conv_chunk(const float *in, int Cin, int Tin, co
   }
 }
 
-// chooses the time chunk so that (Cout x chunks) <= AT thread groups, then the K split that fits `part`
+// chooses the time chunk so that (Cout x chunks) <= AT thread groups, then the K split that fits `part`.
+// STRIDE / KSZ are compile-time at every call site (the kernel is fully inlined).
+template <int STRIDE, int KSZ>
 __device__ __forceinline__ void conv(const float *in, int Cin, int Tin, const float *W, int Cout, int Tout,
-                                     int stride, int ksz, float *out, float *part, int part_floats) {
+                                     float *out, float *part, int part_floats) {
   int tch = 3;
   while (Cout * ((Tout + tch - 1) / tch) > AT) tch *= 2;      // 3, 6, 12, 24
   const int groups = Cout * ((Tout + tch - 1) / tch);
   int KP = AT / groups;
   while (KP > 1 && (KP * Cout * Tout > part_floats || KP > Cin)) KP >>= 1;
   if (KP < 1) KP = 1;
-  if (tch <= 3) conv_chunk<3>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out, part, KP);
-  else if (tch <= 6) conv_chunk<6>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out, part, KP);
-  else if (tch <= 12) conv_chunk<12>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out, part, KP);
-  else conv_chunk<24>(in, Cin, Tin, W, Cout, Tout, stride, ksz, out, part, KP);
+  if (tch <= 3) conv_chunk<3, STRIDE, KSZ>(in, Cin, Tin, W, Cout, Tout, out, part, KP);
+  else if (tch <= 6) conv_chunk<6, STRIDE, KSZ>(in, Cin, Tin, W, Cout, Tout, out, part, KP);
+  else if (tch <= 12) conv_chunk<12, STRIDE, KSZ>(in, Cin, Tin, W, Cout, Tout, out, part, KP);
+  else conv_chunk<24, STRIDE, KSZ>(in, Cin, Tin, W, Cout, Tout, out, part, KP);
 }
 
 // sum over the 16 waves of the actor kernel
@@ -349,14 +362,16 @@ __device__ __forceinline__ void gn(float *buf, int C, int T, const float *__rest
 __device__ __forceinline__ void res1d(const float *in, int Cin, int Tin, const ResW &w, int Cout, int stride,
                                       float *out, float *t1, float *t2, float *red, float *part, int pf) {
   const int Tout = Tin / stride;
-  conv(in, Cin, Tin, w.c1, Cout, Tout, stride, 3, t1, part, pf);
+  if (stride == 1) conv<1, 3>(in, Cin, Tin, w.c1, Cout, Tout, t1, part, pf);
+  else conv<2, 3>(in, Cin, Tin, w.c1, Cout, Tout, t1, part, pf);
   __syncthreads();
   gn(t1, Cout, Tout, w.g1, w.b1, nullptr, true, red);
-  conv(t1, Cout, Tout, w.c2, Cout, Tout, 1, 3, out, part, pf);
+  conv<1, 3>(t1, Cout, Tout, w.c2, Cout, Tout, out, part, pf);
   __syncthreads();
   const float *resid = in;
   if (w.ds) {
-    conv(in, Cin, Tin, w.ds, Cout, Tout, stride, 1, t2, part, pf);
+    if (stride == 1) conv<1, 1>(in, Cin, Tin, w.ds, Cout, Tout, t2, part, pf);
+    else conv<2, 1>(in, Cin, Tin, w.ds, Cout, Tout, t2, part, pf);
     __syncthreads();
     gn(t2, Cout, Tout, w.gd, w.bd, nullptr, false, red);
     resid = t2;
@@ -405,7 +420,7 @@ __global__ __launch_bounds__(AT) void k_actor_net(const float *__restrict__ acto
   res1d(ta, 256, 6, W.res[7], 256, 1, o3, tb, tc, red, part, pf);
   AT_MARK();
   // FPN top-down (network.py:55-58): lateral = conv3 + GN, no activation
-  conv(o3, 256, 6, W.latW[3], 128, 6, 1, 3, fa, part, pf);
+  conv<1, 3>(o3, 256, 6, W.latW[3], 128, 6, fa, part, pf);
   __syncthreads();
   gn(fa, 128, 6, W.latG[3], W.latB[3], nullptr, false, red);
   float *cur = fa, *nxt = fb;
@@ -414,7 +429,7 @@ __global__ __launch_bounds__(AT) void k_actor_net(const float *__restrict__ acto
     const int C = g == 2 ? 128 : (g == 1 ? 64 : 32);
     const int T = g == 2 ? 12 : (g == 1 ? 24 : 48);
     const int Th = T / 2;
-    conv(src_o, C, T, W.latW[g], 128, T, 1, 3, nxt, part, pf);
+    conv<1, 3>(src_o, C, T, W.latW[g], 128, T, nxt, part, pf);
     __syncthreads();
     gn(nxt, 128, T, W.latG[g], W.latB[g], nullptr, false, red);
     // x2 linear upsample of `cur` (align_corners=False) added to the lateral
@@ -434,10 +449,10 @@ __global__ __launch_bounds__(AT) void k_actor_net(const float *__restrict__ acto
   // output Res1d(128,128) at T = 48 (network.py:60); only the last time column is kept
   {
     const ResW &w = W.res[8];
-    conv(cur, 128, 48, w.c1, 128, 48, 1, 3, nxt, part, pf);
+    conv<1, 3>(cur, 128, 48, w.c1, 128, 48, nxt, part, pf);
     __syncthreads();
     gn(nxt, 128, 48, w.g1, w.b1, nullptr, true, red);
-    conv(nxt, 128, 48, w.c2, 128, 48, 1, 3, fo, part, pf);
+    conv<1, 3>(nxt, 128, 48, w.c2, 128, 48, fo, part, pf);
     __syncthreads();
     gn(fo, 128, 48, w.g2, w.b2, cur, true, red);
   }

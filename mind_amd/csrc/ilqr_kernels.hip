@@ -37,34 +37,54 @@
 #define IL_LSUM 2048   // doubles of LDS used to stage the cost sums
 #define IL_RMARGIN 3.0  // [m] the list is exact for queries within this distance of the nominal state
 
+// Pointer into HBM whose accesses are emitted as GLOBAL memory instructions.  The tree / constant structs are read from
+// memory, where the compiler cannot infer an address space: plain pointers would become generic (flat) accesses, which
+// count against the LDS counter as well -- every wait for an LDS operand would then also wait for the global loads that
+// were issued ahead on purpose (the one-node-ahead prefetches of the Riccati sweep and of the chain rollout).
+#define IL_AS1 __attribute__((address_space(1)))
+typedef double il_d2 __attribute__((ext_vector_type(2)));   // built-in vectors: loadable through address-space pointers
+typedef float il_f2 __attribute__((ext_vector_type(2)));
+template <class T> struct GP {
+  T *p;
+  GP() = default;
+  __host__ __device__ GP(T *q) : p(q) {}
+  template <class U> __host__ __device__ GP(const GP<U> &o) : p(o.p) {}
+  __device__ __forceinline__ T IL_AS1 *g() const { return (T IL_AS1 *)p; }
+  __device__ __forceinline__ T IL_AS1 &operator[](size_t i) const { return g()[i]; }
+  __device__ __forceinline__ T IL_AS1 &operator*() const { return *g(); }
+  template <class V> __device__ __forceinline__ V IL_AS1 *as() const { return (V IL_AS1 *)p; }
+  __host__ __device__ __forceinline__ GP operator+(size_t o) const { return GP(p + o); }
+  __host__ __device__ __forceinline__ GP &operator+=(size_t o) { p += o; return *this; }
+  __host__ __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
+};
 struct IlqrTreeDev {
   int M, n_agents, n_levels, pad;
-  const int *parent;        // [M]
-  const int *level_start;   // [n_levels+1]
-  const int *level_nodes;   // [M] nodes sorted by depth (ties: key)
-  const int *child_start;   // [M+1]
-  const int *child_list;    // [M-1] children in key order
+  GP<const int> parent;        // [M]
+  GP<const int> level_start;   // [n_levels+1]
+  GP<const int> level_nodes;   // [M] nodes sorted by depth (ties: key)
+  GP<const int> child_start;   // [M+1]
+  GP<const int> child_list;    // [M-1] children in key order
   // chain segments: maximal single-child paths; one wave walks a segment without workgroup barriers
   int n_segs, n_slevels, max_level_segs, pad2;
-  const int *seg_start;     // [n_segs+1] into seg_nodes (root -> leaf order inside a segment)
-  const int *seg_nodes;     // [M]
-  const int *slevel_start;  // [n_slevels+1] into slevel_segs (segments grouped by depth in the segment tree)
-  const int *slevel_segs;   // [n_segs]
-  const float *prob;        // [M]
-  const float *mean;        // [M,a,2]
-  const float *cov;         // [M,a]
+  GP<const int> seg_start;     // [n_segs+1] into seg_nodes (root -> leaf order inside a segment)
+  GP<const int> seg_nodes;     // [M]
+  GP<const int> slevel_start;  // [n_slevels+1] into slevel_segs (segments grouped by depth in the segment tree)
+  GP<const int> slevel_segs;   // [n_segs]
+  GP<const float> prob;        // [M]
+  GP<const float> mean;        // [M,a,2]
+  GP<const float> cov;         // [M,a]
   // workspace (doubles)
-  double *xs, *us, *Fx, *L, *Lx, *Lxx;                        // [M,*]
-  double *k, *K, *Vx, *Vxx;                                   // [IL_SPEC][M,*]  (one set per speculative mu)
-  double *xs_new, *us_new, *L_new;                            // [IL_SPEC][NA,M,*]
-  int *rel;                 // [M] number of exo agents near the nominal state (<= IL_REL), or -1 = overflow
-  double *relag;            // [M, IL_RA] compact staged records {mean_x, mean_y, sigma+offset, threshold}: entry 0 =
+  GP<double> xs, us, Fx, L, Lx, Lxx;                        // [M,*]
+  GP<double> k, K, Vx, Vxx;                                   // [IL_SPEC][M,*]  (one set per speculative mu)
+  GP<double> xs_new, us_new, L_new;                            // [IL_SPEC][NA,M,*]
+  GP<int> rel;                 // [M] number of exo agents near the nominal state (<= IL_REL), or -1 = overflow
+  GP<double> relag;            // [M, IL_RA] compact staged records {mean_x, mean_y, sigma+offset, threshold}: entry 0 =
                             //   ego, entries 1..rel[c] = the relevant exo agents in ascending agent order
   // generic mode (planners/ilqr surface: arbitrary materialised fields + per-node diagonal weights)
-  const double *field;      // [M, H*W] cost_field of every node's PotentialField, or null
-  const double *node_w;     // [M, IL_NW]: w_des[6] w_con[6] lb[6] ub[6] w_ctrl[2] des[6], or null
+  GP<const double> field;      // [M, H*W] cost_field of every node's PotentialField, or null
+  GP<const double> node_w;     // [M, IL_NW]: w_des[6] w_con[6] lb[6] ub[6] w_ctrl[2] des[6], or null
   // outputs
-  double *stats;            // [IL_NSTAT]: iterations, converged, J, mu, phase cycles, profile slots
+  GP<double> stats;            // [IL_NSTAT]: iterations, converged, J, mu, phase cycles, profile slots
 };
 
 struct IlqrConst {
@@ -75,13 +95,13 @@ struct IlqrConst {
   double x0[6];
   int W, H, max_iter, use_exo;
   double alphas[IL_NA];     // 1.1 ** (-j*j), j = 0..9 (solver.py:125), computed on the host
-  const double *gx, *gy;    // [W], [H] grid coordinates (numpy linspace + offset, built on the host)
+  GP<const double> gx, gy;    // [W], [H] grid coordinates (numpy linspace + offset, built on the host)
   // lin != 0: gx[i] == ((i == W-1 ? fsx : i * stepx) + off_x) bit for bit (checked on the host), so the kernels
   // compute cell centres instead of loading them
   int lin, pad_;
   double stepx, stepy, fsx, fsy;
   double in_x0, in_x1, in_y0, in_y1;   // conservative "window fully inside the grid" box for the list fast path
-  const double *quad;       // [H*W] squared distance to the target lane
+  GP<const double> quad;       // [H*W] squared distance to the target lane
 };
 
 // Ordering point for lane-to-lane exchange through LDS inside ONE wave.  The LDS pipeline executes a wave's DS
@@ -184,8 +204,8 @@ template <bool GEN> struct IlNodeW {
 // as the reference computes it), early-out threshold}: entry 0 = ego (offset w_ego_cov_offset).
 __device__ __forceinline__ void il_stage_agents(const IlqrConst &C, const IlqrTreeDev &T, int i, double *ag) {
   const int lane = threadIdx.x & 63;
-  const float *mean = T.mean + (size_t)i * T.n_agents * 2;
-  const float *cov = T.cov + (size_t)i * T.n_agents;
+  auto mean = T.mean + (size_t)i * T.n_agents * 2;
+  auto cov = T.cov + (size_t)i * T.n_agents;
   IL_WFENCE();
   for (int e = lane; e < T.n_agents; e += 64) {
     const double ec = (double)(cov[e] + (float)(e == 0 ? C.w_ego_off : C.w_exo_off));
@@ -454,7 +474,7 @@ __device__ __forceinline__ int il_gains(const IlqrConst &C, const IlqrTreeDev &T
     if (mat) Tm[lane] = v;
   }
   if (lane >= 42 && lane < 56) {       // gains to global memory: K (12) then k (2)
-    double *dstg = lane < 54 ? T.K + (size_t)key * 12 + (lane - 42) : T.k + (size_t)key * 2 + (lane - 54);
+    const GP<double> dstg = lane < 54 ? T.K + ((size_t)key * 12 + (lane - 42)) : T.k + ((size_t)key * 2 + (lane - 54));
     *dstg = lane < 54 ? Kk[lane - 42] : misc[6 + (lane - 54)];
   }
   IL_WFENCE();
@@ -489,14 +509,14 @@ __device__ __forceinline__ void il_dyn_sc(const IlqrConst &C, const double *x, c
 struct IlKv { double K[12], k[2], us[2], xs[6]; };
 
 __device__ __forceinline__ void il_prefetch_kv(const IlqrTreeDev &T, int c, IlKv &P) {
-  const double2 *pK = reinterpret_cast<const double2 *>(T.K + (size_t)c * 12);
-  const double2 *px = reinterpret_cast<const double2 *>(T.xs + (size_t)c * 6);
+  const auto pK = (T.K + (size_t)c * 12).as<const il_d2>();
+  const auto px = (T.xs + (size_t)c * 6).as<const il_d2>();
 #pragma unroll
-  for (int q = 0; q < 6; ++q) { const double2 v = pK[q]; P.K[2 * q] = v.x; P.K[2 * q + 1] = v.y; }
+  for (int q = 0; q < 6; ++q) { const il_d2 v = pK[q]; P.K[2 * q] = v.x; P.K[2 * q + 1] = v.y; }
 #pragma unroll
-  for (int q = 0; q < 3; ++q) { const double2 v = px[q]; P.xs[2 * q] = v.x; P.xs[2 * q + 1] = v.y; }
-  const double2 vk = *reinterpret_cast<const double2 *>(T.k + (size_t)c * 2);
-  const double2 vu = *reinterpret_cast<const double2 *>(T.us + (size_t)c * 2);
+  for (int q = 0; q < 3; ++q) { const il_d2 v = px[q]; P.xs[2 * q] = v.x; P.xs[2 * q + 1] = v.y; }
+  const il_d2 vk = *(T.k + (size_t)c * 2).as<const il_d2>();
+  const il_d2 vu = *(T.us + (size_t)c * 2).as<const il_d2>();
   P.k[0] = vk.x; P.k[1] = vk.y; P.us[0] = vu.x; P.us[1] = vu.y;
 }
 
@@ -542,9 +562,9 @@ __device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const Ilq
     }
     il_dyn_sc(C, xp, u, x);
     if (writer) {
-      double2 *xn = reinterpret_cast<double2 *>(T.xs_new + ((size_t)a * M + c) * 6);
-      xn[0] = make_double2(x[0], x[1]); xn[1] = make_double2(x[2], x[3]); xn[2] = make_double2(x[4], x[5]);
-      *reinterpret_cast<double2 *>(T.us_new + ((size_t)a * M + c) * 2) = make_double2(u[0], u[1]);
+      const auto xn = (T.xs_new + ((size_t)a * M + c) * 6).as<il_d2>();
+      xn[0] = il_d2{x[0], x[1]}; xn[1] = il_d2{x[2], x[3]}; xn[2] = il_d2{x[4], x[5]};
+      *(T.us_new + ((size_t)a * M + c) * 2).as<il_d2>() = il_d2{u[0], u[1]};
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) { xp[k] = x[k]; xo[k] = Pc.xs[k]; }
@@ -622,8 +642,8 @@ __device__ __forceinline__ void il_cost_pass(const IlqrConst &C, const IlqrTreeD
     const size_t eo = (size_t)(slot * IL_NA + a) * M + c;
     double x[6], u[2];
     {
-      const double2 *px = reinterpret_cast<const double2 *>(T.xs_new + eo * 6);
-      const double2 v0 = px[0], v1 = px[1], v2 = px[2], vu = *reinterpret_cast<const double2 *>(T.us_new + eo * 2);
+      const auto px = (T.xs_new + eo * 6).as<const il_d2>();
+      const il_d2 v0 = px[0], v1 = px[1], v2 = px[2], vu = *(T.us_new + eo * 2).as<const il_d2>();
       x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y; u[0] = vu.x; u[1] = vu.y;
     }
     const float pf = GEN ? 0.f : T.prob[c];
@@ -632,7 +652,7 @@ __device__ __forceinline__ void il_cost_pass(const IlqrConst &C, const IlqrTreeD
     double nx = 0.0, ny = 0.0;
     if (C.use_exo) {
       cnt = T.rel[c];
-      const double2 vn = *reinterpret_cast<const double2 *>(T.xs + (size_t)c * 6);
+      const il_d2 vn = *(T.xs + (size_t)c * 6).as<const il_d2>();
       nx = vn.x; ny = vn.y;
       IL_WFENCE();
 #pragma unroll
@@ -679,8 +699,8 @@ __device__ __forceinline__ void il_cost_pass(const IlqrConst &C, const IlqrTreeD
           }
           ex = rec[0]; ey = rec[1]; ego_cov = rec[2];
         } else {
-          const float *mean = T.mean + (size_t)c * T.n_agents * 2;
-          const float *cv = T.cov + (size_t)c * T.n_agents;
+          auto mean = T.mean + (size_t)c * T.n_agents * 2;
+          auto cv = T.cov + (size_t)c * T.n_agents;
           for (int e = 1; e < T.n_agents; ++e) {
             const double ax = (double)mean[2 * e], ay = (double)mean[2 * e + 1];
             const double ec = (double)(cv[e] + (float)C.w_exo_off), th = ec * ec * 1.000000001;
@@ -726,7 +746,7 @@ __device__ __forceinline__ void il_cost_pass(const IlqrConst &C, const IlqrTreeD
              2.0 * u1 * uu * v1 * v1 * s01 + 2.0 * u1 * uu * 2.0 * v1 * vv * s11 + 2.0 * u1 * uu * vv * vv * s21 +
              uu * uu * v1 * v1 * s02 + uu * uu * 2.0 * v1 * vv * s12 + uu * uu * vv * vv * s22;
     if (valid) {
-      const IlNodeW<GEN> NW{C, GEN ? T.node_w + (size_t)c * IL_NW : nullptr, (double)pf};
+      const IlNodeW<GEN> NW{C, GEN ? (T.node_w + (size_t)c * IL_NW).p : nullptr, (double)pf};
       T.L_new[eo] = il_node_cost<GEN>(NW, x, u, fe);
     }
     IL_PT(4); IL_PCNT(15);
@@ -740,7 +760,7 @@ template <bool GEN>
 __device__ __forceinline__ void il_node_derivs(const IlqrConst &C, const IlqrTreeDev &T, int c, const double *x, const double *u,
                                                double *scr, const double *ag, double *dLxx, double *dFx, double *dLx, double *dL) {
   const int lane = threadIdx.x & 63;
-  const IlNodeW<GEN> NW{C, GEN ? T.node_w + (size_t)c * IL_NW : nullptr, GEN ? 0.0 : (double)T.prob[c]};
+  const IlNodeW<GEN> NW{C, GEN ? (T.node_w + (size_t)c * IL_NW).p : nullptr, GEN ? 0.0 : (double)T.prob[c]};
   FieldOut fe;
   il_field<GEN>(C, T, c, x[0], x[1], scr, ag, true, fe);
   double s3, c3;
@@ -807,7 +827,7 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
     if (exo) {
       for (int q = tid; q < nn * A; q += IL_THREADS) {
         const int n = q / A, e = q - n * A;
-        const float2 m = reinterpret_cast<const float2 *>(T.mean)[(size_t)(n0 + n) * A + e];
+        const il_f2 m = T.mean.as<const il_f2>()[(size_t)(n0 + n) * A + e];
         smx[e * nbp + n] = m.x; smy[e * nbp + n] = m.y; scv[e * nbp + n] = T.cov[(size_t)(n0 + n) * A + e];
       }
       __syncthreads();
@@ -817,8 +837,8 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
     const int c = n0 + n;
     double x[6], u[2];
     {
-      const double2 *px = reinterpret_cast<const double2 *>(T.xs + (size_t)c * 6);
-      const double2 v0 = px[0], v1 = px[1], v2 = px[2], vu = *reinterpret_cast<const double2 *>(T.us + (size_t)c * 2);
+      const auto px = (T.xs + (size_t)c * 6).as<const il_d2>();
+      const il_d2 v0 = px[0], v1 = px[1], v2 = px[2], vu = *(T.us + (size_t)c * 2).as<const il_d2>();
       x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y; u[0] = vu.x; u[1] = vu.y;
     }
     const float pf = GEN ? 0.f : T.prob[c];
@@ -849,7 +869,7 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
       const unsigned m0 = dmask[n * 4], m1 = dmask[n * 4 + 1], m2 = dmask[n * 4 + 2], m3 = dmask[n * 4 + 3];
       cnt = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
       if (cnt > IL_REL) cnt = -1;
-      double *ra = T.relag + (size_t)c * IL_RA;
+      auto ra = T.relag + (size_t)c * IL_RA;
       double *rl = drec + (size_t)n * IL_RA;
       for (int e = 1 + wave; e < A; e += IL_WAVES) {
         const unsigned w_ = e >> 5, bit = 1u << (e & 31);
@@ -861,7 +881,7 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
           const double th = ec * ec * 1.000000001;
           double *dl = rl + 4 * (1 + slot);
           dl[0] = ax; dl[1] = ay; dl[2] = ec; dl[3] = th;
-          if (valid) { double *dg = ra + 4 * (1 + slot); dg[0] = ax; dg[1] = ay; dg[2] = ec; dg[3] = th; }
+          if (valid) { const GP<double> dg = ra + 4 * (1 + slot); dg[0] = ax; dg[1] = ay; dg[2] = ec; dg[3] = th; }
         }
       }
       if (wave == 0) {
@@ -941,7 +961,7 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
         const double c5 = cos(x[5]);
         const double t5 = tan(x[5]);
         if (valid) {
-          double *F = T.Fx + (size_t)c * 36;
+          auto F = T.Fx + (size_t)c * 36;
           F[2] = c3 * C.dt;
           F[3] = -x[2] * s3 * C.dt;
           F[8] = s3 * C.dt;
@@ -993,10 +1013,10 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
       fe.hxy = r2 * (a * av * s00 + a * bv * s10 + a * cv * s20 +
                      b * av * s01 + b * bv * s11 + b * cv * s21 +
                      2.0 * uu * av * s02 + 2.0 * uu * bv * s12 + 2.0 * uu * cv * s22);
-      const IlNodeW<GEN> NW{C, GEN ? T.node_w + (size_t)c * IL_NW : nullptr, (double)pf};
+      const IlNodeW<GEN> NW{C, GEN ? (T.node_w + (size_t)c * IL_NW).p : nullptr, (double)pf};
       const double Lc = il_node_cost<GEN>(NW, x, u, fe);
       if (valid) {
-        double *Lxx = T.Lxx + (size_t)c * 36, *Lx = T.Lx + (size_t)c * 6;
+        const GP<double> Lxx = T.Lxx + (size_t)c * 36, Lx = T.Lx + (size_t)c * 6;
         T.L[c] = Lc;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
@@ -1079,7 +1099,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
     if (sh_accepted) {
       // adopt the accepted candidate as the nominal trajectory, then derivatives for all nodes in parallel
       const size_t off = ((size_t)sh_slot * IL_NA + sh_pick) * M;
-      const double *xn = T.xs_new + off * 6, *un = T.us_new + off * 2;
+      const GP<double> xn = T.xs_new + off * 6, un = T.us_new + off * 2;
       for (int q = tid; q < M * 6; q += IL_THREADS) T.xs[q] = xn[q];
       for (int q = tid; q < M * 2; q += IL_THREADS) T.us[q] = un[q];
       __threadfence_block();
@@ -1091,7 +1111,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
         for (int q = tid; q < M; q += IL_THREADS) lsum[q] = T.L[q];
         __syncthreads();
         if (tid == 0) { sh_J = il_np_sum(lsum, M); sh_accepted = 0; }
-      } else if (tid == 0) { sh_J = il_np_sum(T.L, M); sh_accepted = 0; }
+      } else if (tid == 0) { sh_J = il_np_sum(T.L.p, M); sh_accepted = 0; }
       __syncthreads();
     }
     IL_MARK(t_der);
@@ -1200,7 +1220,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
     }
     if (tid < IL_NA * nuse) {
       double J = 0.0;   // python sum(): sequential
-      const double *Ln = (M * IL_NA * nuse <= IL_LSUM) ? lsum + (size_t)tid * M : T.L_new + (size_t)tid * M;
+      const double *Ln = (M * IL_NA * nuse <= IL_LSUM) ? lsum + (size_t)tid * M : (T.L_new + (size_t)tid * M).p;
       for (int c = 0; c < M; ++c) J += Ln[c];
       Jnew[tid / IL_NA][tid % IL_NA] = J;
     }
@@ -1238,7 +1258,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
   // the reference returns the last ACCEPTED xs/us (Q19: J_opt is the cost before that step)
   if (sh_accepted) {
     const size_t off = ((size_t)sh_slot * IL_NA + sh_pick) * M;
-    const double *xn = T.xs_new + off * 6, *un = T.us_new + off * 2;
+    const GP<double> xn = T.xs_new + off * 6, un = T.us_new + off * 2;
     for (int q = tid; q < M * 6; q += IL_THREADS) T.xs[q] = xn[q];
     for (int q = tid; q < M * 2; q += IL_THREADS) T.us[q] = un[q];
   }
@@ -1264,7 +1284,7 @@ template <bool GEN>
 __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restrict__ trees, const IlqrConst *__restrict__ consts,
                                                      int n_phases) {
   const IlqrTreeDev T = trees[blockIdx.x];
-  for (int ph = 0; ph < n_phases; ++ph) il_fit<GEN>(T, consts[ph], T.stats + (size_t)ph * IL_NSTAT);
+  for (int ph = 0; ph < n_phases; ++ph) il_fit<GEN>(T, consts[ph], (T.stats + (size_t)ph * IL_NSTAT).p);
 }
 
 static inline size_t il_lds_bytes(int /*amax*/) {
@@ -1292,7 +1312,7 @@ __global__ __launch_bounds__(64) void k_cost_eval(const IlqrTreeDev *__restrict_
   double *o = out + (size_t)q * IL_EVAL_OUT;
   il_node_derivs<GEN>(C, T, c, x, u, scr, ag, o + 9, nullptr, o + 1, o);
   if (lane < 2) {
-    const IlNodeW<GEN> NW{C, GEN ? T.node_w + (size_t)c * IL_NW : nullptr, GEN ? 0.0 : (double)T.prob[c]};
+    const IlNodeW<GEN> NW{C, GEN ? (T.node_w + (size_t)c * IL_NW).p : nullptr, GEN ? 0.0 : (double)T.prob[c]};
     o[7 + lane] = 2.0 * (NW.wctrl(lane) * u[lane]);
     o[45 + lane] = 2.0 * NW.wctrl(lane);
   }

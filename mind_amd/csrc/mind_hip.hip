@@ -958,7 +958,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   }
   HIPCHK(c, hipMemcpyAsync(base + o_consts, K2, 2 * sizeof(IlqrConst), hipMemcpyHostToDevice, st));
   const IlqrConst *dK = (const IlqrConst *)(base + o_consts);
-  if (!gen) hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, K.gx, K.gy, W, H, dD + o_lane, n_lane_pts, dD + o_quad);
+  if (!gen) hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, K.gx.p, K.gy.p, W, H, dD + o_lane, n_lane_pts, dD + o_quad);
   int amax = 1;
   for (int t = 0; t < n_trees; ++t) amax = tl[t].a > amax ? tl[t].a : amax;
   const IlqrTreeDev *dT = (const IlqrTreeDev *)(base + o_structs);
