@@ -45,11 +45,84 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 // Keeps the LDS reads of one input row next to the FMAs that consume them: without it the scheduler hoists the reads
 // of ALL R rows above the first FMA (R x DB live values) and spills hundreds of registers at 1024 threads per workgroup.
 #define DENSE_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Few input rows (R <= 8): a thread owns FOUR consecutive outputs, so every weight load is 16 bytes wide, and the K
+// range is split over as many thread groups as the `part` scratch holds -- four times fewer dependent load batches per
+// thread than one output per thread.  out[r][o] = b[o] + sum over the K parts (ascending k inside a part).
+#define DBQ 8
+template <int R>
+__device__ __forceinline__ void dense_quads(const float *in, int ldi, int K, const float *__restrict__ WT,
+                                            const float *__restrict__ b, int NOUT, float *out, int ldo,
+                                            float *part, int part_floats) {
+  const int nthr = blockDim.x;
+  const int NQ = NOUT >> 2;
+  int KP = 1;
+  while (KP * 2 * NQ <= nthr && KP * 2 * R * NOUT <= part_floats && KP * 2 <= (K >> 2)) KP *= 2;
+  const int Kc = ((K / 4 + KP - 1) / KP) * 4;
+  for (int item = threadIdx.x; item < KP * NQ; item += nthr) {      // KP == 1: more quads than threads is allowed
+    const int kp = item / NQ, o = (item % NQ) * 4;
+    float acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[r][c] = (KP == 1 && b) ? b[o + c] : 0.f;
+    const int k0 = kp * Kc, k1 = min(K, k0 + Kc);
+    int k = k0;
+    for (; k + DBQ <= k1; k += DBQ) {
+      f32x4 w[DBQ];
+#pragma unroll
+      for (int q = 0; q < DBQ; ++q) w[q] = *(const f32x4 *)(WT + (size_t)(k + q) * NOUT + o);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int q4 = 0; q4 < DBQ / 4; ++q4) {
+          const f32x4 x = *(const f32x4 *)(in + r * ldi + k + 4 * q4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(w[4 * q4 + j][c], x[j], acc[r][c]);
+        }
+        DENSE_ROW_FENCE();
+      }
+    }
+    for (; k < k1; k += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 w = *(const f32x4 *)(WT + (size_t)(k + j) * NOUT + o);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float x = in[r * ldi + k + j];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(w[c], x, acc[r][c]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (KP == 1) out[r * ldo + o + c] = acc[r][c];
+        else part[(kp * R + r) * NOUT + o + c] = acc[r][c];
+      }
+  }
+  if (KP == 1) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < R * NOUT; i += nthr) {
+    const int r = i / NOUT, oo = i % NOUT;
+    float v = b ? b[oo] : 0.f;
+    for (int q = 0; q < KP; ++q) v += part[(q * R + r) * NOUT + oo];
+    out[r * ldo + oo] = v;
+  }
+}
+
 template <int R>
 __device__ __forceinline__ void dense(const float *in, int ldi, int K, const float *__restrict__ WT,
                                       const float *__restrict__ b, int NOUT, float *out, int ldo,
                                       float *part = nullptr, int part_floats = 0) {
   const int nthr = blockDim.x;
+  if (R <= 8 && part && (NOUT & 3) == 0) {
+    dense_quads<R>(in, ldi, K, WT, b, NOUT, out, ldo, part, part_floats);
+    return;
+  }
   int KP = 1;
   if (part && NOUT < nthr) {
     KP = nthr / NOUT;
@@ -254,10 +327,11 @@ struct ActorW {
 #endif
 
 // out[co][t] = sum_ci sum_dk W[ci][dk][co] * in[ci][t*stride + dk - pad], raw (no norm).
-// thread = (co, time chunk of TCH outputs, K part): the Cin range is split over KP thread groups and the
-// partials are reduced through `part` (LDS, KP*Cout*Tout floats).  Per input channel a thread reads the window
-// of (TCH-1)*STRIDE + KSZ inputs it needs ONCE into registers and reuses it for all taps: the layer is bound by
-// the LDS read rate (one read per FMA if every tap re-reads its inputs), not by FLOPs or by the weight stream.
+// thread = (4 consecutive output channels, time chunk of TCH outputs, K part).  The layer is latency-bound on the
+// weight stream, so every load is made as wide as the layout allows (one 16-byte load = the same tap of four
+// output channels) and the Cin range is split over as many K parts as the LDS scratch `part` holds
+// (KP*Cout*Tout floats; partials reduced there).  Per input channel a thread reads the window of
+// (TCH-1)*STRIDE + KSZ inputs it needs ONCE into registers and reuses it for all taps and all four channels.
 // Contains __syncthreads().
 template <int TCH, int STRIDE, int KSZ>
 __device__ __forceinline__ void conv_chunk(const float *in, int Cin, int Tin, const float *__restrict__ W,
@@ -265,14 +339,17 @@ __device__ __forceinline__ void conv_chunk(const float *in, int Cin, int Tin, co
   constexpr int SPAN = (TCH - 1) * STRIDE + KSZ, PAD = (KSZ - 1) / 2;
   const int tid = threadIdx.x;
   const int nch = (Tout + TCH - 1) / TCH;
-  const int groups = Cout * nch;
+  const int CG = Cout >> 2;                      // channel quads
+  const int groups = CG * nch;
   const int kp = tid / groups, g = tid % groups;
-  const int co = g % Cout, t0 = (g / Cout) * TCH;
+  const int co = (g % CG) * 4, t0 = (g / CG) * TCH;
   const int cpk = (Cin + KP - 1) / KP;
   if (kp < KP) {
-    float acc[TCH];
+    float acc[4][TCH];
 #pragma unroll
-    for (int i = 0; i < TCH; ++i) acc[i] = 0.f;
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < TCH; ++i) acc[c][i] = 0.f;
     const int c0 = kp * cpk, c1 = min(Cin, c0 + cpk);
     const int base = t0 * STRIDE - PAD;
 #ifndef CONV_UNROLL
@@ -280,24 +357,31 @@ __device__ __forceinline__ void conv_chunk(const float *in, int Cin, int Tin, co
 #endif
 #pragma unroll CONV_UNROLL
     for (int ci = c0; ci < c1; ++ci) {
-      float w[KSZ], xw[SPAN];
+      f32x4 w[KSZ];
+      float xw[SPAN];
 #pragma unroll
-      for (int dk = 0; dk < KSZ; ++dk) w[dk] = W[((size_t)ci * KSZ + dk) * Cout + co];
+      for (int dk = 0; dk < KSZ; ++dk) w[dk] = *(const f32x4 *)(W + ((size_t)ci * KSZ + dk) * Cout + co);
 #pragma unroll
       for (int j = 0; j < SPAN; ++j) {
         const int ti = base + j;
         xw[j] = (ti >= 0 && ti < Tin) ? in[ci * Tin + ti] : 0.f;
       }
 #pragma unroll
-      for (int dk = 0; dk < KSZ; ++dk)        // tap-major: the accumulation order of the per-tap formulation
+      for (int dk = 0; dk < KSZ; ++dk)        // tap-major inside a channel
 #pragma unroll
-        for (int i = 0; i < TCH; ++i) acc[i] = fmaf(w[dk], xw[i * STRIDE + dk], acc[i]);
+        for (int i = 0; i < TCH; ++i) {
+          const float x = xw[i * STRIDE + dk];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c][i] = fmaf(w[dk][c], x, acc[c][i]);
+        }
       DENSE_ROW_FENCE();      // keep one channel's window next to its FMAs (see dense())
     }
     float *dst = KP > 1 ? part + (size_t)kp * Cout * Tout : out;
 #pragma unroll
-    for (int i = 0; i < TCH; ++i)
-      if (t0 + i < Tout) dst[co * Tout + t0 + i] = acc[i];
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < TCH; ++i)
+        if (t0 + i < Tout) dst[(co + c) * Tout + t0 + i] = acc[c][i];
   }
   if (KP > 1) {
     __syncthreads();
@@ -309,51 +393,67 @@ __device__ __forceinline__ void conv_chunk(const float *in, int Cin, int Tin, co
   }
 }
 
-// chooses the time chunk so that (Cout x chunks) <= AT thread groups, then the K split that fits `part`.
-// STRIDE / KSZ are compile-time at every call site (the kernel is fully inlined).
+// K split: as many parts as threads and the `part` scratch allow (every layer of the actor net has
+// Cout/4 x ceil(Tout/3) <= 512 thread groups; longer time chunks were measured slower: 274 / 289 / 504 us per
+// launch for 3 / 6 / 12 outputs per thread on the T = 48 layers).  STRIDE / KSZ are compile-time at every call site.
 template <int STRIDE, int KSZ>
 __device__ __forceinline__ void conv(const float *in, int Cin, int Tin, const float *W, int Cout, int Tout,
                                      float *out, float *part, int part_floats) {
-  int tch = 3;
-  while (Cout * ((Tout + tch - 1) / tch) > AT) tch *= 2;      // 3, 6, 12, 24
-  const int groups = Cout * ((Tout + tch - 1) / tch);
+const int groups = (Cout >> 2) * ((Tout + 2) / 3);
   int KP = AT / groups;
   while (KP > 1 && (KP * Cout * Tout > part_floats || KP > Cin)) KP >>= 1;
   if (KP < 1) KP = 1;
-  if (tch <= 3) conv_chunk<3, STRIDE, KSZ>(in, Cin, Tin, W, Cout, Tout, out, part, KP);
-  else if (tch <= 6) conv_chunk<6, STRIDE, KSZ>(in, Cin, Tin, W, Cout, Tout, out, part, KP);
-  else if (tch <= 12) conv_chunk<12, STRIDE, KSZ>(in, Cin, Tin, W, Cout, Tout, out, part, KP);
-  else conv_chunk<24, STRIDE, KSZ>(in, Cin, Tin, W, Cout, Tout, out, part, KP);
+  conv_chunk<3, STRIDE, KSZ>(in, Cin, Tin, W, Cout, Tout, out, part, KP);
 }
 
-// sum over the 16 waves of the actor kernel
-__device__ __forceinline__ float block_sum_a(float v, float *red) {
+// sum over the 16 waves of the actor kernel.  `red` holds two 16-float buffers used alternately (`flip`), so one
+// barrier per reduction is enough: a buffer is rewritten only after the barrier of the reduction in between.
+__device__ __forceinline__ float block_sum_a(float v, float *red, int flip) {
   v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  float *r = red + (flip & 1) * 16;
+  if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
   __syncthreads();
   float s = 0.f;
 #pragma unroll
-  for (int w = 0; w < AT / 64; ++w) s += red[w];
+  for (int w = 0; w < AT / 64; ++w) s += r[w];
   return s;
 }
 
-// GroupNorm(1 group) over C x T, per-channel affine, optional residual add and ReLU, in place.
+// GroupNorm(1 group) over C x T (<= 6 * AT elements), per-channel affine, optional residual add and ReLU, in place.
+// Every thread keeps its elements in registers across the three phases and requests its affine parameters (global
+// memory) before the first reduction, so their latency hides behind the two block reductions.
+#define GN_NE 6
 __device__ __forceinline__ void gn(float *buf, int C, int T, const float *__restrict__ g,
                                    const float *__restrict__ b, const float *resid, bool relu, float *red) {
   const int n = C * T;
+  float x[GN_NE], gg[GN_NE], bb[GN_NE];
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += AT) s += buf[i];
-  const float mean = block_sum_a(s, red) / (float)n;
+#pragma unroll
+  for (int e = 0; e < GN_NE; ++e) {
+    const int i = threadIdx.x + e * AT;
+    if (i < n) {
+      const int c = i / T;
+      x[e] = buf[i];
+      gg[e] = g[c];
+      bb[e] = b[c];
+      s += x[e];
+    }
+  }
+  const float mean = block_sum_a(s, red, 0) / (float)n;
   float v = 0.f;
-  for (int i = threadIdx.x; i < n; i += AT) { const float d = buf[i] - mean; v = fmaf(d, d, v); }
-  const float rstd = 1.0f / sqrtf(block_sum_a(v, red) / (float)n + 1e-5f);
-  for (int i = threadIdx.x; i < n; i += AT) {
-    const int c = i / T;
-    float y = (buf[i] - mean) * rstd * g[c] + b[c];
-    if (resid) y += resid[i];
-    if (relu) y = fmaxf(y, 0.f);
-    buf[i] = y;
+#pragma unroll
+  for (int e = 0; e < GN_NE; ++e)
+    if ((int)threadIdx.x + e * AT < n) { const float d = x[e] - mean; v = fmaf(d, d, v); }
+  const float rstd = 1.0f / sqrtf(block_sum_a(v, red, 1) / (float)n + 1e-5f);
+#pragma unroll
+  for (int e = 0; e < GN_NE; ++e) {
+    const int i = threadIdx.x + e * AT;
+    if (i < n) {
+      float y = (x[e] - mean) * rstd * gg[e] + bb[e];
+      if (resid) y += resid[i];
+      if (relu) y = fmaxf(y, 0.f);
+      buf[i] = y;
+    }
   }
   __syncthreads();
 }
@@ -373,16 +473,16 @@ __device__ __forceinline__ void res1d(const float *in, int Cin, int Tin, const R
     if (stride == 1) conv<1, 1>(in, Cin, Tin, w.ds, Cout, Tout, t2, part, pf);
     else conv<2, 1>(in, Cin, Tin, w.ds, Cout, Tout, t2, part, pf);
     __syncthreads();
-    gn(t2, Cout, Tout, w.gd, w.bd, nullptr, false, red);
-    resid = t2;
+      gn(t2, Cout, Tout, w.gd, w.bd, nullptr, false, red);
+      resid = t2;
   }
   gn(out, Cout, Tout, w.g2, w.b2, resid, true, red);
 }
 
 // LDS carve (floats): xin 672 | o0 1536 | o1 1536 | o2 1536 | o3 1536 | ta 1536 | tb 1536 | tc 1536
 //                     | fa 6144 | fb 6144 ; the final Res1d output reuses the (dead) o0..tc region.
-#define ACT_PART 6144
-#define ACT_LDS_FLOATS (672 + 7 * 1536 + 2 * 6144 + 16 + ACT_PART)
+#define ACT_PART 12288
+#define ACT_LDS_FLOATS (672 + 7 * 1536 + 2 * 6144 + 32 + ACT_PART)
 __global__ __launch_bounds__(AT) void k_actor_net(const float *__restrict__ actors, int n_actors,
                                                   float *__restrict__ out, ActorW W) {
   extern __shared__ float sm[];
@@ -391,7 +491,7 @@ __global__ __launch_bounds__(AT) void k_actor_net(const float *__restrict__ acto
   float *ta = o3 + 1536, *tb = ta + 1536, *tc = tb + 1536;
   float *fa = tc + 1536, *fb = fa + 6144;
   float *red = fb + 6144;
-  float *part = red + 16;
+  float *part = red + 32;
   const int pf = ACT_PART;
   float *fo = o0;  // 10752 floats available, needs 6144
   const int tid = threadIdx.x;
@@ -482,7 +582,8 @@ struct DecW {
   const float *T, *Tp;                                                           // [60][8], [60][7]
 };
 
-#define DEC_SCENE_LDS_FLOATS (256 + 768 + 768 + 2304 + 768 + 9216 + 768 + 144 + 6144)
+#define DEC_SCENE_PART 24576
+#define DEC_SCENE_LDS_FLOATS (256 + 768 + 768 + 2304 + 768 + 9216 + 768 + 144 + DEC_SCENE_PART)
 __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*[tokens,128]*/,
                                                   const int *__restrict__ cls_row /*[B]*/,
                                                   const float *__restrict__ tgt_feat /*[B,128]*/,
@@ -500,7 +601,7 @@ __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*
   float (*t2)[128] = (float (*)[128])(dsm + 14080);
   float (*sc)[6][6] = (float (*)[6][6])(dsm + 14848);
   float *part = dsm + 14992;
-  const int PF = 6144;
+  const int PF = DEC_SCENE_PART;
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   // ---- target embedding (network.py:491-495)
