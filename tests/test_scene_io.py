@@ -253,3 +253,26 @@ def test_replay_world_drives_closed_loop(worlds, name):
     graph = U.lane_graph_from_map(lcl.map_data, orig, rot)
     assert graph["num_lanes"] >= len(w.vector_lane_segments)
     assert lcl.ego_agent.id == "AV" and len(lcl.exo_agents) == w.n_agents - 1
+
+
+def test_replay_world_closed_loop_agent_options(scenes):
+    """configs/demo_*.json: semantic_lane -1 = closest lane, an id = that lane; target_velocity -1 = mean recorded speed
+    (loader.py:56-63, agent.py:164-166)."""
+    smap, sc, meta = scenes["demo_3"]
+    base = scene_io.ReplayWorld(smap, sc, dict(id="AV", enable_timestep=2.5, semantic_lane=-1, target_velocity=-1))
+    assert base.enable_time == 2.5
+    assert base.target_velocity == pytest.approx(float(np.mean(base.vel[0])))
+    lane_id = scene_io.get_closest_semantic_lane(base.smp, base.pos[0], base.ang[0])
+    forced = scene_io.ReplayWorld(smap, sc, dict(id="AV", enable_timestep=4.0, semantic_lane=int(lane_id), target_velocity=6))
+    assert forced.target_velocity == 6 and np.array_equal(forced.target_lane, base.target_lane)
+    other = (lane_id + 1) % len(base.smp.semantic_lanes)
+    w2 = scene_io.ReplayWorld(smap, sc, dict(id="AV", enable_timestep=4.0, semantic_lane=int(other), target_velocity=6))
+    assert np.array_equal(w2.target_lane, base.smp.semantic_lanes[other])
+    # the spliced target lane starts on the recorded path and ends on the chosen semantic lane
+    assert np.array_equal(w2.gt_tgt_lane[0], base.pos[0][0]) or np.linalg.norm(w2.gt_tgt_lane[0] - base.pos[0][0]) < 0.2
+    assert np.array_equal(w2.gt_tgt_lane[-1], base.smp.semantic_lanes[other][-1]) or \
+        np.linalg.norm(w2.gt_tgt_lane[-1] - base.smp.semantic_lanes[other][-1]) <= 4.0
+    with pytest.raises(ValueError):
+        scene_io.ReplayWorld(smap, sc, dict(id="AV", semantic_lane=10_000))
+    with pytest.raises(ValueError):
+        scene_io.ReplayWorld(smap, sc, dict(id="no-such-track"))
