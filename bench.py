@@ -88,7 +88,9 @@ def make_closed_loop(wkw, scripted=True, full_tree=False):
     # curved recorded target lane, so they are kept for the synthetic worlds only
     if scripted and "scene" not in wkw:
         pl.scen_tree_gen.network = (ScriptedFullTree if full_tree else ScriptedBranching)(pl.network)
-    sim = ClosedLoopSim(w, pl)
+    # episodes: the reference's 60 cycles for a recording; 24 for the synthetic worlds (all eight seeds the weak-scaling
+    # and concurrent modes use stay on their lane that long; the default 3 + 20 cycles fit in one episode)
+    sim = ClosedLoopSim(w, pl, episode_plans=60 if "scene" in wkw else 24)
     sim.run_until(sim.enable_time)
     return pl, sim, w
 

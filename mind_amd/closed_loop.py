@@ -31,22 +31,42 @@ class ClosedLoopSim:
     PLAN_STEP = 1.0 / 10 - 1e-4
     WB, MAX_SPD, MAX_STR = 3.0, 15.0, np.deg2rad(45.0)
 
-    def __init__(self, world, planner, enable_time=None):
+    def __init__(self, world, planner, enable_time=None, episode_plans=None):
         self.world = world
         self.planner = planner
         self.enable_time = enable_time if enable_time is not None else getattr(world, "enable_time", 4.0)
-        self.sim_time = 0.0
         self.n_steps = 0
         self.n_plans = 0
-        self.enabled = False
-        self.last_trigger = None
-        self.state = world.agent_state(0, 0.0)          # (x, y, v, yaw)
-        self.ctrl = np.array([0.0, 0.0])
-        self.timestep = 0.0
-        self.last_result = None
+        # episode_plans = E: after E planning cycles the scene starts over from t = 0 (the reference's runs are
+        # episodes too: 500 steps = 60 cycles).  Long throughput runs need it: a recording ends after 11 s, and the
+        # synthetic worlds' non-reactive scripted agents eventually push the ego out of every mode's reach.
+        self.episode_plans = episode_plans
+        self.n_episodes = 0
         gt_lane = getattr(world, "gt_tgt_lane", None)
         planner.update_target_lane(np.asarray(world.target_lane[::2], dtype=np.float64) if gt_lane is None else gt_lane)
         self._valid = getattr(world, "is_valid", None)
+        self._start_episode()
+
+    def _start_episode(self):
+        self.sim_time = 0.0
+        self.enabled = False
+        self.last_trigger = None
+        self.state = self.world.agent_state(0, 0.0)     # (x, y, v, yaw)
+        self.ctrl = np.array([0.0, 0.0])
+        self.timestep = 0.0
+        self.last_result = None
+        self._episode_plan0 = self.n_plans
+        if hasattr(self.planner, "agent_obs"):
+            self.planner.agent_obs.clear()
+
+    def reset(self):
+        """Start the next episode: scene back to t = 0, observation history rebuilt up to the enable time (these
+        replay steps are not counted in n_steps)."""
+        n = self.n_steps
+        self._start_episode()
+        self.n_episodes += 1
+        self.run_until(self.enable_time)
+        self.n_steps = n
 
     def _observation(self):
         t = self.sim_time
@@ -91,5 +111,9 @@ class ClosedLoopSim:
         """advance until n more plans were computed; returns the number of simulator steps taken."""
         s0, p0 = self.n_steps, self.n_plans
         while self.n_plans - p0 < n:
+            if self.episode_plans is not None and self.n_plans - self._episode_plan0 >= self.episode_plans:
+                s_keep = self.n_steps - s0
+                self.reset()
+                s0 = self.n_steps - s_keep
             self.step()
         return self.n_steps - s0

@@ -110,3 +110,34 @@ def test_closed_loop_on_recorded_demo_scene(scene):
             assert np.allclose(da[0], db[0], rtol=1e-5)
             assert da[1].shape == db[1].shape and np.abs(da[1] - db[1]).max() < tol
     assert best_d == best_h and np.abs(st_d - st_h).max() < 5e-2
+
+
+def test_episodes_restart_the_scene():
+    """episode_plans = E: after E planning cycles the scene starts over (history rebuilt up to the enable time); the
+    replayed steps are not counted, every episode repeats the same trigger schedule."""
+    w = SynthWorld(n_agents=3, n_lanes=2, n_segs=6, seed=1)
+
+    class P(_StubPlanner):
+        def __init__(self):
+            super().__init__()
+            self.agent_obs = {"x": 1}
+            self.times = []
+
+        def plan(self, lcl):
+            self.times.append(round(lcl.ego_agent.timestep * 0.1, 3))
+            self.agent_obs["seen"] = True
+            return True, np.array([0.5, 0.0]), None
+
+    p = P()
+    sim = ClosedLoopSim(w, p, episode_plans=3)
+    assert p.agent_obs == {}                                   # a new episode starts from an empty observation history
+    sim.run_until(4.0)
+    steps = sim.run_plans(7)
+    assert sim.n_plans == 7 and sim.n_episodes == 2
+    assert p.times == [4.0, 4.1, 4.2] * 2 + [4.0]
+    assert steps == 1 + 5 + 5 + 1 + 5 + 5 + 1                  # only the steps that lead to a plan inside an episode count
+    assert sim.sim_time < 4.1 and "seen" in p.agent_obs
+    free = ClosedLoopSim(w, P())                               # default: one open-ended episode
+    free.run_until(4.0)
+    free.run_plans(7)
+    assert free.n_episodes == 0 and free.planner.times[-1] == 4.6
