@@ -12,7 +12,7 @@ copied) and replace the Theano dynamics with the closed-form Jacobian of the
 six expressions at planners/mind/trajectory_tree.py:168-175.
 
 Nothing here travels to the GPU box as a dependency: tests/bench/smoke never
-import this module; only tools/gen_golden.py and the `-m "not gpu"` pinning
+import this module; only tests/golden/gen_golden.py and the `-m "not gpu"` pinning
 tests (skipped when /root/reference is missing) do.
 """
 import enum

@@ -1,11 +1,11 @@
 """GPU-box diagnostic: stage-by-stage comparison of the HIP predictor with the CPU oracle.
-Usage (on the GPU box): python tools/gpu_diag_predictor.py [--big]
+Usage (on the GPU box): python tests/diag/gpu_diag_predictor.py [--big]
 """
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 

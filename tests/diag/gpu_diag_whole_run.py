@@ -1,6 +1,6 @@
 """GPU-box diagnostic: teacher-forced whole run on a recorded scene, per-cycle differences against tests/golden/demo_runs.npz."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from bench import WORKLOADS, make_closed_loop

@@ -1,13 +1,13 @@
 """Generate tests/golden/*.npz from the IMPORTED REFERENCE (build container only).
 
 The reference Python cannot travel to the GPU box; these small fixtures (inputs are formula
-generated, so only expected outputs are stored) can.  Re-run:  python tools/gen_golden.py [section ...]
+generated, so only expected outputs are stored) can.  Re-run:  python tests/golden/gen_golden.py [section ...]
 Sections: predictor rpe potential ilqr aime plan scenes demo_plans demo_runs
 """
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_potential_field_matches_reference_golden(hip_predictor):
     """G4: value / gradient / Hessian on a random 32x32 field incl. the 8 border cases and .5 rounding ties
-    (values produced by the reference's PotentialField, tools/gen_golden.py potential)."""
+    (values produced by the reference's PotentialField, tests/golden/gen_golden.py potential)."""
     g = dict(np.load(os.path.join(ROOT, "tests", "golden", "potential.npz")))
     F, off, res = g["F"], g["off"], float(g["res"])
     H, W = F.shape

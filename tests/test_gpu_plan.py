@@ -118,7 +118,7 @@ def test_bench_prints_one_contract_json_line():
 def test_recorded_demo_scenes_match_reference_closed_loop(scene):
     """North-star parity on the reference's four recorded AV2 scenes: the reference's own simulator loop (headless,
     CPU, formula weights -- its trained checkpoint is not in the tree) was run to the first four planning cycles
-    (tools/gen_golden.py demo_plans); the same closed loop here must pick the same AIME branch every cycle and
+    (tests/golden/gen_golden.py demo_plans); the same closed loop here must pick the same AIME branch every cycle and
     reproduce agent / ego trajectories within 1e-3 m (+ float32 resolution of the ~6.5 km map coordinates)."""
     sys.path.insert(0, ROOT)
     from bench import WORKLOADS, make_closed_loop
@@ -180,7 +180,7 @@ def _solution_moves_under_rounding_noise(solve, args, xs_ref):
 @pytest.mark.parametrize("scene", ["demo_1", "demo_2", "demo_3", "demo_4"])
 def test_recorded_demo_scenes_whole_run_teacher_forced(scene):
     """Every planning cycle of the reference's whole closed loop on the recorded scenes (t = 4.0 .. 9.9 s, 60 cycles,
-    tools/gen_golden.py demo_runs), teacher-forced: before each cycle the ego state / control are set to the ones the
+    tests/golden/gen_golden.py demo_runs), teacher-forced: before each cycle the ego state / control are set to the ones the
     reference planned from (free-running loops drift apart once a discrete decision flips).
     Compared in EVERY cycle: number of scenario trees, AIME branch ids, tracked agents, root probability, agent
     trajectories and covariances (every 4th cycle is stored).

@@ -1,5 +1,5 @@
 """CPU: the C tree-iLQR oracle against golden vectors captured from the imported reference
-(tools/gen_golden.py: ilqr, potential) and, in the build container, against the reference itself."""
+(tests/golden/gen_golden.py: ilqr, potential) and, in the build container, against the reference itself."""
 import os
 
 import numpy as np

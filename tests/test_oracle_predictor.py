@@ -1,5 +1,5 @@
 """CPU: the oracle predictor restatement against the committed golden vectors (captured from the
-imported reference by tools/gen_golden.py) and, in the build container, against the reference itself."""
+imported reference by tests/golden/gen_golden.py) and, in the build container, against the reference itself."""
 import numpy as np
 import pytest
 import torch

@@ -3,7 +3,7 @@
 Two layers, two kinds of evidence:
   * mind_amd.scene_io restates the reference's OWN scene logic (semantic lanes, track selection / padding /
     resampling, target lane).  tests/golden/scene_io.npz holds what the reference's code produced on its four
-    demo scenes (tools/gen_golden.py scenes) -> exact comparison.
+    demo scenes (tests/golden/gen_golden.py scenes) -> exact comparison.
   * mind_amd.av2_lite restates the two av2 readers underneath (av2 is not importable here): UNPINNED, checked by
     geometry invariants and, in the build container, against the raw files.
 """
