@@ -1,0 +1,38 @@
+"""Worker for tests/test_gpu_sharded.py: one rank of a gloo group (all ranks on the one GPU of the box) planning the SAME
+scene with AIME rounds and contingency solves sharded over the ranks; writes what it planned."""
+import os
+import pickle
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch.distributed as dist
+
+
+def main(out_path, n_plans):
+    from bench import WORKLOADS, make_closed_loop
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    pl, sim, w = make_closed_loop(dict(WORKLOADS["demo1"]))
+    if world > 1:
+        sh = pl.enable_sharding()
+        assert sh.world == world
+    res = []
+    for _ in range(n_plans):
+        sim.run_plans(1)
+        scen, traj = sim.last_result
+        res.append(dict(ctrl=np.array(sim.ctrl), best=pl.timing["best_traj_idx"], n_trees=pl.timing["n_scen_trees"],
+                        keys=[list(t.nodes.keys()) for t in pl.scen_tree_gen.get_scenario_tree()],
+                        xs=np.array([n.data[0] for k, n in traj[0].nodes.items() if k != -1]),
+                        pos0=next(iter(scen[0].nodes.values())).data[1]))
+    with open(out_path, "wb") as f:
+        pickle.dump(dict(res=res, expanded=pl.scen_tree_gen.n_expanded), f)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]))
