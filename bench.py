@@ -259,6 +259,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="demo1", choices=list(WORKLOADS))
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for --gpus N > 1 (nccl = RCCL; gloo only for tests on a single-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recorded", action="store_true", help="skip the extra closed loops on the four recorded demo scenes")
     ap.add_argument("--concurrent", type=int, default=0,
@@ -278,7 +280,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":       # RCCL over xGMI: one rank per GPU
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:                            # gloo: the same code path on a box with fewer GPUs than ranks (tests)
+            dist.init_process_group(args.backend)
     if args.concurrent > 1:
         return run_concurrent_processes(args) if args.processes else run_concurrent(args)
     wkw = dict(WORKLOADS[args.workload])
@@ -348,10 +353,11 @@ def main():
     rt.set_profiling(False)
     lcl = sim._observation()
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        red_dev = "cuda" if args.backend == "nccl" else "cpu"
+        t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        e = torch.tensor([expansions], device="cuda", dtype=torch.float64)
+        e = torch.tensor([expansions], device=red_dev, dtype=torch.float64)
         dist.all_reduce(e)
         expansions_all = float(e.item())
     else:

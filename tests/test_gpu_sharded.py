@@ -46,3 +46,39 @@ def test_two_sharded_ranks_plan_what_one_process_plans(tmp_path):
     assert len(single["res"][0]["keys"]) >= 2                                    # there was something to shard
     # every rank expanded only its block of each round's scenes
     assert r0["expanded"] + r1["expanded"] == single["expanded"] and 0 < r1["expanded"] < single["expanded"]
+
+
+def _bench_ranks(world, extra, port):
+    import json
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4",
+                                       "--warmup", "1", "--backend", "gloo"] + extra, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, e[-2000:]
+        outs.append([l for l in o.splitlines() if l.strip() and not l.startswith("[Gloo]")])   # gloo's own connection notice
+    assert len(outs[0]) == 1 and all(len(o) == 0 for o in outs[1:])             # rank 0 prints the ONE line
+    return json.loads(outs[0][0])
+
+
+def test_bench_multi_rank_contract_weak_and_strong():
+    """The launch contract of `bench.py --gpus N` with N = 2 ranks (gloo here, RCCL on a multi-GPU node): barrier +
+    max-over-ranks timing, whole-job value, one JSON line from rank 0.  Weak scaling: every rank plans its own scene;
+    --shard: both ranks plan the same scene."""
+    d = _bench_ranks(2, [], 29541)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4 and "cpu_baseline" not in d
+    assert d["config"]["sim_steps_timed"] == 20 and abs(d["value"] - 2 * 20 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+    assert d["nodes_expanded_per_s"] > 0 and d["roofline"]["frac"] > 0
+    s = _bench_ranks(2, ["--shard"], 29542)
+    assert s["n_gpus"] == 2 and s["scaling"] == "strong"
+    assert abs(s["value"] - 20 / (s["ms_per_step"] * 4e-3)) < 1e-6 * s["value"]   # one scene: steps are not multiplied by N
