@@ -142,6 +142,8 @@ class MINDPlanner:
         lane, info = self.resample_target_lane(lcl_smp)
         self.scen_tree_gen.set_target_lane(lane, info)
         n0 = self.scen_tree_gen.n_expanded
+        # warm-start fits of the previous cycle's tree shapes start now, beside the predictor (trajectory_tree.py)
+        self.traj_tree_opt.speculate_warm(self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)
         scen_trees = self.scen_tree_gen.branch_aime(lcl_smp, self.agent_obs)
         t1 = time.perf_counter()
         if len(scen_trees) < 0:

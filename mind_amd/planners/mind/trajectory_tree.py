@@ -70,6 +70,30 @@ def to_traj_tree(flat, x0, xs, us, action_size=2):
     return t
 
 
+class _SideContext:
+    """One background thread with its OWN HIP context on its own stream.  It only ever executes prepared tree-iLQR
+    calls (`IlqrCall.run`: one C call, GIL released), so it neither competes for the interpreter with the main thread's
+    AIME bookkeeping nor shares a stream with the predictor."""
+
+    def __init__(self, device):
+        from concurrent.futures import ThreadPoolExecutor
+        self.device = device
+        self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mind-ilqr-side")
+        self.rt = None
+
+    def _run(self, call):
+        if self.rt is None:
+            import torch
+            from ...predictor import HipPredictor
+            self.stream = torch.cuda.Stream(self.device)
+            with torch.cuda.stream(self.stream):
+                self.rt = HipPredictor(self.device)          # bound to this stream
+        return call.run(self.rt)
+
+    def submit(self, call):
+        return self.pool.submit(self._run, call)
+
+
 class TrajectoryTreeOptimizer:
     def __init__(self, config=None, runtime=None):
         self.config = config
@@ -79,6 +103,12 @@ class TrajectoryTreeOptimizer:
         self.cost_tree = None
         self.debug = None
         self._job = None
+        # speculative warm start (see speculate_warm)
+        self.speculative = True
+        self._worker = None
+        self._last_structs = []
+        self._spec = None
+        self.counters = {"solves": 0, "iterations": 0, "warm_speculated": 0, "warm_hits": 0}
 
     def _runtime(self):
         if self.rt is None:
@@ -115,6 +145,58 @@ class TrajectoryTreeOptimizer:
         xs, us = self._solve(us_init)
         return to_traj_tree(self._job["flat"], self._job["x0"], xs, us, self.config.action_size)
 
+    # ---- speculative warm start ---------------------------------------------------------------------------
+    # The warm-start fit (planner.py:174-176, trajectory_tree.py:19-60) sees the cost tree's SHAPE (parents, node
+    # probabilities), the ego state, the target lane and velocity -- no prediction.  All but the shape are known before
+    # the AIME rounds start, and consecutive planning cycles usually grow trees of the same shape.  So the fits of the
+    # previous cycle's shapes are started on a second stream when a cycle begins and run beside the predictor; after
+    # AIME, every tree whose shape was guessed right takes its warm-start controls from there (bit-identical: same
+    # kernel, same inputs) and only runs the full fit, the others run both fits as before.
+    @staticmethod
+    def _struct_key(par, prob):
+        return (len(par), par.tobytes(), prob.tobytes())
+
+    def speculate_warm(self, init_state, init_ctrl, target_lane, target_vel):
+        if not self.speculative or self.solver is not None or self.shard is not None or not self._last_structs:
+            return
+        from ...predictor import IlqrCall
+        x0 = self._get_init_state(init_state, init_ctrl)
+        lane = np.array(target_lane, dtype=np.float64)
+        # the warm-start cost has no agent term: one dummy agent per node
+        flats = [dict(parent=par, prob=prob, mean=np.zeros((len(par), 1, 2), np.float32), cov=np.zeros((len(par), 1), np.float32))
+                 for par, prob in self._last_structs]
+        call = IlqrCall(self._runtime().lib, ilqr_cfg_from(self.config, "w_opt_cfg"), flats, x0, lane, target_vel, use_exo=0)
+        self._spec = dict(x0=x0, lane=lane, tv=float(target_vel), structs=self._last_structs, call=call,
+                          fut=self._side().submit(call))
+        self.counters["warm_speculated"] += len(self._last_structs)
+
+    def _side(self):
+        if self._worker is None:
+            self._worker = _SideContext(self._runtime().device)
+        return self._worker
+
+    def _take_speculation(self, flats, x0, lane, target_vel):
+        """-> {index into flats: (us_warm, stats_warm)} for the trees whose warm-start fit is already done."""
+        spec, self._spec = self._spec, None
+        if spec is None:
+            return {}
+        try:
+            spec["fut"].result()
+            _, us, st = spec["call"].finish()
+        except Exception:
+            return {}
+        if not (np.array_equal(spec["x0"], x0) and np.array_equal(spec["lane"], lane) and spec["tv"] == float(target_vel)):
+            return {}
+        have = {}
+        for j, (par, prob) in enumerate(spec["structs"]):
+            have.setdefault(self._struct_key(par, prob), j)
+        hits = {}
+        for i, f in enumerate(flats):
+            j = have.get(self._struct_key(f["parent"], f["prob"]))
+            if j is not None:
+                hits[i] = (us[j], st[j])
+        return hits
+
     # all scenario trees of one plan: 2 launches (warm start, full) instead of 2 x n_trees solves
     def solve_batch(self, scen_trees, init_state, init_ctrl, target_lane, target_vel):
         flats = [flatten_scenario_tree(t) for t in scen_trees]
@@ -126,8 +208,34 @@ class TrajectoryTreeOptimizer:
         if mine:
             sub = [flats[i] for i in mine]
             if self.solver is None:      # warm start + full solve in one launch
-                xs, us, st_w, st = self._runtime().ilqr_contingency(ilqr_cfg_from(self.config, "w_opt_cfg"),
-                                                                    ilqr_cfg_from(self.config, "opt_cfg"), sub, x0, lane, target_vel)
+                cfg_w, cfg_f = ilqr_cfg_from(self.config, "w_opt_cfg"), ilqr_cfg_from(self.config, "opt_cfg")
+                hits = self._take_speculation(sub, x0, lane, target_vel) if self.shard is None else {}
+                self._last_structs = [(np.ascontiguousarray(f["parent"], np.int32), np.ascontiguousarray(f["prob"], np.float32)) for f in sub]
+                self.counters["warm_hits"] += len(hits)
+                xs, us, st_w, st = [None] * len(sub), [None] * len(sub), [None] * len(sub), [None] * len(sub)
+                from ...predictor import IlqrCall
+                hit_idx = sorted(hits)
+                miss_idx = [i for i in range(len(sub)) if i not in hits]
+                rt = self._runtime()
+                miss_call = miss_fut = None
+                if miss_idx:             # both fits, as without speculation
+                    miss_call = IlqrCall(rt.lib, cfg_w, [sub[i] for i in miss_idx], x0, lane, target_vel, cfg_full=cfg_f)
+                    if hit_idx:          # ... on the side context, beside the full fits of the guessed trees
+                        miss_fut = self._side().submit(miss_call)
+                    else:
+                        miss_call.run(rt)
+                if hit_idx:              # warm-start controls are there already: full fit only
+                    hx, hu, hs = rt.ilqr_solve(cfg_f, [sub[i] for i in hit_idx], x0, lane, target_vel, 1, [hits[i][0] for i in hit_idx])
+                    for k, i in enumerate(hit_idx):
+                        xs[i], us[i], st_w[i], st[i] = hx[k], hu[k], hits[i][1], hs[k]
+                if miss_idx:
+                    if miss_fut is not None:
+                        miss_fut.result()
+                    mx, mu_, mw, mf = miss_call.finish()
+                    for k, i in enumerate(miss_idx):
+                        xs[i], us[i], st_w[i], st[i] = mx[k], mu_[k], mw[k], mf[k]
+                self.counters["solves"] += 2 * len(sub)
+                self.counters["iterations"] += sum(s_["iterations"] for s_ in st_w) + sum(s_["iterations"] for s_ in st)
             else:
                 _, us_w, st_w = solve(ilqr_cfg_from(self.config, "w_opt_cfg"), sub, x0, lane, target_vel, 0, None)
                 xs, us, st = solve(ilqr_cfg_from(self.config, "opt_cfg"), sub, x0, lane, target_vel, 1, us_w)

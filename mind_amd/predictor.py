@@ -7,6 +7,66 @@ import torch
 from . import _lib
 
 
+class IlqrCall:
+    """One tree-iLQR call split into its three parts, so that a caller can prepare the arguments on its own thread, hand
+    only ``run`` (a single C call, which releases the GIL) to another thread / context and read the results later.
+    cfg_full given: mind_ilqr_contingency (warm-start fit with ``cfg``, then full fit with ``cfg_full``); otherwise
+    mind_ilqr_solve_trees with ``use_exo`` / ``us_init``."""
+
+    def __init__(self, lib, cfg, flats, x0, lane, target_vel, cfg_full=None, use_exo=1, us_init=None):
+        self.lib, self.cfg, self.cfg_full, self.use_exo = lib, cfg, cfg_full, int(use_exo)
+        n = self.n = len(flats)
+        self.trees = (_lib.CostTree * n)()
+        self.keep, self.Ms = [], []
+        for i, f in enumerate(flats):
+            par = np.ascontiguousarray(f["parent"], np.int32)
+            prob = np.ascontiguousarray(f["prob"], np.float32)
+            mean = np.ascontiguousarray(f["mean"], np.float32)
+            cov = np.ascontiguousarray(f["cov"], np.float32)
+            self.keep += [par, prob, mean, cov]
+            t = self.trees[i]
+            t.n_nodes = len(par)
+            t.parent = par.ctypes.data_as(C.POINTER(C.c_int32))
+            t.prob = prob.ctypes.data_as(C.POINTER(C.c_float))
+            t.n_agents = mean.shape[1]
+            t.agent_mean = mean.ctypes.data_as(C.POINTER(C.c_float))
+            t.agent_cov = cov.ctypes.data_as(C.POINTER(C.c_float))
+            self.Ms.append(len(par))
+        Mt = int(sum(self.Ms))
+        self.x0 = np.ascontiguousarray(x0, np.float64)
+        self.lane = np.ascontiguousarray(lane, np.float64)
+        self.tv = C.c_double(float(target_vel))
+        self.xs, self.us = np.zeros((Mt, 6)), np.zeros((Mt, 2))
+        self.st = (_lib.IlqrStats * n)()
+        self.st_full = (_lib.IlqrStats * n)() if cfg_full is not None else None
+        self.ui = None if us_init is None else np.ascontiguousarray(np.concatenate(us_init), np.float64)
+        self.rc, self.ctx = None, None
+
+    def run(self, rt):
+        """the launch (+ its synchronisation) on ``rt``'s context; nothing else happens here"""
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+        self.ctx = rt.ctx
+        if self.cfg_full is not None:
+            self.rc = self.lib.mind_ilqr_contingency(rt.ctx, C.byref(self.cfg), C.byref(self.cfg_full), self.trees, self.n, dp(self.x0),
+                                                     dp(self.lane), len(self.lane), self.tv, dp(self.xs), dp(self.us), self.st, self.st_full)
+        else:
+            self.rc = self.lib.mind_ilqr_solve_trees(rt.ctx, C.byref(self.cfg), self.trees, self.n, dp(self.x0), dp(self.lane),
+                                                     len(self.lane), self.tv, self.use_exo, dp(self.ui), dp(self.xs), dp(self.us), self.st)
+        return self
+
+    def finish(self):
+        name = "mind_ilqr_contingency" if self.cfg_full is not None else "mind_ilqr_solve_trees"
+        _lib.check(self.lib, self.ctx, self.rc, name)
+        offs = np.cumsum([0] + self.Ms)
+        n = self.n
+        stats = lambda s_: [dict(iterations=s_[i].iterations, converged=s_[i].converged, J=s_[i].J, mu=s_[i].mu) for i in range(n)]
+        xs = [self.xs[offs[i]:offs[i + 1]] for i in range(n)]
+        us = [self.us[offs[i]:offs[i + 1]] for i in range(n)]
+        if self.cfg_full is not None:
+            return xs, us, stats(self.st), stats(self.st_full)
+        return xs, us, stats(self.st)
+
+
 class HipPredictor:
     """Owns a ``mind_ctx`` bound to ``device`` and the current torch stream; ``load_state_dict`` mirrors
     ``ScenePredNet.load_state_dict`` (reference planners/mind/planner.py:46-48), ``predict`` mirrors
@@ -124,78 +184,20 @@ class HipPredictor:
         return out
 
     # ------------------------------------------------------------------------------------------
-    def _cost_trees(self, flats, keep):
-        n = len(flats)
-        trees = (_lib.CostTree * n)()
-        Ms = []
-        for i, f in enumerate(flats):
-            par = np.ascontiguousarray(f["parent"], np.int32)
-            prob = np.ascontiguousarray(f["prob"], np.float32)
-            mean = np.ascontiguousarray(f["mean"], np.float32)
-            cov = np.ascontiguousarray(f["cov"], np.float32)
-            keep += [par, prob, mean, cov]
-            trees[i].n_nodes = len(par)
-            trees[i].parent = par.ctypes.data_as(C.POINTER(C.c_int32))
-            trees[i].prob = prob.ctypes.data_as(C.POINTER(C.c_float))
-            trees[i].n_agents = mean.shape[1]
-            trees[i].agent_mean = mean.ctypes.data_as(C.POINTER(C.c_float))
-            trees[i].agent_cov = cov.ctypes.data_as(C.POINTER(C.c_float))
-            Ms.append(len(par))
-        return trees, Ms
-
     def ilqr_contingency(self, cfg_warm, cfg_full, flats, x0, lane, target_vel):
         """Warm-start fit + full fit of all cost trees of a plan in one launch (mind_ilqr_contingency).
         Returns (xs list[[M,6]], us list[[M,2]], stats_warm list[dict], stats_full list[dict])."""
-        keep = []
-        trees, Ms = self._cost_trees(flats, keep)
-        n, Mt = len(flats), int(sum(Ms))
-        x0 = np.ascontiguousarray(x0, np.float64)
-        lane = np.ascontiguousarray(lane, np.float64)
-        xs, us = np.zeros((Mt, 6)), np.zeros((Mt, 2))
-        sw, sf = (_lib.IlqrStats * n)(), (_lib.IlqrStats * n)()
-        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-        rc = self.lib.mind_ilqr_contingency(self.ctx, C.byref(cfg_warm), C.byref(cfg_full), trees, n, dp(x0), dp(lane), len(lane),
-                                            C.c_double(float(target_vel)), dp(xs), dp(us), sw, sf)
-        _lib.check(self.lib, self.ctx, rc, "mind_ilqr_contingency")
-        offs = np.cumsum([0] + Ms)
-        st = lambda s_: [dict(iterations=s_[i].iterations, converged=s_[i].converged, J=s_[i].J, mu=s_[i].mu) for i in range(n)]
-        return ([xs[offs[i]:offs[i + 1]] for i in range(n)], [us[offs[i]:offs[i + 1]] for i in range(n)], st(sw), st(sf))
+        call = IlqrCall(self.lib, cfg_warm, flats, x0, lane, target_vel, cfg_full=cfg_full)
+        call.run(self)
+        return call.finish()
 
     def ilqr_solve(self, cfg, flats, x0, lane, target_vel, use_exo, us_init=None):
         """Solve all cost trees of a plan in one launch.  ``flats``: list of dicts with parent int32 [M],
         prob f32 [M], mean f32 [M,a,2], cov f32 [M,a] (trajectory-node arrays in creation order);
         ``cfg``: ``_lib.IlqrCfg``.  Returns (xs list[[M,6]], us list[[M,2]], stats list[dict])."""
-        n = len(flats)
-        trees = (_lib.CostTree * n)()
-        keep = []
-        Ms = []
-        for i, f in enumerate(flats):
-            par = np.ascontiguousarray(f["parent"], np.int32)
-            prob = np.ascontiguousarray(f["prob"], np.float32)
-            mean = np.ascontiguousarray(f["mean"], np.float32)
-            cov = np.ascontiguousarray(f["cov"], np.float32)
-            keep += [par, prob, mean, cov]
-            trees[i].n_nodes = len(par)
-            trees[i].parent = par.ctypes.data_as(C.POINTER(C.c_int32))
-            trees[i].prob = prob.ctypes.data_as(C.POINTER(C.c_float))
-            trees[i].n_agents = mean.shape[1]
-            trees[i].agent_mean = mean.ctypes.data_as(C.POINTER(C.c_float))
-            trees[i].agent_cov = cov.ctypes.data_as(C.POINTER(C.c_float))
-            Ms.append(len(par))
-        Mt = int(sum(Ms))
-        x0 = np.ascontiguousarray(x0, np.float64)
-        lane = np.ascontiguousarray(lane, np.float64)
-        xs = np.zeros((Mt, 6))
-        us = np.zeros((Mt, 2))
-        st = (_lib.IlqrStats * n)()
-        ui = None if us_init is None else np.ascontiguousarray(np.concatenate(us_init), np.float64)
-        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
-        rc = self.lib.mind_ilqr_solve_trees(self.ctx, C.byref(cfg), trees, n, dp(x0), dp(lane), len(lane),
-                                            C.c_double(float(target_vel)), int(use_exo), dp(ui), dp(xs), dp(us), st)
-        _lib.check(self.lib, self.ctx, rc, "mind_ilqr_solve_trees")
-        offs = np.cumsum([0] + Ms)
-        return ([xs[offs[i]:offs[i + 1]] for i in range(n)], [us[offs[i]:offs[i + 1]] for i in range(n)],
-                [dict(iterations=st[i].iterations, converged=st[i].converged, J=st[i].J, mu=st[i].mu) for i in range(n)])
+        call = IlqrCall(self.lib, cfg, flats, x0, lane, target_vel, use_exo=use_exo, us_init=us_init)
+        call.run(self)
+        return call.finish()
 
     # ---- planners/ilqr surface: arbitrary materialised fields + per-node quadratic potentials -------------
     @staticmethod

@@ -9,6 +9,7 @@ D = np.load(os.path.join(ROOT, "tests", "golden", "demo_runs.npz"))
 pl, sim, w = make_closed_loop(dict(WORKLOADS[scene]), scripted=False)
 from oracle import ilqr as oi
 rt = pl.network.rt
+pl.traj_tree_opt.speculative = False      # this diagnostic captures the arguments of the one-launch contingency call
 cap = {}
 orig_cont = rt.ilqr_contingency
 def capture(*a, **k):

@@ -194,16 +194,20 @@ def test_recorded_demo_scenes_whole_run_teacher_forced(scene):
     from bench import WORKLOADS, make_closed_loop
     D = np.load(os.path.join(ROOT, "tests", "golden", "demo_runs.npz"))
     pl, sim, w = make_closed_loop(dict(WORKLOADS[scene]), scripted=False)
-    rt = pl.network.rt
+    from mind_amd.planners.mind.trajectory_tree import flatten_scenario_tree, ilqr_cfg_from
+    rt, opt = pl.network.rt, pl.traj_tree_opt
     cap = {}
-    orig_cont = rt.ilqr_contingency
+    orig_batch = opt.solve_batch
 
-    def capture(*a, **k):
-        r = orig_cont(*a, **k)
-        cap["args"], cap["xs"] = a, r[0]
-        return r
+    def capture(scen_trees, init_state, init_ctrl, target_lane, target_vel):     # what the contingency solves were given
+        trees = orig_batch(scen_trees, init_state, init_ctrl, target_lane, target_vel)
+        cap["args"] = (ilqr_cfg_from(opt.config, "w_opt_cfg"), ilqr_cfg_from(opt.config, "opt_cfg"),
+                       [flatten_scenario_tree(scen_trees[0])], opt._get_init_state(init_state, init_ctrl),
+                       np.asarray(target_lane, np.float64), target_vel)
+        cap["xs"] = trees[0]._arrays[0][1:]
+        return trees
 
-    rt.ilqr_contingency = capture
+    opt.solve_batch = capture
     ulp = float(np.spacing(np.float32(np.abs(w.pos[0, 0]).max())))
     tol = 1e-3 + 2 * ulp
     state_in, ctrl_in, ctrl_out = D[scene + "_state_in"], D[scene + "_ctrl_in"], D[scene + "_ctrl_out"]
@@ -238,9 +242,35 @@ def test_recorded_demo_scenes_whole_run_teacher_forced(scene):
         if d_ego < tol and d_ctrl < 2e-3:
             agree += 1
             continue
-        moved = _solution_moves_under_rounding_noise(orig_cont, cap["args"], cap["xs"][0])
+        moved = _solution_moves_under_rounding_noise(rt.ilqr_contingency, cap["args"], cap["xs"])
         assert moved > tol, (pi, d_ego, d_ctrl, moved)       # a well-conditioned cycle that disagrees is a real failure
         ill.append(pi)
     assert worst_agents < tol, worst_agents
     assert agree >= 0.8 * n, (agree, ill)
+    # these scenes grow one chain-shaped tree every cycle: from the second cycle on the warm-start fit is the one that ran
+    # beside the predictor (speculate_warm) -- the comparisons above therefore cover that path
+    assert opt.counters["warm_hits"] >= n - 2, opt.counters
     print(f"[{scene}] {agree}/{n} cycles agree outright; ill-conditioned cycles: {ill}")
+
+
+@pytest.mark.parametrize("workload", ["demo1", "demo_1"])
+def test_speculative_warm_start_is_bit_identical(workload):
+    """The warm-start fits that run beside the predictor (previous cycle's tree shapes, second stream, own HIP context)
+    give exactly the controls the in-line path computes: same closed loop with and without speculation."""
+    sys.path.insert(0, ROOT)
+    from bench import WORKLOADS, make_closed_loop
+    runs = {}
+    for spec in (True, False):
+        pl, sim, w = make_closed_loop(dict(WORKLOADS[workload]))
+        pl.traj_tree_opt.speculative = spec
+        out = []
+        for _ in range(6):
+            sim.run_plans(1)
+            tt = sim.last_result[1][0]
+            out.append((np.array(sim.ctrl), tt._arrays[0].copy(), tt._arrays[1].copy(), pl.timing["best_traj_idx"]))
+        runs[spec] = (out, dict(pl.traj_tree_opt.counters))
+    for (c1, x1, u1, b1), (c2, x2, u2, b2) in zip(runs[True][0], runs[False][0]):
+        assert b1 == b2 and np.array_equal(c1, c2) and np.array_equal(x1, x2) and np.array_equal(u1, u2)
+    on, off = runs[True][1], runs[False][1]
+    assert off["warm_speculated"] == 0 and off["warm_hits"] == 0
+    assert on["warm_hits"] >= 3 and on["solves"] == off["solves"] and on["iterations"] == off["iterations"]
