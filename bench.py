@@ -70,7 +70,7 @@ def make_planner(wkw, scripted=True):
     return pl, lcl, w
 
 
-def make_closed_loop(wkw, scripted=True, full_tree=False):
+def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True):
     """planner + closed-loop simulator advanced to the enable time (t = 4.0 s: 40 observation updates)."""
     from mind_amd.closed_loop import ClosedLoopSim
     from mind_amd.planners.mind.planner import MINDPlanner
@@ -90,6 +90,9 @@ def make_closed_loop(wkw, scripted=True, full_tree=False):
         pl.scen_tree_gen.network = (ScriptedFullTree if full_tree else ScriptedBranching)(pl.network)
     # episodes: the reference's 60 cycles for a recording; 24 for the synthetic worlds (all eight seeds the weak-scaling
     # and concurrent modes use stay on their lane that long; the default 3 + 20 cycles fit in one episode)
+    # speculative warm start = a second HIP context per planner: a latency lever for a GPU that one closed loop leaves idle;
+    # with many scenes sharing the device the extra contexts cost more than they hide (measured: 8 processes 3150 -> 2010)
+    pl.traj_tree_opt.speculative = speculative
     sim = ClosedLoopSim(w, pl, episode_plans=60 if "scene" in wkw else 24)
     sim.run_until(sim.enable_time)
     return pl, sim, w
@@ -162,10 +165,10 @@ def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees):
             "plan_ms": plan_s * 1e3}
 
 
-def _proc_scene(i, workload, steps, warmup, ready, go, q):
+def _proc_scene(i, workload, steps, warmup, ready, go, q, speculative):
     """One scene in its own process (own HIP context): signals ready, waits for the common start, reports back."""
     import torch as th
-    pl, sim, w = make_closed_loop(scene_workload(workload, i), full_tree=workload == "cfg4tree")
+    pl, sim, w = make_closed_loop(scene_workload(workload, i), full_tree=workload == "cfg4tree", speculative=speculative)
     sim.run_plans(max(warmup, 1))
     th.cuda.synchronize()
     ready.wait()
@@ -181,7 +184,7 @@ def run_concurrent_processes(args):
     ctx = mp.get_context("spawn")
     P = args.concurrent
     ready, go, q = ctx.Barrier(P + 1), ctx.Barrier(P + 1), ctx.Queue()
-    procs = [ctx.Process(target=_proc_scene, args=(i, args.workload, args.steps, args.warmup, ready, go, q)) for i in range(P)]
+    procs = [ctx.Process(target=_proc_scene, args=(i, args.workload, args.steps, args.warmup, ready, go, q, P <= 4)) for i in range(P)]
     for p_ in procs:
         p_.start()
     ready.wait(timeout=600)
@@ -214,7 +217,7 @@ def run_concurrent(args):
     def worker(i):
         try:
             with torch.cuda.stream(torch.cuda.Stream()):
-                pl, sim, w = make_closed_loop(scene_workload(args.workload, i), full_tree=args.workload == "cfg4tree")
+                pl, sim, w = make_closed_loop(scene_workload(args.workload, i), full_tree=args.workload == "cfg4tree", speculative=P <= 4)
                 sim.run_plans(max(args.warmup, 1))
                 torch.cuda.current_stream().synchronize()
                 loops[i] = (pl, sim)
