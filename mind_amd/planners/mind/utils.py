@@ -62,16 +62,21 @@ def _nn_fill(vals, have):
 
 
 def _agent_trajectories_full_windows(agent_obs, keys, order):
-    """Same result as the per-agent loop of get_agent_trajectories when every kept track carries a full
-    OBS_LEN-row array mirror (the steady state of the closed loop): all agents in one set of array ops."""
+    """Same result as the per-agent loop of get_agent_trajectories, all agents in one set of array ops.  Needs the
+    array mirror of every kept track (maintained by MINDPlanner.update_observation); tracks shorter than OBS_LEN
+    (agents that appeared less than 5 s ago) are left-padded with unobserved rows, which is where the per-agent
+    loop places them (`ts = arange(OBS_LEN - n, OBS_LEN)`)."""
     sel, raws = [], []
     for rank, ki in enumerate(order):
         tr = agent_obs[keys[ki]]
         if tr.object_states[-1].observed is False:
             continue
         raw = getattr(tr, "_arr", None)
-        if raw is None or len(raw) != OBS_LEN or len(tr.object_states) != OBS_LEN:
+        n = len(tr.object_states)
+        if raw is None or len(raw) != n or n > OBS_LEN:
             return None
+        if n < OBS_LEN:
+            raw = np.concatenate([np.zeros((OBS_LEN - n, raw.shape[1]), raw.dtype), raw])
         sel.append((rank, keys[ki], tr))
         raws.append(raw)
     raw = np.stack(raws)                                   # [a,50,6] float64

@@ -114,9 +114,10 @@ def test_agent_trajectories_vectorised_path_equals_per_agent_loop(monkeypatch):
     from mind_amd.planners.mind import utils as U
     rng = np.random.default_rng(0)
     agent_obs = {}
-    for i, key in enumerate(["x3", "AV", "x1", "x2", "x7"]):
+    for i, key in enumerate(["x3", "AV", "x1", "x2", "x7", "s9", "s1"]):
         states, rows = [], []
-        for t in range(50):
+        t_first = {"s9": 41, "s1": 49}.get(key, 0)             # short tracks: agents that appeared 0.9 s / just now
+        for t in range(t_first, 50):
             seen = not (key == "x1" and t < 7) and not (key == "x2" and 20 <= t < 26) and not (key == "x7" and t == 49)
             p, h, v = rng.normal(size=2) * 30, rng.uniform(-3, 3), rng.normal(size=2) * 4
             states.append(SimpleNamespace(observed=seen, timestep=t, position=(p[0], p[1]), heading=h, velocity=(v[0], v[1])))
@@ -126,7 +127,8 @@ def test_agent_trajectories_vectorised_path_equals_per_agent_loop(monkeypatch):
     fast = U.get_agent_trajectories(agent_obs)
     monkeypatch.setattr(U, "_agent_trajectories_full_windows", lambda *a: None)
     slow = U.get_agent_trajectories(agent_obs)
-    assert fast[5] == slow[5] == ["AV", "x3", "x1", "x2"] and fast[6] == slow[6]      # x7 unobserved now: skipped; AV first
+    assert fast[5] == slow[5] == ["AV", "x3", "x1", "x2", "s9", "s1"] and fast[6] == slow[6]   # x7 unobserved now: skipped; AV first
+    assert fast[4][4].sum() == 9 and fast[4][5].sum() == 1                                      # short tracks sit at the end of the window
     for f, s_ in zip(fast[:5], slow[:5]):
         assert f.dtype == s_.dtype and np.array_equal(f, s_)
 
