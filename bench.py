@@ -92,7 +92,7 @@ def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True):
     # and concurrent modes use stay on their lane that long; the default 3 + 20 cycles fit in one episode)
     # speculative warm start = a second HIP context per planner: a latency lever for a GPU that one closed loop leaves idle;
     # with many scenes sharing the device the extra contexts cost more than they hide (measured: 8 processes 3150 -> 2010)
-    pl.traj_tree_opt.speculative = speculative
+    pl.traj_tree_opt.speculative = speculative and pl.traj_tree_opt.speculative      # MIND_SPECULATIVE_WARM_START=0 switches it off
     sim = ClosedLoopSim(w, pl, episode_plans=60 if "scene" in wkw else 24)
     sim.run_until(sim.enable_time)
     return pl, sim, w

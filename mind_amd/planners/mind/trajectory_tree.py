@@ -7,6 +7,8 @@ Python iLQR; here ``init_*`` only flattens the scenario tree (LIFO DFS, every ev
 trajectory node, Q13) and the solve is one persistent HIP kernel (libmind_hip.so:
 mind_ilqr_solve_trees).  ``solve_batch`` solves all scenario trees of a plan in two launches.
 """
+import os
+
 import numpy as np
 
 from ... import _lib
@@ -104,7 +106,7 @@ class TrajectoryTreeOptimizer:
         self.debug = None
         self._job = None
         # speculative warm start (see speculate_warm)
-        self.speculative = True
+        self.speculative = os.environ.get("MIND_SPECULATIVE_WARM_START", "1") != "0"
         self._worker = None
         self._last_structs = []
         self._spec = None
