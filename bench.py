@@ -394,7 +394,10 @@ def main():
                      "launches_profiled": pair_launch, "avg_launch_ms": (sum(pair_ms) / pair_launch) if pair_launch else None,
                      "algorithmic_flops_per_launch": (F_MIN_N2 * pair_n2 / pair_launch) if pair_launch else None,
                      "note": "algorithmic FLOPs = SURVEY 8(d) F_min N^2 term (754944*N^2 per expansion over 6 launches); "
-                             "launch durations from HIP events on the context stream, recorded inside the timed region"},
+                             "launch durations from HIP events on the context stream, recorded inside the timed region"
+                             + ("; measured in situ: launches that coincide with a speculative warm-start fit on the planner's second "
+                                "context take ~4 us longer (frac 0.49 with MIND_SPECULATIVE_WARM_START=0, DESIGN 5)"
+                                if pl.traj_tree_opt.speculative else "")},
         # the tree-iLQR kernel is latency-bound (serial depth x iterations): reported as rates, not against a roofline
         "ilqr": {"solves_per_s": ilqr["trees"] / dt, "iterations_per_s": ilqr["iterations"] / dt,
                  "trees_per_plan": ilqr["trees"] / max(args.steps, 1) / 2, "iterations_per_solve": ilqr["iterations"] / max(ilqr["trees"], 1),
