@@ -185,7 +185,8 @@ class TrajectoryTreeOptimizer:
         try:
             spec["fut"].result()
             _, us, st = spec["call"].finish()
-        except Exception:
+        except Exception:                     # the in-line path below then computes (or reports) the same thing
+            self.counters["warm_failed"] = self.counters.get("warm_failed", 0) + len(spec["structs"])
             return {}
         if not (np.array_equal(spec["x0"], x0) and np.array_equal(spec["lane"], lane) and spec["tv"] == float(target_vel)):
             return {}
