@@ -339,7 +339,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     rt.predict = orig_predict
-    ctr = {k: v - ctr0[k] for k, v in pl.traj_tree_opt.counters.items()}
+    ctr = {k: v - ctr0.get(k, 0) for k, v in pl.traj_tree_opt.counters.items()}
     ilqr = {"trees": ctr["solves"], "iterations": ctr["iterations"]}
     rt.set_profiling(False)
     lcl = sim._observation()
