@@ -26,6 +26,9 @@ WORKLOADS = {
     "cfg4": dict(n_agents=64, n_lanes=8, n_segs=32, seed=4),
     # cfg4 with the full scripted 6-ary depth-4 AIME tree (259 expansions / plan; BASELINE config 4)
     "cfg4tree": dict(n_agents=64, n_lanes=8, n_segs=32, seed=4),
+    # the agent count of BASELINE config 5 (128 agents x 256 lane polylines, N = 385) on the largest tree the
+    # reference's probability floor lets grow (6-ary, 259 expansions), fp32
+    "stress128tree": dict(n_agents=128, n_lanes=8, n_segs=32, seed=5),
     # the reference's four recorded AV2 demo scenes (compact fixtures derived from data/<seq_id>/, tests/golden/scenes)
     "demo_1": dict(scene="demo_1"), "demo_2": dict(scene="demo_2"), "demo_3": dict(scene="demo_3"), "demo_4": dict(scene="demo_4"),
     # BASELINE config 3: demo_{1,2,3,4} concurrently on one GPU (use with --concurrent P: scene i plans demo_(i mod 4 + 1))
@@ -50,6 +53,7 @@ def _concurrent_label(workload, P):
     if "scene" in WORKLOADS[workload]:
         return f"{P} closed loops on the recorded scene {workload}", "recorded AV2 scene, formula-initialised weights"
     return f"{P} {workload}-like synthetic scenes", "synthetic"
+FULL_TREE = ("cfg4tree", "stress128tree")
 F_MIN_N2 = 754944.0   # minimal-algorithm FLOPs per expansion, N^2 coefficient (6 layers)
 PEAK_F32_MFMA = 157.3e12
 
@@ -168,7 +172,7 @@ def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees):
 def _proc_scene(i, workload, steps, warmup, ready, go, q, speculative):
     """One scene in its own process (own HIP context): signals ready, waits for the common start, reports back."""
     import torch as th
-    pl, sim, w = make_closed_loop(scene_workload(workload, i), full_tree=workload == "cfg4tree", speculative=speculative)
+    pl, sim, w = make_closed_loop(scene_workload(workload, i), full_tree=workload in FULL_TREE, speculative=speculative)
     sim.run_plans(max(warmup, 1))
     th.cuda.synchronize()
     ready.wait()
@@ -217,7 +221,7 @@ def run_concurrent(args):
     def worker(i):
         try:
             with torch.cuda.stream(torch.cuda.Stream()):
-                pl, sim, w = make_closed_loop(scene_workload(args.workload, i), full_tree=args.workload == "cfg4tree", speculative=P <= 4)
+                pl, sim, w = make_closed_loop(scene_workload(args.workload, i), full_tree=args.workload in FULL_TREE, speculative=P <= 4)
                 sim.run_plans(max(args.warmup, 1))
                 torch.cuda.current_stream().synchronize()
                 loops[i] = (pl, sim)
@@ -293,7 +297,7 @@ def main():
     if not args.shard and "seed" in wkw:
         wkw["seed"] = wkw["seed"] + rank      # every rank plans its own scene (weak scaling)
     real_scene = "scene" in wkw
-    pl, sim, w = make_closed_loop(wkw, full_tree=args.workload == "cfg4tree")
+    pl, sim, w = make_closed_loop(wkw, full_tree=args.workload in FULL_TREE)
     if args.shard and dist is not None:
         pl.enable_sharding()
     rt = pl.network.rt
