@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MIND_HIP_LIB", os.path.join(_HERE, "libmind_hip.so"))   # override: diagnostic builds only
 
 MIND_OK = 0
+MIND_EINVAL, MIND_ENOMEM, MIND_EHIP, MIND_ESTATE, MIND_ENOTFOUND = -1, -2, -3, -4, -5     # include/mind_hip.h:21-25
 
 
 class TensorDesc(C.Structure):
