@@ -3,7 +3,7 @@ import os, sys, time, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from bench import WORKLOADS, make_closed_loop
+from bench import FULL_TREE, WORKLOADS, make_closed_loop
 
 acc = collections.OrderedDict()
 def wrap(obj, name, label=None, sync=False):
@@ -19,7 +19,7 @@ def wrap(obj, name, label=None, sync=False):
     setattr(obj, name, g)
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "demo1"
-pl, sim, w = make_closed_loop(dict(WORKLOADS[wl]), full_tree=wl == "cfg4tree")
+pl, sim, w = make_closed_loop(dict(WORKLOADS[wl]), full_tree=wl in FULL_TREE)
 gen, net, rt, opt = pl.scen_tree_gen, pl.scen_tree_gen.network, pl.network.rt, pl.traj_tree_opt
 sim.run_plans(3)
 wrap(pl, "plan"); wrap(gen, "branch_aime"); wrap(gen, "process_data"); wrap(gen, "collate"); wrap(net, "pre_process")
