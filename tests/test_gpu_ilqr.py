@@ -118,3 +118,42 @@ def test_tiny_trees_and_ego_only(n_agents, hip_predictor):
         ref = oi.solve(cfg, flat, x0, sst["target_lane"], sst["target_vel"], 1)
         xs, us, stt = hip_predictor.ilqr_solve(cfg, [flat], x0, sst["target_lane"], sst["target_vel"], 1)
         assert np.array_equal(xs[0], ref["xs"]) and np.array_equal(us[0], ref["us"]) and stt[0]["iterations"] == ref["iterations"]
+
+
+def test_full_size_tree_properties(hip_predictor):
+    """Size-independent properties on the biggest cost tree of the full 6-ary AIME tree (hundreds of trajectory nodes), run
+    to the solver's own stop: (1) every accepted step lowers the cost, so the result is never worse than the plain
+    rollout of the initial controls; (2) determinism: the same call twice is bit-identical; (3) fixed point: restarting
+    from the returned controls cannot be improved upon at the first regularisation level, so it returns those controls'
+    own rollout -- the same trajectory; (4) the tree structure of the solution: node states obey the bicycle model from
+    their parent's state under their own control (trajectory_tree.py:168-175), to rounding."""
+    from test_aime_host import _full_tree_run
+    g, trees = _full_tree_run(True)
+    st = max(trees, key=lambda t: len(t.nodes))
+    nodes = [(k, n.parent_key, n.data) for k, n in st.nodes.items()]
+    flat = oi.flatten(nodes)
+    M = len(flat["parent"])
+    assert M > 300
+    lane = np.asarray(g.target_lane[::2], np.float64)
+    d0 = nodes[0][2][1][0, 0]
+    x0 = oi.init_state(np.array([float(d0[0]), float(d0[1]), 4.0, 0.0]), np.array([0.0, 0.0]))
+    cfg = oi.default_cfg(max_iter=100)
+    cfg0 = oi.default_cfg(max_iter=0)
+    _, _, st0 = hip_predictor.ilqr_solve(oi.default_cfg(max_iter=1), [flat], x0, lane, 4.0, 1)   # J = cost of the zero-control rollout
+    xs, us, st1 = hip_predictor.ilqr_solve(cfg, [flat], x0, lane, 4.0, 1)
+    xs2, us2, st2 = hip_predictor.ilqr_solve(cfg, [flat], x0, lane, 4.0, 1)
+    assert np.array_equal(xs[0], xs2[0]) and np.array_equal(us[0], us2[0]) and st1[0]["J"] == st2[0]["J"]
+    assert st1[0]["iterations"] >= 1 and np.all(np.isfinite(xs[0])) and np.all(np.isfinite(us[0]))
+    assert st1[0]["J"] <= st0[0]["J"]                  # J = cost before the last accepted step (Q19): already below the start
+    xs3, us3, st3 = hip_predictor.ilqr_solve(cfg0, [flat], x0, lane, 4.0, 1, us_init=[us[0]])
+    assert np.array_equal(us3[0], us[0])                                                  # max_iter 0: the rollout of us
+    assert np.abs(xs3[0] - xs[0]).max() < 1e-9
+    # bicycle model along every tree edge (node 0 hangs off x0)
+    dt, wb = cfg.dt, cfg.wheelbase
+    par = flat["parent"]
+    prev = np.where(par[:, None] >= 0, xs[0][np.maximum(par, 0)], x0[None, :])
+    u = us[0]
+    nxt = np.stack([prev[:, 0] + prev[:, 2] * np.cos(prev[:, 3]) * dt, prev[:, 1] + prev[:, 2] * np.sin(prev[:, 3]) * dt,
+                    prev[:, 2] + prev[:, 4] * dt, prev[:, 3] + prev[:, 2] / wb * np.tan(prev[:, 5]) * dt,
+                    prev[:, 4] + u[:, 0] * dt, prev[:, 5] + u[:, 1] * dt], axis=1)
+    assert np.abs(nxt - xs[0]).max() < 1e-9
