@@ -276,3 +276,90 @@ def test_replay_world_closed_loop_agent_options(scenes):
         scene_io.ReplayWorld(smap, sc, dict(id="AV", semantic_lane=10_000))
     with pytest.raises(ValueError):
         scene_io.ReplayWorld(smap, sc, dict(id="no-such-track"))
+
+
+def test_track_selection_rules_on_a_toy_scenario():
+    """loader.py:99-129 rule by rule: a track is dropped when it starts after frame 49, when frame 49 is missing, or when any
+    of its first 50 RECORDED samples is 5 m or more from every semantic lane; everything else is kept in the order focal,
+    AV, scored, unscored, fragments; missing frames are padded with the nearest earlier sample (leading gap: the first)."""
+    from types import SimpleNamespace as NS
+    smp = scene_io.SemanticMap()
+    xs = np.arange(0.0, 200.0, 2.0)
+    smp.semantic_lanes = {0: np.stack([xs, np.zeros_like(xs)], 1).astype(np.float32)}
+    smp.semantic_lanes_infos = {0: [np.zeros(len(xs), np.float32)] * 6}
+
+    def track(tid, cat, frames, y=0.5, typ="VEHICLE"):
+        st = [NS(observed=True, timestep=int(t), position=(1.0 + 0.5 * t, y), heading=0.0, velocity=(5.0, 0.0)) for t in frames]
+        return NS(track_id=tid, object_states=st, object_type=av2_lite.ObjectType[typ], category=av2_lite.TrackCategory[cat])
+
+    tracks = [
+        track("frag", "TRACK_FRAGMENT", range(40, 60)),
+        track("late", "SCORED_TRACK", range(60, 110)),                       # starts after frame 49
+        track("gap49", "SCORED_TRACK", [t for t in range(110) if t != 49]),  # not observed at frame 49
+        track("far", "UNSCORED_TRACK", range(110), y=5.5),                   # 5.5 m from the only lane
+        track("far_later", "UNSCORED_TRACK", range(30, 110), y=0.0),         # leaves the lane only after its first 50 samples:
+        track("AV", "UNSCORED_TRACK", range(110)),
+        track("focal", "FOCAL_TRACK", range(110), typ="BUS"),
+        track("holes", "SCORED_TRACK", [0, 10, 49, 50, 109]),
+    ]
+    for s in tracks[4].object_states[55:]:
+        s.position = (s.position[0], 30.0)                                   # ... samples 55.. (frames 85..) are far away
+    sc = av2_lite.Scenario("toy", "focal", tracks)
+    pos, ang, vel, types, tids, cats, flags = scene_io.load_trajs_info(sc, smp)
+    assert tids == ["focal", "AV", "holes", "far_later", "frag"] and cats == ["focal", "av", "score", "unscore", "frag"]
+    assert types[0][0].name == "BUS" and pos.shape == (5, 546, 2) and flags.dtype == np.int16
+    h = tids.index("holes")
+    assert flags[h, ::5].tolist()[:12] == [1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0]      # 10 Hz frames 0..11: observed at 0 and 10
+    assert flags[h, 49 * 5] == 1 and flags[h, 50 * 5] == 1 and flags[h, 80 * 5] == 0
+    assert pos[h, 5 * 5, 0] == np.float32(1.0)                                        # frame 5: padded with frame 0's sample
+    assert pos[h, 30 * 5, 0] == np.float32(1.0 + 0.5 * 10)                            # frame 30: frame 10's sample
+    assert vel[h, 30 * 5] == 0.0 and vel[h, 49 * 5] == 5.0                            # speed is not padded
+    f = tids.index("frag")
+    assert flags[f, 39 * 5] == 0 and flags[f, 40 * 5] == 1 and pos[f, 0, 0] == np.float32(1.0 + 0.5 * 40)   # leading gap: first sample
+    # between frames 49 and 50 the resampling is linear in position, observed when the blend exceeds one half
+    assert np.allclose(pos[0, 49 * 5 + 2, 0], 1.0 + 0.5 * 49.4, atol=1e-5)
+    assert flags[h, 10 * 5 + 2] == 1 and flags[h, 10 * 5 + 3] == 0                    # frame 10 observed, frame 11 not
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not rh.available(), reason="reference tree not present")
+def test_toy_scenario_matches_reference_loader():
+    """Build container only: the reference's own ArgoAgentLoader.get_trajs_info on random toy scenarios (tracks with holes,
+    late starts, off-lane stretches) against load_trajs_info -- the golden scenes do not exercise every drop rule."""
+    import importlib
+    import sys
+    from types import SimpleNamespace as NS
+    rh.install()
+    loader_mod = importlib.import_module("loader")
+    ser = sys.modules["av2.datasets.motion_forecasting.scenario_serialization"]
+    rng = np.random.default_rng(7)
+    smp = scene_io.SemanticMap()
+    xs = np.arange(0.0, 300.0, 3.0)
+    smp.semantic_lanes = {0: np.stack([xs, 2.0 * np.sin(xs / 40.0)], 1).astype(np.float32),
+                          1: np.stack([xs, 3.6 + 2.0 * np.sin(xs / 40.0)], 1).astype(np.float32)}
+    smp.semantic_lanes_infos = {k: [np.zeros(len(xs), np.float32)] * 6 for k in (0, 1)}
+    cats = ["TRACK_FRAGMENT", "UNSCORED_TRACK", "SCORED_TRACK"]
+    for trial in range(4):
+        tracks = []
+        for i in range(14):
+            t0 = int(rng.integers(0, 70)) if i > 1 else 0
+            frames = [t for t in range(t0, 110) if i < 2 or rng.random() > 0.15]
+            x0, v, y0 = rng.uniform(0, 120), rng.uniform(0, 9), rng.choice([0.0, 3.6, 9.0, -4.8])
+            st = [rh.ObjectState(True, int(t), (float(x0 + 0.1 * v * t), float(y0 + 2.0 * np.sin((x0 + 0.1 * v * t) / 40.0) + 0.3 * np.sin(t / 7.0))),
+                                 float(rng.uniform(-3.1, 3.1)), (float(v), float(rng.normal() * 0.2))) for t in frames]
+            tid = ["focal", "AV"][i] if i < 2 else str(100 + i)
+            cat = rh.TrackCategory.FOCAL_TRACK if i == 0 else rh.TrackCategory[cats[i % 3]]
+            tracks.append(rh.Track(tid, st, list(rh.ObjectType)[i % 5], cat))
+        scen = NS(tracks=tracks, focal_track_id="focal")
+        orig = ser.load_argoverse_scenario_parquet
+        ser.load_argoverse_scenario_parquet = lambda path: scen
+        try:
+            want = loader_mod.ArgoAgentLoader("unused").get_trajs_info(smp)
+        finally:
+            ser.load_argoverse_scenario_parquet = orig
+        got = scene_io.load_trajs_info(scen, smp)
+        assert got[4] == want[4] and got[5] == want[5], trial
+        assert [t[0].name for t in got[3]] == [t[0].name for t in want[3]]
+        for k in (0, 1, 2, 6):
+            assert got[k].dtype == want[k].dtype and np.array_equal(got[k], want[k]), (trial, k)
+        assert 2 <= len(got[4]) < 14                                     # some tracks were dropped, some kept
