@@ -363,3 +363,41 @@ def test_toy_scenario_matches_reference_loader():
         for k in (0, 1, 2, 6):
             assert got[k].dtype == want[k].dtype and np.array_equal(got[k], want[k]), (trial, k)
         assert 2 <= len(got[4]) < 14                                     # some tracks were dropped, some kept
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not rh.available(), reason="reference tree not present")
+def test_target_lane_branches_match_reference_agent():
+    """Build container only: CustomizedAgent.get_target_lane / get_closest_semantic_lane (agent.py:179-250) on toy lanes and
+    random recorded paths -- closest lane found / not found, explicit lane id, with and without the recorded path."""
+    import importlib
+    rh.install()
+    agent_mod = importlib.import_module("agent")
+    rng = np.random.default_rng(3)
+    xs = np.arange(0.0, 160.0, 2.5)
+    smp = scene_io.SemanticMap()
+    smp.semantic_lanes = {0: np.stack([xs, np.zeros_like(xs)], 1).astype(np.float32),
+                          1: np.stack([xs, 3.6 + 0.02 * xs], 1).astype(np.float32),
+                          2: np.stack([40.0 + 0.0 * xs, xs - 60.0], 1).astype(np.float32)}          # a crossing lane
+    smp.semantic_lanes_infos = {k: [np.full(len(xs), float(k), np.float32)] * 6 for k in smp.semantic_lanes}
+    seen = set()
+    for trial in range(40):
+        x0, y0, yaw = rng.uniform(0, 60), rng.choice([0.2, 3.9, -9.0, 1.8]), rng.choice([0.0, 0.05, 1.4, -0.6])
+        v = rng.uniform(0.0, 8.0)
+        t = np.arange(0, 546)[:, None] * 0.02
+        pos = (np.array([[x0, y0]]) + v * t * np.array([[np.cos(yaw), np.sin(yaw)]]) + rng.normal(size=(546, 2)) * 0.01).astype(np.float32)
+        ang = np.full(546, yaw, np.float32)
+        ag = agent_mod.CustomizedAgent()
+        ag.traj_info = [pos, ang, np.full(546, v, np.float32), np.ones(546, np.int16)]
+        want_c = ag.get_closest_semantic_lane(smp, pos, ang)
+        assert scene_io.get_closest_semantic_lane(smp, pos, ang) == want_c
+        seen.add(want_c)
+        for use_traj in (False, True):
+            for lane_id in (None, 1, 2):
+                if v < 0.05 and (use_traj or want_c is None):
+                    continue                                             # a standing agent has a one-point path: both sides index [-2]
+                want, want_info = ag.get_target_lane(smp, use_traj, lane_id)
+                got, got_info = scene_io.target_lane_for(smp, pos, ang, use_traj, lane_id)
+                assert got.dtype == want.dtype and np.array_equal(got, want), (trial, use_traj, lane_id)
+                assert (got_info is None) == (want_info is None)
+    assert None in seen and len(seen) >= 3                               # found / not found, different lanes
