@@ -401,3 +401,30 @@ def test_target_lane_branches_match_reference_agent():
                 assert got.dtype == want.dtype and np.array_equal(got, want), (trial, use_traj, lane_id)
                 assert (got_info is None) == (want_info is None)
     assert None in seen and len(seen) >= 3                               # found / not found, different lanes
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not rh.available(), reason="reference tree not present")
+def test_local_semantic_map_matches_reference(scenes):
+    """Build container only: LocalSemanticMap (common/semantic_map.py:176-233) on the recorded demo_1 map: closest semantic
+    lane for random poses, observation split into ego / exo."""
+    import importlib
+    from types import SimpleNamespace as NS
+    rh.install()
+    ref_mod = importlib.import_module("common.semantic_map")
+    smp = scene_io.SemanticMap.from_static_map(scenes["demo_1"][0])
+    ref_smp = NS(map_data=None, semantic_lanes=smp.semantic_lanes, semantic_lanes_infos=smp.semantic_lanes_infos)
+    mine, ref = scene_io.LocalSemanticMap("AV", smp), ref_mod.LocalSemanticMap("AV", ref_smp)
+    rng = np.random.default_rng(5)
+    lo, hi = np.array(smp.limits)[:, 0], np.array(smp.limits)[:, 1]
+    hits = 0
+    for _ in range(200):
+        p, a = rng.uniform(lo, hi), rng.uniform(-np.pi, np.pi)
+        want = ref.get_closest_semantic_lane(p, a)
+        assert mine.get_closest_semantic_lane(p, a) == want
+        hits += want is not None
+    assert 20 < hits <= 200
+    agents = [NS(id=i, state=None) for i in ("7", "AV", "9")]
+    mine.update_observation(agents)
+    ref.update_observation(agents)
+    assert mine.ego_agent is ref.ego_agent and [a.id for a in mine.exo_agents] == [a.id for a in ref.exo_agents] == ["7", "9"]
