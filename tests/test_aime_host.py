@@ -222,3 +222,46 @@ def test_batched_tree_evaluation_equals_per_tree():
     for t in trees:
         t._arrays = None
     assert pl.evaluate_traj_trees(lcl, trees) == want
+
+
+from oracle import ref_harness as _rh  # noqa: E402
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not _rh.available(), reason="reference tree not present")
+def test_planner_helpers_match_reference_live():
+    """Build container only: MINDPlanner.resample_target_lane and evaluate_traj_tree (planner.py:147-198) of the imported
+    reference on random inputs against this package's vectorised versions."""
+    from types import SimpleNamespace
+    from mind_amd.planners.mind.trajectory_tree import to_traj_tree
+    m = _rh.ref_modules()
+    RefPlanner = m["planners.mind.planner"].MINDPlanner
+    RefTree, RefNode = m["planners.basic.tree"].Tree, m["planners.basic.tree"].Node
+    ref, mine = RefPlanner.__new__(RefPlanner), MINDPlanner.__new__(MINDPlanner)
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        P = int(rng.integers(3, 40))
+        dtype = np.float32 if trial % 2 else np.float64
+        lane = np.cumsum(rng.uniform(0.3, 6.0, (P, 2)), axis=0).astype(dtype)
+        info = [rng.integers(0, 2, P).astype(np.float32), np.eye(3, dtype=np.float32)[rng.integers(0, 3, P)],
+                np.eye(3, dtype=np.float32)[rng.integers(0, 3, P)], np.eye(3, dtype=np.float32)[rng.integers(0, 3, P)],
+                rng.integers(0, 2, P).astype(np.float32), rng.integers(0, 2, P).astype(np.float32)]
+        lcl = SimpleNamespace(target_lane=lane, target_lane_info=info, target_velocity=float(rng.uniform(2, 9)))
+        wl, wi = ref.resample_target_lane(lcl)
+        gl, gi = mine.resample_target_lane(lcl)
+        assert np.asarray(gl).dtype == np.asarray(wl).dtype and np.array_equal(gl, wl)
+        assert len(gi) == len(wi) and all(np.array_equal(a, b) for a, b in zip(gi, wi))
+        # evaluation of a random trajectory tree
+        M = int(rng.integers(5, 60))
+        par = np.concatenate([[-1], rng.integers(0, np.arange(1, M))]).astype(np.int32)
+        xs = rng.normal(size=(M, 6)) * np.array([20, 20, 2, 0.3, 1, 0.1]) + np.array([30, 30, 4, 0, 0, 0])
+        us = rng.normal(size=(M, 2))
+        x0 = xs[0] * 0.9
+        tt = to_traj_tree(dict(parent=par), x0, xs, us)
+        rt = RefTree()
+        rt.add_node(RefNode(-1, None, [x0, np.zeros(2)]))
+        for k in range(M):
+            rt.add_node(RefNode(k, int(par[k]), [xs[k], us[k]]))
+        want = ref.evaluate_traj_tree(lcl, rt)
+        assert abs(mine.evaluate_traj_tree(lcl, tt) - want) <= 1e-12 * abs(want)
+        assert abs(mine.evaluate_traj_trees(lcl, [tt])[0] - want) <= 1e-12 * abs(want)
