@@ -265,3 +265,45 @@ def test_planner_helpers_match_reference_live():
         want = ref.evaluate_traj_tree(lcl, rt)
         assert abs(mine.evaluate_traj_tree(lcl, tt) - want) <= 1e-12 * abs(want)
         assert abs(mine.evaluate_traj_trees(lcl, [tt])[0] - want) <= 1e-12 * abs(want)
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not _rh.available(), reason="reference tree not present")
+def test_observation_bookkeeping_matches_reference_live():
+    """Build container only: MINDPlanner.update_observation (planner.py:65-95: 50-frame sliding tracks, dummy states for
+    agents missing from a frame) followed by get_agent_trajectories (utils.py:245-342) of the imported reference, fed with a
+    random appear / disappear pattern over 75 frames -- tracks, flags, padding, type one-hots and agent order after every
+    frame from the tenth on."""
+    import torch as _torch
+    from types import SimpleNamespace as NS
+    m = _rh.ref_modules()
+    ref = m["planners.mind.planner"].MINDPlanner.__new__(m["planners.mind.planner"].MINDPlanner)
+    ref.agent_obs, ref.obs_len = {}, 50
+    mine = MINDPlanner.__new__(MINDPlanner)
+    mine.agent_obs, mine.obs_len = {}, 50
+    rng = np.random.default_rng(21)
+    ids = ["AV"] + [str(100 + i) for i in range(9)]
+    types = [list(_rh.ObjectType)[i % 7] for i in range(10)]
+    present = {i: True for i in ids}
+    for frame in range(75):
+        for i in ids[1:]:
+            if rng.random() < 0.12:
+                present[i] = not present[i]
+        def obs(i):
+            s = np.array([rng.normal() * 40, rng.normal() * 40, abs(rng.normal()) * 5, rng.uniform(-3, 3)])
+            return NS(id=i, type=types[ids.index(i)], state=s, timestep=frame)
+        ego = obs("AV")
+        exo = [obs(i) for i in ids[1:] if present[i]]
+        rng.shuffle(exo)                                                       # first-appearance order defines the agent order
+        lcl = NS(ego_agent=ego, exo_agents=exo)
+        ref.update_observation(lcl)
+        mine.update_observation(lcl)
+        assert list(ref.agent_obs) == list(mine.agent_obs)
+        if frame < 10:
+            continue
+        want = m["planners.mind.utils"].get_agent_trajectories(ref.agent_obs, _torch.device("cpu"))
+        got = U.get_agent_trajectories(mine.agent_obs)
+        assert got[5] == want[5] and got[6] == want[6], frame
+        for g_, w_ in zip(got[:5], want[:5]):
+            w_ = w_.numpy()
+            assert g_.dtype == w_.dtype and g_.shape == w_.shape and np.array_equal(g_, w_), frame
