@@ -1,16 +1,27 @@
 #!/usr/bin/env python
-"""bench.py --gpus N --steps K --warmup W [--workload demo1|cfg4]
+"""bench.py --gpus N --steps K --warmup W [--workload demo_1|demo1|cfg4tree|...] [--shard | --replicas]
 
-A step = one planning cycle of the closed loop on one synthetic scene (mind_amd.closed_loop, mirroring
-simulator.py:58-103 / agent.py:277-331): 5 simulator steps of 0.02 s (observation fan-out, 10 Hz planner
-trigger, ego plant) containing one MINDPlanner.plan() = AIME scenario tree (every tree node through the
-HIP predictor) + tree-iLQR contingency solves (warm start + full) for every scenario tree + selection.
-value = simulator steps / wall time.  One process per GPU; ranks run independent scenes (weak scaling, no
-data-path collective); rank 0 prints ONE JSON line.
+A step = one planning cycle of the headless closed loop (mind_amd.closed_loop, mirroring simulator.py:58-103 /
+agent.py:277-331): 5 simulator steps of 0.02 s (observation fan-out, 10 Hz planner trigger, ego plant) containing one
+MINDPlanner.plan() = AIME scenario tree (every tree node through the HIP predictor) + tree-iLQR contingency solves
+(warm start + full) for every scenario tree + selection.  value = simulator steps / wall time, whole job.
+
+Default workload = BASELINE.json configs[1]: the closed loop on the reference's recorded scene demo_1 (compact fixture
+tests/golden/scenes/demo_1.npz; formula-initialised weights: the trained checkpoint is not in the reference tree).
+
+Multi-GPU (one process per GPU; plain `python bench.py --gpus N` spawns the N ranks itself through
+torch.distributed.run, under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE):
+  * default workload: every rank runs its own closed loop (independent scenes: weak scaling, no data-path collective),
+    and the line also carries `tree_sharded`: the full cfg4 scenario tree planned ONCE by all ranks together (AIME rounds
+    block-sharded, contingency solves round-robin, RCCL all-gather / broadcast per round: strong scaling);
+  * --workload cfg4tree / stress128tree (or --shard): that sharded plan is the headline (`scaling: strong`);
+    --replicas forces independent replicas.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -19,26 +30,48 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
+METRIC = "sim steps/sec (whole node) + scenario-tree nodes expanded/sec, AV2 demo scenes"
 WORKLOADS = {
-    # demo_1-like: ~40 tracked agents, ~55 lane polylines (a<=~40, l~55, N~96)
+    # BASELINE configs[1]: the reference's recorded AV2 demo scenes (compact fixtures derived from data/<seq_id>/)
+    "demo_1": dict(scene="demo_1"), "demo_2": dict(scene="demo_2"), "demo_3": dict(scene="demo_3"), "demo_4": dict(scene="demo_4"),
+    # BASELINE config 3: demo_{1,2,3,4} concurrently on one GPU (use with --concurrent P: scene i plans demo_(i mod 4 + 1))
+    "demo_all": dict(scene="demo_1"),
+    # demo_1-like synthetic scene: ~40 tracked agents, ~55 lane polylines (N ~ 96) with scripted mode branching on top of
+    # the real predictor forward (4 expansions + 3-4 scenario trees per plan: the load a trained checkpoint would produce)
     "demo1": dict(n_agents=40, n_lanes=5, n_segs=11, seed=3),
     # cfg4: 64 agents x 256 lane polylines
     "cfg4": dict(n_agents=64, n_lanes=8, n_segs=32, seed=4),
     # cfg4 with the full scripted 6-ary depth-4 AIME tree (259 expansions / plan; BASELINE config 4)
     "cfg4tree": dict(n_agents=64, n_lanes=8, n_segs=32, seed=4),
     # the agent count of BASELINE config 5 (128 agents x 256 lane polylines, N = 385) on the largest tree the
-    # reference's probability floor lets grow (6-ary, 259 expansions), fp32
+    # reference's probability floor lets grow (6-ary, 259 expansions)
     "stress128tree": dict(n_agents=128, n_lanes=8, n_segs=32, seed=5),
-    # the reference's four recorded AV2 demo scenes (compact fixtures derived from data/<seq_id>/, tests/golden/scenes)
-    "demo_1": dict(scene="demo_1"), "demo_2": dict(scene="demo_2"), "demo_3": dict(scene="demo_3"), "demo_4": dict(scene="demo_4"),
-    # BASELINE config 3: demo_{1,2,3,4} concurrently on one GPU (use with --concurrent P: scene i plans demo_(i mod 4 + 1))
-    "demo_all": dict(scene="demo_1"),
 }
+FULL_TREE = ("cfg4tree", "stress128tree")
+
+# ---- algorithmic work of the pair kernel ----------------------------------------------------------
+F_MIN_N2 = 754944.0        # minimal-algorithm FLOPs per expansion, N^2 coefficient (K and V projections kept)
+PAIR_FULL = 69632.0        # folded algorithm, per pair and layer: 2 x (2*128*128) GEMMs + 2*8*128 scores + 2*8*128 sum p.mem
+PAIR_ATT = 36864.0         # a pair whose edge is not updated: first GEMM + attention
+PAIR_UPD = 32768.0         # the edge-update GEMM alone
+PEAK_F32_MFMA, PEAK_BF16_MFMA, PEAK_HBM = 157.3e12, 2500e12, 8.0e12      # MI355X_MICROARCH.md
+
+
+def fold_flops(N, nf):
+    """FLOPs of the folded algorithm for one scene, all six launches: layers 0-3 update every edge, layer 4 only the
+    a + 1 flagged columns, layer 5 runs only those columns (network.py:249: the last layer has no edge update)."""
+    return 4 * N * N * PAIR_FULL + N * N * PAIR_ATT + N * nf * PAIR_UPD + N * nf * PAIR_ATT
+
+
+def edge_bytes(N, nf):
+    """Algorithmic HBM bytes of the six launches (fp32 edge, 512 B per pair): layer 0 writes, layers 1-3 read + write,
+    layer 4 reads all and writes the flagged columns, layer 5 reads the flagged columns."""
+    return 512.0 * (N * N + 3 * 2 * N * N + N * N + N * nf + N * nf)
 
 
 def scene_workload(workload, i):
-    """workload of the i-th concurrent scene: its own seed for the synthetic worlds, round-robin over the four recorded scenes
-    for demo_all."""
+    """workload of the i-th concurrent scene / replica: its own seed for the synthetic worlds, round-robin over the four
+    recorded scenes for demo_all."""
     if workload == "demo_all":
         return dict(scene="demo_%d" % (i % 4 + 1))
     wkw = dict(WORKLOADS[workload])
@@ -53,9 +86,6 @@ def _concurrent_label(workload, P):
     if "scene" in WORKLOADS[workload]:
         return f"{P} closed loops on the recorded scene {workload}", "recorded AV2 scene, formula-initialised weights"
     return f"{P} {workload}-like synthetic scenes", "synthetic"
-FULL_TREE = ("cfg4tree", "stress128tree")
-F_MIN_N2 = 754944.0   # minimal-algorithm FLOPs per expansion, N^2 coefficient (6 layers)
-PEAK_F32_MFMA = 157.3e12
 
 
 def make_planner(wkw, scripted=True):
@@ -92,53 +122,150 @@ def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True):
     # curved recorded target lane, so they are kept for the synthetic worlds only
     if scripted and "scene" not in wkw:
         pl.scen_tree_gen.network = (ScriptedFullTree if full_tree else ScriptedBranching)(pl.network)
-    # episodes: the reference's 60 cycles for a recording; 24 for the synthetic worlds (all eight seeds the weak-scaling
-    # and concurrent modes use stay on their lane that long; the default 3 + 20 cycles fit in one episode)
     # speculative warm start = a second HIP context per planner: a latency lever for a GPU that one closed loop leaves idle;
     # with many scenes sharing the device the extra contexts cost more than they hide (measured: 8 processes 3150 -> 2010)
     pl.traj_tree_opt.speculative = speculative and pl.traj_tree_opt.speculative      # MIND_SPECULATIVE_WARM_START=0 switches it off
+    # episodes: the reference's 60 cycles for a recording; 24 for the synthetic worlds (all eight seeds the weak-scaling
+    # and concurrent modes use stay on their lane that long; the default 3 + 20 cycles fit in one episode)
     sim = ClosedLoopSim(w, pl, episode_plans=60 if "scene" in wkw else 24)
     sim.run_until(sim.enable_time)
     return pl, sim, w
 
 
-def recorded_scenes(plans=20, warmup=3):
-    """The same closed loop on the reference's four recorded AV2 demo scenes (compact fixtures, tests/golden/scenes) with
-    the predictor's own modes: K timed planning cycles each, synchronised on both sides.  Reported next to the headline
-    (whose synthetic demo_1-like scene adds the branching a trained checkpoint would produce)."""
-    out = {}
-    for name in ("demo_1", "demo_2", "demo_3", "demo_4"):
-        pl, sim, w = make_closed_loop(dict(WORKLOADS[name]))
-        sim.run_plans(warmup)
+class Dist:
+    """torch.distributed for the bench: barrier + max-over-ranks timing, sums; a no-op for one process."""
+
+    def __init__(self, backend, local):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.backend = backend
+        self.d = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":       # RCCL over xGMI: one rank per GPU
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:                       # gloo: the same code path on a box with fewer GPUs than ranks (tests)
+                dist.init_process_group(backend)
+            self.d = dist
+        self.dev = "cuda" if backend == "nccl" else "cpu"
+
+    def barrier(self):
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n0 = pl.scen_tree_gen.n_expanded
-        steps = sim.run_plans(plans)
+        if self.d is not None:
+            self.d.barrier()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out[name] = {"sim_steps_per_s": steps / dt, "ms_per_plan": dt / plans * 1e3, "agents": len(pl.agent_obs),
-                     "lane_polylines": int(pl.scen_tree_gen.lane_feat_in.shape[0]),
-                     "expansions_per_plan": (pl.scen_tree_gen.n_expanded - n0) / plans}
-        if name == "demo_1":
-            # BASELINE configs[0]/[1]: the whole demo_1 closed loop = 500 simulator steps (10 s), 60 planning cycles
-            from mind_amd.closed_loop import ClosedLoopSim
-            from mind_amd.planners.mind.planner import MINDPlanner
-            sim = ClosedLoopSim(w, MINDPlanner(pl.planner_cfg))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(500):
-                sim.step()
-            torch.cuda.synchronize()
-            out[name]["whole_run_500_steps_s"] = time.perf_counter() - t0
-            out[name]["whole_run_plans"] = sim.n_plans
-    out["note"] = ("recorded map + tracks, formula-initialised weights (the trained checkpoint is not in the reference tree); parity of "
-                   "this loop against the reference's own simulator: tests/test_gpu_plan.py::test_recorded_demo_scenes_match_reference_closed_loop")
-    return out
+
+    def reduce(self, v, op="sum"):
+        if self.d is None:
+            return float(v)
+        t = torch.tensor([float(v)], device=self.dev, dtype=torch.float64)
+        self.d.all_reduce(t, op=self.d.ReduceOp.MAX if op == "max" else self.d.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self.d is not None:
+            self.d.barrier()
+            self.d.destroy_process_group()
+
+
+def measure(dist, workload, steps, warmup, shard, replica=0):
+    """K timed planning cycles of one closed loop (barrier + synchronize on both sides, max over ranks), with the pair
+    kernel's launch durations taken from HIP events on the context stream inside the timed region."""
+    wkw = scene_workload(workload, replica)
+    pl, sim, w = make_closed_loop(wkw, full_tree=workload in FULL_TREE)
+    sh = None
+    if shard and dist.world > 1:
+        sh = pl.enable_sharding()
+    rt = pl.network.rt
+    sim.run_plans(max(warmup, 1))
+    rt.set_profiling(True)
+    acc = dict(ms=0.0, launches=0, n2=0.0, fold=0.0, bytes=0.0, calls=0)
+    orig_predict = rt.predict
+
+    def prof_predict(*a, **k):
+        o = orig_predict(*a, **k)
+        n, ms, _ = rt.fusion_stats()
+        a_off, l_off = a[1], a[3]
+        for i in range(len(a_off) - 1):
+            na = a_off[i + 1] - a_off[i]
+            N = na + (l_off[i + 1] - l_off[i]) + 1
+            acc["n2"] += N * N
+            acc["fold"] += fold_flops(N, na + 1)
+            acc["bytes"] += edge_bytes(N, na + 1)
+        acc["ms"] += ms
+        acc["launches"] += n
+        acc["calls"] += 1
+        return o
+
+    rt.predict = prof_predict
+    ctr0 = dict(pl.traj_tree_opt.counters)
+    coll0 = (sh.n_collectives, sh.bytes_gathered) if sh is not None else (0, 0)
+    dist.barrier()
+    t0 = time.perf_counter()
+    n0 = pl.scen_tree_gen.n_expanded
+    sim_steps = sim.run_plans(steps)            # K planning cycles = ~5K simulator steps
+    expansions = pl.scen_tree_gen.n_expanded - n0
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    rt.predict = orig_predict
+    rt.set_profiling(False)
+    dt = dist.reduce(dt, "max")
+    ctr = {k: v - ctr0.get(k, 0) for k, v in pl.traj_tree_opt.counters.items()}
+    return dict(pl=pl, sim=sim, w=w, dt=dt, sim_steps=sim_steps, expansions=expansions, expansions_all=dist.reduce(expansions),
+                pair=acc, ilqr=ctr, a=len(pl.agent_obs), l=int(pl.scen_tree_gen.lane_feat_in.shape[0]), steps=steps,
+                collectives=(sh.n_collectives - coll0[0], sh.bytes_gathered - coll0[1]) if sh is not None else None,
+                real_scene="scene" in wkw, sharded=sh is not None)
+
+
+def roofline(m, prec):
+    """Both bounds of the pair kernel from the launch durations measured inside the timed region.  `achieved` prices the
+    FOLDED algorithm the kernel executes (fold_flops above: never more than the work done, so frac <= 1); the SURVEY 8(d)
+    F_min figure (K/V projections un-folded, 754 944 N^2 per expansion) is quoted beside it."""
+    p = m["pair"]
+    s = p["ms"] * 1e-3
+    if s <= 0 or p["launches"] == 0:
+        return None
+    passes = {"f32": 1, "bf16x3": 3, "bf16": 1}[prec]
+    peak = PEAK_F32_MFMA if prec == "f32" else PEAK_BF16_MFMA / passes
+    f_mfma = p["fold"] / s / peak
+    f_hbm = p["bytes"] / s / PEAK_HBM
+    bound = "hbm" if f_hbm > f_mfma else "mfma"
+    return {
+        "kernel": "k_pair (RelaFusionLayer pair kernel, 6 launches per predictor call)", "bound": bound,
+        "achieved": (p["bytes"] / s / 1e9) if bound == "hbm" else (p["fold"] / s / 1e12),
+        "peak": PEAK_HBM / 1e9 if bound == "hbm" else peak / 1e12, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+        "frac": max(f_hbm, f_mfma), "traffic": None,
+        "mfma": {"achieved_tflops": p["fold"] / s / 1e12, "peak_tflops": peak / 1e12, "frac": f_mfma,
+                 "arith": prec, "note": {"f32": "v_mfma_f32_16x16x4_f32 (fp32 MFMA = the fp32 vector rate)",
+                                         "bf16x3": "operands split into bf16 hi + lo, 3 products per term on v_mfma_f32_16x16x32_bf16, fp32 accumulate: "
+                                                   "peak = dense bf16 peak / 3 passes",
+                                         "bf16": "plain bf16 operands, fp32 accumulate"}[prec]},
+        "hbm": {"achieved_gbs": p["bytes"] / s / 1e9, "peak_gbs": PEAK_HBM / 1e9, "frac": f_hbm},
+        "f_min_tflops": F_MIN_N2 * p["n2"] / s / 1e12,
+        "launches_profiled": p["launches"], "avg_launch_ms": p["ms"] / p["launches"],
+        "algorithmic_flops_per_launch": p["fold"] / p["launches"], "algorithmic_bytes_per_launch": p["bytes"] / p["launches"],
+        "note": "algorithmic FLOPs per scene = 4 N^2 69632 + N^2 36864 + N (a+1) (32768 + 36864) over the six launches (folded algorithm: "
+                "rank-decomposed proj_memory, K projection folded into the query, V projection folded out of the sum); algorithmic bytes = "
+                "512 B per pair read/written once per layer; launch durations from HIP events on the context stream inside the timed "
+                "region; f_min_tflops prices SURVEY 8(d)'s un-folded F_min; traffic: PMC passes are separate runs (profiles/), not "
+                "measured in this run"}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees):
-    """The oracle (CPU restatement, kind 'port') on this host: one predictor forward of the same scene
-    size + the contingency solves of this plan's scenario trees, timed on a bounded sample."""
+    """The oracle (CPU restatement, kind 'port') on this host: one predictor forward of the same scene size at
+    1 / 8 / 16 / 32 / all hardware threads (best kept, 1-thread figure quoted) + the contingency solves of this plan's
+    scenario trees (plain C, 1 thread), timed on a bounded sample."""
     from mind_amd.synth import predictor_batch
     from mind_amd.weights import formula_state_dict
     from oracle import ilqr as oi
@@ -147,12 +274,22 @@ def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees):
     a, l = n_scene_tokens
     pb = predictor_batch(a, l, 1, seed=9)
     tb = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else [torch.from_numpy(x) for x in v]) for k, v in pb.items()}
-    t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < 8.0 and reps < 20:
+    ncpu = os.cpu_count() or 1
+    n_before = torch.get_num_threads()
+    per_threads = {}
+    for nt in sorted({1, 8, 16, 32, ncpu}):
+        if nt > ncpu:
+            continue
+        torch.set_num_threads(nt)
         op.forward(sd, tb)
-        reps += 1
-    t_pred = (time.perf_counter() - t0) / reps
+        t0, reps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 2.0 and reps < 10:
+            op.forward(sd, tb)
+            reps += 1
+        per_threads[nt] = (time.perf_counter() - t0) / reps
+    torch.set_num_threads(n_before)
+    best_nt = min(per_threads, key=per_threads.get)
+    t_pred = per_threads[best_nt]
     cfg = oi.default_cfg()
     t0 = time.perf_counter()
     n_tree = 0
@@ -162,13 +299,58 @@ def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees):
         n_tree += 1
     t_ilqr = (time.perf_counter() - t0) / max(n_tree, 1)
     plan_s = expansions * t_pred + len(scen_trees) * t_ilqr
-    return {"value": 5.0 / plan_s, "unit": "sim steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{reps} oracle predictor forwards (a={a}, l={l}; {t_pred*1e3:.0f} ms each, torch-CPU fp32) + "
+    plan_1 = expansions * per_threads[1] + len(scen_trees) * t_ilqr
+    return {"value": 5.0 / plan_s, "unit": "sim steps/s", "cores": best_nt, "kind": "port", "cpu": cpu_model(), "hardware_threads": ncpu,
+            "value_1_thread": 5.0 / plan_1,
+            "predictor_ms_by_threads": {str(k): v * 1e3 for k, v in per_threads.items()},
+            "sample": f"oracle predictor forward (a={a}, l={l}, torch-CPU fp32) timed at {sorted(per_threads)} threads, best "
+                      f"{t_pred*1e3:.0f} ms at {best_nt} threads ({per_threads[1]*1e3:.0f} ms at 1) + "
                       f"{n_tree} oracle C tree-iLQR contingency solves with materialised 256x256 fields "
                       f"({t_ilqr*1e3:.0f} ms each, 1 thread); plan = {expansions} expansions + {len(scen_trees)} solves",
             "plan_ms": plan_s * 1e3}
 
 
+def summarize(m, prec):
+    """compact block for an extra workload"""
+    r = roofline(m, prec)
+    ctr = m["ilqr"]
+    out = {"sim_steps_per_s": m["sim_steps"] / m["dt"], "ms_per_plan": m["dt"] / m["steps"] * 1e3,
+           "nodes_expanded_per_s": m["expansions_all"] / m["dt"], "expansions_per_plan": m["expansions_all"] / m["steps"],
+           "agents": m["a"], "lane_polylines": m["l"], "scenario_trees_per_plan": m["pl"].timing.get("n_scen_trees"),
+           "ilqr_solves_per_s": ctr["solves"] / m["dt"], "ilqr_iterations_per_s": ctr["iterations"] / m["dt"],
+           "breakdown_ms": {"aime": m["pl"].timing["aime_s"] * 1e3, "ilqr": m["pl"].timing["ilqr_s"] * 1e3}}
+    if r is not None:
+        out["k_pair"] = {"bound": r["bound"], "frac": r["frac"], "mfma_frac": r["mfma"]["frac"], "hbm_frac": r["hbm"]["frac"],
+                         "tflops": r["mfma"]["achieved_tflops"], "gbs": r["hbm"]["achieved_gbs"], "avg_launch_ms": r["avg_launch_ms"],
+                         "f_min_tflops": r["f_min_tflops"]}
+    if m["collectives"] is not None:
+        out["collectives_per_plan"] = m["collectives"][0] / m["steps"]
+        out["gathered_mb_per_plan"] = m["collectives"][1] / m["steps"] / 1e6
+    return out
+
+
+def recorded_scenes(prec, plans=20, warmup=3):
+    """The other three recorded scenes + the whole demo_1 run (BASELINE configs[0]/[1]: 500 simulator steps, 60 cycles)."""
+    dist = Dist.__new__(Dist)
+    dist.rank, dist.world, dist.d, dist.dev, dist.backend = 0, 1, None, "cpu", None
+    out = {}
+    for name in ("demo_2", "demo_3", "demo_4"):
+        m = measure(dist, name, plans, warmup, False)
+        out[name] = {k: v for k, v in summarize(m, prec).items() if k in ("sim_steps_per_s", "ms_per_plan", "agents", "lane_polylines", "expansions_per_plan")}
+    from mind_amd.closed_loop import ClosedLoopSim
+    from mind_amd.planners.mind.planner import MINDPlanner
+    pl, sim, w = make_closed_loop(dict(WORKLOADS["demo_1"]))
+    sim = ClosedLoopSim(w, MINDPlanner(pl.planner_cfg))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(500):
+        sim.step()
+    torch.cuda.synchronize()
+    out["demo_1_whole_run"] = {"simulator_steps": 500, "plans": sim.n_plans, "seconds": time.perf_counter() - t0}
+    return out
+
+
+# ---- concurrent scenes on one GPU (BASELINE config 3) ---------------------------------------------------------------------
 def _proc_scene(i, workload, steps, warmup, ready, go, q, speculative):
     """One scene in its own process (own HIP context): signals ready, waits for the common start, reports back."""
     import torch as th
@@ -199,8 +381,7 @@ def run_concurrent_processes(args):
     dt = max(r[3] for r in res) - min(r[2] for r in res)       # same host clock: first start to last finish
     steps = sum(r[1] for r in res)
     print(json.dumps({
-        "metric": "sim steps/sec (whole node) + scenario-tree nodes expanded/sec, AV2 demo scenes",
-        "value": steps / dt, "unit": "sim steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "metric": METRIC, "value": steps / dt, "unit": "sim steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 predictor / f64 iLQR", "data": _concurrent_label(args.workload, P)[1],
         "config": {"workload": f"{_concurrent_label(args.workload, P)[0]} planned concurrently on one GPU (one host process + HIP "
@@ -248,10 +429,8 @@ def run_concurrent(args):
     if errs:
         raise errs[0]
     steps = sum(done_steps)
-    exp = sum(pl.scen_tree_gen.n_expanded for pl, _ in loops)
     print(json.dumps({
-        "metric": "sim steps/sec (whole node) + scenario-tree nodes expanded/sec, AV2 demo scenes",
-        "value": steps / dt, "unit": "sim steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "metric": METRIC, "value": steps / dt, "unit": "sim steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 predictor / f64 iLQR", "data": _concurrent_label(args.workload, P)[1],
         "config": {"workload": f"{_concurrent_label(args.workload, P)[0]} planned concurrently on one GPU (one host thread + HIP "
@@ -260,166 +439,118 @@ def run_concurrent(args):
         "ms_per_plan_aggregate": dt / (args.steps * P) * 1e3}))
 
 
+# ---- launch ---------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1) and pass their output through."""
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and n_dev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices, {n_dev} visible (RCCL runs one rank per GPU; "
+                         f"--backend gloo shares a device between ranks, for tests only)")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="demo1", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="demo_1", choices=list(WORKLOADS))
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for --gpus N > 1 (nccl = RCCL; gloo only for tests on a single-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-recorded", action="store_true", help="skip the extra closed loops on the four recorded demo scenes")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (synthetic branching, cfg4 tree, other recorded scenes)")
+    ap.add_argument("--tree-steps", type=int, default=2, help="planning cycles of the extra cfg4-tree measurement")
     ap.add_argument("--concurrent", type=int, default=0,
                     help="BASELINE config 3: plan this many independent scenes concurrently on the GPU (one host thread, "
                          "HIP context and stream per scene); prints the aggregate rate")
     ap.add_argument("--processes", action="store_true",
                     help="with --concurrent: one host PROCESS per scene instead of one thread (host bookkeeping in parallel too)")
     ap.add_argument("--shard", action="store_true",
-                    help="strong scaling: all ranks plan the SAME scene, AIME rounds and contingency solves sharded over ranks")
+                    help="strong scaling: all ranks plan the SAME scene, AIME rounds and contingency solves sharded over ranks "
+                         "(the default for the full-tree workloads)")
+    ap.add_argument("--replicas", action="store_true", help="N > 1: independent closed loops per rank even for a full-tree workload")
     args = ap.parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args, sys.argv[1:])
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.backend == "gloo":
+        local = local % torch.cuda.device_count()
+        os.environ["LOCAL_RANK"] = str(local)
     torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":       # RCCL over xGMI: one rank per GPU
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:                            # gloo: the same code path on a box with fewer GPUs than ranks (tests)
-            dist.init_process_group(args.backend)
+    dist = Dist(args.backend, local)
+    rank, world = dist.rank, dist.world
     if args.concurrent > 1:
         return run_concurrent_processes(args) if args.processes else run_concurrent(args)
-    wkw = dict(WORKLOADS[args.workload])
-    if not args.shard and "seed" in wkw:
-        wkw["seed"] = wkw["seed"] + rank      # every rank plans its own scene (weak scaling)
-    real_scene = "scene" in wkw
-    pl, sim, w = make_closed_loop(wkw, full_tree=args.workload in FULL_TREE)
-    if args.shard and dist is not None:
-        pl.enable_sharding()
-    rt = pl.network.rt
-    sim.run_plans(max(args.warmup, 1))
-    rt.set_profiling(True)                     # HIP-event timing of the fusion pair kernels on the ctx stream
-    pair_ms, pair_launch, pair_n2 = [], 0, 0.0
-    pair_exec = [0.0]
-    expansions = 0
-    gen = pl.scen_tree_gen
-    orig_predict = rt.predict
-
-    # live accounting inside the timed region: k_pair launch durations come from HIP events recorded on the
-    # context stream around every launch (read back after the forward's own synchronisation point)
-    def prof_predict(*a, **k):
-        nonlocal pair_launch, pair_n2
-        o = orig_predict(*a, **k)
-        n, ms, pairs = rt.fusion_stats()
-        a_off, l_off = a[1], a[3]
-        n2 = sum(((a_off[i + 1] - a_off[i]) + (l_off[i + 1] - l_off[i]) + 1) ** 2 for i in range(len(a_off) - 1))
-        nfl = sum(((a_off[i + 1] - a_off[i]) + (l_off[i + 1] - l_off[i]) + 1) * (a_off[i + 1] - a_off[i] + 1) for i in range(len(a_off) - 1))
-        pair_ms.append(ms)
-        pair_launch += n
-        pair_n2 += n2
-        # FLOPs the kernel actually issues on the MFMA (after the algebraic folds): per pair 2 x 128x128 GEMMs (65 536) +
-        # 32 score MFMAs per 16 pairs (4 096); layer 4 updates only the actor/cls columns, layer 5 runs only those
-        pair_exec[0] += 4 * n2 * 69632.0 + n2 * 36864.0 + nfl * 32768.0 + nfl * 36864.0
-        return o
-
-    rt.predict = prof_predict
-    ctr0 = dict(pl.traj_tree_opt.counters)      # tree-iLQR accounting: the optimizer's own counters
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    n0 = pl.scen_tree_gen.n_expanded
-    sim_steps = sim.run_plans(args.steps)            # K planning cycles = ~5K simulator steps
-    expansions = pl.scen_tree_gen.n_expanded - n0
-    barrier()
-    dt = time.perf_counter() - t0
-    rt.predict = orig_predict
-    ctr = {k: v - ctr0.get(k, 0) for k, v in pl.traj_tree_opt.counters.items()}
-    ilqr = {"trees": ctr["solves"], "iterations": ctr["iterations"]}
-    rt.set_profiling(False)
-    lcl = sim._observation()
-    if dist is not None:
-        red_dev = "cuda" if args.backend == "nccl" else "cpu"
-        t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        e = torch.tensor([expansions], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(e)
-        expansions_all = float(e.item())
-    else:
-        expansions_all = float(expansions)
-    total_pair_s = sum(pair_ms) * 1e-3
-    achieved = F_MIN_N2 * pair_n2 / total_pair_s if total_pair_s > 0 else 0.0
-    # HBM traffic of k_pair from the committed PMC passes of this same command (FETCH_SIZE, WRITE_SIZE in
-    # separate rocprofv3 runs, gfx950 x2 correction on the fetch side): profiles/r01_pmc_k_pair.json
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_k_pair.json")
-    if args.workload == "demo1" and os.path.exists(pmc_path):
-        try:
-            traffic = json.load(open(pmc_path))["k_pair_per_launch"]["hbm_bytes"]
-        except Exception:
-            traffic = None
-    value = sim_steps * (1 if args.shard else world) / dt
-    a = len(pl.agent_obs)
-    l = gen.lane_feat_in.shape[0]
+    shard = world > 1 and not args.replicas and (args.shard or args.workload in FULL_TREE)
+    m = measure(dist, args.workload, args.steps, args.warmup, shard, replica=0 if shard else rank)
+    pl, sim = m["pl"], m["sim"]
+    prec = pl.network.rt.pair_precision()
+    value = m["sim_steps"] * (1 if shard else world) / m["dt"]
+    a, l = m["a"], m["l"]
+    exp_plan = m["expansions_all"] / args.steps / (1 if shard else world)
+    ctr = m["ilqr"]
+    real = m["real_scene"]
     out = {
-        "metric": "sim steps/sec (whole node) + scenario-tree nodes expanded/sec, AV2 demo scenes",
-        "value": value, "unit": "sim steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.shard else "weak", "vs_baseline": None,
-        "dtype": "f32 predictor / f64 iLQR",
+        "metric": METRIC, "value": value, "unit": "sim steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": m["dt"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
+        "dtype": {"f32": "f32", "bf16x3": "bf16x3 (bf16 hi+lo split operands, fp32 accumulate: fp32-accurate)", "bf16": "bf16"}[prec]
+                 + " pair kernel, f32 elsewhere in the predictor / f64 iLQR",
         "data": ("recorded AV2 scene (map + tracks of the reference's %s, tests/golden/scenes) with synthetic formula-initialised "
-                 "weights" % args.workload) if real_scene else "synthetic",
-        "nodes_expanded_per_s": expansions_all / dt,
-        "config": {"workload": (f"recorded scene {args.workload}" if real_scene else f"{args.workload}-like synthetic scene") +
+                 "weights" % args.workload) if real else "synthetic",
+        "nodes_expanded_per_s": m["expansions_all"] / m["dt"],
+        "config": {"workload": (f"BASELINE configs[1]: closed loop on the recorded scene {args.workload}" if real else f"{args.workload}-like synthetic scene") +
                                f": {a} agents x {l} lane polylines (N={a+l+1} tokens), "
-                               f"one closed-loop planning cycle per step = AIME tree ({expansions // args.steps} node expansions, "
-                               + ("the predictor's own modes with formula weights, exactly what the reference computes with these weights" if real_scene else
+                               f"one closed-loop planning cycle per step = AIME tree ({exp_plan:.1f} node expansions, "
+                               + ("the predictor's own modes with formula weights, exactly what the reference computes with these weights" if real else
                                   "scripted mode branching on top of the real predictor forward: no trained checkpoint exists") + ") + "
-                               f"tree-iLQR warm+full solves of {pl.timing['n_scen_trees']} scenario trees; closed loop: {sim_steps} simulator steps "
+                               f"tree-iLQR warm+full solves of {pl.timing['n_scen_trees']} scenario trees; closed loop: {m['sim_steps']} simulator steps "
                                f"(0.02 s) for {args.steps} plans",
-                   "agents": a, "lane_polylines": l, "expansions_per_plan": expansions // args.steps, "sim_steps_timed": sim_steps,
-                   "scenario_trees_per_plan": pl.timing["n_scen_trees"], "parallelism": f"{world} independent scenes (one per GPU)"},
-        "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F32_MFMA, "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_k_pair.json)", "kernel": "k_pair (RelaFusionLayer pair kernel)",
-                     "mfma_executed": {"tflops": (pair_exec[0] / total_pair_s / 1e12) if total_pair_s > 0 else None,
-                                       "frac_of_peak": (pair_exec[0] / total_pair_s / PEAK_F32_MFMA) if total_pair_s > 0 else None,
-                                       "note": "FLOPs actually issued on the MFMA after the algebraic folds (0.46-0.55 x F_min): frac "
-                                               "above can exceed 1 because `achieved` prices the reference-minimal algorithm F_min, "
-                                               "as SURVEY 8(d) prescribes"},
-                     "launches_profiled": pair_launch, "avg_launch_ms": (sum(pair_ms) / pair_launch) if pair_launch else None,
-                     "algorithmic_flops_per_launch": (F_MIN_N2 * pair_n2 / pair_launch) if pair_launch else None,
-                     "note": "algorithmic FLOPs = SURVEY 8(d) F_min N^2 term (754944*N^2 per expansion over 6 launches); "
-                             "launch durations from HIP events on the context stream, recorded inside the timed region"
-                             + ("; measured in situ: launches that coincide with a speculative warm-start fit on the planner's second "
-                                "context take ~4 us longer (frac 0.49 with MIND_SPECULATIVE_WARM_START=0, DESIGN 5)"
-                                if pl.traj_tree_opt.speculative else "")},
+                   "agents": a, "lane_polylines": l, "expansions_per_plan": exp_plan, "sim_steps_timed": m["sim_steps"],
+                   "scenario_trees_per_plan": pl.timing["n_scen_trees"],
+                   "parallelism": (f"one plan sharded over {world} GPUs (AIME rounds block-sharded, solves round-robin, RCCL all-gather/broadcast per round)" if shard
+                                   else f"{world} independent closed loops (one per GPU, no data-path collective)")},
+        "roofline": roofline(m, prec),
         # the tree-iLQR kernel is latency-bound (serial depth x iterations, SURVEY 8d): reported as rates, not against a roofline
-        "ilqr": {"solves_per_s": ilqr["trees"] / dt, "iterations_per_s": ilqr["iterations"] / dt,
-                 "trees_per_plan": ilqr["trees"] / max(args.steps, 1) / 2, "iterations_per_solve": ilqr["iterations"] / max(ilqr["trees"], 1),
+        "ilqr": {"solves_per_s": ctr["solves"] / m["dt"], "iterations_per_s": ctr["iterations"] / m["dt"],
+                 "trees_per_plan": ctr["solves"] / max(args.steps, 1) / 2, "iterations_per_solve": ctr["iterations"] / max(ctr["solves"], 1),
                  "warm_start_fits_speculated": ctr["warm_speculated"], "warm_start_fits_reused": ctr["warm_hits"],
                  "note": "per rank; every scenario tree is solved twice per plan (warm start, then full cost); the warm-start fits of "
                          "the previous cycle's tree shapes run beside the predictor and are reused where the shape recurs"},
         "breakdown_ms": {"aime": pl.timing["aime_s"] * 1e3, "ilqr": pl.timing["ilqr_s"] * 1e3},
     }
+    if m["collectives"] is not None:
+        out["collectives_per_plan"] = m["collectives"][0] / args.steps
+        out["gathered_mb_per_plan"] = m["collectives"][1] / args.steps / 1e6
+    extras = not args.no_extras and args.workload == "demo_1"
+    if extras:
+        # the full cfg4 scenario tree (259 expansions per plan): on one GPU, or planned once by all ranks together
+        t = measure(dist, "cfg4tree", args.tree_steps, 1, world > 1)
+        out["tree_sharded" if world > 1 else "tree"] = dict(summarize(t, prec), workload="cfg4tree: 64 agents x 256 lane polylines, full scripted 6-ary "
+                                                            "depth-4 AIME tree on the real predictor forward", n_gpus=world,
+                                                            scaling="strong" if world > 1 else None, plans_timed=args.tree_steps)
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            lcl = sim._observation()
+            out["cpu_baseline"] = cpu_baseline(pl, lcl, (a, l), max(int(round(exp_plan)), 1), pl.scen_tree_gen.get_scenario_tree())
+        if extras:
+            out["synthetic_branching"] = dict(summarize(measure(dist, "demo1", args.steps, args.warmup, False), prec),
+                                              workload="demo_1-like synthetic scene, scripted mode branching on the real predictor forward")
+            out["recorded_scenes"] = recorded_scenes(prec)
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            scen_trees = gen.get_scenario_tree()
-            out["cpu_baseline"] = cpu_baseline(pl, lcl, (a, l), expansions // args.steps, scen_trees)
-        if world == 1 and not args.no_recorded and not real_scene:
-            out["recorded_scenes"] = recorded_scenes()
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.close()
 
 
 if __name__ == "__main__":

@@ -5,18 +5,23 @@ The reference has no distributed code at all.  The path shards
   * within one AIME round every branch node's scene forward + prune/merge is independent
     (planners/mind/networks/network.py:318,497 loop per scene), so a round's scenes are block-
     distributed over the ranks; the ONE real exchange step per round is an all-gather of the kept
-    children (small: ids + [a,100,7] histories), after which every rank holds the identical tree and
-    takes the branching decisions redundantly (deterministic host code);
+    children -- a [P, 25] float32 header (scene index in the round, mode, path probability, the
+    node's 11-point target window) and the [a, 60, 6] world-frame rows of the surviving modes, as
+    packed tensors that never leave the device before the collective (RCCL ``all_gather_into_tensor``
+    over xGMI; gloo moves the same tensors in the CPU tests).  Afterwards every rank holds the
+    identical tree and takes the (cheap, deterministic) branching decisions itself; the re-basing of
+    the next round's scenes (mind_aime_rebase) runs only on the rank that owns the scene;
   * contingency solves are independent per scenario tree (planners/mind/planner.py:120-123): trees
-    are dealt round-robin, results all-gathered.
+    are dealt round-robin, their [M, 8] float64 (xs | us) rows all-gathered.
 Predictor results are bit-identical for any batch composition (the kernel's column-split rule depends
 on the scene's own size only), so 1/2/4/8-rank runs build the same node sets.
 """
 import numpy as np
+import torch
 
 
 class Shard:
-    """Contiguous block sharding + object all-gather over a torch.distributed process group."""
+    """Contiguous block / round-robin partitions + packed-tensor all-gather over a process group."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -25,6 +30,11 @@ class Shard:
         self.active = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if self.active else 0
         self.world = dist.get_world_size(group) if self.active else 1
+        self.backend = dist.get_backend(group) if self.active else None
+        # RCCL moves device tensors; gloo (tests) moves host tensors
+        self.device = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
+        self.n_collectives = 0
+        self.bytes_gathered = 0
 
     def block(self, n):
         """[lo, hi) of this rank among n items (first ranks get the remainder)."""
@@ -35,28 +45,61 @@ class Shard:
     def round_robin(self, n):
         return list(range(self.rank, n, self.world))
 
-    def all_gather(self, obj):
-        """list over ranks of `obj` (pickled; one collective)."""
+    def all_gather_rows(self, *tensors):
+        """Every tensor is [n_i, ...] on this rank with rank-dependent n_i.  Returns, per tensor, the rows of all
+        ranks concatenated in rank order (on ``self.device``) -- one small collective for all the counts, one
+        ``all_gather_into_tensor`` per tensor on buffers padded to the largest rank."""
         if not self.active or self.world == 1:
-            return [obj]
-        out = [None] * self.world
-        self.dist.all_gather_object(out, obj, group=self.group)
+            return [t for t in tensors]
+        dist, W, dev = self.dist, self.world, self.device
+        cnt = torch.tensor([int(t.shape[0]) for t in tensors], dtype=torch.int64, device=dev)
+        cnts = torch.empty(W * len(tensors), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(cnts, cnt, group=self.group)
+        cnts = cnts.view(W, len(tensors)).tolist()
+        self.n_collectives += 1
+        out = []
+        for i, t in enumerate(tensors):
+            mx = max(c[i] for c in cnts)
+            tail = tuple(t.shape[1:])
+            if mx == 0:
+                out.append(torch.empty((0,) + tail, dtype=t.dtype, device=dev))
+                continue
+            buf = torch.zeros((mx,) + tail, dtype=t.dtype, device=dev)
+            if t.shape[0]:
+                buf[:t.shape[0]] = t.to(dev)
+            full = torch.empty((W * mx,) + tail, dtype=t.dtype, device=dev)
+            dist.all_gather_into_tensor(full, buf, group=self.group)
+            self.n_collectives += 1
+            self.bytes_gathered += full.numel() * full.element_size()
+            if all(c[i] == mx for c in cnts):
+                out.append(full)
+            else:
+                out.append(torch.cat([full[r * mx:r * mx + cnts[r][i]] for r in range(W)]))
         return out
 
+    def broadcast(self, t, src=0):
+        """In-place broadcast of a tensor on ``self.device`` from ``src``."""
+        if self.active and self.world > 1:
+            self.dist.broadcast(t, src, group=self.group)
+            self.n_collectives += 1
+        return t
 
-def gather_blocks(shard, local_items):
-    """Concatenate per-rank lists in rank order (= original order for block sharding)."""
-    out = []
-    for part in shard.all_gather(local_items):
-        out.extend(part)
-    return out
 
-
-def gather_round_robin(shard, n, local_results):
-    """Inverse of Shard.round_robin: local_results[i] belongs to item shard.rank + i * world."""
-    parts = shard.all_gather(local_results)
-    out = [None] * n
-    for r, part in enumerate(parts):
-        for i, v in enumerate(part):
-            out[r + i * len(parts)] = v
+def gather_round_robin(shard, sizes, local_rows):
+    """Inverse of ``Shard.round_robin`` for variable-size results: item i (dealt to rank i % world) is a
+    [sizes[i], C] array; ``local_rows`` is this rank's items concatenated in its own order.  Returns the list of
+    all n items (numpy) on every rank -- one packed all-gather."""
+    n = len(sizes)
+    t = torch.from_numpy(np.ascontiguousarray(local_rows))
+    if not shard.active or shard.world == 1:
+        flat = t
+        order = list(range(n))
+    else:
+        flat = shard.all_gather_rows(t)[0].cpu()
+        order = [i for r in range(shard.world) for i in range(r, n, shard.world)]
+    flat = flat.numpy()
+    out, o = [None] * n, 0
+    for i in order:
+        out[i] = flat[o:o + sizes[i]]
+        o += sizes[i]
     return out

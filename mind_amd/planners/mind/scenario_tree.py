@@ -50,6 +50,11 @@ class DevScene(dict):
         return dict.__getitem__(self, key)
 
 
+class RemoteScene(dict):
+    """Observation of a branch node that ANOTHER rank re-bases and expands (sharded rounds): only the world-frame fields the
+    tree bookkeeping and the child assembly read; no predictor inputs exist on this rank."""
+
+
 def _np(x):
     if isinstance(x, torch.Tensor):
         return x.detach().cpu().numpy()
@@ -75,12 +80,14 @@ class ScenarioTreeGenerator:
         self.branch_depth = 0
         self.n_expanded = 0           # scenes pushed through the predictor (metric: nodes expanded)
         self.shard = None             # mind_amd.parallel.Shard: block-distribute each round's scenes over ranks
+        self._plan_round = 0
 
     # ------------------------------------------------------------------------------------------
     def reset(self):
         self.branch_depth = 0
         self.tree = Tree()
         self.lane_feat_cache = None
+        self._plan_round = 0
 
     def set_target_lane(self, target_lane, target_lane_info):
         self.target_lane = np.asarray(target_lane).astype(F32) if np.asarray(target_lane).dtype != np.float64 \
@@ -112,17 +119,46 @@ class ScenarioTreeGenerator:
         self.create_nodes(self.expand([root]))
         self.decide_branch()
 
+    HDR = 25      # per kept child: [scene index in the round, mode, path probability, TGT_PTS (11 x 2)]
+
     def expand(self, batch):
-        """One AIME round: predict + prune/merge every scene of the branch set.  With a Shard the scenes
-        are block-distributed over the ranks and the kept children all-gathered (the round's only
-        exchange step); every rank ends up with the same list in batch order."""
-        if self.shard is None or self.shard.world == 1:
-            return self.prune_merge(batch, self.predict_scenes(batch))
-        from ...parallel import gather_blocks
-        lo, hi = self.shard.block(len(batch))
+        """One AIME round: predict + prune/merge every scene of the branch set, then build the child dicts.  With a
+        Shard the scenes are block-distributed over the ranks; the round's only exchange step is one packed all-gather
+        of the kept children (header [P,25] + world-frame rows [sum a,60,6] of the surviving modes, device tensors under
+        RCCL), after which every rank assembles the same list in batch order.  The first round of a plan (the root
+        scene, on rank 0) is followed by a broadcast of LaneNet's output, which every later round reuses."""
+        sh = self.shard
+        if sh is None or sh.world == 1:
+            hdr, rows = self.prune_select(batch, self.predict_scenes(batch) if batch else None, 0)
+            return self.assemble_children(batch, hdr, _np(rows))
+        lo, hi = sh.block(len(batch))
         mine = batch[lo:hi]
-        kept = self.prune_merge(mine, self.predict_scenes(mine), idx_offset=lo) if mine else []
-        return gather_blocks(self.shard, kept)
+        assert not any(isinstance(s, RemoteScene) for s in mine), "a rank was dealt a scene it did not re-base"
+        first_round = self._plan_round == 0
+        self._plan_round += 1
+        if mine:
+            hdr, rows = self.prune_select(mine, self.predict_scenes(mine), lo)
+        else:
+            hdr, rows = np.zeros((0, self.HDR), F32), torch.zeros(0, 60, 6)
+        if first_round:
+            self._broadcast_lane_features(sh)
+        hdr_all, rows_all = sh.all_gather_rows(torch.from_numpy(np.ascontiguousarray(hdr, F32)), rows.reshape(-1, 360))
+        return self.assemble_children(batch, hdr_all.cpu().numpy(), rows_all.cpu().numpy().reshape(-1, 60, 6))
+
+    def _broadcast_lane_features(self, sh):
+        """LaneNet's output [l,128] (instance-frame lane features: constant within a plan, utils.py:171-177) from the rank
+        that ran the root scene to every rank: RCCL broadcast of the device tensor (a host tensor over gloo).  The last
+        element says whether the sender's network left a cache at all (host networks of the CPU tests do not)."""
+        l = int(self.lane_feat_in.shape[0])
+        buf = torch.zeros(l * 128 + 1, dtype=torch.float32, device=sh.device)
+        cache = self.lane_feat_cache
+        if sh.rank == 0 and cache is not None and cache.shape[0] == l:
+            buf[:l * 128] = cache.reshape(-1).to(sh.device)
+            buf[-1] = 1.0
+        sh.broadcast(buf, 0)
+        if sh.rank != 0 and float(buf[-1]) == 1.0:
+            dev = getattr(getattr(self.network, "rt", None), "device", None)
+            self.lane_feat_cache = buf[:l * 128].view(l, 128).to(dev if dev is not None else buf.device).contiguous()
 
     # ------------------------------------------------------------------------------------------
     def collate(self, scenes):
@@ -212,7 +248,10 @@ class ScenarioTreeGenerator:
             else:
                 l.data.end_flag = True
         if todo:
-            for l, (obs, cur) in zip(todo, self.update_obser_batch([l.data.data for l in todo])):
+            own = None
+            if self.shard is not None and self.shard.world > 1:
+                own = self.shard.block(len(todo))       # the rank that expands a scene next round is the one that re-bases it
+            for l, (obs, cur) in zip(todo, self.update_obser_batch([l.data.data for l in todo], own)):
                 l.data.obs_data, l.data.data = obs, cur
                 l.data.branch_flag = True
 
@@ -341,10 +380,18 @@ class ScenarioTreeGenerator:
             cands = rest
         return selected
 
-    def _prune_merge_device(self, scenes, packed, idx_offset):
-        """prune_merge with the per-(agent, mode, step) arithmetic on the MI355X (mind_aime_world): the predictor
-        outputs never leave the device; the host reads cls / topology signatures / ego end points (one small
-        copy), decides, and fetches the world-frame histories of the SURVIVING modes only (second copy)."""
+    def _hdr(self, picks, scenes, idx_offset):
+        hdr = np.zeros((len(picks), self.HDR), F32)
+        for r, (lidx, k, prob) in enumerate(picks):
+            hdr[r, 0], hdr[r, 1], hdr[r, 2] = lidx + idx_offset, k, prob
+            hdr[r, 3:] = np.asarray(scenes[lidx]["TGT_PTS"], F32).reshape(-1)
+        return hdr
+
+    def _prune_select_device(self, scenes, packed, idx_offset):
+        """Pruning decisions with the per-(agent, mode, step) arithmetic on the MI355X (mind_aime_world): the predictor
+        outputs never leave the device; the host reads cls / topology signatures / ego end points (one small copy) and
+        decides; the world-frame rows of the SURVIVING modes are gathered on the device (``rows`` stays there: the caller
+        copies it to the host once, after the multi-GPU exchange if there is one)."""
         rt, a_off = packed["rt"], packed["a_off"]
         B, A, L = len(scenes), int(packed["a_off"][-1]), self.seq_len
         lasts = [L - 1 - sc["TRAJS_POS_HIST"].shape[1] for sc in scenes]
@@ -369,35 +416,25 @@ class ScenarioTreeGenerator:
             for k, prob in self._select_modes(sc, cls_all[lidx], topo[a_off[lidx] + 1:a_off[lidx + 1]], ego_end,
                                               None if dis_round is None else dis_round[lidx]):
                 picks.append((lidx, k, prob))
-        if not picks:
-            return []
-        flat = np.concatenate([np.arange(a_off[l], a_off[l + 1]) * 6 + k for l, k, _ in picks])       # (agent row, mode) -> row of [A*6]
         dev = w["world"].device
-        sel = w["world"].view(A * 6, 60, 6).index_select(0, torch.from_numpy(flat).to(dev)).cpu().numpy()   # [R,60,6]
-        kept, r0 = [], 0
-        for lidx, k, prob in picks:
-            sc = scenes[lidx]
-            a = a_off[lidx + 1] - a_off[lidx]
-            m = sel[r0:r0 + a]
-            r0 += a
-            kept.append({
-                "SCEN_PROB": prob, "CUR_T": sc["CUR_T"], "END_T": sc["END_T"],
-                "PARENT_ID": sc["SCEN_ID"], "SCEN_ID": "{}_{}_{}".format(self.branch_depth, lidx + idx_offset, k),
-                "TRAJS_TYPE": sc["TRAJS_TYPE"], "TRAJS_TID": sc["TRAJS_TID"], "TRAJS_CAT": sc["TRAJS_CAT"],
-                "TRAJS_POS_HIST": np.concatenate([sc["TRAJS_POS_HIST"], m[:, :, 0:2]], axis=1)[:, :L],
-                "TRAJS_COV_HIST": np.concatenate([sc["TRAJS_COV_HIST"], m[:, :, 5:6]], axis=1)[:, :L],
-                "TRAJS_ANG_HIST": np.concatenate([sc["TRAJS_ANG_HIST"], m[:, :, 4]], axis=1)[:, :L],
-                "TRAJS_VEL_HIST": np.concatenate([sc["TRAJS_VEL_HIST"], m[:, :, 2:4]], axis=1)[:, :L],
-                "TGT_PTS": sc["TGT_PTS"],
-            })
-        return kept
+        if not picks:
+            return np.zeros((0, self.HDR), F32), torch.zeros(0, 60, 6, device=dev)
+        flat = np.concatenate([np.arange(a_off[l], a_off[l + 1]) * 6 + k for l, k, _ in picks])       # (agent row, mode) -> row of [A*6]
+        rows = w["world"].view(A * 6, 60, 6).index_select(0, torch.from_numpy(flat).to(dev))           # [R,60,6] (x,y,vx,vy,heading,max-sigma)
+        return self._hdr(picks, scenes, idx_offset), rows
 
-    def prune_merge(self, scenes, out, idx_offset=0):
+    def prune_select(self, scenes, out, idx_offset=0):
+        """prune_merge, first half (scenario_tree.py:281-395): world-frame modes, probability / target-lane pruning, greedy
+        topology merge.  -> (hdr [P,25] float32: scene index in the round's full batch, mode, path probability, the
+        scene's target window; rows [sum a,60,6]: (x, y, vx, vy, heading, max-sigma) of every agent of every kept mode,
+        a device tensor when the predictor outputs live on the device)."""
+        if not scenes:
+            return np.zeros((0, self.HDR), F32), torch.zeros(0, 60, 6)
         res_cls_b, res_reg_b, res_aux_b = out
         packed = getattr(self.network, "last_packed", None)
         if (self.device_glue and packed is not None and packed["n"] == len(scenes) and packed.get("rt") is not None
                 and packed.get("actor_ctrs") is not None and self.ego_idx == 0):
-            return self._prune_merge_device(scenes, packed, idx_offset)
+            return self._prune_select_device(scenes, packed, idx_offset)
         if packed is not None and packed["n"] == len(scenes):
             # one device->host copy per tensor for the whole round instead of three per scene
             cls_all, reg_all, vel_all = (_np(packed[k]) for k in ("cls", "reg", "vel"))
@@ -405,9 +442,8 @@ class ScenarioTreeGenerator:
             res_cls_b = [cls_all[i:i + 1] for i in range(len(scenes))]
             res_reg_b = [reg_all[off[i]:off[i + 1]] for i in range(len(scenes))]
             res_aux_b = [(vel_all[off[i]:off[i + 1]], None, None) for i in range(len(scenes))]
-        kept = []
+        picks, rows = [], []
         for lidx, sc in enumerate(scenes):
-            idx = lidx + idx_offset      # position in the round's full batch (part of the node id)
             rot, orig = sc["ROT"], sc["ORIG"]
             ctrs, vecs = sc["TRAJS_CTRS"], sc["TRAJS_VECS"]
             theta_g = np.arctan2(rot[1, 0], rot[0, 0])
@@ -436,20 +472,43 @@ class ScenarioTreeGenerator:
                 if last >= 0:
                     return pos_all[self.ego_idx, k, last], cov_all[self.ego_idx, k, last]
                 return sc["TRAJS_POS_HIST"][self.ego_idx][L - 1], sc["TRAJS_COV_HIST"][self.ego_idx][L - 1]
-            selected = self._select_modes(sc, cls[0], topo_all, ego_end)
-            # only the surviving modes get their histories extended (world frame, truncated to seq_len, Q8)
-            for k, prob in selected:
-                kept.append({
-                    "SCEN_PROB": prob, "CUR_T": sc["CUR_T"], "END_T": sc["END_T"],
-                    "PARENT_ID": sc["SCEN_ID"], "SCEN_ID": "{}_{}_{}".format(self.branch_depth, idx, k),
-                    "TRAJS_TYPE": sc["TRAJS_TYPE"], "TRAJS_TID": sc["TRAJS_TID"], "TRAJS_CAT": sc["TRAJS_CAT"],
-                    "TRAJS_POS_HIST": np.concatenate([sc["TRAJS_POS_HIST"], pos_all[:, k]], axis=1)[:, :L],
-                    "TRAJS_COV_HIST": np.concatenate([sc["TRAJS_COV_HIST"], cov_all[:, k].astype(F32)], axis=1)[:, :L],
-                    "TRAJS_ANG_HIST": np.concatenate([sc["TRAJS_ANG_HIST"], ang_all[:, k]], axis=1)[:, :L],
-                    "TRAJS_VEL_HIST": np.concatenate([sc["TRAJS_VEL_HIST"], vel_all[:, k]], axis=1)[:, :L],
-                    "TGT_PTS": sc["TGT_PTS"],
-                })
+            for k, prob in self._select_modes(sc, cls[0], topo_all, ego_end):
+                picks.append((lidx, k, prob))
+                rows.append(np.concatenate([pos_all[:, k], vel_all[:, k], ang_all[:, k][..., None],
+                                            cov_all[:, k].astype(F32).reshape(a_, T_, 1)], axis=-1).astype(F32, copy=False))
+        if not picks:
+            return np.zeros((0, self.HDR), F32), torch.zeros(0, 60, 6)
+        return self._hdr(picks, scenes, idx_offset), torch.from_numpy(np.ascontiguousarray(np.concatenate(rows)))
+
+    def assemble_children(self, batch, hdr, rows):
+        """prune_merge, second half (scenario_tree.py:396-412): the child dict of every kept mode -- the parent's world-frame
+        history extended by the mode's 60 steps and truncated to seq_len (Q8).  ``batch`` is the round's full branch set
+        (every rank holds its world-frame fields), ``hdr`` / ``rows`` as returned by prune_select, concatenated in batch order
+        over all ranks when the round was sharded."""
+        kept, r0, L = [], 0, self.seq_len
+        for h in hdr:
+            gidx, k = int(h[0]), int(h[1])
+            sc = batch[gidx]
+            a = sc["TRAJS_POS_HIST"].shape[0]
+            m = rows[r0:r0 + a]
+            r0 += a
+            kept.append({
+                "SCEN_PROB": F32(h[2]), "CUR_T": sc["CUR_T"], "END_T": sc["END_T"],
+                "PARENT_ID": sc["SCEN_ID"], "SCEN_ID": "{}_{}_{}".format(self.branch_depth, gidx, k),
+                "TRAJS_TYPE": sc["TRAJS_TYPE"], "TRAJS_TID": sc["TRAJS_TID"], "TRAJS_CAT": sc["TRAJS_CAT"],
+                "TRAJS_POS_HIST": np.concatenate([sc["TRAJS_POS_HIST"], m[:, :, 0:2]], axis=1)[:, :L],
+                "TRAJS_COV_HIST": np.concatenate([sc["TRAJS_COV_HIST"], m[:, :, 5:6]], axis=1)[:, :L],
+                "TRAJS_ANG_HIST": np.concatenate([sc["TRAJS_ANG_HIST"], m[:, :, 4]], axis=1)[:, :L],
+                "TRAJS_VEL_HIST": np.concatenate([sc["TRAJS_VEL_HIST"], m[:, :, 2:4]], axis=1)[:, :L],
+                "TGT_PTS": np.array(h[3:], F32).reshape(11, 2),
+            })
+        assert r0 == len(rows), (r0, len(rows))
         return kept
+
+    def prune_merge(self, scenes, out):
+        """scenario_tree.py:281-412 in one call (single process)."""
+        hdr, rows = self.prune_select(scenes, out, 0)
+        return self.assemble_children(scenes, hdr, _np(rows))
 
     def get_branch_time(self, d):
         cov = d["TRAJS_COV_HIST"]
@@ -541,9 +600,28 @@ class ScenarioTreeGenerator:
             self._seg_cache = (lane, np.sqrt((dl * dl).sum(-1), dtype=F32))
         return self._seg_cache[1]
 
-    def update_obser_batch(self, curs):
+    def update_obser_batch(self, curs, own=None):
         """update_obser (scenario_tree.py:467-567) for all branching nodes of a round at once; nodes must share the
-        agent set (they are children of one plan).  Returns [(obs_data, cur)] in order."""
+        agent set (they are children of one plan).  Returns [(obs_data, cur)] in order.  ``own`` = [lo, hi): only these
+        nodes are re-based here (sharded rounds); the others get a RemoteScene with the world-frame fields."""
+        if own is not None:
+            lo, hi = own
+            o = self.obs_len
+            out = [None] * len(curs)
+            for g, c in enumerate(curs):
+                if lo <= g < hi:
+                    continue
+                keep = o + (c["END_T"] - c["CUR_T"])
+                for k in ("TRAJS_POS_HIST", "TRAJS_COV_HIST", "TRAJS_ANG_HIST", "TRAJS_VEL_HIST"):
+                    c[k] = c[k][:, :keep]
+                out[g] = (RemoteScene({"TRAJS_TYPE": c["TRAJS_TYPE"], "SCEN_PROB": c["SCEN_PROB"], "SCEN_ID": c["SCEN_ID"],
+                                       "PARENT_ID": c["PARENT_ID"], "CUR_T": c["END_T"], "END_T": self.pred_len,
+                                       "TRAJS_TID": c["TRAJS_TID"], "TRAJS_CAT": c["TRAJS_CAT"],
+                                       "TRAJS_POS_HIST": c["TRAJS_POS_HIST"][:, -o:].copy(), "TRAJS_COV_HIST": c["TRAJS_COV_HIST"][:, -o:].copy(),
+                                       "TRAJS_ANG_HIST": c["TRAJS_ANG_HIST"][:, -o:].copy(), "TRAJS_VEL_HIST": c["TRAJS_VEL_HIST"][:, -o:].copy()}), c)
+            if hi > lo:
+                out[lo:hi] = self.update_obser_batch(curs[lo:hi])
+            return out
         a_counts = {c["TRAJS_POS_HIST"].shape[0] for c in curs}
         rt = getattr(self.network, "rt", None) if self.device_glue else None
         on_dev = (rt is not None and len(a_counts) == 1 and self.target_lane is not None and len(self.target_lane) >= 12

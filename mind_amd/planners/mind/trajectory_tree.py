@@ -44,6 +44,12 @@ def flatten_scenario_tree(scen_tree):
 def ilqr_cfg_from(config, block, max_iter=100):
     """TrajTreeCfg (w_opt_cfg / opt_cfg dict) -> C struct."""
     o = getattr(config, block)
+    for name in ("w_des_state", "w_state_con", "w_ctrl"):
+        m = np.asarray(o[name], np.float64)
+        if m.ndim != 2 or np.any(m - np.diag(np.diag(m)) != 0.0):
+            # the kernel carries the diagonals of the reference's weight matrices (all of its planning configs are
+            # diagonal, configs/planning/demo_*.py:21-81); a full matrix would silently be a different problem
+            raise ValueError(f"{block}.{name}: only diagonal weight matrices are supported by the tree-iLQR kernel")
     c = _lib.IlqrCfg()
     c.dt, c.wheelbase = config.dt, 2.5                       # trajectory_tree.py:15
     c.w_des_state[:] = list(np.diag(o["w_des_state"]))
@@ -110,6 +116,7 @@ class TrajectoryTreeOptimizer:
         self._worker = None
         self._last_structs = []
         self._spec = None
+        self._spec_skip, self._spec_backoff, self._spec_last = 0, 4, None
         self.counters = {"solves": 0, "iterations": 0, "warm_speculated": 0, "warm_hits": 0}
 
     def _runtime(self):
@@ -161,6 +168,12 @@ class TrajectoryTreeOptimizer:
     def speculate_warm(self, init_state, init_ctrl, target_lane, target_vel):
         if not self.speculative or self.solver is not None or self.shard is not None or not self._last_structs:
             return
+        # a speculated fit only pays when the tree shape (parents + node probabilities) recurs: after a cycle in which
+        # fewer than half of the guesses were used, skip the next `_spec_backoff` cycles, then probe again
+        if self._spec_skip > 0:
+            self._spec_skip -= 1
+            self._spec_last = None
+            return
         from ...predictor import IlqrCall
         x0 = self._get_init_state(init_state, init_ctrl)
         lane = np.array(target_lane, dtype=np.float64)
@@ -171,6 +184,7 @@ class TrajectoryTreeOptimizer:
         self._spec = dict(x0=x0, lane=lane, tv=float(target_vel), structs=self._last_structs, call=call,
                           fut=self._side().submit(call))
         self.counters["warm_speculated"] += len(self._last_structs)
+        self._spec_last = len(self._last_structs)
 
     def _side(self):
         if self._worker is None:
@@ -185,7 +199,7 @@ class TrajectoryTreeOptimizer:
         try:
             spec["fut"].result()
             _, us, st = spec["call"].finish()
-        except Exception:                     # the in-line path below then computes (or reports) the same thing
+        except _lib.MindError:                # the in-line path below then computes (or reports) the same thing
             self.counters["warm_failed"] = self.counters.get("warm_failed", 0) + len(spec["structs"])
             return {}
         if not (np.array_equal(spec["x0"], x0) and np.array_equal(spec["lane"], lane) and spec["tv"] == float(target_vel)):
@@ -215,6 +229,9 @@ class TrajectoryTreeOptimizer:
                 hits = self._take_speculation(sub, x0, lane, target_vel) if self.shard is None else {}
                 self._last_structs = [(np.ascontiguousarray(f["parent"], np.int32), np.ascontiguousarray(f["prob"], np.float32)) for f in sub]
                 self.counters["warm_hits"] += len(hits)
+                if self._spec_last is not None and 2 * len(hits) < self._spec_last:
+                    self._spec_skip = self._spec_backoff
+                self._spec_last = None
                 xs, us, st_w, st = [None] * len(sub), [None] * len(sub), [None] * len(sub), [None] * len(sub)
                 from ...predictor import IlqrCall
                 hit_idx = sorted(hits)
@@ -243,8 +260,11 @@ class TrajectoryTreeOptimizer:
                 _, us_w, st_w = solve(ilqr_cfg_from(self.config, "w_opt_cfg"), sub, x0, lane, target_vel, 0, None)
                 xs, us, st = solve(ilqr_cfg_from(self.config, "opt_cfg"), sub, x0, lane, target_vel, 1, us_w)
         if self.shard is not None and self.shard.world > 1:
+            # one packed all-gather of the [M, 8] float64 (xs | us) rows of every rank's trees
             from ...parallel import gather_round_robin
-            res = gather_round_robin(self.shard, len(flats), list(zip(xs, us)))
-            xs, us = [r[0] for r in res], [r[1] for r in res]
+            local = (np.concatenate([np.concatenate([np.asarray(x, np.float64), np.asarray(u, np.float64)], axis=1) for x, u in zip(xs, us)])
+                     if mine else np.zeros((0, 8)))
+            res = gather_round_robin(self.shard, [len(f["parent"]) for f in flats], local)
+            xs, us = [np.ascontiguousarray(r[:, :6]) for r in res], [np.ascontiguousarray(r[:, 6:]) for r in res]
         self.debug = dict(warm=st_w, full=st)
         return [to_traj_tree(f, x0, x, u, self.config.action_size) for f, x, u in zip(flats, xs, us)]

@@ -18,6 +18,10 @@ def get_runtime(device=None):
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
         rt = _local.rt = HipPredictor(device)
+    elif device is not None and int(device) != rt.device.index:
+        # one context per thread: a second device in the same thread would silently run on the first one
+        raise RuntimeError(f"this thread's HIP runtime is bound to cuda:{rt.device.index}, cuda:{int(device)} was requested; "
+                           "use one host thread (or process) per device, or reset_runtime() first")
     return rt
 
 

@@ -14,7 +14,13 @@ def main(out_path, n_plans):
     from bench import WORKLOADS, make_closed_loop
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
-        dist.init_process_group("gloo")
+        backend = os.environ.get("MIND_DIST_BACKEND", "gloo")      # nccl = RCCL, one rank per GPU (LOCAL_RANK)
+        if backend == "nccl":
+            import torch
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+        else:
+            dist.init_process_group("gloo")
     pl, sim, w = make_closed_loop(dict(WORKLOADS["demo1"]))
     if world > 1:
         sh = pl.enable_sharding()

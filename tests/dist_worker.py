@@ -54,12 +54,29 @@ def run(shard_on):
     return out
 
 
+def collectives():
+    """ragged packed all-gather (a rank with zero rows included), round-robin gather, broadcast"""
+    from mind_amd.parallel import Shard, gather_round_robin
+    sh = Shard()
+    r, W = sh.rank, sh.world
+    a = torch.arange(r * 3 * 4, dtype=torch.float32).reshape(-1, 4) + 100 * r          # rank r: 3r rows (rank 0: none)
+    b = torch.full((2 + r, 2, 3), float(r))
+    ga, gb = sh.all_gather_rows(a, b)
+    sizes = [2, 1, 3, 2, 4]
+    mine = sh.round_robin(len(sizes))
+    local = np.concatenate([np.full((sizes[i], 8), float(i)) for i in mine]) if mine else np.zeros((0, 8))
+    rr = gather_round_robin(sh, sizes, local)
+    t = torch.full((5,), float(r + 7), device=sh.device)
+    sh.broadcast(t, 0)
+    return {"ga": ga.numpy(), "gb": gb.numpy(), "rr": [x.copy() for x in rr], "bc": t.numpy(), "n_coll": sh.n_collectives}
+
+
 if __name__ == "__main__":
     out_path = sys.argv[1]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         dist.init_process_group("gloo")
-    res = run(world > 1)
+    res = collectives() if len(sys.argv) > 2 and sys.argv[2] == "collectives" else run(world > 1)
     rank = dist.get_rank() if world > 1 else 0
     with open(f"{out_path}.{rank}", "wb") as f:
         pickle.dump(res, f)

@@ -170,7 +170,7 @@ def _full_tree_run(batched):
     lane, info = MINDPlanner.resample_target_lane(MINDPlanner.__new__(MINDPlanner), lcl)
     g = ScenarioTreeGenerator(torch.device("cpu"), CpuFull(Stub()), 50, 50, ScenTreeCfg())
     if not batched:
-        g.update_obser_batch = lambda curs: [g.update_obser(c) for c in curs]
+        g.update_obser_batch = lambda curs, own=None: [g.update_obser(c) for c in curs]
         g.get_branch_times = lambda datas: [g.get_branch_time(d) for d in datas]
     g.reset()
     g.set_target_lane(lane, info)

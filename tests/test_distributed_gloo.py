@@ -1,5 +1,5 @@
 """CPU, world_size 2 over gloo: the sharded hot path (scenes of every AIME round block-distributed over
-the ranks + all-gather of kept children; contingency solves dealt round-robin + all-gather) builds
+the ranks + packed-tensor all-gather of kept children (header + world-frame rows), lane-feature broadcast; contingency solves dealt round-robin + all-gather) builds
 exactly the same scenario / trajectory trees as the single-process run, on every rank."""
 import os
 import pickle
@@ -15,13 +15,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def _run(world, out, port):
+def _run(world, out, port, *extra):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
     if world == 1:
-        subprocess.check_call([sys.executable, WORKER, out], env=dict(env, WORLD_SIZE="1"), timeout=300)
+        subprocess.check_call([sys.executable, WORKER, out, *extra], env=dict(env, WORLD_SIZE="1"), timeout=300)
     else:
         subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-                               "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, out], env=env, timeout=600)
+                               "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, out, *extra], env=env, timeout=600)
     return [pickle.load(open(f"{out}.{r}", "rb")) for r in range(world)]
 
 
@@ -42,6 +42,20 @@ def test_sharded_rounds_equal_single_process(tmp_path):
     assert ranks[0]["calls"][1] >= 1 and ranks[1]["calls"][0] >= 1
 
 
+def test_packed_tensor_collectives_world_3(tmp_path):
+    """Shard.all_gather_rows with ragged per-rank row counts (rank 0 contributes none), the round-robin gather of
+    variable-size items and the broadcast, three gloo ranks: every rank ends with the same, correctly ordered tensors."""
+    ranks = _run(3, str(tmp_path / "c"), 29613, "collectives")
+    want_a = np.concatenate([np.arange(r * 12, dtype=np.float32).reshape(-1, 4) + 100 * r for r in range(3)])
+    want_b = np.concatenate([np.full((2 + r, 2, 3), float(r), np.float32) for r in range(3)])
+    sizes = [2, 1, 3, 2, 4]
+    for r in ranks:
+        assert np.array_equal(r["ga"], want_a) and np.array_equal(r["gb"], want_b)
+        assert [x.shape[0] for x in r["rr"]] == sizes and all((x == i).all() for i, x in enumerate(r["rr"]))
+        assert (r["bc"] == 7.0).all()
+        assert r["n_coll"] == 3 + 2 + 1          # counts + two tensors; counts + one tensor; broadcast
+
+
 def test_block_and_round_robin_partition():
     class S(Shard):
         def __init__(self, rank, world):
@@ -54,4 +68,6 @@ def test_block_and_round_robin_partition():
             rr = sorted(i for r in range(w) for i in S(r, w).round_robin(n))
             assert rr == list(range(n))
     s = S(0, 1)
-    assert gather_round_robin(s, 3, ["a", "b", "c"]) == ["a", "b", "c"]
+    rows = np.arange(12.0).reshape(6, 2)
+    got = gather_round_robin(s, [1, 3, 2], rows)              # variable-size items, one rank: identity split
+    assert [g.tolist() for g in got] == [rows[:1].tolist(), rows[1:4].tolist(), rows[4:].tolist()]

@@ -109,9 +109,14 @@ def test_bench_prints_one_contract_json_line():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "sim steps/s" and d["value"] > 83.0 and "workload" in d["config"]
+    assert "recorded scene demo_1" in d["config"]["workload"] and d["data"].startswith("recorded AV2 scene")     # BASELINE configs[1]
     r, c = d["roofline"], d["cpu_baseline"]
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] == "TFLOP/s"
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] in ("TFLOP/s", "GB/s")
+    assert 0 < r["frac"] <= 1.0 and 0 < r["mfma"]["frac"] <= 1.0 and 0 < r["hbm"]["frac"] <= 1.0 and r["traffic"] is None
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["value_1_thread"] > 0
+    # extras: the synthetic branching scene, the full cfg4 tree on this GPU, the other recorded scenes
+    assert d["synthetic_branching"]["expansions_per_plan"] >= 2 and d["tree"]["expansions_per_plan"] == 259
+    assert d["tree"]["k_pair"]["frac"] <= 1.0 and set(d["recorded_scenes"]) >= {"demo_2", "demo_3", "demo_4", "demo_1_whole_run"}
 
 
 @pytest.mark.parametrize("scene", ["demo_1", "demo_2", "demo_3", "demo_4"])

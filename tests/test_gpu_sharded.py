@@ -73,12 +73,55 @@ def _bench_ranks(world, extra, port):
 
 def test_bench_multi_rank_contract_weak_and_strong():
     """The launch contract of `bench.py --gpus N` with N = 2 ranks (gloo here, RCCL on a multi-GPU node): barrier +
-    max-over-ranks timing, whole-job value, one JSON line from rank 0.  Weak scaling: every rank plans its own scene;
+    max-over-ranks timing, whole-job value, one JSON line from rank 0.  Weak scaling: every rank runs its own closed loop;
     --shard: both ranks plan the same scene."""
-    d = _bench_ranks(2, [], 29541)
+    d = _bench_ranks(2, ["--workload", "demo1", "--no-extras"], 29541)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4 and "cpu_baseline" not in d
     assert d["config"]["sim_steps_timed"] == 20 and abs(d["value"] - 2 * 20 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
-    assert d["nodes_expanded_per_s"] > 0 and d["roofline"]["frac"] > 0
-    s = _bench_ranks(2, ["--shard"], 29542)
-    assert s["n_gpus"] == 2 and s["scaling"] == "strong"
+    assert d["nodes_expanded_per_s"] > 0 and 0 < d["roofline"]["frac"] <= 1
+    s = _bench_ranks(2, ["--workload", "demo1", "--shard"], 29542)
+    assert s["n_gpus"] == 2 and s["scaling"] == "strong" and s["collectives_per_plan"] >= 3
     assert abs(s["value"] - 20 / (s["ms_per_step"] * 4e-3)) < 1e-6 * s["value"]   # one scene: steps are not multiplied by N
+
+
+def test_bench_spawns_its_own_ranks_and_checks_the_world_size():
+    """`python bench.py --gpus 2` with no launcher in the environment starts the two ranks itself (torch.distributed.run on
+    127.0.0.1) and reports n_gpus = 2; the default multi-rank line carries the sharded cfg4-tree plan next to the replicas;
+    a launcher world that disagrees with --gpus is refused."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+                          "--tree-steps", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "recorded scene demo_1" in d["config"]["workload"]
+    t = d["tree_sharded"]
+    assert t["n_gpus"] == 2 and t["scaling"] == "strong" and t["expansions_per_plan"] == 259 and t["collectives_per_plan"] >= 9
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+
+
+def test_two_ranks_over_rccl_when_two_devices_are_visible(tmp_path):
+    """The same sharded plan over the nccl (= RCCL) backend, one rank per GPU: needs two devices, skipped on the one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL runs one rank per device)")
+    single = _run(1, tmp_path)[0]
+    procs, outs = [], []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29551",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", MIND_DIST_BACKEND="nccl")
+        out = os.path.join(tmp_path, f"nccl_r{r}.pkl")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, WORKER, out, "3"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        log, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, log.decode()[-2000:]
+    for o in outs:
+        b = pickle.load(open(o, "rb"))
+        for pa, pb in zip(single["res"], b["res"]):
+            assert pa["keys"] == pb["keys"] and pa["best"] == pb["best"]
+            assert np.array_equal(pa["pos0"], pb["pos0"]) and np.array_equal(pa["xs"], pb["xs"])
