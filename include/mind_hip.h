@@ -86,6 +86,20 @@ int mind_last_fusion_stats(mind_ctx *ctx, int *n_launches, float *total_ms, doub
 /* enable/disable event timing (off by default: events add a little latency) */
 int mind_set_profiling(mind_ctx *ctx, int enable);
 
+/* Arithmetic of the RelaFusionLayer pair contractions (planners/mind/networks/network.py:165-232; the reference runs them
+ * in torch fp32): MIND_PAIR_F32 = fp32 MFMA (v_mfma_f32_16x16x4_f32); MIND_PAIR_BF16X3 (default) = both operands split into
+ * bf16 hi + lo parts, hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fp32-class accuracy, ~5 x the
+ * fp32-MFMA rate); MIND_PAIR_BF16 = plain bf16 operands (BASELINE config 5's "bf16 MFMA attention": misses the 1e-3 m
+ * parity bar, never the default).  Also settable at context creation through the environment, MIND_PAIR_PREC=f32|bf16x3|bf16. */
+#define MIND_PAIR_F32 0
+#define MIND_PAIR_BF16X3 1
+#define MIND_PAIR_BF16 2
+int mind_set_pair_precision(mind_ctx *ctx, int mode);
+int mind_get_pair_precision(mind_ctx *ctx);   /* -> mode, or MIND_EINVAL */
+/* host-only helper (tests): the bf16 hi / lo MFMA fragment packing of one [128][row_stride] weight matrix,
+ * out[16384] dwords = [part 2][out block 8][k group 4][lane 64][4] (see pair_bf16_kernels.hip).  Needs no GPU. */
+int mind_debug_pack_bfrag(const float *w, int row_stride, uint32_t *out);
+
 /* Debug taps used by the parity tests only: run just the first n (0..6) fusion layers on the next
  * mind_predict_batch calls, and read internal device buffers ("x", "ST", "QK", "edge", "part",
  * "actor_feat", "tokpos") back to the host.  mind_debug_read returns the number of floats copied (or

@@ -80,7 +80,7 @@ class IlqrStats(C.Structure):
 EXPORTS = ["mind_ctx_create", "mind_ctx_destroy", "mind_last_error_string", "mind_ctx_synchronize",
            "mind_weights_load", "mind_predict_batch", "mind_last_fusion_stats", "mind_set_profiling",
            "mind_ilqr_solve_trees", "mind_ilqr_contingency", "mind_ilqr_solve_fields", "mind_cost_eval", "mind_lane_dist_field", "mind_aime_world", "mind_aime_rebase", "mind_debug_set_layers",
-           "mind_debug_read"]
+           "mind_debug_read", "mind_set_pair_precision", "mind_get_pair_precision", "mind_debug_pack_bfrag"]
 
 _lib = None
 
@@ -120,6 +120,9 @@ def load():
                                          C.c_double] + [C.POINTER(C.c_double)] * 4
     lib.mind_aime_world.argtypes = [C.c_void_p, C.POINTER(WorldIn), C.POINTER(WorldOut)]
     lib.mind_aime_rebase.argtypes = [C.c_void_p, C.POINTER(RebaseIn), C.POINTER(RebaseOut)]
+    lib.mind_set_pair_precision.argtypes = [C.c_void_p, C.c_int]
+    lib.mind_get_pair_precision.argtypes = [C.c_void_p]
+    lib.mind_debug_pack_bfrag.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_uint32)]
     lib.mind_debug_set_layers.argtypes = [C.c_void_p, C.c_int]
     lib.mind_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64]
     for n in EXPORTS:

@@ -15,17 +15,31 @@
 //  * K/V projections are folded algebraically: s = (W_k^T q).mem (+const), o = W_v (sum_i p mem) + b_v,
 //    so only two 128x128 GEMMs per pair remain (W_e, W_p) instead of five.
 //  * online softmax over i inside the wave; column partials (m, l, sum p*mem) go to k_token.
+//  * the edge tensor is stored [scene][j][i][128] (query column major): a column job streams contiguous memory.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef unsigned int u32;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32 pk_bf16(float a, float b) {   // {bf16(a) in bits 0..15, bf16(b) in bits 16..31}, RNE
+  f32x2_t v = {a, b};
+  return __builtin_bit_cast(u32, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float bf_lo_f32(u32 pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float bf_hi_f32(u32 pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+
 #define D_ 128
 #define PART_STRIDE 1040  // 8 (m) + 8 (l) + 8*128 (sum p*mem)
 
 struct PairJob {
-  long long edge_base;  // first pair index of the scene's edge tensor (pairs, not floats)
+  long long edge_base;  // first pair index of the scene's edge tensor (pairs, not floats); pair (i, j) lives at edge_base + j * N + i
   int N;                // tokens in scene (a + l + 1)
   int j;                // column (query token)
   int t0, t1;           // i-tile range [t0, t1), 32 rows each
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair(const PairJob *__restr
           for (int n = 0; n < 2; ++n) {
             int irow = i0 + 8 * n + (ll >> 3);
             irow = irow < N ? irow : N - 1;
-            raw[2 * qt + n] = *(const f32x4 *)(edge + (((size_t)J.edge_base + (size_t)irow * N + j) << 7) + qt * 32 + (ll & 7) * 4);
+            raw[2 * qt + n] = *(const f32x4 *)(edge + (((size_t)J.edge_base + (size_t)j * N + irow) << 7) + qt * 32 + (ll & 7) * 4);
           }
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair(const PairJob *__restr
             const int cp = ll & 7;
             const f32x4 v = *(const f32x4 *)(stage + sw_pos(r, cp));
             if (i0 + r < N)
-              *(f32x4 *)(edge + (((size_t)J.edge_base + (size_t)(i0 + r) * N + j) << 7) + qt * 32 + cp * 4) = v;
+              *(f32x4 *)(edge + (((size_t)J.edge_base + (size_t)j * N + (i0 + r)) << 7) + qt * 32 + cp * 4) = v;
           }
           LDS_FENCE();
         }
@@ -592,7 +606,8 @@ __device__ __forceinline__ void ln2tok(float &p0, float &p1, float g, float be, 
   p1 = d1 * (1.0f / sqrtf(s1 * (1.0f / 128.0f) + 1e-5f)) * g + be;
 }
 
-// mode bits: 1 = init (x0 from actor/lane features), 2 = has epilogue, 4 = has prologue, 8 = only flagged
+// mode bits: 1 = init (x0 from actor/lane features), 2 = has epilogue, 4 = has prologue, 8 = only flagged,
+// 16 = write the folded query as bf16 hi / lo A fragments (for k_pair_bf) instead of fp32
 __global__ __launch_bounds__(TT_THREADS) void k_token(const TokMeta *__restrict__ meta, int n_tok, int mode,
                                                       const float *__restrict__ actor_feat,
                                                       const float *__restrict__ lane_feat, float *__restrict__ x,
@@ -798,7 +813,22 @@ __global__ __launch_bounds__(TT_THREADS) void k_token(const TokMeta *__restrict_
           acc[t] = fmaf(w[d + 2], xv.z, acc[t]);
           acc[t] = fmaf(w[d + 3], xv.w, acc[t]);
         }
-      for (int t = 0; t < nt; ++t) QK[(size_t)(tok0 + t) * 1024 + hd * 128 + col] = acc[t] * 0.25f;
+      if (mode & 16) {
+        // bf16 hi / lo parts in the A-operand order of k_pair_bf (pair_bf16_kernels.hip): per token 2048 x u16 =
+        // [part 2][k-group 4][row 32 = head 8 x lane quarter 4][slot 8], feature 16 (2g + (i >> 2)) + 4q + (i & 3) <-> slot i
+        const int g = col >> 5, qq = (col >> 2) & 3, i = 4 * ((col >> 4) & 1) + (col & 3);
+        const int idx = ((g * 32) + hd * 4 + qq) * 8 + i;
+        for (int t = 0; t < nt; ++t) {
+          const float v = acc[t] * 0.25f;
+          const u32 h = pk_bf16(v, v) & 0xffffu;
+          const u32 l = pk_bf16(v - bf_lo_f32(h), 0.f) & 0xffffu;
+          unsigned short *qs = reinterpret_cast<unsigned short *>(QK + (size_t)(tok0 + t) * 1024);
+          qs[idx] = (unsigned short)h;
+          qs[1024 + idx] = (unsigned short)l;
+        }
+      } else {
+        for (int t = 0; t < nt; ++t) QK[(size_t)(tok0 + t) * 1024 + hd * 128 + col] = acc[t] * 0.25f;
+      }
     }
   }
   TT(7);

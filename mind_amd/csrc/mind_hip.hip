@@ -15,6 +15,7 @@
 #include "../../include/mind_hip.h"
 #include "encdec_kernels.hip"
 #include "fusion_kernels.hip"
+#include "pair_bf16_kernels.hip"
 #include "ilqr_kernels.hip"
 #include "aime_kernels.hip"
 
@@ -57,6 +58,8 @@ struct mind_ctx {
   DecW decW;
   TokWeights tokW[7];  // [L]: epilogue of layer L-1 (L>=1) + prologue of layer L (L<=5); [0] = init
   const float *WAe[6], *WAp[6], *vtab[6], *rtab = nullptr;
+  const u32 *WBe[6], *WBp[6];   // bf16 hi / lo fragments of the same matrices (pair_bf16_kernels.hip)
+  int pair_prec = 1;            // arithmetic of the pair kernel: 0 = fp32 MFMA, 1 = bf16x3 (split operands, default), 2 = bf16
   // workspaces (grow only)
   DevBuf edge, x, ST, QK, part, tokpos, meta, jobs, actor_feat, lane_feat, tgt_feat, cmode, tgt_emb,
       rows, rpe_ptrs;
@@ -127,6 +130,16 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   (void)hipFuncSetAttribute((const void *)k_pair<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_pair<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_pair_bf<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_pair_bf<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_pair_bf<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_pair_bf<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
+  if (const char *pe = getenv("MIND_PAIR_PREC")) {
+    const std::string v = pe;
+    if (v == "f32" || v == "0") c->pair_prec = 0;
+    else if (v == "bf16x3" || v == "1") c->pair_prec = 1;
+    else if (v == "bf16" || v == "2") c->pair_prec = 2;
+  }
   (void)hipFuncSetAttribute((const void *)k_actor_net, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_actor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
@@ -156,6 +169,24 @@ extern "C" const char *mind_last_error_string(mind_ctx *c) { return c ? c->err.c
 extern "C" int mind_ctx_synchronize(mind_ctx *c) {
   if (!c) return MIND_EINVAL;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MIND_OK;
+}
+
+extern "C" int mind_set_pair_precision(mind_ctx *c, int mode) {
+  if (!c || mode < 0 || mode > 2) return MIND_EINVAL;
+  c->pair_prec = mode;
+  return MIND_OK;
+}
+
+extern "C" int mind_get_pair_precision(mind_ctx *c) { return c ? c->pair_prec : MIND_EINVAL; }
+
+namespace { std::vector<float> pack_bfrag(const std::vector<float> &w, int row_stride); }
+extern "C" int mind_debug_pack_bfrag(const float *w, int row_stride, uint32_t *out) {
+  if (!w || !out || row_stride < 128) return MIND_EINVAL;
+  std::vector<float> v(w, w + (size_t)127 * row_stride + 128);
+  v.resize((size_t)128 * row_stride, 0.f);
+  const std::vector<float> t = pack_bfrag(v, row_stride);
+  memcpy(out, t.data(), 16384 * sizeof(uint32_t));
   return MIND_OK;
 }
 
@@ -214,6 +245,64 @@ std::vector<float> pack_afrag(const float *w, int row_stride) {
           t[((size_t)(ob * 8 + s4) * 64 + lane) * 4 + k] =
               w[(size_t)(16 * ob + (lane & 15)) * row_stride + 16 * s4 + 4 * (lane >> 4) + k];
   return t;
+}
+
+// round-to-nearest-even bf16 of a float (bits), and the split x = hi + lo
+inline uint16_t bf16_rne(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f32(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// bf16 MFMA 16x16x32 A-fragment order, hi and lo parts: [part 2][ob 8][g 4][lane 64][dword 4]; dword d of lane
+// (r = lane & 15, q = lane >> 4) packs k-slots 2d, 2d+1; k-slot (q, i) <-> input feature 16 (2g + (i >> 2)) + 4q + (i & 3)
+// (the chained B-operand order of pair_bf16_kernels.hip).  Returned as float bit patterns (16384 dwords).
+std::vector<float> pack_bfrag(const std::vector<float> &w, int row_stride) {
+  std::vector<uint32_t> t(16384, 0u);
+  for (int ob = 0; ob < 8; ++ob)
+    for (int g = 0; g < 4; ++g)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int d = 0; d < 4; ++d) {
+          uint32_t hi = 0, lo = 0;
+          for (int e = 0; e < 2; ++e) {
+            const int i = 2 * d + e, q = lane >> 4;
+            const int f = 16 * (2 * g + (i >> 2)) + 4 * q + (i & 3);
+            const float x = w[(size_t)(16 * ob + (lane & 15)) * row_stride + f];
+            const uint16_t h = bf16_rne(x);
+            const uint16_t l = bf16_rne(x - bf16_to_f32(h));
+            hi |= (uint32_t)h << (16 * e);
+            lo |= (uint32_t)l << (16 * e);
+          }
+          const size_t o = ((size_t)(ob * 4 + g) * 64 + lane) * 4 + d;
+          t[o] = hi;
+          t[8192 + o] = lo;
+        }
+  std::vector<float> out(16384);
+  memcpy(out.data(), t.data(), 16384 * sizeof(float));
+  return out;
+}
+
+// LayerNorm is invariant to a shift along the features: fold the mean subtraction of the LayerNorm that follows a Linear
+// into the Linear ((I - 11^T/n) W, (I - 11^T/n) b).  W is [n_out][n_in] row-major.
+void center_outputs(std::vector<float> &W, std::vector<float> &b, int n_out, int n_in) {
+  for (int k = 0; k < n_in; ++k) {
+    double m = 0;
+    for (int o = 0; o < n_out; ++o) m += W[(size_t)o * n_in + k];
+    m /= n_out;
+    for (int o = 0; o < n_out; ++o) W[(size_t)o * n_in + k] = (float)((double)W[(size_t)o * n_in + k] - m);
+  }
+  double mb = 0;
+  for (int o = 0; o < n_out; ++o) mb += b[o];
+  mb /= n_out;
+  for (int o = 0; o < n_out; ++o) b[o] = (float)((double)b[o] - mb);
 }
 
 // conv weight [co][ci][k] -> [ci][k][co]
@@ -310,11 +399,16 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
   }
   for (int L = 0; L < 6; ++L) {
     std::string p = "fusion_net.fuse_scene.fusion." + std::to_string(L), k = "fus.L" + std::to_string(L);
-    const float *Wm = sd.get(p + ".proj_memory.0.weight", 128 * 384);
+    // proj_memory / proj_edge are followed by a LayerNorm: its mean subtraction is folded into the weights (center_outputs)
+    std::vector<float> Wmc = vec(sd.get(p + ".proj_memory.0.weight", 128 * 384), 128 * 384);
+    std::vector<float> bmc = vec(sd.get(p + ".proj_memory.0.bias", 128), 128);
+    center_outputs(Wmc, bmc, 128, 384);
+    const float *Wm = Wmc.data();
     B.add(k + ".WAe", pack_afrag(Wm, 384));
+    B.add(k + ".WBe", pack_bfrag(Wmc, 384));
     B.add(k + ".WsT", transpose(Wm, 128, 128, 384, 128));
     B.add(k + ".WtT", transpose(Wm, 128, 128, 384, 256));
-    B.add(k + ".bm", vec(sd.get(p + ".proj_memory.0.bias", 128), 128));
+    B.add(k + ".bm", bmc);
     std::vector<float> vt(VT_SIZE, 0.f);
     auto put = [&](int off, const float *src) {
       if (src) memcpy(vt.data() + off, src, 128 * sizeof(float));
@@ -322,8 +416,12 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
     put(VT_GM, sd.get(p + ".proj_memory.1.weight", 128));
     put(VT_BM, sd.get(p + ".proj_memory.1.bias", 128));
     if (L != 5) {
-      B.add(k + ".WAp", pack_afrag(sd.get(p + ".proj_edge.0.weight", 128 * 128), 128));
-      put(VT_BP, sd.get(p + ".proj_edge.0.bias", 128));
+      std::vector<float> Wpc = vec(sd.get(p + ".proj_edge.0.weight", 128 * 128), 128 * 128);
+      std::vector<float> bpc = vec(sd.get(p + ".proj_edge.0.bias", 128), 128);
+      center_outputs(Wpc, bpc, 128, 128);
+      B.add(k + ".WAp", pack_afrag(Wpc.data(), 128));
+      B.add(k + ".WBp", pack_bfrag(Wpc, 128));
+      put(VT_BP, bpc.data());
       put(VT_GP, sd.get(p + ".proj_edge.1.weight", 128));
       put(VT_BEP, sd.get(p + ".proj_edge.1.bias", 128));
       put(VT_GE, sd.get(p + ".norm_edge.weight", 128));
@@ -430,6 +528,8 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
     std::string k = "fus.L" + std::to_string(L);
     c->WAe[L] = P(k + ".WAe");
     c->WAp[L] = P(k + ".WAp");
+    c->WBe[L] = (const u32 *)P(k + ".WBe");
+    c->WBp[L] = (const u32 *)P(k + ".WBp");
     c->vtab[L] = P(k + ".vtab");
   }
   for (int L = 0; L <= 6; ++L) {
@@ -622,7 +722,8 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
 
   // ---- fusion: init tokens + 6 x (pair kernel, token kernel)
   const int tok_blocks = (ntok + TPW - 1) / TPW;
-  hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok, 1 | 4, actor_feat, lane_feat, x, part, ST, QK,
+  const int qsplit = c->pair_prec != 0 ? 16 : 0;      // the bf16 pair kernels read the folded query as hi / lo fragments
+  hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok, 1 | 4 | qsplit, actor_feat, lane_feat, x, part, ST, QK,
                      c->tokW[0]);
   int grid = njobs < c->n_cu ? njobs : c->n_cu;      // jobs are dealt wave-major over the workgroups
   const size_t lds = mind_pair_lds_bytes();
@@ -639,16 +740,27 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   for (int L = 0; L < c->debug_layers; ++L) {
     const int um = L < 4 ? 0 : (L == 4 ? 1 : 2);
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2 * L], st));
-    if (L == 0)
-      hipLaunchKernelGGL(k_pair<0>, dim3(grid), dim3(PAIR_THREADS), lds, st, djobs, njobs, edge, ST, QK, part, c->WAe[L], c->WAp[L],
-                         c->vtab[L], c->rtab, tokpos, rpe_dev, um);
-    else
-      hipLaunchKernelGGL(k_pair<1>, dim3(grid), dim3(PAIR_THREADS), lds, st, djobs, njobs, edge, ST, QK, part, c->WAe[L],
-                         L == 5 ? c->WAe[L] : c->WAp[L], c->vtab[L], c->rtab, tokpos, rpe_dev, um);
+    if (c->pair_prec == 0) {
+      if (L == 0)
+        hipLaunchKernelGGL(k_pair<0>, dim3(grid), dim3(PAIR_THREADS), lds, st, djobs, njobs, edge, ST, QK, part, c->WAe[L], c->WAp[L],
+                           c->vtab[L], c->rtab, tokpos, rpe_dev, um);
+      else
+        hipLaunchKernelGGL(k_pair<1>, dim3(grid), dim3(PAIR_THREADS), lds, st, djobs, njobs, edge, ST, QK, part, c->WAe[L],
+                           L == 5 ? c->WAe[L] : c->WAp[L], c->vtab[L], c->rtab, tokpos, rpe_dev, um);
+    } else {
+      const size_t ldsb = mind_pair_bf_lds_bytes();
+      const u32 *we = c->WBe[L], *wp = L == 5 ? c->WBe[L] : c->WBp[L];
+#define LAUNCH_BF(M, NPV)                                                                                                       \
+  hipLaunchKernelGGL((k_pair_bf<M, NPV>), dim3(grid), dim3(PAIR_THREADS), ldsb, st, djobs, njobs, edge, ST, QK, part, we, wp, \
+                     c->vtab[L], c->rtab, tokpos, rpe_dev, um)
+      if (c->pair_prec == 1) { if (L == 0) LAUNCH_BF(0, 3); else LAUNCH_BF(1, 3); }
+      else { if (L == 0) LAUNCH_BF(0, 1); else LAUNCH_BF(1, 1); }
+#undef LAUNCH_BF
+    }
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2 * L + 1], st));
     c->n_pair_launch++;
     c->pairs_done += (L == 5) ? pairs_l5 : pairs_full;
-    const int mode = 2 | (L < 5 ? 4 : 8);
+    const int mode = 2 | (L < 5 ? 4 : 8) | qsplit;
     hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok, mode, actor_feat, lane_feat, x, part, ST, QK,
                        c->tokW[L + 1]);
   }

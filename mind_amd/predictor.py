@@ -108,6 +108,15 @@ class HipPredictor:
         rc = self.lib.mind_weights_load(self.ctx, descs, len(sd))
         _lib.check(self.lib, self.ctx, rc, "mind_weights_load")
 
+    PAIR_PREC = ("f32", "bf16x3", "bf16")
+
+    def pair_precision(self):
+        """arithmetic of the pair kernel: 'f32' | 'bf16x3' (default) | 'bf16' (include/mind_hip.h)"""
+        return self.PAIR_PREC[self.lib.mind_get_pair_precision(self.ctx)]
+
+    def set_pair_precision(self, name):
+        _lib.check(self.lib, self.ctx, self.lib.mind_set_pair_precision(self.ctx, self.PAIR_PREC.index(name)), "mind_set_pair_precision")
+
     def set_profiling(self, on):
         self.lib.mind_set_profiling(self.ctx, 1 if on else 0)
 

@@ -1,6 +1,7 @@
 """GPU parity: the HIP predictor (through the C-ABI) against the oracle and the golden vectors.
-Tolerance: fp32 forward, 2e-4 absolute on O(1..10 m) trajectory outputs (north_star asks 1e-3 m);
-observed ~4e-6."""
+Tolerance: 2e-4 absolute on O(1..10 m) trajectory outputs (north_star asks 1e-3 m), in the default arithmetic of the pair
+kernel (bf16x3: bf16 hi + lo split operands, fp32 accumulate) AND in its fp32-MFMA mode; observed ~4e-6 (f32), ~1e-5 (bf16x3).
+The plain-bf16 mode (BASELINE config 5) is measured and reported, against a bar it can meet."""
 import numpy as np
 import pytest
 import torch
@@ -113,3 +114,51 @@ def test_hip_matches_oracle_at_benchmark_sizes(a, l, seed, hip_predictor, formul
     assert np.abs(out["cls"].cpu().numpy()[0] - oc[0].numpy()[0]).max() < 1e-5
     assert np.abs(out["reg"].cpu().numpy() - orr[0].numpy()).max() < TOL
     assert np.abs(out["vel"].cpu().numpy() - ov[0].numpy()).max() < TOL
+
+
+@pytest.mark.parametrize("prec,bar", [("f32", 2e-4), ("bf16x3", 2e-4)])
+@pytest.mark.parametrize("a,l,B,seed", [(8, 20, 2, 1), (40, 55, 1, 1), (33, 64, 2, 6), (64, 256, 1, 21)])
+def test_pair_kernel_arithmetics_meet_the_parity_bar(prec, bar, a, l, B, seed, hip_predictor, formula_sd):
+    """Both fp32-class arithmetics of the pair kernel against the oracle at small, demo and cfg4 sizes (the default mode is
+    whatever MIND_PAIR_PREC / the library default says; this test pins each explicitly)."""
+    pb = predictor_batch(a, l, B, seed=seed)
+    oc, orr, ov = op.forward(formula_sd, to_t(pb))
+    before = hip_predictor.pair_precision()
+    try:
+        hip_predictor.set_pair_precision(prec)
+        assert hip_predictor.pair_precision() == prec
+        out = hip_predictor.predict_numpy_batch(pb)
+    finally:
+        hip_predictor.set_pair_precision(before)
+    cls, reg, vel = out["cls"].cpu().numpy(), out["reg"].cpu().numpy(), out["vel"].cpu().numpy()
+    for b in range(B):
+        assert np.abs(cls[b] - oc[b].numpy()[0]).max() < 1e-5
+        assert np.abs(reg[b * a:(b + 1) * a] - orr[b].numpy()).max() < bar
+        assert np.abs(vel[b * a:(b + 1) * a] - ov[b].numpy()).max() < bar
+
+
+def test_default_pair_arithmetic_is_bf16x3(hip_predictor):
+    import os
+    if "MIND_PAIR_PREC" not in os.environ:
+        assert hip_predictor.pair_precision() == "bf16x3"
+
+
+def test_plain_bf16_mode_error_is_reported(hip_predictor, formula_sd):
+    """BASELINE config 5's 'bf16 MFMA attention': plain bf16 operands in the pair contractions.  It cannot meet the 1e-3 m
+    bar (CPU emulation tests/diag/bf16_split_emulation.py: 2e-3 .. 4e-3 m); the test records what it does reach at the
+    demo and stress scene sizes and bounds it, so that a regression of the mode is still caught."""
+    worst = 0.0
+    for a, l, seed in ((40, 55, 1), (128, 256, 22)):
+        pb = predictor_batch(a, l, 1, seed=seed)
+        oc, orr, ov = op.forward(formula_sd, to_t(pb))
+        try:
+            hip_predictor.set_pair_precision("bf16")
+            out = hip_predictor.predict_numpy_batch(pb)
+        finally:
+            hip_predictor.set_pair_precision("bf16x3")
+        err = float(np.abs(out["reg"].cpu().numpy() - orr[0].numpy()).max())
+        print(f"plain bf16 pair kernel, a={a} l={l}: max |reg - oracle| = {err:.3e} m")
+        assert np.isfinite(err) and err < 5e-2
+        assert np.abs(out["cls"].cpu().numpy()[0] - oc[0].numpy()[0]).max() < 5e-3
+        worst = max(worst, err)
+    assert worst > 1e-5          # it really ran in reduced precision
