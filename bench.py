@@ -264,7 +264,7 @@ def cpu_model():
 
 def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees):
     """The oracle (CPU restatement, kind 'port') on this host: one predictor forward of the same scene size at
-    1 / 8 / 16 / 32 / all hardware threads (best kept, 1-thread figure quoted) + the contingency solves of this plan's
+    1 / 8 / 16 / 32 / 64 threads (best kept, 1-thread figure quoted) + the contingency solves of this plan's
     scenario trees (plain C, 1 thread), timed on a bounded sample."""
     from mind_amd.synth import predictor_batch
     from mind_amd.weights import formula_state_dict
@@ -277,7 +277,9 @@ def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees):
     ncpu = os.cpu_count() or 1
     n_before = torch.get_num_threads()
     per_threads = {}
-    for nt in sorted({1, 8, 16, 32, ncpu}):
+    # all hardware threads only on small hosts: torch-CPU on a tensor this size collapses under 128+ threads (measured on the
+    # 256-thread GPU box: 55 s per forward at 256 threads vs 36 ms at 16)
+    for nt in sorted({1, 8, 16, 32, 64, ncpu if ncpu <= 64 else 64}):
         if nt > ncpu:
             continue
         torch.set_num_threads(nt)
