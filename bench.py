@@ -104,8 +104,9 @@ def make_planner(wkw, scripted=True):
     return pl, lcl, w
 
 
-def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True):
-    """planner + closed-loop simulator advanced to the enable time (t = 4.0 s: 40 observation updates)."""
+def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True, ckpt=None):
+    """planner + closed-loop simulator advanced to the enable time (t = 4.0 s: 40 observation updates).
+    ckpt: override of the planner config's ckpt_path (e.g. "formula_branching:20240121", mind_amd/weights.py)."""
     from mind_amd.closed_loop import ClosedLoopSim
     from mind_amd.planners.mind.planner import MINDPlanner
     from mind_amd.synth import ScriptedBranching, ScriptedFullTree, SynthWorld
@@ -116,6 +117,8 @@ def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True):
         cfg = dict(json.load(open(cfg)), planning_config="planners.mind.configs.planning." + wkw["scene"])
     else:
         w = SynthWorld(**wkw)
+    if ckpt is not None:
+        cfg = dict(cfg if isinstance(cfg, dict) else json.load(open(cfg)), ckpt_path=ckpt)
     pl = MINDPlanner(cfg)
     # recorded scenes run the predictor's own modes, as the reference does with the same weights (its AIME tree then
     # collapses to a few nodes); the scripted modes are straight-line motions in the agent frame and would leave a

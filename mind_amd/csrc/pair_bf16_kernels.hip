@@ -28,6 +28,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// tuning switches (A/B-measured on the MI355X): where the next tile's edge rows and this tile's folded query
+// are requested
+#ifndef PBF_PREFETCH_TOP
+#define PBF_PREFETCH_TOP 1      // 1: next tile's edge rows requested right after this tile's rows left the load registers
+#endif
+#ifndef PBF_QK_EARLY
+#define PBF_QK_EARLY 1          // 1: folded-query fragments requested before the edge store's staging passes
+#endif
+
 #define LB_WE 0                                       // [part 2][ob 8][g 4][lane 64][4 dwords] = 16384 dwords (64 KB)
 #define LB_WP 16384
 #define LB_STAGE 32768                                // 8 waves x 512 dwords
@@ -163,6 +172,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
   const int cq_r = (0x1320 >> (4 * ((p >> 2) & 3))) & 3;
   const int tw_base = (4 * q) * 16 + (((p >> 2) ^ cq_w) * 4) + (p & 3);
   const int tr_base = p * 16 + ((q ^ cq_r) * 4);
+  PT_DECL
 
   for (int job = wave * gridDim.x + blockIdx.x; job < n_jobs; job += gridDim.x * PAIR_WAVES) {
     const PairJob J = jobs[job];
@@ -188,19 +198,15 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
       const f32x4 t = *(const f32x4 *)(tokpos + (size_t)(J.tok_base + j) * 4);
       pj[0] = t[0]; pj[1] = t[1]; pj[2] = t[2]; pj[3] = t[3];
     }
-    // first edge tile of the job (later ones are requested one tile ahead, after the previous tile's store)
+    // first edge tile of the job (later ones are requested one tile ahead)
     f32x4 raw[8];
-    if (MODE == 1) {
-      const int i0 = J.t0 * 16;
-#pragma unroll
-      for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          int irow = i0 + 8 * n + (lane >> 3);
-          irow = irow < N ? irow : N - 1;
-          raw[2 * qt + n] = *(const f32x4 *)(ecol + ((size_t)irow << 7) + qt * 32 + (lane & 7) * 4);
-        }
-    }
+#define PBF_LOAD_RAW(ROW0, LANEV)                                                                       \
+  _Pragma("unroll") for (int qt = 0; qt < 4; ++qt) _Pragma("unroll") for (int n = 0; n < 2; ++n) {     \
+    int irow = (ROW0) + 8 * n + ((LANEV) >> 3);                                                         \
+    irow = irow < N ? irow : N - 1;                                                                     \
+    raw[2 * qt + n] = *(const f32x4 *)(ecol + ((size_t)irow << 7) + qt * 32 + ((LANEV)&7) * 4);        \
+  }
+    if (MODE == 1) { PBF_LOAD_RAW(J.t0 * 16, lane) }
     LDS_FENCE();
 
     for (int tile = J.t0; tile < J.t1; ++tile) {
@@ -230,6 +236,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
           for (int b2 = 0; b2 < 2; ++b2) ef[2 * qt + b2] = *(const f32x4 *)(stage + sw_pos(lp, 4 * b2 + lq));
           LDS_FENCE();
         }
+        if (PBF_PREFETCH_TOP && tile + 1 < J.t1) { PBF_LOAD_RAW(i0 + 16, ll) }
       } else {
         // ---- layer 0: edge0 = ReLU(LN(W_r rpe + b_r)), zeros on the cls row / column (network.py:326-330)
         float r5[5];
@@ -297,6 +304,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
       }
 
       // ---- memory = ReLU(LN(W_e e + S[j] + T[i]))   (network.py:197-199, rank-decomposed, mean folded away)
+      PT(0);
       u32x4 mhi[4], mlo[4];
       {
         u32x4 ehi[4], elo[4];
@@ -307,20 +315,32 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
         SCHED_FENCE();
         gemm_bf<NP>(mem, wbe, ehi, elo, lane);
       }
+      PT(1);
       ln_nomean(mem, vtq, VT_GM, VT_BM);
       SCHED_FENCE();
       split_frag<NP>(mem, mhi, mlo);
+      PT(2);
 
+      u32x4 qhi[4], qlo[4];
+#define PBF_LOAD_QK()                                                                              \
+  _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                  \
+    qhi[g] = *(const u32x4 *)(qs + g * 128);                                                       \
+    if (NP == 3) qlo[g] = *(const u32x4 *)(qs + (4 + g) * 128);                                    \
+  }
       // ---- edge update e' = LN_e(e + ReLU(LN(W_p mem + b_p)))   (network.py:201-202)
       if (do_update) {
         frag8 up;
 #pragma unroll
         for (int b = 0; b < 8; ++b) up[b] = *(const f32x4 *)(vtq + VT_BP + 16 * b);
         gemm_bf<NP>(up, wbp, mhi, mlo, lane);
+        PT(3);
         ln_nomean(up, vtq, VT_GP, VT_BEP);
 #pragma unroll
         for (int b = 0; b < 8; ++b) up[b] += ef[b];
         ln_pairs(up, vtq, VT_GE, VT_BE, false);
+        SCHED_FENCE();
+        if (PBF_QK_EARLY) { PBF_LOAD_QK() }
+        SCHED_FENCE();
         // store through the staging buffer: full 128-byte row segments
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
@@ -338,27 +358,16 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
         }
       }
       SCHED_FENCE();
-      // ---- next tile's edge rows: in flight during the attention phase
-      if (MODE == 1 && tile + 1 < J.t1) {
-        const int n0 = i0 + 16;
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-          for (int n = 0; n < 2; ++n) {
-            int irow = n0 + 8 * n + (ll >> 3);
-            irow = irow < N ? irow : N - 1;
-            raw[2 * qt + n] = *(const f32x4 *)(ecol + ((size_t)irow << 7) + qt * 32 + (ll & 7) * 4);
-          }
-      }
+      PT(4);
+      // ---- next tile's edge rows (late variant): in flight during the attention phase only
+      if (MODE == 1 && !PBF_PREFETCH_TOP && tile + 1 < J.t1) { PBF_LOAD_RAW(i0 + 16, ll) }
       // ---- attention scores: S^T[head, pair] = QK_j[head, :] . mem^T[:, pair]; the memory tile is already the B operand
       f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, sb = sa, sc = sa;
       {
-        u32x4 qhi[4], qlo[4];
+        if (!(PBF_QK_EARLY && do_update)) { PBF_LOAD_QK() }
+        if (!qrow) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          qhi[g] = *(const u32x4 *)(qs + g * 128);
-          if (NP == 3) qlo[g] = *(const u32x4 *)(qs + (4 + g) * 128);
-          if (!qrow) { qhi[g] = (u32x4){0u, 0u, 0u, 0u}; qlo[g] = (u32x4){0u, 0u, 0u, 0u}; }
+          for (int g = 0; g < 4; ++g) { qhi[g] = (u32x4){0u, 0u, 0u, 0u}; qlo[g] = (u32x4){0u, 0u, 0u, 0u}; }
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
       }
       LDS_FENCE();
       // A operand: p[head = lane & 15][pairs 4q .. 4q+3], each duplicated over the (hi, lo) parts of the memory rows
+      PT(5);
       u32x4 pah, pal;
       {
         f32x4 pv = *(const f32x4 *)(ptab + (lp & 7) * 16 + 4 * lq);
@@ -439,6 +449,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
           mbar[2 * g + 1] = MFMA_BF(pal, f1, mbar[2 * g + 1]);
         }
       }
+      PT(6);
     }  // tiles
 
     // ---- column partial: m[8], l[8], mbar[8][128]
@@ -455,6 +466,11 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
         for (int r = 0; r < 4; ++r) po[16 + (4 * q + r) * 128 + 16 * b + p] = mbar[b][r];
     }
   }
+#ifdef MIND_PAIR_TRACE
+  if (blockIdx.x == 0 && tid == 0)
+    printf("[k_pair_bf<%d,%d> um=%d] cycles: load+stage %lld split+gemm1 %lld LN1+split %lld gemm2 %lld LN2/3+store %lld scores+softmax %lld sum_p_mem %lld\n",
+           MODE, NP, update_mode, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[5], pt_[6]);
+#endif
 }
 
 #define PAIR_BF_INST(M, NPV)                                                                                           \

@@ -68,9 +68,10 @@ class MINDPlanner:
         from .networks.network import ScenePredNet
         self.network = ScenePredNet(net_cfg, self.device)
         path = self.planner_cfg["ckpt_path"]
-        if str(path).startswith("formula:"):
+        if str(path).startswith("formula"):         # "formula:<seed>" or "formula_<variant>:<seed>" (mind_amd/weights.py)
             from ...weights import formula_state_dict
-            sd = formula_state_dict(int(path.split(":")[1]), as_torch=True)
+            head, seed = str(path).split(":")
+            sd = formula_state_dict(int(seed), as_torch=True, variant=head[len("formula_"):] or None if head != "formula" else None)
         else:
             sd = torch.load(path, map_location="cpu")["state_dict"]
         self.network.load_state_dict(sd)

@@ -129,11 +129,19 @@ def uniform_pm1(key: str, n: int, seed: int = 0) -> np.ndarray:
     return 2.0 * ((z >> np.uint64(11)).astype(np.float64) / float(1 << 53)) - 1.0
 
 
-def formula_state_dict(seed: int = 20240121, as_torch: bool = False):
+def formula_state_dict(seed: int = 20240121, as_torch: bool = False, variant: str = None):
     """Formula weights for every tensor of ``state_dict_spec()`` (fp32).
 
     1-D ``*.weight`` (all norm gains) <- 1 + 0.1u; every ``*bias`` <- 0.05u;
     matrices / conv kernels <- u * sqrt(3 / fan_in).
+
+    ``variant="branching"`` re-scales the decoder heads so that the AIME tree BRANCHES on the reference's recorded demo
+    scenes the way a trained checkpoint makes it branch (the plain formula weights predict six near-identical, static
+    modes that merge into one node): the Bezier xy control points get 6 x the hidden-state gain (modes separate by metres,
+    distinct topology signatures) on top of a 2 m/s forward motion, the sigma control points grow from 0.2 to 8 over the
+    horizon (the branch-time ratio test fires), the classification logits get 3 x the gain (a clear mode ranking).  With
+    it the reference itself expands 6 scenes in two AIME rounds per plan on demo_1 and keeps 3-5 modes per round on all
+    four scenes (tests/golden/gen_golden.py demo_branch).
     """
     sd = OrderedDict()
     for name, shape in state_dict_spec():
@@ -147,6 +155,19 @@ def formula_state_dict(seed: int = 20240121, as_torch: bool = False):
             fan_in = int(np.prod(shape[1:]))
             v = u * np.sqrt(3.0 / fan_in)
         sd[name] = v.astype(np.float32).reshape(shape)
+    if variant == "branching":
+        W = sd["pred_scene.reg.6.weight"].reshape(8, 5, D).copy()
+        b = sd["pred_scene.reg.6.bias"].reshape(8, 5).copy()
+        W[:, 0:2] *= np.float32(6.0)
+        for k in range(8):
+            b[k, 0] = 2.0 * 6.0 * k / 7.0
+            b[k, 2] = np.log(0.2) + (np.log(8.0) - np.log(0.2)) * k / 7.0
+            b[k, 3] = b[k, 2] + np.log(0.8)
+        sd["pred_scene.reg.6.weight"] = W.reshape(40, D).astype(np.float32)
+        sd["pred_scene.reg.6.bias"] = b.reshape(40).astype(np.float32)
+        sd["pred_scene.cls.6.weight"] = (sd["pred_scene.cls.6.weight"] * np.float32(3.0)).astype(np.float32)
+    elif variant is not None:
+        raise ValueError(f"unknown formula weight variant {variant!r}")
     if as_torch:
         import torch
         return OrderedDict((k, torch.from_numpy(v.copy())) for k, v in sd.items())

@@ -37,7 +37,8 @@ def main():
     for prec in precs:
         hp.set_pair_precision(prec)
         print(f"######## pair kernel arithmetic: {prec}")
-        ok = run_parity(hp, sd, prec) and ok
+        if "--timing-only" not in sys.argv:
+            ok = run_parity(hp, sd, prec) and ok
         run_timing(hp)
     print("DIAG_OK" if ok else "DIAG_FAIL")
 
@@ -121,7 +122,7 @@ def run_parity(hp, sd, prec):
 
 def run_timing(hp):
     hp.set_profiling(True)
-    for (a, l, B) in [(40, 55, 6), (64, 256, 4)] + ([(64, 256, 24)] if "--big" in sys.argv else []):
+    for (a, l, B) in [(40, 55, 1), (40, 55, 6), (64, 256, 4)] + ([(64, 256, 24)] if "--big" in sys.argv else []):
         pb = predictor_batch(a, l, B, seed=2)
         out = hp.predict_numpy_batch(pb)
         torch.cuda.synchronize()

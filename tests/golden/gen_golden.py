@@ -2,7 +2,7 @@
 
 The reference Python cannot travel to the GPU box; these small fixtures (inputs are formula
 generated, so only expected outputs are stored) can.  Re-run:  python tests/golden/gen_golden.py [section ...]
-Sections: predictor rpe potential ilqr aime plan scenes demo_plans demo_runs
+Sections: predictor rpe potential ilqr aime plan scenes demo_plans demo_branch demo_runs
 """
 import os
 import sys
@@ -289,7 +289,15 @@ def gen_scenes():
     np.savez_compressed(os.path.join(GOLD, "scene_io.npz"), **out)
 
 
-def gen_demo_plans(n_plans=4):
+def gen_demo_branch(n_plans=4):
+    """G11: the same as demo_plans with the BRANCHING formula weights (mind_amd.weights variant "branching"): the reference's
+    AIME tree then keeps several modes and runs two rounds per plan on every recorded scene (6 expansions on demo_1), so
+    the branch-selection parity of the four demo scenes is exercised on multi-node trees.  Also stores, per plan, every
+    node of the internal AIME tree (ids, END_T, flags) via the number of nodes, and every returned scenario tree."""
+    gen_demo_plans(n_plans, variant="branching", fname="demo_branch.npz")
+
+
+def gen_demo_plans(n_plans=4, variant=None, fname="demo_plans.npz"):
     """G9: the reference's OWN closed loop (Simulator.run_sim, headless) on its four recorded demo scenes up to the
     first `n_plans` planning cycles (t = 4.0 s, 4.1 s, ...), with the formula weights (the trained checkpoint is not in the
     reference tree): control, chosen scenario/trajectory trees and the ego state after each cycle."""
@@ -307,8 +315,20 @@ def gen_demo_plans(n_plans=4):
     Simulator = importlib.import_module("simulator").Simulator
     tmp = tempfile.mkdtemp()
     ck = os.path.join(tmp, "formula.tar")
-    torch.save({"state_dict": formula_state_dict(as_torch=True)}, ck)
+    torch.save({"state_dict": formula_state_dict(as_torch=True, variant=variant)}, ck)
     out = {}
+    # every plan's whole AIME tree (not only the best scenario tree the simulator keeps): recorded around branch_aime
+    stm = importlib.import_module("planners.mind.scenario_tree")
+    all_trees = []
+    if not hasattr(stm.ScenarioTreeGenerator, "_orig_branch_aime"):
+        stm.ScenarioTreeGenerator._orig_branch_aime = stm.ScenarioTreeGenerator.branch_aime
+    def branch_aime(self, lcl_smp, agent_obs):
+        trees = stm.ScenarioTreeGenerator._orig_branch_aime(self, lcl_smp, agent_obs)
+        all_trees.append(([list(t.nodes.keys()) for t in trees],
+                          sorted((k, int(n.data.data["END_T"]) if n.data.data is not None else -1, bool(n.data.end_flag))
+                                 for k, n in self.tree.nodes.items() if k != "root")))
+        return trees
+    stm.ScenarioTreeGenerator.branch_aime = branch_aime
     for name in DEMO_SCENES:
         cfg = json.load(open(os.path.join(rh.REF_ROOT, "configs", name + ".json")))
         pcfg = json.load(open(os.path.join(rh.REF_ROOT, cfg["cl_agents"][0]["planner_config"])))
@@ -319,13 +339,19 @@ def gen_demo_plans(n_plans=4):
         cfg.update(render=False, output_dir=tmp)
         cp = os.path.join(tmp, name + ".json")
         json.dump(cfg, open(cp, "w"))
+        del all_trees[:]
         sim = Simulator(cp)
         sim.init_sim()
         sim.sim_horizon = 201 + 5 * (n_plans - 1)
         sim.run_sim()
         ego = [a for a in sim.agents if a.id == "AV"][0]
         planned = [i for i, f in enumerate(sim.frames) if "scen_tree" in f]
-        assert len(planned) == n_plans, planned
+        assert len(planned) == n_plans == len(all_trees), planned
+        for pi, (tree_keys, nodes) in enumerate(all_trees):
+            out[f"{name}_p{pi}_all_tree_keys"] = np.array(["|".join(k) for k in tree_keys])
+            out[f"{name}_p{pi}_all_node_ids"] = np.array([n[0] for n in nodes])
+            out[f"{name}_p{pi}_all_node_end_t"] = np.array([n[1] for n in nodes])
+            out[f"{name}_p{pi}_all_node_end_flag"] = np.array([n[2] for n in nodes])
         out[name + "_plan_steps"] = np.array(planned)
         out[name + "_final_state"] = np.array(ego.state, np.float64)
         out[name + "_final_ctrl"] = np.array(ego.ctrl, np.float64)
@@ -346,7 +372,8 @@ def gen_demo_plans(n_plans=4):
             print(name, "plan", pi, "step", fi, "scen keys", keys, "traj nodes", len(tk), "agents",
                   st.nodes[keys[0]].data[1].shape[0])
         print(name, "final state", ego.state, "ctrl", ego.ctrl)
-    np.savez_compressed(os.path.join(GOLD, "demo_plans.npz"), **out)
+    stm.ScenarioTreeGenerator.branch_aime = stm.ScenarioTreeGenerator._orig_branch_aime
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
 
 
 def gen_demo_runs(n_plans=60):
@@ -418,7 +445,7 @@ def gen_demo_runs(n_plans=60):
     np.savez_compressed(os.path.join(GOLD, "demo_runs.npz"), **out)
 
 
-SECTIONS = {"demo_runs": gen_demo_runs, "demo_plans": gen_demo_plans, "scenes": gen_scenes, "predictor": gen_predictor, "ilqr": gen_ilqr, "potential": gen_potential, "aime": gen_aime, "plan": gen_plan}
+SECTIONS = {"demo_runs": gen_demo_runs, "demo_plans": gen_demo_plans, "demo_branch": gen_demo_branch, "scenes": gen_scenes, "predictor": gen_predictor, "ilqr": gen_ilqr, "potential": gen_potential, "aime": gen_aime, "plan": gen_plan}
 
 if __name__ == "__main__":
     torch.manual_seed(0)
