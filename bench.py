@@ -172,11 +172,11 @@ class Dist:
             self.d.destroy_process_group()
 
 
-def measure(dist, workload, steps, warmup, shard, replica=0):
+def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None):
     """K timed planning cycles of one closed loop (barrier + synchronize on both sides, max over ranks), with the pair
     kernel's launch durations taken from HIP events on the context stream inside the timed region."""
     wkw = scene_workload(workload, replica)
-    pl, sim, w = make_closed_loop(wkw, full_tree=workload in FULL_TREE)
+    pl, sim, w = make_closed_loop(wkw, full_tree=workload in FULL_TREE, ckpt=ckpt)
     sh = None
     if shard and dist.world > 1:
         sh = pl.enable_sharding()
@@ -356,10 +356,10 @@ def recorded_scenes(prec, plans=20, warmup=3):
 
 
 # ---- concurrent scenes on one GPU (BASELINE config 3) ---------------------------------------------------------------------
-def _proc_scene(i, workload, steps, warmup, ready, go, q, speculative):
+def _proc_scene(i, workload, steps, warmup, ready, go, q, speculative, ckpt=None):
     """One scene in its own process (own HIP context): signals ready, waits for the common start, reports back."""
     import torch as th
-    pl, sim, w = make_closed_loop(scene_workload(workload, i), full_tree=workload in FULL_TREE, speculative=speculative)
+    pl, sim, w = make_closed_loop(scene_workload(workload, i), full_tree=workload in FULL_TREE, speculative=speculative, ckpt=ckpt)
     sim.run_plans(max(warmup, 1))
     th.cuda.synchronize()
     ready.wait()
@@ -375,7 +375,7 @@ def run_concurrent_processes(args):
     ctx = mp.get_context("spawn")
     P = args.concurrent
     ready, go, q = ctx.Barrier(P + 1), ctx.Barrier(P + 1), ctx.Queue()
-    procs = [ctx.Process(target=_proc_scene, args=(i, args.workload, args.steps, args.warmup, ready, go, q, P <= 4)) for i in range(P)]
+    procs = [ctx.Process(target=_proc_scene, args=(i, args.workload, args.steps, args.warmup, ready, go, q, P <= 4, args.ckpt)) for i in range(P)]
     for p_ in procs:
         p_.start()
     ready.wait(timeout=600)
@@ -444,6 +444,34 @@ def run_concurrent(args):
         "ms_per_plan_aggregate": dt / (args.steps * P) * 1e3}))
 
 
+def run_fused(args):
+    """BASELINE config 3 as written: P closed loops in ONE process, the AIME rounds of all scenes merged into one predictor
+    batch per round (mind_amd.fused); to be compared with --concurrent P --processes (one process per scene)."""
+    from mind_amd.fused import FusedClosedLoops
+    P = args.concurrent
+    loops = [make_closed_loop(scene_workload(args.workload, i), scripted=False, speculative=False, ckpt=args.ckpt) for i in range(P)]
+    fl = FusedClosedLoops([l[1] for l in loops])
+    fl.run_plans(max(args.warmup, 1))
+    torch.cuda.synchronize()
+    n0 = sum(l[0].scen_tree_gen.n_expanded for l in loops)
+    c0, sc0 = fl.fused.n_calls, fl.fused.n_scenes
+    t0 = time.perf_counter()
+    steps = fl.run_plans(args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    plans = sum(l[1].n_plans for l in loops)
+    print(json.dumps({
+        "metric": METRIC, "value": steps / dt, "unit": "sim steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16x3 pair kernel / f32 predictor / f64 iLQR", "data": _concurrent_label(args.workload, P)[1],
+        "nodes_expanded_per_s": (sum(l[0].scen_tree_gen.n_expanded for l in loops) - n0) / dt,
+        "config": {"workload": f"{_concurrent_label(args.workload, P)[0]} planned by ONE process, the AIME rounds of all scenes fused into one "
+                               f"predictor batch per round, {args.steps} planning cycles each", "concurrent_scenes": P, "sim_steps_timed": steps,
+                   "weights": args.ckpt or "formula:20240121"},
+        "predictor_calls": fl.fused.n_calls - c0, "scenes_per_predictor_call": (fl.fused.n_scenes - sc0) / max(fl.fused.n_calls - c0, 1),
+        "ms_per_plan_aggregate": dt / (args.steps * P) * 1e3}))
+
+
 # ---- launch ---------------------------------------------------------------------------------------------------------------
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run (one process per
@@ -478,6 +506,9 @@ def main():
                          "HIP context and stream per scene); prints the aggregate rate")
     ap.add_argument("--processes", action="store_true",
                     help="with --concurrent: one host PROCESS per scene instead of one thread (host bookkeeping in parallel too)")
+    ap.add_argument("--fused", action="store_true",
+                    help="with --concurrent: ONE process, the scenes' AIME rounds fused into one predictor batch (BASELINE config 3 as written)")
+    ap.add_argument("--ckpt", default=None, help='planner ckpt_path override, e.g. "formula_branching:20240121" (mind_amd/weights.py) or a .tar')
     ap.add_argument("--shard", action="store_true",
                     help="strong scaling: all ranks plan the SAME scene, AIME rounds and contingency solves sharded over ranks "
                          "(the default for the full-tree workloads)")
@@ -497,9 +528,11 @@ def main():
     dist = Dist(args.backend, local)
     rank, world = dist.rank, dist.world
     if args.concurrent > 1:
+        if args.fused:
+            return run_fused(args)
         return run_concurrent_processes(args) if args.processes else run_concurrent(args)
     shard = world > 1 and not args.replicas and (args.shard or args.workload in FULL_TREE)
-    m = measure(dist, args.workload, args.steps, args.warmup, shard, replica=0 if shard else rank)
+    m = measure(dist, args.workload, args.steps, args.warmup, shard, replica=0 if shard else rank, ckpt=args.ckpt)
     pl, sim = m["pl"], m["sim"]
     prec = pl.network.rt.pair_precision()
     value = m["sim_steps"] * (1 if shard else world) / m["dt"]

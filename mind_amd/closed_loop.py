@@ -79,9 +79,9 @@ class ClosedLoopSim:
         return SimpleNamespace(ego_agent=ego, exo_agents=exo, map_data=w, target_lane=w.target_lane,
                                target_lane_info=w.target_lane_info, target_velocity=w.target_velocity)
 
-    def step(self):
-        """One simulator step (0.02 s).  Returns True if a plan was computed in this step."""
-        planned = False
+    def step_begin(self):
+        """First half of a simulator step: take-over check, observation fan-out, planner trigger.  Returns the local
+        semantic map if a plan is due in this step (the caller plans and passes the result to step_end), else None."""
         if self.sim_time >= self.enable_time and not self.enabled:
             self.enabled = True                                  # check_enable: take over from the recording
             self.state = self.world.agent_state(0, self.sim_time)
@@ -92,20 +92,38 @@ class ClosedLoopSim:
             self.planner.update_observation(lcl)
             if self.enabled:
                 self.planner.update_state_ctrl(lcl.ego_agent.state, self.ctrl)
-                ok, self.ctrl, self.last_result = self.planner.plan(lcl)
-                if not ok:
-                    raise RuntimeError("plan failed")
-                self.n_plans += 1
-                planned = True
+                return lcl
+        return None
+
+    def step_end(self, plan_result=None):
+        """Second half: apply the plan computed for this step (if one was due), propagate the ego plant, advance time."""
+        planned = plan_result is not None
+        if planned:
+            ok, self.ctrl, self.last_result = plan_result
+            if not ok:
+                raise RuntimeError("plan failed")
+            self.n_plans += 1
         if self.enabled:
             self.state = kine_propagate(self.state, self.ctrl, self.SIM_STEP, self.WB, self.MAX_SPD, self.MAX_STR)
         self.sim_time += self.SIM_STEP
         self.n_steps += 1
         return planned
 
+    def step(self):
+        """One simulator step (0.02 s).  Returns True if a plan was computed in this step."""
+        lcl = self.step_begin()
+        return self.step_end(self.planner.plan(lcl) if lcl is not None else None)
+
     def run_until(self, t_end):
         while self.sim_time < t_end - 1e-9:
             self.step()
+
+    def maybe_restart_episode(self):
+        """start the next episode if this one is over (used by run_plans and by lock-step multi-scene drivers)"""
+        if self.episode_plans is not None and self.n_plans - self._episode_plan0 >= self.episode_plans:
+            self.reset()
+            return True
+        return False
 
     def run_plans(self, n):
         """advance until n more plans were computed; returns the number of simulator steps taken."""

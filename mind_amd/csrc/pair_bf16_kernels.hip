@@ -31,10 +31,22 @@
 // tuning switches (A/B-measured on the MI355X): where the next tile's edge rows and this tile's folded query
 // are requested
 #ifndef PBF_PREFETCH_TOP
-#define PBF_PREFETCH_TOP 1      // 1: next tile's edge rows requested right after this tile's rows left the load registers
+#define PBF_PREFETCH_TOP 0      // 1: next tile's edge rows requested right after this tile's rows left the load registers
 #endif
 #ifndef PBF_QK_EARLY
-#define PBF_QK_EARLY 1          // 1: folded-query fragments requested before the edge store's staging passes
+#define PBF_QK_EARLY 0          // 1: folded-query fragments requested before the edge store's staging passes (spills: slower)
+#endif
+#ifndef PBF_LDS_WAIT
+#define PBF_LDS_WAIT 0          // 1: drain the LDS queue (s_waitcnt lgkmcnt(0)) between the passes over a wave-private staging buffer;
+#endif                          // 0: rely on the in-order execution of one wave's DS instructions (compiler barrier only)
+#ifndef PBF_DIRECT_EDGE
+#define PBF_DIRECT_EDGE 0       // 1: edge tiles move between HBM and the C/D register layout directly (64-byte row segments per
+#endif                          // instruction) instead of full 128-byte lines staged through LDS
+
+#if PBF_LDS_WAIT
+#define PBF_FENCE() LDS_FENCE()
+#else
+#define PBF_FENCE() asm volatile("" ::: "memory")
 #endif
 
 #define LB_WE 0                                       // [part 2][ob 8][g 4][lane 64][4 dwords] = 16384 dwords (64 KB)
@@ -181,7 +193,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
     const int N = J.N;
     const int j = J.j;
     float *ecol = edge + (((size_t)J.edge_base + (size_t)j * N) << 7);      // this column's pairs are contiguous: [i][128]
-    LDS_FENCE();
+    PBF_FENCE();
     if (lane < 32) *(f32x4 *)(svec + lane * 4) = *(const f32x4 *)(ST + (size_t)(J.tok_base + j) * 256 + lane * 4);
     float m_run[4], l_part[4];
 #pragma unroll
@@ -200,14 +212,24 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
     }
     // first edge tile of the job (later ones are requested one tile ahead)
     f32x4 raw[8];
+#if PBF_DIRECT_EDGE
+#define PBF_LOAD_RAW(ROW0, LANEV)                                                                       \
+  {                                                                                                     \
+    int irow = (ROW0) + ((LANEV)&15);                                                                   \
+    irow = irow < N ? irow : N - 1;                                                                     \
+    const float *rp_ = ecol + ((size_t)irow << 7) + ((LANEV) >> 4) * 4;                                 \
+    _Pragma("unroll") for (int b = 0; b < 8; ++b) raw[b] = *(const f32x4 *)(rp_ + 16 * b);             \
+  }
+#else
 #define PBF_LOAD_RAW(ROW0, LANEV)                                                                       \
   _Pragma("unroll") for (int qt = 0; qt < 4; ++qt) _Pragma("unroll") for (int n = 0; n < 2; ++n) {     \
     int irow = (ROW0) + 8 * n + ((LANEV) >> 3);                                                         \
     irow = irow < N ? irow : N - 1;                                                                     \
     raw[2 * qt + n] = *(const f32x4 *)(ecol + ((size_t)irow << 7) + qt * 32 + ((LANEV)&7) * 4);        \
   }
+#endif
     if (MODE == 1) { PBF_LOAD_RAW(J.t0 * 16, lane) }
-    LDS_FENCE();
+    PBF_FENCE();
 
     for (int tile = J.t0; tile < J.t1; ++tile) {
       const int i0 = tile * 16;
@@ -225,16 +247,20 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
         for (int b = 0; b < 8; ++b) mem[b] = *(const f32x4 *)(Ti + 16 * b);
       }
       frag8 ef;
-      if (MODE == 1) {
+      if (MODE == 1 && PBF_DIRECT_EDGE) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) ef[b] = raw[b];
+        if (PBF_PREFETCH_TOP && tile + 1 < J.t1) { PBF_LOAD_RAW(i0 + 16, ll) }
+      } else if (MODE == 1) {
         // ---- edge tile -> registers through the swizzled staging buffer (full 128-byte row segments)
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
 #pragma unroll
           for (int n = 0; n < 2; ++n) *(f32x4 *)(stage + sw_pos(8 * n + (ll >> 3), ll & 7)) = raw[2 * qt + n];
-          LDS_FENCE();
+          PBF_FENCE();
 #pragma unroll
           for (int b2 = 0; b2 < 2; ++b2) ef[2 * qt + b2] = *(const f32x4 *)(stage + sw_pos(lp, 4 * b2 + lq));
-          LDS_FENCE();
+          PBF_FENCE();
         }
         if (PBF_PREFETCH_TOP && tile + 1 < J.t1) { PBF_LOAD_RAW(i0 + 16, ll) }
       } else {
@@ -341,12 +367,19 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
         SCHED_FENCE();
         if (PBF_QK_EARLY) { PBF_LOAD_QK() }
         SCHED_FENCE();
+        if (PBF_DIRECT_EDGE) {
+          if (valid) {
+            float *wp_ = ecol + ((size_t)i << 7) + lq * 4;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) *(f32x4 *)(wp_ + 16 * b) = up[b];
+          }
+        } else {
         // store through the staging buffer: full 128-byte row segments
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
 #pragma unroll
           for (int b2 = 0; b2 < 2; ++b2) *(f32x4 *)(stage + sw_pos(lp, 4 * b2 + lq)) = up[2 * qt + b2];
-          LDS_FENCE();
+          PBF_FENCE();
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
             const int r = 8 * n + (ll >> 3);
@@ -354,7 +387,8 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
             const f32x4 v = *(const f32x4 *)(stage + sw_pos(r, cp));
             if (i0 + r < N) *(f32x4 *)(ecol + ((size_t)(i0 + r) << 7) + qt * 32 + cp * 4) = v;
           }
-          LDS_FENCE();
+          PBF_FENCE();
+        }
         }
       }
       SCHED_FENCE();
@@ -393,7 +427,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
         l_part[r] = l_part[r] * scl[r] + pr[r];
         m_run[r] = m_new;
       }
-      LDS_FENCE();
+      PBF_FENCE();
       if (lq < 2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) ptab[(4 * lq + r) * 16 + lp] = pr[r];
@@ -406,7 +440,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
 #pragma unroll
           for (int r = 0; r < 4; ++r) mbar[b][r] *= scl[r];
       }
-      LDS_FENCE();
+      PBF_FENCE();
       // A operand: p[head = lane & 15][pairs 4q .. 4q+3], each duplicated over the (hi, lo) parts of the memory rows
       PT(5);
       u32x4 pah, pal;
@@ -438,10 +472,10 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
             stw[tw_base + (16 * b2 + 2 * rr) * 16] = (X & 0xffffu) | (Y << 16);
             stw[tw_base + (16 * b2 + 2 * rr + 1) * 16] = (X >> 16) | (Y & 0xffff0000u);
           }
-        LDS_FENCE();
+        PBF_FENCE();
         const u32x4 f0 = *(const u32x4 *)(stu + tr_base);
         const u32x4 f1 = *(const u32x4 *)(stu + tr_base + 256);
-        LDS_FENCE();
+        PBF_FENCE();
         mbar[2 * g] = MFMA_BF(pah, f0, mbar[2 * g]);
         mbar[2 * g + 1] = MFMA_BF(pah, f1, mbar[2 * g + 1]);
         if (NP == 3) {

@@ -153,7 +153,8 @@ class MINDPlanner:
                                                     lcl_smp.target_velocity)
         t2 = time.perf_counter()
         best, min_cost = None, np.inf
-        for i, cost in enumerate(self.evaluate_traj_trees(lcl_smp, traj_trees)):
+        costs = self.evaluate_traj_trees(lcl_smp, traj_trees)
+        for i, cost in enumerate(costs):
             if cost < min_cost:
                 min_cost, best = cost, i
         opt = traj_trees[best]
@@ -161,8 +162,31 @@ class MINDPlanner:
         ret_ctrl = nxt.data[0][-2:]          # (a, delta) of the first rolled-out state (Q15)
         self.timing = {"aime_s": t1 - t0, "ilqr_s": t2 - t1, "total_s": time.perf_counter() - t0,
                        "nodes_expanded": self.scen_tree_gen.n_expanded - n0, "n_scen_trees": len(scen_trees),
-                       "best_traj_idx": best}
+                       "best_traj_idx": best, "tree_costs": [float(c) for c in costs]}
         return True, ret_ctrl, [[scen_trees[best]], [traj_trees[best]]]
+
+    def plan_rounds(self, lcl_smp):
+        """plan() as a generator over the AIME rounds (ScenarioTreeGenerator.branch_aime_rounds): yields each round's
+        (scenes, predictor inputs), is sent the predictor outputs, returns plan()'s result.  mind_amd.fused drives several
+        planners' generators in lock-step and answers all their rounds with ONE predictor batch (BASELINE config 3)."""
+        import time
+        t0 = time.perf_counter()
+        self.scen_tree_gen.reset()
+        lane, info = self.resample_target_lane(lcl_smp)
+        self.scen_tree_gen.set_target_lane(lane, info)
+        n0 = self.scen_tree_gen.n_expanded
+        scen_trees = yield from self.scen_tree_gen.branch_aime_rounds(lcl_smp, self.agent_obs)
+        t1 = time.perf_counter()
+        traj_trees = self.traj_tree_opt.solve_batch(scen_trees, self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)
+        t2 = time.perf_counter()
+        costs = self.evaluate_traj_trees(lcl_smp, traj_trees)
+        best = int(np.argmin(costs))            # first minimum, as the reference's strict `<` scan keeps it
+        opt = traj_trees[best]
+        nxt = opt.get_node(opt.get_root().children_keys[0])
+        self.timing = {"aime_s": t1 - t0, "ilqr_s": t2 - t1, "total_s": time.perf_counter() - t0,
+                       "nodes_expanded": self.scen_tree_gen.n_expanded - n0, "n_scen_trees": len(scen_trees),
+                       "best_traj_idx": best, "tree_costs": [float(c) for c in costs]}
+        return True, nxt.data[0][-2:], [[scen_trees[best]], [traj_trees[best]]]
 
     def resample_target_lane(self, lcl_smp):
         """1 m resampling of the target lane and its per-point info (planner.py:147-171)."""

@@ -207,18 +207,46 @@ class ScenarioTreeGenerator:
                 "actor_ctrs": dev["actor_ctrs"][g0 * a:(g0 + B) * a], "actor_vecs": dev["actor_vecs"][g0 * a:(g0 + B) * a],
                 "lane_ctrs": dev["lane_ctrs"][g0 * l:(g0 + B) * l], "lane_vecs": dev["lane_vecs"][g0 * l:(g0 + B) * l]}
 
-    def predict_scenes(self, scenes):
+    def predict_inputs(self, scenes):
+        """The predictor input dict of a round's scenes (device tensors + offsets, what ScenePredNet.__call__ takes) and
+        the collated host batch it came from (None when the inputs were built on the device by mind_aime_rebase)."""
         d = self._device_batch(scenes) if self.device_glue else None
         if d is not None:          # inputs already on the device: no collate, no host->device copies
-            self.n_expanded += len(scenes)
-            return self.network(d)
+            return d, None
         data = self.collate(scenes)
+        return self.network.pre_process(data), data
+
+    def predict_done(self, scenes, data, lane_feat):
+        """bookkeeping after a predictor call: expansion count, LaneNet output of a first round kept for the plan"""
         self.n_expanded += len(scenes)
-        out = self.network(self.network.pre_process(data))
-        cache = getattr(self.network, "last_lane_feat", None)
-        if cache is not None and data["LANE_SHARED"]:
-            self.lane_feat_cache = cache
+        if data is not None and lane_feat is not None and data["LANE_SHARED"]:
+            self.lane_feat_cache = lane_feat
+
+    def predict_scenes(self, scenes):
+        d, data = self.predict_inputs(scenes)
+        out = self.network(d)
+        self.predict_done(scenes, data, getattr(self.network, "last_lane_feat", None) if data is not None else None)
         return out
+
+    def branch_aime_rounds(self, lcl_smp, agent_obs):
+        """branch_aime as a generator over its rounds: yields (scenes, d) -- the branch set and its predictor inputs -- and
+        is sent (out, packed, lane_feat) = the network outputs for exactly these scenes; returns the scenario trees.  Lets a
+        caller merge the rounds of SEVERAL scenes' trees into one predictor batch (mind_amd.fused, BASELINE config 3);
+        driven alone it computes what branch_aime computes."""
+        root = self.process_data(lcl_smp, agent_obs)
+        self.prepare_root_data(root)
+        self.tree.add_node(Node("root", None, ScenarioData(None, root, branch_flag=True)))
+        batch = [root]
+        while batch:
+            d, data = self.predict_inputs(batch)
+            out, packed, lane_feat = yield batch, d
+            self.predict_done(batch, data, lane_feat)
+            hdr, rows = self.prune_select(batch, out, 0, packed=packed)
+            self.create_nodes(self.assemble_children(batch, hdr, _np(rows)))
+            self.decide_branch()
+            batch = [n.data.obs_data for n in self.get_branch_set()]
+        assert len(self.get_end_set()) > 0, "No end node found in the scenario tree."
+        return self.get_scenario_tree()
 
     def create_nodes(self, pred_bar):
         for pred in pred_bar:
@@ -423,7 +451,7 @@ class ScenarioTreeGenerator:
         rows = w["world"].view(A * 6, 60, 6).index_select(0, torch.from_numpy(flat).to(dev))           # [R,60,6] (x,y,vx,vy,heading,max-sigma)
         return self._hdr(picks, scenes, idx_offset), rows
 
-    def prune_select(self, scenes, out, idx_offset=0):
+    def prune_select(self, scenes, out, idx_offset=0, packed=None):
         """prune_merge, first half (scenario_tree.py:281-395): world-frame modes, probability / target-lane pruning, greedy
         topology merge.  -> (hdr [P,25] float32: scene index in the round's full batch, mode, path probability, the
         scene's target window; rows [sum a,60,6]: (x, y, vx, vy, heading, max-sigma) of every agent of every kept mode,
@@ -431,7 +459,8 @@ class ScenarioTreeGenerator:
         if not scenes:
             return np.zeros((0, self.HDR), F32), torch.zeros(0, 60, 6)
         res_cls_b, res_reg_b, res_aux_b = out
-        packed = getattr(self.network, "last_packed", None)
+        if packed is None:
+            packed = getattr(self.network, "last_packed", None)
         if (self.device_glue and packed is not None and packed["n"] == len(scenes) and packed.get("rt") is not None
                 and packed.get("actor_ctrs") is not None and self.ego_idx == 0):
             return self._prune_select_device(scenes, packed, idx_offset)

@@ -329,6 +329,24 @@ def gen_demo_plans(n_plans=4, variant=None, fname="demo_plans.npz"):
                                  for k, n in self.tree.nodes.items() if k != "root")))
         return trees
     stm.ScenarioTreeGenerator.branch_aime = branch_aime
+    # per plan: the ego state / control the reference planned from (for teacher forcing) and the cost of EVERY candidate
+    # trajectory tree (planner.py:131-137), so that a near-tie between two candidates can be told from a real disagreement
+    agent_mod = importlib.import_module("agent")
+    plm = importlib.import_module("planners.mind.planner")
+    plan_in, plan_costs = [], []
+    if not hasattr(agent_mod.MINDAgent, "_orig_plan"):
+        agent_mod.MINDAgent._orig_plan = agent_mod.MINDAgent.plan
+        plm.MINDPlanner._orig_eval = plm.MINDPlanner.evaluate_traj_tree
+    def rec_plan(self):
+        plan_in.append((np.array(self.lcl_smp.ego_agent.state, np.float64), np.array(self.ctrl, np.float64)))
+        plan_costs.append([])
+        return agent_mod.MINDAgent._orig_plan(self)
+    def rec_eval(self, lcl_smp, traj_tree):
+        c = plm.MINDPlanner._orig_eval(self, lcl_smp, traj_tree)
+        plan_costs[-1].append(float(c))
+        return c
+    agent_mod.MINDAgent.plan = rec_plan
+    plm.MINDPlanner.evaluate_traj_tree = rec_eval
     for name in DEMO_SCENES:
         cfg = json.load(open(os.path.join(rh.REF_ROOT, "configs", name + ".json")))
         pcfg = json.load(open(os.path.join(rh.REF_ROOT, cfg["cl_agents"][0]["planner_config"])))
@@ -340,6 +358,8 @@ def gen_demo_plans(n_plans=4, variant=None, fname="demo_plans.npz"):
         cp = os.path.join(tmp, name + ".json")
         json.dump(cfg, open(cp, "w"))
         del all_trees[:]
+        del plan_in[:]
+        del plan_costs[:]
         sim = Simulator(cp)
         sim.init_sim()
         sim.sim_horizon = 201 + 5 * (n_plans - 1)
@@ -347,7 +367,11 @@ def gen_demo_plans(n_plans=4, variant=None, fname="demo_plans.npz"):
         ego = [a for a in sim.agents if a.id == "AV"][0]
         planned = [i for i, f in enumerate(sim.frames) if "scen_tree" in f]
         assert len(planned) == n_plans == len(all_trees), planned
+        assert len(plan_in) == n_plans == len(plan_costs)
+        out[name + "_state_in"] = np.array([p[0] for p in plan_in])
+        out[name + "_ctrl_in"] = np.array([p[1] for p in plan_in])
         for pi, (tree_keys, nodes) in enumerate(all_trees):
+            out[f"{name}_p{pi}_tree_costs"] = np.array(plan_costs[pi])
             out[f"{name}_p{pi}_all_tree_keys"] = np.array(["|".join(k) for k in tree_keys])
             out[f"{name}_p{pi}_all_node_ids"] = np.array([n[0] for n in nodes])
             out[f"{name}_p{pi}_all_node_end_t"] = np.array([n[1] for n in nodes])
@@ -373,6 +397,8 @@ def gen_demo_plans(n_plans=4, variant=None, fname="demo_plans.npz"):
                   st.nodes[keys[0]].data[1].shape[0])
         print(name, "final state", ego.state, "ctrl", ego.ctrl)
     stm.ScenarioTreeGenerator.branch_aime = stm.ScenarioTreeGenerator._orig_branch_aime
+    agent_mod.MINDAgent.plan = agent_mod.MINDAgent._orig_plan
+    plm.MINDPlanner.evaluate_traj_tree = plm.MINDPlanner._orig_eval
     np.savez_compressed(os.path.join(GOLD, fname), **out)
 
 

@@ -19,11 +19,12 @@ def wrap(obj, name, label=None, sync=False):
     setattr(obj, name, g)
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "demo1"
-pl, sim, w = make_closed_loop(dict(WORKLOADS[wl]), full_tree=wl in FULL_TREE)
+ckpt = sys.argv[3] if len(sys.argv) > 3 else None
+pl, sim, w = make_closed_loop(dict(WORKLOADS[wl]), full_tree=wl in FULL_TREE, ckpt=ckpt)
 gen, net, rt, opt = pl.scen_tree_gen, pl.scen_tree_gen.network, pl.network.rt, pl.traj_tree_opt
 sim.run_plans(3)
 wrap(pl, "plan"); wrap(gen, "branch_aime"); wrap(gen, "process_data"); wrap(gen, "collate"); wrap(net, "pre_process")
-wrap(rt, "predict", "rt.predict(launch)"); wrap(rt, "aime_world", "rt.aime_world(sync+launch)"); wrap(gen, "_prune_merge_device")
+wrap(rt, "predict", "rt.predict(launch)"); wrap(rt, "aime_world", "rt.aime_world(sync+launch)"); wrap(gen, "prune_select"); wrap(gen, "assemble_children"); wrap(gen, "predict_inputs"); wrap(rt, "aime_rebase"); wrap(rt, "ilqr_solve"); wrap(opt, "speculate_warm"); wrap(pl, "resample_target_lane")
 wrap(gen, "create_nodes"); wrap(gen, "decide_branch"); wrap(gen, "update_obser_batch"); wrap(gen, "get_scenario_tree")
 wrap(rt, "ilqr_contingency"); wrap(opt, "solve_batch"); wrap(pl, "evaluate_traj_trees"); wrap(pl, "update_observation")
 wrap(sim, "_observation", "sim._observation"); wrap(gen, "prepare_root_data"); wrap(gen, "_select_modes")
