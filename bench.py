@@ -7,7 +7,10 @@ MINDPlanner.plan() = AIME scenario tree (every tree node through the HIP predict
 (warm start + full) for every scenario tree + selection.  value = simulator steps / wall time, whole job.
 
 Default workload = BASELINE.json configs[1]: the closed loop on the reference's recorded scene demo_1 (compact fixture
-tests/golden/scenes/demo_1.npz; formula-initialised weights: the trained checkpoint is not in the reference tree).
+tests/golden/scenes/demo_1.npz).  The trained checkpoint is not in the reference tree; the recorded scenes run with the
+BRANCHING formula weights (mind_amd/weights.py, variant "branching": the reference itself then expands 6 scenes in two AIME
+rounds and solves 5 scenario trees per plan on demo_1 -- the load a trained checkpoint produces), the plain formula weights
+(one expansion, one or two trees per plan) are reported beside it as `plain_formula_weights`.
 
 Multi-GPU (one process per GPU; plain `python bench.py --gpus N` spawns the N ranks itself through
 torch.distributed.run, under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE):
@@ -48,6 +51,7 @@ WORKLOADS = {
     "stress128tree": dict(n_agents=128, n_lanes=8, n_segs=32, seed=5),
 }
 FULL_TREE = ("cfg4tree", "stress128tree")
+BRANCHING_WEIGHTS, PLAIN_WEIGHTS = "formula_branching:20240121", "formula:20240121"
 
 # ---- algorithmic work of the pair kernel ----------------------------------------------------------
 F_MIN_N2 = 754944.0        # minimal-algorithm FLOPs per expansion, N^2 coefficient (K and V projections kept)
@@ -176,6 +180,8 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None):
     """K timed planning cycles of one closed loop (barrier + synchronize on both sides, max over ranks), with the pair
     kernel's launch durations taken from HIP events on the context stream inside the timed region."""
     wkw = scene_workload(workload, replica)
+    if ckpt is None and "scene" in wkw:
+        ckpt = BRANCHING_WEIGHTS
     pl, sim, w = make_closed_loop(wkw, full_tree=workload in FULL_TREE, ckpt=ckpt)
     sh = None
     if shard and dist.world > 1:
@@ -216,7 +222,7 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None):
     dt = dist.reduce(dt, "max")
     ctr = {k: v - ctr0.get(k, 0) for k, v in pl.traj_tree_opt.counters.items()}
     return dict(pl=pl, sim=sim, w=w, dt=dt, sim_steps=sim_steps, expansions=expansions, expansions_all=dist.reduce(expansions),
-                pair=acc, ilqr=ctr, a=len(pl.agent_obs), l=int(pl.scen_tree_gen.lane_feat_in.shape[0]), steps=steps,
+                pair=acc, ilqr=ctr, a=len(pl.agent_obs), l=int(pl.scen_tree_gen.lane_feat_in.shape[0]), steps=steps, weights=ckpt or PLAIN_WEIGHTS,
                 collectives=(sh.n_collectives - coll0[0], sh.bytes_gathered - coll0[1]) if sh is not None else None,
                 real_scene="scene" in wkw, sharded=sh is not None)
 
@@ -344,14 +350,15 @@ def recorded_scenes(prec, plans=20, warmup=3):
         out[name] = {k: v for k, v in summarize(m, prec).items() if k in ("sim_steps_per_s", "ms_per_plan", "agents", "lane_polylines", "expansions_per_plan")}
     from mind_amd.closed_loop import ClosedLoopSim
     from mind_amd.planners.mind.planner import MINDPlanner
-    pl, sim, w = make_closed_loop(dict(WORKLOADS["demo_1"]))
+    pl, sim, w = make_closed_loop(dict(WORKLOADS["demo_1"]), ckpt=BRANCHING_WEIGHTS)
     sim = ClosedLoopSim(w, MINDPlanner(pl.planner_cfg))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(500):
         sim.step()
     torch.cuda.synchronize()
-    out["demo_1_whole_run"] = {"simulator_steps": 500, "plans": sim.n_plans, "seconds": time.perf_counter() - t0}
+    out["demo_1_whole_run"] = {"simulator_steps": 500, "plans": sim.n_plans, "seconds": time.perf_counter() - t0, "weights": BRANCHING_WEIGHTS,
+                               "note": "BASELINE configs[0]/[1]: the reference's whole demo_1 run (10 s, 60 planning cycles; ~10 min with rendering on its own hardware)"}
     return out
 
 
@@ -551,12 +558,12 @@ def main():
         "config": {"workload": (f"BASELINE configs[1]: closed loop on the recorded scene {args.workload}" if real else f"{args.workload}-like synthetic scene") +
                                f": {a} agents x {l} lane polylines (N={a+l+1} tokens), "
                                f"one closed-loop planning cycle per step = AIME tree ({exp_plan:.1f} node expansions, "
-                               + ("the predictor's own modes with formula weights, exactly what the reference computes with these weights" if real else
+                               + (f"the predictor's own modes with the formula weights {m['weights']}, exactly what the reference computes with these weights" if real else
                                   "scripted mode branching on top of the real predictor forward: no trained checkpoint exists") + ") + "
                                f"tree-iLQR warm+full solves of {pl.timing['n_scen_trees']} scenario trees; closed loop: {m['sim_steps']} simulator steps "
                                f"(0.02 s) for {args.steps} plans",
                    "agents": a, "lane_polylines": l, "expansions_per_plan": exp_plan, "sim_steps_timed": m["sim_steps"],
-                   "scenario_trees_per_plan": pl.timing["n_scen_trees"],
+                   "scenario_trees_per_plan": pl.timing["n_scen_trees"], "weights": m["weights"],
                    "parallelism": (f"one plan sharded over {world} GPUs (AIME rounds block-sharded, solves round-robin, RCCL all-gather/broadcast per round)" if shard
                                    else f"{world} independent closed loops (one per GPU, no data-path collective)")},
         "roofline": roofline(m, prec),
@@ -583,6 +590,8 @@ def main():
             lcl = sim._observation()
             out["cpu_baseline"] = cpu_baseline(pl, lcl, (a, l), max(int(round(exp_plan)), 1), pl.scen_tree_gen.get_scenario_tree())
         if extras:
+            pm = measure(dist, "demo_1", args.steps, args.warmup, False, ckpt=PLAIN_WEIGHTS)
+            out["plain_formula_weights"] = dict(summarize(pm, prec), workload="recorded demo_1 with the plain formula weights (all modes merge: one expansion per plan)")
             out["synthetic_branching"] = dict(summarize(measure(dist, "demo1", args.steps, args.warmup, False), prec),
                                               workload="demo_1-like synthetic scene, scripted mode branching on the real predictor forward")
             out["recorded_scenes"] = recorded_scenes(prec)

@@ -43,6 +43,15 @@
 #define PBF_DIRECT_EDGE 0       // 1: edge tiles move between HBM and the C/D register layout directly (64-byte row segments per
 #endif                          // instruction) instead of full 128-byte lines staged through LDS
 
+#ifndef PBF_PINGPONG
+#define PBF_PINGPONG 0          // 1: the two waves of a SIMD (w, w + 4) run in lock-step one segment apart (six s_barrier per tile):
+#endif                          // the matrix segments of one coincide with the vector / memory segments of the other
+#if PBF_PINGPONG
+#define PP_BAR() __builtin_amdgcn_s_barrier()
+#else
+#define PP_BAR() do {} while (0)
+#endif
+
 #if PBF_LDS_WAIT
 #define PBF_FENCE() LDS_FENCE()
 #else
@@ -185,6 +194,21 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
   const int tw_base = (4 * q) * 16 + (((p >> 2) ^ cq_w) * 4) + (p & 3);
   const int tr_base = p * 16 + ((q ^ cq_r) * 4);
   PT_DECL
+#if PBF_PINGPONG
+  // every wave of the workgroup passes the same number of barriers: 6 per tile of the busiest wave (+ 1 for the offset)
+  int my_tiles = 0, wg_tiles = 0;
+  for (int job = wave * gridDim.x + blockIdx.x; job < n_jobs; job += gridDim.x * PAIR_WAVES) {
+    const int fl = jobs[job].flags, t0_ = jobs[job].t0, t1_ = jobs[job].t1;
+    if (update_mode == 2 && !(fl & 1)) continue;
+    my_tiles += t1_ - t0_;
+  }
+  if (lane == 0) ((int *)ptab)[0] = my_tiles;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < PAIR_WAVES; ++w) wg_tiles = max(wg_tiles, ((const int *)(lds + LB_PTAB + w * 128))[0]);
+  __syncthreads();
+  if (wave >= PAIR_WAVES / 2) PP_BAR();          // the second wave of every SIMD runs one segment behind the first
+#endif
 
   for (int job = wave * gridDim.x + blockIdx.x; job < n_jobs; job += gridDim.x * PAIR_WAVES) {
     const PairJob J = jobs[job];
@@ -339,13 +363,16 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
 #pragma unroll
         for (int b = 0; b < 8; ++b) mem[b] += *(const f32x4 *)(svq + 16 * b);
         SCHED_FENCE();
+        PP_BAR();                                  // ---- segment boundary 1: loads / staging / split | first GEMM
         gemm_bf<NP>(mem, wbe, ehi, elo, lane);
       }
+      PP_BAR();                                    // ---- 2: first GEMM | LayerNorm + split
       PT(1);
       ln_nomean(mem, vtq, VT_GM, VT_BM);
       SCHED_FENCE();
       split_frag<NP>(mem, mhi, mlo);
       PT(2);
+      PP_BAR();                                    // ---- 3: LayerNorm + split | second GEMM
 
       u32x4 qhi[4], qlo[4];
 #define PBF_LOAD_QK()                                                                              \
@@ -354,11 +381,13 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
     if (NP == 3) qlo[g] = *(const u32x4 *)(qs + (4 + g) * 128);                                    \
   }
       // ---- edge update e' = LN_e(e + ReLU(LN(W_p mem + b_p)))   (network.py:201-202)
+      if (!do_update) PP_BAR();                    // (segment boundary 4 of a tile whose edge is not updated)
       if (do_update) {
         frag8 up;
 #pragma unroll
         for (int b = 0; b < 8; ++b) up[b] = *(const f32x4 *)(vtq + VT_BP + 16 * b);
         gemm_bf<NP>(up, wbp, mhi, mlo, lane);
+        PP_BAR();                                  // ---- 4: second GEMM | LayerNorms + edge store
         PT(3);
         ln_nomean(up, vtq, VT_GP, VT_BEP);
 #pragma unroll
@@ -393,6 +422,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
       }
       SCHED_FENCE();
       PT(4);
+      PP_BAR();                                    // ---- 5: LayerNorms + edge store | attention
       // ---- next tile's edge rows (late variant): in flight during the attention phase only
       if (MODE == 1 && !PBF_PREFETCH_TOP && tile + 1 < J.t1) { PBF_LOAD_RAW(i0 + 16, ll) }
       // ---- attention scores: S^T[head, pair] = QK_j[head, :] . mem^T[:, pair]; the memory tile is already the B operand
@@ -484,6 +514,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
         }
       }
       PT(6);
+      PP_BAR();                                    // ---- 6: attention | next tile
     }  // tiles
 
     // ---- column partial: m[8], l[8], mbar[8][128]
@@ -500,6 +531,10 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
         for (int r = 0; r < 4; ++r) po[16 + (4 * q + r) * 128 + 16 * b + p] = mbar[b][r];
     }
   }
+#if PBF_PINGPONG
+  for (int it = my_tiles; it < wg_tiles; ++it) { PP_BAR(); PP_BAR(); PP_BAR(); PP_BAR(); PP_BAR(); PP_BAR(); }
+  if (wave < PAIR_WAVES / 2) PP_BAR();
+#endif
 #ifdef MIND_PAIR_TRACE
   if (blockIdx.x == 0 && tid == 0)
     printf("[k_pair_bf<%d,%d> um=%d] cycles: load+stage %lld split+gemm1 %lld LN1+split %lld gemm2 %lld LN2/3+store %lld scores+softmax %lld sum_p_mem %lld\n",

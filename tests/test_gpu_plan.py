@@ -115,6 +115,8 @@ def test_bench_prints_one_contract_json_line():
     assert 0 < r["frac"] <= 1.0 and 0 < r["mfma"]["frac"] <= 1.0 and 0 < r["hbm"]["frac"] <= 1.0 and r["traffic"] is None
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["value_1_thread"] > 0
     # extras: the synthetic branching scene, the full cfg4 tree on this GPU, the other recorded scenes
+    assert d["config"]["weights"] == "formula_branching:20240121" and d["config"]["expansions_per_plan"] >= 2      # a real AIME tree
+    assert d["plain_formula_weights"]["expansions_per_plan"] == 1.0
     assert d["synthetic_branching"]["expansions_per_plan"] >= 2 and d["tree"]["expansions_per_plan"] == 259
     assert d["tree"]["k_pair"]["frac"] <= 1.0 and set(d["recorded_scenes"]) >= {"demo_2", "demo_3", "demo_4", "demo_1_whole_run"}
 
