@@ -185,10 +185,12 @@ __device__ __forceinline__ int sw_pos(int r, int c) { return (r * 8 + (c ^ ((r >
 // update_mode 0: update every edge; 1: update only flagged columns; 2: run only flagged columns,
 // no edge update (last layer).
 #ifdef MIND_PAIR_TRACE
-#define PT_DECL long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pt_t = clock64();
+#define PT_DECL long long pt_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_t = clock64();
+#define PT_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define PT(i) do { long long n_ = clock64(); pt_[i] += n_ - pt_t; pt_t = n_; } while (0)
 #else
 #define PT_DECL
+#define PT_DRAIN()
 #define PT(i)
 #endif
 
@@ -208,9 +210,22 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair(const PairJob *__restr
   const int q = lane >> 4;
 
   // ---- stage weights / tables (once per workgroup) ----
-  for (int i = tid; i < 4096; i += PAIR_THREADS) {
-    ((f32x4 *)(lds + LDS_WAE))[i] = ((const f32x4 *)WAe)[i];
-    if (update_mode != 2) ((f32x4 *)(lds + LDS_WAP))[i] = ((const f32x4 *)WAp)[i];
+  {
+    // all loads of a matrix in flight before the first LDS write (the load -> wait -> write loop serialised 16 L2 round trips)
+    constexpr int PER = 4096 / PAIR_THREADS;
+    f32x4 te[PER], tp[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) te[k] = ((const f32x4 *)WAe)[tid + k * PAIR_THREADS];
+    if (update_mode != 2) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) tp[k] = ((const f32x4 *)WAp)[tid + k * PAIR_THREADS];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) ((f32x4 *)(lds + LDS_WAE))[tid + k * PAIR_THREADS] = te[k];
+    if (update_mode != 2) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) ((f32x4 *)(lds + LDS_WAP))[tid + k * PAIR_THREADS] = tp[k];
+    }
   }
   for (int i = tid; i < VT_SIZE; i += PAIR_THREADS) lds[LDS_VT + i] = vtab[i];
   if (MODE == 0)

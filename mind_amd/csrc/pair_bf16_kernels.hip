@@ -31,32 +31,11 @@
 // tuning switches (A/B-measured on the MI355X): where the next tile's edge rows and this tile's folded query
 // are requested
 #ifndef PBF_PREFETCH_TOP
-#define PBF_PREFETCH_TOP 0      // 1: next tile's edge rows requested right after this tile's rows left the load registers
+#define PBF_PREFETCH_TOP 0      // 1: next tile's edge rows requested right after this tile's rows left the load registers (measured: no difference)
 #endif
-#ifndef PBF_QK_EARLY
-#define PBF_QK_EARLY 0          // 1: folded-query fragments requested before the edge store's staging passes (spills: slower)
-#endif
-#ifndef PBF_LDS_WAIT
-#define PBF_LDS_WAIT 0          // 1: drain the LDS queue (s_waitcnt lgkmcnt(0)) between the passes over a wave-private staging buffer;
-#endif                          // 0: rely on the in-order execution of one wave's DS instructions (compiler barrier only)
-#ifndef PBF_DIRECT_EDGE
-#define PBF_DIRECT_EDGE 0       // 1: edge tiles move between HBM and the C/D register layout directly (64-byte row segments per
-#endif                          // instruction) instead of full 128-byte lines staged through LDS
-
-#ifndef PBF_PINGPONG
-#define PBF_PINGPONG 0          // 1: the two waves of a SIMD (w, w + 4) run in lock-step one segment apart (six s_barrier per tile):
-#endif                          // the matrix segments of one coincide with the vector / memory segments of the other
-#if PBF_PINGPONG
-#define PP_BAR() __builtin_amdgcn_s_barrier()
-#else
-#define PP_BAR() do {} while (0)
-#endif
-
-#if PBF_LDS_WAIT
-#define PBF_FENCE() LDS_FENCE()
-#else
+// the staging buffers are private to a wave and one wave's DS instructions execute in order: no s_waitcnt between the passes
+// over a buffer, only a compiler barrier (draining the LDS queue there measured no difference: DESIGN 4)
 #define PBF_FENCE() asm volatile("" ::: "memory")
-#endif
 
 #define LB_WE 0                                       // [part 2][ob 8][g 4][lane 64][4 dwords] = 16384 dwords (64 KB)
 #define LB_WP 16384
@@ -166,12 +145,23 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
   const int p = lane & 15;
   const int q = lane >> 4;
 
-  // ---- stage weights / tables (once per workgroup); the lo halves are only needed by the split arithmetic
+  // ---- stage weights / tables (once per workgroup); the lo halves are only needed by the split arithmetic.  All loads of
+  //      a matrix are requested before the first LDS write (a load -> wait -> write loop costs 16 L2 round trips per
+  //      workgroup, a quarter of a small launch)
   {
-    const int n4 = NP == 3 ? 4096 : 2048;
-    for (int i = tid; i < n4; i += PAIR_THREADS) {
-      ((f32x4 *)(lds + LB_WE))[i] = ((const f32x4 *)WBe)[i];
-      if (update_mode != 2) ((f32x4 *)(lds + LB_WP))[i] = ((const f32x4 *)WBp)[i];
+    constexpr int PER = (NP == 3 ? 4096 : 2048) / PAIR_THREADS;
+    f32x4 te[PER], tp[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) te[k] = ((const f32x4 *)WBe)[tid + k * PAIR_THREADS];
+    if (update_mode != 2) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) tp[k] = ((const f32x4 *)WBp)[tid + k * PAIR_THREADS];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) ((f32x4 *)(lds + LB_WE))[tid + k * PAIR_THREADS] = te[k];
+    if (update_mode != 2) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) ((f32x4 *)(lds + LB_WP))[tid + k * PAIR_THREADS] = tp[k];
     }
   }
   for (int i = tid; i < VT_SIZE; i += PAIR_THREADS) lds[LB_VT + i] = vtab[i];
@@ -194,21 +184,6 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
   const int tw_base = (4 * q) * 16 + (((p >> 2) ^ cq_w) * 4) + (p & 3);
   const int tr_base = p * 16 + ((q ^ cq_r) * 4);
   PT_DECL
-#if PBF_PINGPONG
-  // every wave of the workgroup passes the same number of barriers: 6 per tile of the busiest wave (+ 1 for the offset)
-  int my_tiles = 0, wg_tiles = 0;
-  for (int job = wave * gridDim.x + blockIdx.x; job < n_jobs; job += gridDim.x * PAIR_WAVES) {
-    const int fl = jobs[job].flags, t0_ = jobs[job].t0, t1_ = jobs[job].t1;
-    if (update_mode == 2 && !(fl & 1)) continue;
-    my_tiles += t1_ - t0_;
-  }
-  if (lane == 0) ((int *)ptab)[0] = my_tiles;
-  __syncthreads();
-#pragma unroll
-  for (int w = 0; w < PAIR_WAVES; ++w) wg_tiles = max(wg_tiles, ((const int *)(lds + LB_PTAB + w * 128))[0]);
-  __syncthreads();
-  if (wave >= PAIR_WAVES / 2) PP_BAR();          // the second wave of every SIMD runs one segment behind the first
-#endif
 
   for (int job = wave * gridDim.x + blockIdx.x; job < n_jobs; job += gridDim.x * PAIR_WAVES) {
     const PairJob J = jobs[job];
@@ -236,22 +211,12 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
     }
     // first edge tile of the job (later ones are requested one tile ahead)
     f32x4 raw[8];
-#if PBF_DIRECT_EDGE
-#define PBF_LOAD_RAW(ROW0, LANEV)                                                                       \
-  {                                                                                                     \
-    int irow = (ROW0) + ((LANEV)&15);                                                                   \
-    irow = irow < N ? irow : N - 1;                                                                     \
-    const float *rp_ = ecol + ((size_t)irow << 7) + ((LANEV) >> 4) * 4;                                 \
-    _Pragma("unroll") for (int b = 0; b < 8; ++b) raw[b] = *(const f32x4 *)(rp_ + 16 * b);             \
-  }
-#else
 #define PBF_LOAD_RAW(ROW0, LANEV)                                                                       \
   _Pragma("unroll") for (int qt = 0; qt < 4; ++qt) _Pragma("unroll") for (int n = 0; n < 2; ++n) {     \
     int irow = (ROW0) + 8 * n + ((LANEV) >> 3);                                                         \
     irow = irow < N ? irow : N - 1;                                                                     \
     raw[2 * qt + n] = *(const f32x4 *)(ecol + ((size_t)irow << 7) + qt * 32 + ((LANEV)&7) * 4);        \
   }
-#endif
     if (MODE == 1) { PBF_LOAD_RAW(J.t0 * 16, lane) }
     PBF_FENCE();
 
@@ -270,12 +235,11 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
 #pragma unroll
         for (int b = 0; b < 8; ++b) mem[b] = *(const f32x4 *)(Ti + 16 * b);
       }
+      PT(7);                 // (trace) tile top: address setup + issue of the T loads
+      PT_DRAIN();
+      PT(8);                 // (trace) wait for every outstanding global access: T rows, prefetched edge rows, earlier stores
       frag8 ef;
-      if (MODE == 1 && PBF_DIRECT_EDGE) {
-#pragma unroll
-        for (int b = 0; b < 8; ++b) ef[b] = raw[b];
-        if (PBF_PREFETCH_TOP && tile + 1 < J.t1) { PBF_LOAD_RAW(i0 + 16, ll) }
-      } else if (MODE == 1) {
+      if (MODE == 1) {
         // ---- edge tile -> registers through the swizzled staging buffer (full 128-byte row segments)
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
@@ -363,16 +327,13 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
 #pragma unroll
         for (int b = 0; b < 8; ++b) mem[b] += *(const f32x4 *)(svq + 16 * b);
         SCHED_FENCE();
-        PP_BAR();                                  // ---- segment boundary 1: loads / staging / split | first GEMM
         gemm_bf<NP>(mem, wbe, ehi, elo, lane);
       }
-      PP_BAR();                                    // ---- 2: first GEMM | LayerNorm + split
       PT(1);
       ln_nomean(mem, vtq, VT_GM, VT_BM);
       SCHED_FENCE();
       split_frag<NP>(mem, mhi, mlo);
       PT(2);
-      PP_BAR();                                    // ---- 3: LayerNorm + split | second GEMM
 
       u32x4 qhi[4], qlo[4];
 #define PBF_LOAD_QK()                                                                              \
@@ -381,28 +342,17 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
     if (NP == 3) qlo[g] = *(const u32x4 *)(qs + (4 + g) * 128);                                    \
   }
       // ---- edge update e' = LN_e(e + ReLU(LN(W_p mem + b_p)))   (network.py:201-202)
-      if (!do_update) PP_BAR();                    // (segment boundary 4 of a tile whose edge is not updated)
       if (do_update) {
         frag8 up;
 #pragma unroll
         for (int b = 0; b < 8; ++b) up[b] = *(const f32x4 *)(vtq + VT_BP + 16 * b);
         gemm_bf<NP>(up, wbp, mhi, mlo, lane);
-        PP_BAR();                                  // ---- 4: second GEMM | LayerNorms + edge store
         PT(3);
         ln_nomean(up, vtq, VT_GP, VT_BEP);
 #pragma unroll
         for (int b = 0; b < 8; ++b) up[b] += ef[b];
         ln_pairs(up, vtq, VT_GE, VT_BE, false);
         SCHED_FENCE();
-        if (PBF_QK_EARLY) { PBF_LOAD_QK() }
-        SCHED_FENCE();
-        if (PBF_DIRECT_EDGE) {
-          if (valid) {
-            float *wp_ = ecol + ((size_t)i << 7) + lq * 4;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) *(f32x4 *)(wp_ + 16 * b) = up[b];
-          }
-        } else {
         // store through the staging buffer: full 128-byte row segments
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
@@ -418,17 +368,18 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
           }
           PBF_FENCE();
         }
-        }
       }
       SCHED_FENCE();
       PT(4);
-      PP_BAR();                                    // ---- 5: LayerNorms + edge store | attention
       // ---- next tile's edge rows (late variant): in flight during the attention phase only
       if (MODE == 1 && !PBF_PREFETCH_TOP && tile + 1 < J.t1) { PBF_LOAD_RAW(i0 + 16, ll) }
       // ---- attention scores: S^T[head, pair] = QK_j[head, :] . mem^T[:, pair]; the memory tile is already the B operand
       f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, sb = sa, sc = sa;
       {
-        if (!(PBF_QK_EARLY && do_update)) { PBF_LOAD_QK() }
+        PT(9);               // (trace) next-tile prefetch issue
+        PBF_LOAD_QK()
+        PT_DRAIN();
+        PT(10);              // (trace) wait for the folded-query fragments (and the edge stores / prefetch queued before them)
         if (!qrow) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) { qhi[g] = (u32x4){0u, 0u, 0u, 0u}; qlo[g] = (u32x4){0u, 0u, 0u, 0u}; }
@@ -514,7 +465,6 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
         }
       }
       PT(6);
-      PP_BAR();                                    // ---- 6: attention | next tile
     }  // tiles
 
     // ---- column partial: m[8], l[8], mbar[8][128]
@@ -531,14 +481,11 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
         for (int r = 0; r < 4; ++r) po[16 + (4 * q + r) * 128 + 16 * b + p] = mbar[b][r];
     }
   }
-#if PBF_PINGPONG
-  for (int it = my_tiles; it < wg_tiles; ++it) { PP_BAR(); PP_BAR(); PP_BAR(); PP_BAR(); PP_BAR(); PP_BAR(); }
-  if (wave < PAIR_WAVES / 2) PP_BAR();
-#endif
 #ifdef MIND_PAIR_TRACE
   if (blockIdx.x == 0 && tid == 0)
-    printf("[k_pair_bf<%d,%d> um=%d] cycles: load+stage %lld split+gemm1 %lld LN1+split %lld gemm2 %lld LN2/3+store %lld scores+softmax %lld sum_p_mem %lld\n",
-           MODE, NP, update_mode, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[5], pt_[6]);
+    printf("[k_pair_bf<%d,%d> um=%d] cycles: tile-top issue %lld | WAIT global (T, edge prefetch, stores) %lld | stage+split %lld | gemm1 %lld | LN1+split %lld | gemm2 %lld | "
+           "LN2/3+store %lld | prefetch issue %lld | WAIT query frags (+stores) %lld | scores+softmax %lld | sum_p_mem %lld\n",
+           MODE, NP, update_mode, pt_[7], pt_[8], pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[9], pt_[10], pt_[5], pt_[6]);
 #endif
 }
 
