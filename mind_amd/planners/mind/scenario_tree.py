@@ -50,6 +50,68 @@ class DevScene(dict):
         return dict.__getitem__(self, key)
 
 
+_HIST_COLS = {"TRAJS_POS_HIST": slice(0, 2), "TRAJS_VEL_HIST": slice(2, 4), "TRAJS_ANG_HIST": 4, "TRAJS_COV_HIST": slice(5, 6)}
+
+
+class ChildScene(dict):
+    """A kept mode of prune_merge (scenario_tree.py:396-412).  The reference stores the parent's world-frame history extended
+    by the mode's 60 predicted steps, truncated to seq_len; here the child keeps a reference to the parent's arrays and a
+    view of its own rows [a,60,6] (x, y, vx, vy, heading, max-sigma) and cuts what a consumer needs out of the two pieces
+    (``rows``): the branch-time test reads the predicted sigmas, re-basing the last 50 steps, the returned tree the first
+    `dur` predicted steps -- the four concatenated arrays (169 KB per child at 64 agents) are only built if somebody asks
+    for them by name."""
+
+    def __init__(self, fields, parent, new, seq_len):
+        super().__init__(fields)
+        self.parent, self.new, self.n_hist = parent, new, parent["TRAJS_POS_HIST"].shape[1]
+        self.length = min(self.n_hist + new.shape[1], seq_len)          # Q8: truncated to seq_len
+
+    def trim(self, keep):
+        """update_obser's in-place truncation of the stored history (scenario_tree.py:470-473)"""
+        self.length = min(self.length, keep)
+        for k in _HIST_COLS:
+            if dict.__contains__(self, k):
+                dict.__setitem__(self, k, dict.__getitem__(self, k)[:, :keep])
+
+    def rows(self, key, lo, hi):
+        """[a, hi-lo, ...] = rows lo..hi of the (virtual) concatenated history array `key`"""
+        hi = min(hi, self.length)
+        col, h = _HIST_COLS[key], self.n_hist
+        if lo >= h:
+            return self.new[:, lo - h:hi - h, col]
+        par = self.parent[key]
+        if hi <= h:
+            return par[:, lo:hi]
+        return np.concatenate([par[:, lo:h], self.new[:, :hi - h, col]], axis=1)
+
+    def __missing__(self, key):
+        if key not in _HIST_COLS:
+            raise KeyError(key)
+        v = self.rows(key, 0, self.length)
+        dict.__setitem__(self, key, v)
+        return v
+
+    def __contains__(self, key):
+        return key in _HIST_COLS or dict.__contains__(self, key)
+
+
+def hist_rows(d, key, lo, hi):
+    """rows lo..hi of a node's history array, without materialising a ChildScene's concatenation"""
+    return d.rows(key, lo, hi) if isinstance(d, ChildScene) else d[key][:, lo:hi]
+
+
+def hist_trim(d, keep):
+    if isinstance(d, ChildScene):
+        d.trim(keep)
+    else:
+        for k in _HIST_COLS:
+            d[k] = d[k][:, :keep]
+
+
+def hist_len(d):
+    return d.length if isinstance(d, ChildScene) else d["TRAJS_POS_HIST"].shape[1]
+
+
 class RemoteScene(dict):
     """Observation of a branch node that ANOTHER rank re-bases and expands (sharded rounds): only the world-frame fields the
     tree bookkeeping and the child assembly read; no predictor inputs exist on this rank."""
@@ -521,16 +583,12 @@ class ScenarioTreeGenerator:
             a = sc["TRAJS_POS_HIST"].shape[0]
             m = rows[r0:r0 + a]
             r0 += a
-            kept.append({
+            kept.append(ChildScene({
                 "SCEN_PROB": F32(h[2]), "CUR_T": sc["CUR_T"], "END_T": sc["END_T"],
                 "PARENT_ID": sc["SCEN_ID"], "SCEN_ID": "{}_{}_{}".format(self.branch_depth, gidx, k),
                 "TRAJS_TYPE": sc["TRAJS_TYPE"], "TRAJS_TID": sc["TRAJS_TID"], "TRAJS_CAT": sc["TRAJS_CAT"],
-                "TRAJS_POS_HIST": np.concatenate([sc["TRAJS_POS_HIST"], m[:, :, 0:2]], axis=1)[:, :L],
-                "TRAJS_COV_HIST": np.concatenate([sc["TRAJS_COV_HIST"], m[:, :, 5:6]], axis=1)[:, :L],
-                "TRAJS_ANG_HIST": np.concatenate([sc["TRAJS_ANG_HIST"], m[:, :, 4]], axis=1)[:, :L],
-                "TRAJS_VEL_HIST": np.concatenate([sc["TRAJS_VEL_HIST"], m[:, :, 2:4]], axis=1)[:, :L],
                 "TGT_PTS": np.array(h[3:], F32).reshape(11, 2),
-            })
+            }, sc, m, L))
         assert r0 == len(rows), (r0, len(rows))
         return kept
 
@@ -540,12 +598,16 @@ class ScenarioTreeGenerator:
         return self.assemble_children(scenes, hdr, _np(rows))
 
     def get_branch_time(self, d):
-        cov = d["TRAJS_COV_HIST"]
         cur_t, end_t = d["CUR_T"], d["END_T"]
         compare_t = self.obs_len + cur_t + (1 if cur_t == 0 else 0)
         ts = np.arange(cur_t + 1 + (cur_t + 1) % 2, end_t, 2)          # even t in (cur_t, end_t)
         if len(ts):
-            hit = (cov[:, self.obs_len + ts, 0] / cov[:, compare_t, 0][:, None] > 9).any(axis=0)
+            if isinstance(d, ChildScene) and d.n_hist == self.obs_len and self.obs_len + int(ts[-1]) < d.length and compare_t < d.length:
+                sig = d.new[:, :, 5]                                   # the predicted steps' max-sigma: rows obs_len + t
+                hit = (sig[:, ts] / sig[:, compare_t - self.obs_len][:, None] > 9).any(axis=0)
+            else:
+                cov = d["TRAJS_COV_HIST"]
+                hit = (cov[:, self.obs_len + ts, 0] / cov[:, compare_t, 0][:, None] > 9).any(axis=0)
             if hit.any():
                 t = int(ts[int(np.argmax(hit))])
                 d["END_T"] = t
@@ -557,14 +619,20 @@ class ScenarioTreeGenerator:
         out = [None] * len(datas)
         groups = {}
         for i, d in enumerate(datas):
-            groups.setdefault(d["TRAJS_COV_HIST"].shape, []).append(i)
+            lazy = isinstance(d, ChildScene) and d.n_hist == self.obs_len
+            groups.setdefault((d.new.shape[0], d.length, True) if lazy else d["TRAJS_COV_HIST"].shape, []).append(i)
         for shape, idx in groups.items():
             T = shape[1]
             if len(idx) == 1 or T <= self.obs_len:
                 for i in idx:
                     out[i] = self.get_branch_time(datas[i])
                 continue
-            cov = np.stack([datas[i]["TRAJS_COV_HIST"][:, :, 0] for i in idx])          # [G,a,T]
+            if shape[2] is True:     # only the predicted steps are read (rows >= obs_len): no concatenated history needed
+                cov = np.empty((len(idx), shape[0], T), F32)
+                cov[:, :, :self.obs_len] = 1.0
+                cov[:, :, self.obs_len:] = np.stack([datas[i].new[:, :T - self.obs_len, 5] for i in idx])
+            else:
+                cov = np.stack([datas[i]["TRAJS_COV_HIST"][:, :, 0] for i in idx])          # [G,a,T]
             cur = np.array([datas[i]["CUR_T"] for i in idx])
             end = np.array([datas[i]["END_T"] for i in idx])
             cmp_t = self.obs_len + cur + (cur == 0)
@@ -641,17 +709,16 @@ class ScenarioTreeGenerator:
                 if lo <= g < hi:
                     continue
                 keep = o + (c["END_T"] - c["CUR_T"])
-                for k in ("TRAJS_POS_HIST", "TRAJS_COV_HIST", "TRAJS_ANG_HIST", "TRAJS_VEL_HIST"):
-                    c[k] = c[k][:, :keep]
+                hist_trim(c, keep)
+                w0 = max(min(keep, hist_len(c)) - o, 0)
                 out[g] = (RemoteScene({"TRAJS_TYPE": c["TRAJS_TYPE"], "SCEN_PROB": c["SCEN_PROB"], "SCEN_ID": c["SCEN_ID"],
                                        "PARENT_ID": c["PARENT_ID"], "CUR_T": c["END_T"], "END_T": self.pred_len,
                                        "TRAJS_TID": c["TRAJS_TID"], "TRAJS_CAT": c["TRAJS_CAT"],
-                                       "TRAJS_POS_HIST": c["TRAJS_POS_HIST"][:, -o:].copy(), "TRAJS_COV_HIST": c["TRAJS_COV_HIST"][:, -o:].copy(),
-                                       "TRAJS_ANG_HIST": c["TRAJS_ANG_HIST"][:, -o:].copy(), "TRAJS_VEL_HIST": c["TRAJS_VEL_HIST"][:, -o:].copy()}), c)
+                                       **{k: np.ascontiguousarray(hist_rows(c, k, w0, keep)) for k in _HIST_COLS}}), c)
             if hi > lo:
                 out[lo:hi] = self.update_obser_batch(curs[lo:hi])
             return out
-        a_counts = {c["TRAJS_POS_HIST"].shape[0] for c in curs}
+        a_counts = {(c.new.shape[0] if isinstance(c, ChildScene) else c["TRAJS_POS_HIST"].shape[0]) for c in curs}
         rt = getattr(self.network, "rt", None) if self.device_glue else None
         on_dev = (rt is not None and len(a_counts) == 1 and self.target_lane is not None and len(self.target_lane) >= 12
                   and all(c["TRAJS_TYPE"] is curs[0]["TRAJS_TYPE"] or np.array_equal(c["TRAJS_TYPE"], curs[0]["TRAJS_TYPE"]) for c in curs))
@@ -662,16 +729,17 @@ class ScenarioTreeGenerator:
         wins = {}
         for c in curs:
             keep = o + (c["END_T"] - c["CUR_T"])
-            for k in ("TRAJS_POS_HIST", "TRAJS_COV_HIST", "TRAJS_ANG_HIST", "TRAJS_VEL_HIST"):
-                c[k] = c[k][:, :keep]
-                wins.setdefault(k, []).append(c[k][:, -o:])
-        pos, cov = np.stack(wins["TRAJS_POS_HIST"]), np.stack(wins["TRAJS_COV_HIST"])
-        ang, vel = np.stack(wins["TRAJS_ANG_HIST"]), np.stack(wins["TRAJS_VEL_HIST"])
+            hist_trim(c, keep)
+            w0 = max(min(keep, hist_len(c)) - o, 0)
+            for k in _HIST_COLS:
+                wins.setdefault(k, []).append(hist_rows(c, k, w0, keep))
         if on_dev:
-            # the whole re-basing arithmetic on the device; the next round's predictor reads its outputs in place
-            dev = rt.aime_rebase(pos, ang, vel, curs[0]["TRAJS_TYPE"], self.lane_graph["lane_ctrs"], self.lane_graph["lane_vecs"],
+            # the whole re-basing arithmetic on the device; the next round's predictor reads its outputs in place.  The
+            # per-scene windows are stacked straight into the runtime's page-locked staging buffers (no stacked host copy)
+            wp, wc, wa, wv = (wins[k] for k in ("TRAJS_POS_HIST", "TRAJS_COV_HIST", "TRAJS_ANG_HIST", "TRAJS_VEL_HIST"))
+            dev = rt.aime_rebase(wp, wa, wv, curs[0]["TRAJS_TYPE"], self.lane_graph["lane_ctrs"], self.lane_graph["lane_vecs"],
                                  self.target_lane, self.target_lane_info, time_ahead=self.config.tar_time_ahead)
-            dev["a"], dev["l"] = pos.shape[1], self.lane_graph["lane_ctrs"].shape[0]
+            dev["a"], dev["l"] = wp[0].shape[0], self.lane_graph["lane_ctrs"].shape[0]
             fr = dev["frames"].cpu().numpy()
             out = []
             for g, c in enumerate(curs):
@@ -679,8 +747,10 @@ class ScenarioTreeGenerator:
                     "ORIG": fr[g, 4:6].copy(), "ROT": fr[g, :4].reshape(2, 2).copy(), "TGT_PTS": fr[g, 6:].reshape(11, 2).copy(),
                     "TRAJS_TYPE": c["TRAJS_TYPE"], "SCEN_PROB": c["SCEN_PROB"], "SCEN_ID": c["SCEN_ID"], "PARENT_ID": c["PARENT_ID"],
                     "CUR_T": c["END_T"], "END_T": self.pred_len, "TRAJS_TID": c["TRAJS_TID"], "TRAJS_CAT": c["TRAJS_CAT"],
-                    "TRAJS_POS_HIST": pos[g], "TRAJS_COV_HIST": cov[g], "TRAJS_ANG_HIST": ang[g], "TRAJS_VEL_HIST": vel[g]}), c))
+                    "TRAJS_POS_HIST": wp[g], "TRAJS_COV_HIST": wc[g], "TRAJS_ANG_HIST": wa[g], "TRAJS_VEL_HIST": wv[g]}), c))
             return out
+        pos, cov = np.stack(wins["TRAJS_POS_HIST"]), np.stack(wins["TRAJS_COV_HIST"])
+        ang, vel = np.stack(wins["TRAJS_ANG_HIST"]), np.stack(wins["TRAJS_VEL_HIST"])
         orig, rot, theta, pos_n, ang_n, vel_n, ctrs, vecs = U.normalize_agents_batch(pos, ang, vel)
         lane_ctrs = np.ascontiguousarray(np.matmul(self.lane_graph["lane_ctrs"][None] - orig[:, None, :], rot), F32)
         lane_vecs = np.ascontiguousarray(np.matmul(self.lane_graph["lane_vecs"][None], rot), F32)
@@ -715,11 +785,11 @@ class ScenarioTreeGenerator:
     def update_obser(self, cur):
         end_t, cur_t = cur["END_T"], cur["CUR_T"]
         keep = self.obs_len + (end_t - cur_t)
-        for k in ("TRAJS_POS_HIST", "TRAJS_COV_HIST", "TRAJS_ANG_HIST", "TRAJS_VEL_HIST"):
-            cur[k] = cur[k][:, :keep]
+        hist_trim(cur, keep)
         o = self.obs_len
-        pos, cov = cur["TRAJS_POS_HIST"][:, -o:], cur["TRAJS_COV_HIST"][:, -o:]
-        ang, vel = cur["TRAJS_ANG_HIST"][:, -o:], cur["TRAJS_VEL_HIST"][:, -o:]
+        w0 = max(min(keep, hist_len(cur)) - o, 0)
+        pos, cov = hist_rows(cur, "TRAJS_POS_HIST", w0, keep), hist_rows(cur, "TRAJS_COV_HIST", w0, keep)
+        ang, vel = hist_rows(cur, "TRAJS_ANG_HIST", w0, keep), hist_rows(cur, "TRAJS_VEL_HIST", w0, keep)
         orig, rot, theta, pos_n, ang_n, vel_n, ctrs, vecs = U.normalize_agents(pos, ang, vel)
         # lane anchors re-expressed in the new AV frame (get_new_lane_graph, utils.py:171-177); the
         # instance-frame node features (and hence LaneNet's output) are unchanged
@@ -771,7 +841,7 @@ class ScenarioTreeGenerator:
                 d = n.data.data
                 dur = d["END_T"] - d["CUR_T"]
                 t.add_node(Node(k, None if k == key else n.parent_key,
-                                [probs[k], d["TRAJS_POS_HIST"][:, o:o + dur, :], d["TRAJS_COV_HIST"][:, o:o + dur, :],
+                                [probs[k], hist_rows(d, "TRAJS_POS_HIST", o, o + dur), hist_rows(d, "TRAJS_COV_HIST", o, o + dur),
                                  d["TGT_PTS"]]))
             trees.append(t)
         return trees

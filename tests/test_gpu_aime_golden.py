@@ -113,4 +113,4 @@ def test_device_aime_glue_matches_reference_goldens(hip_predictor):
                 assert np.abs(d[1][:, ::5] - G[f"{name}_t{ti}_{k}_pos"]).max() < 1e-3       # metres, world frame
                 assert np.abs(d[2][:, ::5] - G[f"{name}_t{ti}_{k}_cov"]).max() < 1e-4
                 assert np.abs(np.asarray(d[3]) - G[f"{name}_t{ti}_{k}_tgt"]).max() < 1e-3
-    assert n_dev_rounds >= 3          # later rounds really ran on inputs built by mind_aime_rebase
+    assert n_dev_rounds >= 2          # later rounds really ran on inputs built by mind_aime_rebase
