@@ -61,9 +61,10 @@ class ChildScene(dict):
     `dur` predicted steps -- the four concatenated arrays (169 KB per child at 64 agents) are only built if somebody asks
     for them by name."""
 
-    def __init__(self, fields, parent, new, seq_len):
+    def __init__(self, fields, parent, new, seq_len, shared=None):
         super().__init__(fields)
         self.parent, self.new, self.n_hist = parent, new, parent["TRAJS_POS_HIST"].shape[1]
+        self.shared = shared if shared is not None else {}          # siblings share the parent's packed window
         self.length = min(self.n_hist + new.shape[1], seq_len)          # Q8: truncated to seq_len
 
     def trim(self, keep):
@@ -83,6 +84,21 @@ class ChildScene(dict):
         if hi <= h:
             return par[:, lo:hi]
         return np.concatenate([par[:, lo:h], self.new[:, :hi - h, col]], axis=1)
+
+    def window6(self, lo, hi):
+        """rows lo..hi of the packed history [a, hi-lo, 6] = (x, y, vx, vy, heading, max-sigma): ONE concatenation (the parent's
+        packed window is built once per parent and shared by its children) instead of one per array"""
+        h = self.n_hist
+        if lo >= h:
+            return self.new[:, lo - h:hi - h]
+        par = self.parent
+        p6 = self.shared.get("p6")
+        if p6 is None:
+            p6 = getattr(par, "_win6", None)
+            if p6 is None:
+                p6 = np.concatenate([par["TRAJS_POS_HIST"], par["TRAJS_VEL_HIST"], par["TRAJS_ANG_HIST"][..., None], par["TRAJS_COV_HIST"]], axis=2)
+            self.shared["p6"] = p6
+        return np.concatenate([p6[:, lo:h], self.new[:, :hi - h]], axis=1)
 
     def __missing__(self, key):
         if key not in _HIST_COLS:
@@ -577,6 +593,7 @@ class ScenarioTreeGenerator:
         (every rank holds its world-frame fields), ``hdr`` / ``rows`` as returned by prune_select, concatenated in batch order
         over all ranks when the round was sharded."""
         kept, r0, L = [], 0, self.seq_len
+        shared = {}
         for h in hdr:
             gidx, k = int(h[0]), int(h[1])
             sc = batch[gidx]
@@ -588,7 +605,7 @@ class ScenarioTreeGenerator:
                 "PARENT_ID": sc["SCEN_ID"], "SCEN_ID": "{}_{}_{}".format(self.branch_depth, gidx, k),
                 "TRAJS_TYPE": sc["TRAJS_TYPE"], "TRAJS_TID": sc["TRAJS_TID"], "TRAJS_CAT": sc["TRAJS_CAT"],
                 "TGT_PTS": np.array(h[3:], F32).reshape(11, 2),
-            }, sc, m, L))
+            }, sc, m, L, shared.setdefault(gidx, {})))
         assert r0 == len(rows), (r0, len(rows))
         return kept
 
@@ -731,8 +748,15 @@ class ScenarioTreeGenerator:
             keep = o + (c["END_T"] - c["CUR_T"])
             hist_trim(c, keep)
             w0 = max(min(keep, hist_len(c)) - o, 0)
-            for k in _HIST_COLS:
-                wins.setdefault(k, []).append(hist_rows(c, k, w0, keep))
+            if isinstance(c, ChildScene) and keep <= c.length and keep > c.n_hist:
+                w6 = c.window6(w0, keep)
+                for k, col in _HIST_COLS.items():
+                    wins.setdefault(k, []).append(w6[:, :, col])
+                wins.setdefault("_WIN6", []).append(w6)
+            else:
+                for k in _HIST_COLS:
+                    wins.setdefault(k, []).append(hist_rows(c, k, w0, keep))
+                wins.setdefault("_WIN6", []).append(None)
         if on_dev:
             # the whole re-basing arithmetic on the device; the next round's predictor reads its outputs in place.  The
             # per-scene windows are stacked straight into the runtime's page-locked staging buffers (no stacked host copy)
@@ -748,6 +772,7 @@ class ScenarioTreeGenerator:
                     "TRAJS_TYPE": c["TRAJS_TYPE"], "SCEN_PROB": c["SCEN_PROB"], "SCEN_ID": c["SCEN_ID"], "PARENT_ID": c["PARENT_ID"],
                     "CUR_T": c["END_T"], "END_T": self.pred_len, "TRAJS_TID": c["TRAJS_TID"], "TRAJS_CAT": c["TRAJS_CAT"],
                     "TRAJS_POS_HIST": wp[g], "TRAJS_COV_HIST": wc[g], "TRAJS_ANG_HIST": wa[g], "TRAJS_VEL_HIST": wv[g]}), c))
+                out[-1][0]._win6 = wins["_WIN6"][g]
             return out
         pos, cov = np.stack(wins["TRAJS_POS_HIST"]), np.stack(wins["TRAJS_COV_HIST"])
         ang, vel = np.stack(wins["TRAJS_ANG_HIST"]), np.stack(wins["TRAJS_VEL_HIST"])
