@@ -59,6 +59,14 @@ struct mind_ctx {
   TokWeights tokW[7];  // [L]: epilogue of layer L-1 (L>=1) + prologue of layer L (L<=5); [0] = init
   const float *WAe[6], *WAp[6], *vtab[6], *rtab = nullptr;
   const u32 *WBe[6], *WBp[6];   // bf16 hi / lo fragments of the same matrices (pair_bf16_kernels.hip)
+  // job / token tables of the last mind_predict_batch: reused (no rebuild, no upload, no synchronisation) when the next
+  // call has the same scene sizes -- the closed loop's root scene every cycle, a full tree's rounds every plan
+  std::vector<int> tab_key;
+  std::vector<int> tab_actor_row, tab_cls_row;
+  long long tab_edge_pairs = 0;
+  int tab_ntok = 0, tab_slot = 0, tab_njobs = 0;
+  double tab_pairs_full = 0, tab_pairs_l5 = 0;
+  long long n_table_hits = 0;
   int pair_prec = 1;            // arithmetic of the pair kernel: 0 = fp32 MFMA, 1 = bf16x3 (split operands, default), 2 = bf16
   // workspaces (grow only)
   DevBuf edge, x, ST, QK, part, tokpos, meta, jobs, actor_feat, lane_feat, tgt_feat, cmode, tgt_emb,
@@ -604,94 +612,112 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   const int A = in->actor_off[Bn], Ltot = in->lane_off[Bn];
   if (A <= 0 || Ltot < 0) return fail(c, MIND_EINVAL, "empty batch");
 
-  // ---- host tables: tokens, jobs
-  std::vector<TokMeta> meta;
-  std::vector<PairJob> jobs;
-  std::vector<int> actor_row(A), actor_scene(A), cls_row(Bn);
-  long long edge_pairs = 0;
-  int ntok = 0;
-  long long total_cols = 0;
-  for (int b = 0; b < Bn; ++b) {
-    const int a = in->actor_off[b + 1] - in->actor_off[b], l = in->lane_off[b + 1] - in->lane_off[b];
-    if (a <= 0 || l < 0) return fail(c, MIND_EINVAL, "scene %d has %d agents, %d lanes", b, a, l);
-    total_cols += a + l + 1;
-  }
-  int slot = 0;
-  double pairs_full = 0, pairs_l5 = 0;
-  for (int b = 0; b < Bn; ++b) {
-    const int a = in->actor_off[b + 1] - in->actor_off[b], l = in->lane_off[b + 1] - in->lane_off[b];
-    const int N = a + l + 1;
-    const int tiles = (N + 15) / 16;
-    // split count depends on the scene's own size only, so a scene's result is bit-identical whatever
-    // batch it is collated into (needed for identical AIME node sets when rounds are sharded over GPUs)
-    int ns = (1024 + N - 1) / N;
-    ns = ns < 1 ? 1 : ns;
-    ns = ns > 8 ? 8 : ns;
-    ns = ns > tiles ? tiles : ns;
-    for (int j = 0; j < N; ++j) {
-      TokMeta m;
-      memset(&m, 0, sizeof(m));
-      m.type = j < a ? 0 : (j < a + l ? 1 : 2);
-      m.src = j < a ? in->actor_off[b] + j : (j < a + l ? in->lane_off[b] + (j - a) : 0);
-      m.slot0 = slot;
-      m.nsplit = ns;
-      m.flags = (j < a || j == N - 1) ? 1 : 0;
-      meta.push_back(m);
-      for (int s = 0; s < ns; ++s) {
-        PairJob J;
-        memset(&J, 0, sizeof(J));
-        J.edge_base = edge_pairs;
-        J.N = N;
-        J.j = j;
-        J.t0 = (int)((long long)tiles * s / ns);
-        J.t1 = (int)((long long)tiles * (s + 1) / ns);
-        J.tok_base = ntok;
-        J.slot = slot++;
-        J.flags = m.flags;
-        J.scene = b;
-        jobs.push_back(J);
-      }
-      if (j < a) { actor_row[in->actor_off[b] + j] = ntok + j; actor_scene[in->actor_off[b] + j] = b; }
+  // ---- host tables: tokens, jobs (cached by the batch's scene sizes)
+  std::vector<int> key;
+  key.reserve(2 * Bn + 3);
+  key.push_back(Bn);
+  for (int b = 0; b <= Bn; ++b) key.push_back(in->actor_off[b]);
+  for (int b = 0; b <= Bn; ++b) key.push_back(in->lane_off[b]);
+  const bool tab_hit = key == c->tab_key;
+  int rc;
+  if (!tab_hit) {
+    std::vector<TokMeta> meta;
+    std::vector<PairJob> jobs;
+    std::vector<int> actor_row(A), actor_scene(A), cls_row(Bn);
+    long long edge_pairs = 0;
+    int ntok = 0;
+    for (int b = 0; b < Bn; ++b) {
+      const int a = in->actor_off[b + 1] - in->actor_off[b], l = in->lane_off[b + 1] - in->lane_off[b];
+      if (a <= 0 || l < 0) return fail(c, MIND_EINVAL, "scene %d has %d agents, %d lanes", b, a, l);
     }
-    cls_row[b] = ntok + N - 1;
-    ntok += N;
-    edge_pairs += (long long)N * N;
-    pairs_full += (double)N * N;
-    pairs_l5 += (double)N * (a + 1);
+    int slot = 0;
+    double pairs_full = 0, pairs_l5 = 0;
+    for (int b = 0; b < Bn; ++b) {
+      const int a = in->actor_off[b + 1] - in->actor_off[b], l = in->lane_off[b + 1] - in->lane_off[b];
+      const int N = a + l + 1;
+      const int tiles = (N + 15) / 16;
+      // split count depends on the scene's own size only, so a scene's result is bit-identical whatever
+      // batch it is collated into (needed for identical AIME node sets when rounds are sharded over GPUs)
+      int ns = (1024 + N - 1) / N;
+      ns = ns < 1 ? 1 : ns;
+      ns = ns > 8 ? 8 : ns;
+      ns = ns > tiles ? tiles : ns;
+      for (int j = 0; j < N; ++j) {
+        TokMeta m;
+        memset(&m, 0, sizeof(m));
+        m.type = j < a ? 0 : (j < a + l ? 1 : 2);
+        m.src = j < a ? in->actor_off[b] + j : (j < a + l ? in->lane_off[b] + (j - a) : 0);
+        m.slot0 = slot;
+        m.nsplit = ns;
+        m.flags = (j < a || j == N - 1) ? 1 : 0;
+        meta.push_back(m);
+        for (int s_ = 0; s_ < ns; ++s_) {
+          PairJob J;
+          memset(&J, 0, sizeof(J));
+          J.edge_base = edge_pairs;
+          J.N = N;
+          J.j = j;
+          J.t0 = (int)((long long)tiles * s_ / ns);
+          J.t1 = (int)((long long)tiles * (s_ + 1) / ns);
+          J.tok_base = ntok;
+          J.slot = slot++;
+          J.flags = m.flags;
+          J.scene = b;
+          jobs.push_back(J);
+        }
+        if (j < a) { actor_row[in->actor_off[b] + j] = ntok + j; actor_scene[in->actor_off[b] + j] = b; }
+      }
+      cls_row[b] = ntok + N - 1;
+      ntok += N;
+      edge_pairs += (long long)N * N;
+      pairs_full += (double)N * N;
+      pairs_l5 += (double)N * (a + 1);
+    }
+    c->tab_key.clear();                 // invalid until the upload below has completed
+    if ((rc = ensure(c, c->meta, meta.size() * sizeof(TokMeta)))) return rc;
+    if ((rc = ensure(c, c->jobs, jobs.size() * sizeof(PairJob)))) return rc;
+    if ((rc = ensure(c, c->rows, (size_t)(2 * A + Bn) * sizeof(int)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->meta.p, meta.data(), meta.size() * sizeof(TokMeta), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->jobs.p, jobs.data(), jobs.size() * sizeof(PairJob), hipMemcpyHostToDevice, st));
+    std::vector<int> rows(2 * A + Bn);
+    memcpy(rows.data(), actor_row.data(), A * sizeof(int));
+    memcpy(rows.data() + A, actor_scene.data(), A * sizeof(int));
+    memcpy(rows.data() + 2 * A, cls_row.data(), Bn * sizeof(int));
+    HIPCHK(c, hipMemcpyAsync(c->rows.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    // the host vectors above must outlive the async copies
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->tab_actor_row.swap(actor_row);
+    c->tab_cls_row.swap(cls_row);
+    c->tab_edge_pairs = edge_pairs; c->tab_ntok = ntok; c->tab_slot = slot; c->tab_njobs = (int)jobs.size();
+    c->tab_pairs_full = pairs_full; c->tab_pairs_l5 = pairs_l5;
+    c->tab_key.swap(key);
+  } else {
+    c->n_table_hits++;
   }
-  const int njobs = (int)jobs.size();
+  const std::vector<int> &actor_row = c->tab_actor_row, &cls_row = c->tab_cls_row;
+  const long long edge_pairs = c->tab_edge_pairs;
+  const int ntok = c->tab_ntok, slot = c->tab_slot, njobs = c->tab_njobs;
+  const double pairs_full = c->tab_pairs_full, pairs_l5 = c->tab_pairs_l5;
 
   // ---- workspaces
-  int rc;
   if ((rc = ensure(c, c->edge, (size_t)edge_pairs * 128 * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->x, (size_t)ntok * 128 * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->ST, (size_t)ntok * 256 * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->QK, (size_t)ntok * 1024 * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->part, (size_t)slot * PART_STRIDE * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->tokpos, (size_t)ntok * 4 * sizeof(float)))) return rc;
-  if ((rc = ensure(c, c->meta, meta.size() * sizeof(TokMeta)))) return rc;
-  if ((rc = ensure(c, c->jobs, jobs.size() * sizeof(PairJob)))) return rc;
   if ((rc = ensure(c, c->actor_feat, (size_t)A * 128 * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->lane_feat, (size_t)(Ltot > 0 ? Ltot : 1) * 128 * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->tgt_feat, (size_t)Bn * 128 * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->cmode, (size_t)Bn * 768 * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->tgt_emb, (size_t)Bn * 128 * sizeof(float)))) return rc;
-  if ((rc = ensure(c, c->rows, (size_t)(2 * A + Bn) * sizeof(int)))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->meta.p, meta.data(), meta.size() * sizeof(TokMeta), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->jobs.p, jobs.data(), jobs.size() * sizeof(PairJob), hipMemcpyHostToDevice, st));
-  std::vector<int> rows(2 * A + Bn);
-  memcpy(rows.data(), actor_row.data(), A * sizeof(int));
-  memcpy(rows.data() + A, actor_scene.data(), A * sizeof(int));
-  memcpy(rows.data() + 2 * A, cls_row.data(), Bn * sizeof(int));
-  HIPCHK(c, hipMemcpyAsync(c->rows.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st));
   const float *const *rpe_dev = nullptr;
   if (in->rpe) {
     if ((rc = ensure(c, c->rpe_ptrs, (size_t)Bn * sizeof(float *)))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->rpe_ptrs.p, in->rpe, (size_t)Bn * sizeof(float *), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));          // in->rpe is the caller's host array
     rpe_dev = (const float *const *)c->rpe_ptrs.p;
   }
-  // the host vectors above must outlive the async copies
-  HIPCHK(c, hipStreamSynchronize(st));
 
   const TokMeta *dmeta = (const TokMeta *)c->meta.p;
   const PairJob *djobs = (const PairJob *)c->jobs.p;
@@ -1184,11 +1210,17 @@ extern "C" int mind_aime_world(mind_ctx *c, const mind_world_in *in, const mind_
   int rc;
   if ((rc = ensure(c, c->aime_dev, bS + bI + bC + (size_t)(n_lane > 0 ? n_lane : 1) * 2 * sizeof(float)))) return rc;
   char *base = (char *)c->aime_dev.p;
-  HIPCHK(c, hipMemcpyAsync(base, hs.data(), (size_t)B * sizeof(AimeScene), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(base + bS, ascene.data(), (size_t)A * sizeof(int), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(base + bS + bI, in->cov_last, (size_t)A * sizeof(float), hipMemcpyHostToDevice, st));
-  if (n_lane) HIPCHK(c, hipMemcpyAsync(base + bS + bI + bC, in->target_lane, (size_t)n_lane * 2 * sizeof(float), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipStreamSynchronize(st));     // the staging vectors go out of scope
+  {
+    // one staged host->device copy for the four small tables
+    const size_t tot = bS + bI + bC + (size_t)n_lane * 2 * sizeof(float);
+    std::vector<char> stage(tot, 0);
+    memcpy(stage.data(), hs.data(), (size_t)B * sizeof(AimeScene));
+    memcpy(stage.data() + bS, ascene.data(), (size_t)A * sizeof(int));
+    memcpy(stage.data() + bS + bI, in->cov_last, (size_t)A * sizeof(float));
+    if (n_lane) memcpy(stage.data() + bS + bI + bC, in->target_lane, (size_t)n_lane * 2 * sizeof(float));
+    HIPCHK(c, hipMemcpyAsync(base, stage.data(), tot, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));     // the staging vector goes out of scope
+  }
   hipLaunchKernelGGL(k_aime_world, dim3(A * AIME_K), dim3(64), 0, st, (const AimeScene *)base, (const int *)(base + bS), in->reg, in->vel,
                      in->actor_ctrs, in->actor_vecs, (const float *)(base + bS + bI), out->world, out->topo, out->ego_end,
                      (const float *)(base + bS + bI + bC), n_lane);
@@ -1215,14 +1247,17 @@ extern "C" int mind_aime_rebase(mind_ctx *c, const mind_rebase_in *in, const min
   HIPCHK(c, hipMemcpyAsync(d + o_pos, in->pos, n_pos * sizeof(float), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(d + o_ang, in->ang, n_ang * sizeof(float), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(d + o_vel, in->vel, n_pos * sizeof(float), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d + o_types, in->types, n_types * sizeof(float), hipMemcpyHostToDevice, st));
-  if (in->pad) HIPCHK(c, hipMemcpyAsync(d + o_pad, in->pad, n_pad * sizeof(float), hipMemcpyHostToDevice, st));
+  // the small tables (types | pad | lane anchors | target lane | its info: contiguous in the arena) go in ONE staged copy
+  std::vector<float> small(total - o_types);
+  memcpy(small.data(), in->types, n_types * sizeof(float));
+  if (in->pad) memcpy(small.data() + (o_pad - o_types), in->pad, n_pad * sizeof(float));
   if (l) {
-    HIPCHK(c, hipMemcpyAsync(d + o_lc, in->lane_ctrs, 2 * l * sizeof(float), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d + o_lv, in->lane_vecs, 2 * l * sizeof(float), hipMemcpyHostToDevice, st));
+    memcpy(small.data() + (o_lc - o_types), in->lane_ctrs, 2 * l * sizeof(float));
+    memcpy(small.data() + (o_lv - o_types), in->lane_vecs, 2 * l * sizeof(float));
   }
-  HIPCHK(c, hipMemcpyAsync(d + o_tl, in->target_lane, 2 * P * sizeof(float), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d + o_ti, in->target_lane_info, 12 * P * sizeof(float), hipMemcpyHostToDevice, st));
+  memcpy(small.data() + (o_tl - o_types), in->target_lane, 2 * P * sizeof(float));
+  memcpy(small.data() + (o_ti - o_types), in->target_lane_info, 12 * P * sizeof(float));
+  HIPCHK(c, hipMemcpyAsync(d + o_types, small.data(), small.size() * sizeof(float), hipMemcpyHostToDevice, st));
   RebaseArgs A;
   A.a = (int)a; A.l = (int)l; A.n_lane = (int)P; A.pad_ones = in->pad ? 0 : 1;
   A.pos = d + o_pos; A.ang = d + o_ang; A.vel = d + o_vel; A.types = d + o_types; A.pad = in->pad ? d + o_pad : nullptr;
