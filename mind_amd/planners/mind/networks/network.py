@@ -38,36 +38,7 @@ class ScenePredNet:
     def pre_process(self, data):
         """Host batch dict (collate layout, mind/utils.py:142-168) -> device tensors + offsets."""
         dev = self.rt.device
-        # every host array of the batch goes to the device in ONE copy: packed (64-float aligned) into a page-locked
-        # staging buffer, uploaded, handed out as views
-        pend, total = [], 0
-
-        def g(t):
-            if isinstance(t, torch.Tensor) and t.device == dev:
-                return t.to(torch.float32).contiguous()
-            a = (t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)).astype(np.float32, copy=False)
-            nonlocal total
-            slot = [total, a, None]
-            total += (a.size + 63) // 64 * 64
-            pend.append(slot)
-            return slot
-
-        def flush():
-            if not pend:
-                return
-            pin = getattr(self, "_pin", None)
-            if pin is None or pin.numel() < total:
-                pin = self._pin = torch.empty(max(total + total // 4, 1 << 16), dtype=torch.float32).pin_memory()
-            hv = pin.numpy()
-            for off, a, _ in pend:
-                hv[off:off + a.size] = a.reshape(-1)
-            dv = pin[:total].to(dev)                      # blocking copy from page-locked memory: the buffer is reusable after it
-            for slot in pend:
-                off, a, _ = slot
-                slot[2] = dv[off:off + a.size].view(a.shape)
-
-        def val(x):
-            return x[2] if isinstance(x, list) and len(x) == 3 and isinstance(x[1], np.ndarray) else x
+        g = lambda t: (t if isinstance(t, torch.Tensor) else torch.as_tensor(t)).to(dev, torch.float32, non_blocking=True).contiguous()
         a_off = [0]
         for i in data["ACTOR_IDCS"]:
             a_off.append(a_off[-1] + len(i))
@@ -89,9 +60,6 @@ class ScenePredNet:
             out["lane_feat"] = cache.repeat(B, 1) if B > 1 else cache
         else:
             out["lanes"] = g(data["LANES"])
-        flush()
-        for k, v in list(out.items()):
-            out[k] = [val(r) for r in v] if (k == "rpe" and v is not None) else val(v)
         return out
 
     def __call__(self, d):
