@@ -580,11 +580,16 @@ def main():
         out["gathered_mb_per_plan"] = m["collectives"][1] / args.steps / 1e6
     extras = not args.no_extras and args.workload == "demo_1"
     if extras:
-        # the full cfg4 scenario tree (259 expansions per plan): on one GPU, or planned once by all ranks together
-        t = measure(dist, "cfg4tree", args.tree_steps, 1, world > 1)
-        out["tree_sharded" if world > 1 else "tree"] = dict(summarize(t, prec), workload="cfg4tree: 64 agents x 256 lane polylines, full scripted 6-ary "
-                                                            "depth-4 AIME tree on the real predictor forward", n_gpus=world,
-                                                            scaling="strong" if world > 1 else None, plans_timed=args.tree_steps)
+        # the full cfg4 scenario tree (259 expansions per plan): on one GPU, or planned once by all ranks together.  A failure
+        # here must not cost the headline line (every rank reaches the same except branch or none does: the plan is replicated)
+        key = "tree_sharded" if world > 1 else "tree"
+        try:
+            t = measure(dist, "cfg4tree", args.tree_steps, 1, world > 1)
+            out[key] = dict(summarize(t, prec), workload="cfg4tree: 64 agents x 256 lane polylines, full scripted 6-ary "
+                            "depth-4 AIME tree on the real predictor forward", n_gpus=world,
+                            scaling="strong" if world > 1 else None, plans_timed=args.tree_steps)
+        except Exception as e:       # noqa: BLE001
+            out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             lcl = sim._observation()

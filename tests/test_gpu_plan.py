@@ -302,6 +302,36 @@ def test_four_recorded_scenes_fused_in_one_process_equal_separate_runs(ckpt):
         assert fl.fused.n_scenes >= 3 * (4 + 4)         # branching weights: at least a second round per scene and plan
 
 
+@pytest.mark.parametrize("scene", ["demo_1", "demo_4"])
+def test_aime_tree_does_not_depend_on_the_pair_kernel_arithmetic(scene):
+    """The discrete AIME result (node ids, branch times, chosen tree) of a branching closed loop is the same whether the pair
+    kernel runs on the fp32 MFMA or in its default bf16x3 arithmetic, and the trajectories agree to 1e-4 m: the decisions do
+    not sit on the rounding difference between the two fp32-class modes."""
+    sys.path.insert(0, ROOT)
+    from bench import WORKLOADS, make_closed_loop
+    runs = {}
+    for prec in ("f32", "bf16x3"):
+        pl, sim, w = make_closed_loop(dict(WORKLOADS[scene]), scripted=False, speculative=False, ckpt="formula_branching:20240121")
+        before = pl.network.rt.pair_precision()
+        try:
+            pl.network.rt.set_pair_precision(prec)
+            snaps = []
+            for _ in range(3):
+                sim.run_plans(1)
+                gen = pl.scen_tree_gen
+                nodes = sorted((k, int(n.data.data["END_T"]), bool(n.data.end_flag)) for k, n in gen.tree.nodes.items() if k != "root")
+                st = sim.last_result[0][0]
+                snaps.append((nodes, list(st.nodes.keys()), np.concatenate([st.nodes[k].data[1].ravel() for k in st.nodes]),
+                              np.array(sim.state)))
+            runs[prec] = snaps
+        finally:
+            pl.network.rt.set_pair_precision(before)
+    for a, b in zip(runs["f32"], runs["bf16x3"]):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert np.abs(a[2] - b[2]).max() < 1e-4 + 2 * float(np.spacing(np.float32(np.abs(a[2]).max())))
+        assert np.abs(a[3] - b[3]).max() < 1e-3
+
+
 def _solution_moves_under_rounding_noise(solve, args, xs_ref):
     """Largest displacement of the ego trajectory when the solver inputs are moved by their own rounding resolution:
     agent means by +-1 float32 ulp (4 draws), the initial state by a relative 1e-13 (2 draws)."""
