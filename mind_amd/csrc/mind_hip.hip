@@ -40,6 +40,17 @@ struct WeightBlob {
 
 }  // namespace
 
+// job / token tables of one batch shape (scene sizes), resident on the device
+struct TableSet {
+  std::vector<int> key;               // Bn, actor_off[0..Bn], lane_off[0..Bn]
+  DevBuf meta, jobs, rows;
+  std::vector<int> actor_row, cls_row;
+  long long edge_pairs = 0, stamp = 0;
+  int ntok = 0, slot = 0, njobs = 0;
+  double pairs_full = 0, pairs_l5 = 0;
+};
+#define MIND_TABLE_SETS 8
+
 struct mind_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -59,14 +70,13 @@ struct mind_ctx {
   TokWeights tokW[7];  // [L]: epilogue of layer L-1 (L>=1) + prologue of layer L (L<=5); [0] = init
   const float *WAe[6], *WAp[6], *vtab[6], *rtab = nullptr;
   const u32 *WBe[6], *WBp[6];   // bf16 hi / lo fragments of the same matrices (pair_bf16_kernels.hip)
-  // job / token tables of the last mind_predict_batch: reused (no rebuild, no upload, no synchronisation) when the next
-  // call has the same scene sizes -- the closed loop's root scene every cycle, a full tree's rounds every plan
-  std::vector<int> tab_key;
-  std::vector<int> tab_actor_row, tab_cls_row;
-  long long tab_edge_pairs = 0;
-  int tab_ntok = 0, tab_slot = 0, tab_njobs = 0;
-  double tab_pairs_full = 0, tab_pairs_l5 = 0;
+  // job / token tables of recent mind_predict_batch calls (least-recently-used of MIND_TABLE_SETS): a call whose scene sizes
+  // were seen before rebuilds, uploads and synchronises nothing -- the closed loop's rounds recur every cycle, a full tree's
+  // rounds (1 / 6 / 36 / 216 scenes) every plan
+  TableSet tabs[MIND_TABLE_SETS];
+  long long tab_clock = 0;
   long long n_table_hits = 0;
+  bool xcd_order = true;        // XCD-aware job order for big batches (MIND_XCD_ORDER=0 switches it off, for A/B measurements)
   int pair_prec = 1;            // arithmetic of the pair kernel: 0 = fp32 MFMA, 1 = bf16x3 (split operands, default), 2 = bf16
   // workspaces (grow only)
   DevBuf edge, x, ST, QK, part, tokpos, meta, jobs, actor_feat, lane_feat, tgt_feat, cmode, tgt_emb,
@@ -142,6 +152,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   (void)hipFuncSetAttribute((const void *)k_pair_bf<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_pair_bf<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_pair_bf<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
+  if (const char *xe = getenv("MIND_XCD_ORDER")) c->xcd_order = !(xe[0] == '0');
   if (const char *pe = getenv("MIND_PAIR_PREC")) {
     const std::string v = pe;
     if (v == "f32" || v == "0") c->pair_prec = 0;
@@ -163,6 +174,9 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
                     &c->lane_feat, &c->tgt_feat, &c->cmode, &c->tgt_emb, &c->rows, &c->rpe_ptrs, &c->ilqr_dev, &c->aime_dev, &c->rebase_dev};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
+  for (TableSet &t : c->tabs)
+    for (DevBuf *b : {&t.meta, &t.jobs, &t.rows})
+      if (b->p) (void)hipFree(b->p);
   if (c->wdev) (void)hipFree(c->wdev);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->ev_side) (void)hipEventDestroy(c->ev_side);
@@ -618,7 +632,16 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   key.push_back(Bn);
   for (int b = 0; b <= Bn; ++b) key.push_back(in->actor_off[b]);
   for (int b = 0; b <= Bn; ++b) key.push_back(in->lane_off[b]);
-  const bool tab_hit = key == c->tab_key;
+  TableSet *ts = nullptr;
+  for (TableSet &t : c->tabs)
+    if (t.key == key) ts = &t;
+  const bool tab_hit = ts != nullptr;
+  if (!ts) {
+    ts = &c->tabs[0];
+    for (TableSet &t : c->tabs)
+      if (t.stamp < ts->stamp) ts = &t;         // least recently used (empty sets have stamp 0)
+  }
+  ts->stamp = ++c->tab_clock;
   int rc;
   if (!tab_hit) {
     std::vector<TokMeta> meta;
@@ -673,31 +696,52 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
       pairs_full += (double)N * N;
       pairs_l5 += (double)N * (a + 1);
     }
-    c->tab_key.clear();                 // invalid until the upload below has completed
-    if ((rc = ensure(c, c->meta, meta.size() * sizeof(TokMeta)))) return rc;
-    if ((rc = ensure(c, c->jobs, jobs.size() * sizeof(PairJob)))) return rc;
-    if ((rc = ensure(c, c->rows, (size_t)(2 * A + Bn) * sizeof(int)))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->meta.p, meta.data(), meta.size() * sizeof(TokMeta), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->jobs.p, jobs.data(), jobs.size() * sizeof(PairJob), hipMemcpyHostToDevice, st));
+    // XCD-aware job order for big batches: workgroup b runs on XCD b % 8 and jobs are dealt job -> workgroup job % grid, so
+    // jobs are interleaved such that job index = scene (mod 8): all column jobs of a scene then run on one XCD, whose L2 keeps
+    // that scene's T rows (re-read by every tile of every column; PMC: they missed the per-XCD L2 40 % of the time when a
+    // scene's jobs were spread over all XCDs).  Lanes of unequal length are padded with empty jobs (t0 == t1).
+    {
+      const int grid_ = (int)jobs.size() < c->n_cu ? (int)jobs.size() : c->n_cu;
+      if (c->xcd_order && Bn >= 8 && grid_ % 8 == 0 && (int)jobs.size() >= 4 * grid_) {
+        std::vector<std::vector<PairJob>> lanes(8);
+        for (const PairJob &J : jobs) lanes[J.scene % 8].push_back(J);
+        size_t mx = 0;
+        for (const auto &l_ : lanes) mx = std::max(mx, l_.size());
+        PairJob nullj;
+        memset(&nullj, 0, sizeof(nullj));
+        nullj.N = 1;
+        std::vector<PairJob> re;
+        re.reserve(8 * mx);
+        for (size_t i = 0; i < mx; ++i)
+          for (int x = 0; x < 8; ++x) re.push_back(i < lanes[x].size() ? lanes[x][i] : nullj);
+        jobs.swap(re);
+      }
+    }
+    ts->key.clear();                    // invalid until the upload below has completed
+    if ((rc = ensure(c, ts->meta, meta.size() * sizeof(TokMeta)))) return rc;
+    if ((rc = ensure(c, ts->jobs, jobs.size() * sizeof(PairJob)))) return rc;
+    if ((rc = ensure(c, ts->rows, (size_t)(2 * A + Bn) * sizeof(int)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(ts->meta.p, meta.data(), meta.size() * sizeof(TokMeta), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(ts->jobs.p, jobs.data(), jobs.size() * sizeof(PairJob), hipMemcpyHostToDevice, st));
     std::vector<int> rows(2 * A + Bn);
     memcpy(rows.data(), actor_row.data(), A * sizeof(int));
     memcpy(rows.data() + A, actor_scene.data(), A * sizeof(int));
     memcpy(rows.data() + 2 * A, cls_row.data(), Bn * sizeof(int));
-    HIPCHK(c, hipMemcpyAsync(c->rows.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(ts->rows.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, st));
     // the host vectors above must outlive the async copies
     HIPCHK(c, hipStreamSynchronize(st));
-    c->tab_actor_row.swap(actor_row);
-    c->tab_cls_row.swap(cls_row);
-    c->tab_edge_pairs = edge_pairs; c->tab_ntok = ntok; c->tab_slot = slot; c->tab_njobs = (int)jobs.size();
-    c->tab_pairs_full = pairs_full; c->tab_pairs_l5 = pairs_l5;
-    c->tab_key.swap(key);
+    ts->actor_row.swap(actor_row);
+    ts->cls_row.swap(cls_row);
+    ts->edge_pairs = edge_pairs; ts->ntok = ntok; ts->slot = slot; ts->njobs = (int)jobs.size();
+    ts->pairs_full = pairs_full; ts->pairs_l5 = pairs_l5;
+    ts->key.swap(key);
   } else {
     c->n_table_hits++;
   }
-  const std::vector<int> &actor_row = c->tab_actor_row, &cls_row = c->tab_cls_row;
-  const long long edge_pairs = c->tab_edge_pairs;
-  const int ntok = c->tab_ntok, slot = c->tab_slot, njobs = c->tab_njobs;
-  const double pairs_full = c->tab_pairs_full, pairs_l5 = c->tab_pairs_l5;
+  const std::vector<int> &actor_row = ts->actor_row, &cls_row = ts->cls_row;
+  const long long edge_pairs = ts->edge_pairs;
+  const int ntok = ts->ntok, slot = ts->slot, njobs = ts->njobs;
+  const double pairs_full = ts->pairs_full, pairs_l5 = ts->pairs_l5;
 
   // ---- workspaces
   if ((rc = ensure(c, c->edge, (size_t)edge_pairs * 128 * sizeof(float)))) return rc;
@@ -719,8 +763,8 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
     rpe_dev = (const float *const *)c->rpe_ptrs.p;
   }
 
-  const TokMeta *dmeta = (const TokMeta *)c->meta.p;
-  const PairJob *djobs = (const PairJob *)c->jobs.p;
+  const TokMeta *dmeta = (const TokMeta *)ts->meta.p;
+  const PairJob *djobs = (const PairJob *)ts->jobs.p;
   float *x = (float *)c->x.p, *ST = (float *)c->ST.p, *QK = (float *)c->QK.p, *part = (float *)c->part.p;
   float *edge = (float *)c->edge.p, *tokpos = (float *)c->tokpos.p;
   float *actor_feat = (float *)c->actor_feat.p;
@@ -791,7 +835,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
                        c->tokW[L + 1]);
   }
   // ---- decoder
-  const int *d_actor_row = (const int *)c->rows.p;
+  const int *d_actor_row = (const int *)ts->rows.p;
   const int *d_actor_scene = d_actor_row + A;
   const int *d_cls_row = d_actor_row + 2 * A;
   hipLaunchKernelGGL(k_dec_scene, dim3(Bn), dim3(DT), mind_dec_scene_lds_bytes(), st, x, d_cls_row, (const float *)c->tgt_feat.p, in->tgt_rpe,

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
   for (int job = wave * gridDim.x + blockIdx.x; job < n_jobs; job += gridDim.x * PAIR_WAVES) {
     const PairJob J = jobs[job];
     if (update_mode == 2 && !(J.flags & 1)) continue;
+    if (J.t1 <= J.t0) continue;                  // padding job of the XCD-aware order
     const bool do_update = (update_mode == 0) || (update_mode == 1 && (J.flags & 1));
     const int N = J.N;
     const int j = J.j;
