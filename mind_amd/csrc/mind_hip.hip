@@ -58,7 +58,7 @@ struct mind_ctx {
   // internal side stream: the lane encoders run beside the actor encoder; always fenced against `stream` with
   // events on both sides, so callers only ever see work ordered on `stream`
   hipStream_t side = nullptr;
-  hipEvent_t ev_side = nullptr;
+  hipEvent_t ev_side = nullptr, ev_main = nullptr;
   std::string err;
   // weights
   float *wdev = nullptr;
@@ -144,6 +144,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   c->stream = (hipStream_t)stream;
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
   if (c->side && hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
+  if (c->side && hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   (void)hipFuncSetAttribute((const void *)k_pair<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_lds_bytes());
@@ -180,6 +181,7 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
   if (c->wdev) (void)hipFree(c->wdev);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->ev_side) (void)hipEventDestroy(c->ev_side);
+  if (c->ev_main) (void)hipEventDestroy(c->ev_main);
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -773,6 +775,12 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   // ---- encoders: ActorNet on the context stream, the (independent) lane encoders and token positions beside it on
   //      the side stream (everything they read was complete at the synchronisation point above)
   hipStream_t ss = c->side ? c->side : st;
+  if (c->side) {
+    // the side stream reads inputs the caller produced on the context stream (uploads, mind_aime_rebase outputs): it starts
+    // behind everything queued there so far (a table-cache hit no longer synchronises the stream on the way in)
+    HIPCHK(c, hipEventRecord(c->ev_main, st));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0));
+  }
   hipLaunchKernelGGL(k_actor_net, dim3(A), dim3(AT), mind_actor_lds_bytes(), st, in->actors, A, actor_feat, c->actorW);
   if (!lane_feat) {
     float *lf = out->lane_feat ? out->lane_feat : (float *)c->lane_feat.p;
