@@ -307,3 +307,39 @@ def test_observation_bookkeeping_matches_reference_live():
         for g_, w_ in zip(got[:5], want[:5]):
             w_ = w_.numpy()
             assert g_.dtype == w_.dtype and g_.shape == w_.shape and np.array_equal(g_, w_), frame
+
+
+def test_child_scene_views_equal_the_reference_concatenation():
+    """ChildScene (a kept mode that references its parent's history and a view of its own rows) against the arrays
+    prune_merge builds in the reference (scenario_tree.py:396-412: parent history ++ 60 predicted steps, truncated to
+    seq_len): every accessor the AIME bookkeeping uses -- rows(), window6(), the by-name materialisation, trim() -- for
+    parents of 50 steps (root / re-based nodes) and of another length."""
+    from mind_amd.planners.mind.scenario_tree import ChildScene, hist_len, hist_rows, hist_trim
+    rng = np.random.default_rng(5)
+    for n_hist, L in ((50, 100), (37, 100), (50, 80)):
+        a = 7
+        parent = {"TRAJS_POS_HIST": rng.standard_normal((a, n_hist, 2)).astype(np.float32),
+                  "TRAJS_VEL_HIST": rng.standard_normal((a, n_hist, 2)).astype(np.float32),
+                  "TRAJS_ANG_HIST": rng.standard_normal((a, n_hist)).astype(np.float32),
+                  "TRAJS_COV_HIST": rng.random((a, n_hist, 1)).astype(np.float32)}
+        new = rng.standard_normal((a, 60, 6)).astype(np.float32)
+        want = {"TRAJS_POS_HIST": np.concatenate([parent["TRAJS_POS_HIST"], new[:, :, 0:2]], 1)[:, :L],
+                "TRAJS_VEL_HIST": np.concatenate([parent["TRAJS_VEL_HIST"], new[:, :, 2:4]], 1)[:, :L],
+                "TRAJS_ANG_HIST": np.concatenate([parent["TRAJS_ANG_HIST"], new[:, :, 4]], 1)[:, :L],
+                "TRAJS_COV_HIST": np.concatenate([parent["TRAJS_COV_HIST"], new[:, :, 5:6]], 1)[:, :L]}
+        c = ChildScene({"CUR_T": 0, "END_T": 50}, parent, new, L)
+        assert hist_len(c) == min(n_hist + 60, L) and "TRAJS_POS_HIST" in c and "NOPE" not in c
+        for k, w in want.items():
+            for lo, hi in ((0, 10), (n_hist - 5, n_hist + 7), (n_hist, n_hist + 20), (60, 100), (0, 200)):
+                assert np.array_equal(hist_rows(c, k, lo, hi), w[:, lo:hi]), (k, lo, hi)
+        w6 = c.window6(30, 80)
+        assert np.array_equal(w6[:, :, 0:2], want["TRAJS_POS_HIST"][:, 30:80]) and np.array_equal(w6[:, :, 4], want["TRAJS_ANG_HIST"][:, 30:80])
+        assert np.array_equal(w6[:, :, 5:6], want["TRAJS_COV_HIST"][:, 30:80]) and np.array_equal(w6[:, :, 2:4], want["TRAJS_VEL_HIST"][:, 30:80])
+        for k, w in want.items():                       # by-name access builds exactly the reference's array
+            assert np.array_equal(c[k], w) and c[k].dtype == np.float32
+        hist_trim(c, 72)                                # update_obser's truncation, also of already materialised arrays
+        assert hist_len(c) == min(72, min(n_hist + 60, L))
+        for k, w in want.items():
+            assert np.array_equal(c[k], w[:, :72]) and np.array_equal(hist_rows(c, k, 22, 72), w[:, 22:72])
+        with pytest.raises(KeyError):
+            c["MISSING"]
