@@ -154,6 +154,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   (void)hipFuncSetAttribute((const void *)k_pair_bf<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_pair_bf<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
   if (const char *xe = getenv("MIND_XCD_ORDER")) c->xcd_order = !(xe[0] == '0');
+
   if (const char *pe = getenv("MIND_PAIR_PREC")) {
     const std::string v = pe;
     if (v == "f32" || v == "0") c->pair_prec = 0;
