@@ -100,6 +100,11 @@ int mind_get_pair_precision(mind_ctx *ctx);   /* -> mode, or MIND_EINVAL */
  * out[16384] dwords = [part 2][out block 8][k group 4][lane 64][4] (see pair_bf16_kernels.hip).  Needs no GPU. */
 int mind_debug_pack_bfrag(const float *w, int row_stride, uint32_t *out);
 
+/* host-only helper (tests): the bf16 hi / mid / lo MFMA A-operand packing of one Conv1d weight [co][ci][ksz] (torch layout) for the
+ * ActorNet GEMMs of actor_mfma_kernels.hip: [co/16][k-step][part 3 = hi, mid, lo][lane 64][4] dwords, GEMM index k = tap * ci_pad + ci
+ * (ci_pad = ci rounded up to a power of two >= 16).  Returns the number of dwords written (<= cap) or a negative error. */
+int mind_debug_pack_conv_frag(const float *w, int co, int ci, int ksz, uint32_t *out, size_t cap);
+
 /* Debug taps used by the parity tests only: run just the first n (0..6) fusion layers on the next
  * mind_predict_batch calls, and read internal device buffers ("x", "ST", "QK", "edge", "part",
  * "actor_feat", "tokpos") back to the host.  mind_debug_read returns the number of floats copied (or

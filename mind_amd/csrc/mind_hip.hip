@@ -16,6 +16,7 @@
 #include "encdec_kernels.hip"
 #include "fusion_kernels.hip"
 #include "pair_bf16_kernels.hip"
+#include "actor_mfma_kernels.hip"
 #include "ilqr_kernels.hip"
 #include "aime_kernels.hip"
 
@@ -66,6 +67,7 @@ struct mind_ctx {
   WeightBlob blob;
   LaneW laneW;
   ActorW actorW;
+  AmW actorBW;   // the same convolutions as bf16 hi / lo MFMA fragments (actor_mfma_kernels.hip)
   DecW decW;
   TokWeights tokW[7];  // [L]: epilogue of layer L-1 (L>=1) + prologue of layer L (L<=5); [0] = init
   const float *WAe[6], *WAp[6], *vtab[6], *rtab = nullptr;
@@ -76,6 +78,8 @@ struct mind_ctx {
   TableSet tabs[MIND_TABLE_SETS];
   long long tab_clock = 0;
   long long n_table_hits = 0;
+  int actor_np = 6;             // partial products per term of the MFMA ActorNet under bf16x3: 6 (three-way split, fp32-class) or 3 (MIND_ACTOR_SPLIT=3)
+  bool enc_mfma = true;         // MFMA ActorNet under the bf16x3 / bf16 settings (MIND_ENC_MFMA=0: the fp32 VALU kernel, for A/B)
   bool xcd_order = true;        // XCD-aware job order for big batches (MIND_XCD_ORDER=0 switches it off, for A/B measurements)
   int pair_prec = 1;            // arithmetic of the pair kernel: 0 = fp32 MFMA, 1 = bf16x3 (split operands, default), 2 = bf16
   // workspaces (grow only)
@@ -162,6 +166,11 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
     else if (v == "bf16" || v == "2") c->pair_prec = 2;
   }
   (void)hipFuncSetAttribute((const void *)k_actor_net, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_actor_mfma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_mfma_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_actor_mfma<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_mfma_lds_bytes());
+  if (const char *se = getenv("MIND_ACTOR_SPLIT")) c->actor_np = atoi(se) == 3 ? 3 : 6;
+  (void)hipFuncSetAttribute((const void *)k_actor_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_mfma_lds_bytes());
+  if (const char *me = getenv("MIND_ENC_MFMA")) c->enc_mfma = !(me[0] == '0');
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_actor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
   *out = c;
@@ -340,7 +349,48 @@ std::vector<float> conv_t(const float *w, int co, int ci, int k) {
   return t;
 }
 
+// conv weight [co][ci][k] (torch layout) -> A-operand fragments of v_mfma_f32_16x16x32_bf16 for the GEMM of actor_mfma_kernels.hip:
+// [m-tile co/16][k-step][part hi, mid, lo][lane 64][4 dwords] (w = hi + mid + lo exactly, three bf16 parts); lane (r, q) holds row
+// co = 16 mt + r, k-slots 8 q + (0..7) of the step, dword d = slots 2 d, 2 d + 1; GEMM index k = dk * ci_pad + ci (ci_pad = ci
+// rounded up to a power of two >= 16; zeros beyond).
+std::vector<float> pack_conv_frag(const float *w, int co, int ci, int ksz) {
+  int cp = 16;
+  while (cp < ci) cp *= 2;
+  const int ks = (ksz * cp + 31) / 32, mts = co / 16;
+  std::vector<uint32_t> t((size_t)mts * ks * 768, 0u);
+  if (w)
+    for (int mt = 0; mt < mts; ++mt)
+      for (int s = 0; s < ks; ++s)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int d = 0; d < 4; ++d) {
+            uint32_t part[3] = {0, 0, 0};
+            for (int e = 0; e < 2; ++e) {
+              const int k = s * 32 + 8 * (lane >> 4) + 2 * d + e;
+              const int dk = k / cp, c = k % cp, o = 16 * mt + (lane & 15);
+              float x = (dk < ksz && c < ci) ? w[((size_t)o * ci + c) * ksz + dk] : 0.f;
+              for (int pi = 0; pi < 3; ++pi) {
+                const uint16_t h = bf16_rne(x);
+                part[pi] |= (uint32_t)h << (16 * e);
+                x -= bf16_to_f32(h);
+              }
+            }
+            const size_t base = ((size_t)(mt * ks + s) * 3) * 256 + (size_t)lane * 4 + d;
+            for (int pi = 0; pi < 3; ++pi) t[base + 256 * pi] = part[pi];
+          }
+  std::vector<float> out(t.size());
+  memcpy(out.data(), t.data(), t.size() * sizeof(float));
+  return out;
+}
+
 }  // namespace
+
+extern "C" int mind_debug_pack_conv_frag(const float *w, int co, int ci, int ksz, uint32_t *out, size_t cap) {
+  if (!w || !out || co <= 0 || co % 16 || ci <= 0 || ksz <= 0) return MIND_EINVAL;
+  const std::vector<float> t = pack_conv_frag(w, co, ci, ksz);
+  if (t.size() > cap) return MIND_EINVAL;
+  memcpy(out, t.data(), t.size() * sizeof(float));
+  return (int)t.size();
+}
 
 extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, int n) {
   if (!c || !tensors || n <= 0) return MIND_EINVAL;
@@ -378,12 +428,15 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
       std::string k = "act.r" + std::to_string(ri++);
       B.add(k + ".c1", conv_t(sd.get(p + ".conv1.weight", (int64_t)co * ci * 3), co, ci, 3));
       B.add(k + ".c2", conv_t(sd.get(p + ".conv2.weight", (int64_t)co * co * 3), co, co, 3));
+      B.add(k + ".c1B", pack_conv_frag(sd.get(p + ".conv1.weight", (int64_t)co * ci * 3), co, ci, 3));
+      B.add(k + ".c2B", pack_conv_frag(sd.get(p + ".conv2.weight", (int64_t)co * co * 3), co, co, 3));
       B.add(k + ".g1", vec(sd.get(p + ".bn1.weight", co), co));
       B.add(k + ".b1", vec(sd.get(p + ".bn1.bias", co), co));
       B.add(k + ".g2", vec(sd.get(p + ".bn2.weight", co), co));
       B.add(k + ".b2", vec(sd.get(p + ".bn2.bias", co), co));
       if (ds) {
         B.add(k + ".ds", conv_t(sd.get(p + ".downsample.0.weight", (int64_t)co * ci), co, ci, 1));
+        B.add(k + ".dsB", pack_conv_frag(sd.get(p + ".downsample.0.weight", (int64_t)co * ci), co, ci, 1));
         B.add(k + ".gd", vec(sd.get(p + ".downsample.1.weight", co), co));
         B.add(k + ".bd", vec(sd.get(p + ".downsample.1.bias", co), co));
       }
@@ -397,6 +450,7 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
     for (int g = 0; g < 4; ++g) {
       std::string p = "actor_net.lateral." + std::to_string(g), k = "act.lat" + std::to_string(g);
       B.add(k + ".W", conv_t(sd.get(p + ".conv.weight", (int64_t)128 * chans[g] * 3), 128, chans[g], 3));
+      B.add(k + ".WB", pack_conv_frag(sd.get(p + ".conv.weight", (int64_t)128 * chans[g] * 3), 128, chans[g], 3));
       B.add(k + ".g", vec(sd.get(p + ".norm.weight", 128), 128));
       B.add(k + ".b", vec(sd.get(p + ".norm.bias", 128), 128));
     }
@@ -547,6 +601,18 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
   for (int g = 0; g < 4; ++g) {
     std::string k = "act.lat" + std::to_string(g);
     aw.latW[g] = P(k + ".W"); aw.latG[g] = P(k + ".g"); aw.latB[g] = P(k + ".b");
+  }
+  AmW &bw = c->actorBW;
+  for (int r = 0; r < 9; ++r) {
+    std::string k = "act.r" + std::to_string(r);
+    AmRes &R = bw.res[r];
+    R.c1 = (const u32 *)P(k + ".c1B"); R.c2 = (const u32 *)P(k + ".c2B"); R.ds = (const u32 *)P(k + ".dsB");
+    R.g1 = aw.res[r].g1; R.b1 = aw.res[r].b1; R.g2 = aw.res[r].g2; R.b2 = aw.res[r].b2;
+    R.gd = aw.res[r].gd; R.bd = aw.res[r].bd;
+  }
+  for (int g = 0; g < 4; ++g) {
+    bw.lat[g].w = (const u32 *)P("act.lat" + std::to_string(g) + ".WB");
+    bw.lat[g].g = aw.latG[g]; bw.lat[g].b = aw.latB[g];
   }
   c->rtab = P("fus.rtab");
   for (int L = 0; L < 6; ++L) {
@@ -782,7 +848,16 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
     HIPCHK(c, hipEventRecord(c->ev_main, st));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0));
   }
-  hipLaunchKernelGGL(k_actor_net, dim3(A), dim3(AT), mind_actor_lds_bytes(), st, in->actors, A, actor_feat, c->actorW);
+  // ActorNet: fp32 VALU kernel under MIND_PAIR_F32, the bf16-split / bf16 MFMA kernel otherwise (the precision setting covers
+  // every MFMA contraction of the predictor)
+  if (c->pair_prec == 0 || !c->enc_mfma)
+    hipLaunchKernelGGL(k_actor_net, dim3(A), dim3(AT), mind_actor_lds_bytes(), st, in->actors, A, actor_feat, c->actorW);
+  else if (c->pair_prec == 1 && c->actor_np == 6)
+    hipLaunchKernelGGL(k_actor_mfma<6>, dim3(A), dim3(AM_T), mind_actor_mfma_lds_bytes(), st, in->actors, A, actor_feat, c->actorBW);
+  else if (c->pair_prec == 1)
+    hipLaunchKernelGGL(k_actor_mfma<3>, dim3(A), dim3(AM_T), mind_actor_mfma_lds_bytes(), st, in->actors, A, actor_feat, c->actorBW);
+  else
+    hipLaunchKernelGGL(k_actor_mfma<1>, dim3(A), dim3(AM_T), mind_actor_mfma_lds_bytes(), st, in->actors, A, actor_feat, c->actorBW);
   if (!lane_feat) {
     float *lf = out->lane_feat ? out->lane_feat : (float *)c->lane_feat.p;
     if (Ltot > 0)

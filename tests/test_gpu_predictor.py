@@ -35,6 +35,23 @@ def test_hip_matches_golden(a, l, B, seed, hip_predictor, golden_predictor):
     assert np.abs(vel - g[key + "_vel"]).max() < TOL
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("bf16x3", 5e-5)])
+@pytest.mark.parametrize("a,l,B,seed", [(3, 4, 1, 1), (8, 20, 2, 1), (40, 55, 1, 1)])
+def test_actor_net_tap_by_arithmetic(prec, tol, a, l, B, seed, hip_predictor, golden_predictor):
+    """ActorNet output against the reference's golden tap, 5e-5 absolute on values up to ~4: the fp32 VALU kernel (k_actor_net,
+    "f32") and the MFMA kernel with both operands split into three bf16 parts (k_actor_mfma<6>, the default)."""
+    g = golden_predictor
+    pb = predictor_batch(a, l, B, seed=seed)
+    before = hip_predictor.pair_precision()
+    try:
+        hip_predictor.set_pair_precision(prec)
+        hip_predictor.predict_numpy_batch(pb)
+        af = hip_predictor.debug_read("actor_feat").reshape(-1, 128)
+    finally:
+        hip_predictor.set_pair_precision(before)
+    assert np.abs(af - g[f"a{a}_l{l}_b{B}_s{seed}_actor_net"]).max() < tol
+
+
 @pytest.mark.parametrize("a,l,B,seed", [(1, 1, 1, 5), (5, 1, 2, 5), (16, 15, 3, 2), (17, 30, 3, 4), (33, 64, 2, 6)])
 def test_hip_matches_oracle_ragged_tiles(a, l, B, seed, hip_predictor, formula_sd):
     """N = a+l+1 around the 16-row tile boundary (N=3, 7, 32, 48, 98), multi-scene batches, l=1
