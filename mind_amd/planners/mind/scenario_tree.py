@@ -452,38 +452,42 @@ class ScenarioTreeGenerator:
         root["END_T"] = self.pred_len
         return root
 
-    def _select_modes(self, sc, cls_row, topo_all, ego_end, dis_all=None):
+    def _select_modes(self, sc, cls_row, topo_all, ego_end, dis_all=None, ego_cov=None):
         """Pruning decisions of one scene (scenario_tree.py:293-327, 361-395): probability floor, distance of the
         ego end point to the target lane, greedy merge of modes with the same topology.  cls_row [K] f32,
-        topo_all [a-1,K], ego_end(k) -> (mean [2], cov [1]).  -> [(k, prob)] in visiting order."""
+        topo_all [a-1,K], ego_end(k) -> (mean [2], cov [1]) (or ego_cov [K] with dis_all [K]: every mode's end-point sigma
+        and lane distance at once).  -> [(k, prob)] in visiting order.  Same float32 arithmetic per element as the
+        reference's per-mode loop; the per-pair signature comparisons of the greedy merge are taken in one array op."""
+        K = len(cls_row)
         order = np.argsort(-cls_row, kind="stable")
-        cands = []
-        lane_check = self.target_lane is not None and self.ego_idx is not None
-        if lane_check:       # ego end point of every mode against the target lane, all modes at once
-            ends = [ego_end(int(k)) for k in range(len(cls_row))]
-            if dis_all is None:
-                dis_all = U.get_distances_to_polyline(self.target_lane, np.stack([e[0] for e in ends]).astype(F32, copy=False))
-        for k in order:
-            prob = F32(cls_row[k] * sc["SCEN_PROB"])
-            if prob < F32(0.001):
-                continue
-            if lane_check:
-                if (dis_all[k] - ends[k][1] > self.config.tar_dist_thres).any():
-                    continue
-            cands.append((int(k), prob, topo_all[:, k] if len(topo_all) else np.zeros(0, F32)))
-        # greedy merge of modes whose signatures differ by <= pi/6 for every exo agent
-        thr = F32(np.pi / 6)
-        selected = []
-        while cands:
-            sel = cands[0]
-            selected.append(sel[:2])
-            rest = []
-            for cd in cands[1:]:
-                diff = sel[2] - cd[2]
-                diff = np.arctan2(np.sin(diff), np.cos(diff))
-                if ((np.abs(diff) - thr) > 0).sum() > 0:
-                    rest.append(cd)
-            cands = rest
+        probs = np.asarray(cls_row * sc["SCEN_PROB"]).astype(F32, copy=False)
+        keep = ~(probs < F32(0.001))
+        if self.target_lane is not None and self.ego_idx is not None:
+            # ego end point of every mode against the target lane, all modes at once
+            if ego_cov is None or dis_all is None:
+                ends = [ego_end(int(k)) for k in range(K)]
+                if dis_all is None:
+                    dis_all = U.get_distances_to_polyline(self.target_lane, np.stack([e[0] for e in ends]).astype(F32, copy=False))
+                ego_cov = np.stack([np.asarray(e[1], F32).reshape(-1) for e in ends])          # [K, 1]
+            else:
+                ego_cov = np.asarray(ego_cov, F32).reshape(K, -1)
+            keep &= ~((np.asarray(dis_all)[:, None] - ego_cov) > self.config.tar_dist_thres).any(axis=1)
+        ks = [int(k) for k in order if keep[k]]
+        if not ks:
+            return []
+        if len(ks) == 1:
+            return [(ks[0], probs[ks[0]])]
+        # greedy merge of modes whose signatures differ by <= pi/6 for every exo agent: differ[i][j] for candidate i before j
+        sig = topo_all[:, ks] if len(topo_all) else np.zeros((0, len(ks)), F32)
+        diff = sig[:, :, None] - sig[:, None, :]
+        diff = np.arctan2(np.sin(diff), np.cos(diff))
+        differ = (((np.abs(diff) - F32(np.pi / 6)) > 0).sum(axis=0) > 0).tolist()
+        selected, alive = [], list(range(len(ks)))
+        while alive:
+            i = alive[0]
+            selected.append((ks[i], probs[ks[i]]))
+            row = differ[i]
+            alive = [j for j in alive[1:] if row[j]]
         return selected
 
     def _hdr(self, picks, scenes, idx_offset):
@@ -520,7 +524,8 @@ class ScenarioTreeGenerator:
                     return ego_all[lidx, k, :2], ego_all[lidx, k, 2:3]
                 return sc["TRAJS_POS_HIST"][self.ego_idx][L - 1], sc["TRAJS_COV_HIST"][self.ego_idx][L - 1]
             for k, prob in self._select_modes(sc, cls_all[lidx], topo[a_off[lidx] + 1:a_off[lidx + 1]], ego_end,
-                                              None if dis_round is None else dis_round[lidx]):
+                                              None if dis_round is None else dis_round[lidx],
+                                              None if dis_round is None else ego_all[lidx, :, 2]):
                 picks.append((lidx, k, prob))
         dev = w["world"].device
         if not picks:

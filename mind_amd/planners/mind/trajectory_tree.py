@@ -21,22 +21,25 @@ def flatten_scenario_tree(scen_tree):
     the array indices (creation order of trajectory_tree.py:30-54: stack pop() = last child first)."""
     parent, prob, mean, cov = [], [], [], []
     last = {}
+    count = 0
     stack = [scen_tree.get_root()]
     while stack:
         node = stack.pop()
         p, trajs, covs = node.data[0], node.data[1], node.data[2]
-        li = last[node.parent_key] if node.parent_key is not None else -1
-        steps = np.arange(0, trajs.shape[1], 2)
-        for i in steps:
-            cur = len(parent)
-            parent.append(li)
-            li = cur
-        prob.extend([np.float32(p)] * len(steps))
-        mean.append(np.transpose(trajs[:, steps, :], (1, 0, 2)))
-        cov.append(np.transpose(covs[:, steps, 0], (1, 0)))
-        last[node.key] = len(parent) - 1
+        n = (trajs.shape[1] + 1) // 2                          # every even sub-step -> one trajectory node, chained
+        if n:
+            par = np.arange(count - 1, count + n - 1, dtype=np.int32)
+            par[0] = last[node.parent_key] if node.parent_key is not None else -1
+            parent.append(par)
+            prob.append(np.full(n, p, np.float32))
+            mean.append(np.transpose(trajs[:, ::2, :], (1, 0, 2)))
+            cov.append(np.transpose(covs[:, ::2, 0], (1, 0)))
+            count += n
+            last[node.key] = count - 1
+        else:
+            last[node.key] = last[node.parent_key] if node.parent_key is not None else -1
         stack.extend(scen_tree.get_node(k) for k in node.children_keys)
-    return dict(parent=np.asarray(parent, np.int32), prob=np.asarray(prob, np.float32),
+    return dict(parent=np.concatenate(parent), prob=np.concatenate(prob),
                 mean=np.ascontiguousarray(np.concatenate(mean), np.float32),
                 cov=np.ascontiguousarray(np.concatenate(cov), np.float32))
 
@@ -66,16 +69,35 @@ def ilqr_cfg_from(config, block, max_iter=100):
     return c
 
 
+class _LazyTrajTree(Tree):
+    """Trajectory tree whose Node objects are only created when somebody looks at them (a plan builds one tree per scenario
+    tree and keeps the cheapest: the others are only ever read through ``_arrays`` by evaluate_traj_trees)."""
+
+    def __init__(self, parents, x0, xs, us, action_size):
+        # no Tree.__init__: nodes / root / _leaves appear on first access (__getattr__)
+        self._lazy = (parents, x0, xs, us, action_size)
+        self.n_nodes = len(parents) + 1
+        # node-order arrays for evaluate_traj_tree (root first), so that it does not rebuild them from the nodes
+        self._arrays = (np.concatenate([np.asarray(x0, np.float64)[None], xs]), np.concatenate([np.zeros((1, action_size)), us]))
+
+    def __getattr__(self, name):
+        if name in ("nodes", "root", "_leaves") and "_lazy" in self.__dict__:
+            par, x0, xs, us, action_size = self.__dict__.pop("_lazy")
+            Tree.__init__(self)
+            self.add_node(Node(-1, None, [x0, np.zeros(action_size)]))
+            par = par.tolist()
+            for k in range(len(par)):
+                self.add_node(Node(k, par[k], [xs[k], us[k]]))
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+    def size(self):
+        return self.n_nodes
+
+
 def to_traj_tree(flat, x0, xs, us, action_size=2):
     """root key -1 holds [x0, 0]; node k holds [xs[k], us[k]] (trajectory_tree.py:140-146)."""
-    t = Tree()
-    t.add_node(Node(-1, None, [x0, np.zeros(action_size)]))
-    par = flat["parent"].tolist()
-    for k in range(len(par)):
-        t.add_node(Node(k, par[k], [xs[k], us[k]]))
-    # node-order arrays for evaluate_traj_tree (root first), so that it does not rebuild them from the nodes
-    t._arrays = (np.concatenate([np.asarray(x0, np.float64)[None], xs]), np.concatenate([np.zeros((1, action_size)), us]))
-    return t
+    return _LazyTrajTree(flat["parent"], x0, xs, us, action_size)
 
 
 class _SideContext:

@@ -2,9 +2,9 @@
 
 The lane-level numpy model of v_mfma_f32_16x16x32_bf16 from test_pair_layout.py is driven the way am_conv drives the hardware:
 A operand = the library's own host-side fragment packing of a Conv1d weight (mind_debug_pack_conv_frag, the function
-mind_weights_load uses), B operand = 8 consecutive input channels of one tap read from a time-major [T][C + 4] image (zeros for
-the conv padding, for time columns past Tout and for k-slots past ksz * Cin_pad), tiles enumerated time-fastest and dealt to 8
-waves, the C/D lanes written back as 4 consecutive channels of one time column.  The result must equal torch's conv1d of the
+mind_weights_load uses), B operand = 8 consecutive input channels of one tap read from the time-major image of three bf16
+planes the producing layer wrote (zeros for the conv padding, for time columns past Tout and for k-slots past ksz * Cin_pad),
+tiles enumerated time-fastest, the C/D lanes written back as 4 consecutive channels of one time column.  The result must equal torch's conv1d of the
 same bf16-split values for every layer geometry of the network (network.py:20-61: 14->32 ... 256->256, strides 1 / 2, taps 3 / 1)."""
 import ctypes as C
 
@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from mind_amd import _lib
-from tests.test_pair_layout import from16, mfma_16x16x32, split
+from tests.test_pair_layout import bits16, from16, mfma_16x16x32, split
 
 
 @pytest.fixture(scope="module")
@@ -54,24 +54,29 @@ def am_conv_model(lib, X, W, stride):
     while cp < ci:
         cp *= 2
     lgc = cp.bit_length() - 1
-    LD = cp + 4
+    RSD = 3 * cp // 2 + 4                               # AM_RSD: three bf16 planes of cp channels + 16 bytes pad, in dwords
+    plane = cp // 2
     pad = (ksz - 1) // 2
     KS = (ksz * cp + 31) // 32
-    img = np.full((Tin, LD), np.nan, np.float32)       # pad columns are never read
-    img[:, :cp] = 0.0
-    img[:, :ci] = X.T
+    # the split image the producing layer writes (am_store_split): dword = channels (2 j, 2 j + 1) of one plane
+    Xp = np.zeros((cp, Tin), np.float32)
+    Xp[:ci] = X
+    img = np.full((Tin, RSD), 0xFFFFFFFF, np.uint32)     # pad dwords (NaN patterns) are never read
+    for pi, part in enumerate(split3(Xp)):
+        b = bits16(part.T)                              # [Tin][cp] bf16 bit patterns
+        img[:, pi * plane:(pi + 1) * plane] = b[:, 0::2].astype(np.uint32) | (b[:, 1::2].astype(np.uint32) << 16)
     img = img.reshape(-1)
     packed = pack_conv(lib, W)
     assert packed.size == (co // 16) * KS * 768
     ntt = (Tout + 15) >> 4
     tiles = (co >> 4) * ntt
     out = np.full((Tout, co + 4), np.nan)
-    assert tiles <= 24                                  # AM_MAXT * AM_WAVES
+    assert tiles <= 32                                  # AM_MAXT * AM_WAVES
     for ti in range(tiles):
         mt, nt = divmod(ti, ntt)
         acc = np.zeros((64, 4))
         for ks in range(KS):
-            B = np.zeros((64, 8), np.float32)
+            Bp = np.zeros((3, 64, 8), np.float32)
             for lane in range(64):
                 r, q = lane & 15, lane >> 4
                 t = nt * 16 + r
@@ -79,8 +84,11 @@ def am_conv_model(lib, X, W, stride):
                 dk, c0 = k0 >> lgc, k0 & (cp - 1)
                 row = t * stride + dk - pad
                 if dk < ksz and t < Tout and 0 <= row < Tin:
-                    B[lane] = img[row * LD + c0:row * LD + c0 + 8]
-            bh, bm, bl = split3(B)
+                    for pi in range(3):
+                        d = img[row * RSD + pi * plane + (c0 >> 1):row * RSD + pi * plane + (c0 >> 1) + 4]
+                        Bp[pi, lane, 0::2] = from16((d & 0xffff).astype(np.uint16))
+                        Bp[pi, lane, 1::2] = from16((d >> 16).astype(np.uint16))
+            bh, bm, bl = Bp
             ah, am, al = (frag(packed, KS, mt, ks, p) for p in range(3))
             for x, y in ((ah, bh), (al, bh), (ah, bl), (am, bm), (am, bh), (ah, bm)):
                 acc = mfma_16x16x32(x, y, acc)
