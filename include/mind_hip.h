@@ -166,7 +166,7 @@ int mind_ilqr_contingency(mind_ctx *ctx, const mind_ilqr_cfg *cfg_warm, const mi
  * AIME glue (k7): the arithmetic of ScenarioTreeGenerator.prune_merge (planners/mind/scenario_tree.py:
  * 281-412) that touches every (agent, mode, step) -- world-frame positions / velocities / headings,
  * max-sigma covariances and the topology signatures -- for all scenes of one AIME round, reading the
- * predictor outputs where they already are (device).  The pruning decisions stay on the host.
+ * predictor outputs where they already are (device), and optionally the pruning decisions themselves.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   int n_scenes;
@@ -178,6 +178,12 @@ typedef struct {
   const int32_t *last;        /* HOST [n] index of the last predicted step kept by seq_len (or < 0) */
   const float *target_lane;   /* HOST [n_lane_pts,2] target lane polyline (float32), or NULL            */
   int n_lane_pts;
+  /* optional: the pruning decisions on the device too (needs mind_world_out.sel / sel_prob) */
+  const float *cls;           /* DEVICE [n,6] mode probabilities (mind_pred_out.cls), or NULL                */
+  const float *scen_prob;     /* HOST [n] SCEN_PROB of every scene                                          */
+  int lane_check;             /* 1: drop modes whose ego end point is farther than dist_thres (+ sigma) from the target
+                                 lane (needs target_lane and last >= 0 for every scene)                     */
+  float dist_thres;           /* tar_dist_thres                                                             */
 } mind_world_in;
 
 typedef struct {
@@ -185,6 +191,9 @@ typedef struct {
   float *topo;                /* DEVICE [A,6] winding of (agent - ego of its scene); ego rows = 0   */
   float *ego_end;             /* DEVICE [n,6,4]: ego x, y, max-sigma at step `last` and the distance */
                               /*   of that point to the target lane (if last >= 0; inf without lane) */
+  float *sel, *sel_prob;      /* DEVICE [n,6] or NULL: kept modes of every scene in visiting order (mode index as a    */
+                              /*   float, -1 = none) and their path probabilities: probability floor, target-lane      */
+                              /*   pruning and the greedy topology merge of prune_merge (:293-327, 361-395)            */
 } mind_world_out;
 
 /* asynchronous on the context stream (read the outputs after mind_ctx_synchronize or a stream-ordered copy) */

@@ -44,11 +44,12 @@ class WorldIn(C.Structure):
     _fields_ = [("n_scenes", C.c_int), ("actor_off", C.POINTER(C.c_int32)), ("reg", C.c_void_p), ("vel", C.c_void_p),
                 ("actor_ctrs", C.c_void_p), ("actor_vecs", C.c_void_p), ("rot", C.POINTER(C.c_float)),
                 ("orig", C.POINTER(C.c_float)), ("cov_last", C.POINTER(C.c_float)), ("last", C.POINTER(C.c_int32)),
-                ("target_lane", C.POINTER(C.c_float)), ("n_lane_pts", C.c_int)]
+                ("target_lane", C.POINTER(C.c_float)), ("n_lane_pts", C.c_int), ("cls", C.c_void_p),
+                ("scen_prob", C.POINTER(C.c_float)), ("lane_check", C.c_int), ("dist_thres", C.c_float)]
 
 
 class WorldOut(C.Structure):
-    _fields_ = [("world", C.c_void_p), ("topo", C.c_void_p), ("ego_end", C.c_void_p)]
+    _fields_ = [("world", C.c_void_p), ("topo", C.c_void_p), ("ego_end", C.c_void_p), ("sel", C.c_void_p), ("sel_prob", C.c_void_p)]
 
 
 class RebaseIn(C.Structure):

@@ -99,6 +99,85 @@ __global__ __launch_bounds__(64) void k_aime_world(const AimeScene *__restrict__
 }
 
 // -------------------------------------------------------------------------------------------------
+// Pruning decisions of prune_merge (scenario_tree.py:293-327, 361-395) for every scene of a round, one wave per scene:
+// path probability floor (cls * SCEN_PROB < 1e-3), ego end point against the target lane (distance - max-sigma > threshold),
+// then the greedy merge in descending-probability order of modes whose topology signatures differ by <= pi/6 for every exo
+// agent.  Same float32 expressions as the reference's per-mode loop; the signatures and end points are the ones k_aime_world
+// just wrote.  sel[b][j] = mode index of the j-th kept mode (visiting order) or -1, sel_prob[b][j] its path probability.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_aime_select(const AimeScene *__restrict__ scenes, const float *__restrict__ cls,
+                                                    const float *__restrict__ scen_prob, const float *__restrict__ topo,
+                                                    const float *__restrict__ ego_end, int lane_check, float dist_thres,
+                                                    float *__restrict__ sel, float *__restrict__ sel_prob) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  const AimeScene S = scenes[b];
+  float cl[AIME_K], pr[AIME_K];
+  bool keep[AIME_K];
+  const float sp = scen_prob[b];
+#pragma unroll
+  for (int k = 0; k < AIME_K; ++k) {
+    cl[k] = cls[b * AIME_K + k];
+    pr[k] = cl[k] * sp;
+    keep[k] = !(pr[k] < 0.001f);
+    if (lane_check) {
+      const float *e = ego_end + ((size_t)b * AIME_K + k) * 4;
+      if ((e[3] - e[2]) > dist_thres) keep[k] = false;
+    }
+  }
+  // visiting order: stable argsort of -cls
+  int order[AIME_K];
+#pragma unroll
+  for (int k = 0; k < AIME_K; ++k) {
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < AIME_K; ++j) rank += (cl[j] > cl[k]) || (cl[j] == cl[k] && j < k);
+#pragma unroll
+    for (int j = 0; j < AIME_K; ++j) if (rank == j) order[j] = k;
+  }
+  // differ[k1][k2] (k1 < k2): some exo agent's signatures differ by more than pi/6 -- lanes stride over the agents
+  const float thr = (float)(3.14159265358979323846 / 6.0);
+  unsigned mask = 0;
+  for (int i = S.a0 + 1 + t; i < S.a1; i += 64) {
+    float sg[AIME_K];
+#pragma unroll
+    for (int k = 0; k < AIME_K; ++k) sg[k] = topo[(size_t)i * AIME_K + k];
+    int bit = 0;
+#pragma unroll
+    for (int k1 = 0; k1 < AIME_K; ++k1)
+#pragma unroll
+      for (int k2 = k1 + 1; k2 < AIME_K; ++k2, ++bit) {
+        float d = sg[k1] - sg[k2];
+        d = atan2f(sinf(d), cosf(d));
+        if ((fabsf(d) - thr) > 0.f) mask |= 1u << bit;
+      }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mask |= __shfl_xor(mask, o, 64);
+  if (t != 0) return;
+  // greedy merge over the kept modes in visiting order
+  int alive[AIME_K], na = 0, ns = 0;
+#pragma unroll
+  for (int j = 0; j < AIME_K; ++j)
+    if (keep[order[j]]) alive[na++] = order[j];
+  float *so = sel + (size_t)b * AIME_K, *po = sel_prob + (size_t)b * AIME_K;
+  while (na > 0) {
+    const int k = alive[0];
+    so[ns] = (float)k;
+    po[ns] = pr[k];
+    ++ns;
+    int nn = 0;
+    for (int j = 1; j < na; ++j) {
+      const int k2 = alive[j];
+      const int lo = k < k2 ? k : k2, hi = k < k2 ? k2 : k;
+      const int bit = lo * AIME_K - lo * (lo + 1) / 2 + (hi - lo - 1);     // index of the pair (lo, hi) in the loop above
+      if ((mask >> bit) & 1u) alive[nn++] = k2;
+    }
+    na = nn;
+  }
+  for (; ns < AIME_K; ++ns) { so[ns] = -1.f; po[ns] = 0.f; }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Re-basing of the observation at a branch point (scenario_tree.py:467-567 update_obser, with
 // utils.py:171-190 get_new_lane_graph / get_origin_rotation, :113-134 actor features, scenario_tree.py:
 // 613-652 get_high_level_command, utils.py:193-242 get_rpe): from the last 50 world-frame steps of every

@@ -1333,25 +1333,36 @@ extern "C" int mind_aime_world(mind_ctx *c, const mind_world_in *in, const mind_
   }
   const size_t bS = ((size_t)B * sizeof(AimeScene) + 15) & ~(size_t)15, bI = ((size_t)A * sizeof(int) + 15) & ~(size_t)15;
   const size_t bC = ((size_t)A * sizeof(float) + 15) & ~(size_t)15;
+  const bool select = in->cls && in->scen_prob && out->sel && out->sel_prob;
+  const size_t bP = select ? (((size_t)B * sizeof(float) + 15) & ~(size_t)15) : 0;
   const int n_lane = in->target_lane ? in->n_lane_pts : 0;
   if (in->target_lane && n_lane < 2) return fail(c, MIND_EINVAL, "mind_aime_world: target lane needs >= 2 points");
   int rc;
-  if ((rc = ensure(c, c->aime_dev, bS + bI + bC + (size_t)(n_lane > 0 ? n_lane : 1) * 2 * sizeof(float)))) return rc;
+  if (select && in->lane_check) {
+    if (!n_lane) return fail(c, MIND_EINVAL, "mind_aime_world: lane_check needs the target lane");
+    for (int b = 0; b < B; ++b)
+      if (in->last[b] < 0) return fail(c, MIND_EINVAL, "mind_aime_world: lane_check needs last >= 0 (scene %d)", b);
+  }
+  if ((rc = ensure(c, c->aime_dev, bS + bI + bC + bP + (size_t)(n_lane > 0 ? n_lane : 1) * 2 * sizeof(float)))) return rc;
   char *base = (char *)c->aime_dev.p;
   {
     // one staged host->device copy for the four small tables
-    const size_t tot = bS + bI + bC + (size_t)n_lane * 2 * sizeof(float);
+    const size_t tot = bS + bI + bC + bP + (size_t)n_lane * 2 * sizeof(float);
     std::vector<char> stage(tot, 0);
+    if (select) memcpy(stage.data() + bS + bI + bC, in->scen_prob, (size_t)B * sizeof(float));
     memcpy(stage.data(), hs.data(), (size_t)B * sizeof(AimeScene));
     memcpy(stage.data() + bS, ascene.data(), (size_t)A * sizeof(int));
     memcpy(stage.data() + bS + bI, in->cov_last, (size_t)A * sizeof(float));
-    if (n_lane) memcpy(stage.data() + bS + bI + bC, in->target_lane, (size_t)n_lane * 2 * sizeof(float));
+    if (n_lane) memcpy(stage.data() + bS + bI + bC + bP, in->target_lane, (size_t)n_lane * 2 * sizeof(float));
     HIPCHK(c, hipMemcpyAsync(base, stage.data(), tot, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st));     // the staging vector goes out of scope
   }
   hipLaunchKernelGGL(k_aime_world, dim3(A * AIME_K), dim3(64), 0, st, (const AimeScene *)base, (const int *)(base + bS), in->reg, in->vel,
                      in->actor_ctrs, in->actor_vecs, (const float *)(base + bS + bI), out->world, out->topo, out->ego_end,
-                     (const float *)(base + bS + bI + bC), n_lane);
+                     (const float *)(base + bS + bI + bC + bP), n_lane);
+  if (select)
+    hipLaunchKernelGGL(k_aime_select, dim3(B), dim3(64), 0, st, (const AimeScene *)base, in->cls, (const float *)(base + bS + bI + bC),
+                       out->topo, out->ego_end, in->lane_check ? 1 : 0, in->dist_thres, out->sel, out->sel_prob);
   HIPCHK(c, hipGetLastError());
   return MIND_OK;
 }

@@ -155,6 +155,7 @@ class ScenarioTreeGenerator:
         self.target_lane_info = None
         self.ego_idx = 0
         self.device_glue = True     # prune_merge arithmetic on the device when the network leaves its outputs there
+        self.device_select = True   # ... and its pruning decisions (k_aime_select); False: decided on the host from the device's signatures
         self.branch_depth = 0
         self.n_expanded = 0           # scenes pushed through the predictor (metric: nodes expanded)
         self.shard = None             # mind_amd.parallel.Shard: block-distribute each round's scenes over ranks
@@ -497,18 +498,8 @@ class ScenarioTreeGenerator:
             hdr[r, 3:] = np.asarray(scenes[lidx]["TGT_PTS"], F32).reshape(-1)
         return hdr
 
-    def _prune_select_device(self, scenes, packed, idx_offset):
-        """Pruning decisions with the per-(agent, mode, step) arithmetic on the MI355X (mind_aime_world): the predictor
-        outputs never leave the device; the host reads cls / topology signatures / ego end points (one small copy) and
-        decides; the world-frame rows of the SURVIVING modes are gathered on the device (``rows`` stays there: the caller
-        copies it to the host once, after the multi-GPU exchange if there is one)."""
-        rt, a_off = packed["rt"], packed["a_off"]
-        B, A, L = len(scenes), int(packed["a_off"][-1]), self.seq_len
-        lasts = [L - 1 - sc["TRAJS_POS_HIST"].shape[1] for sc in scenes]
-        w = rt.aime_world(packed["reg"], packed["vel"], packed["actor_ctrs"], packed["actor_vecs"], a_off,
-                          np.stack([sc["ROT"] for sc in scenes]), np.stack([sc["ORIG"] for sc in scenes]),
-                          np.concatenate([sc["TRAJS_COV_HIST"][:, -1, 0] for sc in scenes]), [max(l, -1) for l in lasts],
-                          target_lane=self.target_lane, cls=packed["cls"])
+    def _select_round_host(self, scenes, w, a_off, lasts, B, A, L):
+        """the pruning decisions of a round on the host, from the device's signatures / end points (one small copy)"""
         small = w["small"].cpu().numpy()            # [cls | topology signatures | ego end points], one copy
         cls_all = small[:B * 6].reshape(B, 6)
         topo = small[B * 6:B * 6 + A * 6].reshape(A, 6)
@@ -527,6 +518,32 @@ class ScenarioTreeGenerator:
                                               None if dis_round is None else dis_round[lidx],
                                               None if dis_round is None else ego_all[lidx, :, 2]):
                 picks.append((lidx, k, prob))
+        return picks
+
+    def _prune_select_device(self, scenes, packed, idx_offset):
+        """Pruning decisions with the per-(agent, mode, step) arithmetic on the MI355X (mind_aime_world): the predictor
+        outputs never leave the device; the host reads cls / topology signatures / ego end points (one small copy) and
+        decides; the world-frame rows of the SURVIVING modes are gathered on the device (``rows`` stays there: the caller
+        copies it to the host once, after the multi-GPU exchange if there is one)."""
+        rt, a_off = packed["rt"], packed["a_off"]
+        B, A, L = len(scenes), int(packed["a_off"][-1]), self.seq_len
+        lasts = [L - 1 - sc["TRAJS_POS_HIST"].shape[1] for sc in scenes]
+        lane_check = self.target_lane is not None and self.ego_idx is not None
+        # the decisions themselves on the device too, unless an ego end point lies in the history (then the host decides)
+        dev_select = self.device_select and (not lane_check or all(l >= 0 for l in lasts))
+        w = rt.aime_world(packed["reg"], packed["vel"], packed["actor_ctrs"], packed["actor_vecs"], a_off,
+                          np.stack([sc["ROT"] for sc in scenes]), np.stack([sc["ORIG"] for sc in scenes]),
+                          np.concatenate([sc["TRAJS_COV_HIST"][:, -1, 0] for sc in scenes]), [max(l, -1) for l in lasts],
+                          target_lane=self.target_lane, cls=packed["cls"],
+                          scen_prob=[sc["SCEN_PROB"] for sc in scenes] if dev_select else None,
+                          dist_thres=self.config.tar_dist_thres if (dev_select and lane_check) else None)
+        picks = []
+        if dev_select:
+            sel = w["sel"].cpu().numpy()                # [2, B, 6]: kept modes in visiting order (-1 = none), path probabilities
+            li, ji = np.nonzero(sel[0] >= 0)            # row-major = scene by scene, visiting order within a scene
+            picks = list(zip(li.tolist(), sel[0][li, ji].astype(np.int64).tolist(), sel[1][li, ji]))
+        else:
+            picks = self._select_round_host(scenes, w, a_off, lasts, B, A, L)
         dev = w["world"].device
         if not picks:
             return np.zeros((0, self.HDR), F32), torch.zeros(0, 60, 6, device=dev)

@@ -291,11 +291,15 @@ class HipPredictor:
         luu[:, 0, 0], luu[:, 1, 1] = out[:, 45], out[:, 46]
         return dict(l=out[:, 0].copy(), l_x=out[:, 1:7].copy(), l_u=out[:, 7:9].copy(), l_xx=out[:, 9:45].reshape(-1, 6, 6).copy(), l_uu=luu)
 
-    def aime_world(self, reg, vel, actor_ctrs, actor_vecs, a_off, rots, origs, cov_last, last, target_lane=None, cls=None):
+    def aime_world(self, reg, vel, actor_ctrs, actor_vecs, a_off, rots, origs, cov_last, last, target_lane=None, cls=None,
+                   scen_prob=None, dist_thres=None):
         """k7 on the device (mind_aime_world): reg [A,6,60,5] / vel [A,6,60,2] / actor_ctrs, actor_vecs [A,2] device
         tensors; a_off [B+1]; rots [B,2,2], origs [B,2], cov_last [A] host float32; last [B] int.
         target_lane [P,2] float32 (optional).  Returns device tensors world [A,6,60,6] (x,y,vx,vy,heading,max-sigma),
-        topo [A,6], ego_end [B,6,4] (ego x, y, max-sigma at step `last`, distance of that point to the target lane)."""
+        topo [A,6], ego_end [B,6,4] (ego x, y, max-sigma at step `last`, distance of that point to the target lane).
+        With ``cls`` [B,6] (device) and ``scen_prob`` [B] the pruning decisions are taken on the device as well (k_aime_select):
+        ``sel`` [2,B,6] = (mode index or -1, path probability) of the kept modes in visiting order; ``dist_thres`` switches the
+        target-lane test on (needs target_lane and last >= 0 everywhere)."""
         dev = self.device
         B, A = len(a_off) - 1, int(a_off[-1])
         for t_ in (reg, vel, actor_ctrs, actor_vecs):
@@ -323,6 +327,16 @@ class HipPredictor:
         out = dict(world=torch.empty(A, 6, 60, 6, device=dev), small=small, topo=small[B * 6:B * 6 + A * 6].view(A, 6),
                    ego_end=small[B * 6 + A * 6:].view(B, 6, 4))
         wo.world, wo.topo, wo.ego_end = (C.c_void_p(out[k].data_ptr()) for k in ("world", "topo", "ego_end"))
+        if cls is not None and scen_prob is not None:
+            cls = cls.contiguous()
+            assert cls.device == dev and cls.dtype == torch.float32 and cls.numel() == B * 6
+            out["_cls"] = cls                       # keeps the (possibly fresh) buffer alive until the kernel ran
+            sp = np.ascontiguousarray(scen_prob, np.float32).reshape(B)
+            out["sel"] = torch.empty(2, B, 6, device=dev)
+            wi.cls, wi.scen_prob = C.c_void_p(cls.data_ptr()), fp(sp)
+            wi.lane_check = int(dist_thres is not None)
+            wi.dist_thres = float(dist_thres) if dist_thres is not None else 0.0
+            wo.sel, wo.sel_prob = C.c_void_p(out["sel"][0].data_ptr()), C.c_void_p(out["sel"][1].data_ptr())
         rc = self.lib.mind_aime_world(self.ctx, C.byref(wi), C.byref(wo))
         _lib.check(self.lib, self.ctx, rc, "mind_aime_world")
         return out

@@ -167,3 +167,61 @@ def test_devscene_lazily_materialises_host_inputs():
     assert np.abs(sc["TGT_RPE"] - sc.dev["tgt_rpe"][sc.g].cpu().numpy()).max() < 2e-5
     batch = gen.collate([sc])                                  # the host collate path accepts the scene
     assert batch["ACTORS"].shape == (a, 14, 48) and batch["TGT_NODES"].shape == (1, 10, 16)
+
+
+@pytest.mark.parametrize("lane_on", [True, False])
+def test_device_pruning_decisions_equal_the_host_decisions(hip_predictor, lane_on):
+    """k_aime_select (probability floor, target-lane test, greedy topology merge on the device) against _select_modes (the host
+    restatement of scenario_tree.py:293-327, 361-395, pinned by tests/golden/aime.npz) on the SAME signatures / end points, over
+    many random scenes: near-duplicate modes that merge, modes under the probability floor, end points around the lane
+    threshold, ego-only scenes, ties in cls."""
+    from types import SimpleNamespace
+    rng = np.random.default_rng(11 + lane_on)
+    B = 40
+    counts = rng.integers(1, 14, B)
+    counts[3] = 1
+    a_off = np.concatenate([[0], np.cumsum(counts)]).astype(int)
+    A = int(a_off[-1])
+    t = np.arange(1, 61, dtype=F32) * F32(0.1)
+    reg = np.zeros((A, 6, 60, 5), F32)
+    base = rng.uniform(2, 9, (A, 1, 1)).astype(F32)
+    curv = rng.normal(0, 2.0, (A, 6, 1)).astype(F32)
+    curv[:, 1] = curv[:, 0] + rng.normal(0, 1e-3, (A, 1)).astype(F32)       # mode 1 ~ mode 0: merges
+    curv[:, 4] = curv[:, 2]                                                   # exact duplicates
+    reg[..., 0] = (base + rng.normal(0, 0.3, (A, 6, 1)).astype(F32)) * t
+    reg[..., 1] = curv * (t / 6) ** 2
+    reg[..., 2:4] = rng.uniform(0.1, 1.0, (A, 6, 60, 2))
+    vel = rng.normal(0, 3.0, (A, 6, 60, 2)).astype(F32)
+    ctrs = rng.uniform(-30, 30, (A, 2)).astype(F32)
+    th = rng.uniform(-np.pi, np.pi, A)
+    vecs = np.stack([np.cos(th), np.sin(th)], -1).astype(F32)
+    rots = np.stack([U.rot2(F32(x)) for x in rng.uniform(-3, 3, B)])
+    origs = rng.uniform(-5, 5, (B, 2)).astype(F32)
+    ctrs[a_off[:-1]] = rng.uniform(-3, 3, (B, 2)).astype(F32)                 # ego rows: end points 0 .. ~55 m off the lane (y = 0)
+    cov_last = rng.uniform(1e-5, 0.5, A).astype(F32)
+    last = [59] * B
+    cls = rng.dirichlet(np.full(6, 0.4), B).astype(F32)
+    cls[5, :] = F32(1.0 / 6.0)                                               # all tied: stable order decides
+    cls[6, 2] = cls[6, 3]
+    scen_prob = rng.choice([1.0, 0.5, 0.02, 0.004], B).astype(F32)
+    lane = (np.stack([np.linspace(-80, 80, 200), np.zeros(200)], -1) + rng.normal(0, 0.05, (200, 2))).astype(F32)
+    dev = hip_predictor.device
+    g = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    thres = 20.0
+    w = hip_predictor.aime_world(g(reg), g(vel), g(ctrs), g(vecs), a_off, rots, origs, cov_last, last,
+                                 target_lane=lane if lane_on else None, cls=g(cls), scen_prob=scen_prob,
+                                 dist_thres=thres if lane_on else None)
+    sel = w["sel"].cpu().numpy()
+    stg = STG.__new__(STG)
+    stg.target_lane = lane if lane_on else None
+    stg.ego_idx = 0
+    stg.config = SimpleNamespace(tar_dist_thres=thres)
+    scenes = [{"SCEN_PROB": F32(p)} for p in scen_prob]
+    want = stg._select_round_host(scenes, w, a_off, last, B, A, 110)
+    got = [(b, int(sel[0, b, j]), sel[1, b, j]) for b in range(B) for j in range(6) if sel[0, b, j] >= 0]
+    assert [(b, k) for b, k, _ in got] == [(b, k) for b, k, _ in want]
+    assert all(np.float32(p) == np.float32(q) for (_, _, p), (_, _, q) in zip(got, want))       # same float32 product
+    n_kept = np.array([sum(1 for b, _, _ in got if b == i) for i in range(B)])
+    assert (n_kept < 6).any() and (n_kept > 1).any()                          # merging and pruning both happened
+    for b in range(B):                                                        # the tail of every row is -1
+        assert (sel[0, b, n_kept[b]:] == -1).all()
