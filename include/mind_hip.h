@@ -95,6 +95,13 @@ int mind_set_profiling(mind_ctx *ctx, int enable);
 #define MIND_PAIR_BF16X3 1
 #define MIND_PAIR_BF16 2
 int mind_set_pair_precision(mind_ctx *ctx, int mode);
+
+/* Kernel-selection knobs (A/B measurements and tests; the defaults are the measured winners, the results are the same within the
+ * arithmetic's accuracy): "dec_mfma_min" (agents per call from which the decoder's actor part uses the MFMA kernel; default: never),
+ * "enc_mfma" (0: the fp32 VALU ActorNet / decoder kernels under every precision), "actor_split" (6: three-way operand split,
+ * fp32-class; 3: two-way), "xcd_order" (XCD-aware job order of the pair kernel).  Environment: MIND_DEC_MFMA_MIN, MIND_ENC_MFMA,
+ * MIND_ACTOR_SPLIT, MIND_XCD_ORDER at context creation. */
+int mind_set_tuning(mind_ctx *ctx, const char *name, int value);
 int mind_get_pair_precision(mind_ctx *ctx);   /* -> mode, or MIND_EINVAL */
 /* host-only helper (tests): the bf16 hi / lo MFMA fragment packing of one [128][row_stride] weight matrix,
  * out[16384] dwords = [part 2][out block 8][k group 4][lane 64][4] (see pair_bf16_kernels.hip).  Needs no GPU. */

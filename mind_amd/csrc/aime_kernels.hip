@@ -124,55 +124,65 @@ __global__ __launch_bounds__(64) void k_aime_select(const AimeScene *__restrict_
       if ((e[3] - e[2]) > dist_thres) keep[k] = false;
     }
   }
-  // visiting order: stable argsort of -cls
-  int order[AIME_K];
+  // visiting rank of every mode: stable argsort of -cls
+  int rank[AIME_K];
 #pragma unroll
   for (int k = 0; k < AIME_K; ++k) {
-    int rank = 0;
+    rank[k] = 0;
 #pragma unroll
-    for (int j = 0; j < AIME_K; ++j) rank += (cl[j] > cl[k]) || (cl[j] == cl[k] && j < k);
-#pragma unroll
-    for (int j = 0; j < AIME_K; ++j) if (rank == j) order[j] = k;
+    for (int j = 0; j < AIME_K; ++j) rank[k] += (cl[j] > cl[k]) || (cl[j] == cl[k] && j < k);
   }
-  // differ[k1][k2] (k1 < k2): some exo agent's signatures differ by more than pi/6 -- lanes stride over the agents
+  // differ bit (k1, k2), k1 < k2: some exo agent's signatures differ by more than pi/6 (angle difference wrapped to (-pi, pi]:
+  // d - 2 pi rint(d / 2 pi), within 1e-6 of the reference's atan2(sin d, cos d)) -- lanes stride over the agents
   const float thr = (float)(3.14159265358979323846 / 6.0);
   unsigned mask = 0;
   for (int i = S.a0 + 1 + t; i < S.a1; i += 64) {
     float sg[AIME_K];
 #pragma unroll
     for (int k = 0; k < AIME_K; ++k) sg[k] = topo[(size_t)i * AIME_K + k];
-    int bit = 0;
 #pragma unroll
     for (int k1 = 0; k1 < AIME_K; ++k1)
 #pragma unroll
-      for (int k2 = k1 + 1; k2 < AIME_K; ++k2, ++bit) {
+      for (int k2 = k1 + 1; k2 < AIME_K; ++k2) {
         float d = sg[k1] - sg[k2];
-        d = atan2f(sinf(d), cosf(d));
-        if ((fabsf(d) - thr) > 0.f) mask |= 1u << bit;
+        d = d - 6.28318530717958647692f * rintf(d * 0.15915494309189533577f);
+        if ((fabsf(d) - thr) > 0.f) mask |= 1u << (k1 * AIME_K + k2);
       }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mask |= __shfl_xor(mask, o, 64);
   if (t != 0) return;
-  // greedy merge over the kept modes in visiting order
-  int alive[AIME_K], na = 0, ns = 0;
+  // greedy merge over the kept modes in visiting order, all state in bit masks (no indexed arrays): the next selected mode is the
+  // alive one of lowest rank; the modes that stay alive are those that differ from it
+  unsigned alive = 0;
 #pragma unroll
-  for (int j = 0; j < AIME_K; ++j)
-    if (keep[order[j]]) alive[na++] = order[j];
+  for (int k = 0; k < AIME_K; ++k) alive |= keep[k] ? 1u << k : 0u;
   float *so = sel + (size_t)b * AIME_K, *po = sel_prob + (size_t)b * AIME_K;
-  while (na > 0) {
-    const int k = alive[0];
-    so[ns] = (float)k;
-    po[ns] = pr[k];
-    ++ns;
-    int nn = 0;
-    for (int j = 1; j < na; ++j) {
-      const int k2 = alive[j];
-      const int lo = k < k2 ? k : k2, hi = k < k2 ? k2 : k;
-      const int bit = lo * AIME_K - lo * (lo + 1) / 2 + (hi - lo - 1);     // index of the pair (lo, hi) in the loop above
-      if ((mask >> bit) & 1u) alive[nn++] = k2;
+  int ns = 0;
+#pragma unroll
+  for (int it = 0; it < AIME_K; ++it) {
+    int best = -1, brank = AIME_K;
+    float bp = 0.f;
+    unsigned brow = 0;
+#pragma unroll
+    for (int k = 0; k < AIME_K; ++k)
+      if (((alive >> k) & 1u) && rank[k] < brank) {
+        best = k; brank = rank[k]; bp = pr[k];
+        // symmetric row of the pair matrix for mode k: bit j set <=> (k, j) differ
+        unsigned row = 0;
+#pragma unroll
+        for (int j = 0; j < AIME_K; ++j) {
+          const int lo = k < j ? k : j, hi = k < j ? j : k;
+          if (j != k && ((mask >> (lo * AIME_K + hi)) & 1u)) row |= 1u << j;
+        }
+        brow = row;
+      }
+    if (best >= 0) {
+      so[ns] = (float)best;
+      po[ns] = bp;
+      ++ns;
+      alive &= brow;            // drops the selected mode itself (its own bit is 0) and everything merged into it
     }
-    na = nn;
   }
   for (; ns < AIME_K; ++ns) { so[ns] = -1.f; po[ns] = 0.f; }
 }

@@ -17,6 +17,7 @@
 #include "fusion_kernels.hip"
 #include "pair_bf16_kernels.hip"
 #include "actor_mfma_kernels.hip"
+#include "dec_mfma_kernels.hip"
 #include "ilqr_kernels.hip"
 #include "aime_kernels.hip"
 
@@ -67,6 +68,7 @@ struct mind_ctx {
   WeightBlob blob;
   LaneW laneW;
   ActorW actorW;
+  DmW decBW;     // actor part of the decoder, same packing (dec_mfma_kernels.hip)
   AmW actorBW;   // the same convolutions as bf16 hi / lo MFMA fragments (actor_mfma_kernels.hip)
   DecW decW;
   TokWeights tokW[7];  // [L]: epilogue of layer L-1 (L>=1) + prologue of layer L (L<=5); [0] = init
@@ -79,6 +81,7 @@ struct mind_ctx {
   long long tab_clock = 0;
   long long n_table_hits = 0;
   int actor_np = 6;             // partial products per term of the MFMA ActorNet under bf16x3: 6 (three-way split, fp32-class) or 3 (MIND_ACTOR_SPLIT=3)
+  int dec_mfma_min = 1 << 30;   // agents per call from which the decoder's actor part runs on the MFMA kernel (MIND_DEC_MFMA_MIN; default: never)
   bool enc_mfma = true;         // MFMA ActorNet under the bf16x3 / bf16 settings (MIND_ENC_MFMA=0: the fp32 VALU kernel, for A/B)
   bool xcd_order = true;        // XCD-aware job order for big batches (MIND_XCD_ORDER=0 switches it off, for A/B measurements)
   int pair_prec = 1;            // arithmetic of the pair kernel: 0 = fp32 MFMA, 1 = bf16x3 (split operands, default), 2 = bf16
@@ -168,9 +171,13 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   (void)hipFuncSetAttribute((const void *)k_actor_net, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_actor_mfma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_mfma_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_actor_mfma<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_mfma_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_dec_actor_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_mfma_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_dec_actor_mfma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_mfma_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_dec_actor_mfma<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_mfma_lds_bytes());
   if (const char *se = getenv("MIND_ACTOR_SPLIT")) c->actor_np = atoi(se) == 3 ? 3 : 6;
   (void)hipFuncSetAttribute((const void *)k_actor_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_mfma_lds_bytes());
   if (const char *me = getenv("MIND_ENC_MFMA")) c->enc_mfma = !(me[0] == '0');
+  if (const char *de = getenv("MIND_DEC_MFMA_MIN")) c->dec_mfma_min = atoi(de);
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_actor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
   *out = c;
@@ -203,6 +210,17 @@ extern "C" const char *mind_last_error_string(mind_ctx *c) { return c ? c->err.c
 extern "C" int mind_ctx_synchronize(mind_ctx *c) {
   if (!c) return MIND_EINVAL;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MIND_OK;
+}
+
+extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
+  if (!c || !name) return MIND_EINVAL;
+  const std::string n = name;
+  if (n == "dec_mfma_min") c->dec_mfma_min = value;
+  else if (n == "enc_mfma") c->enc_mfma = value != 0;
+  else if (n == "actor_split") c->actor_np = value == 3 ? 3 : 6;
+  else if (n == "xcd_order") c->xcd_order = value != 0;
+  else return fail(c, MIND_EINVAL, "mind_set_tuning: unknown knob '%s'", name);
   return MIND_OK;
 }
 
@@ -353,10 +371,11 @@ std::vector<float> conv_t(const float *w, int co, int ci, int k) {
 // [m-tile co/16][k-step][part hi, mid, lo][lane 64][4 dwords] (w = hi + mid + lo exactly, three bf16 parts); lane (r, q) holds row
 // co = 16 mt + r, k-slots 8 q + (0..7) of the step, dword d = slots 2 d, 2 d + 1; GEMM index k = dk * ci_pad + ci (ci_pad = ci
 // rounded up to a power of two >= 16; zeros beyond).
-std::vector<float> pack_conv_frag(const float *w, int co, int ci, int ksz) {
+std::vector<float> pack_conv_frag(const float *w, int co, int ci, int ksz, int cp_force = 0, int co_pad = 0) {
   int cp = 16;
   while (cp < ci) cp *= 2;
-  const int ks = (ksz * cp + 31) / 32, mts = co / 16;
+  if (cp_force) cp = cp_force;     // Linear layers: ci itself (a multiple of 32); co_pad: output rows rounded up to 16 (zero rows)
+  const int ks = (ksz * cp + 31) / 32, mts = (co_pad > co ? co_pad : co) / 16;
   std::vector<uint32_t> t((size_t)mts * ks * 768, 0u);
   if (w)
     for (int mt = 0; mt < mts; ++mt)
@@ -367,7 +386,7 @@ std::vector<float> pack_conv_frag(const float *w, int co, int ci, int ksz) {
             for (int e = 0; e < 2; ++e) {
               const int k = s * 32 + 8 * (lane >> 4) + 2 * d + e;
               const int dk = k / cp, c = k % cp, o = 16 * mt + (lane & 15);
-              float x = (dk < ksz && c < ci) ? w[((size_t)o * ci + c) * ksz + dk] : 0.f;
+              float x = (dk < ksz && c < ci && o < co) ? w[((size_t)o * ci + c) * ksz + dk] : 0.f;
               for (int pi = 0; pi < 3; ++pi) {
                 const uint16_t h = bf16_rne(x);
                 part[pi] |= (uint32_t)h << (16 * e);
@@ -533,6 +552,16 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
   lin_ln("dec.c3", "pred_scene.ctx_proj", 3, 768, 384);
   lin_ln("dec.a0", "pred_scene.actor_proj", 0, 384, 128);
   lin_ln("dec.a3", "pred_scene.actor_proj", 3, 768, 384);
+  B.add("dec.a0.WB", pack_conv_frag(sd.get("pred_scene.actor_proj.0.weight", 384 * 128), 384, 128, 1, 128));
+  B.add("dec.a3.WB", pack_conv_frag(sd.get("pred_scene.actor_proj.3.weight", 768 * 384), 768, 384, 1, 384));
+  B.add("dec.reg0.WB", pack_conv_frag(sd.get("pred_scene.reg.0.weight", 128 * 128), 128, 128, 1, 128));
+  B.add("dec.reg3.WB", pack_conv_frag(sd.get("pred_scene.reg.3.weight", 128 * 128), 128, 128, 1, 128));
+  B.add("dec.reg6.WB", pack_conv_frag(sd.get("pred_scene.reg.6.weight", 40 * 128), 40, 128, 1, 128, 48));
+  {
+    std::vector<float> b6 = vec(sd.get("pred_scene.reg.6.bias", 40), 40);
+    b6.resize(48, 0.f);
+    B.add("dec.reg6.bB", b6);
+  }
   for (int L = 0; L < 2; ++L) {
     std::string p = "pred_scene.ctx_sat.layers." + std::to_string(L), k = "dec.e" + std::to_string(L);
     B.add(k + ".inW", transpose(sd.get(p + ".self_attn.in_proj_weight", 384 * 128), 384, 128));
@@ -661,6 +690,12 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
   d.r3W = P("dec.reg3.W"); d.r3b = P("dec.reg3.b"); d.r3g = P("dec.reg3.g"); d.r3be = P("dec.reg3.be");
   d.r6W = P("dec.reg6.W"); d.r6b = P("dec.reg6.b");
   d.T = P("dec.T"); d.Tp = P("dec.Tp");
+  DmW &m = c->decBW;
+  m.a0 = (const u32 *)P("dec.a0.WB"); m.a3 = (const u32 *)P("dec.a3.WB"); m.r0 = (const u32 *)P("dec.reg0.WB");
+  m.r3 = (const u32 *)P("dec.reg3.WB"); m.r6 = (const u32 *)P("dec.reg6.WB");
+  m.a0b = d.a0b; m.a0g = d.a0g; m.a0be = d.a0be; m.a3b = d.a3b; m.a3g = d.a3g; m.a3be = d.a3be;
+  m.r0b = d.r0b; m.r0g = d.r0g; m.r0be = d.r0be; m.r3b = d.r3b; m.r3g = d.r3g; m.r3be = d.r3be; m.r6b = P("dec.reg6.bB");
+  m.T = d.T; m.Tp = d.Tp;
   c->have_weights = true;
   return MIND_OK;
 }
@@ -924,8 +959,21 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   const int *d_cls_row = d_actor_row + 2 * A;
   hipLaunchKernelGGL(k_dec_scene, dim3(Bn), dim3(DT), mind_dec_scene_lds_bytes(), st, x, d_cls_row, (const float *)c->tgt_feat.p, in->tgt_rpe,
                      (float *)c->cmode.p, (float *)c->tgt_emb.p, out->cls, c->decW);
-  hipLaunchKernelGGL(k_dec_actor, dim3((A + RA - 1) / RA), dim3(DT), mind_dec_actor_lds_bytes(), st, x, d_actor_row, d_actor_scene, A,
-                     (const float *)c->cmode.p, (const float *)c->tgt_emb.p, out->reg, out->vel, c->decW);
+  // actor part of the decoder: the K-split fp32 kernel (a handful of workgroups, bound by the latency of one pass over the weights:
+  // 62 us at 40 agents), or -- opt-in, mind_set_tuning("dec_mfma_min") -- the MFMA kernel (16 agents per workgroup: 104 us at 40
+  // agents, 209 vs 277 us at 13.8 k).  Off by default: a plan's result must not depend on what else is in the batch.
+  if (c->pair_prec == 0 || !c->enc_mfma || A < c->dec_mfma_min)
+    hipLaunchKernelGGL(k_dec_actor, dim3((A + RA - 1) / RA), dim3(DT), mind_dec_actor_lds_bytes(), st, x, d_actor_row, d_actor_scene, A,
+                       (const float *)c->cmode.p, (const float *)c->tgt_emb.p, out->reg, out->vel, c->decW);
+  else if (c->pair_prec == 1 && c->actor_np == 6)
+    hipLaunchKernelGGL(k_dec_actor_mfma<6>, dim3((A + DM_RA - 1) / DM_RA), dim3(DM_T), mind_dec_actor_mfma_lds_bytes(), st, x, d_actor_row,
+                       d_actor_scene, A, (const float *)c->cmode.p, (const float *)c->tgt_emb.p, out->reg, out->vel, c->decBW);
+  else if (c->pair_prec == 1)
+    hipLaunchKernelGGL(k_dec_actor_mfma<3>, dim3((A + DM_RA - 1) / DM_RA), dim3(DM_T), mind_dec_actor_mfma_lds_bytes(), st, x, d_actor_row,
+                       d_actor_scene, A, (const float *)c->cmode.p, (const float *)c->tgt_emb.p, out->reg, out->vel, c->decBW);
+  else
+    hipLaunchKernelGGL(k_dec_actor_mfma<1>, dim3((A + DM_RA - 1) / DM_RA), dim3(DM_T), mind_dec_actor_mfma_lds_bytes(), st, x, d_actor_row,
+                       d_actor_scene, A, (const float *)c->cmode.p, (const float *)c->tgt_emb.p, out->reg, out->vel, c->decBW);
   if (out->actor_emb || out->cls_emb) {
     // debug taps: gather fused tokens
     for (int a = 0; a < A && out->actor_emb; ++a)

@@ -114,6 +114,10 @@ class HipPredictor:
         """arithmetic of the pair kernel: 'f32' | 'bf16x3' (default) | 'bf16' (include/mind_hip.h)"""
         return self.PAIR_PREC[self.lib.mind_get_pair_precision(self.ctx)]
 
+    def set_tuning(self, name, value):
+        """kernel-selection knobs of include/mind_hip.h (mind_set_tuning): dec_mfma_min, enc_mfma, actor_split, xcd_order"""
+        _lib.check(self.lib, self.ctx, self.lib.mind_set_tuning(self.ctx, name.encode(), int(value)), "mind_set_tuning")
+
     def set_pair_precision(self, name):
         _lib.check(self.lib, self.ctx, self.lib.mind_set_pair_precision(self.ctx, self.PAIR_PREC.index(name)), "mind_set_pair_precision")
 

@@ -179,3 +179,24 @@ def test_plain_bf16_mode_error_is_reported(hip_predictor, formula_sd):
         assert np.abs(out["cls"].cpu().numpy()[0] - oc[0].numpy()[0]).max() < 5e-3
         worst = max(worst, err)
     assert worst > 1e-5          # it really ran in reduced precision
+
+
+@pytest.mark.parametrize("a,l,B,seed", [(3, 4, 1, 1), (17, 30, 3, 4), (40, 55, 1, 1), (64, 256, 1, 21)])
+def test_decoder_actor_part_on_the_mfma_kernel(a, l, B, seed, hip_predictor, formula_sd):
+    """k_dec_actor_mfma (actor_proj / reg head GEMMs on the bf16 MFMA with three-way split operands; opt-in:
+    mind_set_tuning) switched on at small and ragged sizes (3, 51, 40, 64 agents: partial 16-agent workgroups) against the oracle, and
+    against the fp32 VALU kernel it replaces."""
+    pb = predictor_batch(a, l, B, seed=seed)
+    oc, orr, ov = op.forward(formula_sd, to_t(pb))
+    ref = hip_predictor.predict_numpy_batch(pb)
+    try:
+        hip_predictor.set_tuning("dec_mfma_min", 0)
+        out = hip_predictor.predict_numpy_batch(pb)
+    finally:
+        hip_predictor.set_tuning("dec_mfma_min", 1 << 30)
+    reg, vel = out["reg"].cpu().numpy(), out["vel"].cpu().numpy()
+    for b in range(B):
+        assert np.abs(reg[b * a:(b + 1) * a] - orr[b].numpy()).max() < TOL
+        assert np.abs(vel[b * a:(b + 1) * a] - ov[b].numpy()).max() < TOL
+    assert (out["reg"] - ref["reg"]).abs().max().item() < 5e-5
+    assert not torch.equal(out["reg"], ref["reg"])          # it really was the other kernel
