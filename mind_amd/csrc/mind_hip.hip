@@ -60,7 +60,9 @@ struct mind_ctx {
   // internal side stream: the lane encoders run beside the actor encoder; always fenced against `stream` with
   // events on both sides, so callers only ever see work ordered on `stream`
   hipStream_t side = nullptr;
-  hipEvent_t ev_side = nullptr, ev_main = nullptr;
+  hipEvent_t ev_side = nullptr, ev_main = nullptr, ev_stage = nullptr;
+  std::vector<char> aime_stage;   // host staging of mind_aime_world's small tables (guarded by ev_stage)
+  bool aime_stage_busy = false;
   std::string err;
   // weights
   float *wdev = nullptr;
@@ -152,6 +154,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
   if (c->side && hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
   if (c->side && hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
+  if (hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming) != hipSuccess) { *out = nullptr; delete c; return MIND_EHIP; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   (void)hipFuncSetAttribute((const void *)k_pair<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_lds_bytes());
@@ -199,6 +202,7 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->ev_side) (void)hipEventDestroy(c->ev_side);
   if (c->ev_main) (void)hipEventDestroy(c->ev_main);
+  if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1395,15 +1399,20 @@ extern "C" int mind_aime_world(mind_ctx *c, const mind_world_in *in, const mind_
   char *base = (char *)c->aime_dev.p;
   {
     // one staged host->device copy for the four small tables
+    // (the staging buffer lives in the context and is guarded by an event: the copy is queued behind the predictor's kernels and
+    // the host goes on to queue k_aime_world / k_aime_select without waiting for them)
     const size_t tot = bS + bI + bC + bP + (size_t)n_lane * 2 * sizeof(float);
-    std::vector<char> stage(tot, 0);
+    if (c->aime_stage_busy) { HIPCHK(c, hipEventSynchronize(c->ev_stage)); c->aime_stage_busy = false; }
+    std::vector<char> &stage = c->aime_stage;
+    stage.assign(tot, 0);
     if (select) memcpy(stage.data() + bS + bI + bC, in->scen_prob, (size_t)B * sizeof(float));
     memcpy(stage.data(), hs.data(), (size_t)B * sizeof(AimeScene));
     memcpy(stage.data() + bS, ascene.data(), (size_t)A * sizeof(int));
     memcpy(stage.data() + bS + bI, in->cov_last, (size_t)A * sizeof(float));
     if (n_lane) memcpy(stage.data() + bS + bI + bC + bP, in->target_lane, (size_t)n_lane * 2 * sizeof(float));
     HIPCHK(c, hipMemcpyAsync(base, stage.data(), tot, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));     // the staging vector goes out of scope
+    HIPCHK(c, hipEventRecord(c->ev_stage, st));
+    c->aime_stage_busy = true;
   }
   hipLaunchKernelGGL(k_aime_world, dim3(A * AIME_K), dim3(64), 0, st, (const AimeScene *)base, (const int *)(base + bS), in->reg, in->vel,
                      in->actor_ctrs, in->actor_vecs, (const float *)(base + bS + bI), out->world, out->topo, out->ego_end,

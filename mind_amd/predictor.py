@@ -325,9 +325,12 @@ class HipPredictor:
             tl = np.ascontiguousarray(target_lane, np.float32).reshape(-1, 2)
             wi.target_lane, wi.n_lane_pts = fp(tl), len(tl)
         # topo and ego_end live in one buffer behind a copy of cls, so that the host fetches all three with one copy
-        small = torch.zeros(B * 6 + A * 6 + B * 24, device=dev)
-        if cls is not None:
-            small[:B * 6] = cls.reshape(-1)
+        if cls is not None and scen_prob is not None:
+            small = torch.empty(B * 6 + A * 6 + B * 24, device=dev)     # the host only reads `sel`
+        else:
+            small = torch.zeros(B * 6 + A * 6 + B * 24, device=dev)
+            if cls is not None:
+                small[:B * 6] = cls.reshape(-1)
         out = dict(world=torch.empty(A, 6, 60, 6, device=dev), small=small, topo=small[B * 6:B * 6 + A * 6].view(A, 6),
                    ego_end=small[B * 6 + A * 6:].view(B, 6, 4))
         wo.world, wo.topo, wo.ego_end = (C.c_void_p(out[k].data_ptr()) for k in ("world", "topo", "ego_end"))

@@ -217,7 +217,10 @@ def test_device_pruning_decisions_equal_the_host_decisions(hip_predictor, lane_o
     stg.ego_idx = 0
     stg.config = SimpleNamespace(tar_dist_thres=thres)
     scenes = [{"SCEN_PROB": F32(p)} for p in scen_prob]
-    want = stg._select_round_host(scenes, w, a_off, last, B, A, 110)
+    w_host = hip_predictor.aime_world(g(reg), g(vel), g(ctrs), g(vecs), a_off, rots, origs, cov_last, last,
+                                      target_lane=lane if lane_on else None, cls=g(cls))     # round-1 interface: no decisions
+    assert torch.equal(w_host["topo"], w["topo"]) and torch.equal(w_host["world"], w["world"])
+    want = stg._select_round_host(scenes, w_host, a_off, last, B, A, 110)
     got = [(b, int(sel[0, b, j]), sel[1, b, j]) for b in range(B) for j in range(6) if sel[0, b, j] >= 0]
     assert [(b, k) for b, k, _ in got] == [(b, k) for b, k, _ in want]
     assert all(np.float32(p) == np.float32(q) for (_, _, p), (_, _, q) in zip(got, want))       # same float32 product
