@@ -28,6 +28,15 @@ wrap(rt, "predict", "rt.predict(launch)"); wrap(rt, "aime_world", "rt.aime_world
 wrap(gen, "create_nodes"); wrap(gen, "decide_branch"); wrap(gen, "update_obser_batch"); wrap(gen, "get_scenario_tree")
 wrap(rt, "ilqr_contingency"); wrap(opt, "solve_batch"); wrap(pl, "evaluate_traj_trees"); wrap(pl, "update_observation")
 wrap(sim, "_observation", "sim._observation"); wrap(gen, "prepare_root_data"); wrap(gen, "_select_modes")
+import mind_amd.planners.mind.trajectory_tree as TT
+import mind_amd.predictor as PR
+wrap(TT, "flatten_scenario_tree"); wrap(TT, "to_traj_tree"); wrap(TT, "ilqr_cfg_from")
+wrap(PR.IlqrCall, "__init__", "IlqrCall.__init__"); wrap(PR.IlqrCall, "run", "IlqrCall.run (C call: prep + kernel + copies)"); wrap(PR.IlqrCall, "finish", "IlqrCall.finish")
+wrap(opt, "_take_speculation")
+import mind_amd.planners.mind.utils as UU
+for fn in ("get_agent_trajectories", "normalize_agents", "lane_graph_from_map", "lane_features", "actor_features"):
+    if hasattr(UU, fn): wrap(UU, fn, "U." + fn)
+wrap(gen, "_scene_inputs"); wrap(gen, "get_branch_times"); wrap(gen, "_prune_select_device"); wrap(gen, "_hdr")
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 t0 = time.perf_counter()
 sim.run_plans(n)
