@@ -1174,18 +1174,22 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     for (int d = 0; d <= maxsd; ++d) tl[t].maxls = std::max(tl[t].maxls, sl_start[t][d + 1] - sl_start[t][d]);
     tl[t].sstart = takeI(nseg + 1); tl[t].snodes = takeI(M); tl[t].slstart = takeI(maxsd + 2); tl[t].slsegs = takeI(nseg);
   }
-  const size_t bytesD = nd * sizeof(double), bytesF = nf * sizeof(float), bytesI = ni * sizeof(int);
-  const size_t o_structs = bytesD + bytesF + bytesI;
-  // generic mode: the materialised fields go behind the structs, copied straight from the caller's arrays
+  // arena: [uploaded doubles (nd_in) | floats | ints | tree structs | constants] = ONE host->device copy, then the doubles the
+  // kernels produce (workspace + results), then (generic mode) the materialised fields
+  const size_t bytesIn = nd_in * sizeof(double), bytesF = nf * sizeof(float), bytesI = ni * sizeof(int);
+  const size_t o_structs = bytesIn + bytesF + bytesI;
   const size_t o_consts = (o_structs + (size_t)n_trees * sizeof(IlqrTreeDev) + 15) & ~(size_t)15;
-  size_t total = (o_consts + 2 * sizeof(IlqrConst) + 15) & ~(size_t)15;
+  const size_t o_work = (o_consts + 2 * sizeof(IlqrConst) + 15) & ~(size_t)15;
+  size_t total = (o_work + (nd - nd_in) * sizeof(double) + 15) & ~(size_t)15;
   for (int t = 0; t < n_trees && gen; ++t) { tl[t].field = total; total += (size_t)tl[t].M * W * H * sizeof(double); }
   int rc;
   if ((rc = ensure(c, c->ilqr_dev, total))) return rc;
   char *base = (char *)c->ilqr_dev.p;
-  double *dD = (double *)base;
-  float *dF = (float *)(base + bytesD);
-  int *dI = (int *)(base + bytesD + bytesF);
+  double *dD = (double *)base;                 // uploaded doubles: offsets < nd_in
+  double *dW = (double *)(base + o_work);      // produced doubles: offsets >= nd_in
+  auto Dp = [&](size_t o) -> double * { return o < nd_in ? dD + o : dW + (o - nd_in); };
+  float *dF = (float *)(base + bytesIn);
+  int *dI = (int *)(base + bytesIn + bytesF);
   // host staging of the read-only part
   std::vector<double> hD(nd_in, 0.0);
   std::vector<float> hF(nf, 0.f);
@@ -1225,21 +1229,17 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     D.parent = dI + L.parent; D.level_start = dI + L.lstart; D.level_nodes = dI + L.lnodes;
     D.child_start = dI + L.cstart; D.child_list = dI + L.clist;
     D.rel = dI + L.rel;
-    D.relag = dD + L.relag;
+    D.relag = Dp(L.relag);
     D.field = gen ? (const double *)(base + L.field) : nullptr;
-    D.node_w = gen ? dD + L.nodew : nullptr;
+    D.node_w = gen ? Dp(L.nodew) : nullptr;
     D.n_segs = L.nseg; D.n_slevels = L.nsl; D.max_level_segs = L.maxls; D.pad2 = 0;
     D.seg_start = dI + L.sstart; D.seg_nodes = dI + L.snodes; D.slevel_start = dI + L.slstart; D.slevel_segs = dI + L.slsegs;
     D.prob = dF + L.prob; D.mean = dF + L.mean; D.cov = dF + L.cov;
-    D.xs = dD + L.xs; D.us = dD + L.us; D.Fx = dD + L.Fx; D.L = dD + L.L; D.Lx = dD + L.Lx; D.Lxx = dD + L.Lxx;
-    D.k = dD + L.k; D.K = dD + L.K; D.Vx = dD + L.Vx; D.Vxx = dD + L.Vxx;
-    D.xs_new = dD + L.xsn; D.us_new = dD + L.usn; D.L_new = dD + L.Ln; D.stats = dD + L.stats;
+    D.xs = Dp(L.xs); D.us = Dp(L.us); D.Fx = Dp(L.Fx); D.L = Dp(L.L); D.Lx = Dp(L.Lx); D.Lxx = Dp(L.Lxx);
+    D.k = Dp(L.k); D.K = Dp(L.K); D.Vx = Dp(L.Vx); D.Vxx = Dp(L.Vxx);
+    D.xs_new = Dp(L.xsn); D.us_new = Dp(L.usn); D.L_new = Dp(L.Ln); D.stats = Dp(L.stats);
     moff += (long)M;
   }
-  HIPCHK(c, hipMemcpyAsync(dD, hD.data(), nd_in * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(dF, hF.data(), bytesF, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(dI, hI.data(), bytesI, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(base + o_structs, hT.data(), (size_t)n_trees * sizeof(IlqrTreeDev), hipMemcpyHostToDevice, st));
   for (int t = 0; t < n_trees && gen; ++t)
     HIPCHK(c, hipMemcpyAsync(base + tl[t].field, trees[t].field, (size_t)tl[t].M * W * H * sizeof(double), hipMemcpyHostToDevice, st));
   IlqrConst K;
@@ -1252,7 +1252,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   K.res = grid_res; K.off_x = offx; K.off_y = offy; K.target_vel = target_vel;
   K.W = W; K.H = H; K.max_iter = cfg->max_iter; K.use_exo = use_exo_first;
   for (int j = 0; j < IL_NA; ++j) K.alphas[j] = std::pow(1.1, -(double)(j * j));
-  K.gx = dD + o_gx; K.gy = dD + o_gy; K.quad = dD + o_quad;
+  K.gx = Dp(o_gx); K.gy = Dp(o_gy); K.quad = Dp(o_quad);
   // cell centres are computed in the kernels when the grid is the numpy linspace (always in the planner mode)
   K.stepx = fsx / (double)(W - 1); K.stepy = fsy / (double)(H - 1); K.fsx = fsx; K.fsy = fsy;
   K.lin = 1;
@@ -1274,20 +1274,32 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
         cfg2->grid_h != cfg->grid_h)
       return fail(c, MIND_EINVAL, "mind_ilqr_contingency: both configurations must share dt / wheelbase / grid");
   }
-  HIPCHK(c, hipMemcpyAsync(base + o_consts, K2, 2 * sizeof(IlqrConst), hipMemcpyHostToDevice, st));
+  // one staged copy of everything the host provides (`up` lives until the stream has been synchronised below)
+  std::vector<char> up(o_work, 0);
+  {
+    memcpy(up.data(), hD.data(), bytesIn);
+    if (bytesF) memcpy(up.data() + bytesIn, hF.data(), bytesF);
+    if (bytesI) memcpy(up.data() + bytesIn + bytesF, hI.data(), bytesI);
+    memcpy(up.data() + o_structs, hT.data(), (size_t)n_trees * sizeof(IlqrTreeDev));
+    memcpy(up.data() + o_consts, K2, 2 * sizeof(IlqrConst));
+    HIPCHK(c, hipMemcpyAsync(base, up.data(), o_work, hipMemcpyHostToDevice, st));
+  }
   const IlqrConst *dK = (const IlqrConst *)(base + o_consts);
-  if (!gen) hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, K.gx.p, K.gy.p, W, H, dD + o_lane, n_lane_pts, dD + o_quad);
+  if (!gen) hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, K.gx.p, K.gy.p, W, H, Dp(o_lane), n_lane_pts, Dp(o_quad));
   int amax = 1;
   for (int t = 0; t < n_trees; ++t) amax = tl[t].a > amax ? tl[t].a : amax;
   const IlqrTreeDev *dT = (const IlqrTreeDev *)(base + o_structs);
-  c->il_dbg[0] = tl[0].L * 8; c->il_dbg[1] = tl[0].Lx * 8; c->il_dbg[2] = tl[0].Lxx * 8; c->il_dbg[3] = tl[0].Fx * 8; c->il_dbg[4] = tl[0].xs * 8;
+  {
+    auto off = [&](size_t o) { return (size_t)((const char *)Dp(o) - base); };
+    c->il_dbg[0] = off(tl[0].L); c->il_dbg[1] = off(tl[0].Lx); c->il_dbg[2] = off(tl[0].Lxx); c->il_dbg[3] = off(tl[0].Fx); c->il_dbg[4] = off(tl[0].xs);
+  }
   c->il_dbg[5] = (size_t)tl[0].M;
   if (ev) {
     const size_t lds = (IL_SCR + (size_t)4 * amax) * sizeof(double);
-    if (gen) hipLaunchKernelGGL(k_cost_eval<true>, dim3(ev->nq), dim3(64), lds, st, dT, K, ev->nq, dI + o_evn, dD + o_evx, dD + o_evu, dD + o_evo);
-    else hipLaunchKernelGGL(k_cost_eval<false>, dim3(ev->nq), dim3(64), lds, st, dT, K, ev->nq, dI + o_evn, dD + o_evx, dD + o_evu, dD + o_evo);
+    if (gen) hipLaunchKernelGGL(k_cost_eval<true>, dim3(ev->nq), dim3(64), lds, st, dT, K, ev->nq, dI + o_evn, Dp(o_evx), Dp(o_evu), Dp(o_evo));
+    else hipLaunchKernelGGL(k_cost_eval<false>, dim3(ev->nq), dim3(64), lds, st, dT, K, ev->nq, dI + o_evn, Dp(o_evx), Dp(o_evu), Dp(o_evo));
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(ev->out, dD + o_evo, (size_t)ev->nq * IL_EVAL_OUT * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(ev->out, Dp(o_evo), (size_t)ev->nq * IL_EVAL_OUT * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     return MIND_OK;
   }
@@ -1301,10 +1313,14 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   }
   HIPCHK(c, hipGetLastError());
   std::vector<double> hs((size_t)2 * IL_NSTAT * n_trees);
-  HIPCHK(c, hipMemcpyAsync(xs, dD + tl[0].xs, (size_t)Mtot * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(us, dD + tl[0].us, (size_t)Mtot * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(hs.data(), dD + tl[0].stats, hs.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  // xs of all trees and, right behind them, the stats of all trees: one copy; us lives in the uploaded region
+  const size_t n_xs = (size_t)(tl[0].stats - tl[0].xs);
+  std::vector<double> hx(n_xs + hs.size());
+  HIPCHK(c, hipMemcpyAsync(hx.data(), Dp(tl[0].xs), hx.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(us, Dp(tl[0].us), (size_t)Mtot * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
+  memcpy(xs, hx.data(), (size_t)Mtot * 6 * sizeof(double));
+  memcpy(hs.data(), hx.data() + n_xs, hs.size() * sizeof(double));
   for (int ph = 0; ph < n_phases; ++ph) {
     mind_ilqr_stats *so = ph == 0 ? stats : stats2;
     if (!so) continue;
@@ -1440,20 +1456,30 @@ extern "C" int mind_aime_rebase(mind_ctx *c, const mind_rebase_in *in, const min
   int rc;
   if ((rc = ensure(c, c->rebase_dev, total * sizeof(float)))) return rc;
   float *d = (float *)c->rebase_dev.p;
-  HIPCHK(c, hipMemcpyAsync(d + o_pos, in->pos, n_pos * sizeof(float), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d + o_ang, in->ang, n_ang * sizeof(float), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d + o_vel, in->vel, n_pos * sizeof(float), hipMemcpyHostToDevice, st));
-  // the small tables (types | pad | lane anchors | target lane | its info: contiguous in the arena) go in ONE staged copy
-  std::vector<float> small(total - o_types);
-  memcpy(small.data(), in->types, n_types * sizeof(float));
-  if (in->pad) memcpy(small.data() + (o_pad - o_types), in->pad, n_pad * sizeof(float));
-  if (l) {
-    memcpy(small.data() + (o_lc - o_types), in->lane_ctrs, 2 * l * sizeof(float));
-    memcpy(small.data() + (o_lv - o_types), in->lane_vecs, 2 * l * sizeof(float));
+  // the arena is contiguous: small rounds (a few child scenes) go in ONE staged copy; big ones (cfg4: 80 MB of windows) copy the
+  // three window arrays straight from the caller's memory and stage only the small tables (types | pad | lane anchors | target
+  // lane | its info)
+  const bool one_copy = total * sizeof(float) <= ((size_t)1 << 20);
+  const size_t s0 = one_copy ? 0 : o_types;
+  std::vector<float> small(total - s0);
+  if (one_copy) {
+    memcpy(small.data() + o_pos, in->pos, n_pos * sizeof(float));
+    memcpy(small.data() + o_ang, in->ang, n_ang * sizeof(float));
+    memcpy(small.data() + o_vel, in->vel, n_pos * sizeof(float));
+  } else {
+    HIPCHK(c, hipMemcpyAsync(d + o_pos, in->pos, n_pos * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d + o_ang, in->ang, n_ang * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d + o_vel, in->vel, n_pos * sizeof(float), hipMemcpyHostToDevice, st));
   }
-  memcpy(small.data() + (o_tl - o_types), in->target_lane, 2 * P * sizeof(float));
-  memcpy(small.data() + (o_ti - o_types), in->target_lane_info, 12 * P * sizeof(float));
-  HIPCHK(c, hipMemcpyAsync(d + o_types, small.data(), small.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  memcpy(small.data() + (o_types - s0), in->types, n_types * sizeof(float));
+  if (in->pad) memcpy(small.data() + (o_pad - s0), in->pad, n_pad * sizeof(float));
+  if (l) {
+    memcpy(small.data() + (o_lc - s0), in->lane_ctrs, 2 * l * sizeof(float));
+    memcpy(small.data() + (o_lv - s0), in->lane_vecs, 2 * l * sizeof(float));
+  }
+  memcpy(small.data() + (o_tl - s0), in->target_lane, 2 * P * sizeof(float));
+  memcpy(small.data() + (o_ti - s0), in->target_lane_info, 12 * P * sizeof(float));
+  HIPCHK(c, hipMemcpyAsync(d + s0, small.data(), small.size() * sizeof(float), hipMemcpyHostToDevice, st));
   RebaseArgs A;
   A.a = (int)a; A.l = (int)l; A.n_lane = (int)P; A.pad_ones = in->pad ? 0 : 1;
   A.pos = d + o_pos; A.ang = d + o_ang; A.vel = d + o_vel; A.types = d + o_types; A.pad = in->pad ? d + o_pad : nullptr;

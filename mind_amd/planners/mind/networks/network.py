@@ -38,29 +38,57 @@ class ScenePredNet:
     def pre_process(self, data):
         """Host batch dict (collate layout, mind/utils.py:142-168) -> device tensors + offsets."""
         dev = self.rt.device
-        g = lambda t: (t if isinstance(t, torch.Tensor) else torch.as_tensor(t)).to(dev, torch.float32, non_blocking=True).contiguous()
         a_off = [0]
         for i in data["ACTOR_IDCS"]:
             a_off.append(a_off[-1] + len(i))
         l_off = [0]
         for i in data["LANE_IDCS"]:
             l_off.append(l_off[-1] + len(i))
-        out = {"actors": g(data["ACTORS"]), "a_off": a_off, "l_off": l_off, "tgt_nodes": g(data["TGT_NODES"]),
-               "tgt_rpe": g(data["TGT_RPE"]), "lanes": None, "lane_feat": None, "rpe": None,
-               "lane_shared": bool(data.get("LANE_SHARED", False))}
-        if "ACTOR_CTRS" in data:
-            out.update(actor_ctrs=g(data["ACTOR_CTRS"]), actor_vecs=g(data["ACTOR_VECS"]),
-                       lane_ctrs=g(data["LANE_CTRS"]), lane_vecs=g(data["LANE_VECS"]))
-        else:   # reference-style input: precomputed RPE tensors only
-            out.update(actor_ctrs=None, actor_vecs=None, lane_ctrs=None, lane_vecs=None)
-            out["rpe"] = [g(r["scene"] if isinstance(r, dict) else r) for r in data["RPE"]]
-        cache = data.get("LANE_FEAT_CACHE")
         B = len(a_off) - 1
-        if cache is not None and out["lane_shared"] and cache.shape[0] * B == l_off[-1]:
+        cache = data.get("LANE_FEAT_CACHE")
+        lane_shared = bool(data.get("LANE_SHARED", False))
+        use_cache = cache is not None and lane_shared and cache.shape[0] * B == l_off[-1]
+        want = {"actors": data["ACTORS"], "tgt_nodes": data["TGT_NODES"], "tgt_rpe": data["TGT_RPE"]}
+        if "ACTOR_CTRS" in data:
+            want.update(actor_ctrs=data["ACTOR_CTRS"], actor_vecs=data["ACTOR_VECS"], lane_ctrs=data["LANE_CTRS"],
+                        lane_vecs=data["LANE_VECS"])
+        if not use_cache:
+            want["lanes"] = data["LANES"]
+        out = {"a_off": a_off, "l_off": l_off, "lanes": None, "lane_feat": None, "rpe": None, "lane_shared": lane_shared,
+               "actor_ctrs": None, "actor_vecs": None, "lane_ctrs": None, "lane_vecs": None}
+        out.update(self._upload(want, dev))
+        if "ACTOR_CTRS" not in data:   # reference-style input: precomputed RPE tensors only
+            g = lambda t: (t if isinstance(t, torch.Tensor) else torch.as_tensor(t)).to(dev, torch.float32, non_blocking=True).contiguous()
+            out["rpe"] = [g(r["scene"] if isinstance(r, dict) else r) for r in data["RPE"]]
+        if use_cache:
             out["lane_feat"] = cache.repeat(B, 1) if B > 1 else cache
-        else:
-            out["lanes"] = g(data["LANES"])
         return out
+
+    @staticmethod
+    def _upload(want, dev):
+        """host arrays -> device float32 tensors through ONE packed host->device copy (every array starts on a 256-byte
+        boundary of the packed buffer); tensors already on the device are passed through"""
+        res, host = {}, []
+        for k, v in want.items():
+            if isinstance(v, torch.Tensor) and v.device.type != "cpu":
+                res[k] = v.to(dev, torch.float32).contiguous()
+            else:
+                a = np.ascontiguousarray(v.numpy() if isinstance(v, torch.Tensor) else v, np.float32)
+                host.append((k, a))
+        if len(host) == 1:
+            res[host[0][0]] = torch.from_numpy(host[0][1]).to(dev, non_blocking=True)
+        elif host:
+            offs, n = [], 0
+            for _, a in host:
+                offs.append(n)
+                n += (a.size + 63) & ~63
+            buf = np.zeros(n, np.float32)
+            for (_, a), o in zip(host, offs):
+                buf[o:o + a.size] = a.reshape(-1)
+            dbuf = torch.from_numpy(buf).to(dev, non_blocking=True)
+            for (k, a), o in zip(host, offs):
+                res[k] = dbuf[o:o + a.size].view(a.shape)
+        return res
 
     def __call__(self, d):
         if not self._loaded:

@@ -46,6 +46,7 @@ class MINDPlanner:
         self.gt_tgt_lane = None
         self.last_ctrl_seq = []
         self.timing = {}
+        self.timing_sum = {"plans": 0, "aime_s": 0.0, "ilqr_s": 0.0, "total_s": 0.0}   # running totals over all plans
         if isinstance(config_dir, dict):
             self.planner_cfg = config_dir
         else:
@@ -163,7 +164,14 @@ class MINDPlanner:
         self.timing = {"aime_s": t1 - t0, "ilqr_s": t2 - t1, "total_s": time.perf_counter() - t0,
                        "nodes_expanded": self.scen_tree_gen.n_expanded - n0, "n_scen_trees": len(scen_trees),
                        "best_traj_idx": best, "tree_costs": [float(c) for c in costs]}
+        self._accumulate_timing()
         return True, ret_ctrl, [[scen_trees[best]], [traj_trees[best]]]
+
+    def _accumulate_timing(self):
+        ts = self.timing_sum
+        ts["plans"] += 1
+        for k in ("aime_s", "ilqr_s", "total_s"):
+            ts[k] += self.timing[k]
 
     def plan_rounds(self, lcl_smp):
         """plan() as a generator over the AIME rounds (ScenarioTreeGenerator.branch_aime_rounds): yields each round's
@@ -186,6 +194,7 @@ class MINDPlanner:
         self.timing = {"aime_s": t1 - t0, "ilqr_s": t2 - t1, "total_s": time.perf_counter() - t0,
                        "nodes_expanded": self.scen_tree_gen.n_expanded - n0, "n_scen_trees": len(scen_trees),
                        "best_traj_idx": best, "tree_costs": [float(c) for c in costs]}
+        self._accumulate_timing()
         return True, nxt.data[0][-2:], [[scen_trees[best]], [traj_trees[best]]]
 
     def resample_target_lane(self, lcl_smp):
