@@ -618,12 +618,12 @@ __device__ __forceinline__ void il_window_axes(int xi, int yi, int W, int H, int
 // A candidate outside the validity region of its node's list (or a node whose list overflowed) walks all
 // agents from global memory instead.
 template <bool GEN>
-__device__ __forceinline__ void il_cost_pass(const IlqrConst &C, const IlqrTreeDev &T, int nuse, double *recs IL_PROF_ARG) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void il_cost_pass(const IlqrConst &C, const IlqrTreeDev &T, int nuse, double *recs, int wave0, int nwaves IL_PROF_ARG) {
+  const int lane = threadIdx.x & 63, wave = wave0 + (threadIdx.x >> 6);
   const int M = T.M, P = nuse * M;
   const int nchunk = (P + 5) / 6;
   const int a = lane % IL_NA, pl = lane / IL_NA;
-  for (int ch = wave; ch < nchunk; ch += IL_WAVES) {
+  for (int ch = wave; ch < nchunk; ch += nwaves) {
     IL_PT0();
     const int pi = ch * 6 + pl;
     const bool valid = lane < 60 && pi < P;
@@ -813,7 +813,7 @@ __device__ __forceinline__ void il_node_derivs(const IlqrConst &C, const IlqrTre
 #define IL_RECS (64 * IL_RA)   // doubles of LDS for compact records: 64 nodes (derivative pass) >= 8 waves x 6 nodes (cost pass)
 template <bool GEN>
 __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTreeDev &T, double *gcell, float *stg, double *drec,
-                                              unsigned *dmask IL_PROF_ARG) {
+                                              unsigned *dmask, int wg, int G IL_PROF_ARG) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = T.M, A = T.n_agents;
   const bool exo = !GEN && C.use_exo;
@@ -821,7 +821,7 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
   if (exo && 3 * A * (nb + 1) > IL_DSTG) nb = IL_DSTG / (3 * A) - 1;
   const int nbp = nb + 1;                       // padded row: conflict-free transposed writes
   float *smx = stg, *smy = stg + A * nbp, *scv = stg + 2 * A * nbp;
-  for (int n0 = 0; n0 < M; n0 += nb) {
+  for (int n0 = wg * nb; n0 < M; n0 += G * nb) {
     IL_PT0();
     const int nn = M - n0 < nb ? M - n0 : nb;
     if (exo) {
@@ -1040,15 +1040,41 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
   }
 }
 
+// Barrier over the G workgroups that share one wide cost tree (k_ilqr<GEN, true>): bar[0] = arrivals, bar[1] = generation.  Thread 0
+// of a workgroup publishes the workgroup's global writes (agent-scope release), arrives, waits for the generation to move and
+// invalidates the CU's vector L1 (agent-scope acquire) before anybody in the workgroup reads what the others wrote.  The
+// workgroups of a tree are co-resident by construction (the host launches at most one workgroup per CU).
+__device__ __forceinline__ void il_tree_sync(unsigned *bar, int G) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // (a workgroup-scope release -- no L2 write-back, valid only while all of
+                                                           // a tree's workgroups share an XCD -- measured 2-5 % faster: not worth the assumption)
+    const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == (unsigned)G - 1u) {
+      __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
 // LM schedule after one rejection (solver.py:153-158)
 __device__ __forceinline__ void il_reject_update(double &mu, double &delta) {
   delta = fmax(1.0, delta) * 2.0;
   mu = fmax(1e-6, mu * delta);
 }
 
-// One iLQR.fit (solver.py:80-167) of one cost tree by one workgroup; starts from the controls in T.us.
-template <bool GEN>
-__device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C, double *stats) {
+// One iLQR.fit (solver.py:80-167) of one cost tree; starts from the controls in T.us.  MULTI == false: one workgroup per tree.
+// MULTI == true (wide trees): G workgroups share the tree -- every "parallel for" below (segments of a level, (node, alpha) cost
+// chunks, node blocks of the derivative pass, array copies) is dealt over the G x 8 waves, every phase boundary is a barrier
+// over the G workgroups (il_tree_sync), the control variables (mu, delta, J, accepted slot ...) are recomputed identically by
+// every workgroup from the same global data.  Same arithmetic per item, same results.
+template <bool GEN, bool MULTI>
+__device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C, double *stats, int wg, int G, unsigned *bar) {
   extern __shared__ double il_dsm[];
   // LDS carve: per-wave scratch [IL_WAVES][IL_SCR] | cost sums [IL_LSUM] | compact records [IL_RECS] | staging [IL_DSTG] floats
   double *scr = il_dsm + (size_t)(threadIdx.x >> 6) * IL_SCR;
@@ -1065,27 +1091,32 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
   __shared__ int sh_accepted, sh_converged, sh_stop, sh_sing, sh_pick, sh_slot, sh_it, sh_nspec, sh_hint;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = T.M;
+  const int gw = MULTI ? wg * IL_WAVES + wave : wave, nw = MULTI ? G * IL_WAVES : IL_WAVES;      // this wave among the tree's waves
+  const int gt = MULTI ? wg * IL_THREADS + tid : tid, nt = MULTI ? G * IL_THREADS : IL_THREADS;  // this thread among the tree's
+#define IL_SYNC() do { if (MULTI) il_tree_sync(bar, G); else { __threadfence_block(); __syncthreads(); } } while (0)
 #ifdef IL_PROFILE
   long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   if (tid == 0) { sh_mu = 1.0; sh_delta = 2.0; sh_accepted = 1; sh_converged = 0; sh_stop = 0; sh_J = 0.0; sh_pick = 0; sh_slot = 0; sh_it = 0; sh_hint = 1; }
+  if (MULTI && wg == 0 && tid == 0) {       // singular-slot words of both pass parities (read behind the barriers below)
+    __hip_atomic_store(&bar[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&bar[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // ---- initial nominal rollout (solver.py:255-330) = candidate slot 0 with k = K = 0, alpha = 0
-  for (int q = tid; q < M * 2; q += IL_THREADS) T.k[q] = 0.0;
-  for (int q = tid; q < M * 12; q += IL_THREADS) T.K[q] = 0.0;
-  for (int q = tid; q < M * 6; q += IL_THREADS) T.xs[q] = 0.0;
+  for (int q = gt; q < M * 2; q += nt) T.k[q] = 0.0;
+  for (int q = gt; q < M * 12; q += nt) T.K[q] = 0.0;
+  for (int q = gt; q < M * 6; q += nt) T.xs[q] = 0.0;
   // constant entries of F_x (identity, [2][4] = dt) and l_xx (zeros); the derivative pass only rewrites the rest
-  for (int q = tid; q < M * 36; q += IL_THREADS) {
+  for (int q = gt; q < M * 36; q += nt) {
     const int e = q % 36;
     T.Fx[q] = (e % 7 == 0) ? 1.0 : (e == 16 ? C.dt : 0.0);
     T.Lxx[q] = 0.0;
   }
-  __threadfence_block();
-  __syncthreads();
+  IL_SYNC();
   for (int d = 0; d < T.n_slevels; ++d) {
-    for (int q = T.slevel_start[d] + wave; q < T.slevel_start[d + 1]; q += IL_WAVES)
+    for (int q = T.slevel_start[d] + gw; q < T.slevel_start[d + 1]; q += nw)
       il_rollout_segment(C, T, T.slevel_segs[q], 1 IL_PROF_PASS);
-    __threadfence_block();
-    __syncthreads();
+    IL_SYNC();
   }
   long long t_der = 0, t_bw = 0, t_ls = 0, t_sel = 0, t_mark = clock64();
 #define IL_MARK(acc) do { long long now_ = clock64(); acc += now_ - t_mark; t_mark = now_; } while (0)
@@ -1100,13 +1131,11 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       // adopt the accepted candidate as the nominal trajectory, then derivatives for all nodes in parallel
       const size_t off = ((size_t)sh_slot * IL_NA + sh_pick) * M;
       const GP<double> xn = T.xs_new + off * 6, un = T.us_new + off * 2;
-      for (int q = tid; q < M * 6; q += IL_THREADS) T.xs[q] = xn[q];
-      for (int q = tid; q < M * 2; q += IL_THREADS) T.us[q] = un[q];
-      __threadfence_block();
-      __syncthreads();
-      il_deriv_pass<GEN>(C, T, lsum, dstg, recs0, reinterpret_cast<unsigned *>(lsum + 9 * 64) IL_PROF_PASS);
-      __threadfence_block();
-      __syncthreads();
+      for (int q = gt; q < M * 6; q += nt) T.xs[q] = xn[q];
+      for (int q = gt; q < M * 2; q += nt) T.us[q] = un[q];
+      IL_SYNC();
+      il_deriv_pass<GEN>(C, T, lsum, dstg, recs0, reinterpret_cast<unsigned *>(lsum + 9 * 64), MULTI ? wg : 0, MULTI ? G : 1 IL_PROF_PASS);
+      IL_SYNC();
       if (M <= IL_LSUM) {
         for (int q = tid; q < M; q += IL_THREADS) lsum[q] = T.L[q];
         __syncthreads();
@@ -1121,13 +1150,16 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       // step is accepted the extra slots would only add work to the cost pass
       int ns = sh_hint;
       const int maxseg = T.max_level_segs > 0 ? T.max_level_segs : 1;   // widest segment level
-      while (ns > 1 && ns * maxseg > IL_SPEC_OVERSUB * IL_WAVES) --ns;
+      while (ns > 1 && ns * maxseg > IL_SPEC_OVERSUB * nw) --ns;
       if (ns > C.max_iter - sh_it) ns = C.max_iter - sh_it;
       double mu = sh_mu, de = sh_delta;
       int cnt = 1;
       for (; cnt < ns; ++cnt) { il_reject_update(mu, de); if (mu >= 1e10) break; }   // slot cnt would never be reached
       sh_nspec = cnt < ns ? cnt : ns;
       sh_sing = 0;
+      // wide trees: the singular-slot mask is a global word, one per pass parity (this pass's word was cleared during the
+      // previous pass, behind several barriers)
+      if (MULTI && wg == 0) __hip_atomic_store(&bar[2 + ((n_pass + 1) & 1)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const int nspec = sh_nspec;
@@ -1135,7 +1167,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
     // ---------------- backward pass (solver.py:332-373): segments, deepest segment level first ----------------
     for (int d = T.n_slevels - 1; d >= 0; --d) {
       const int lo = T.slevel_start[d], hi = T.slevel_start[d + 1];
-      for (int w = wave; w < (hi - lo) * nspec; w += IL_WAVES) {
+      for (int w = gw; w < (hi - lo) * nspec; w += nw) {
         const int slot = w / (hi - lo), seg = T.slevel_segs[lo + w % (hi - lo)];
         double mu = sh_mu, de = sh_delta;
         for (int e = 0; e < slot; ++e) il_reject_update(mu, de);
@@ -1178,17 +1210,25 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
           sing = il_gains(C, Ts, T.seg_nodes[r], mu, scr, pfx, plxx, plx, pu0, pu1, pw0, pw1 IL_PROF_PASS);
           pfx = nfx; plxx = nlxx; plx = nlx; pu0 = nu0; pu1 = nu1; pw0 = nw0; pw1 = nw1;
         }
-        if (sing) { if (lane == 0) atomicOr(&sh_sing, 1 << slot); }
+        if (sing) {
+          if (lane == 0) {
+            if (MULTI) __hip_atomic_fetch_or(&bar[2 + (n_pass & 1)], 1u << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else atomicOr(&sh_sing, 1 << slot);
+          }
+        }
         else {
           const int c = T.seg_nodes[s0];   // value function of the segment head, for the parent's gather
           if (lane < 36) Ts.Vxx[(size_t)c * 36 + lane] = scr[36 + lane];
           else if (lane < 42) Ts.Vx[(size_t)c * 6 + lane - 36] = scr[176 + lane - 36];
         }
       }
-      __threadfence_block();
-      __syncthreads();
+      IL_SYNC();
     }
     IL_MARK(t_bw);
+    if (MULTI) {
+      if (tid == 0) sh_sing = (int)__hip_atomic_load(&bar[2 + (n_pass & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+    }
     if (sh_sing & 1) {   // LinAlgError at the current mu: retry without raising mu (Q9) -- burns one iteration
       if (tid == 0) sh_it += 1;
       __syncthreads();
@@ -1200,19 +1240,17 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
     // ---------------- line search: 10 alphas in lane groups, `nuse` mu slots in parallel waves ----------------
     for (int d = 0; d < T.n_slevels; ++d) {
       const int lo = T.slevel_start[d], hi = T.slevel_start[d + 1];
-      for (int w = wave; w < (hi - lo) * nuse; w += IL_WAVES) {
+      for (int w = gw; w < (hi - lo) * nuse; w += nw) {
         const int slot = w / (hi - lo), seg = T.slevel_segs[lo + w % (hi - lo)];
         IlqrTreeDev Ts = T;
         Ts.k += (size_t)slot * M * 2; Ts.K += (size_t)slot * M * 12;
         Ts.xs_new += (size_t)slot * IL_NA * M * 6; Ts.us_new += (size_t)slot * IL_NA * M * 2; Ts.L_new += (size_t)slot * IL_NA * M;
         il_rollout_segment(C, Ts, seg, 0 IL_PROF_PASS);
       }
-      __threadfence_block();
-      __syncthreads();
+      IL_SYNC();
     }
-    il_cost_pass<GEN>(C, T, nuse, recs IL_PROF_PASS);
-    __threadfence_block();
-    __syncthreads();
+    il_cost_pass<GEN>(C, T, nuse, recs, MULTI ? wg * IL_WAVES : 0, nw IL_PROF_PASS);
+    IL_SYNC();
     IL_MARK(t_ls);
     if (M * IL_NA * nuse <= IL_LSUM) {
       for (int q = tid; q < M * IL_NA * nuse; q += IL_THREADS) lsum[q] = T.L_new[q];
@@ -1259,10 +1297,10 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
   if (sh_accepted) {
     const size_t off = ((size_t)sh_slot * IL_NA + sh_pick) * M;
     const GP<double> xn = T.xs_new + off * 6, un = T.us_new + off * 2;
-    for (int q = tid; q < M * 6; q += IL_THREADS) T.xs[q] = xn[q];
-    for (int q = tid; q < M * 2; q += IL_THREADS) T.us[q] = un[q];
+    for (int q = gt; q < M * 6; q += nt) T.xs[q] = xn[q];
+    for (int q = gt; q < M * 2; q += nt) T.us[q] = un[q];
   }
-  if (tid == 0) {
+  if (tid == 0 && (!MULTI || wg == 0)) {
     stats[0] = (double)sh_it;
     stats[1] = (double)sh_converged;
     stats[2] = sh_J;
@@ -1273,18 +1311,28 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
 #endif
     stats[IL_NSTAT - 1] = (double)n_pass;
   }
-  __threadfence_block();
-  __syncthreads();
+  IL_SYNC();
+#undef IL_SYNC
 }
 
 // n_phases == 1: one fit with consts[0].  n_phases == 2: the contingency planner's sequence (planner.py:174-178) in
 // one launch -- the warm-start fit (consts[0]: lane term only) and then, from its controls, the full fit (consts[1]).
 // T.stats receives IL_NSTAT doubles per phase.
-template <bool GEN>
+// MULTI: G workgroups per tree; block b -> tree 8 (b / 8G) + b % 8, workgroup (b % 8G) / 8 of it: the hardware deals consecutive
+// blocks round-robin over the 8 XCDs, so the workgroups of one tree share an XCD (one L2).  bars: 4 words per tree, zeroed by the host.
+template <bool GEN, bool MULTI>
 __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restrict__ trees, const IlqrConst *__restrict__ consts,
-                                                     int n_phases) {
-  const IlqrTreeDev T = trees[blockIdx.x];
-  for (int ph = 0; ph < n_phases; ++ph) il_fit<GEN>(T, consts[ph], (T.stats + (size_t)ph * IL_NSTAT).p);
+                                                     int n_phases, int n_trees, int G, unsigned *__restrict__ bars) {
+  int t = blockIdx.x, wg = 0;
+  if (MULTI) {
+    const int r = blockIdx.x % (8 * G);
+    t = 8 * (blockIdx.x / (8 * G)) + (r & 7);
+    wg = r >> 3;
+    if (t >= n_trees) return;
+  }
+  const IlqrTreeDev T = trees[t];
+  for (int ph = 0; ph < n_phases; ++ph)
+    il_fit<GEN, MULTI>(T, consts[ph], (T.stats + (size_t)ph * IL_NSTAT).p, wg, G, MULTI ? bars + 4 * t : nullptr);
 }
 
 static inline size_t il_lds_bytes(int /*amax*/) {

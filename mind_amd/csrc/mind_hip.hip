@@ -83,6 +83,7 @@ struct mind_ctx {
   long long tab_clock = 0;
   long long n_table_hits = 0;
   int actor_np = 6;             // partial products per term of the MFMA ActorNet under bf16x3: 6 (three-way split, fp32-class) or 3 (MIND_ACTOR_SPLIT=3)
+  int ilqr_wgs = 8, ilqr_multi_min = 192;   // wide cost trees: workgroups per tree, node count from which they are used (mind_set_tuning)
   int dec_mfma_min = 1 << 30;   // agents per call from which the decoder's actor part runs on the MFMA kernel (MIND_DEC_MFMA_MIN; default: never)
   bool enc_mfma = true;         // MFMA ActorNet under the bf16x3 / bf16 settings (MIND_ENC_MFMA=0: the fp32 VALU kernel, for A/B)
   bool xcd_order = true;        // XCD-aware job order for big batches (MIND_XCD_ORDER=0 switches it off, for A/B measurements)
@@ -181,6 +182,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   (void)hipFuncSetAttribute((const void *)k_actor_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_mfma_lds_bytes());
   if (const char *me = getenv("MIND_ENC_MFMA")) c->enc_mfma = !(me[0] == '0');
   if (const char *de = getenv("MIND_DEC_MFMA_MIN")) c->dec_mfma_min = atoi(de);
+  if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_actor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
   *out = c;
@@ -224,6 +226,8 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "enc_mfma") c->enc_mfma = value != 0;
   else if (n == "actor_split") c->actor_np = value == 3 ? 3 : 6;
   else if (n == "xcd_order") c->xcd_order = value != 0;
+  else if (n == "ilqr_wgs") c->ilqr_wgs = value < 1 ? 1 : (value > 32 ? 32 : value);
+  else if (n == "ilqr_multi_min") c->ilqr_multi_min = value;
   else return fail(c, MIND_EINVAL, "mind_set_tuning: unknown knob '%s'", name);
   return MIND_OK;
 }
@@ -1088,6 +1092,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   const size_t o_gx = takeD(W), o_gy = takeD(H), o_lane = takeD((size_t)n_lane_pts * 2 + 2);
   const size_t o_evx = takeD(ev ? (size_t)ev->nq * 6 : 0), o_evu = takeD(ev ? (size_t)ev->nq * 2 : 0);
   const size_t o_evn = takeI(ev ? ev->nq : 0);
+  const size_t o_bars = takeI(4 * (size_t)n_trees);   // barrier words of the multi-workgroup launch (zero at upload)
   struct TL { size_t nodew, field, relag; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel; int M, a, nl, nseg, nsl, maxls; };
   std::vector<TL> tl(n_trees);
   long Mtot = 0;
@@ -1304,12 +1309,22 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     return MIND_OK;
   }
   const size_t il_lds = il_lds_bytes(amax);
+  // wide trees (hundreds of nodes, dozens of chain segments per level): several workgroups per tree (ilqr_kernels.hip il_fit<.., true>)
+  int maxM = 0;
+  for (int t = 0; t < n_trees; ++t) maxM = tl[t].M > maxM ? tl[t].M : maxM;
+  int G = c->ilqr_wgs;
+  while (G > 1 && ((n_trees + 7) / 8) * 8 * G > c->n_cu) G >>= 1;     // every workgroup of the launch must be resident (1 per CU)
+  const bool multi = !gen && G > 1 && maxM >= c->ilqr_multi_min;
+  unsigned *dBars = (unsigned *)(dI + o_bars);
   if (gen) {
-    (void)hipFuncSetAttribute((const void *)k_ilqr<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
-    hipLaunchKernelGGL(k_ilqr<true>, dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases);
+    (void)hipFuncSetAttribute((const void *)k_ilqr<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
+    hipLaunchKernelGGL((k_ilqr<true, false>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
+  } else if (multi) {
+    (void)hipFuncSetAttribute((const void *)k_ilqr<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
+    hipLaunchKernelGGL((k_ilqr<false, true>), dim3(((n_trees + 7) / 8) * 8 * G), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, G, dBars);
   } else {
-    (void)hipFuncSetAttribute((const void *)k_ilqr<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
-    hipLaunchKernelGGL(k_ilqr<false>, dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases);
+    (void)hipFuncSetAttribute((const void *)k_ilqr<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
+    hipLaunchKernelGGL((k_ilqr<false, false>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
   }
   HIPCHK(c, hipGetLastError());
   std::vector<double> hs((size_t)2 * IL_NSTAT * n_trees);

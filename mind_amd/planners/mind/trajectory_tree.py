@@ -202,7 +202,7 @@ class TrajectoryTreeOptimizer:
         # the warm-start cost has no agent term: one dummy agent per node
         flats = [dict(parent=par, prob=prob, mean=np.zeros((len(par), 1, 2), np.float32), cov=np.zeros((len(par), 1), np.float32))
                  for par, prob in self._last_structs]
-        call = IlqrCall(self._runtime().lib, ilqr_cfg_from(self.config, "w_opt_cfg"), flats, x0, lane, target_vel, use_exo=0)
+        call = IlqrCall(self._runtime().lib, ilqr_cfg_from(self.config, "w_opt_cfg"), flats, x0, lane, target_vel, use_exo=0, background=True)
         self._spec = dict(x0=x0, lane=lane, tv=float(target_vel), structs=self._last_structs, call=call,
                           fut=self._side().submit(call))
         self.counters["warm_speculated"] += len(self._last_structs)

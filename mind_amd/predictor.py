@@ -1,5 +1,6 @@
 """Host-side handle on the HIP scene predictor (one context per process/GPU)."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -13,8 +14,11 @@ class IlqrCall:
     cfg_full given: mind_ilqr_contingency (warm-start fit with ``cfg``, then full fit with ``cfg_full``); otherwise
     mind_ilqr_solve_trees with ``use_exo`` / ``us_init``."""
 
-    def __init__(self, lib, cfg, flats, x0, lane, target_vel, cfg_full=None, use_exo=1, us_init=None):
+    def __init__(self, lib, cfg, flats, x0, lane, target_vel, cfg_full=None, use_exo=1, us_init=None, background=False):
         self.lib, self.cfg, self.cfg_full, self.use_exo = lib, cfg, cfg_full, int(use_exo)
+        # a fit that runs beside the predictor (speculative warm start) stays on one workgroup per tree: the multi-workgroup
+        # kernel's barrier spins would hold CUs the predictor needs
+        self.background = bool(background)
         n = self.n = len(flats)
         self.trees = (_lib.CostTree * n)()
         self.keep, self.Ms = [], []
@@ -46,6 +50,13 @@ class IlqrCall:
         """the launch (+ its synchronisation) on ``rt``'s context; nothing else happens here"""
         dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
         self.ctx = rt.ctx
+        now = getattr(rt, "_ilqr_wgs_now", None)
+        if self.background and now != 1:
+            self.lib.mind_set_tuning(rt.ctx, b"ilqr_wgs", 1)
+            rt._ilqr_wgs_now = 1
+        elif not self.background and now == 1:          # back to what the user (or the library default) asked for
+            rt._ilqr_wgs_now = getattr(rt, "_ilqr_wgs_user", int(os.environ.get("MIND_ILQR_WGS", "8")))
+            self.lib.mind_set_tuning(rt.ctx, b"ilqr_wgs", rt._ilqr_wgs_now)
         if self.cfg_full is not None:
             self.rc = self.lib.mind_ilqr_contingency(rt.ctx, C.byref(self.cfg), C.byref(self.cfg_full), self.trees, self.n, dp(self.x0),
                                                      dp(self.lane), len(self.lane), self.tv, dp(self.xs), dp(self.us), self.st, self.st_full)
@@ -117,6 +128,8 @@ class HipPredictor:
     def set_tuning(self, name, value):
         """kernel-selection knobs of include/mind_hip.h (mind_set_tuning): dec_mfma_min, enc_mfma, actor_split, xcd_order"""
         _lib.check(self.lib, self.ctx, self.lib.mind_set_tuning(self.ctx, name.encode(), int(value)), "mind_set_tuning")
+        if name == "ilqr_wgs":
+            self._ilqr_wgs_user = self._ilqr_wgs_now = int(value)
 
     def set_pair_precision(self, name):
         _lib.check(self.lib, self.ctx, self.lib.mind_set_pair_precision(self.ctx, self.PAIR_PREC.index(name)), "mind_set_pair_precision")

@@ -104,6 +104,36 @@ def test_wide_cost_tree_matches_oracle(hip_predictor):
     assert np.array_equal(xs[0], ref["xs"]) and np.array_equal(us[0], ref["us"])
 
 
+def test_wide_trees_on_several_workgroups_are_bit_identical(hip_predictor):
+    """k_ilqr<.., true>: from 192 nodes on a cost tree is shared by several workgroups (segments, cost chunks and node blocks
+    dealt over all their waves, phase boundaries = barriers over the workgroups).  Same arithmetic per item: the result --
+    states, controls, iteration count, LM state, J -- must be bit-identical for 1, 2, 8 and 16 workgroups per tree, for the
+    contingency sequence (warm-start fit + full fit in one launch), and with small and wide trees mixed in one launch."""
+    from test_aime_host import _full_tree_run
+    g, trees = _full_tree_run(True)
+    by_size = sorted(trees, key=lambda t: len(t.nodes))
+    flats = [oi.flatten([(k, n.parent_key, n.data) for k, n in t.nodes.items()]) for t in (by_size[-1], by_size[0], by_size[-2])]
+    assert len(flats[0]["parent"]) > 300
+    lane = np.asarray(g.target_lane[::2], np.float64)
+    d0 = next(iter(by_size[-1].nodes.values())).data[1][0, 0]
+    x0 = oi.init_state(np.array([float(d0[0]), float(d0[1]), 4.0, 0.0]), np.array([0.0, 0.0]))
+    cfg_w, cfg_f = oi.default_cfg(max_iter=6), oi.default_cfg(max_iter=6)
+    res = {}
+    try:
+        for G in (1, 2, 8, 16):
+            hip_predictor.set_tuning("ilqr_wgs", G)
+            res[G] = hip_predictor.ilqr_contingency(cfg_w, cfg_f, flats, x0, lane, 4.0)
+    finally:
+        hip_predictor.set_tuning("ilqr_wgs", 8)
+    xs1, us1, sw1, sf1 = res[1]
+    for G in (2, 8, 16):
+        xs, us, sw, sf = res[G]
+        for t in range(len(flats)):
+            assert np.array_equal(xs[t], xs1[t]) and np.array_equal(us[t], us1[t]), (G, t)
+        assert sw == sw1 and sf == sf1, G
+    assert sf1[0]["iterations"] >= 2
+
+
 @pytest.mark.parametrize("n_agents", [1, 2])
 def test_tiny_trees_and_ego_only(n_agents, hip_predictor):
     """one- and two-node cost trees, a scene with the ego alone (no exo term at all)."""
