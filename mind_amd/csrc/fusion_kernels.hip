@@ -624,7 +624,7 @@ __device__ __forceinline__ void ln2tok(float &p0, float &p1, float g, float be, 
 
 // mode bits: 1 = init (x0 from actor/lane features), 2 = has epilogue, 4 = has prologue, 8 = only flagged,
 // 16 = write the folded query as bf16 hi / lo A fragments (for k_pair_bf) instead of fp32
-__global__ __launch_bounds__(TT_THREADS) void k_token(const TokMeta *__restrict__ meta, int n_tok, int mode,
+__global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_token(const TokMeta *__restrict__ meta, int n_tok, int mode,
                                                       const float *__restrict__ actor_feat,
                                                       const float *__restrict__ lane_feat, float *__restrict__ x,
                                                       const float *__restrict__ part, float *__restrict__ ST,
