@@ -289,7 +289,7 @@ def gen_scenes():
     np.savez_compressed(os.path.join(GOLD, "scene_io.npz"), **out)
 
 
-def gen_demo_branch(n_plans=4):
+def gen_demo_branch(n_plans=12):
     """G11: the same as demo_plans with the BRANCHING formula weights (mind_amd.weights variant "branching"): the reference's
     AIME tree then keeps several modes and runs two rounds per plan on every recorded scene (6 expansions on demo_1), so
     the branch-selection parity of the four demo scenes is exercised on multi-node trees.  Also stores, per plan, every
