@@ -212,6 +212,18 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None):
         return o
 
     rt.predict = prof_predict
+    # the tree-iLQR launch of every plan, timed by HIP events on the context stream (mind_last_ilqr_stats)
+    il = {"ms": 0.0, "launches": 0, "trees": 0, "wgs": 1}
+    orig_solve = pl.traj_tree_opt.solve_batch
+
+    def prof_solve(*a, **k):
+        r = orig_solve(*a, **k)
+        ms, nt, g = rt.ilqr_stats()
+        if ms > 0:
+            il["ms"] += ms; il["launches"] += 1; il["trees"] += nt; il["wgs"] = g
+        return r
+
+    pl.traj_tree_opt.solve_batch = prof_solve
     ctr0 = dict(pl.traj_tree_opt.counters)
     tsum0 = dict(pl.timing_sum)
     coll0 = (sh.n_collectives, sh.bytes_gathered) if sh is not None else (0, 0)
@@ -223,13 +235,14 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None):
     dist.barrier()
     dt = time.perf_counter() - t0
     rt.predict = orig_predict
+    pl.traj_tree_opt.solve_batch = orig_solve
     rt.set_profiling(False)
     dt = dist.reduce(dt, "max")
     ctr = {k: v - ctr0.get(k, 0) for k, v in pl.traj_tree_opt.counters.items()}
     npl = max(pl.timing_sum["plans"] - tsum0["plans"], 1)
     brk = {"aime": (pl.timing_sum["aime_s"] - tsum0["aime_s"]) / npl * 1e3, "ilqr": (pl.timing_sum["ilqr_s"] - tsum0["ilqr_s"]) / npl * 1e3,
            "note": "host wall time per plan, mean over the timed plans: AIME rounds (predictor + glue) | tree-iLQR (solve_batch)"}
-    return dict(pl=pl, sim=sim, w=w, dt=dt, breakdown_ms=brk, sim_steps=sim_steps, expansions=expansions, expansions_all=dist.reduce(expansions),
+    return dict(pl=pl, sim=sim, w=w, dt=dt, breakdown_ms=brk, ilqr_kernel=il, sim_steps=sim_steps, expansions=expansions, expansions_all=dist.reduce(expansions),
                 pair=acc, ilqr=ctr, a=len(pl.agent_obs), l=int(pl.scen_tree_gen.lane_feat_in.shape[0]), steps=steps, weights=ckpt or PLAIN_WEIGHTS,
                 collectives=(sh.n_collectives - coll0[0], sh.bytes_gathered - coll0[1]) if sh is not None else None,
                 real_scene="scene" in wkw, sharded=sh is not None)
@@ -337,6 +350,8 @@ def summarize(m, prec):
            "nodes_expanded_per_s": m["expansions_all"] / m["dt"], "expansions_per_plan": m["expansions_all"] / m["steps"],
            "agents": m["a"], "lane_polylines": m["l"], "scenario_trees_per_plan": m["pl"].timing.get("n_scen_trees"),
            "ilqr_solves_per_s": ctr["solves"] / m["dt"], "ilqr_iterations_per_s": ctr["iterations"] / m["dt"],
+           "k_ilqr_ms_per_launch": (m["ilqr_kernel"]["ms"] / m["ilqr_kernel"]["launches"]) if m["ilqr_kernel"]["launches"] else None,
+           "k_ilqr_workgroups_per_tree": m["ilqr_kernel"]["wgs"],
            "breakdown_ms": m["breakdown_ms"]}
     if r is not None:
         out["k_pair"] = {"bound": r["bound"], "frac": r["frac"], "mfma_frac": r["mfma"]["frac"], "hbm_frac": r["hbm"]["frac"],
@@ -579,7 +594,9 @@ def main():
         "ilqr": {"solves_per_s": ctr["solves"] / m["dt"], "iterations_per_s": ctr["iterations"] / m["dt"],
                  "trees_per_plan": ctr["solves"] / max(args.steps, 1) / 2, "iterations_per_solve": ctr["iterations"] / max(ctr["solves"], 1),
                  "warm_start_fits_speculated": ctr["warm_speculated"], "warm_start_fits_reused": ctr["warm_hits"],
-                 "note": "per rank; every scenario tree is solved twice per plan (warm start, then full cost); the warm-start fits of "
+                 "kernel_ms_per_launch": (m["ilqr_kernel"]["ms"] / m["ilqr_kernel"]["launches"]) if m["ilqr_kernel"]["launches"] else None,
+                 "kernel_launches_timed": m["ilqr_kernel"]["launches"], "workgroups_per_tree": m["ilqr_kernel"]["wgs"],
+                 "note": "per rank; kernel_ms_per_launch = k_ilqr (warm-start fit + full fit of all scenario trees of a plan) from HIP events on the context stream; every scenario tree is solved twice per plan (warm start, then full cost); the warm-start fits of "
                          "the previous cycle's tree shapes run beside the predictor and are reused where the shape recurs"},
         "breakdown_ms": m["breakdown_ms"],
     }

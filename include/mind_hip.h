@@ -83,6 +83,9 @@ int mind_predict_batch(mind_ctx *ctx, const mind_scene_batch *in, mind_pred_out 
 /* Per-kernel timing of the last mind_predict_batch measured with HIP events on the context stream:
  * returns the number of fusion pair-kernel launches and their summed milliseconds. */
 int mind_last_fusion_stats(mind_ctx *ctx, int *n_launches, float *total_ms, double *pairs_processed);
+/* Duration of the tree-iLQR kernel of the last mind_ilqr_* call on this context (HIP events on the context stream; 0 unless
+ * profiling is on), its number of cost trees and the workgroups per tree it ran with. */
+int mind_last_ilqr_stats(mind_ctx *ctx, float *kernel_ms, int *n_trees, int *workgroups_per_tree);
 /* enable/disable event timing (off by default: events add a little latency) */
 int mind_set_profiling(mind_ctx *ctx, int enable);
 

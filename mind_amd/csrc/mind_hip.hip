@@ -95,6 +95,9 @@ struct mind_ctx {
   DevBuf ilqr_dev, aime_dev, rebase_dev;
   // profiling
   bool profiling = false;
+  hipEvent_t ev_il0 = nullptr, ev_il1 = nullptr;   // around the tree-iLQR launch of the last call (profiling on)
+  float ilqr_ms = 0.f;
+  int ilqr_multi = 0, ilqr_trees = 0;
   int n_pair_launch = 0;
   float pair_ms = 0.f;
   double pairs_done = 0.0;
@@ -205,6 +208,8 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
   if (c->ev_side) (void)hipEventDestroy(c->ev_side);
   if (c->ev_main) (void)hipEventDestroy(c->ev_main);
   if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
+  if (c->ev_il0) (void)hipEventDestroy(c->ev_il0);
+  if (c->ev_il1) (void)hipEventDestroy(c->ev_il1);
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -253,6 +258,14 @@ extern "C" int mind_debug_pack_bfrag(const float *w, int row_stride, uint32_t *o
 extern "C" int mind_set_profiling(mind_ctx *c, int enable) {
   if (!c) return MIND_EINVAL;
   c->profiling = enable != 0;
+  return MIND_OK;
+}
+
+extern "C" int mind_last_ilqr_stats(mind_ctx *c, float *kernel_ms, int *n_trees, int *workgroups_per_tree) {
+  if (!c) return MIND_EINVAL;
+  if (kernel_ms) *kernel_ms = c->ilqr_ms;
+  if (n_trees) *n_trees = c->ilqr_trees;
+  if (workgroups_per_tree) *workgroups_per_tree = c->ilqr_multi;
   return MIND_OK;
 }
 
@@ -1316,6 +1329,11 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   while (G > 1 && ((n_trees + 7) / 8) * 8 * G > c->n_cu) G >>= 1;     // every workgroup of the launch must be resident (1 per CU)
   const bool multi = !gen && G > 1 && maxM >= c->ilqr_multi_min;
   unsigned *dBars = (unsigned *)(dI + o_bars);
+  if (c->profiling) {
+    if (!c->ev_il0) { HIPCHK(c, hipEventCreate(&c->ev_il0)); HIPCHK(c, hipEventCreate(&c->ev_il1)); }
+    HIPCHK(c, hipEventRecord(c->ev_il0, st));
+  }
+  c->ilqr_trees = n_trees; c->ilqr_multi = multi ? G : 1; c->ilqr_ms = 0.f;
   if (gen) {
     (void)hipFuncSetAttribute((const void *)k_ilqr<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
     hipLaunchKernelGGL((k_ilqr<true, false>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
@@ -1327,6 +1345,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     hipLaunchKernelGGL((k_ilqr<false, false>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
   }
   HIPCHK(c, hipGetLastError());
+  if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_il1, st));
   std::vector<double> hs((size_t)2 * IL_NSTAT * n_trees);
   // xs of all trees and, right behind them, the stats of all trees: one copy; us lives in the uploaded region
   const size_t n_xs = (size_t)(tl[0].stats - tl[0].xs);
@@ -1334,6 +1353,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   HIPCHK(c, hipMemcpyAsync(hx.data(), Dp(tl[0].xs), hx.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(us, Dp(tl[0].us), (size_t)Mtot * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
+  if (c->profiling) HIPCHK(c, hipEventElapsedTime(&c->ilqr_ms, c->ev_il0, c->ev_il1));
   memcpy(xs, hx.data(), (size_t)Mtot * 6 * sizeof(double));
   memcpy(hs.data(), hx.data() + n_xs, hs.size() * sizeof(double));
   for (int ph = 0; ph < n_phases; ++ph) {

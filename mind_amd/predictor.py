@@ -137,6 +137,12 @@ class HipPredictor:
     def set_profiling(self, on):
         self.lib.mind_set_profiling(self.ctx, 1 if on else 0)
 
+    def ilqr_stats(self):
+        """(kernel ms, cost trees, workgroups per tree) of the last tree-iLQR call on this context (ms = 0 unless profiling)"""
+        ms, n, g = C.c_float(), C.c_int(), C.c_int()
+        self.lib.mind_last_ilqr_stats(self.ctx, C.byref(ms), C.byref(n), C.byref(g))
+        return ms.value, n.value, g.value
+
     def fusion_stats(self):
         n = C.c_int()
         ms = C.c_float()
