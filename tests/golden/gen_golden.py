@@ -297,7 +297,15 @@ def gen_demo_branch(n_plans=12):
     gen_demo_plans(n_plans, variant="branching", fname="demo_branch.npz")
 
 
-def gen_demo_plans(n_plans=4, variant=None, fname="demo_plans.npz"):
+def gen_demo_branch_runs(n_plans=60):
+    """G12: the reference's WHOLE closed loop (t = 4.0 .. 9.9 s, 60 planning cycles) on the four recorded scenes with the
+    branching formula weights -- discrete results only (every scenario tree's keys, every internal AIME node with END_T and end
+    flag, candidate costs, chosen tree, the ego state / control planned from), for a teacher-forced comparison of the
+    branch-selection indices over entire runs."""
+    gen_demo_plans(n_plans, variant="branching", fname="demo_branch_runs.npz", slim=True)
+
+
+def gen_demo_plans(n_plans=4, variant=None, fname="demo_plans.npz", slim=False):
     """G9: the reference's OWN closed loop (Simulator.run_sim, headless) on its four recorded demo scenes up to the
     first `n_plans` planning cycles (t = 4.0 s, 4.1 s, ...), with the formula weights (the trained checkpoint is not in the
     reference tree): control, chosen scenario/trajectory trees and the ego state after each cycle."""
@@ -385,13 +393,16 @@ def gen_demo_plans(n_plans=4, variant=None, fname="demo_plans.npz"):
             keys = list(st.nodes.keys())
             out[f"{name}_p{pi}_scen_keys"] = np.array(keys)
             out[f"{name}_p{pi}_scen_probs"] = np.array([float(np.ravel(st.nodes[k].data[0])[0]) for k in keys])
-            for k in keys:
-                out[f"{name}_p{pi}_scen_{k}_pos"] = st.nodes[k].data[1][:, ::5]
-                out[f"{name}_p{pi}_scen_{k}_cov"] = st.nodes[k].data[2][:, ::5]
             tk = [k for k in tt.nodes.keys() if k != -1]
-            out[f"{name}_p{pi}_traj_xs"] = np.array([tt.nodes[k].data[0] for k in tk])
-            out[f"{name}_p{pi}_traj_us"] = np.array([tt.nodes[k].data[1] for k in tk])
-            out[f"{name}_p{pi}_traj_parent"] = np.array([tt.nodes[k].parent_key for k in tk])
+            if not slim:
+                for k in keys:
+                    out[f"{name}_p{pi}_scen_{k}_pos"] = st.nodes[k].data[1][:, ::5]
+                    out[f"{name}_p{pi}_scen_{k}_cov"] = st.nodes[k].data[2][:, ::5]
+                out[f"{name}_p{pi}_traj_xs"] = np.array([tt.nodes[k].data[0] for k in tk])
+                out[f"{name}_p{pi}_traj_us"] = np.array([tt.nodes[k].data[1] for k in tk])
+                out[f"{name}_p{pi}_traj_parent"] = np.array([tt.nodes[k].parent_key for k in tk])
+            else:
+                out[f"{name}_p{pi}_ctrl_out"] = np.array(tt.nodes[tk[0]].data[0][-2:], np.float64) if tk else np.zeros(2)
             out[f"{name}_p{pi}_n_scen_trees"] = np.array(len(sim.frames[fi]["scen_tree"]))
             print(name, "plan", pi, "step", fi, "scen keys", keys, "traj nodes", len(tk), "agents",
                   st.nodes[keys[0]].data[1].shape[0])
@@ -471,7 +482,7 @@ def gen_demo_runs(n_plans=60):
     np.savez_compressed(os.path.join(GOLD, "demo_runs.npz"), **out)
 
 
-SECTIONS = {"demo_runs": gen_demo_runs, "demo_plans": gen_demo_plans, "demo_branch": gen_demo_branch, "scenes": gen_scenes, "predictor": gen_predictor, "ilqr": gen_ilqr, "potential": gen_potential, "aime": gen_aime, "plan": gen_plan}
+SECTIONS = {"demo_runs": gen_demo_runs, "demo_plans": gen_demo_plans, "demo_branch": gen_demo_branch, "demo_branch_runs": gen_demo_branch_runs, "scenes": gen_scenes, "predictor": gen_predictor, "ilqr": gen_ilqr, "potential": gen_potential, "aime": gen_aime, "plan": gen_plan}
 
 if __name__ == "__main__":
     torch.manual_seed(0)
