@@ -225,6 +225,16 @@ typedef struct {
   const float *target_lane_info;    /* HOST [P,12]                                                         */
   int n_lane_pts;                   /* P >= 12                                                             */
   float time_ahead, min_vel;        /* tar_time_ahead (5.0), 0.5                                           */
+  /* Optional: the windows assembled ON THE DEVICE instead of uploaded (pos / ang / vel may then be NULL).  A child's window is
+   * the last 50 steps of [its parent's window | its own first `dur` predicted steps] (scenario_tree.py:396-412, 470-473): the
+   * parent's window is taken from the arena of the PREVIOUS mind_aime_rebase call on this context (its generation must be
+   * prev_gen), the child's steps from `rows` (the [R,60,6] world-frame rows mind_aime_world's caller gathered for the kept modes:
+   * x, y, vx, vy, heading, max-sigma). */
+  const float *rows_dev;            /* DEVICE [R,60,6] or NULL (= host windows above)                      */
+  const int32_t *parent_slot;       /* HOST [S] scene index of the parent in the previous call             */
+  const int32_t *row0;              /* HOST [S] first row (agent 0) of the child in rows_dev                */
+  const int32_t *dur;               /* HOST [S] number of predicted steps kept (END_T - CUR_T), 0..60       */
+  int prev_gen;                     /* generation of the call that re-based the parents                     */
 } mind_rebase_in;
 
 typedef struct {
@@ -233,6 +243,7 @@ typedef struct {
   float *lane_ctrs, *lane_vecs;     /* DEVICE [S*l,2]                                                      */
   float *tgt_nodes, *tgt_rpe;       /* DEVICE [S,10,16], [S,20]                                            */
   float *frames;                    /* DEVICE [S,28]: ROT (4, row-major), ORIG (2), TGT_PTS (11 x 2)       */
+  int32_t *gen;                     /* HOST, optional: receives this call's generation (for the children's prev_gen) */
 } mind_rebase_out;
 
 int mind_aime_rebase(mind_ctx *ctx, const mind_rebase_in *in, const mind_rebase_out *out);

@@ -57,12 +57,14 @@ class RebaseIn(C.Structure):
                 ("ang", C.POINTER(C.c_float)), ("vel", C.POINTER(C.c_float)), ("types", C.POINTER(C.c_float)),
                 ("pad", C.POINTER(C.c_float)), ("lane_ctrs", C.POINTER(C.c_float)), ("lane_vecs", C.POINTER(C.c_float)),
                 ("target_lane", C.POINTER(C.c_float)), ("target_lane_info", C.POINTER(C.c_float)), ("n_lane_pts", C.c_int),
-                ("time_ahead", C.c_float), ("min_vel", C.c_float)]
+                ("time_ahead", C.c_float), ("min_vel", C.c_float), ("rows_dev", C.c_void_p), ("parent_slot", C.POINTER(C.c_int32)),
+                ("row0", C.POINTER(C.c_int32)), ("dur", C.POINTER(C.c_int32)), ("prev_gen", C.c_int)]
 
 
 class RebaseOut(C.Structure):
     _fields_ = [("actors", C.c_void_p), ("actor_ctrs", C.c_void_p), ("actor_vecs", C.c_void_p), ("lane_ctrs", C.c_void_p),
-                ("lane_vecs", C.c_void_p), ("tgt_nodes", C.c_void_p), ("tgt_rpe", C.c_void_p), ("frames", C.c_void_p)]
+                ("lane_vecs", C.c_void_p), ("tgt_nodes", C.c_void_p), ("tgt_rpe", C.c_void_p), ("frames", C.c_void_p),
+                ("gen", C.POINTER(C.c_int32))]
 
 
 class IlqrCfg(C.Structure):

@@ -214,6 +214,30 @@ __device__ __forceinline__ void rb_cs(float ax, float ay, float bx, float by, fl
   s = (ax * by - ay * bx) / den;
 }
 
+// Window of a child scene assembled on the device: the last 50 steps of [parent window (50) | the child's first `dur` predicted
+// steps] -- what ChildScene.window6 / update_obser cut out on the host (scenario_tree.py:396-412, 470-473).  One block per
+// (scene, agent), lane = window step.  prev_*: the previous re-basing call's window arrays ([S_prev, a, 50, .]).
+__global__ __launch_bounds__(64) void k_aime_windows(const float *__restrict__ prev_pos, const float *__restrict__ prev_ang,
+                                                     const float *__restrict__ prev_vel, const float *__restrict__ rows,
+                                                     const int *__restrict__ parent_slot, const int *__restrict__ row0,
+                                                     const int *__restrict__ dur, int a, float *__restrict__ pos,
+                                                     float *__restrict__ ang, float *__restrict__ vel) {
+  const int s = blockIdx.x / a, i = blockIdx.x - s * a, t = threadIdx.x;
+  if (t >= RB_T) return;
+  const int d = dur[s];
+  const int src = t + d;                         // index into [parent window | child steps]
+  float x, y, vx, vy, h;
+  if (src < RB_T) {
+    const size_t p = ((size_t)parent_slot[s] * a + i) * RB_T + src;
+    x = prev_pos[2 * p]; y = prev_pos[2 * p + 1]; vx = prev_vel[2 * p]; vy = prev_vel[2 * p + 1]; h = prev_ang[p];
+  } else {
+    const float *r = rows + ((size_t)(row0[s] + i) * AIME_T + (src - RB_T)) * AIME_PK;
+    x = r[0]; y = r[1]; vx = r[2]; vy = r[3]; h = r[4];
+  }
+  const size_t o = ((size_t)s * a + i) * RB_T + t;
+  pos[2 * o] = x; pos[2 * o + 1] = y; vel[2 * o] = vx; vel[2 * o + 1] = vy; ang[o] = h;
+}
+
 __global__ __launch_bounds__(RB_THREADS) void k_aime_rebase(RebaseArgs A) {
   const int sc = blockIdx.x, tid = threadIdx.x;
   const int a = A.a;

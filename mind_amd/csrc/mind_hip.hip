@@ -92,7 +92,9 @@ struct mind_ctx {
   DevBuf edge, x, ST, QK, part, tokpos, meta, jobs, actor_feat, lane_feat, tgt_feat, cmode, tgt_emb,
       rows, rpe_ptrs;
   // ilqr workspaces
-  DevBuf ilqr_dev, aime_dev, rebase_dev;
+  DevBuf ilqr_dev, aime_dev, rebase_dev2[2];
+  int rb_cur = 0, rb_gen = 0;     // re-basing arenas: which one the last call filled, its generation and geometry
+  size_t rb_S = 0, rb_a = 0;
   // profiling
   bool profiling = false;
   hipEvent_t ev_il0 = nullptr, ev_il1 = nullptr;   // around the tree-iLQR launch of the last call (profiling on)
@@ -197,7 +199,7 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf *bufs[] = {&c->edge, &c->x, &c->ST, &c->QK, &c->part, &c->tokpos, &c->meta, &c->jobs, &c->actor_feat,
-                    &c->lane_feat, &c->tgt_feat, &c->cmode, &c->tgt_emb, &c->rows, &c->rpe_ptrs, &c->ilqr_dev, &c->aime_dev, &c->rebase_dev};
+                    &c->lane_feat, &c->tgt_feat, &c->cmode, &c->tgt_emb, &c->rows, &c->rpe_ptrs, &c->ilqr_dev, &c->aime_dev, &c->rebase_dev2[0], &c->rebase_dev2[1]};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (TableSet &t : c->tabs)
@@ -1476,7 +1478,9 @@ extern "C" int mind_aime_world(mind_ctx *c, const mind_world_in *in, const mind_
 }
 
 extern "C" int mind_aime_rebase(mind_ctx *c, const mind_rebase_in *in, const mind_rebase_out *out) {
-  if (!c || !in || !out || in->n_scenes <= 0 || in->n_agents <= 0 || in->n_lanes < 0 || !in->pos || !in->ang || !in->vel || !in->types ||
+  const bool dev_src = in && in->rows_dev;
+  if (!c || !in || !out || in->n_scenes <= 0 || in->n_agents <= 0 || in->n_lanes < 0 ||
+      (!dev_src && (!in->pos || !in->ang || !in->vel)) || (dev_src && (!in->parent_slot || !in->row0 || !in->dur)) || !in->types ||
       (in->n_lanes > 0 && (!in->lane_ctrs || !in->lane_vecs)) || !in->target_lane || !in->target_lane_info || in->n_lane_pts < 12 ||
       !out->actors || !out->actor_ctrs || !out->actor_vecs || (in->n_lanes > 0 && (!out->lane_ctrs || !out->lane_vecs)) ||
       !out->tgt_nodes || !out->tgt_rpe || !out->frames)
@@ -1484,24 +1488,38 @@ extern "C" int mind_aime_rebase(mind_ctx *c, const mind_rebase_in *in, const min
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = c->stream;
   const size_t S = in->n_scenes, a = in->n_agents, l = in->n_lanes, P = in->n_lane_pts;
-  // staging layout (floats): pos | ang | vel | types | pad | lane_ctrs | lane_vecs | tlane | tinfo
+  if (dev_src) {
+    if (in->prev_gen != c->rb_gen || c->rb_gen == 0 || c->rb_a != a)
+      return fail(c, MIND_ESTATE, "mind_aime_rebase: the parents' windows (generation %d, %zu agents) are not the previous call's (%d, %zu)",
+                  in->prev_gen, a, c->rb_gen, c->rb_a);
+    for (size_t s_ = 0; s_ < S; ++s_)
+      if (in->parent_slot[s_] < 0 || (size_t)in->parent_slot[s_] >= c->rb_S || in->row0[s_] < 0 || in->dur[s_] < 0 || in->dur[s_] > AIME_T)
+        return fail(c, MIND_EINVAL, "mind_aime_rebase: scene %zu: parent slot %d / row %d / dur %d out of range", s_, in->parent_slot[s_],
+                    in->row0[s_], in->dur[s_]);
+  }
+  // staging layout (floats): pos | ang | vel | types | pad | lane_ctrs | lane_vecs | tlane | tinfo | (device source: parent_slot | row0 | dur)
   const size_t n_pos = S * a * 50 * 2, n_ang = S * a * 50, n_types = a * 50 * 7, n_pad = in->pad ? S * a * 50 : 0;
   const size_t o_pos = 0, o_ang = o_pos + n_pos, o_vel = o_ang + n_ang, o_types = o_vel + n_pos, o_pad = o_types + n_types;
-  const size_t o_lc = o_pad + n_pad, o_lv = o_lc + 2 * l, o_tl = o_lv + 2 * l, o_ti = o_tl + 2 * P, total = o_ti + 12 * P;
+  const size_t o_lc = o_pad + n_pad, o_lv = o_lc + 2 * l, o_tl = o_lv + 2 * l, o_ti = o_tl + 2 * P, o_idx = o_ti + 12 * P;
+  const size_t total = o_idx + (dev_src ? 3 * S : 0);
+  // two arenas, used alternately: the windows of THIS call are the parents' windows of the next one
+  DevBuf &cur = c->rebase_dev2[c->rb_cur ^ 1];
+  const float *prev = (const float *)c->rebase_dev2[c->rb_cur].p;
+  const size_t prev_o_ang = c->rb_S * c->rb_a * 50 * 2, prev_o_vel = prev_o_ang + c->rb_S * c->rb_a * 50;
   int rc;
-  if ((rc = ensure(c, c->rebase_dev, total * sizeof(float)))) return rc;
-  float *d = (float *)c->rebase_dev.p;
-  // the arena is contiguous: small rounds (a few child scenes) go in ONE staged copy; big ones (cfg4: 80 MB of windows) copy the
+  if ((rc = ensure(c, cur, total * sizeof(float)))) return rc;
+  float *d = (float *)cur.p;
+  // the arena is contiguous: small rounds (a few child scenes) go in ONE staged copy; big ones (cfg4: 14 MB of windows) copy the
   // three window arrays straight from the caller's memory and stage only the small tables (types | pad | lane anchors | target
-  // lane | its info)
-  const bool one_copy = total * sizeof(float) <= ((size_t)1 << 20);
+  // lane | its info | indices); with a device source the windows are not uploaded at all
+  const bool one_copy = !dev_src && total * sizeof(float) <= ((size_t)1 << 20);
   const size_t s0 = one_copy ? 0 : o_types;
   std::vector<float> small(total - s0);
   if (one_copy) {
     memcpy(small.data() + o_pos, in->pos, n_pos * sizeof(float));
     memcpy(small.data() + o_ang, in->ang, n_ang * sizeof(float));
     memcpy(small.data() + o_vel, in->vel, n_pos * sizeof(float));
-  } else {
+  } else if (!dev_src) {
     HIPCHK(c, hipMemcpyAsync(d + o_pos, in->pos, n_pos * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(d + o_ang, in->ang, n_ang * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(d + o_vel, in->vel, n_pos * sizeof(float), hipMemcpyHostToDevice, st));
@@ -1514,7 +1532,19 @@ extern "C" int mind_aime_rebase(mind_ctx *c, const mind_rebase_in *in, const min
   }
   memcpy(small.data() + (o_tl - s0), in->target_lane, 2 * P * sizeof(float));
   memcpy(small.data() + (o_ti - s0), in->target_lane_info, 12 * P * sizeof(float));
+  if (dev_src) {
+    memcpy(small.data() + (o_idx - s0), in->parent_slot, S * sizeof(int));
+    memcpy(small.data() + (o_idx - s0) + S, in->row0, S * sizeof(int));
+    memcpy(small.data() + (o_idx - s0) + 2 * S, in->dur, S * sizeof(int));
+  }
   HIPCHK(c, hipMemcpyAsync(d + s0, small.data(), small.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  if (dev_src) {
+    const int *di = (const int *)(d + o_idx);
+    hipLaunchKernelGGL(k_aime_windows, dim3((unsigned)(S * a)), dim3(64), 0, st, prev, prev + prev_o_ang, prev + prev_o_vel, in->rows_dev,
+                       di, di + S, di + 2 * S, (int)a, d + o_pos, d + o_ang, d + o_vel);
+  }
+  c->rb_cur ^= 1; c->rb_gen += 1; c->rb_S = S; c->rb_a = a;
+  if (out->gen) *out->gen = c->rb_gen;
   RebaseArgs A;
   A.a = (int)a; A.l = (int)l; A.n_lane = (int)P; A.pad_ones = in->pad ? 0 : 1;
   A.pos = d + o_pos; A.ang = d + o_ang; A.vel = d + o_vel; A.types = d + o_types; A.pad = in->pad ? d + o_pad : nullptr;

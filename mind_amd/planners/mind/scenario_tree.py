@@ -12,6 +12,8 @@ Reference map (file:line in planners/mind/scenario_tree.py):
   prune_merge :281-412, prepare_root_data :414-465, update_obser :467-567, get_branch_time :592-611,
   get_high_level_command :613-652.  Quirks Q5, Q8, Q12, Q20 are reproduced.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -37,11 +39,26 @@ class DevScene(dict):
     _HOST_KEYS = ("TRAJS_POS_OBS", "TRAJS_ANG_OBS", "TRAJS_VEL_OBS", "PAD_OBS", "TRAJS_CTRS", "TRAJS_VECS", "ACTORS",
                   "LANES", "LANE_CTRS", "LANE_VECS", "TGT_NODES", "TGT_RPE")
 
-    def __init__(self, gen, dev, g, fields):
+    def __init__(self, gen, dev, g, fields, lazy=None, cov_last=None):
         super().__init__(fields)
         self.gen, self.dev, self.g = gen, dev, g
+        # windows assembled on the device (mind_aime_rebase with a device source): the host copies of the four 50-step history
+        # windows are cut out of (child, w0, keep) only if somebody asks for them by name
+        self.lazy = lazy
+        if lazy is not None:
+            self.hist_n, self.cov_last = gen.obs_len, cov_last
+
+    def __contains__(self, key):
+        return (self.lazy is not None and key in _HIST_COLS) or dict.__contains__(self, key)
 
     def __missing__(self, key):
+        if self.lazy is not None and key in _HIST_COLS:
+            c, w0, keep = self.lazy
+            w6 = c.window6(w0, keep)
+            self._win6 = w6
+            for k, col in _HIST_COLS.items():
+                dict.__setitem__(self, k, w6[:, :, col])
+            return dict.__getitem__(self, key)
         if key not in self._HOST_KEYS:
             raise KeyError(key)
         full = self.gen._host_obs(self["TRAJS_POS_HIST"], self["TRAJS_ANG_HIST"], self["TRAJS_VEL_HIST"], self["TRAJS_TYPE"])
@@ -63,7 +80,7 @@ class ChildScene(dict):
 
     def __init__(self, fields, parent, new, seq_len, shared=None):
         super().__init__(fields)
-        self.parent, self.new, self.n_hist = parent, new, parent["TRAJS_POS_HIST"].shape[1]
+        self.parent, self.new, self.n_hist = parent, new, hist_len(parent)
         self.shared = shared if shared is not None else {}          # siblings share the parent's packed window
         self.length = min(self.n_hist + new.shape[1], seq_len)          # Q8: truncated to seq_len
 
@@ -125,7 +142,16 @@ def hist_trim(d, keep):
 
 
 def hist_len(d):
-    return d.length if isinstance(d, ChildScene) else d["TRAJS_POS_HIST"].shape[1]
+    if isinstance(d, ChildScene):
+        return d.length
+    n = getattr(d, "hist_n", None)           # DevScene whose windows were assembled on the device
+    return n if n is not None else d["TRAJS_POS_HIST"].shape[1]
+
+
+def cov_last_of(d):
+    """TRAJS_COV_HIST[:, -1, 0] of a scene, without materialising a lazily held history"""
+    v = getattr(d, "cov_last", None)
+    return v if v is not None else d["TRAJS_COV_HIST"][:, -1, 0]
 
 
 class RemoteScene(dict):
@@ -155,6 +181,10 @@ class ScenarioTreeGenerator:
         self.target_lane_info = None
         self.ego_idx = 0
         self.device_glue = True     # prune_merge arithmetic on the device when the network leaves its outputs there
+        # re-basing windows of the kept modes cut out of the device-resident rows (mind_aime_rebase device source) instead of stacked
+        # and uploaded: bit-identical, but measured no faster on the full cfg4 tree (the call then stalls on entry for as long as
+        # the host-side window building took) -- off unless MIND_DEVICE_WINDOWS=1
+        self.device_windows = os.environ.get("MIND_DEVICE_WINDOWS", "0") == "1"
         self.device_select = True   # ... and its pruning decisions (k_aime_select); False: decided on the host from the device's signatures
         self.branch_depth = 0
         self.n_expanded = 0           # scenes pushed through the predictor (metric: nodes expanded)
@@ -209,7 +239,7 @@ class ScenarioTreeGenerator:
         sh = self.shard
         if sh is None or sh.world == 1:
             hdr, rows = self.prune_select(batch, self.predict_scenes(batch) if batch else None, 0)
-            return self.assemble_children(batch, hdr, _np(rows))
+            return self.assemble_children(batch, hdr, _np(rows), rows if isinstance(rows, torch.Tensor) and rows.is_cuda else None)
         lo, hi = sh.block(len(batch))
         mine = batch[lo:hi]
         assert not any(isinstance(s, RemoteScene) for s in mine), "a rank was dealt a scene it did not re-base"
@@ -321,7 +351,7 @@ class ScenarioTreeGenerator:
             out, packed, lane_feat = yield batch, d
             self.predict_done(batch, data, lane_feat)
             hdr, rows = self.prune_select(batch, out, 0, packed=packed)
-            self.create_nodes(self.assemble_children(batch, hdr, _np(rows)))
+            self.create_nodes(self.assemble_children(batch, hdr, _np(rows), rows if isinstance(rows, torch.Tensor) and rows.is_cuda else None))
             self.decide_branch()
             batch = [n.data.obs_data for n in self.get_branch_set()]
         assert len(self.get_end_set()) > 0, "No end node found in the scenario tree."
@@ -527,13 +557,13 @@ class ScenarioTreeGenerator:
         copies it to the host once, after the multi-GPU exchange if there is one)."""
         rt, a_off = packed["rt"], packed["a_off"]
         B, A, L = len(scenes), int(packed["a_off"][-1]), self.seq_len
-        lasts = [L - 1 - sc["TRAJS_POS_HIST"].shape[1] for sc in scenes]
+        lasts = [L - 1 - hist_len(sc) for sc in scenes]
         lane_check = self.target_lane is not None and self.ego_idx is not None
         # the decisions themselves on the device too, unless an ego end point lies in the history (then the host decides)
         dev_select = self.device_select and (not lane_check or all(l >= 0 for l in lasts))
         w = rt.aime_world(packed["reg"], packed["vel"], packed["actor_ctrs"], packed["actor_vecs"], a_off,
                           np.stack([sc["ROT"] for sc in scenes]), np.stack([sc["ORIG"] for sc in scenes]),
-                          np.concatenate([sc["TRAJS_COV_HIST"][:, -1, 0] for sc in scenes]), [max(l, -1) for l in lasts],
+                          np.concatenate([cov_last_of(sc) for sc in scenes]), [max(l, -1) for l in lasts],
                           target_lane=self.target_lane, cls=packed["cls"],
                           scen_prob=[sc["SCEN_PROB"] for sc in scenes] if dev_select else None,
                           dist_thres=self.config.tar_dist_thres if (dev_select and lane_check) else None)
@@ -609,7 +639,7 @@ class ScenarioTreeGenerator:
             return np.zeros((0, self.HDR), F32), torch.zeros(0, 60, 6)
         return self._hdr(picks, scenes, idx_offset), torch.from_numpy(np.ascontiguousarray(np.concatenate(rows)))
 
-    def assemble_children(self, batch, hdr, rows):
+    def assemble_children(self, batch, hdr, rows, rows_dev=None):
         """prune_merge, second half (scenario_tree.py:396-412): the child dict of every kept mode -- the parent's world-frame
         history extended by the mode's 60 steps and truncated to seq_len (Q8).  ``batch`` is the round's full branch set
         (every rank holds its world-frame fields), ``hdr`` / ``rows`` as returned by prune_select, concatenated in batch order
@@ -619,8 +649,9 @@ class ScenarioTreeGenerator:
         for h in hdr:
             gidx, k = int(h[0]), int(h[1])
             sc = batch[gidx]
-            a = sc["TRAJS_POS_HIST"].shape[0]
+            a = sc["TRAJS_TYPE"].shape[0]
             m = rows[r0:r0 + a]
+            row_first = r0
             r0 += a
             kept.append(ChildScene({
                 "SCEN_PROB": F32(h[2]), "CUR_T": sc["CUR_T"], "END_T": sc["END_T"],
@@ -628,6 +659,8 @@ class ScenarioTreeGenerator:
                 "TRAJS_TYPE": sc["TRAJS_TYPE"], "TRAJS_TID": sc["TRAJS_TID"], "TRAJS_CAT": sc["TRAJS_CAT"],
                 "TGT_PTS": np.array(h[3:], F32).reshape(11, 2),
             }, sc, m, L, shared.setdefault(gidx, {})))
+            # where the child's rows live on the device (the re-basing of the next round can cut its window out of them there)
+            kept[-1].dev_rows, kept[-1].row0 = rows_dev, row_first
         assert r0 == len(rows), (r0, len(rows))
         return kept
 
@@ -765,6 +798,10 @@ class ScenarioTreeGenerator:
             return [self.update_obser(c) for c in curs]
         o = self.obs_len
         G = len(curs)
+        if on_dev and self.device_windows:
+            dev_out = self._update_obser_device_windows(curs, rt)
+            if dev_out is not None:
+                return dev_out
         wins = {}
         for c in curs:
             keep = o + (c["END_T"] - c["CUR_T"])
@@ -817,6 +854,43 @@ class ScenarioTreeGenerator:
                  "CUR_T": c["END_T"], "END_T": self.pred_len, "TRAJS_TID": c["TRAJS_TID"], "TRAJS_CAT": c["TRAJS_CAT"],
                  "TRAJS_POS_HIST": pos[g], "TRAJS_COV_HIST": cov[g], "TRAJS_ANG_HIST": ang[g], "TRAJS_VEL_HIST": vel[g]}
             out.append((s, c))
+        return out
+
+    def _update_obser_device_windows(self, curs, rt):
+        """update_obser_batch with the 50-step windows assembled ON THE DEVICE (mind_aime_rebase, device source): possible when
+        every node is a kept mode whose parent was re-based by the previous mind_aime_rebase call of this runtime (its window is
+        still in that call's arena) and whose own rows are still on the device (the tensor prune_select gathered).  Nothing is
+        stacked or uploaded; the host copies of the windows are only cut out if somebody asks (DevScene.lazy).  None = not
+        applicable (the caller then takes the host-window path)."""
+        o = self.obs_len
+        c0 = curs[0]
+        if not all(isinstance(c, ChildScene) and isinstance(c.parent, DevScene) and c.n_hist == o for c in curs):
+            return None
+        pd, rows_dev = c0.parent.dev, getattr(c0, "dev_rows", None)
+        if rows_dev is None or pd.get("gen") is None or getattr(rt, "_rebase_gen", None) != pd["gen"]:
+            return None
+        durs = []
+        for c in curs:
+            dur = c["END_T"] - c["CUR_T"]
+            if c.parent.dev is not pd or getattr(c, "dev_rows", None) is not rows_dev or not (1 <= dur <= 60) or o + dur > c.length:
+                return None
+            durs.append(int(dur))
+        a = c0.new.shape[0]
+        dev = rt.aime_rebase(None, None, None, c0["TRAJS_TYPE"], self.lane_graph["lane_ctrs"], self.lane_graph["lane_vecs"],
+                             self.target_lane, self.target_lane_info, time_ahead=self.config.tar_time_ahead,
+                             dev_src=dict(rows=rows_dev, parent_slot=[c.parent.g for c in curs], row0=[c.row0 for c in curs],
+                                          dur=durs, gen=pd["gen"], a=a))
+        dev["a"], dev["l"] = a, self.lane_graph["lane_ctrs"].shape[0]
+        fr = dev["frames"].cpu().numpy()
+        out = []
+        for g, (c, dur) in enumerate(zip(curs, durs)):
+            keep = o + dur
+            hist_trim(c, keep)
+            out.append((DevScene(self, dev, g, {
+                "ORIG": fr[g, 4:6].copy(), "ROT": fr[g, :4].reshape(2, 2).copy(), "TGT_PTS": fr[g, 6:].reshape(11, 2).copy(),
+                "TRAJS_TYPE": c["TRAJS_TYPE"], "SCEN_PROB": c["SCEN_PROB"], "SCEN_ID": c["SCEN_ID"], "PARENT_ID": c["PARENT_ID"],
+                "CUR_T": c["END_T"], "END_T": self.pred_len, "TRAJS_TID": c["TRAJS_TID"], "TRAJS_CAT": c["TRAJS_CAT"]},
+                lazy=(c, dur, keep), cov_last=np.ascontiguousarray(c.new[:, dur - 1, 5])), c))
         return out
 
     def _host_obs(self, pos, ang, vel, types):

@@ -368,27 +368,41 @@ class HipPredictor:
         return out
 
     def aime_rebase(self, pos, ang, vel, types, lane_ctrs, lane_vecs, target_lane, target_lane_info, pad=None,
-                    time_ahead=5.0, min_vel=0.5):
+                    time_ahead=5.0, min_vel=0.5, dev_src=None):
         """update_obser for S child scenes on the device (mind_aime_rebase).  pos [S,a,50,2], ang [S,a,50], vel [S,a,50,2]
         (world-frame windows), types [a,50,7], lane_ctrs / lane_vecs [l,2], target_lane [P,2], target_lane_info [P,12]: host
         float32.  Returns device tensors actors [S*a,14,48], actor_ctrs, actor_vecs [S*a,2], lane_ctrs, lane_vecs [S*l,2],
-        tgt_nodes [S,10,16], tgt_rpe [S,20], frames [S,28] (ROT, ORIG, TGT_PTS)."""
+        tgt_nodes [S,10,16], tgt_rpe [S,20], frames [S,28] (ROT, ORIG, TGT_PTS) and ``gen``, the call's generation.
+        ``dev_src`` = dict(rows=device [R,60,6], parent_slot, row0, dur: int [S], gen, a): the windows are assembled on the device
+        from the parents' windows of the previous call (generation ``gen``) and the kept rows; pos / ang / vel are ignored."""
         dev = self.device
         f = lambda x: np.ascontiguousarray(x, np.float32)
-        # lists of per-scene windows are stacked here (page-locked staging buffers were measured slower than the runtime's own
-        # pageable path: 15 vs 10 ms per plan at 216 scenes x 64 agents)
-        stk = lambda x: f(np.stack(x) if isinstance(x, (list, tuple)) else x)
-        pos, ang, vel = stk(pos), stk(ang), stk(vel)
         types = f(types)
         lane_ctrs, lane_vecs, tl, ti = f(lane_ctrs), f(lane_vecs), f(target_lane), f(target_lane_info)
-        S, a = pos.shape[:2]
-        l = lane_ctrs.shape[0]
-        assert pos.shape == (S, a, 50, 2) and ang.shape == (S, a, 50) and vel.shape == (S, a, 50, 2) and types.shape == (a, 50, 7)
-        assert tl.ndim == 2 and ti.shape == (len(tl), 12)
         ri, ro = _lib.RebaseIn(), _lib.RebaseOut()
         fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+        ip = lambda x: x.ctypes.data_as(C.POINTER(C.c_int32))
+        keep = []
+        if dev_src is not None:
+            rows = dev_src["rows"]
+            assert rows.device == dev and rows.dtype == torch.float32 and rows.is_contiguous() and tuple(rows.shape[1:]) == (60, 6)
+            ps, r0, du = (np.ascontiguousarray(dev_src[k], np.int32) for k in ("parent_slot", "row0", "dur"))
+            S, a = len(ps), int(dev_src["a"])
+            assert len(r0) == S and len(du) == S and int(r0.max()) + a <= rows.shape[0]
+            ri.rows_dev, ri.parent_slot, ri.row0, ri.dur, ri.prev_gen = C.c_void_p(rows.data_ptr()), ip(ps), ip(r0), ip(du), int(dev_src["gen"])
+            keep += [ps, r0, du, rows]
+        else:
+            # lists of per-scene windows are stacked here (page-locked staging buffers were measured slower than the runtime's own
+            # pageable path: 15 vs 10 ms per plan at 216 scenes x 64 agents)
+            stk = lambda x: f(np.stack(x) if isinstance(x, (list, tuple)) else x)
+            pos, ang, vel = stk(pos), stk(ang), stk(vel)
+            S, a = pos.shape[:2]
+            assert pos.shape == (S, a, 50, 2) and ang.shape == (S, a, 50) and vel.shape == (S, a, 50, 2)
+            ri.pos, ri.ang, ri.vel = fp(pos), fp(ang), fp(vel)
+        l = lane_ctrs.shape[0]
+        assert types.shape == (a, 50, 7) and tl.ndim == 2 and ti.shape == (len(tl), 12)
         ri.n_scenes, ri.n_agents, ri.n_lanes = S, a, l
-        ri.pos, ri.ang, ri.vel, ri.types = fp(pos), fp(ang), fp(vel), fp(types)
+        ri.types = fp(types)
         padk = None
         if pad is not None:
             padk = f(pad)
@@ -401,8 +415,11 @@ class HipPredictor:
                    tgt_rpe=torch.empty(S, 20, device=dev), frames=torch.empty(S, 28, device=dev))
         for k in out:
             setattr(ro, k, C.c_void_p(out[k].data_ptr()))
+        gen = C.c_int32(0)
+        ro.gen = C.pointer(gen)
         rc = self.lib.mind_aime_rebase(self.ctx, C.byref(ri), C.byref(ro))
         _lib.check(self.lib, self.ctx, rc, "mind_aime_rebase")
+        out["gen"] = self._rebase_gen = int(gen.value)      # the arena of THIS call is what a device-source call can build on next
         return out
 
     def lane_dist_field(self, ego_xy, lane, W, H, res):

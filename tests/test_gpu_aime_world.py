@@ -129,7 +129,7 @@ def test_rebase_kernel_matches_host_update_obser(hip_predictor):
     th = rng.uniform(-np.pi, np.pi, l)
     lane_v = np.stack([np.cos(th), np.sin(th)], -1).astype(F32)
     o = hip_predictor.aime_rebase(pos, ang, vel, types, lane_c, lane_v, lane_xy, info)
-    got = {k: v.cpu().numpy() for k, v in o.items()}
+    got = {k: v.cpu().numpy() for k, v in o.items() if isinstance(v, torch.Tensor)}
     orig, rot, theta, pos_n, ang_n, vel_n, ctrs, vecs = U.normalize_agents_batch(pos, ang, vel)
     pad = np.ones(ang.shape, F32)
     actors = U.actor_features_batch(pos_n, ang_n, vel_n, np.broadcast_to(types, (S,) + types.shape), pad)
@@ -228,3 +228,56 @@ def test_device_pruning_decisions_equal_the_host_decisions(hip_predictor, lane_o
     assert (n_kept < 6).any() and (n_kept > 1).any()                          # merging and pruning both happened
     for b in range(B):                                                        # the tail of every row is -1
         assert (sel[0, b, n_kept[b]:] == -1).all()
+
+
+def test_rebase_windows_assembled_on_the_device_equal_uploaded_windows(hip_predictor):
+    """mind_aime_rebase with a device source: a child's 50-step window = the last 50 steps of [its parent's window | its own first
+    `dur` kept steps], cut out of the previous call's arena and the device-resident rows (k_aime_windows) instead of being
+    stacked and uploaded by the host.  Every output tensor must be bit-identical to the call with the same windows uploaded,
+    for dur = 1, mid-range, 50 (parent window fully shifted out) and 60, several children per parent, parents in any order."""
+    rng = np.random.default_rng(5)
+    S0, a, l, P = 4, 7, 11, 160
+    lane_xy = np.stack([np.linspace(100.0, 100.0 + 1.0 * (P - 1), P), 300.0 + 5.0 * np.sin(np.linspace(0, 3, P))], 1).astype(F32)
+    info = rng.integers(0, 2, (P, 12)).astype(F32)
+    types = np.zeros((a, 50, 7), F32)
+    types[np.arange(a), :, np.arange(a) % 7] = 1.0
+    lane_c = rng.uniform(-50, 150, (l, 2)).astype(F32)
+    th = rng.uniform(-np.pi, np.pi, l)
+    lane_v = np.stack([np.cos(th), np.sin(th)], -1).astype(F32)
+
+    def tracks(n, T):                                                        # smooth world-frame tracks [n, a, T, 6]
+        t = np.arange(T, dtype=F32) * F32(0.1)
+        w = np.zeros((n, a, T, 6), F32)
+        for s_ in range(n):
+            for i in range(a):
+                h = rng.uniform(-0.4, 0.4) + 0.02 * np.sin(t + i)
+                v = rng.uniform(0.5, 9.0)
+                w[s_, i, :, 2], w[s_, i, :, 3], w[s_, i, :, 4] = v * np.cos(h), v * np.sin(h), h
+                w[s_, i, :, :2] = np.array([120.0 + 10.0 * s_ + rng.uniform(-10, 20), 300.0 + rng.uniform(-5, 5)]) + np.cumsum(w[s_, i, :, 2:4] * 0.1, axis=0)
+                w[s_, i, :, 5] = rng.uniform(0.01, 2.0, T)
+        return w
+    par = tracks(S0, 50)                                                     # the parents' windows
+    kids = [(2, 1), (0, 17), (2, 50), (3, 60), (0, 33), (1, 49)]             # (parent slot, dur)
+    rows = tracks(len(kids), 60).reshape(len(kids) * a, 60, 6)
+    rows_dev = torch.from_numpy(rows).to(hip_predictor.device)
+    win = np.stack([np.concatenate([par[p], rows[j * a:(j + 1) * a]], axis=1)[:, d:d + 50] for j, (p, d) in enumerate(kids)])
+
+    def call(**kw):
+        return hip_predictor.aime_rebase(kw.get("pos"), kw.get("ang"), kw.get("vel"), types, lane_c, lane_v, lane_xy, info,
+                                         dev_src=kw.get("dev_src"))
+    p0 = call(pos=par[..., :2], ang=par[..., 4], vel=par[..., 2:4])
+    dev = call(dev_src=dict(rows=rows_dev, parent_slot=[p for p, _ in kids], row0=[j * a for j in range(len(kids))],
+                            dur=[d for _, d in kids], gen=p0["gen"], a=a))
+    assert dev["gen"] == p0["gen"] + 1
+    host = call(pos=np.ascontiguousarray(win[..., :2]), ang=np.ascontiguousarray(win[..., 4]), vel=np.ascontiguousarray(win[..., 2:4]))
+    for k in ("actors", "actor_ctrs", "actor_vecs", "lane_ctrs", "lane_vecs", "tgt_nodes", "tgt_rpe", "frames"):
+        assert torch.equal(dev[k], host[k]), k
+    # grandchildren can build on the device-assembled windows as well: one more generation
+    g2 = call(dev_src=dict(rows=rows_dev, parent_slot=[1, 5], row0=[0, a], dur=[10, 3], gen=host["gen"], a=a))
+    w2 = np.stack([np.concatenate([win[1], rows[0:a]], axis=1)[:, 10:60], np.concatenate([win[5], rows[a:2 * a]], axis=1)[:, 3:53]])
+    h2 = call(pos=np.ascontiguousarray(w2[..., :2]), ang=np.ascontiguousarray(w2[..., 4]), vel=np.ascontiguousarray(w2[..., 2:4]))
+    assert torch.equal(g2["actors"], h2["actors"]) and torch.equal(g2["frames"], h2["frames"])
+    # a stale generation is refused
+    from mind_amd._lib import MindError
+    with pytest.raises(MindError):
+        call(dev_src=dict(rows=rows_dev, parent_slot=[0], row0=[0], dur=[5], gen=p0["gen"], a=a))

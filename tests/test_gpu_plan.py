@@ -312,6 +312,41 @@ def test_recorded_demo_scenes_branching_weights_whole_run(scene):
     assert max(n_nodes) > 1 and same_choice >= 48
 
 
+def test_full_tree_plan_is_identical_with_device_assembled_windows():
+    """The full scripted 6-ary tree (rounds of 1 / 6 / 36 / 216 scenes): from the third round on, the re-basing windows of the kept
+    modes are cut out of the previous round's device arena and the device-resident rows (mind_aime_rebase device source) instead
+    of being stacked and uploaded.  The plan -- every scenario tree's nodes with probabilities, agent trajectories and
+    covariances, the ego plan, the control -- must be bit-identical to the run that uploads the windows, and the lazily held
+    host windows must equal the uploaded ones when somebody asks for them."""
+    sys.path.insert(0, ROOT)
+    from bench import WORKLOADS, make_closed_loop
+    from mind_amd.planners.mind.scenario_tree import DevScene
+    res, lazies = [], []
+    for dev_win in (True, False):
+        pl, sim, w = make_closed_loop(dict(WORKLOADS["cfg4tree"]), full_tree=True, speculative=False)
+        pl.scen_tree_gen.device_windows = dev_win
+        sim.run_plans(2)
+        trees = pl.scen_tree_gen.get_scenario_tree()
+        flat = []
+        for t in trees:
+            for k, n in t.nodes.items():
+                flat.append((k, float(np.ravel(n.data[0])[0]), np.asarray(n.data[1]).copy(), np.asarray(n.data[2]).copy()))
+        tt = sim.last_result[1][0]
+        res.append((flat, np.array(sim.ctrl), tt._arrays[0].copy(), pl.timing["best_traj_idx"]))
+        obs = [n.data.obs_data for n in pl.scen_tree_gen.tree.nodes.values() if isinstance(getattr(n.data, "obs_data", None), DevScene)]
+        lazies.append((sum(1 for o_ in obs if o_.lazy is not None), {o_["SCEN_ID"]: o_ for o_ in obs}))
+    (fa, ca, xa, ba), (fb, cb, xb, bb) = res
+    assert len(fa) == len(fb) > 200 and ba == bb
+    for (ka, pa, ma, va), (kb, pb, mb, vb) in zip(fa, fb):
+        assert ka == kb and pa == pb and np.array_equal(ma, mb) and np.array_equal(va, vb), ka
+    assert np.array_equal(ca, cb) and np.array_equal(xa, xb)
+    assert lazies[0][0] >= 36 and lazies[1][0] == 0                      # rounds 3 and 4 really took the device path
+    for sid, o_ in list(lazies[0][1].items())[::17]:                      # lazily materialised host windows = the uploaded ones
+        ref = lazies[1][1][sid]
+        for key in ("TRAJS_POS_HIST", "TRAJS_ANG_HIST", "TRAJS_VEL_HIST", "TRAJS_COV_HIST"):
+            assert np.array_equal(o_[key], ref[key]), (sid, key)
+
+
 def test_checkpoint_tar_goes_through_the_same_loader(tmp_path):
     """The reference's checkpoint format (planner.py:46-47: torch.load(path)["state_dict"], a .tar written by torch.save):
     a planner configured with such a file plans exactly what the formula-weight planner plans."""

@@ -20,7 +20,7 @@ def wrap(obj, name, label=None, sync=False):
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "demo1"
 ckpt = sys.argv[3] if len(sys.argv) > 3 else None
-pl, sim, w = make_closed_loop(dict(WORKLOADS[wl]), full_tree=wl in FULL_TREE, ckpt=ckpt)
+pl, sim, w = make_closed_loop(dict(WORKLOADS[wl]), full_tree=wl in FULL_TREE, ckpt=ckpt, speculative=os.environ.get("SPEC", "1") == "1")
 gen, net, rt, opt = pl.scen_tree_gen, pl.scen_tree_gen.network, pl.network.rt, pl.traj_tree_opt
 sim.run_plans(3)
 wrap(pl, "plan"); wrap(gen, "branch_aime"); wrap(gen, "process_data"); wrap(gen, "collate"); wrap(net, "pre_process")
@@ -37,6 +37,18 @@ import mind_amd.planners.mind.utils as UU
 for fn in ("get_agent_trajectories", "normalize_agents", "lane_graph_from_map", "lane_features", "actor_features"):
     if hasattr(UU, fn): wrap(UU, fn, "U." + fn)
 wrap(gen, "_scene_inputs"); wrap(gen, "get_branch_times"); wrap(gen, "_prune_select_device"); wrap(gen, "_hdr")
+class _LibTimer:
+    def __init__(self, fn, label):
+        self.fn, self.label = fn, label
+    def __call__(self, *a):
+        t0 = time.perf_counter()
+        r = self.fn(*a)
+        acc[self.label] = acc.get(self.label, 0.0) + time.perf_counter() - t0
+        return r
+rt.lib.mind_aime_rebase = _LibTimer(rt.lib.mind_aime_rebase, "C: mind_aime_rebase")
+rt.lib.mind_aime_world = _LibTimer(rt.lib.mind_aime_world, "C: mind_aime_world")
+rt.lib.mind_predict_batch = _LibTimer(rt.lib.mind_predict_batch, "C: mind_predict_batch")
+wrap(gen, "_update_obser_device_windows")
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 t0 = time.perf_counter()
 sim.run_plans(n)
