@@ -138,7 +138,7 @@ class TrajectoryTreeOptimizer:
         self._worker = None
         self._last_structs = []
         self._spec = None
-        self._spec_skip, self._spec_backoff, self._spec_last = 0, 4, None
+        self._spec_skip, self._spec_backoff, self._spec_last = 0, 4, None     # back-off doubles after every failed probe (4 .. 256 cycles)
         self.counters = {"solves": 0, "iterations": 0, "warm_speculated": 0, "warm_hits": 0}
 
     def _runtime(self):
@@ -191,7 +191,7 @@ class TrajectoryTreeOptimizer:
         if not self.speculative or self.solver is not None or self.shard is not None or not self._last_structs:
             return
         # a speculated fit only pays when the tree shape (parents + node probabilities) recurs: after a cycle in which
-        # fewer than half of the guesses were used, skip the next `_spec_backoff` cycles, then probe again
+        # fewer than half of the guesses were used, skip the next `_spec_backoff` cycles (doubling after every failed probe), then probe again
         if self._spec_skip > 0:
             self._spec_skip -= 1
             self._spec_last = None
@@ -251,8 +251,14 @@ class TrajectoryTreeOptimizer:
                 hits = self._take_speculation(sub, x0, lane, target_vel) if self.shard is None else {}
                 self._last_structs = [(np.ascontiguousarray(f["parent"], np.int32), np.ascontiguousarray(f["prob"], np.float32)) for f in sub]
                 self.counters["warm_hits"] += len(hits)
-                if self._spec_last is not None and 2 * len(hits) < self._spec_last:
-                    self._spec_skip = self._spec_backoff
+                if self._spec_last is not None:
+                    if 2 * len(hits) < self._spec_last:
+                        # the shapes did not recur: a probe costs ~1.5 % of a branching cycle (measured on demo_1), so wait twice
+                        # as long before the next one
+                        self._spec_skip = self._spec_backoff
+                        self._spec_backoff = min(2 * self._spec_backoff, 256)
+                    else:
+                        self._spec_backoff = 4
                 self._spec_last = None
                 xs, us, st_w, st = [None] * len(sub), [None] * len(sub), [None] * len(sub), [None] * len(sub)
                 from ...predictor import IlqrCall
