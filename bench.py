@@ -530,7 +530,7 @@ def main():
                     help="torch.distributed backend for --gpus N > 1 (nccl = RCCL; gloo only for tests on a single-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (synthetic branching, cfg4 tree, other recorded scenes)")
-    ap.add_argument("--tree-steps", type=int, default=2, help="planning cycles of the extra cfg4-tree measurement")
+    ap.add_argument("--tree-steps", type=int, default=5, help="planning cycles of the extra cfg4-tree measurement")
     ap.add_argument("--concurrent", type=int, default=0,
                     help="BASELINE config 3: plan this many independent scenes concurrently on the GPU (one host thread, "
                          "HIP context and stream per scene); prints the aggregate rate")
@@ -613,7 +613,7 @@ def main():
         # here must not cost the headline line (every rank reaches the same except branch or none does: the plan is replicated)
         key = "tree_sharded" if world > 1 else "tree"
         try:
-            t = measure(dist, "cfg4tree", args.tree_steps, 1, world > 1)
+            t = measure(dist, "cfg4tree", args.tree_steps, 2, world > 1)      # two warm-up plans: the arenas and table caches reach their final sizes
             out[key] = dict(summarize(t, prec), workload="cfg4tree: 64 agents x 256 lane polylines, full scripted 6-ary "
                             "depth-4 AIME tree on the real predictor forward", n_gpus=world,
                             scaling="strong" if world > 1 else None, plans_timed=args.tree_steps)
