@@ -1044,9 +1044,15 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
 // of a workgroup publishes the workgroup's global writes (agent-scope release), arrives, waits for the generation to move and
 // invalidates the CU's vector L1 (agent-scope acquire) before anybody in the workgroup reads what the others wrote.  The
 // workgroups of a tree are co-resident by construction (the host launches at most one workgroup per CU).
-__device__ __forceinline__ void il_tree_sync(unsigned *bar, int G) {
+// Returns true when the launch was aborted: a workgroup that waits longer than ~2 s for its peers (they can only be missing if the
+// launch was not fully resident) raises the launch-wide abort word, and every workgroup leaves at its next barrier; the host
+// reports the failure instead of a hung device.
+#define IL_SYNC_SPINS (1u << 24)
+__device__ __forceinline__ bool il_tree_sync(unsigned *bar, int G, unsigned *abort_word) {
+  __shared__ int sh_aborted;
   __syncthreads();
   if (threadIdx.x == 0) {
+    int aborted = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // (a workgroup-scope release -- no L2 write-back, valid only while all of
                                                            // a tree's workgroups share an XCD -- measured 2-5 % faster: not worth the assumption)
     const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1055,11 +1061,20 @@ __device__ __forceinline__ void il_tree_sync(unsigned *bar, int G) {
       __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(4);
+      unsigned spins = 0;
+      while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((++spins & 0xfffu) == 0u) {          // the abort word is only looked at by a workgroup that has been waiting for a while
+          if (spins >= IL_SYNC_SPINS) __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { aborted = 1; break; }
+        }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    sh_aborted = aborted;
   }
   __syncthreads();
+  return sh_aborted != 0;
 }
 
 // LM schedule after one rejection (solver.py:153-158)
@@ -1074,7 +1089,7 @@ __device__ __forceinline__ void il_reject_update(double &mu, double &delta) {
 // over the G workgroups (il_tree_sync), the control variables (mu, delta, J, accepted slot ...) are recomputed identically by
 // every workgroup from the same global data.  Same arithmetic per item, same results.
 template <bool GEN, bool MULTI>
-__device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C, double *stats, int wg, int G, unsigned *bar) {
+__device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C, double *stats, int wg, int G, unsigned *bar, unsigned *abort_word) {
   extern __shared__ double il_dsm[];
   // LDS carve: per-wave scratch [IL_WAVES][IL_SCR] | cost sums [IL_LSUM] | compact records [IL_RECS] | staging [IL_DSTG] floats
   double *scr = il_dsm + (size_t)(threadIdx.x >> 6) * IL_SCR;
@@ -1093,7 +1108,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
   const int M = T.M;
   const int gw = MULTI ? wg * IL_WAVES + wave : wave, nw = MULTI ? G * IL_WAVES : IL_WAVES;      // this wave among the tree's waves
   const int gt = MULTI ? wg * IL_THREADS + tid : tid, nt = MULTI ? G * IL_THREADS : IL_THREADS;  // this thread among the tree's
-#define IL_SYNC() do { if (MULTI) il_tree_sync(bar, G); else { __threadfence_block(); __syncthreads(); } } while (0)
+#define IL_SYNC() do { if (MULTI) { if (il_tree_sync(bar, G, abort_word)) return; } else { __threadfence_block(); __syncthreads(); } } while (0)
 #ifdef IL_PROFILE
   long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -1319,7 +1334,8 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
 // one launch -- the warm-start fit (consts[0]: lane term only) and then, from its controls, the full fit (consts[1]).
 // T.stats receives IL_NSTAT doubles per phase.
 // MULTI: G workgroups per tree; block b -> tree 8 (b / 8G) + b % 8, workgroup (b % 8G) / 8 of it: the hardware deals consecutive
-// blocks round-robin over the 8 XCDs, so the workgroups of one tree share an XCD (one L2).  bars: 4 words per tree, zeroed by the host.
+// blocks round-robin over the 8 XCDs, so the workgroups of one tree share an XCD (one L2).  bars: 4 words per tree + one abort word
+// for the launch, zeroed by the host.
 template <bool GEN, bool MULTI>
 __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restrict__ trees, const IlqrConst *__restrict__ consts,
                                                      int n_phases, int n_trees, int G, unsigned *__restrict__ bars) {
@@ -1332,7 +1348,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
   }
   const IlqrTreeDev T = trees[t];
   for (int ph = 0; ph < n_phases; ++ph)
-    il_fit<GEN, MULTI>(T, consts[ph], (T.stats + (size_t)ph * IL_NSTAT).p, wg, G, MULTI ? bars + 4 * t : nullptr);
+    il_fit<GEN, MULTI>(T, consts[ph], (T.stats + (size_t)ph * IL_NSTAT).p, wg, G, MULTI ? bars + 4 * t : nullptr, MULTI ? bars + 4 * n_trees : nullptr);
 }
 
 static inline size_t il_lds_bytes(int /*amax*/) {

@@ -1107,7 +1107,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   const size_t o_gx = takeD(W), o_gy = takeD(H), o_lane = takeD((size_t)n_lane_pts * 2 + 2);
   const size_t o_evx = takeD(ev ? (size_t)ev->nq * 6 : 0), o_evu = takeD(ev ? (size_t)ev->nq * 2 : 0);
   const size_t o_evn = takeI(ev ? ev->nq : 0);
-  const size_t o_bars = takeI(4 * (size_t)n_trees);   // barrier words of the multi-workgroup launch (zero at upload)
+  const size_t o_bars = takeI(4 * (size_t)n_trees + 4);   // barrier words of the multi-workgroup launch + its abort word (zero at upload)
   struct TL { size_t nodew, field, relag; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel; int M, a, nl, nseg, nsl, maxls; };
   std::vector<TL> tl(n_trees);
   long Mtot = 0;
@@ -1356,6 +1356,11 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   HIPCHK(c, hipMemcpyAsync(us, Dp(tl[0].us), (size_t)Mtot * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   if (c->profiling) HIPCHK(c, hipEventElapsedTime(&c->ilqr_ms, c->ev_il0, c->ev_il1));
+  if (multi) {
+    unsigned aborted = 0;
+    HIPCHK(c, hipMemcpy(&aborted, dBars + 4 * (size_t)n_trees, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (aborted) return fail(c, MIND_EHIP, "k_ilqr: the workgroups of a cost tree did not meet at a barrier (launch not fully resident?)");
+  }
   memcpy(xs, hx.data(), (size_t)Mtot * 6 * sizeof(double));
   memcpy(hs.data(), hx.data() + n_xs, hs.size() * sizeof(double));
   for (int ph = 0; ph < n_phases; ++ph) {
