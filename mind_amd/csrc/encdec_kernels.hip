@@ -710,12 +710,16 @@ __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*
 // =================================================================================================
 #define RA 4
 #define DEC_ACTOR_LDS_FLOATS (512 + 1536 + 3072 + 3072 + 3072 + 960 + 6144)
+// PART 0: the whole actor part.  PART 1 / 2: its two halves as separate launches -- actor_proj (128 -> 384 -> 768, needs only the
+// fused actor tokens: runs on the side stream beside k_dec_scene) writes h2g [A,768]; the head (mode embedding, reg head, Bezier)
+// reads it once k_dec_scene's Cmode / tgt are there.  Same code, same arithmetic per element in all three.
+template <int PART>
 __global__ __launch_bounds__(DT) void k_dec_actor(const float *__restrict__ x /*[tokens,128]*/,
                                                   const int *__restrict__ actor_row /*[A]*/,
                                                   const int *__restrict__ actor_scene /*[A]*/, int n_actors,
                                                   const float *__restrict__ Cmode /*[B,6,128]*/,
                                                   const float *__restrict__ tgt /*[B,128]*/,
-                                                  float *__restrict__ reg, float *__restrict__ vel, DecW W) {
+                                                  float *__restrict__ reg, float *__restrict__ vel, DecW W, float *__restrict__ h2g) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   float (*xin)[128] = (float (*)[128])(dsm);
   float (*h1)[384] = (float (*)[384])(dsm + 512);
@@ -727,19 +731,34 @@ __global__ __launch_bounds__(DT) void k_dec_actor(const float *__restrict__ x /*
   const int PF = 6144;
   const int tid = threadIdx.x;
   const int a0 = blockIdx.x * RA;
-  for (int i = tid; i < RA * 128; i += blockDim.x) {
-    const int r = i / 128, a = a0 + r;
-    xin[r][i % 128] = a < n_actors ? x[(size_t)actor_row[a] * 128 + i % 128] : 0.f;
+  if (PART != 2) {
+    for (int i = tid; i < RA * 128; i += blockDim.x) {
+      const int r = i / 128, a = a0 + r;
+      xin[r][i % 128] = a < n_actors ? x[(size_t)actor_row[a] * 128 + i % 128] : 0.f;
+    }
+    __syncthreads();
+    dense<RA>(&xin[0][0], 128, 128, W.a0W, W.a0b, 384, &h1[0][0], 384, part, PF);
+    __syncthreads();
+    ln_rows(&h1[0][0], 384, RA, 384, W.a0g, W.a0be, true);
+    __syncthreads();
+    dense<RA>(&h1[0][0], 384, 384, W.a3W, W.a3b, 768, &h2[0][0], 768, part, PF);
+    __syncthreads();
+    ln_rows(&h2[0][0], 768, RA, 768, W.a3g, W.a3be, true);
+    __syncthreads();
+    if (PART == 1) {
+      for (int i = tid; i < RA * 768; i += blockDim.x) {
+        const int r = i / 768, a = a0 + r;
+        if (a < n_actors) h2g[(size_t)a * 768 + i % 768] = h2[r][i % 768];
+      }
+      return;
+    }
+  } else {
+    for (int i = tid; i < RA * 768; i += blockDim.x) {
+      const int r = i / 768, a = a0 + r;
+      h2[r][i % 768] = a < n_actors ? h2g[(size_t)a * 768 + i % 768] : 0.f;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  dense<RA>(&xin[0][0], 128, 128, W.a0W, W.a0b, 384, &h1[0][0], 384, part, PF);
-  __syncthreads();
-  ln_rows(&h1[0][0], 384, RA, 384, W.a0g, W.a0be, true);
-  __syncthreads();
-  dense<RA>(&h1[0][0], 384, 384, W.a3W, W.a3b, 768, &h2[0][0], 768, part, PF);
-  __syncthreads();
-  ln_rows(&h2[0][0], 768, RA, 768, W.a3g, W.a3be, true);
-  __syncthreads();
   // embed = cls_embed + actor_embed (+ tgt on mode 0 only)  (network.py:506-510)
   for (int i = tid; i < RA * 768; i += blockDim.x) {
     const int r = i / 768, k = (i % 768) / 128, c = i % 128;

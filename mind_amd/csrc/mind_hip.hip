@@ -92,7 +92,8 @@ struct mind_ctx {
   DevBuf edge, x, ST, QK, part, tokpos, meta, jobs, actor_feat, lane_feat, tgt_feat, cmode, tgt_emb,
       rows, rpe_ptrs;
   // ilqr workspaces
-  DevBuf ilqr_dev, aime_dev, rebase_dev2[2];
+  DevBuf ilqr_dev, aime_dev, rebase_dev2[2], dec_h2;
+  bool dec_overlap = true;      // actor_proj of the decoder on the side stream beside k_dec_scene (mind_set_tuning("dec_overlap"))
   int rb_cur = 0, rb_gen = 0;     // re-basing arenas: which one the last call filled, its generation and geometry
   size_t rb_S = 0, rb_a = 0;
   // profiling
@@ -187,9 +188,12 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   (void)hipFuncSetAttribute((const void *)k_actor_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_mfma_lds_bytes());
   if (const char *me = getenv("MIND_ENC_MFMA")) c->enc_mfma = !(me[0] == '0');
   if (const char *de = getenv("MIND_DEC_MFMA_MIN")) c->dec_mfma_min = atoi(de);
+  if (const char *oe = getenv("MIND_DEC_OVERLAP")) c->dec_overlap = !(oe[0] == '0');
   if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
-  (void)hipFuncSetAttribute((const void *)k_dec_actor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_dec_actor<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_dec_actor<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_dec_actor<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
   *out = c;
   return MIND_OK;
 }
@@ -199,7 +203,7 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf *bufs[] = {&c->edge, &c->x, &c->ST, &c->QK, &c->part, &c->tokpos, &c->meta, &c->jobs, &c->actor_feat,
-                    &c->lane_feat, &c->tgt_feat, &c->cmode, &c->tgt_emb, &c->rows, &c->rpe_ptrs, &c->ilqr_dev, &c->aime_dev, &c->rebase_dev2[0], &c->rebase_dev2[1]};
+                    &c->lane_feat, &c->tgt_feat, &c->cmode, &c->tgt_emb, &c->rows, &c->rpe_ptrs, &c->ilqr_dev, &c->aime_dev, &c->rebase_dev2[0], &c->rebase_dev2[1], &c->dec_h2};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (TableSet &t : c->tabs)
@@ -233,6 +237,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "enc_mfma") c->enc_mfma = value != 0;
   else if (n == "actor_split") c->actor_np = value == 3 ? 3 : 6;
   else if (n == "xcd_order") c->xcd_order = value != 0;
+  else if (n == "dec_overlap") c->dec_overlap = value != 0;
   else if (n == "ilqr_wgs") c->ilqr_wgs = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (n == "ilqr_multi_min") c->ilqr_multi_min = value;
   else return fail(c, MIND_EINVAL, "mind_set_tuning: unknown knob '%s'", name);
@@ -980,14 +985,30 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   const int *d_actor_row = (const int *)ts->rows.p;
   const int *d_actor_scene = d_actor_row + A;
   const int *d_cls_row = d_actor_row + 2 * A;
+  // the actor part's first half (actor_proj: 85 % of its weights) needs only the fused actor tokens: it runs on the side stream
+  // beside k_dec_scene, the head follows both on the context stream (bit-identical to the one-kernel form)
+  const bool fp32_dec = c->pair_prec == 0 || !c->enc_mfma || A < c->dec_mfma_min;
+  const bool split_dec = fp32_dec && c->side && c->dec_overlap;
+  if (split_dec) {
+    if ((rc = ensure(c, c->dec_h2, (size_t)A * 768 * sizeof(float)))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_main, st));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0));
+    hipLaunchKernelGGL(k_dec_actor<1>, dim3((A + RA - 1) / RA), dim3(DT), mind_dec_actor_lds_bytes(), c->side, x, d_actor_row, d_actor_scene, A,
+                       (const float *)nullptr, (const float *)nullptr, (float *)nullptr, (float *)nullptr, c->decW, (float *)c->dec_h2.p);
+    HIPCHK(c, hipEventRecord(c->ev_side, c->side));
+  }
   hipLaunchKernelGGL(k_dec_scene, dim3(Bn), dim3(DT), mind_dec_scene_lds_bytes(), st, x, d_cls_row, (const float *)c->tgt_feat.p, in->tgt_rpe,
                      (float *)c->cmode.p, (float *)c->tgt_emb.p, out->cls, c->decW);
   // actor part of the decoder: the K-split fp32 kernel (a handful of workgroups, bound by the latency of one pass over the weights:
   // 62 us at 40 agents), or -- opt-in, mind_set_tuning("dec_mfma_min") -- the MFMA kernel (16 agents per workgroup: 104 us at 40
   // agents, 209 vs 277 us at 13.8 k).  Off by default: a plan's result must not depend on what else is in the batch.
-  if (c->pair_prec == 0 || !c->enc_mfma || A < c->dec_mfma_min)
-    hipLaunchKernelGGL(k_dec_actor, dim3((A + RA - 1) / RA), dim3(DT), mind_dec_actor_lds_bytes(), st, x, d_actor_row, d_actor_scene, A,
-                       (const float *)c->cmode.p, (const float *)c->tgt_emb.p, out->reg, out->vel, c->decW);
+  if (split_dec) {
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_side, 0));
+    hipLaunchKernelGGL(k_dec_actor<2>, dim3((A + RA - 1) / RA), dim3(DT), mind_dec_actor_lds_bytes(), st, x, d_actor_row, d_actor_scene, A,
+                       (const float *)c->cmode.p, (const float *)c->tgt_emb.p, out->reg, out->vel, c->decW, (float *)c->dec_h2.p);
+  } else if (fp32_dec)
+    hipLaunchKernelGGL(k_dec_actor<0>, dim3((A + RA - 1) / RA), dim3(DT), mind_dec_actor_lds_bytes(), st, x, d_actor_row, d_actor_scene, A,
+                       (const float *)c->cmode.p, (const float *)c->tgt_emb.p, out->reg, out->vel, c->decW, (float *)nullptr);
   else if (c->pair_prec == 1 && c->actor_np == 6)
     hipLaunchKernelGGL(k_dec_actor_mfma<6>, dim3((A + DM_RA - 1) / DM_RA), dim3(DM_T), mind_dec_actor_mfma_lds_bytes(), st, x, d_actor_row,
                        d_actor_scene, A, (const float *)c->cmode.p, (const float *)c->tgt_emb.p, out->reg, out->vel, c->decBW);

@@ -200,3 +200,18 @@ def test_decoder_actor_part_on_the_mfma_kernel(a, l, B, seed, hip_predictor, for
         assert np.abs(vel[b * a:(b + 1) * a] - ov[b].numpy()).max() < TOL
     assert (out["reg"] - ref["reg"]).abs().max().item() < 5e-5
     assert not torch.equal(out["reg"], ref["reg"])          # it really was the other kernel
+
+
+@pytest.mark.parametrize("a,l,B,seed", [(3, 4, 1, 1), (17, 30, 3, 4), (40, 55, 2, 1)])
+def test_decoder_halves_on_two_streams_are_bit_identical(a, l, B, seed, hip_predictor):
+    """The decoder's actor part as two launches (actor_proj on the side stream beside k_dec_scene, then the head on the context
+    stream: the default) against the one-kernel form: same code per element, identical bits, also when called back to back."""
+    pb = predictor_batch(a, l, B, seed=seed)
+    two = [hip_predictor.predict_numpy_batch(pb) for _ in range(2)]
+    try:
+        hip_predictor.set_tuning("dec_overlap", 0)
+        one = hip_predictor.predict_numpy_batch(pb)
+    finally:
+        hip_predictor.set_tuning("dec_overlap", 1)
+    for k in ("cls", "reg", "vel"):
+        assert torch.equal(two[0][k], one[k]) and torch.equal(two[1][k], one[k]), k
