@@ -343,3 +343,69 @@ def test_child_scene_views_equal_the_reference_concatenation():
             assert np.array_equal(c[k], w[:, :72]) and np.array_equal(hist_rows(c, k, 22, 72), w[:, 22:72])
         with pytest.raises(KeyError):
             c["MISSING"]
+
+
+def test_device_window_bookkeeping_and_lazy_host_windows():
+    """_update_obser_device_windows (re-basing windows cut out on the device): with a stand-in runtime that only records what it is
+    asked, the request must name the right parent slots / row offsets / durations, and the DevScenes it returns must hold, lazily,
+    exactly the windows the host path uploads (ChildScene.window6), the right cov_last and history length -- and chain: a
+    grandchild built on a lazy DevScene sees the same parent history as one built on uploaded windows."""
+    import torch
+    from types import SimpleNamespace
+    from mind_amd.planners.mind.configs.planning._base import ScenTreeCfg
+    from mind_amd.planners.mind.scenario_tree import ChildScene, DevScene, ScenarioTreeGenerator, cov_last_of, hist_len
+    rng = np.random.default_rng(9)
+    a, o = 5, 50
+    gen = ScenarioTreeGenerator(torch.device("cpu"), None, 50, 60, ScenTreeCfg())
+    gen.target_lane = np.stack([np.arange(40, dtype=np.float32), np.zeros(40, np.float32)], 1)
+    gen.target_lane_info = np.zeros((40, 12), np.float32)
+    gen.lane_graph = {"lane_ctrs": np.zeros((3, 2), np.float32), "lane_vecs": np.ones((3, 2), np.float32)}
+    types = np.zeros((a, 50, 7), np.float32)
+    calls = []
+
+    class FakeRT:
+        _rebase_gen = 7
+
+        def aime_rebase(self, pos, ang, vel, types_, lc, lv, tl, ti, time_ahead=5.0, dev_src=None, **kw):
+            calls.append(dev_src)
+            S = len(dev_src["parent_slot"])
+            self._rebase_gen += 1
+            return {"frames": torch.zeros(S, 28), "gen": self._rebase_gen}
+    rt = FakeRT()
+    prev_dev = {"gen": 7, "a": a, "l": 3}
+    parents = []
+    for g in range(3):                                   # three parents re-based by "the previous call" (host windows known)
+        w6 = rng.standard_normal((a, 50, 6)).astype(np.float32)
+        p = DevScene(gen, prev_dev, g, {"TRAJS_POS_HIST": w6[:, :, 0:2], "TRAJS_VEL_HIST": w6[:, :, 2:4], "TRAJS_ANG_HIST": w6[:, :, 4],
+                                        "TRAJS_COV_HIST": w6[:, :, 5:6], "TRAJS_TYPE": types, "SCEN_ID": f"p{g}"})
+        p._win6 = w6
+        parents.append(p)
+    rows_dev = object()                                  # stands for the device tensor of the round's kept rows
+    curs, want = [], []
+    for j, (pg, dur) in enumerate(((2, 4), (0, 30), (2, 60), (1, 1))):
+        new = rng.standard_normal((a, 60, 6)).astype(np.float32)
+        c = ChildScene({"CUR_T": 0, "END_T": dur, "SCEN_PROB": np.float32(0.5), "SCEN_ID": f"c{j}", "PARENT_ID": f"p{pg}", "TRAJS_TYPE": types,
+                        "TRAJS_TID": None, "TRAJS_CAT": None}, parents[pg], new, 110)
+        c.dev_rows, c.row0 = rows_dev, j * a
+        curs.append(c)
+        want.append(np.concatenate([parents[pg]._win6, new], axis=1)[:, dur:dur + 50])
+    out = gen._update_obser_device_windows(curs, rt)
+    assert out is not None and len(calls) == 1
+    src = calls[0]
+    assert src["rows"] is rows_dev and src["gen"] == 7 and src["a"] == a
+    assert list(src["parent_slot"]) == [2, 0, 2, 1] and list(src["row0"]) == [0, a, 2 * a, 3 * a] and list(src["dur"]) == [4, 30, 60, 1]
+    for (obs, cur), w, c in zip(out, want, curs):
+        assert cur is c and obs.lazy is not None and hist_len(obs) == 50 and not dict.__contains__(obs, "TRAJS_POS_HIST")
+        assert np.array_equal(cov_last_of(obs), w[:, -1, 5])
+        assert "TRAJS_POS_HIST" in obs and np.array_equal(obs["TRAJS_POS_HIST"], w[:, :, 0:2]) and np.array_equal(obs["TRAJS_ANG_HIST"], w[:, :, 4])
+        assert np.array_equal(obs["TRAJS_VEL_HIST"], w[:, :, 2:4]) and np.array_equal(obs["TRAJS_COV_HIST"], w[:, :, 5:6])
+        assert obs["CUR_T"] == c["END_T"] and obs.g == curs.index(c)
+    # a grandchild of a lazily held scene: its window is cut out of the same parent history
+    lazy_parent = out[0][0]
+    assert gen._update_obser_device_windows(curs[:1], rt) is None          # the parents' arena is two calls old by now
+    new = rng.standard_normal((a, 60, 6)).astype(np.float32)
+    gc = ChildScene({"CUR_T": 4, "END_T": 14}, lazy_parent, new, 110)
+    assert hist_len(gc) == 110 and np.array_equal(gc.window6(10, 60), np.concatenate([want[0], new], axis=1)[:, 10:60])
+    # not applicable: a parent that is not a re-based scene, or a stale generation -> None (the caller uploads the windows)
+    rt._rebase_gen = 99
+    assert gen._update_obser_device_windows(curs, rt) is None
