@@ -197,6 +197,7 @@ class ScenarioTreeGenerator:
         self.tree = Tree()
         self.lane_feat_cache = None
         self._plan_round = 0
+        self._root_todo = None
 
     def set_target_lane(self, target_lane, target_lane_info):
         self.target_lane = np.asarray(target_lane).astype(F32) if np.asarray(target_lane).dtype != np.float64 \
@@ -223,12 +224,19 @@ class ScenarioTreeGenerator:
         return self.get_scenario_tree()
 
     def init_scenario_tree(self, root):
-        self.prepare_root_data(root)
+        # prepare_root_data (the root's world-frame histories: read by prune_merge, not by the predictor) runs while the first
+        # predictor call is in flight (expand -> _finish_root)
+        self._root_todo = root
         self.tree.add_node(Node("root", None, ScenarioData(None, root, branch_flag=True)))
         self.create_nodes(self.expand([root]))
         self.decide_branch()
 
     HDR = 25      # per kept child: [scene index in the round, mode, path probability, TGT_PTS (11 x 2)]
+
+    def _finish_root(self):
+        root, self._root_todo = getattr(self, "_root_todo", None), None
+        if root is not None:
+            self.prepare_root_data(root)
 
     def expand(self, batch):
         """One AIME round: predict + prune/merge every scene of the branch set, then build the child dicts.  With a
@@ -238,15 +246,19 @@ class ScenarioTreeGenerator:
         scene, on rank 0) is followed by a broadcast of LaneNet's output, which every later round reuses."""
         sh = self.shard
         if sh is None or sh.world == 1:
-            hdr, rows = self.prune_select(batch, self.predict_scenes(batch) if batch else None, 0)
+            pred = self.predict_scenes(batch) if batch else None
+            self._finish_root()
+            hdr, rows = self.prune_select(batch, pred, 0)
             return self.assemble_children(batch, hdr, _np(rows), rows if isinstance(rows, torch.Tensor) and rows.is_cuda else None)
         lo, hi = sh.block(len(batch))
         mine = batch[lo:hi]
         assert not any(isinstance(s, RemoteScene) for s in mine), "a rank was dealt a scene it did not re-base"
         first_round = self._plan_round == 0
         self._plan_round += 1
+        pred = self.predict_scenes(mine) if mine else None
+        self._finish_root()
         if mine:
-            hdr, rows = self.prune_select(mine, self.predict_scenes(mine), lo)
+            hdr, rows = self.prune_select(mine, pred, lo)
         else:
             hdr, rows = np.zeros((0, self.HDR), F32), torch.zeros(0, 60, 6)
         if first_round:
