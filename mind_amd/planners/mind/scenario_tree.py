@@ -590,7 +590,18 @@ class ScenarioTreeGenerator:
         if not picks:
             return np.zeros((0, self.HDR), F32), torch.zeros(0, 60, 6, device=dev)
         flat = np.concatenate([np.arange(a_off[l], a_off[l + 1]) * 6 + k for l, k, _ in picks])       # (agent row, mode) -> row of [A*6]
-        rows = w["world"].view(A * 6, 60, 6).index_select(0, torch.from_numpy(flat).to(dev))           # [R,60,6] (x,y,vx,vy,heading,max-sigma)
+        idx = torch.from_numpy(flat).to(dev)
+        if self.device_windows:
+            # the kept rows stay on the device until the next re-basing cuts the children's windows out of them: they go into one
+            # of two persistent buffers of the runtime (alternating by round) instead of a fresh allocator block -- holding
+            # allocator blocks across rounds pushed the caching allocator into its slow path (hipMalloc) every plan
+            bufs = rt.__dict__.setdefault("_rows_bufs", [None, None])
+            k = rt.__dict__["_rows_turn"] = 1 - rt.__dict__.get("_rows_turn", 0)
+            if bufs[k] is None or bufs[k].shape[0] < len(flat):
+                bufs[k] = torch.empty(max(len(flat), 2 * (0 if bufs[k] is None else bufs[k].shape[0])), 60, 6, device=dev)
+            rows = torch.index_select(w["world"].view(A * 6, 60, 6), 0, idx, out=bufs[k][:len(flat)])
+        else:
+            rows = w["world"].view(A * 6, 60, 6).index_select(0, idx)           # [R,60,6] (x,y,vx,vy,heading,max-sigma)
         return self._hdr(picks, scenes, idx_offset), rows
 
     def prune_select(self, scenes, out, idx_offset=0, packed=None):
