@@ -182,9 +182,11 @@ class ScenarioTreeGenerator:
         self.ego_idx = 0
         self.device_glue = True     # prune_merge arithmetic on the device when the network leaves its outputs there
         # re-basing windows of the kept modes cut out of the device-resident rows (mind_aime_rebase device source) instead of stacked
-        # and uploaded: bit-identical, but measured no faster on the full cfg4 tree (the call then stalls on entry for as long as
-        # the host-side window building took) -- off unless MIND_DEVICE_WINDOWS=1
-        self.device_windows = os.environ.get("MIND_DEVICE_WINDOWS", "0") == "1"
+        # and uploaded: bit-identical; - 5 ms per cfg4 plan when the planner's context stream is a non-blocking stream, but on the
+        # legacy default stream the call stalls on entry for longer than the host-side window building took.  None =
+        # decide by the runtime's stream; MIND_DEVICE_WINDOWS=0/1 forces it
+        env = os.environ.get("MIND_DEVICE_WINDOWS")
+        self.device_windows = None if env is None else env == "1"
         self.device_select = True   # ... and its pruning decisions (k_aime_select); False: decided on the host from the device's signatures
         self.branch_depth = 0
         self.n_expanded = 0           # scenes pushed through the predictor (metric: nodes expanded)
@@ -232,6 +234,13 @@ class ScenarioTreeGenerator:
         self.decide_branch()
 
     HDR = 25      # per kept child: [scene index in the round, mode, path probability, TGT_PTS (11 x 2)]
+
+    def _use_device_windows(self, rt, n_scenes):
+        """device-side window assembly for this round?  Forced by MIND_DEVICE_WINDOWS / the attribute; otherwise only on a
+        non-default context stream and for rounds of >= 16 kept modes (a handful of windows upload faster than they pay)"""
+        if self.device_windows is not None:
+            return self.device_windows
+        return n_scenes >= 16 and not getattr(rt, "on_default_stream", True)
 
     def _finish_root(self):
         root, self._root_todo = getattr(self, "_root_todo", None), None
@@ -591,7 +600,7 @@ class ScenarioTreeGenerator:
             return np.zeros((0, self.HDR), F32), torch.zeros(0, 60, 6, device=dev)
         flat = np.concatenate([np.arange(a_off[l], a_off[l + 1]) * 6 + k for l, k, _ in picks])       # (agent row, mode) -> row of [A*6]
         idx = torch.from_numpy(flat).to(dev)
-        if self.device_windows:
+        if self._use_device_windows(rt, len(picks)):
             # the kept rows stay on the device until the next re-basing cuts the children's windows out of them: they go into one
             # of two persistent buffers of the runtime (alternating by round) instead of a fresh allocator block -- holding
             # allocator blocks across rounds pushed the caching allocator into its slow path (hipMalloc) every plan
@@ -821,7 +830,7 @@ class ScenarioTreeGenerator:
             return [self.update_obser(c) for c in curs]
         o = self.obs_len
         G = len(curs)
-        if on_dev and self.device_windows:
+        if on_dev and self._use_device_windows(rt, len(curs)):
             dev_out = self._update_obser_device_windows(curs, rt)
             if dev_out is not None:
                 return dev_out

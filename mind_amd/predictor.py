@@ -91,6 +91,9 @@ class HipPredictor:
         torch.cuda.set_device(self.device)
         self.ctx = C.c_void_p()
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        # the legacy default stream couples every synchronisation and kernel of this context to the other streams of the process
+        # (measured: the device-side window assembly of mind_aime_rebase then stalls for 10-25 ms on entry)
+        self.on_default_stream = int(stream or 0) == 0
         rc = self.lib.mind_ctx_create(self.device.index, C.c_void_p(stream), C.byref(self.ctx))
         _lib.check(self.lib, None, rc, "mind_ctx_create")
         self._keep = []
