@@ -32,7 +32,7 @@
 #define IL_MAXA 128   // agents per scene staged in LDS (cfg4: 64, stress: 128)
 #define IL_REL 15     // relevant-agent list length per node
 #define IL_RA 64      // doubles per node in T.relag: (1 + IL_REL) records x 4
-#define IL_SCR 208    // doubles of per-wave LDS scratch (Riccati operands 0..190, constants 192..204)
+#define IL_SCR 288    // doubles of per-wave LDS scratch (Riccati operands 0..190, constants 192..204, dump slots 208..287)
 #define IL_CST 192    // scr[IL_CST..+6) = {1,0,0,0,0,0}, scr[IL_CST+6..+12) = {dt,0,0,0,0,0}
 #define IL_LSUM 2048   // doubles of LDS used to stage the cost sums
 #define IL_RMARGIN 3.0  // [m] the list is exact for queries within this distance of the nominal state
@@ -370,120 +370,166 @@ __device__ double il_np_sum(const double *a, long n) {
   return il_np_sum(a, n2) + il_np_sum(a + n2, n - n2);
 }
 
-// Riccati step for one node, cooperative over one wave (solver.py:352-421).  On entry scr holds the
-// children-summed value function (Vxx at scr+36, Vx at scr+176); on exit it holds this node's value
-// function in the same place (so a chain is walked without touching global memory for V).
-// Returns (wave-uniform) 1 if Q_uu is singular.
-// pre_*: this node's Fx[lane], Lxx[lane] (lanes < 36), Lx[lane-36] (lanes 36..41), controls and control
-// weights (w_ctrl x prob), loaded by the caller one node ahead so that the global-memory latency overlaps
-// the previous node's algebra.
-// All first-stage products (F_x^T V_xx, Q_x, Q_ux, Q_uu, Q_u) are ONE instruction stream: every lane runs the
-// same six-term sum  s += (sc * (A[r] + add_r)) * B[r]  over its own LDS operands (role-dependent code would be
-// serialised by the SIMT hardware); sc = 1 / add = 0 / B = {c,0,0,0,0,0} reproduce the shorter expressions bit for bit.
-__device__ __forceinline__ int il_gains(const IlqrConst &C, const IlqrTreeDev &T, int key, double mu, double *scr,
-                                        double pre_fx, double pre_lxx, double pre_lx, double pre_u0, double pre_u1, double pre_wc0, double pre_wc1 IL_PROF_ARG) {
+// ---- Riccati sweep of one chain segment, one wave (solver.py:344-421) -----------------------------------------------------
+// Per-wave LDS scratch (doubles): fx 0 | Vxx 36 | Tm 72 | Vr 108 (dt (V_xx[4+a][r] + mu [r == 4+a]), a < 2) | Vxr 120 (dt V_x[4+a]) |
+// U 124 (2 x 7: Q_ux rows with Q_u in column 6) | KK 138 (2 x 7: K rows with k in column 6) | Quu 152 | Vx 176 | constants IL_CST |
+// dump slots IL_DMP.. (lanes without a result write there: the node body has no branches).
+#define IL_U 124
+#define IL_KK 138
+#define IL_QUU 152
+#define IL_DMP 208
+// The node step is ONE straight-line instruction stream for all 64 lanes: roles differ only in the LDS addresses and constants of a
+// per-lane plan that is built once per segment (role-dependent CODE is serialised by the SIMT hardware, and the branches around
+// it keep the compiler from overlapping the LDS reads, the 2x2 solves and the products).  Arithmetic per entry is the oracle's:
+//   stage 1, every lane  s = sum_r A_r B_r  (six terms, r ascending), result = addend + s:
+//     T = F_x^T V_xx (36 lanes), Q_x = l_x + F_x^T V_x (6), Q_ux = f_u^T (V_xx + mu I) F_x (12; f_u^T picks rows 4, 5 scaled by dt:
+//     the scaled, regularised rows Vr are written by the lanes that produce V_xx), Q_uu = l_uu + f_u^T (V_xx + mu I) f_u (4),
+//     Q_u = l_u + f_u^T V_x (2); the terms the oracle multiplies by an exact 0 / 1 constant are kept as such (B = {dt,0,..} / {1,0,..});
+//   stage 2  Q_xx = l_xx + T F_x; 2x2 solves with partial pivoting (LAPACK dgesv order), every lane owns one right-hand side;
+//   value update V = Q + K^T Q_uu K + K^T Q_u. + Q_.u K (V_xx lanes and V_x lanes in one stream), symmetrisation, 0 + V.
+// On entry scr holds the children-summed value function (V_xx at 36, V_x at 176); on exit the value function of the segment's
+// head node.  Per-node operands (F_x, l_xx, l_x, controls, control weights) are requested one node ahead, the node index two
+// ahead.  Returns (wave-uniform) 1 if a Q_uu is singular.
+template <bool GEN>
+__device__ __forceinline__ int il_backward_segment(const IlqrConst &C, const IlqrTreeDev &T, const IlqrTreeDev &Ts, int s0, int s1,
+                                                   double mu, double *scr IL_PROF_ARG) {
   const int lane = threadIdx.x & 63;
-  IL_PT0();
-  const int i = lane / 6, j = lane % 6;   // lanes 0..35 <-> (i,j)
-  // scr offsets: fx 0, Vxx 36, Tm 72, Qxx 108, Qux 144, Kk 156, Qx 170, Vx 176, misc 182 (Qu[2], Quu[4], k[2])
-  double *fx = scr, *Vxx = scr + 36, *Tm = scr + 72, *Qxx = scr + 108, *Qux = scr + 144, *Kk = scr + 156;
-  double *Vx = scr + 176, *misc = scr + 182;
+  const int i = lane / 6, j = lane % 6;
+  const bool mat = lane < 36, vxl = lane >= 36 && lane < 42;
   const double dt = C.dt;
-  // ---- per-lane operand description of the first stage
-  int ao, as, bo, bs, radd = -1, dst;
-  double sc = 1.0, addend = 0.0;
-  if (lane < 36) {                    // T = F_x^T V_xx
-    ao = i; as = 6; bo = 36 + j; bs = 6; dst = 72 + lane;
-  } else if (lane < 42) {             // Q_x = l_x + F_x^T V_x
-    ao = lane - 36; as = 6; bo = 176; bs = 1; dst = 170 + (lane - 36); addend = pre_lx;
-  } else if (lane < 54) {             // Q_ux = f_u^T (V_xx + mu I) f_x ; f_u^T picks rows 4,5 scaled by dt
-    const int a = (lane - 42) / 6, jj = (lane - 42) % 6;
-    ao = 36 + (4 + a) * 6; as = 1; bo = jj; bs = 6; dst = 144 + (lane - 42); sc = dt; radd = 4 + a;
-  } else if (lane < 58) {             // Q_uu = l_uu + f_u^T (V_xx + mu I) f_u
-    const int a = (lane - 54) / 2, b = (lane - 54) % 2;
-    ao = 36 + (4 + a) * 6 + 4 + b; as = 0; bo = IL_CST + 6; bs = 1; dst = 182 + 2 + (lane - 54); sc = dt;
-    radd = a == b ? 0 : -1;
-    addend = a == b ? 2.0 * (a == 0 ? pre_wc0 : pre_wc1) : 0.0;
-  } else if (lane < 60) {             // Q_u = l_u + f_u^T V_x
-    const int a = lane - 58;
-    ao = 176 + 4 + a; as = 0; bo = IL_CST; bs = 1; dst = 182 + a; sc = dt;
-    addend = 2.0 * ((a == 0 ? pre_wc0 : pre_wc1) * (a == 0 ? pre_u0 : pre_u1));
-  } else {
-    ao = 0; as = 0; bo = IL_CST + 1; bs = 0; dst = 0;
-  }
-  if (lane < 36) fx[lane] = pre_fx;
-  IL_WFENCE();
+  // ---- per-lane plan
+  int a_off, a_str, b_off, b_str, dst1, kind = 0, asel = 0;     // kind: 1 l_x, 2 l_uu diagonal, 3 l_u
+  if (mat) { a_off = i; a_str = 6; b_off = 36 + j; b_str = 6; dst1 = 72 + lane; }
+  else if (vxl) { a_off = lane - 36; a_str = 6; b_off = 176; b_str = 1; dst1 = IL_DMP + lane; kind = 1; }
+  else if (lane < 54) { const int a = (lane - 42) / 6, jj = (lane - 42) % 6; a_off = 108 + a * 6; a_str = 1; b_off = jj; b_str = 6; dst1 = IL_U + a * 7 + jj; }
+  else if (lane < 58) { const int a = (lane - 54) / 2, b = (lane - 54) % 2; a_off = 108 + a * 6 + 4 + b; a_str = 0; b_off = IL_CST + 6; b_str = 1;
+                        dst1 = IL_QUU + (lane - 54); kind = a == b ? 2 : 0; asel = a; }
+  else if (lane < 60) { const int a = lane - 58; a_off = 120 + a; a_str = 0; b_off = IL_CST; b_str = 1; dst1 = IL_U + a * 7 + 6; kind = 3; asel = a; }
+  else { a_off = 0; a_str = 0; b_off = IL_CST + 1; b_str = 0; dst1 = IL_DMP + lane; }
+  int t_off = 72 + (mat ? i * 6 : 0), f_off = mat ? j : 0;                 // stage 2
+  int rho = lane < 7 ? lane : 6, rho_w = lane < 7 ? IL_KK + lane : IL_DMP + lane;   // solve: right-hand side / result column
+  int jx = mat ? j : 6, ix = mat ? i : (vxl ? lane - 36 : 0);              // value update: columns of K / Q_ux (6 = k / Q_u)
+  int tm_w = mat ? 72 + lane : IL_DMP + lane, tm_r = mat ? 72 + j * 6 + i : IL_DMP + lane;
+  int v_dst = mat ? 36 + lane : (vxl ? 176 + (lane - 36) : IL_DMP + lane);
+  int vr_dst = (mat && i >= 4) ? 108 + (i - 4) * 6 + j : ((vxl && lane >= 40) ? 120 + (lane - 40) : IL_DMP + lane);
+  int fx_dst = mat ? lane : IL_DMP + lane;
+  double madd = (mat && i >= 4 && i == j) ? mu : 0.0;
+  // per-lane global pointers (VGPRs: the tree struct's base pointers would be re-read from spilled SGPRs in every node):
+  // this lane's entry of F_x / l_xx / l_x, the controls, the node weights, where this lane's gains go
+  const int lfx = mat ? lane : 35, llx = vxl ? lane - 36 : 0;
+  const double IL_AS1 *pFx = T.Fx.g() + lfx, *pLxx = T.Lxx.g() + lfx, *pLx = T.Lx.g() + llx, *pUs = T.us.g();
+  const float IL_AS1 *pProb = T.prob.g();
+  const double IL_AS1 *pNw = GEN ? T.node_w.g() + 24 : nullptr;
+  const int IL_AS1 *pSeg = T.seg_nodes.g();
+  double IL_AS1 *pGa = lane < 6 ? Ts.K.g() + lane : Ts.k.g();        // K column `lane` (rows 6 apart) | k
+  int ga_str = lane < 6 ? 12 : 2, ga_row = lane < 6 ? 6 : 1;
+  // the plan is opaque to the optimiser: it must stay in registers over the node loop instead of being rebuilt per node
+  asm volatile("" : "+v"(a_off), "+v"(a_str), "+v"(b_off), "+v"(b_str), "+v"(dst1), "+v"(t_off), "+v"(f_off), "+v"(rho), "+v"(rho_w));
+  long long mk1 = kind == 1 ? -1ll : 0ll, mk2 = kind == 2 ? -1ll : 0ll, mk3 = kind == 3 ? -1ll : 0ll;     // addend selection masks
+  asm volatile("" : "+v"(jx), "+v"(ix), "+v"(tm_w), "+v"(tm_r), "+v"(v_dst), "+v"(vr_dst), "+v"(fx_dst), "+v"(madd), "+v"(asel));
+  asm volatile("" : "+v"(mk1), "+v"(mk2), "+v"(mk3));
+  asm volatile("" : "+v"(pFx), "+v"(pLxx), "+v"(pLx), "+v"(pUs), "+v"(pProb), "+v"(pSeg), "+v"(pGa), "+v"(ga_str), "+v"(ga_row));
+  // ---- regularised, scaled rows of the entry value function
   {
-    double s = 0.0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const double R = sc * (scr[ao + r * as] + (r == radd ? mu : 0.0));
-      s += R * scr[bo + r * bs];
+    const double vin = scr[v_dst];
+    IL_WFENCE();
+    scr[vr_dst] = dt * (vin + madd);
+    IL_WFENCE();
+  }
+  struct Pre { double fx, lxx, lx, u0, u1, w0, w1; };
+  auto request = [&](int c, Pre &P) {
+    P.fx = pFx[(size_t)c * 36];
+    P.lxx = pLxx[(size_t)c * 36];
+    P.lx = pLx[(size_t)c * 6];
+    const il_d2 u = *(const il_d2 IL_AS1 *)(pUs + (size_t)c * 2);
+    P.u0 = u.x; P.u1 = u.y;
+    if (GEN) { P.w0 = pNw[(size_t)c * IL_NW]; P.w1 = pNw[(size_t)c * IL_NW + 1]; }
+    else { const double pp = (double)pProb[c]; P.w0 = C.w_ctrl[0] * pp; P.w1 = C.w_ctrl[1] * pp; }
+  };
+  int r = s1 - 1;
+  int c = __builtin_amdgcn_readfirstlane(pSeg[r]);
+  int cn_v = pSeg[r > s0 ? r - 1 : r];          // node indices travel two nodes ahead, in a VGPR until they are needed
+  Pre P, N;
+  request(c, P);
+  // gains of the node before (loads and stores share one in-order counter: a store issued at the end of a node would be waited for at
+  // the top of the next one, so it is issued behind the next node's loads instead and has a whole node to retire)
+  double g0 = 0.0, g1 = 0.0;
+  int gc = c;
+  for (; r >= s0; --r) {
+    IL_PT0();
+    const int cn = __builtin_amdgcn_readfirstlane(cn_v);
+    cn_v = pSeg[r - 2 >= s0 ? r - 2 : s0];
+    request(cn, N);
+    if (lane < 7 && r != s1 - 1) {      // gains to global memory: K columns (lanes 0..5), k (lane 6)
+      double IL_AS1 *g = pGa + (size_t)gc * ga_str;
+      g[0] = g0; g[ga_row] = g1;
     }
-    IL_WFENCE();                      // all operands read before the results overwrite Tm / Qux / misc
-    if (lane < 60) scr[dst] = addend + s;
-  }
-  IL_WFENCE();
-  IL_PT(6);
-  if (lane < 36) {
+    // ---- stage 1
+    scr[fx_dst] = P.fx;
+    const double wsel = asel ? P.w1 : P.w0, usel = asel ? P.u1 : P.u0;
+    double ad2 = 2.0 * wsel, ad3 = 2.0 * (wsel * usel);
+    // every lane computes both, then picks by bit masks: no branches in the body
+    const double addend = __longlong_as_double((__double_as_longlong(P.lx) & mk1) | (__double_as_longlong(ad2) & mk2) | (__double_as_longlong(ad3) & mk3));
+    IL_WFENCE();
     double s = 0.0;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) s += Tm[i * 6 + r] * fx[r * 6 + j];
-    Qxx[lane] = pre_lxx + s;
-  }
-  IL_PT(7);
-  // 2x2 solves with partial pivoting (LAPACK dgesv order): lanes 0..6 each own one right-hand side
-  int singular = 0;
-  {
-    double a00 = misc[2], a01 = misc[3], a10 = misc[4], a11 = misc[5];
+    for (int q = 0; q < 6; ++q) s += scr[a_off + q * a_str] * scr[b_off + q * b_str];
+    const double r1 = addend + s;
+    IL_WFENCE();                      // all operands read before the results overwrite Tm / U / Quu
+    scr[dst1] = r1;
+    IL_WFENCE();
+    IL_PT(6);
+    // ---- stage 2: Q_xx (V_xx lanes; the others compute a value nobody reads)
+    double qb = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) qb += scr[t_off + q] * scr[f_off + q * 6];
+    qb = P.lxx + qb;
+    asm volatile("" : "+v"(qb));
+    qb = mat ? qb : r1;                // V_x lanes: Q_x
+    IL_PT(7);
+    // ---- 2x2 solves: every lane factorises Q_uu, lanes 0..6 own the right-hand sides (Q_ux columns, Q_u)
+    const double q00 = scr[IL_QUU], q01 = scr[IL_QUU + 1], q10 = scr[IL_QUU + 2], q11 = scr[IL_QUU + 3];
+    double a00 = q00, a01 = q01, a10 = q10, a11 = q11;
+    double b0 = scr[IL_U + rho], b1 = scr[IL_U + 7 + rho];
     const bool swp = fabs(a10) > fabs(a00);
-    if (swp) { double t = a00; a00 = a10; a10 = t; t = a01; a01 = a11; a11 = t; }
+    if (swp) { double t = a00; a00 = a10; a10 = t; t = a01; a01 = a11; a11 = t; t = b0; b0 = b1; b1 = t; }
     const double l = a10 / a00;
     const double u11 = a11 - l * a01;
-    singular = (a00 == 0.0) || (u11 == 0.0);
-    if (lane < 7 && !singular) {
-      double b0 = lane < 6 ? Qux[lane] : misc[0];
-      double b1 = lane < 6 ? Qux[6 + lane] : misc[1];
-      if (swp) { double t = b0; b0 = b1; b1 = t; }
-      b1 = b1 - l * b0;
-      const double x1 = b1 / u11;
-      const double x0 = (b0 - a01 * x1) / a00;
-      if (lane < 6) { Kk[lane] = -x0; Kk[6 + lane] = -x1; }
-      else { misc[6] = -x0; misc[7] = -x1; }
-    }
-  }
-  IL_WFENCE();
-  IL_PT(8);
-  if (singular) return 1;
-  // ---- value update, V_xx (lanes < 36) and V_x (lanes 36..41, the "k column") in one stream:
-  //      V = Q + K^T Q_uu K + K^T Q_u. + Q_.u K   with (K_j, Q_ux_j, Q) -> (k, Q_u, Q_x) for the V_x lanes
-  const double q00 = misc[2], q01 = misc[3], q10 = misc[4], q11 = misc[5];
-  double vnew = 0.0;
-  {
-    const bool mat = lane < 36;
-    const int ii = mat ? i : (lane < 42 ? lane - 36 : 0);
-    const double Kj0 = scr[mat ? 156 + j : 182 + 6], Kj1 = scr[mat ? 156 + 6 + j : 182 + 7];
-    const double Uj0 = scr[mat ? 144 + j : 182 + 0], Uj1 = scr[mat ? 144 + 6 + j : 182 + 1];
-    const double Qb = scr[mat ? 108 + lane : 170 + ii];
-    const double Ki0 = Kk[ii], Ki1 = Kk[6 + ii], Ui0 = Qux[ii], Ui1 = Qux[6 + ii];
+    const int singular = __builtin_amdgcn_readfirstlane((int)((a00 == 0.0) || (u11 == 0.0)));
+    b1 = b1 - l * b0;
+    const double x1 = b1 / u11;
+    const double x0 = (b0 - a01 * x1) / a00;
+    if (singular) return 1;             // (the slot is unusable: nobody reads its gains)
+    IL_WFENCE();
+    scr[rho_w] = -x0; scr[rho_w + 7] = -x1;
+    IL_WFENCE();
+    IL_PT(8);
+    // ---- value update
+    const double Kj0 = scr[IL_KK + jx], Kj1 = scr[IL_KK + 7 + jx], Uj0 = scr[IL_U + jx], Uj1 = scr[IL_U + 7 + jx];
+    const double Ki0 = scr[IL_KK + ix], Ki1 = scr[IL_KK + 7 + ix], Ui0 = scr[IL_U + ix], Ui1 = scr[IL_U + 7 + ix];
     const double QuuK0 = q00 * Kj0 + q01 * Kj1;
     const double QuuK1 = q10 * Kj0 + q11 * Kj1;
-    double v = Qb + (Ki0 * QuuK0 + Ki1 * QuuK1);
+    double v = qb + (Ki0 * QuuK0 + Ki1 * QuuK1);
     v += (Ki0 * Uj0 + Ki1 * Uj1) + (Ui0 * Kj0 + Ui1 * Kj1);
-    vnew = v;                          // lanes 36..41: the new V_x entry
-    if (mat) Tm[lane] = v;
+    IL_WFENCE();
+    scr[tm_w] = v;
+    IL_WFENCE();
+    const double vt = scr[tm_r];
+    double vs = 0.5 * (v + vt);
+    asm volatile("" : "+v"(vs));
+    const double vnew = 0.0 + (mat ? vs : v);          // parent accumulates 0 + V[child] (solver.py:349-350)
+    IL_WFENCE();
+    scr[v_dst] = vnew;
+    scr[vr_dst] = dt * (vnew + madd);
+    IL_WFENCE();
+    g0 = -x0; g1 = -x1; gc = c;
+    IL_PT(9); IL_PCNT(10);
+    P = N; c = cn;
   }
-  if (lane >= 42 && lane < 56) {       // gains to global memory: K (12) then k (2)
-    const GP<double> dstg = lane < 54 ? T.K + ((size_t)key * 12 + (lane - 42)) : T.k + ((size_t)key * 2 + (lane - 54));
-    *dstg = lane < 54 ? Kk[lane - 42] : misc[6 + (lane - 54)];
+  if (lane < 7) {
+    double IL_AS1 *g = pGa + (size_t)gc * ga_str;
+    g[0] = g0; g[ga_row] = g1;
   }
-  IL_WFENCE();
-  if (lane < 36) vnew = 0.5 * (Tm[i * 6 + j] + Tm[j * 6 + i]);
-  IL_WFENCE();
-  if (lane < 36) Vxx[lane] = 0.0 + vnew;            // parent accumulates 0 + V[child] (solver.py:349-350)
-  if (lane >= 36 && lane < 42) Vx[lane - 36] = 0.0 + vnew;
-  IL_WFENCE();
-  IL_PT(9); IL_PCNT(10);
   return 0;
 }
 
@@ -508,21 +554,10 @@ __device__ __forceinline__ void il_dyn_sc(const IlqrConst &C, const double *x, c
 // registers: the addresses are wave-uniform, every lane holds the full set.
 struct IlKv { double K[12], k[2], us[2], xs[6]; };
 
-__device__ __forceinline__ void il_prefetch_kv(const IlqrTreeDev &T, int c, IlKv &P) {
-  const auto pK = (T.K + (size_t)c * 12).as<const il_d2>();
-  const auto px = (T.xs + (size_t)c * 6).as<const il_d2>();
-#pragma unroll
-  for (int q = 0; q < 6; ++q) { const il_d2 v = pK[q]; P.K[2 * q] = v.x; P.K[2 * q + 1] = v.y; }
-#pragma unroll
-  for (int q = 0; q < 3; ++q) { const il_d2 v = px[q]; P.xs[2 * q] = v.x; P.xs[2 * q + 1] = v.y; }
-  const il_d2 vk = *(T.k + (size_t)c * 2).as<const il_d2>();
-  const il_d2 vu = *(T.us + (size_t)c * 2).as<const il_d2>();
-  P.k[0] = vk.x; P.k[1] = vk.y; P.us[0] = vu.x; P.us[1] = vu.y;
-}
-
 // Phase 1: states/controls of ALL 10 line-search candidates along one chain segment, one wave, candidate
 // a = lane % 10 (lanes >= 10 mirror lanes < 10 and do not store).  init != 0: nominal rollout (alpha = 0,
-// gains are zero).  Writes T.xs_new / T.us_new.
+// gains are zero).  Writes T.xs_new / T.us_new.  Base pointers live in VGPRs (the tree struct's would be re-read from
+// spilled SGPRs in every node), the node index travels two nodes ahead, the node's operands one node ahead.
 __device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const IlqrTreeDev &T, int seg, int init IL_PROF_ARG) {
   const int lane = threadIdx.x & 63;
   const int M = T.M;
@@ -530,22 +565,39 @@ __device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const Ilq
   const bool writer = lane < IL_NA;
   const double alpha = init ? 0.0 : C.alphas[a];
   const int s0 = T.seg_start[seg], s1 = T.seg_start[seg + 1];
-  int c = T.seg_nodes[s0];
-  const int p0 = c == 0 ? -1 : T.parent[c];      // node 0 is the only child of the x0 root (checked on the host)
+  const int IL_AS1 *pSeg = T.seg_nodes.g();
+  const double IL_AS1 *pK = T.K.g(), *pk = T.k.g(), *pUs = T.us.g(), *pXs = T.xs.g();
+  double IL_AS1 *pXn = T.xs_new.g() + (size_t)a * M * 6, *pUn = T.us_new.g() + (size_t)a * M * 2;
+  asm volatile("" : "+v"(pSeg), "+v"(pK), "+v"(pk), "+v"(pUs), "+v"(pXs), "+v"(pXn), "+v"(pUn));
+  auto prefetch = [&](int c, IlKv &P) {
+    const auto qK = (const il_d2 IL_AS1 *)(pK + (size_t)c * 12);
+    const auto qx = (const il_d2 IL_AS1 *)(pXs + (size_t)c * 6);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { const il_d2 v = qK[q]; P.K[2 * q] = v.x; P.K[2 * q + 1] = v.y; }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const il_d2 v = qx[q]; P.xs[2 * q] = v.x; P.xs[2 * q + 1] = v.y; }
+    const il_d2 vk = *(const il_d2 IL_AS1 *)(pk + (size_t)c * 2);
+    const il_d2 vu = *(const il_d2 IL_AS1 *)(pUs + (size_t)c * 2);
+    P.k[0] = vk.x; P.k[1] = vk.y; P.us[0] = vu.x; P.us[1] = vu.y;
+  };
+  int c = __builtin_amdgcn_readfirstlane(pSeg[s0]);
+  int cn_v = pSeg[s0 + 1 < s1 ? s0 + 1 : s1 - 1];
+  const int p0 = c == 0 ? -1 : __builtin_amdgcn_readfirstlane(T.parent[c]);      // node 0 is the only child of the x0 root (checked on the host)
   double xp[6], xo[6];
   if (p0 < 0) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) { xp[k] = C.x0[k]; xo[k] = C.x0[k]; }
   } else {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { xp[k] = T.xs_new[((size_t)a * M + p0) * 6 + k]; xo[k] = T.xs[(size_t)p0 * 6 + k]; }
+    for (int k = 0; k < 6; ++k) { xp[k] = pXn[(size_t)p0 * 6 + k]; xo[k] = pXs[(size_t)p0 * 6 + k]; }
   }
   IlKv Pc, Pn;
-  il_prefetch_kv(T, c, Pc);
+  prefetch(c, Pc);
   for (int q = s0; q < s1; ++q) {
     IL_PT0();
-    const int cn = q + 1 < s1 ? T.seg_nodes[q + 1] : c;
-    il_prefetch_kv(T, cn, Pn);
+    const int cn = __builtin_amdgcn_readfirstlane(cn_v);
+    cn_v = pSeg[q + 2 < s1 ? q + 2 : s1 - 1];
+    prefetch(cn, Pn);
     IL_PT(0);
     double u[2], x[6];
     if (c == 0) {
@@ -562,9 +614,9 @@ __device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const Ilq
     }
     il_dyn_sc(C, xp, u, x);
     if (writer) {
-      const auto xn = (T.xs_new + ((size_t)a * M + c) * 6).as<il_d2>();
+      const auto xn = (il_d2 IL_AS1 *)(pXn + (size_t)c * 6);
       xn[0] = il_d2{x[0], x[1]}; xn[1] = il_d2{x[2], x[3]}; xn[2] = il_d2{x[4], x[5]};
-      *(T.us_new + ((size_t)a * M + c) * 2).as<il_d2>() = il_d2{u[0], u[1]};
+      *(il_d2 IL_AS1 *)(pUn + (size_t)c * 2) = il_d2{u[0], u[1]};
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) { xp[k] = x[k]; xo[k] = Pc.xs[k]; }
@@ -1202,29 +1254,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
           else if (lane < 42) scr[176 + lane - 36] = acc;
           IL_WFENCE();
         }
-        int sing = 0;
-        double pfx = 0.0, plxx = 0.0, plx = 0.0, pu0, pu1, pw0, pw1;
-        {
-          const int c = T.seg_nodes[s1 - 1];
-          if (lane < 36) { pfx = T.Fx[(size_t)c * 36 + lane]; plxx = T.Lxx[(size_t)c * 36 + lane]; }
-          else if (lane < 42) plx = T.Lx[(size_t)c * 6 + lane - 36];
-          pu0 = T.us[(size_t)c * 2]; pu1 = T.us[(size_t)c * 2 + 1];
-          if (GEN) { pw0 = T.node_w[(size_t)c * IL_NW + 24]; pw1 = T.node_w[(size_t)c * IL_NW + 25]; }
-          else { const double pp = (double)T.prob[c]; pw0 = C.w_ctrl[0] * pp; pw1 = C.w_ctrl[1] * pp; }
-        }
-        for (int r = s1 - 1; r >= s0 && !sing; --r) {
-          double nfx = 0.0, nlxx = 0.0, nlx = 0.0, nu0 = 0.0, nu1 = 0.0, nw0 = 0.0, nw1 = 0.0;
-          if (r > s0) {
-            const int cn = T.seg_nodes[r - 1];
-            if (lane < 36) { nfx = T.Fx[(size_t)cn * 36 + lane]; nlxx = T.Lxx[(size_t)cn * 36 + lane]; }
-            else if (lane < 42) nlx = T.Lx[(size_t)cn * 6 + lane - 36];
-            nu0 = T.us[(size_t)cn * 2]; nu1 = T.us[(size_t)cn * 2 + 1];
-            if (GEN) { nw0 = T.node_w[(size_t)cn * IL_NW + 24]; nw1 = T.node_w[(size_t)cn * IL_NW + 25]; }
-            else { const double np_ = (double)T.prob[cn]; nw0 = C.w_ctrl[0] * np_; nw1 = C.w_ctrl[1] * np_; }
-          }
-          sing = il_gains(C, Ts, T.seg_nodes[r], mu, scr, pfx, plxx, plx, pu0, pu1, pw0, pw1 IL_PROF_PASS);
-          pfx = nfx; plxx = nlxx; plx = nlx; pu0 = nu0; pu1 = nu1; pw0 = nw0; pw1 = nw1;
-        }
+        const int sing = il_backward_segment<GEN>(C, T, Ts, s0, s1, mu, scr IL_PROF_PASS);
         if (sing) {
           if (lane == 0) {
             if (MULTI) __hip_atomic_fetch_or(&bar[2 + (n_pass & 1)], 1u << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1247,6 +1277,9 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
     if (sh_sing & 1) {   // LinAlgError at the current mu: retry without raising mu (Q9) -- burns one iteration
       if (tid == 0) sh_it += 1;
       __syncthreads();
+      // wide trees: every workgroup must have read this pass's singular word before workgroup 0 clears it again (it is the word of
+      // the pass after next, cleared at the top of the NEXT pass -- and this path has no other barrier in between)
+      IL_SYNC();
       continue;
     }
     // slots behind a singular slot cannot be used this pass
