@@ -212,6 +212,25 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None):
         return o
 
     rt.predict = prof_predict
+    # recorded scenes run the whole AIME loop inside ONE native call (mind_aime_plan): its pair-kernel launches are timed by the same
+    # HIP events, summed over the plan's rounds
+    orig_plan = rt.aime_plan
+
+    def prof_plan(*a, **k):
+        r = orig_plan(*a, **k)
+        if r is not None:
+            info = r[2]
+            na, N = info["a"], info["a"] + info["l"] + 1
+            for B in info["round_scenes"]:
+                acc["n2"] += B * N * N
+                acc["fold"] += B * fold_flops(N, na + 1)
+                acc["bytes"] += B * edge_bytes(N, na + 1)
+            acc["ms"] += info["pair_ms"]
+            acc["launches"] += info["pair_launches"]
+            acc["calls"] += len(info["round_scenes"])
+        return r
+
+    rt.aime_plan = prof_plan
     # the tree-iLQR launch of every plan, timed by HIP events on the context stream (mind_last_ilqr_stats)
     il = {"ms": 0.0, "launches": 0, "trees": 0, "wgs": 1}
     orig_solve = pl.traj_tree_opt.solve_batch
@@ -235,6 +254,7 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None):
     dist.barrier()
     dt = time.perf_counter() - t0
     rt.predict = orig_predict
+    rt.aime_plan = orig_plan
     pl.traj_tree_opt.solve_batch = orig_solve
     rt.set_profiling(False)
     dt = dist.reduce(dt, "max")

@@ -250,6 +250,64 @@ typedef struct {
 int mind_aime_rebase(mind_ctx *ctx, const mind_rebase_in *in, const mind_rebase_out *out);
 
 /* ------------------------------------------------------------------------------------------------
+ * ScenarioTreeGenerator.branch_aime (planners/mind/scenario_tree.py:38-58) in ONE call: every AIME round -- the batched scene
+ * prediction (:69-71), prune_merge (:281-412), create_nodes (:73-80), decide_branch / get_branch_time (:82-100, 592-611) and
+ * update_obser (:467-567) of the branching nodes -- runs on the device with the per-round bookkeeping in native code; the host
+ * sees one small read-back per round (kept modes + branch-time bits).  The caller supplies what process_data (:122-206) and
+ * prepare_root_data (:414-465) produce for the root and receives the internal tree's nodes plus, for the nodes of finished
+ * branches, the rows get_scenario_tree (:208-272) attaches.  All pointers HOST, float32.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int n_agents, n_lanes, n_lane_pts;
+  const float *actors;                       /* [a,14,48]  ACTORS of the root scene                                       */
+  const float *actor_ctrs, *actor_vecs;      /* [a,2]      TRAJS_CTRS / TRAJS_VECS                                        */
+  const float *lanes;                        /* [l,10,16]  LANES (instance-frame lane features)                           */
+  const float *lane_ctrs, *lane_vecs;        /* [l,2]      lane_graph anchors (AV frame; update_obser re-expresses them)  */
+  const float *tgt_nodes, *tgt_rpe;          /* [10,16], [20]                                                             */
+  const float *rot, *orig, *tgt_pts;         /* [2,2], [2], [11,2]: ROT, ORIG, TGT_PTS of the root                        */
+  const float *hist;                         /* [a,50,6]   root world-frame history: x, y, vx, vy, heading, max-sigma     */
+  const float *types;                        /* [a,50,7]   TRAJS_TYPE                                                     */
+  const float *target_lane;                  /* [P,2]                                                                     */
+  const float *target_lane_info;             /* [P,12]                                                                    */
+  float time_ahead, min_vel, dist_thres;     /* tar_time_ahead, 0.5, tar_dist_thres                                       */
+  int max_depth;                             /* ScenTreeCfg.max_depth                                                     */
+  int max_rounds;                            /* safety bound on the number of rounds (>= max_depth + 1)                   */
+  int pred_len;                              /* planning horizon in predicted steps (the generator's pred_len, 50: END_T of  */
+                                             /*   a fresh observation; seq_len = 50 + pred_len), <= 60                     */
+} mind_aime_plan_in;
+
+#define MIND_AIME_BRANCH 1
+#define MIND_AIME_END 2
+#define MIND_AIME_TERMINATE 4
+typedef struct {
+  int round, scene, mode;      /* SCEN_ID = "{round}_{scene}_{mode}" (scenario_tree.py:321)                               */
+  int parent;                  /* index of the parent node in this table, -1 = child of the root                          */
+  float prob;                  /* SCEN_PROB (path probability, float32)                                                   */
+  int cur_t, end_t;            /* CUR_T, END_T after the branching decisions                                              */
+  int flags;                   /* MIND_AIME_BRANCH | _END | _TERMINATE of the internal tree node                          */
+  int dur;                     /* steps of `rows` (END_T - CUR_T), 0 when the node is not on a finished branch            */
+  int64_t row_off;             /* offset in floats of its rows [a, dur, 3] = (x, y, max-sigma) in out->rows, or -1        */
+  float tgt_pts[22];           /* TGT_PTS [11,2] of the scene the node was predicted from                                 */
+} mind_aime_node;
+
+typedef struct {
+  const mind_aime_node *nodes; /* library-owned host table [n_nodes] in creation order (= the internal tree's insertion order     */
+  int n_nodes;                 /*   without its root), valid until the next mind_aime_plan call on this context                 */
+  const float *rows;           /* library-owned host buffer [n_row_floats], same lifetime                                        */
+  int64_t n_row_floats;
+  int n_expanded, n_rounds;    /* scenes pushed through the predictor, rounds                                             */
+  int root_flags;              /* flags of the internal root node                                                         */
+  int round_scenes[32];        /* scenes of every round (for the caller's throughput accounting)                          */
+  float pair_ms;               /* summed duration of the pair-kernel launches (HIP events; 0 unless profiling is on)      */
+  int pair_launches;
+} mind_aime_plan_out;
+
+/* Returns MIND_ESTATE ("unsupported: ...") for the situations only the round-by-round host path handles -- a node re-expanded in a
+ * later round than the one that created it, no finished branch (the host path raises the reference's assertion), more than
+ * max_rounds rounds -- in which case the caller runs that path instead. */
+int mind_aime_plan(mind_ctx *ctx, const mind_aime_plan_in *in, mind_aime_plan_out *out);
+
+/* ------------------------------------------------------------------------------------------------
  * planners/ilqr call surface (iLQR.fit over a TreeCost of arbitrary PotentialField / StatePotential /
  * StateConstraint / ControlPotential objects; solver.py:80-167, cost.py:326-446, potential.py:62-264).
  * The grid is what PotentialField.__init__ receives: field_offset, resolution, xx[0,:], yy[:,0].

@@ -67,6 +67,25 @@ class RebaseOut(C.Structure):
                 ("gen", C.POINTER(C.c_int32))]
 
 
+class AimePlanIn(C.Structure):
+    _fields_ = [("n_agents", C.c_int), ("n_lanes", C.c_int), ("n_lane_pts", C.c_int)] + \
+               [(k, C.POINTER(C.c_float)) for k in ("actors", "actor_ctrs", "actor_vecs", "lanes", "lane_ctrs", "lane_vecs", "tgt_nodes", "tgt_rpe",
+                                                    "rot", "orig", "tgt_pts", "hist", "types", "target_lane", "target_lane_info")] + \
+               [("time_ahead", C.c_float), ("min_vel", C.c_float), ("dist_thres", C.c_float), ("max_depth", C.c_int), ("max_rounds", C.c_int), ("pred_len", C.c_int)]
+
+
+class AimeNode(C.Structure):
+    _fields_ = [("round", C.c_int), ("scene", C.c_int), ("mode", C.c_int), ("parent", C.c_int), ("prob", C.c_float),
+                ("cur_t", C.c_int), ("end_t", C.c_int), ("flags", C.c_int), ("dur", C.c_int), ("row_off", C.c_int64),
+                ("tgt_pts", C.c_float * 22)]
+
+
+class AimePlanOut(C.Structure):
+    _fields_ = [("nodes", C.POINTER(AimeNode)), ("n_nodes", C.c_int), ("rows", C.POINTER(C.c_float)), ("n_row_floats", C.c_int64),
+                ("n_expanded", C.c_int), ("n_rounds", C.c_int), ("root_flags", C.c_int), ("round_scenes", C.c_int * 32),
+                ("pair_ms", C.c_float), ("pair_launches", C.c_int)]
+
+
 class IlqrCfg(C.Structure):
     _fields_ = [("dt", C.c_double), ("wheelbase", C.c_double), ("w_des_state", C.c_double * 6),
                 ("w_state_con", C.c_double * 6), ("state_lower", C.c_double * 6), ("state_upper", C.c_double * 6),
@@ -83,7 +102,7 @@ class IlqrStats(C.Structure):
 EXPORTS = ["mind_ctx_create", "mind_ctx_destroy", "mind_last_error_string", "mind_ctx_synchronize",
            "mind_weights_load", "mind_predict_batch", "mind_last_fusion_stats", "mind_set_profiling",
            "mind_ilqr_solve_trees", "mind_ilqr_contingency", "mind_ilqr_solve_fields", "mind_cost_eval", "mind_lane_dist_field", "mind_aime_world", "mind_aime_rebase", "mind_debug_set_layers",
-           "mind_debug_read", "mind_set_pair_precision", "mind_get_pair_precision", "mind_debug_pack_bfrag", "mind_debug_pack_conv_frag", "mind_set_tuning", "mind_last_ilqr_stats"]
+           "mind_debug_read", "mind_set_pair_precision", "mind_get_pair_precision", "mind_debug_pack_bfrag", "mind_debug_pack_conv_frag", "mind_set_tuning", "mind_last_ilqr_stats", "mind_aime_plan"]
 
 _lib = None
 
@@ -123,6 +142,7 @@ def load():
                                          C.c_double] + [C.POINTER(C.c_double)] * 4
     lib.mind_aime_world.argtypes = [C.c_void_p, C.POINTER(WorldIn), C.POINTER(WorldOut)]
     lib.mind_aime_rebase.argtypes = [C.c_void_p, C.POINTER(RebaseIn), C.POINTER(RebaseOut)]
+    lib.mind_aime_plan.argtypes = [C.c_void_p, C.POINTER(AimePlanIn), C.POINTER(AimePlanOut)]
     lib.mind_set_pair_precision.argtypes = [C.c_void_p, C.c_int]
     lib.mind_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.mind_last_ilqr_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]

@@ -12,7 +12,8 @@
 
 struct AimeScene {
   int a0, a1;               // agent rows of the scene in the round's batch (a0 = ego)
-  int last, pad;            // index of the last predicted step that fits seq_len (may be < 0)
+  int last, cmp;            // index of the last predicted step that fits seq_len (may be < 0); predicted step the branch-time test
+                            // compares against (k_aime_branch: CUR_T, or 1 when CUR_T == 0)
   float r00, r01, r10, r11; // scene rotation ROT (row-major)
   float ox, oy, theta_g, pad2;
 };
@@ -217,11 +218,15 @@ __device__ __forceinline__ void rb_cs(float ax, float ay, float bx, float by, fl
 // Window of a child scene assembled on the device: the last 50 steps of [parent window (50) | the child's first `dur` predicted
 // steps] -- what ChildScene.window6 / update_obser cut out on the host (scenario_tree.py:396-412, 470-473).  One block per
 // (scene, agent), lane = window step.  prev_*: the previous re-basing call's window arrays ([S_prev, a, 50, .]).
+// rows: [., 60, 6] world-frame rows; agent i of child s is row row0[s] + i * row_stride (1: rows gathered per kept mode, 6: k_aime_world's
+// [A,6,60,6] buffer with row0 = first agent * 6 + mode).  cov_last (optional) receives the window's last max-sigma per agent
+// (= TRAJS_COV_HIST[:, -1, 0] of the re-based scene: the child's own step dur - 1).
 __global__ __launch_bounds__(64) void k_aime_windows(const float *__restrict__ prev_pos, const float *__restrict__ prev_ang,
                                                      const float *__restrict__ prev_vel, const float *__restrict__ rows,
                                                      const int *__restrict__ parent_slot, const int *__restrict__ row0,
                                                      const int *__restrict__ dur, int a, float *__restrict__ pos,
-                                                     float *__restrict__ ang, float *__restrict__ vel) {
+                                                     float *__restrict__ ang, float *__restrict__ vel, int row_stride,
+                                                     float *__restrict__ cov_last) {
   const int s = blockIdx.x / a, i = blockIdx.x - s * a, t = threadIdx.x;
   if (t >= RB_T) return;
   const int d = dur[s];
@@ -231,11 +236,54 @@ __global__ __launch_bounds__(64) void k_aime_windows(const float *__restrict__ p
     const size_t p = ((size_t)parent_slot[s] * a + i) * RB_T + src;
     x = prev_pos[2 * p]; y = prev_pos[2 * p + 1]; vx = prev_vel[2 * p]; vy = prev_vel[2 * p + 1]; h = prev_ang[p];
   } else {
-    const float *r = rows + ((size_t)(row0[s] + i) * AIME_T + (src - RB_T)) * AIME_PK;
+    const float *r = rows + (((size_t)row0[s] + (size_t)i * row_stride) * AIME_T + (src - RB_T)) * AIME_PK;
     x = r[0]; y = r[1]; vx = r[2]; vy = r[3]; h = r[4];
+    if (cov_last && t == RB_T - 1) cov_last[(size_t)s * a + i] = r[5];
   }
   const size_t o = ((size_t)s * a + i) * RB_T + t;
   pos[2 * o] = x; pos[2 * o + 1] = y; vel[2 * o] = vx; vel[2 * o + 1] = vy; ang[o] = h;
+}
+
+// Branch-time test of decide_branch / get_branch_time (scenario_tree.py:82-100, 592-611) for every kept mode of a round: bit t of
+// hit[b][j] (two 32-bit words) is set when some agent's predicted max-sigma at step t exceeds 9 x its max-sigma at the scene's
+// compare step (float32 division and comparison, as the reference).  The host picks the first even t inside (CUR_T, END_T).
+// One wave per (scene, kept slot), lane = step; sel as written by k_aime_select.
+__global__ __launch_bounds__(64) void k_aime_branch(const AimeScene *__restrict__ scenes, const float *__restrict__ sel,
+                                                    const float *__restrict__ world, unsigned *__restrict__ hit) {
+  const int b = blockIdx.x / AIME_K, j = blockIdx.x % AIME_K, t = threadIdx.x;
+  const AimeScene S = scenes[b];
+  const int k = (int)sel[(size_t)b * AIME_K + j];
+  bool h = false;
+  if (k >= 0 && t < AIME_T) {
+    for (int i = S.a0; i < S.a1; ++i) {
+      const float *r = world + ((size_t)i * AIME_K + k) * AIME_T * AIME_PK;
+      h |= (r[t * AIME_PK + 5] / r[S.cmp * AIME_PK + 5]) > 9.0f;
+    }
+  }
+  const unsigned long long m = __ballot(h);
+  if (t == 0) { hit[2 * (size_t)blockIdx.x] = (unsigned)m; hit[2 * (size_t)blockIdx.x + 1] = (unsigned)(m >> 32); }
+}
+
+// Rows of the returned scenario trees (get_scenario_tree, scenario_tree.py:208-272): the first `dur` predicted steps (x, y, max-sigma)
+// of every agent of the listed nodes, packed [a, dur, 3] per node.  job = {first row in world (agent 0), dur, destination offset
+// in floats, agents}; one block per (job, agent).
+struct AimeGather { int row0, dur, dst, a; };
+__global__ __launch_bounds__(64) void k_aime_gather(const AimeGather *__restrict__ jobs, const int *__restrict__ job_of_block,
+                                                    const int *__restrict__ agent_of_block, const float *const *__restrict__ world_of_job,
+                                                    float *__restrict__ out) {
+  const AimeGather J = jobs[job_of_block[blockIdx.x]];
+  const int i = agent_of_block[blockIdx.x], t = threadIdx.x;
+  if (t >= J.dur) return;
+  const float *r = world_of_job[job_of_block[blockIdx.x]] + (((size_t)J.row0 + (size_t)i * AIME_K) * AIME_T + t) * AIME_PK;
+  float *o = out + (size_t)J.dst + ((size_t)i * J.dur + t) * 3;
+  o[0] = r[0]; o[1] = r[1]; o[2] = r[5];
+}
+
+// rows [n,128] repeated `times` times (LaneNet's output shared by every scene of a round)
+__global__ void k_repeat_rows(const float *__restrict__ src, size_t n, int times, float *__restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * (size_t)times) return;
+  dst[i] = src[i % n];
 }
 
 __global__ __launch_bounds__(RB_THREADS) void k_aime_rebase(RebaseArgs A) {

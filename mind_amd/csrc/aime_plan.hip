@@ -1,0 +1,367 @@
+// mind_aime_plan: ScenarioTreeGenerator.branch_aime (planners/mind/scenario_tree.py:38-58) in one call.  Included by mind_hip.hip
+// (uses mind_ctx, ensure / fail / HIPCHK, mind_predict_batch and the kernels of aime_kernels.hip).
+//
+// Per round the device runs  predictor -> k_aime_world -> k_aime_select -> k_aime_branch  and the host reads ONE small buffer (kept
+// modes, path probabilities, branch-time bits: 72 B per scene); create_nodes / decide_branch (scenario_tree.py:73-100) are restated
+// here over plain arrays; the branching nodes' observations are re-based where they are (k_aime_windows from k_aime_world's rows
+// and the parents' windows, k_aime_rebase) and the next predictor call is queued before the host looks at anything else.  Every
+// small table goes through page-locked staging, so no copy waits for the stream to drain.  At the end one gather kernel packs the
+// rows get_scenario_tree (scenario_tree.py:208-272) attaches to the nodes of finished branches.
+namespace {
+
+struct PlScene {            // an observation pushed through the predictor: the root or a re-based branch node
+  int node;                 // internal tree node it belongs to (0 = root)
+  float prob;
+  int cur_t, end_t;
+  float rot[4], orig[2], tgt[22];
+};
+
+struct PlNode {
+  int round, scene, mode, parent, depth;
+  float prob;
+  int cur_t, end_t;
+  bool branch, end, term, rebased;
+  unsigned long long hit;   // bit t: some agent's sigma at predicted step t > 9 x its sigma at the compare step
+  float tgt[22];
+};
+
+int pl_pin(mind_ctx *c, int which, size_t bytes) {
+  if (bytes <= c->pl_pin_cap[which]) return MIND_OK;
+  if (c->pl_pin[which]) (void)hipHostFree(c->pl_pin[which]);
+  c->pl_pin[which] = nullptr; c->pl_pin_cap[which] = 0;
+  const size_t want = bytes + bytes / 2 + 4096;
+  if (hipHostMalloc(&c->pl_pin[which], want, hipHostMallocDefault) != hipSuccess)
+    return fail(c, MIND_ENOMEM, "hipHostMalloc(%zu) failed", want);
+  c->pl_pin_cap[which] = want;
+  return MIND_OK;
+}
+
+}  // namespace
+
+extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aime_plan_out *out) {
+  if (!c || !in || !out) return MIND_EINVAL;
+  if (!c->have_weights) return fail(c, MIND_ESTATE, "weights not loaded");
+  const int a = in->n_agents, l = in->n_lanes, P = in->n_lane_pts;
+  if (a <= 0 || l <= 0 || P < 12 || !in->actors || !in->actor_ctrs || !in->actor_vecs || !in->lanes || !in->lane_ctrs || !in->lane_vecs ||
+      !in->tgt_nodes || !in->tgt_rpe || !in->rot || !in->orig || !in->tgt_pts || !in->hist || !in->types || !in->target_lane ||
+      !in->target_lane_info || in->max_depth < 0 || in->max_rounds <= 0 || in->max_rounds > 32 || in->pred_len < 2 || in->pred_len > AIME_T)
+    return fail(c, MIND_EINVAL, "mind_aime_plan: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  if (!c->ev_pl) HIPCHK(c, hipEventCreateWithFlags(&c->ev_pl, hipEventDisableTiming));
+  int rc;
+  const int T = AIME_T, OBS = RB_T, HZ = in->pred_len;     // predicted steps per mode, history window, planning horizon
+  // ---- root upload (one page-locked staging buffer -> one async copy), floats
+  size_t o = 0;
+  auto take = [&](size_t n) { const size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
+  const size_t o_actors = take((size_t)a * 14 * 48), o_ctrs = take((size_t)a * 2), o_vecs = take((size_t)a * 2), o_lanes = take((size_t)l * 160);
+  const size_t o_lc = take((size_t)l * 2), o_lv = take((size_t)l * 2), o_tn = take(160), o_tr = take(20), o_cov = take(a);
+  const size_t o_types = take((size_t)a * OBS * 7), o_tl = take((size_t)P * 2), o_ti = take((size_t)P * 12);
+  const size_t o_wpos = take((size_t)a * OBS * 2), o_wang = take((size_t)a * OBS), o_wvel = take((size_t)a * OBS * 2);
+  const size_t n_root = o;
+  if ((rc = ensure(c, c->pl_root, n_root * sizeof(float)))) return rc;
+  if ((rc = pl_pin(c, 0, n_root * sizeof(float)))) return rc;
+  {
+    float *h = (float *)c->pl_pin[0];
+    memcpy(h + o_actors, in->actors, (size_t)a * 14 * 48 * sizeof(float));
+    memcpy(h + o_ctrs, in->actor_ctrs, (size_t)a * 2 * sizeof(float));
+    memcpy(h + o_vecs, in->actor_vecs, (size_t)a * 2 * sizeof(float));
+    memcpy(h + o_lanes, in->lanes, (size_t)l * 160 * sizeof(float));
+    memcpy(h + o_lc, in->lane_ctrs, (size_t)l * 2 * sizeof(float));
+    memcpy(h + o_lv, in->lane_vecs, (size_t)l * 2 * sizeof(float));
+    memcpy(h + o_tn, in->tgt_nodes, 160 * sizeof(float));
+    memcpy(h + o_tr, in->tgt_rpe, 20 * sizeof(float));
+    memcpy(h + o_types, in->types, (size_t)a * OBS * 7 * sizeof(float));
+    memcpy(h + o_tl, in->target_lane, (size_t)P * 2 * sizeof(float));
+    memcpy(h + o_ti, in->target_lane_info, (size_t)P * 12 * sizeof(float));
+    for (int i = 0; i < a; ++i) {
+      h[o_cov + i] = in->hist[((size_t)i * OBS + OBS - 1) * 6 + 5];           // TRAJS_COV_HIST[:, -1, 0]
+      for (int t = 0; t < OBS; ++t) {
+        const float *r = in->hist + ((size_t)i * OBS + t) * 6;
+        h[o_wpos + ((size_t)i * OBS + t) * 2] = r[0]; h[o_wpos + ((size_t)i * OBS + t) * 2 + 1] = r[1];
+        h[o_wvel + ((size_t)i * OBS + t) * 2] = r[2]; h[o_wvel + ((size_t)i * OBS + t) * 2 + 1] = r[3];
+        h[o_wang + (size_t)i * OBS + t] = r[4];
+      }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->pl_root.p, h, n_root * sizeof(float), hipMemcpyHostToDevice, st));
+  }
+  const float *droot = (const float *)c->pl_root.p;
+  if ((rc = ensure(c, c->pl_lf, (size_t)l * 128 * sizeof(float)))) return rc;
+
+  // ---- internal tree (scenario_tree.py:60-67): root = node 0, a leaf with branch_flag
+  std::vector<PlNode> nodes(1);
+  {
+    PlNode &r = nodes[0];
+    memset(&r, 0, sizeof(r));
+    r.round = -1; r.parent = -1; r.prob = 1.f; r.end_t = HZ; r.branch = true;
+  }
+  std::vector<int> leaves(1, 0);
+  std::vector<PlScene> batch(1);
+  {
+    PlScene &s = batch[0];
+    s.node = 0; s.prob = 1.f; s.cur_t = 0; s.end_t = HZ;
+    memcpy(s.rot, in->rot, 4 * sizeof(float)); memcpy(s.orig, in->orig, 2 * sizeof(float)); memcpy(s.tgt, in->tgt_pts, 22 * sizeof(float));
+  }
+  const float *prev_pos = droot + o_wpos, *prev_ang = droot + o_wang, *prev_vel = droot + o_wvel;
+  const float *cov_last_dev = droot + o_cov;
+  int cur_in = -1;                 // which pl_in holds the current round's predictor inputs (-1: the root upload)
+  bool frames_pending = false;
+  int n_expanded = 0, round = 0;
+  float pair_ms = 0.f;
+  int pair_launches = 0;
+  memset(out, 0, sizeof(*out));
+
+  // layout of one re-based input set (floats): actors | actor_ctrs | actor_vecs | lane_ctrs | lane_vecs | tgt_nodes | tgt_rpe | frames | cov_last
+  struct InOff { size_t actors, ctrs, vecs, lc, lv, tn, tr, fr, cov, total; };
+  auto in_off = [&](size_t S) {
+    InOff q; size_t p = 0;
+    auto tk = [&](size_t n) { const size_t r = p; p += (n + 3) & ~(size_t)3; return r; };
+    q.actors = tk(S * a * 14 * 48); q.ctrs = tk(S * a * 2); q.vecs = tk(S * a * 2); q.lc = tk(S * l * 2); q.lv = tk(S * l * 2);
+    q.tn = tk(S * 160); q.tr = tk(S * 20); q.fr = tk(S * 28); q.cov = tk(S * a); q.total = p;
+    return q;
+  };
+
+  for (;; ++round) {
+    const int B = (int)batch.size(), A = B * a;
+    if (round >= in->max_rounds) return fail(c, MIND_ESTATE, "unsupported: more than %d AIME rounds", in->max_rounds);
+    out->round_scenes[round] = B;
+    // ---- predictor on the round's scenes
+    std::vector<int32_t> ao(B + 1), lo(B + 1);
+    for (int b = 0; b <= B; ++b) { ao[b] = a * b; lo[b] = l * b; }
+    if ((rc = ensure(c, c->pl_pred, ((size_t)B * 6 + (size_t)A * 6 * T * 7) * sizeof(float)))) return rc;
+    float *d_cls = (float *)c->pl_pred.p, *d_reg = d_cls + (((size_t)B * 6 + 3) & ~(size_t)3), *d_vel = d_reg + (size_t)A * 6 * T * 5;
+    if ((rc = ensure(c, c->pl_pred, ((size_t)(d_vel - d_cls) + (size_t)A * 6 * T * 2) * sizeof(float)))) return rc;
+    d_cls = (float *)c->pl_pred.p; d_reg = d_cls + (((size_t)B * 6 + 3) & ~(size_t)3); d_vel = d_reg + (size_t)A * 6 * T * 5;
+    mind_scene_batch sb;
+    memset(&sb, 0, sizeof(sb));
+    mind_pred_out po;
+    memset(&po, 0, sizeof(po));
+    sb.n_scenes = B; sb.actor_off = ao.data(); sb.lane_off = lo.data();
+    const float *d_ctrs, *d_vecs;
+    if (cur_in < 0) {
+      sb.actors = droot + o_actors; sb.lanes = droot + o_lanes; sb.actor_ctrs = d_ctrs = droot + o_ctrs; sb.actor_vecs = d_vecs = droot + o_vecs;
+      sb.lane_ctrs = droot + o_lc; sb.lane_vecs = droot + o_lv; sb.tgt_nodes = droot + o_tn; sb.tgt_rpe = droot + o_tr;
+      po.lane_feat = (float *)c->pl_lf.p;
+    } else {
+      const InOff q = in_off(B);
+      const float *d = (const float *)c->pl_in[cur_in].p;
+      sb.actors = d + q.actors; sb.actor_ctrs = d_ctrs = d + q.ctrs; sb.actor_vecs = d_vecs = d + q.vecs; sb.lane_ctrs = d + q.lc; sb.lane_vecs = d + q.lv;
+      sb.tgt_nodes = d + q.tn; sb.tgt_rpe = d + q.tr;
+      sb.lane_feat = B == 1 ? (const float *)c->pl_lf.p : (const float *)c->pl_lrep.p;
+    }
+    po.cls = d_cls; po.reg = d_reg; po.vel = d_vel;
+    if ((rc = mind_predict_batch(c, &sb, &po))) return rc;
+    n_expanded += B;
+    if (c->profiling) { pair_ms += c->pair_ms; pair_launches += c->n_pair_launch; }
+    // ---- the frames of the re-based scenes (queued behind k_aime_rebase, before this round's predictor): ROT, ORIG, TGT_PTS
+    if (frames_pending) {
+      HIPCHK(c, hipEventSynchronize(c->ev_pl));
+      const float *fr = (const float *)c->pl_pin[3];
+      for (int b = 0; b < B; ++b) {
+        memcpy(batch[b].rot, fr + (size_t)b * 28, 4 * sizeof(float));
+        memcpy(batch[b].orig, fr + (size_t)b * 28 + 4, 2 * sizeof(float));
+        memcpy(batch[b].tgt, fr + (size_t)b * 28 + 6, 22 * sizeof(float));
+      }
+      frames_pending = false;
+    }
+    // ---- prune_merge arithmetic + decisions + branch-time bits on the device
+    const size_t bS = ((size_t)B * sizeof(AimeScene) + 15) & ~(size_t)15, bI = ((size_t)A * sizeof(int) + 15) & ~(size_t)15;
+    const size_t bP = ((size_t)B * sizeof(float) + 15) & ~(size_t)15;
+    const size_t tab_bytes = bS + bI + bP;
+    if ((rc = ensure(c, c->pl_tab, tab_bytes + 3 * (size_t)6 * B * sizeof(int) + 64))) return rc;
+    if ((rc = pl_pin(c, 1, tab_bytes + 3 * (size_t)6 * B * sizeof(int) + 64))) return rc;
+    {
+      char *h = (char *)c->pl_pin[1];
+      AimeScene *hs = (AimeScene *)h;
+      int *as = (int *)(h + bS);
+      float *sp = (float *)(h + bS + bI);
+      for (int b = 0; b < B; ++b) {
+        AimeScene &S = hs[b];
+        const PlScene &q = batch[b];
+        S.a0 = a * b; S.a1 = a * (b + 1); S.last = HZ - 1;     /* seq_len - 1 - history length */ S.cmp = q.cur_t == 0 ? 1 : q.cur_t; S.pad2 = 0.f;
+        S.r00 = q.rot[0]; S.r01 = q.rot[1]; S.r10 = q.rot[2]; S.r11 = q.rot[3];
+        S.ox = q.orig[0]; S.oy = q.orig[1];
+        S.theta_g = atan2f(S.r10, S.r00);
+        for (int i = S.a0; i < S.a1; ++i) as[i] = b;
+        sp[b] = q.prob;
+      }
+      HIPCHK(c, hipMemcpyAsync(c->pl_tab.p, h, tab_bytes, hipMemcpyHostToDevice, st));
+    }
+    const char *dtab = (const char *)c->pl_tab.p;
+    if ((int)c->pl_world.size() <= round) c->pl_world.resize(round + 1);
+    if ((rc = ensure(c, c->pl_world[round], (size_t)A * 6 * T * 6 * sizeof(float)))) return rc;
+    float *d_world = (float *)c->pl_world[round].p;
+    // small outputs: topo [A,6] | ego_end [B,6,4] | sel [B,6] | sel_prob [B,6] | hit [B,6,2] (the last three are read back)
+    const size_t n_topo = ((size_t)A * 6 + 3) & ~(size_t)3, n_ego = (size_t)B * 24, n_back = (size_t)B * 6 * 4;
+    if ((rc = ensure(c, c->pl_small, (n_topo + n_ego + n_back) * sizeof(float)))) return rc;
+    float *d_topo = (float *)c->pl_small.p, *d_ego = d_topo + n_topo, *d_sel = d_ego + n_ego, *d_selp = d_sel + (size_t)B * 6;
+    unsigned *d_hit = (unsigned *)(d_selp + (size_t)B * 6);
+    hipLaunchKernelGGL(k_aime_world, dim3(A * AIME_K), dim3(64), 0, st, (const AimeScene *)dtab, (const int *)(dtab + bS), d_reg, d_vel, d_ctrs, d_vecs,
+                       cov_last_dev, d_world, d_topo, d_ego, droot + o_tl, P);
+    hipLaunchKernelGGL(k_aime_select, dim3(B), dim3(64), 0, st, (const AimeScene *)dtab, d_cls, (const float *)(dtab + bS + bI), d_topo, d_ego, 1,
+                       in->dist_thres, d_sel, d_selp);
+    hipLaunchKernelGGL(k_aime_branch, dim3(B * AIME_K), dim3(64), 0, st, (const AimeScene *)dtab, d_sel, d_world, d_hit);
+    HIPCHK(c, hipGetLastError());
+    if ((rc = pl_pin(c, 2, n_back * sizeof(float)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pl_pin[2], d_sel, n_back * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const float *h_sel = (const float *)c->pl_pin[2], *h_selp = h_sel + (size_t)B * 6;
+    const unsigned *h_hit = (const unsigned *)(h_selp + (size_t)B * 6);
+    // ---- create_nodes (scenario_tree.py:73-80): the kept modes scene by scene, visiting order within a scene
+    for (int b = 0; b < B; ++b)
+      for (int j = 0; j < AIME_K; ++j) {
+        const int k = (int)h_sel[(size_t)b * 6 + j];
+        if (k < 0) continue;
+        PlNode n;
+        memset(&n, 0, sizeof(n));
+        n.round = round; n.scene = b; n.mode = k; n.parent = batch[b].node; n.depth = nodes[n.parent].depth + 1;
+        n.prob = h_selp[(size_t)b * 6 + j]; n.cur_t = batch[b].cur_t; n.end_t = batch[b].end_t;
+        n.hit = (unsigned long long)h_hit[2 * ((size_t)b * 6 + j)] | ((unsigned long long)h_hit[2 * ((size_t)b * 6 + j) + 1] << 32);
+        memcpy(n.tgt, batch[b].tgt, sizeof(n.tgt));
+        const int idx = (int)nodes.size();
+        nodes.push_back(n);
+        for (size_t q = 0; q < leaves.size(); ++q)
+          if (leaves[q] == n.parent) { leaves.erase(leaves.begin() + q); break; }
+        leaves.push_back(idx);
+      }
+    // ---- decide_branch (scenario_tree.py:82-100) over the leaves in insertion order
+    std::vector<int> cand, todo;
+    for (int li : leaves) {
+      PlNode &n = nodes[li];
+      if (n.branch) { n.branch = false; n.term = true; }
+      else if (!n.end) {
+        if (n.depth >= in->max_depth) n.term = true;
+        else cand.push_back(li);
+      }
+    }
+    for (int li : cand) {
+      PlNode &n = nodes[li];
+      if (li == 0) return fail(c, MIND_ESTATE, "unsupported: the root is a branching candidate");
+      // get_branch_time (:592-611): first even t in (CUR_T, END_T) whose sigma ratio exceeds 9.  A node that was re-based before and
+      // has CUR_T > 0 would index past its trimmed history in the reference: left to the host path.
+      if (n.rebased && n.cur_t > 0) return fail(c, MIND_ESTATE, "unsupported: branch time of a trimmed node with CUR_T > 0");
+      int t_b = n.end_t;
+      for (int t = n.cur_t + 1 + (n.cur_t + 1) % 2; t < n.end_t; t += 2)
+        if ((n.hit >> t) & 1ull) { t_b = t; break; }
+      if (t_b < n.end_t) n.end_t = t_b;
+      if (t_b < HZ) todo.push_back(li);
+      else n.end = true;
+    }
+    if (todo.empty()) { ++round; break; }
+    // ---- update_obser (:467-567) of the branching nodes: windows + predictor inputs of the next round, on the device
+    const int S = (int)todo.size();
+    for (int li : todo)
+      if (nodes[li].round != round) return fail(c, MIND_ESTATE, "unsupported: a node of round %d is expanded again in round %d", nodes[li].round, round + 1);
+    {
+      int *hi = (int *)((char *)c->pl_pin[1] + tab_bytes);
+      for (int s = 0; s < S; ++s) {
+        const PlNode &n = nodes[todo[s]];
+        hi[s] = n.scene;                                  // parent window: the scene of this round the node was predicted from
+        hi[S + s] = n.scene * a * AIME_K + n.mode;        // first row (agent 0) of the node's mode in d_world
+        hi[2 * S + s] = n.end_t - n.cur_t;                // steps kept
+      }
+      HIPCHK(c, hipMemcpyAsync((char *)c->pl_tab.p + tab_bytes, hi, 3 * (size_t)S * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    const int *d_idx = (const int *)((const char *)c->pl_tab.p + tab_bytes);
+    const int nxt = cur_in < 0 ? 0 : cur_in ^ 1;
+    const InOff q = in_off(S);
+    if ((rc = ensure(c, c->pl_in[nxt], q.total * sizeof(float)))) return rc;
+    const size_t n_wpos = (size_t)S * a * OBS * 2, n_wang = (size_t)S * a * OBS;
+    if ((rc = ensure(c, c->pl_win[nxt], (2 * n_wpos + n_wang) * sizeof(float)))) return rc;
+    float *w_pos = (float *)c->pl_win[nxt].p, *w_ang = w_pos + n_wpos, *w_vel = w_ang + n_wang;
+    float *d_in = (float *)c->pl_in[nxt].p;
+    hipLaunchKernelGGL(k_aime_windows, dim3((unsigned)(S * a)), dim3(64), 0, st, prev_pos, prev_ang, prev_vel, (const float *)d_world, d_idx, d_idx + S,
+                       d_idx + 2 * S, a, w_pos, w_ang, w_vel, AIME_K, d_in + q.cov);
+    RebaseArgs R;
+    R.a = a; R.l = l; R.n_lane = P; R.pad_ones = 1;
+    R.pos = w_pos; R.ang = w_ang; R.vel = w_vel; R.types = droot + o_types; R.pad = nullptr;
+    R.lane_ctrs0 = droot + o_lc; R.lane_vecs0 = droot + o_lv; R.tlane = droot + o_tl; R.tinfo = droot + o_ti;
+    R.time_ahead = in->time_ahead; R.min_vel = in->min_vel;
+    R.actors = d_in + q.actors; R.actor_ctrs = d_in + q.ctrs; R.actor_vecs = d_in + q.vecs; R.lane_ctrs = d_in + q.lc; R.lane_vecs = d_in + q.lv;
+    R.tgt_nodes = d_in + q.tn; R.tgt_rpe = d_in + q.tr; R.frames = d_in + q.fr;
+    hipLaunchKernelGGL(k_aime_rebase, dim3((unsigned)S), dim3(RB_THREADS), 5 * (size_t)a * sizeof(float), st, R);
+    if (S > 1) {
+      if ((rc = ensure(c, c->pl_lrep, (size_t)S * l * 128 * sizeof(float)))) return rc;
+      const size_t n = (size_t)l * 128;
+      hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((n * S + 255) / 256)), dim3(256), 0, st, (const float *)c->pl_lf.p, n, S, (float *)c->pl_lrep.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    if ((rc = pl_pin(c, 3, (size_t)S * 28 * sizeof(float)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pl_pin[3], d_in + q.fr, (size_t)S * 28 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(c->ev_pl, st));
+    frames_pending = true;
+    // next round's batch = the branch set in leaf order (scenario_tree.py:102-108)
+    batch.assign(S, PlScene());
+    for (int s = 0; s < S; ++s) {
+      PlNode &n = nodes[todo[s]];
+      n.branch = true; n.rebased = true;
+      PlScene &sc = batch[s];
+      sc.node = todo[s]; sc.prob = n.prob; sc.cur_t = n.end_t; sc.end_t = HZ;
+    }
+    prev_pos = w_pos; prev_ang = w_ang; prev_vel = w_vel;
+    cov_last_dev = d_in + q.cov;
+    cur_in = nxt;
+  }
+  // ---- get_scenario_tree, first step (:208-216): every node on a finished branch is labelled; their rows are packed by one kernel
+  bool any_end = false;
+  for (int li : leaves) any_end |= nodes[li].end;
+  if (!any_end) return fail(c, MIND_ESTATE, "unsupported: no end node found in the scenario tree");
+  for (int li : leaves) {
+    if (!nodes[li].end) continue;
+    for (int q = li; q > 0; q = nodes[q].parent) nodes[q].end = true;
+  }
+  const int N = (int)nodes.size() - 1;
+  c->pl_nodes.assign(N, mind_aime_node());
+  std::vector<AimeGather> jobs;
+  std::vector<const float *> job_world;
+  std::vector<int> job_of_block, agent_of_block;
+  int64_t n_rows = 0;
+  for (int i = 0; i < N; ++i) {
+    const PlNode &n = nodes[i + 1];
+    mind_aime_node &p = c->pl_nodes[i];
+    p.round = n.round; p.scene = n.scene; p.mode = n.mode; p.parent = n.parent - 1; p.prob = n.prob; p.cur_t = n.cur_t; p.end_t = n.end_t;
+    p.flags = (n.branch ? MIND_AIME_BRANCH : 0) | (n.end ? MIND_AIME_END : 0) | (n.term ? MIND_AIME_TERMINATE : 0);
+    memcpy(p.tgt_pts, n.tgt, sizeof(p.tgt_pts));
+    p.dur = 0; p.row_off = -1;
+    if (n.end) {
+      const int dur = n.end_t - n.cur_t;
+      p.dur = dur; p.row_off = n_rows;
+      if (dur > 0) {
+        AimeGather J;
+        J.row0 = n.scene * a * AIME_K + n.mode; J.dur = dur; J.dst = (int)n_rows; J.a = a;
+        for (int e = 0; e < a; ++e) { job_of_block.push_back((int)jobs.size()); agent_of_block.push_back(e); }
+        jobs.push_back(J);
+        job_world.push_back((const float *)c->pl_world[n.round].p);
+      }
+      n_rows += (int64_t)a * dur * 3;
+    }
+  }
+  c->pl_rows_host.resize((size_t)n_rows);
+  if (!jobs.empty()) {
+    const size_t bJ = (jobs.size() * sizeof(AimeGather) + 15) & ~(size_t)15, bW = (jobs.size() * sizeof(float *) + 15) & ~(size_t)15;
+    const size_t bB = (job_of_block.size() * sizeof(int) + 15) & ~(size_t)15;
+    if ((rc = ensure(c, c->pl_gather, bJ + bW + 2 * bB))) return rc;
+    if ((rc = pl_pin(c, 1, bJ + bW + 2 * bB))) return rc;
+    char *h = (char *)c->pl_pin[1];
+    memcpy(h, jobs.data(), jobs.size() * sizeof(AimeGather));
+    memcpy(h + bJ, job_world.data(), jobs.size() * sizeof(float *));
+    memcpy(h + bJ + bW, job_of_block.data(), job_of_block.size() * sizeof(int));
+    memcpy(h + bJ + bW + bB, agent_of_block.data(), agent_of_block.size() * sizeof(int));
+    HIPCHK(c, hipMemcpyAsync(c->pl_gather.p, h, bJ + bW + 2 * bB, hipMemcpyHostToDevice, st));
+    if ((rc = ensure(c, c->pl_rows, (size_t)n_rows * sizeof(float)))) return rc;
+    const char *d = (const char *)c->pl_gather.p;
+    hipLaunchKernelGGL(k_aime_gather, dim3((unsigned)job_of_block.size()), dim3(64), 0, st, (const AimeGather *)d, (const int *)(d + bJ + bW),
+                       (const int *)(d + bJ + bW + bB), (const float *const *)(d + bJ), (float *)c->pl_rows.p);
+    HIPCHK(c, hipGetLastError());
+    if ((rc = pl_pin(c, 2, (size_t)n_rows * sizeof(float)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pl_pin[2], c->pl_rows.p, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    memcpy(c->pl_rows_host.data(), c->pl_pin[2], (size_t)n_rows * sizeof(float));
+  }
+  out->nodes = c->pl_nodes.data(); out->n_nodes = N;
+  out->rows = c->pl_rows_host.data(); out->n_row_floats = n_rows;
+  out->n_expanded = n_expanded; out->n_rounds = round;
+  out->root_flags = (nodes[0].branch ? MIND_AIME_BRANCH : 0) | (nodes[0].end ? MIND_AIME_END : 0) | (nodes[0].term ? MIND_AIME_TERMINATE : 0);
+  out->pair_ms = pair_ms; out->pair_launches = pair_launches;
+  return MIND_OK;
+}

@@ -591,13 +591,26 @@ __device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const Ilq
 #pragma unroll
     for (int k = 0; k < 6; ++k) { xp[k] = pXn[(size_t)p0 * 6 + k]; xo[k] = pXs[(size_t)p0 * 6 + k]; }
   }
-  IlKv Pc, Pn;
-  prefetch(c, Pc);
-  for (int q = s0; q < s1; ++q) {
+  // Two nodes per loop trip (the operand sets swap roles instead of being copied).  A node's results are stored at the top of the
+  // NEXT node, behind that node's operand loads: loads and stores share one in-order counter, so a store issued at the end of a
+  // node would be waited for (several hundred cycles) by the next wait for a load.
+  IlKv PA, PB;
+  prefetch(c, PA);
+  double sx[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, su[2] = {0.0, 0.0};
+  int sc = c;
+  auto store = [&]() {
+    if (writer) {
+      const auto xn = (il_d2 IL_AS1 *)(pXn + (size_t)sc * 6);
+      xn[0] = il_d2{sx[0], sx[1]}; xn[1] = il_d2{sx[2], sx[3]}; xn[2] = il_d2{sx[4], sx[5]};
+      *(il_d2 IL_AS1 *)(pUn + (size_t)sc * 2) = il_d2{su[0], su[1]};
+    }
+  };
+  auto node = [&](const IlKv &Pc, IlKv &Pn, int q) {
     IL_PT0();
     const int cn = __builtin_amdgcn_readfirstlane(cn_v);
     cn_v = pSeg[q + 2 < s1 ? q + 2 : s1 - 1];
     prefetch(cn, Pn);
+    if (q != s0) store();
     IL_PT(0);
     double u[2], x[6];
     if (c == 0) {
@@ -613,17 +626,18 @@ __device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const Ilq
       }
     }
     il_dyn_sc(C, xp, u, x);
-    if (writer) {
-      const auto xn = (il_d2 IL_AS1 *)(pXn + (size_t)c * 6);
-      xn[0] = il_d2{x[0], x[1]}; xn[1] = il_d2{x[2], x[3]}; xn[2] = il_d2{x[4], x[5]};
-      *(il_d2 IL_AS1 *)(pUn + (size_t)c * 2) = il_d2{u[0], u[1]};
-    }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { xp[k] = x[k]; xo[k] = Pc.xs[k]; }
-    Pc = Pn;
+    for (int k = 0; k < 6; ++k) { xp[k] = x[k]; xo[k] = Pc.xs[k]; sx[k] = x[k]; }
+    su[0] = u[0]; su[1] = u[1];
+    sc = c;
     c = cn;
     IL_PT(1); IL_PCNT(5);
+  };
+  for (int q = s0; q < s1; q += 2) {
+    node(PA, PB, q);
+    if (q + 1 < s1) node(PB, PA, q + 1);
   }
+  store();
 }
 
 // 3x3 window as separable axes: source column of window column c, source row of window row r, -1 = the
@@ -1185,7 +1199,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       il_rollout_segment(C, T, T.slevel_segs[q], 1 IL_PROF_PASS);
     IL_SYNC();
   }
-  long long t_der = 0, t_bw = 0, t_ls = 0, t_sel = 0, t_mark = clock64();
+  long long t_der = 0, t_bw = 0, t_ls = 0, t_sel = 0, t_roll = 0, t_mark = clock64();
 #define IL_MARK(acc) do { long long now_ = clock64(); acc += now_ - t_mark; t_mark = now_; } while (0)
   // Each pass of this loop consumes 1..IL_SPEC reference iterations: the backward pass and line search are
   // evaluated for the current mu AND for the next mu values the LM schedule would visit if the step keeps
@@ -1297,6 +1311,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       }
       IL_SYNC();
     }
+    IL_MARK(t_roll);
     il_cost_pass<GEN>(C, T, nuse, recs, MULTI ? wg * IL_WAVES : 0, nw IL_PROF_PASS);
     IL_SYNC();
     IL_MARK(t_ls);
@@ -1356,6 +1371,8 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
     stats[4] = (double)t_der; stats[5] = (double)t_bw; stats[6] = (double)t_ls; stats[7] = (double)t_sel;
 #ifdef IL_PROFILE
     for (int q = 0; q < 16; ++q) stats[8 + q] = (double)prof[q];
+#else
+    stats[8] = (double)t_roll;          // state-chain part of the line search (stats[6] = its cost pass)
 #endif
     stats[IL_NSTAT - 1] = (double)n_pass;
   }

@@ -93,6 +93,15 @@ struct mind_ctx {
       rows, rpe_ptrs;
   // ilqr workspaces
   DevBuf ilqr_dev, aime_dev, rebase_dev2[2], dec_h2;
+  // mind_aime_plan (aime_plan.hip): device arenas, page-locked staging (uploads / read-backs are true async copies: a pageable
+  // source makes hipMemcpyAsync wait for the stream to drain first), host result tables
+  DevBuf pl_root, pl_in[2], pl_lf, pl_lrep, pl_pred, pl_small, pl_tab, pl_win[2], pl_gather, pl_rows;
+  std::vector<DevBuf> pl_world;
+  void *pl_pin[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t pl_pin_cap[4] = {0, 0, 0, 0};
+  hipEvent_t ev_pl = nullptr;
+  std::vector<mind_aime_node> pl_nodes;
+  std::vector<float> pl_rows_host;
   bool dec_overlap = true;      // actor_proj of the decoder on the side stream beside k_dec_scene (mind_set_tuning("dec_overlap"))
   int rb_cur = 0, rb_gen = 0;     // re-basing arenas: which one the last call filled, its generation and geometry
   size_t rb_S = 0, rb_a = 0;
@@ -210,6 +219,14 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
     for (DevBuf *b : {&t.meta, &t.jobs, &t.rows})
       if (b->p) (void)hipFree(b->p);
   if (c->wdev) (void)hipFree(c->wdev);
+  for (DevBuf *b : {&c->pl_root, &c->pl_in[0], &c->pl_in[1], &c->pl_lf, &c->pl_lrep, &c->pl_pred, &c->pl_small, &c->pl_tab, &c->pl_win[0],
+                    &c->pl_win[1], &c->pl_gather, &c->pl_rows})
+    if (b->p) (void)hipFree(b->p);
+  for (DevBuf &b : c->pl_world)
+    if (b.p) (void)hipFree(b.p);
+  for (void *q : c->pl_pin)
+    if (q) (void)hipHostFree(q);
+  if (c->ev_pl) (void)hipEventDestroy(c->ev_pl);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->ev_side) (void)hipEventDestroy(c->ev_side);
   if (c->ev_main) (void)hipEventDestroy(c->ev_main);
@@ -1393,8 +1410,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
       stats[t].iterations = (int)h[0]; stats[t].converged = (int)h[1];
       stats[t].J = h[2]; stats[t].mu = h[3];
       if (getenv("MIND_ILQR_TRACE"))
-        fprintf(stderr, "[k_ilqr] tree %d exo %d M %d segs %d seg-levels %d widest %d agents %d it %d passes %.0f: cycles derivatives %.0f backward %.0f linesearch %.0f select %.0f\n", t,
-                n_phases == 2 ? ph : use_exo, tl[t].M, tl[t].nseg, tl[t].nsl, tl[t].maxls, tl[t].a, stats[t].iterations, h[IL_NSTAT - 1], h[4], h[5], h[6], h[7]);
+        fprintf(stderr, "[k_ilqr] tree %d exo %d M %d segs %d seg-levels %d widest %d agents %d it %d passes %.0f: cycles derivatives %.0f backward %.0f state chain %.0f cost pass %.0f select %.0f\n", t,
+                n_phases == 2 ? ph : use_exo, tl[t].M, tl[t].nseg, tl[t].nsl, tl[t].maxls, tl[t].a, stats[t].iterations, h[IL_NSTAT - 1], h[4], h[5], h[8], h[6], h[7]);
 #ifdef IL_PROFILE
       if (getenv("MIND_ILQR_TRACE")) {
         fprintf(stderr, "[k_ilqr prof] wave0: chain node (n=%.0f): stage %.0f u+dyn+store %.0f | cost chunk (n=%.0f): stage+loads %.0f field %.0f cost+store %.0f | riccati node (n=%.0f): products %.0f Qxx %.0f solve %.0f update %.0f | deriv block (n=%.0f): setup %.0f tasks %.0f assemble %.0f\n",
@@ -1455,7 +1472,7 @@ extern "C" int mind_aime_world(mind_ctx *c, const mind_world_in *in, const mind_
   std::vector<int> ascene(A);
   for (int b = 0; b < B; ++b) {
     AimeScene &S = hs[b];
-    S.a0 = in->actor_off[b]; S.a1 = in->actor_off[b + 1]; S.last = in->last[b]; S.pad = 0; S.pad2 = 0.f;
+    S.a0 = in->actor_off[b]; S.a1 = in->actor_off[b + 1]; S.last = in->last[b]; S.cmp = 0; S.pad2 = 0.f;
     if (S.a1 <= S.a0) return fail(c, MIND_EINVAL, "mind_aime_world: scene %d has no agents", b);
     S.r00 = in->rot[4 * b]; S.r01 = in->rot[4 * b + 1]; S.r10 = in->rot[4 * b + 2]; S.r11 = in->rot[4 * b + 3];
     S.ox = in->orig[2 * b]; S.oy = in->orig[2 * b + 1];
@@ -1567,7 +1584,7 @@ extern "C" int mind_aime_rebase(mind_ctx *c, const mind_rebase_in *in, const min
   if (dev_src) {
     const int *di = (const int *)(d + o_idx);
     hipLaunchKernelGGL(k_aime_windows, dim3((unsigned)(S * a)), dim3(64), 0, st, prev, prev + prev_o_ang, prev + prev_o_vel, in->rows_dev,
-                       di, di + S, di + 2 * S, (int)a, d + o_pos, d + o_ang, d + o_vel);
+                       di, di + S, di + 2 * S, (int)a, d + o_pos, d + o_ang, d + o_vel, 1, (float *)nullptr);
   }
   c->rb_cur ^= 1; c->rb_gen += 1; c->rb_S = S; c->rb_a = a;
   if (out->gen) *out->gen = c->rb_gen;
@@ -1583,6 +1600,8 @@ extern "C" int mind_aime_rebase(mind_ctx *c, const mind_rebase_in *in, const min
   HIPCHK(c, hipStreamSynchronize(st));     // the caller's host arrays may be reused after return
   return MIND_OK;
 }
+
+#include "aime_plan.hip"
 
 // ---- debug taps (tests only): run only the first n fusion layers; read back internal buffers
 extern "C" int mind_debug_set_layers(mind_ctx *c, int n) {

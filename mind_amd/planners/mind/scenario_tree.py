@@ -130,7 +130,7 @@ class ChildScene(dict):
 
 def hist_rows(d, key, lo, hi):
     """rows lo..hi of a node's history array, without materialising a ChildScene's concatenation"""
-    return d.rows(key, lo, hi) if isinstance(d, ChildScene) else d[key][:, lo:hi]
+    return d.rows(key, lo, hi) if isinstance(d, (ChildScene, NativeScene)) else d[key][:, lo:hi]
 
 
 def hist_trim(d, keep):
@@ -152,6 +152,22 @@ def cov_last_of(d):
     """TRAJS_COV_HIST[:, -1, 0] of a scene, without materialising a lazily held history"""
     v = getattr(d, "cov_last", None)
     return v if v is not None else d["TRAJS_COV_HIST"][:, -1, 0]
+
+
+class NativeScene(dict):
+    """Data of a tree node grown by mind_aime_plan (the whole AIME loop in native code): the fields the returned scenario trees and
+    the planner read, and the node's first `dur` predicted steps [a,dur,3] = (x, y, max-sigma) -- the only rows get_scenario_tree
+    (scenario_tree.py:208-272) attaches."""
+
+    def __init__(self, fields, packed, obs_len):
+        super().__init__(fields)
+        self.packed, self.obs_len = packed, obs_len
+
+    def rows(self, key, lo, hi):
+        if lo != self.obs_len or self.packed is None or key not in ("TRAJS_POS_HIST", "TRAJS_COV_HIST"):
+            raise KeyError(f"{key}[{lo}:{hi}] of a natively grown node is not held on the host")
+        n = min(hi - lo, self.packed.shape[1])
+        return self.packed[:, :n, 0:2] if key == "TRAJS_POS_HIST" else self.packed[:, :n, 2:3]
 
 
 class RemoteScene(dict):
@@ -188,6 +204,10 @@ class ScenarioTreeGenerator:
         env = os.environ.get("MIND_DEVICE_WINDOWS")
         self.device_windows = None if env is None else env == "1"
         self.device_select = True   # ... and its pruning decisions (k_aime_select); False: decided on the host from the device's signatures
+        # the whole AIME loop in ONE native call (mind_aime_plan: per-round bookkeeping in C++, one small read-back per round) when the
+        # network is the HIP predictor itself; MIND_NATIVE_AIME=0 / the attribute keep the round-by-round path (same kernels, same trees)
+        self.native_aime = os.environ.get("MIND_NATIVE_AIME", "1") != "0"
+        self.n_native_plans = 0
         self.branch_depth = 0
         self.n_expanded = 0           # scenes pushed through the predictor (metric: nodes expanded)
         self.shard = None             # mind_amd.parallel.Shard: block-distribute each round's scenes over ranks
@@ -213,8 +233,53 @@ class ScenarioTreeGenerator:
         self.target_lane_info = np.concatenate(cols, axis=-1).astype(F32)
 
     # ------------------------------------------------------------------------------------------
+    def _native_ok(self):
+        net = self.network
+        return (self.native_aime and self.device_glue and self.device_select and type(net).__name__ == "ScenePredNet"
+                and getattr(net, "rt", None) is not None and getattr(net, "_loaded", False) and hasattr(net.rt, "aime_plan")
+                and (self.shard is None or self.shard.world == 1) and self.ego_idx == 0 and self.target_lane is not None
+                and len(self.target_lane) >= 12 and self.config is not None)
+
+    def _branch_aime_native(self, root):
+        """branch_aime through mind_aime_plan; None = the library left this plan to the round-by-round path."""
+        self.prepare_root_data(root)
+        hist = np.concatenate([root["TRAJS_POS_HIST"], root["TRAJS_VEL_HIST"], root["TRAJS_ANG_HIST"][..., None], root["TRAJS_COV_HIST"]], axis=2)
+        if hist.shape[1] != self.obs_len or self.obs_len != 50 or not (2 <= self.pred_len <= 60) or root["LANES"].shape[0] == 0:
+            return None
+        res = self.network.rt.aime_plan(root, hist, self.lane_graph["lane_ctrs"], self.lane_graph["lane_vecs"], self.target_lane,
+                                        self.target_lane_info, self.config.tar_time_ahead, self.config.tar_dist_thres, self.config.max_depth,
+                                        pred_len=self.pred_len)
+        if res is None:
+            return None
+        nodes, rows, info = res
+        rf = info["root_flags"]
+        self.tree.add_node(Node("root", None, ScenarioData(None, root, branch_flag=bool(rf & 1), end_flag=bool(rf & 2), terminate_flag=bool(rf & 4))))
+        a = info["a"]
+        keys = []
+        types, tids, cats = root["TRAJS_TYPE"], root["TRAJS_TID"], root["TRAJS_CAT"]
+        for n in nodes:
+            key = "{}_{}_{}".format(int(n["round"]), int(n["scene"]), int(n["mode"]))
+            pkey = "root" if n["parent"] < 0 else keys[int(n["parent"])]
+            dur, off = int(n["dur"]), int(n["row_off"])
+            packed = rows[off:off + a * dur * 3].reshape(a, dur, 3) if off >= 0 else None
+            fl = int(n["flags"])
+            d = NativeScene({"SCEN_PROB": F32(n["prob"]), "CUR_T": int(n["cur_t"]), "END_T": int(n["end_t"]), "PARENT_ID": pkey, "SCEN_ID": key,
+                             "TRAJS_TYPE": types, "TRAJS_TID": tids, "TRAJS_CAT": cats,
+                             "TGT_PTS": np.array(n["tgt_pts"], F32).reshape(11, 2)}, packed, self.obs_len)
+            self.tree.add_node(Node(key, pkey, ScenarioData(d, None, branch_flag=bool(fl & 1), end_flag=bool(fl & 2), terminate_flag=bool(fl & 4))))
+            keys.append(key)
+        self.n_expanded += info["n_expanded"]
+        self.branch_depth = info["n_rounds"]
+        self.n_native_plans += 1
+        return self.get_scenario_tree()
+
     def branch_aime(self, lcl_smp, agent_obs):
         root = self.process_data(lcl_smp, agent_obs)
+        if self._native_ok():
+            trees = self._branch_aime_native(root)
+            if trees is not None:
+                return trees
+            self.reset()            # (keeps lane graph / target lane: only the per-plan bookkeeping)
         self.init_scenario_tree(root)
         branch_nodes = self.get_branch_set()
         while branch_nodes:

@@ -8,6 +8,12 @@ import torch
 from . import _lib
 
 
+# record layout of mind_aime_node (include/mind_hip.h)
+AIME_NODE_DTYPE = np.dtype({"names": ["round", "scene", "mode", "parent", "prob", "cur_t", "end_t", "flags", "dur", "row_off", "tgt_pts"],
+                            "formats": ["<i4", "<i4", "<i4", "<i4", "<f4", "<i4", "<i4", "<i4", "<i4", "<i8", ("<f4", (22,))],
+                            "offsets": [0, 4, 8, 12, 16, 20, 24, 28, 32, 40, 48], "itemsize": 136})
+
+
 class IlqrCall:
     """One tree-iLQR call split into its three parts, so that a caller can prepare the arguments on its own thread, hand
     only ``run`` (a single C call, which releases the GIL) to another thread / context and read the results later.
@@ -424,6 +430,43 @@ class HipPredictor:
         _lib.check(self.lib, self.ctx, rc, "mind_aime_rebase")
         out["gen"] = self._rebase_gen = int(gen.value)      # the arena of THIS call is what a device-source call can build on next
         return out
+
+    def aime_plan(self, root, hist, lane_ctrs, lane_vecs, target_lane, target_lane_info, time_ahead, dist_thres, max_depth,
+                  pred_len=50, min_vel=0.5, max_rounds=16):
+        """ScenarioTreeGenerator.branch_aime in one call (mind_aime_plan): ``root`` = the root scene dict of process_data (ACTORS,
+        TRAJS_CTRS, TRAJS_VECS, LANES, TGT_NODES, TGT_RPE, ROT, ORIG, TGT_PTS, TRAJS_TYPE), ``hist`` [a,50,6] its world-frame history
+        (x, y, vx, vy, heading, max-sigma).  Returns (nodes: structured array, one record per internal tree node in creation order,
+        rows: float32 [n], info dict) or None when the library reports a situation only the round-by-round path handles."""
+        f = lambda x: np.ascontiguousarray(x, np.float32)
+        fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+        arrs = dict(actors=f(root["ACTORS"]), actor_ctrs=f(root["TRAJS_CTRS"]), actor_vecs=f(root["TRAJS_VECS"]), lanes=f(root["LANES"]),
+                    lane_ctrs=f(lane_ctrs), lane_vecs=f(lane_vecs), tgt_nodes=f(root["TGT_NODES"]), tgt_rpe=f(root["TGT_RPE"]),
+                    rot=f(root["ROT"]), orig=f(root["ORIG"]), tgt_pts=f(root["TGT_PTS"]), hist=f(hist), types=f(root["TRAJS_TYPE"]),
+                    target_lane=f(target_lane), target_lane_info=f(target_lane_info))
+        a, l, P = arrs["actors"].shape[0], arrs["lanes"].shape[0], arrs["target_lane"].shape[0]
+        assert arrs["actors"].shape == (a, 14, 48) and arrs["hist"].shape == (a, 50, 6) and arrs["types"].shape == (a, 50, 7)
+        assert arrs["lanes"].shape == (l, 10, 16) and arrs["lane_ctrs"].shape == (l, 2) and arrs["target_lane_info"].shape == (P, 12)
+        pi, po = _lib.AimePlanIn(), _lib.AimePlanOut()
+        pi.n_agents, pi.n_lanes, pi.n_lane_pts = a, l, P
+        for k, v in arrs.items():
+            setattr(pi, k, fp(v))
+        pi.time_ahead, pi.min_vel, pi.dist_thres = float(time_ahead), float(min_vel), float(dist_thres)
+        pi.max_depth, pi.max_rounds, pi.pred_len = int(max_depth), int(max_rounds), int(pred_len)
+        rc = self.lib.mind_aime_plan(self.ctx, C.byref(pi), C.byref(po))
+        if rc == _lib.MIND_ESTATE:
+            msg = self.lib.mind_last_error_string(self.ctx) or b""
+            if msg.startswith(b"unsupported"):
+                self.last_aime_fallback = msg.decode()
+                return None
+        _lib.check(self.lib, self.ctx, rc, "mind_aime_plan")
+        n = po.n_nodes
+        nodes = np.frombuffer(C.string_at(po.nodes, n * C.sizeof(_lib.AimeNode)), dtype=AIME_NODE_DTYPE) if n else np.zeros(0, AIME_NODE_DTYPE)
+        nf = int(po.n_row_floats)
+        rows = np.frombuffer(C.string_at(po.rows, nf * 4), dtype=np.float32) if nf else np.zeros(0, np.float32)
+        info = dict(n_expanded=po.n_expanded, n_rounds=po.n_rounds, root_flags=po.root_flags, a=a, l=l,
+                    round_scenes=[po.round_scenes[i] for i in range(po.n_rounds)], pair_ms=po.pair_ms, pair_launches=po.pair_launches)
+        self.last_aime_info = info
+        return nodes, rows, info
 
     def lane_dist_field(self, ego_xy, lane, W, H, res):
         """gen_dist_field (ilqr/utils.py:5-22) -> (offset [2], gx [W], gy [H], dist [H,W])."""

@@ -1,0 +1,53 @@
+"""mind_aime_plan (the whole AIME loop of ScenarioTreeGenerator.branch_aime, scenario_tree.py:38-58, in one native call: per-round
+bookkeeping in C++, branch-time test / windows / re-basing on the device) against the round-by-round host path over the same
+kernels: the internal tree (node ids in insertion order, CUR_T / END_T, branch / end / terminate flags) and every returned scenario
+tree (sibling-normalised probabilities, agent trajectories, covariances, target windows) must be bit-identical, cycle by cycle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _flat(trees):
+    out = []
+    for t in trees:
+        for k, n in t.nodes.items():
+            out.append((k, n.parent_key, np.asarray(n.data[0]).copy(), np.asarray(n.data[1]).copy(), np.asarray(n.data[2]).copy(),
+                        np.asarray(n.data[3]).copy()))
+    return out
+
+
+@pytest.mark.parametrize("scene", ["demo_1", "demo_3"])
+def test_native_plan_equals_the_round_by_round_path(scene):
+    sys.path.insert(0, ROOT)
+    from bench import BRANCHING_WEIGHTS, WORKLOADS, make_closed_loop
+    sims = []
+    for native in (True, False):
+        pl, sim, w = make_closed_loop(dict(WORKLOADS[scene]), ckpt=BRANCHING_WEIGHTS, speculative=False)
+        pl.scen_tree_gen.native_aime = native
+        sims.append((pl, sim))
+    n_multi = 0
+    for cycle in range(8):
+        res = []
+        for pl, sim in sims:
+            sim.run_plans(1)
+            gen = pl.scen_tree_gen
+            internal = [(k, n.parent_key, int(n.data.data["CUR_T"]) if n.data.data is not None else -1,
+                         int(n.data.data["END_T"]) if n.data.data is not None else -1,
+                         bool(n.data.branch_flag), bool(n.data.end_flag), bool(n.data.terminate_flag)) for k, n in gen.tree.nodes.items()]
+            res.append((internal, _flat(gen.get_scenario_tree()), np.array(sim.ctrl), pl.timing["nodes_expanded"], pl.timing["best_traj_idx"]))
+        (ia, fa, ca, ea, ba), (ib, fb, cb, eb, bb) = res
+        assert ia == ib, (cycle, ia, ib)
+        assert len(fa) == len(fb) and ea == eb and ba == bb
+        for x, y in zip(fa, fb):
+            assert x[0] == y[0] and x[1] == y[1], (cycle, x[0], y[0])
+            for u, v in zip(x[2:], y[2:]):
+                assert u.dtype == v.dtype and u.shape == v.shape and np.array_equal(u, v), (cycle, x[0])
+        assert np.array_equal(ca, cb)
+        n_multi += len(ia) > 3
+    assert sims[0][0].scen_tree_gen.n_native_plans == 8 and sims[1][0].scen_tree_gen.n_native_plans == 0
+    assert n_multi >= 4                 # the branching weights really grow multi-round trees here
