@@ -110,6 +110,8 @@ struct mind_ctx {
   hipEvent_t ev_il0 = nullptr, ev_il1 = nullptr;   // around the tree-iLQR launch of the last call (profiling on)
   float ilqr_ms = 0.f;
   int ilqr_multi = 0, ilqr_trees = 0;
+  bool ilqr_test_starve = false;
+  long long n_ilqr_fallbacks = 0;   // wide-tree launches that were not fully resident and were re-run on one workgroup per tree
   int n_pair_launch = 0;
   float pair_ms = 0.f;
   double pairs_done = 0.0;
@@ -257,6 +259,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "dec_overlap") c->dec_overlap = value != 0;
   else if (n == "ilqr_wgs") c->ilqr_wgs = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (n == "ilqr_multi_min") c->ilqr_multi_min = value;
+  else if (n == "ilqr_test_starve") c->ilqr_test_starve = value != 0;   // tests: launch a wide tree without its last workgroups
   else return fail(c, MIND_EINVAL, "mind_set_tuning: unknown knob '%s'", name);
   return MIND_OK;
 }
@@ -1374,16 +1377,22 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     HIPCHK(c, hipEventRecord(c->ev_il0, st));
   }
   c->ilqr_trees = n_trees; c->ilqr_multi = multi ? G : 1; c->ilqr_ms = 0.f;
-  if (gen) {
-    (void)hipFuncSetAttribute((const void *)k_ilqr<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
-    hipLaunchKernelGGL((k_ilqr<true, false>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
-  } else if (multi) {
-    (void)hipFuncSetAttribute((const void *)k_ilqr<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
-    hipLaunchKernelGGL((k_ilqr<false, true>), dim3(((n_trees + 7) / 8) * 8 * G), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, G, dBars);
-  } else {
-    (void)hipFuncSetAttribute((const void *)k_ilqr<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
-    hipLaunchKernelGGL((k_ilqr<false, false>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
-  }
+  auto launch = [&](bool multi_) {
+    if (gen) {
+      (void)hipFuncSetAttribute((const void *)k_ilqr<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
+      hipLaunchKernelGGL((k_ilqr<true, false>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
+    } else if (multi_) {
+      (void)hipFuncSetAttribute((const void *)k_ilqr<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
+      // (ilqr_test_starve: the last eight workgroups are withheld, as if the device could not hold the whole launch: their peers wait
+      // at the first barrier, raise the abort word and the call falls back to the one-workgroup kernel below)
+      hipLaunchKernelGGL((k_ilqr<false, true>), dim3(((n_trees + 7) / 8) * 8 * G - (c->ilqr_test_starve ? 8 : 0)), dim3(IL_THREADS), il_lds, st, dT, dK,
+                         n_phases, n_trees, G, dBars);
+    } else {
+      (void)hipFuncSetAttribute((const void *)k_ilqr<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
+      hipLaunchKernelGGL((k_ilqr<false, false>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
+    }
+  };
+  launch(multi);
   HIPCHK(c, hipGetLastError());
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_il1, st));
   std::vector<double> hs((size_t)2 * IL_NSTAT * n_trees);
@@ -1397,7 +1406,19 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   if (multi) {
     unsigned aborted = 0;
     HIPCHK(c, hipMemcpy(&aborted, dBars + 4 * (size_t)n_trees, sizeof(unsigned), hipMemcpyDeviceToHost));
-    if (aborted) return fail(c, MIND_EHIP, "k_ilqr: the workgroups of a cost tree did not meet at a barrier (launch not fully resident?)");
+    if (aborted) {
+      // the workgroups of a wide tree did not meet at a barrier within ~2 s: the launch was not fully resident (another context or
+      // stream held CUs -- several planners on one GPU).  The one-workgroup-per-tree kernel needs no co-residency: the upload (initial
+      // controls, zeroed barrier words) is repeated and the call solved with it -- same arithmetic, same results, just slower.
+      c->n_ilqr_fallbacks++;
+      HIPCHK(c, hipMemcpyAsync(base, up.data(), o_work, hipMemcpyHostToDevice, st));
+      launch(false);
+      HIPCHK(c, hipGetLastError());
+      c->ilqr_multi = 1;
+      HIPCHK(c, hipMemcpyAsync(hx.data(), Dp(tl[0].xs), hx.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipMemcpyAsync(us, Dp(tl[0].us), (size_t)Mtot * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipStreamSynchronize(st));
+    }
   }
   memcpy(xs, hx.data(), (size_t)Mtot * 6 * sizeof(double));
   memcpy(hs.data(), hx.data() + n_xs, hs.size() * sizeof(double));

@@ -35,6 +35,15 @@ class Shard:
         self.device = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
         self.n_collectives = 0
         self.bytes_gathered = 0
+        # a one-rank group normally short-cuts every collective; MIND_FORCE_COLLECTIVES=1 (tests: a world-size-1 nccl group on the
+        # one-GPU box) runs them for real, so the RCCL code path is executed even where a second device is missing
+        import os
+        self.force = os.environ.get("MIND_FORCE_COLLECTIVES", "0") == "1"
+
+    @property
+    def sharded(self):
+        """do the collectives run?  (more than one rank, or forced on a one-rank group)"""
+        return self.active and (self.world > 1 or self.force)
 
     def block(self, n):
         """[lo, hi) of this rank among n items (first ranks get the remainder)."""
@@ -49,7 +58,7 @@ class Shard:
         """Every tensor is [n_i, ...] on this rank with rank-dependent n_i.  Returns, per tensor, the rows of all
         ranks concatenated in rank order (on ``self.device``) -- one small collective for all the counts, one
         ``all_gather_into_tensor`` per tensor on buffers padded to the largest rank."""
-        if not self.active or self.world == 1:
+        if not self.sharded:
             return [t for t in tensors]
         dist, W, dev = self.dist, self.world, self.device
         cnt = torch.tensor([int(t.shape[0]) for t in tensors], dtype=torch.int64, device=dev)
@@ -79,7 +88,7 @@ class Shard:
 
     def broadcast(self, t, src=0):
         """In-place broadcast of a tensor on ``self.device`` from ``src``."""
-        if self.active and self.world > 1:
+        if self.sharded:
             self.dist.broadcast(t, src, group=self.group)
             self.n_collectives += 1
         return t
@@ -91,7 +100,7 @@ def gather_round_robin(shard, sizes, local_rows):
     all n items (numpy) on every rank -- one packed all-gather."""
     n = len(sizes)
     t = torch.from_numpy(np.ascontiguousarray(local_rows))
-    if not shard.active or shard.world == 1:
+    if not shard.sharded:
         flat = t
         order = list(range(n))
     else:

@@ -6,6 +6,7 @@ plan() = AIME scenario tree (batched predictor on the GPU) -> contingency tree-i
 scenario tree (all trees in one launch) -> min-cost tree -> first control.
 """
 import json
+import re
 import os
 from collections import namedtuple
 from importlib import import_module
@@ -69,10 +70,10 @@ class MINDPlanner:
         from .networks.network import ScenePredNet
         self.network = ScenePredNet(net_cfg, self.device)
         path = self.planner_cfg["ckpt_path"]
-        if str(path).startswith("formula"):         # "formula:<seed>" or "formula_<variant>:<seed>" (mind_amd/weights.py)
+        m = re.fullmatch(r"formula(?:_(\w+))?:(\d+)", str(path))     # "formula:<seed>" or "formula_<variant>:<seed>" (mind_amd/weights.py);
+        if m is not None:                                            # anything else -- "formula_runs/x.tar" included -- is a checkpoint file
             from ...weights import formula_state_dict
-            head, seed = str(path).split(":")
-            sd = formula_state_dict(int(seed), as_torch=True, variant=head[len("formula_"):] or None if head != "formula" else None)
+            sd = formula_state_dict(int(m.group(2)), as_torch=True, variant=m.group(1))
         else:
             sd = torch.load(path, map_location="cpu")["state_dict"]
         self.network.load_state_dict(sd)
@@ -150,6 +151,12 @@ class MINDPlanner:
         t1 = time.perf_counter()
         if len(scen_trees) < 0:
             return False, None, None
+        return self._solve_and_select(lcl_smp, scen_trees, t0, t1, n0)
+
+    def _solve_and_select(self, lcl_smp, scen_trees, t0, t1, n0):
+        """planner.py:120-145: contingency solve of every scenario tree, evaluation, the reference's strict `<` scan for the
+        cheapest tree (the first minimum; a NaN cost never wins), first control.  Shared by plan() and plan_rounds()."""
+        import time
         traj_trees = self.traj_tree_opt.solve_batch(scen_trees, self.state, self.ctrl, self.gt_tgt_lane,
                                                     lcl_smp.target_velocity)
         t2 = time.perf_counter()
@@ -185,17 +192,7 @@ class MINDPlanner:
         n0 = self.scen_tree_gen.n_expanded
         scen_trees = yield from self.scen_tree_gen.branch_aime_rounds(lcl_smp, self.agent_obs)
         t1 = time.perf_counter()
-        traj_trees = self.traj_tree_opt.solve_batch(scen_trees, self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)
-        t2 = time.perf_counter()
-        costs = self.evaluate_traj_trees(lcl_smp, traj_trees)
-        best = int(np.argmin(costs))            # first minimum, as the reference's strict `<` scan keeps it
-        opt = traj_trees[best]
-        nxt = opt.get_node(opt.get_root().children_keys[0])
-        self.timing = {"aime_s": t1 - t0, "ilqr_s": t2 - t1, "total_s": time.perf_counter() - t0,
-                       "nodes_expanded": self.scen_tree_gen.n_expanded - n0, "n_scen_trees": len(scen_trees),
-                       "best_traj_idx": best, "tree_costs": [float(c) for c in costs]}
-        self._accumulate_timing()
-        return True, nxt.data[0][-2:], [[scen_trees[best]], [traj_trees[best]]]
+        return self._solve_and_select(lcl_smp, scen_trees, t0, t1, n0)
 
     def resample_target_lane(self, lcl_smp):
         """1 m resampling of the target lane and its per-point info (planner.py:147-171)."""

@@ -237,7 +237,7 @@ class ScenarioTreeGenerator:
         net = self.network
         return (self.native_aime and self.device_glue and self.device_select and type(net).__name__ == "ScenePredNet"
                 and getattr(net, "rt", None) is not None and getattr(net, "_loaded", False) and hasattr(net.rt, "aime_plan")
-                and (self.shard is None or self.shard.world == 1) and self.ego_idx == 0 and self.target_lane is not None
+                and (self.shard is None or not self.shard.sharded) and self.ego_idx == 0 and self.target_lane is not None
                 and len(self.target_lane) >= 12 and self.config is not None)
 
     def _branch_aime_native(self, root):
@@ -319,11 +319,11 @@ class ScenarioTreeGenerator:
         RCCL), after which every rank assembles the same list in batch order.  The first round of a plan (the root
         scene, on rank 0) is followed by a broadcast of LaneNet's output, which every later round reuses."""
         sh = self.shard
-        if sh is None or sh.world == 1:
+        if sh is None or not sh.sharded:
             pred = self.predict_scenes(batch) if batch else None
             self._finish_root()
             hdr, rows = self.prune_select(batch, pred, 0)
-            return self.assemble_children(batch, hdr, _np(rows), rows if isinstance(rows, torch.Tensor) and rows.is_cuda else None)
+            return self.assemble_children(batch, hdr, _np(rows), rows if getattr(self, "_rows_persistent", False) else None)
         lo, hi = sh.block(len(batch))
         mine = batch[lo:hi]
         assert not any(isinstance(s, RemoteScene) for s in mine), "a rank was dealt a scene it did not re-base"
@@ -437,7 +437,7 @@ class ScenarioTreeGenerator:
             out, packed, lane_feat = yield batch, d
             self.predict_done(batch, data, lane_feat)
             hdr, rows = self.prune_select(batch, out, 0, packed=packed)
-            self.create_nodes(self.assemble_children(batch, hdr, _np(rows), rows if isinstance(rows, torch.Tensor) and rows.is_cuda else None))
+            self.create_nodes(self.assemble_children(batch, hdr, _np(rows), rows if getattr(self, "_rows_persistent", False) else None))
             self.decide_branch()
             batch = [n.data.obs_data for n in self.get_branch_set()]
         assert len(self.get_end_set()) > 0, "No end node found in the scenario tree."
@@ -472,7 +472,7 @@ class ScenarioTreeGenerator:
                 l.data.end_flag = True
         if todo:
             own = None
-            if self.shard is not None and self.shard.world > 1:
+            if self.shard is not None and self.shard.sharded:
                 own = self.shard.block(len(todo))       # the rank that expands a scene next round is the one that re-bases it
             for l, (obs, cur) in zip(todo, self.update_obser_batch([l.data.data for l in todo], own)):
                 l.data.obs_data, l.data.data = obs, cur
@@ -665,7 +665,10 @@ class ScenarioTreeGenerator:
             return np.zeros((0, self.HDR), F32), torch.zeros(0, 60, 6, device=dev)
         flat = np.concatenate([np.arange(a_off[l], a_off[l + 1]) * 6 + k for l, k, _ in picks])       # (agent row, mode) -> row of [A*6]
         idx = torch.from_numpy(flat).to(dev)
-        if self._use_device_windows(rt, len(picks)):
+        # the children only keep a handle on the device rows when those sit in the persistent ping-pong buffer (the next re-basing then
+        # cuts their windows out of it): a fresh index_select block held by the whole tree until reset() pinned tens of MB per round
+        self._rows_persistent = self._use_device_windows(rt, len(picks))
+        if self._rows_persistent:
             # the kept rows stay on the device until the next re-basing cuts the children's windows out of them: they go into one
             # of two persistent buffers of the runtime (alternating by round) instead of a fresh allocator block -- holding
             # allocator blocks across rounds pushed the caching allocator into its slow path (hipMalloc) every plan
@@ -683,6 +686,7 @@ class ScenarioTreeGenerator:
         topology merge.  -> (hdr [P,25] float32: scene index in the round's full batch, mode, path probability, the
         scene's target window; rows [sum a,60,6]: (x, y, vx, vy, heading, max-sigma) of every agent of every kept mode,
         a device tensor when the predictor outputs live on the device)."""
+        self._rows_persistent = False
         if not scenes:
             return np.zeros((0, self.HDR), F32), torch.zeros(0, 60, 6)
         res_cls_b, res_reg_b, res_aux_b = out

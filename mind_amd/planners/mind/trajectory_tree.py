@@ -287,7 +287,7 @@ class TrajectoryTreeOptimizer:
             else:
                 _, us_w, st_w = solve(ilqr_cfg_from(self.config, "w_opt_cfg"), sub, x0, lane, target_vel, 0, None)
                 xs, us, st = solve(ilqr_cfg_from(self.config, "opt_cfg"), sub, x0, lane, target_vel, 1, us_w)
-        if self.shard is not None and self.shard.world > 1:
+        if self.shard is not None and self.shard.sharded:
             # one packed all-gather of the [M, 8] float64 (xs | us) rows of every rank's trees
             from ...parallel import gather_round_robin
             local = (np.concatenate([np.concatenate([np.asarray(x, np.float64), np.asarray(u, np.float64)], axis=1) for x, u in zip(xs, us)])

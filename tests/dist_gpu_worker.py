@@ -13,7 +13,8 @@ import torch.distributed as dist
 def main(out_path, n_plans):
     from bench import WORKLOADS, make_closed_loop
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    forced = os.environ.get("MIND_FORCE_COLLECTIVES", "0") == "1"     # a one-rank group whose collectives really run (parallel.Shard.force)
+    if world > 1 or forced:
         backend = os.environ.get("MIND_DIST_BACKEND", "gloo")      # nccl = RCCL, one rank per GPU (LOCAL_RANK)
         if backend == "nccl":
             import torch
@@ -22,9 +23,10 @@ def main(out_path, n_plans):
         else:
             dist.init_process_group("gloo")
     pl, sim, w = make_closed_loop(dict(WORKLOADS["demo1"]))
-    if world > 1:
+    sh = None
+    if world > 1 or forced:
         sh = pl.enable_sharding()
-        assert sh.world == world
+        assert sh.world == world and sh.sharded
     res = []
     for _ in range(n_plans):
         sim.run_plans(1)
@@ -34,8 +36,10 @@ def main(out_path, n_plans):
                         xs=np.array([n.data[0] for k, n in traj[0].nodes.items() if k != -1]),
                         pos0=next(iter(scen[0].nodes.values())).data[1]))
     with open(out_path, "wb") as f:
-        pickle.dump(dict(res=res, expanded=pl.scen_tree_gen.n_expanded), f)
-    if world > 1:
+        pickle.dump(dict(res=res, expanded=pl.scen_tree_gen.n_expanded, backend=None if sh is None else sh.backend,
+                         collectives=0 if sh is None else sh.n_collectives, gathered=0 if sh is None else sh.bytes_gathered,
+                         native_plans=pl.scen_tree_gen.n_native_plans), f)
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -134,6 +134,64 @@ def test_wide_trees_on_several_workgroups_are_bit_identical(hip_predictor):
     assert sf1[0]["iterations"] >= 2
 
 
+def test_singular_q_uu_path_on_one_and_on_several_workgroups(hip_predictor):
+    """Quirk Q9 (solver.py:147-151): a LinAlgError of the 2x2 solve burns an iteration without raising mu.  With control weights
+    -dt^2 / 2 the leaf's Q_uu = 2 w p + dt^2 (0 + mu) is EXACTLY zero at mu = 1 (node probability 1), so every pass of the fit
+    takes the singular-retry path until max_iter.  The kernel must follow the oracle through it -- and the several-workgroup
+    variant (whose singular-slot word lives in global memory and is cleared by workgroup 0 at the top of the pass after next: the
+    retry path needs its own barrier for that) must equal the one-workgroup kernel."""
+    sst = scripted_scenario_tree("straight", 4)
+    flat = oi.flatten(sst["nodes"])
+    assert set(flat["prob"].tolist()) == {1.0}
+    x0 = oi.init_state(sst["state"], sst["ctrl"])
+    cfg = oi.default_cfg(max_iter=9)
+    w = -(0.2 * 0.2) / 2
+    cfg.w_ctrl[:] = [w, w]
+    ref = oi.solve(cfg, flat, x0, sst["target_lane"], sst["target_vel"], 1)
+    assert ref["iterations"] == 9 and ref["mu"] == 1.0                      # the oracle never leaves the retry path
+    one = hip_predictor.ilqr_solve(cfg, [flat], x0, sst["target_lane"], sst["target_vel"], 1)
+    assert one[2][0]["iterations"] == 9 and one[2][0]["mu"] == 1.0
+    assert np.array_equal(one[0][0], ref["xs"]) and np.array_equal(one[1][0], ref["us"])
+    try:
+        hip_predictor.set_tuning("ilqr_multi_min", 8)
+        for G in (2, 4, 8):
+            hip_predictor.set_tuning("ilqr_wgs", G)
+            for rep in range(3):
+                got = hip_predictor.ilqr_solve(cfg, [flat, flat], x0, sst["target_lane"], sst["target_vel"], 1)
+                assert hip_predictor.ilqr_stats()[2] == G
+                for t in range(2):
+                    assert np.array_equal(got[0][t], one[0][0]) and np.array_equal(got[1][t], one[1][0]) and got[2][t] == one[2][0], G
+    finally:
+        hip_predictor.set_tuning("ilqr_multi_min", 192)
+        hip_predictor.set_tuning("ilqr_wgs", 8)
+
+
+def test_wide_tree_launch_that_is_not_resident_falls_back_to_one_workgroup(hip_predictor):
+    """Several workgroups per tree need every workgroup of the launch on the device at once; when another context holds CUs
+    (several planners on one GPU) the barrier would never complete.  The waiting workgroups raise the abort word (~1 s) and the
+    call is solved again by the one-workgroup-per-tree kernel: same results, no error.  Reproduced by withholding the last
+    workgroups of the launch (mind_set_tuning("ilqr_test_starve"))."""
+    sst = scripted_scenario_tree("branch3", 6)
+    flat = oi.flatten(sst["nodes"])
+    x0 = oi.init_state(sst["state"], sst["ctrl"])
+    cfg = oi.default_cfg(max_iter=5)
+    ref = hip_predictor.ilqr_solve(cfg, [flat], x0, sst["target_lane"], sst["target_vel"], 1)
+    try:
+        hip_predictor.set_tuning("ilqr_multi_min", 8)
+        hip_predictor.set_tuning("ilqr_wgs", 4)
+        ok = hip_predictor.ilqr_solve(cfg, [flat], x0, sst["target_lane"], sst["target_vel"], 1)
+        assert hip_predictor.ilqr_stats()[2] == 4                       # really on four workgroups
+        hip_predictor.set_tuning("ilqr_test_starve", 1)
+        got = hip_predictor.ilqr_solve(cfg, [flat], x0, sst["target_lane"], sst["target_vel"], 1)
+        assert hip_predictor.ilqr_stats()[2] == 1                       # aborted, solved again on one workgroup
+    finally:
+        hip_predictor.set_tuning("ilqr_test_starve", 0)
+        hip_predictor.set_tuning("ilqr_multi_min", 192)
+        hip_predictor.set_tuning("ilqr_wgs", 8)
+    for r in (ok, got):
+        assert np.array_equal(r[0][0], ref[0][0]) and np.array_equal(r[1][0], ref[1][0]) and r[2] == ref[2]
+
+
 @pytest.mark.parametrize("n_agents", [1, 2])
 def test_tiny_trees_and_ego_only(n_agents, hip_predictor):
     """one- and two-node cost trees, a scene with the ego alone (no exo term at all)."""

@@ -125,3 +125,22 @@ def test_two_ranks_over_rccl_when_two_devices_are_visible(tmp_path):
         for pa, pb in zip(single["res"], b["res"]):
             assert pa["keys"] == pb["keys"] and pa["best"] == pb["best"]
             assert np.array_equal(pa["pos0"], pb["pos0"]) and np.array_equal(pa["xs"], pb["xs"])
+
+
+def test_one_rank_rccl_group_runs_every_collective_of_the_sharded_plan(tmp_path):
+    """RCCL executed on the one-GPU box: a world-size-1 `nccl` process group with the short-cuts of parallel.Shard switched off
+    (MIND_FORCE_COLLECTIVES=1), so every exchange step of the sharded plan -- the per-round packed all_gather_into_tensor of the
+    kept children (header + world-frame rows, device tensors), the broadcast of LaneNet's output, the round-robin gather of the
+    tree-iLQR rows -- goes through the RCCL backend.  The plan must equal the plain single-process plan bit for bit."""
+    single = _run(1, tmp_path)[0]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", MIND_DIST_BACKEND="nccl", MIND_FORCE_COLLECTIVES="1")
+    out = os.path.join(tmp_path, "nccl_w1.pkl")
+    p = subprocess.run([sys.executable, WORKER, out, "3"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    b = pickle.load(open(out, "rb"))
+    assert b["backend"] == "nccl" and b["collectives"] >= 3 * 4 and b["gathered"] > 0          # >= 3 plans x (rounds + broadcast + solves)
+    for pa, pb in zip(single["res"], b["res"]):
+        assert pa["keys"] == pb["keys"] and pa["best"] == pb["best"] and pa["n_trees"] == pb["n_trees"]
+        assert np.array_equal(pa["pos0"], pb["pos0"]) and np.array_equal(pa["xs"], pb["xs"]) and np.array_equal(pa["ctrl"], pb["ctrl"])
+    assert b["expanded"] == single["expanded"]

@@ -48,7 +48,11 @@ class _LibTimer:
 rt.lib.mind_aime_rebase = _LibTimer(rt.lib.mind_aime_rebase, "C: mind_aime_rebase")
 rt.lib.mind_aime_world = _LibTimer(rt.lib.mind_aime_world, "C: mind_aime_world")
 rt.lib.mind_predict_batch = _LibTimer(rt.lib.mind_predict_batch, "C: mind_predict_batch")
-wrap(gen, "_update_obser_device_windows")
+wrap(gen, "_update_obser_device_windows"); wrap(gen, "_branch_aime_native"); wrap(rt, "aime_plan", "rt.aime_plan (C call + marshalling)")
+rt.lib.mind_aime_plan = _LibTimer(rt.lib.mind_aime_plan, "C: mind_aime_plan")
+wrap(sim, "step_begin", "sim.step_begin"); wrap(sim, "step_end", "sim.step_end")
+import mind_amd.closed_loop as CLm
+wrap(CLm, "kine_propagate")
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 t0 = time.perf_counter()
 sim.run_plans(n)
