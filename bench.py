@@ -176,7 +176,7 @@ class Dist:
             self.d.destroy_process_group()
 
 
-def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None):
+def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None, pair_prec=None):
     """K timed planning cycles of one closed loop (barrier + synchronize on both sides, max over ranks), with the pair
     kernel's launch durations taken from HIP events on the context stream inside the timed region."""
     wkw = scene_workload(workload, replica)
@@ -187,6 +187,9 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None):
     if shard and dist.world > 1:
         sh = pl.enable_sharding()
     rt = pl.network.rt
+    prec_before = rt.pair_precision()
+    if pair_prec is not None:
+        rt.set_pair_precision(pair_prec)        # every MFMA contraction of the predictor (pair kernel, ActorNet) follows this setting
     if workload in FULL_TREE:
         # thousands of agents per decoder call: the MFMA variant of its actor part pays here (209 vs 277 us at 13.8 k agents);
         # every rank of a sharded run takes the same kernel
@@ -232,7 +235,7 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None):
 
     rt.aime_plan = prof_plan
     # the tree-iLQR launch of every plan, timed by HIP events on the context stream (mind_last_ilqr_stats)
-    il = {"ms": 0.0, "launches": 0, "trees": 0, "wgs": 1}
+    il = {"ms": 0.0, "launches": 0, "trees": 0, "wgs": 1, "prof": {}}
     orig_solve = pl.traj_tree_opt.solve_batch
 
     def prof_solve(*a, **k):
@@ -240,6 +243,9 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None):
         ms, nt, g = rt.ilqr_stats()
         if ms > 0:
             il["ms"] += ms; il["launches"] += 1; il["trees"] += nt; il["wgs"] = g
+            for kk, v in rt.ilqr_profile().items():        # phase cycles of the launch's critical cost tree
+                il["prof"][kk] = il["prof"].get(kk, 0.0) + v
+            il["prof"]["node_steps"] = il["prof"].get("node_steps", 0.0) + rt.ilqr_profile()["passes"] * rt.ilqr_profile()["depth"]
         return r
 
     pl.traj_tree_opt.solve_batch = prof_solve
@@ -257,6 +263,8 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None):
     rt.aime_plan = orig_plan
     pl.traj_tree_opt.solve_batch = orig_solve
     rt.set_profiling(False)
+    if pair_prec is not None:
+        rt.set_pair_precision(prec_before)
     dt = dist.reduce(dt, "max")
     ctr = {k: v - ctr0.get(k, 0) for k, v in pl.traj_tree_opt.counters.items()}
     npl = max(pl.timing_sum["plans"] - tsum0["plans"], 1)
@@ -300,6 +308,50 @@ def roofline(m, prec):
                 "512 B per pair read/written once per layer; launch durations from HIP events on the context stream inside the timed "
                 "region; f_min_tflops prices SURVEY 8(d)'s un-folded F_min; traffic: PMC passes are separate runs (profiles/), not "
                 "measured in this run"}
+
+
+def measure_traffic(workload, alg_bytes_per_launch, steps=6, warmup=2):
+    """HBM traffic of the pair kernel from the hardware counters: two sibling runs of this script under `rocprofv3 --pmc
+    FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes with --kernel-trace only, as MI355X_MICROARCH.md prescribes: the two do not fit
+    one pass).  FETCH_SIZE / WRITE_SIZE count kilobytes; FETCH_SIZE reports half the bytes of wide coalesced reads on gfx950 and is
+    doubled.  Returns (bytes per launch, details) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        return None, "rocprofv3 not on PATH"
+    per = {}
+    for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mind_pmc_")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([prof, "--pmc", cnt, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                                "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-extras",
+                                "--no-traffic"], cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {cnt} exited with {r.returncode}: {r.stderr[-200:]}"
+            tot, disp = 0.0, set()
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "k_pair" in row.get("Kernel_Name", "") and row.get("Counter_Name") == cnt:
+                        tot += float(row["Counter_Value"])
+                        disp.add(row.get("Dispatch_Id"))
+            if not disp:
+                return None, f"no {cnt} rows for the pair kernel"
+            per[cnt] = (tot / len(disp), len(disp))
+        except Exception as e:      # noqa: BLE001
+            return None, f"{type(e).__name__}: {e}"[:300]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch = 2.0 * per["FETCH_SIZE"][0] * 1024.0
+    write = per["WRITE_SIZE"][0] * 1024.0
+    return fetch + write, {"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "launches_counted": per["FETCH_SIZE"][1],
+                           "over_algorithmic": (fetch + write) / alg_bytes_per_launch if alg_bytes_per_launch else None,
+                           "how": "two sibling runs of bench.py under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (+ --kernel-trace only); "
+                                  "counters in KB, FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM); mean over every k_pair launch of the runs; "
+                                  "at this scene size (N = 96, 4.7 MB of edges) the traffic includes Infinity-Cache hits"}
 
 
 def cpu_model():
@@ -362,6 +414,34 @@ def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees):
             "plan_ms": plan_s * 1e3}
 
 
+def ilqr_block(m):
+    """The tree-iLQR kernel of the workload: launch duration (HIP events on the context stream), its share of the step, how much of
+    the device it uses and -- from the kernel's own cycle counters for the launch's critical cost tree -- the cycles per node of its
+    two serial loops and the split over its phases."""
+    k, steps = m["ilqr_kernel"], max(m["steps"], 1)
+    if not k["launches"]:
+        return None
+    p = k["prof"]
+    ns = max(p.get("node_steps", 0.0), 1.0)
+    tot = sum(p.get(q, 0.0) for q in ("derivatives", "backward", "state_chain", "cost_pass", "selection")) or 1.0
+    ctr = m["ilqr"]
+    ms_launch = k["ms"] / k["launches"]
+    # algorithmic bytes of the sweep (SURVEY 8d): 2 x 115 doubles per node and iteration between forward and backward pass + 12 B per
+    # agent for each of the <= 11 cost evaluations of an iteration of the full fit
+    nbytes = ctr.get("node_iterations", 0) * 2 * 115 * 8 + ctr.get("node_iterations_exo", 0) * 11 * 12
+    return {"kernel_ms_per_launch": ms_launch, "share_of_step": k["ms"] / (m["dt"] * 1e3),
+            "cost_trees_per_launch": k["trees"] / k["launches"], "workgroups_per_tree": k["wgs"],
+            "cus_busy": k["trees"] / k["launches"] * k["wgs"], "cus": 256,
+            "critical_tree": {"nodes": p.get("nodes", 0) / k["launches"], "serial_depth": p.get("depth", 0) / k["launches"],
+                              "passes_per_launch": p.get("passes", 0) / k["launches"]},
+            "cycles_per_node_step": {"riccati": p.get("backward", 0.0) / ns, "state_chain": p.get("state_chain", 0.0) / ns},
+            "phase_share": {q: p.get(q, 0.0) / tot for q in ("derivatives", "backward", "state_chain", "cost_pass", "selection")},
+            "sweep_gb_per_s": nbytes / max(k["ms"] * 1e-3, 1e-12) / 1e9,
+            "note": "latency-bound (serial depth x iterations of dependent float64 chains; a float64 VALU instruction issues in ~6 cycles on "
+                    "gfx950), hence cycles per node step instead of a bandwidth fraction; sweep_gb_per_s prices SURVEY 8(d)'s algorithmic bytes "
+                    "of the sweep against the kernel's launch time"}
+
+
 def summarize(m, prec):
     """compact block for an extra workload"""
     r = roofline(m, prec)
@@ -372,7 +452,7 @@ def summarize(m, prec):
            "ilqr_solves_per_s": ctr["solves"] / m["dt"], "ilqr_iterations_per_s": ctr["iterations"] / m["dt"],
            "k_ilqr_ms_per_launch": (m["ilqr_kernel"]["ms"] / m["ilqr_kernel"]["launches"]) if m["ilqr_kernel"]["launches"] else None,
            "k_ilqr_workgroups_per_tree": m["ilqr_kernel"]["wgs"],
-           "breakdown_ms": m["breakdown_ms"]}
+           "breakdown_ms": m["breakdown_ms"], "k_ilqr": ilqr_block(m)}
     if r is not None:
         out["k_pair"] = {"bound": r["bound"], "frac": r["frac"], "mfma_frac": r["mfma"]["frac"], "hbm_frac": r["hbm"]["frac"],
                          "tflops": r["mfma"]["achieved_tflops"], "gbs": r["hbm"]["achieved_gbs"], "avg_launch_ms": r["avg_launch_ms"],
@@ -549,8 +629,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for --gpus N > 1 (nccl = RCCL; gloo only for tests on a single-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc sibling runs that fill roofline.traffic")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (synthetic branching, cfg4 tree, other recorded scenes)")
-    ap.add_argument("--tree-steps", type=int, default=5, help="planning cycles of the extra cfg4-tree measurement")
+    ap.add_argument("--tree-steps", type=int, default=20, help="planning cycles of the extra cfg4-tree measurement")
     ap.add_argument("--concurrent", type=int, default=0,
                     help="BASELINE config 3: plan this many independent scenes concurrently on the GPU (one host thread, "
                          "HIP context and stream per scene); prints the aggregate rate")
@@ -623,6 +704,7 @@ def main():
                  "note": "per rank; kernel_ms_per_launch = k_ilqr (warm-start fit + full fit of all scenario trees of a plan) from HIP events on the context stream; every scenario tree is solved twice per plan (warm start, then full cost); the warm-start fits of "
                          "the previous cycle's tree shapes run beside the predictor and are reused where the shape recurs"},
         "breakdown_ms": m["breakdown_ms"],
+        "k_ilqr": ilqr_block(m),
     }
     if m["collectives"] is not None:
         out["collectives_per_plan"] = m["collectives"][0] / args.steps
@@ -640,6 +722,10 @@ def main():
         except Exception as e:       # noqa: BLE001
             out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if rank == 0 and world == 1:
+        if not args.no_traffic and out.get("roofline"):
+            tb, det = measure_traffic(args.workload, out["roofline"]["algorithmic_bytes_per_launch"])
+            out["roofline"]["traffic"] = tb
+            out["roofline"]["traffic_detail"] = det
         if not args.no_cpu_baseline:
             lcl = sim._observation()
             out["cpu_baseline"] = cpu_baseline(pl, lcl, (a, l), max(int(round(exp_plan)), 1), pl.scen_tree_gen.get_scenario_tree())
@@ -649,6 +735,25 @@ def main():
             out["synthetic_branching"] = dict(summarize(measure(dist, "demo1", args.steps, args.warmup, False), prec),
                                               workload="demo_1-like synthetic scene, scripted mode branching on the real predictor forward")
             out["recorded_scenes"] = recorded_scenes(prec)
+            # the headline workload in the reference's own arithmetic class (fp32 MFMA pair kernel, fp32 VALU ActorNet)
+            fm = measure(dist, "demo_1", args.steps, args.warmup, False, pair_prec="f32")
+            fr = roofline(fm, "f32")
+            out["exact_fp32"] = {"value": fm["sim_steps"] / fm["dt"], "unit": "sim steps/s", "ms_per_step": fm["dt"] / fm["steps"] * 1e3,
+                                 "pair_kernel_avg_launch_ms": fr["avg_launch_ms"] if fr else None,
+                                 "pair_kernel_frac_of_fp32_mfma_peak": fr["mfma"]["frac"] if fr else None,
+                                 "pair_kernel_frac_of_hbm_peak": fr["hbm"]["frac"] if fr else None,
+                                 "note": "same workload with MIND_PAIR_PREC=f32: every contraction of the predictor in fp32 (v_mfma_f32_16x16x4_f32 pair "
+                                         "kernel, fp32 VALU encoders); the headline runs them as bf16 hi + lo split operands with fp32 accumulation"}
+            try:
+                sm = measure(dist, "stress128tree", 6, 2, False)
+                out["stress"] = dict(summarize(sm, prec), workload="stress128tree: 128 agents x 256 lane polylines (N = 385), full scripted 6-ary depth-4 AIME "
+                                     "tree (259 expansions per plan: the largest tree the reference's probability floor lets grow), default arithmetic",
+                                     plans_timed=6)
+                bm = measure(dist, "stress128tree", 6, 2, False, pair_prec="bf16")
+                out["stress_bf16"] = dict(summarize(bm, "bf16"), workload="the same in plain bf16 (BASELINE config 5's 'bf16 MFMA attention'; misses the 1e-3 m bar)",
+                                          plans_timed=6)
+            except Exception as e:       # noqa: BLE001
+                out["stress"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if rank == 0:
         print(json.dumps(out))
     dist.close()

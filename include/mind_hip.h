@@ -86,6 +86,10 @@ int mind_last_fusion_stats(mind_ctx *ctx, int *n_launches, float *total_ms, doub
 /* Duration of the tree-iLQR kernel of the last mind_ilqr_* call on this context (HIP events on the context stream; 0 unless
  * profiling is on), its number of cost trees and the workgroups per tree it ran with. */
 int mind_last_ilqr_stats(mind_ctx *ctx, float *kernel_ms, int *n_trees, int *workgroups_per_tree);
+/* Shader-clock cycles of the last tree-iLQR launch's critical cost tree (the one that bounds the launch), summed over its fits:
+ * out9 = { nodes M, serial depth (levels), passes of the iteration loop, cycles of the derivative pass, the backward (Riccati) sweep,
+ * the line search's state chain, its cost pass, the selection, cost trees in the launch }. */
+int mind_last_ilqr_profile(mind_ctx *ctx, double *out9);
 /* enable/disable event timing (off by default: events add a little latency) */
 int mind_set_profiling(mind_ctx *ctx, int enable);
 

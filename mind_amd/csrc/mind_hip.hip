@@ -111,6 +111,7 @@ struct mind_ctx {
   float ilqr_ms = 0.f;
   int ilqr_multi = 0, ilqr_trees = 0;
   bool ilqr_test_starve = false;
+  double il_prof[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // critical tree of the last launch: M, depth, passes, cycles of the five phases, trees
   long long n_ilqr_fallbacks = 0;   // wide-tree launches that were not fully resident and were re-run on one workgroup per tree
   int n_pair_launch = 0;
   float pair_ms = 0.f;
@@ -293,6 +294,12 @@ extern "C" int mind_last_ilqr_stats(mind_ctx *c, float *kernel_ms, int *n_trees,
   if (kernel_ms) *kernel_ms = c->ilqr_ms;
   if (n_trees) *n_trees = c->ilqr_trees;
   if (workgroups_per_tree) *workgroups_per_tree = c->ilqr_multi;
+  return MIND_OK;
+}
+
+extern "C" int mind_last_ilqr_profile(mind_ctx *c, double *out9) {
+  if (!c || !out9) return MIND_EINVAL;
+  memcpy(out9, c->il_prof, sizeof(c->il_prof));
   return MIND_OK;
 }
 
@@ -1422,6 +1429,26 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   }
   memcpy(xs, hx.data(), (size_t)Mtot * 6 * sizeof(double));
   memcpy(hs.data(), hx.data() + n_xs, hs.size() * sizeof(double));
+  {
+    // phase cycles of the launch's critical tree (the one with the most cycles over all its fits): what bounds the launch
+    double best = -1.0;
+    for (int t = 0; t < n_trees; ++t) {
+      double tot = 0.0, ph_c[5] = {0, 0, 0, 0, 0}, passes = 0.0;
+      for (int ph = 0; ph < n_phases; ++ph) {
+        const double *h = hs.data() + (size_t)2 * IL_NSTAT * t + (size_t)ph * IL_NSTAT;
+        ph_c[0] += h[4]; ph_c[1] += h[5]; ph_c[2] += h[8]; ph_c[3] += h[6]; ph_c[4] += h[7];
+        passes += h[IL_NSTAT - 1];
+      }
+      for (double v : ph_c) tot += v;
+      if (tot > best) {
+        best = tot;
+        double *o = c->il_prof;
+        o[0] = tl[t].M; o[1] = tl[t].nl; o[2] = passes;
+        for (int q = 0; q < 5; ++q) o[3 + q] = ph_c[q];       // derivatives, backward, state chain, cost pass, selection
+        o[8] = (double)n_trees;
+      }
+    }
+  }
   for (int ph = 0; ph < n_phases; ++ph) {
     mind_ilqr_stats *so = ph == 0 ? stats : stats2;
     if (!so) continue;

@@ -284,6 +284,11 @@ class TrajectoryTreeOptimizer:
                         xs[i], us[i], st_w[i], st[i] = mx[k], mu_[k], mw[k], mf[k]
                 self.counters["solves"] += 2 * len(sub)
                 self.counters["iterations"] += sum(s_["iterations"] for s_ in st_w) + sum(s_["iterations"] for s_ in st)
+                # node-iterations and agent-weighted cost evaluations (bench: algorithmic bytes of the sweep)
+                self.counters["node_iterations"] = self.counters.get("node_iterations", 0) + sum(
+                    len(f["parent"]) * (w_["iterations"] + f_["iterations"]) for f, w_, f_ in zip(sub, st_w, st))
+                self.counters["node_iterations_exo"] = self.counters.get("node_iterations_exo", 0) + sum(
+                    len(f["parent"]) * f_["iterations"] * f["mean"].shape[1] for f, f_ in zip(sub, st))
             else:
                 _, us_w, st_w = solve(ilqr_cfg_from(self.config, "w_opt_cfg"), sub, x0, lane, target_vel, 0, None)
                 xs, us, st = solve(ilqr_cfg_from(self.config, "opt_cfg"), sub, x0, lane, target_vel, 1, us_w)

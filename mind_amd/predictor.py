@@ -152,6 +152,13 @@ class HipPredictor:
         self.lib.mind_last_ilqr_stats(self.ctx, C.byref(ms), C.byref(n), C.byref(g))
         return ms.value, n.value, g.value
 
+    def ilqr_profile(self):
+        """phase cycles of the critical cost tree of the last tree-iLQR launch (mind_last_ilqr_profile)"""
+        v = (C.c_double * 9)()
+        self.lib.mind_last_ilqr_profile(self.ctx, v)
+        keys = ("nodes", "depth", "passes", "derivatives", "backward", "state_chain", "cost_pass", "selection", "trees")
+        return dict(zip(keys, [float(x) for x in v]))
+
     def fusion_stats(self):
         n = C.c_int()
         ms = C.c_float()

@@ -98,8 +98,8 @@ def test_bench_prints_one_contract_json_line():
     import json
     import subprocess
     import sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"],
-                         capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--tree-steps", "2"],
+                         capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -112,7 +112,12 @@ def test_bench_prints_one_contract_json_line():
     assert "recorded scene demo_1" in d["config"]["workload"] and d["data"].startswith("recorded AV2 scene")     # BASELINE configs[1]
     r, c = d["roofline"], d["cpu_baseline"]
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] in ("TFLOP/s", "GB/s")
-    assert 0 < r["frac"] <= 1.0 and 0 < r["mfma"]["frac"] <= 1.0 and 0 < r["hbm"]["frac"] <= 1.0 and r["traffic"] is None
+    assert 0 < r["frac"] <= 1.0 and 0 < r["mfma"]["frac"] <= 1.0 and 0 < r["hbm"]["frac"] <= 1.0
+    # traffic: HBM bytes per launch from two sibling rocprofv3 --pmc passes (null only where rocprofv3 is missing)
+    assert r["traffic"] is None or (r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"] and r["traffic_detail"]["launches_counted"] > 0)
+    k = d["k_ilqr"]
+    assert 0 < k["share_of_step"] < 1 and k["cycles_per_node_step"]["riccati"] > 100 and abs(sum(k["phase_share"].values()) - 1) < 1e-6
+    assert d["exact_fp32"]["value"] > 83.0 and d["stress"]["expansions_per_plan"] == 259 and d["stress_bf16"]["expansions_per_plan"] == 259
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["value_1_thread"] > 0
     # extras: the synthetic branching scene, the full cfg4 tree on this GPU, the other recorded scenes
     assert d["config"]["weights"] == "formula_branching:20240121" and d["config"]["expansions_per_plan"] >= 2      # a real AIME tree

@@ -1,0 +1,61 @@
+"""BASELINE configs[4] as a workload: 128 agents x 256 lane polylines (N = 385) on the largest tree the reference's probability
+floor lets grow (full scripted 6-ary depth-4 AIME tree on the real predictor forward, 259 expansions per plan: `stress128tree` of
+bench.py), end to end -- predictor, AIME, tree-iLQR with several workgroups per cost tree -- in the default arithmetic and in the
+plain bf16 mode the config names.  No CPU oracle finishes at this size in test time, so the checks are the size-independent
+properties: expansion counts, sibling probabilities summing to one, finite world-frame rows, converged / improving solves, equal
+tree structure between the two arithmetics and a bounded difference of the ego plans."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _plans(prec, n=2):
+    sys.path.insert(0, ROOT)
+    from bench import WORKLOADS, make_closed_loop
+    pl, sim, w = make_closed_loop(dict(WORKLOADS["stress128tree"]), full_tree=True, speculative=False)
+    rt = pl.network.rt
+    before = rt.pair_precision()
+    out = []
+    try:
+        rt.set_pair_precision(prec)
+        for _ in range(n):
+            e0 = pl.scen_tree_gen.n_expanded
+            sim.run_plans(1)
+            trees = pl.scen_tree_gen.get_scenario_tree()
+            scen, traj = sim.last_result
+            out.append(dict(expanded=pl.scen_tree_gen.n_expanded - e0, trees=trees, best=pl.timing["best_traj_idx"], costs=pl.timing["tree_costs"],
+                            xs=np.array([n_.data[0] for k, n_ in traj[0].nodes.items() if k != -1]), ctrl=np.array(sim.ctrl),
+                            debug=pl.traj_tree_opt.debug, wgs=rt.ilqr_stats()[2]))
+    finally:
+        rt.set_pair_precision(before)
+    return out
+
+
+def test_stress_workload_end_to_end_in_both_arithmetics():
+    a = _plans("bf16x3")
+    b = _plans("bf16")
+    for runs in (a, b):
+        for p in runs:
+            assert p["expanded"] == 259                                           # 1 + 6 + 36 + 216 scenes through the predictor
+            assert len(p["trees"]) == 6 and p["wgs"] >= 2                           # six scenario trees, several workgroups per cost tree
+            assert 100 <= sum(len(t.nodes) for t in p["trees"]) <= 1555             # nodes of finished branches (at most 6 + 36 + 216 + 1296)
+            for t in p["trees"]:
+                for k, n in t.nodes.items():
+                    pos, cov = np.asarray(n.data[1]), np.asarray(n.data[2])
+                    assert pos.shape[0] == 128 and pos.shape[2] == 2 and np.isfinite(pos).all() and np.isfinite(cov).all() and (cov > 0).all()
+                    ch = [t.nodes[c] for c in n.children_keys]
+                    if ch:                                                         # sibling probabilities: renormalised to the parent's
+                        assert abs(sum(float(np.ravel(c.data[0])[0]) for c in ch) - float(np.ravel(n.data[0])[0])) < 1e-5
+            assert np.isfinite(p["xs"]).all() and np.isfinite(p["costs"]).all() and len(p["costs"]) == 6
+            assert all(s["iterations"] >= 1 for s in p["debug"]["full"]) and all(np.isfinite(s["J"]) for s in p["debug"]["full"])
+    # same tree structure in both arithmetics (the scripted modes fix the branching), ego plans close
+    for pa, pb in zip(a, b):
+        assert [list(t.nodes.keys()) for t in pa["trees"]] == [list(t.nodes.keys()) for t in pb["trees"]]
+    d = float(np.abs(a[0]["xs"][:, :2] - b[0]["xs"][:, :2]).max()) if a[0]["best"] == b[0]["best"] and a[0]["xs"].shape == b[0]["xs"].shape else float("nan")
+    print(f"stress128tree, first plan: max |ego xy (bf16x3) - ego xy (bf16)| = {d:.3e} m, chosen trees {a[0]['best']} / {b[0]['best']}")
+    assert not (d > 5.0)
