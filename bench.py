@@ -271,7 +271,7 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None, pair_pre
     brk = {"aime": (pl.timing_sum["aime_s"] - tsum0["aime_s"]) / npl * 1e3, "ilqr": (pl.timing_sum["ilqr_s"] - tsum0["ilqr_s"]) / npl * 1e3,
            "note": "host wall time per plan, mean over the timed plans: AIME rounds (predictor + glue) | tree-iLQR (solve_batch)"}
     return dict(pl=pl, sim=sim, w=w, dt=dt, breakdown_ms=brk, ilqr_kernel=il, sim_steps=sim_steps, expansions=expansions, expansions_all=dist.reduce(expansions),
-                pair=acc, ilqr=ctr, a=len(pl.agent_obs), l=int(pl.scen_tree_gen.lane_feat_in.shape[0]), steps=steps, weights=ckpt or PLAIN_WEIGHTS,
+                pair=acc, ilqr=ctr, a=len(pl.agent_obs), l=int(pl.scen_tree_gen.n_lanes or pl.scen_tree_gen.lane_feat_in.shape[0]), steps=steps, weights=ckpt or PLAIN_WEIGHTS,
                 collectives=(sh.n_collectives - coll0[0], sh.bytes_gathered - coll0[1]) if sh is not None else None,
                 real_scene="scene" in wkw, sharded=sh is not None)
 

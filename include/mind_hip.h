@@ -279,6 +279,17 @@ typedef struct {
   int max_rounds;                            /* safety bound on the number of rounds (>= max_depth + 1)                   */
   int pred_len;                              /* planning horizon in predicted steps (the generator's pred_len, 50: END_T of  */
                                              /*   a fresh observation; seq_len = 50 + pred_len), <= 60                     */
+  /* Root scene built ON THE DEVICE (process_data + prepare_root_data as kernels): when raw_pos != NULL the fields actors ... hist
+   * above are ignored (may be NULL) and the library computes them from what get_agent_trajectories (utils.py:245-342) returns and
+   * the map's resampled lane polylines: normalisation into the AV / agent frames and actor features (k_aime_rebase on the raw
+   * windows), lane graph + LANES features (k_aime_root_lanes, float64 as update_lane_graph_from_argo), high-level command, the
+   * root's world-frame histories as prepare_root_data reconstructs them (k_aime_root_hist). */
+  const float *raw_pos, *raw_ang, *raw_vel;  /* [a,50,2], [a,50], [a,50,2] world-frame padded histories, AV first            */
+  const float *raw_pad;                      /* [a,50] observed flags (PAD_OBS)                                               */
+  const double *lane_pts;                    /* [l,11,2] world-frame points of every 15 m lane piece (10 sub-segments)        */
+  const int32_t *lane_flags;                 /* [l,6]: lane type (0 vehicle, 1 bike, 2 bus), intersection, left / right mark   */
+                                             /*   class (0 crossable, 1 not, 2 other), has left / right neighbour              */
+  float travel0;                             /* max(ego speed, min_vel) * time_ahead (float32), scenario_tree.py:131,620-624   */
 } mind_aime_plan_in;
 
 #define MIND_AIME_BRANCH 1

@@ -71,7 +71,9 @@ class AimePlanIn(C.Structure):
     _fields_ = [("n_agents", C.c_int), ("n_lanes", C.c_int), ("n_lane_pts", C.c_int)] + \
                [(k, C.POINTER(C.c_float)) for k in ("actors", "actor_ctrs", "actor_vecs", "lanes", "lane_ctrs", "lane_vecs", "tgt_nodes", "tgt_rpe",
                                                     "rot", "orig", "tgt_pts", "hist", "types", "target_lane", "target_lane_info")] + \
-               [("time_ahead", C.c_float), ("min_vel", C.c_float), ("dist_thres", C.c_float), ("max_depth", C.c_int), ("max_rounds", C.c_int), ("pred_len", C.c_int)]
+               [("time_ahead", C.c_float), ("min_vel", C.c_float), ("dist_thres", C.c_float), ("max_depth", C.c_int), ("max_rounds", C.c_int), ("pred_len", C.c_int),
+                ("raw_pos", C.POINTER(C.c_float)), ("raw_ang", C.POINTER(C.c_float)), ("raw_vel", C.POINTER(C.c_float)), ("raw_pad", C.POINTER(C.c_float)),
+                ("lane_pts", C.POINTER(C.c_double)), ("lane_flags", C.POINTER(C.c_int32)), ("travel0", C.c_float)]
 
 
 class AimeNode(C.Structure):

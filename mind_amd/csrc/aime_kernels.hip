@@ -207,6 +207,8 @@ struct RebaseArgs {
   const float *tlane, *tinfo;         // target lane [n_lane,2], per-point info [n_lane,12]
   float time_ahead, min_vel;
   float *actors, *actor_ctrs, *actor_vecs, *lane_ctrs, *lane_vecs, *tgt_nodes, *tgt_rpe, *frames;
+  float travel0;            // >= 0: the look-ahead distance of get_high_level_command given by the caller (root scene: the ego speed comes
+                            // from the ego state, scenario_tree.py:131, not from the window); < 0: max(|v_ego|, min_vel) * time_ahead
 };
 
 __device__ __forceinline__ void rb_cs(float ax, float ay, float bx, float by, float &c, float &s) {
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_aime_rebase(RebaseArgs A) {
       const float vx1 = vx0 * c0 + vy0 * s0, vy1 = vx0 * (-s0) + vy0 * c0;
       const float vnx = vx1 * f[3] + vy1 * f[4], vny = vx1 * (-f[4]) + vy1 * f[3];
       const float cur_vel = sqrtf(vnx * vnx + vny * vny);
-      float travel = fmaxf(cur_vel, A.min_vel) * A.time_ahead;
+      float travel = A.travel0 >= 0.f ? A.travel0 : fmaxf(cur_vel, A.min_vel) * A.time_ahead;
       int idx = rdi[0];
       const int n = A.n_lane;
       while (idx < n - 1 && travel > 0.f) {
@@ -442,4 +444,91 @@ __global__ __launch_bounds__(RB_THREADS) void k_aime_rebase(RebaseArgs A) {
         }
     }
   }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Root scene on the device (process_data, scenario_tree.py:122-206, and prepare_root_data :414-465): the agent part is
+// k_aime_rebase on the raw world-frame windows (same normalisation, utils.py:245-342 / scenario_tree.py:128-158); here the lane graph
+// of update_lane_graph_from_argo (utils.py:345-483) from the map's resampled world-frame polylines -- float64 like the host code, cast
+// to float32 at the end -- and the root's world-frame histories as prepare_root_data reconstructs them from the NORMALISED arrays
+// (a float32 round trip the later re-basings build on).
+// -------------------------------------------------------------------------------------------------
+// one block per lane piece, 11 resampled points each: lane_ctrs / lane_vecs [l,2] (AV frame), LANES [l,10,16]
+__global__ __launch_bounds__(64) void k_aime_root_lanes(const double *__restrict__ pts, const int *__restrict__ flags, const float *__restrict__ frames,
+                                                        float *__restrict__ lane_ctrs, float *__restrict__ lane_vecs, float *__restrict__ lanes) {
+  __shared__ double c[11][2], inst[11][2];
+  __shared__ double anch[4];
+  const int q = blockIdx.x, t = threadIdx.x;
+  // frames: ROT row-major (c0, -s0, s0, c0), ORIG
+  const double r00 = (double)frames[0], r01 = (double)frames[1], r10 = (double)frames[2], r11 = (double)frames[3];
+  const double ox = (double)frames[4], oy = (double)frames[5];
+  if (t < 11) {
+    const double x = pts[((size_t)q * 11 + t) * 2] - ox, y = pts[((size_t)q * 11 + t) * 2 + 1] - oy;
+    c[t][0] = x * r00 + y * r10;
+    c[t][1] = x * r01 + y * r11;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double mx = 0.0, my = 0.0;
+    for (int k = 0; k < 11; ++k) { mx += c[k][0]; my += c[k][1]; }
+    mx /= 11.0; my /= 11.0;
+    const double dvx = c[10][0] - c[0][0], dvy = c[10][1] - c[0][1];
+    const double nrm = sqrt(dvx * dvx + dvy * dvy);
+    anch[0] = mx; anch[1] = my; anch[2] = dvx / nrm; anch[3] = dvy / nrm;
+    lane_ctrs[2 * q] = (float)mx; lane_ctrs[2 * q + 1] = (float)my;
+    lane_vecs[2 * q] = (float)anch[2]; lane_vecs[2 * q + 1] = (float)anch[3];
+  }
+  __syncthreads();
+  if (t < 11) {
+    const double x1 = c[t][0] - anch[0], y1 = c[t][1] - anch[1];
+    inst[t][0] = x1 * anch[2] + y1 * anch[3];             // (x, y) @ [[ax, -ay], [ay, ax]]
+    inst[t][1] = x1 * (-anch[3]) + y1 * anch[2];
+  }
+  __syncthreads();
+  if (t < 10) {
+    float *o = lanes + ((size_t)q * 10 + t) * 16;
+    const int *f = flags + (size_t)q * 6;       // lane type (0..2), intersection, left mark class, right mark class, has left / right neighbour
+    o[0] = (float)((inst[t][0] + inst[t + 1][0]) / 2.0);
+    o[1] = (float)((inst[t][1] + inst[t + 1][1]) / 2.0);
+    o[2] = (float)(inst[t + 1][0] - inst[t][0]);
+    o[3] = (float)(inst[t + 1][1] - inst[t][1]);
+    o[4] = (float)f[1];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[5 + k] = f[0] == k ? 1.f : 0.f; o[8 + k] = f[2] == k ? 1.f : 0.f; o[11 + k] = f[3] == k ? 1.f : 0.f; }
+    o[14] = (float)f[4]; o[15] = (float)f[5];
+  }
+}
+
+// one block per agent, lane = history step: the root's world-frame windows [a,50,.] from the normalised arrays (float32, the
+// expressions of k_aime_rebase for the normalisation and of prepare_root_data / _to_world for the way back), cov_last = 1e-5
+__global__ __launch_bounds__(64) void k_aime_root_hist(const float *__restrict__ pos, const float *__restrict__ ang, const float *__restrict__ vel,
+                                                       const float *__restrict__ frames, const float *__restrict__ actor_ctrs,
+                                                       const float *__restrict__ actor_vecs, float *__restrict__ wpos, float *__restrict__ wang,
+                                                       float *__restrict__ wvel, float *__restrict__ cov_last) {
+  const int i = blockIdx.x, t = threadIdx.x;
+  if (t >= RB_T) return;
+  const float c0 = frames[0], s0 = frames[2], ox = frames[4], oy = frames[5];
+  const float th0 = ang[RB_T - 1];                         // ego heading at the last step (agent 0)
+  const float cx = actor_ctrs[2 * i], cy = actor_ctrs[2 * i + 1], ci = actor_vecs[2 * i], si = actor_vecs[2 * i + 1];
+  const float thi = ang[i * RB_T + RB_T - 1] - th0;
+  // normalised position / heading / velocity (normalize_agents)
+  const float dx = pos[(i * RB_T + t) * 2] - ox, dy = pos[(i * RB_T + t) * 2 + 1] - oy;
+  const float x1 = (dx * c0 + dy * s0) - cx, y1 = (dx * (-s0) + dy * c0) - cy;
+  const float pnx = x1 * ci + y1 * si, pny = x1 * (-si) + y1 * ci;
+  const float an = (ang[i * RB_T + t] - th0) - thi;
+  const float vx0 = vel[(i * RB_T + t) * 2], vy0 = vel[(i * RB_T + t) * 2 + 1];
+  const float vx1 = vx0 * c0 + vy0 * s0, vy1 = vx0 * (-s0) + vy0 * c0;
+  const float vnx = vx1 * ci + vy1 * si, vny = vx1 * (-si) + vy1 * ci;
+  // back to the world frame (prepare_root_data): R_i = rot(atan2(vec_i)), then the scene rotation / origin
+  const float th = atan2f(si, ci);
+  const float c = cosf(th), s = sinf(th);
+  AimeScene S;
+  S.r00 = c0; S.r01 = -s0; S.r10 = s0; S.r11 = c0; S.ox = ox; S.oy = oy;
+  float wx, wy, wvx, wvy;
+  aime_to_world(pnx, pny, c, s, cx, cy, S, true, wx, wy);
+  aime_to_world(vnx, vny, c, s, 0.f, 0.f, S, false, wvx, wvy);
+  const size_t o = (size_t)i * RB_T + t;
+  wpos[2 * o] = wx; wpos[2 * o + 1] = wy; wvel[2 * o] = wvx; wvel[2 * o + 1] = wvy;
+  wang[o] = (an + th) + atan2f(S.r10, S.r00);
+  if (t == 0) cov_last[i] = 1e-5f;
 }

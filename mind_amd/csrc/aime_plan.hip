@@ -42,9 +42,11 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   if (!c || !in || !out) return MIND_EINVAL;
   if (!c->have_weights) return fail(c, MIND_ESTATE, "weights not loaded");
   const int a = in->n_agents, l = in->n_lanes, P = in->n_lane_pts;
-  if (a <= 0 || l <= 0 || P < 12 || !in->actors || !in->actor_ctrs || !in->actor_vecs || !in->lanes || !in->lane_ctrs || !in->lane_vecs ||
-      !in->tgt_nodes || !in->tgt_rpe || !in->rot || !in->orig || !in->tgt_pts || !in->hist || !in->types || !in->target_lane ||
-      !in->target_lane_info || in->max_depth < 0 || in->max_rounds <= 0 || in->max_rounds > 32 || in->pred_len < 2 || in->pred_len > AIME_T)
+  const bool raw = in->raw_pos != nullptr;      // root scene featurised on the device
+  if (a <= 0 || l <= 0 || P < 12 || !in->types || !in->target_lane || !in->target_lane_info ||
+      (raw ? (!in->raw_ang || !in->raw_vel || !in->raw_pad || !in->lane_pts || !in->lane_flags || !(in->travel0 >= 0.f))
+           : (!in->actors || !in->actor_ctrs || !in->actor_vecs || !in->lanes || !in->lane_ctrs || !in->lane_vecs || !in->tgt_nodes ||
+              !in->tgt_rpe || !in->rot || !in->orig || !in->tgt_pts || !in->hist)) || in->max_depth < 0 || in->max_rounds <= 0 || in->max_rounds > 32 || in->pred_len < 2 || in->pred_len > AIME_T)
     return fail(c, MIND_EINVAL, "mind_aime_plan: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = c->stream;
@@ -58,10 +60,44 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   const size_t o_lc = take((size_t)l * 2), o_lv = take((size_t)l * 2), o_tn = take(160), o_tr = take(20), o_cov = take(a);
   const size_t o_types = take((size_t)a * OBS * 7), o_tl = take((size_t)P * 2), o_ti = take((size_t)P * 12);
   const size_t o_wpos = take((size_t)a * OBS * 2), o_wang = take((size_t)a * OBS), o_wvel = take((size_t)a * OBS * 2);
+  // (device-built root: raw windows / pad flags / lane polylines go up, the slots above are filled by kernels)
+  const size_t o_fr = take(28), o_rpos = take(raw ? (size_t)a * OBS * 2 : 0), o_rang = take(raw ? (size_t)a * OBS : 0);
+  const size_t o_rvel = take(raw ? (size_t)a * OBS * 2 : 0), o_rpad = take(raw ? (size_t)a * OBS : 0);
+  const size_t o_lpts = take(raw ? (size_t)l * 11 * 2 * 2 : 0), o_lfl = take(raw ? (size_t)l * 6 : 0);      // doubles (2 floats each), ints
   const size_t n_root = o;
   if ((rc = ensure(c, c->pl_root, n_root * sizeof(float)))) return rc;
   if ((rc = pl_pin(c, 0, n_root * sizeof(float)))) return rc;
-  {
+  if (raw) {
+    float *h = (float *)c->pl_pin[0];
+    memcpy(h + o_types, in->types, (size_t)a * OBS * 7 * sizeof(float));
+    memcpy(h + o_tl, in->target_lane, (size_t)P * 2 * sizeof(float));
+    memcpy(h + o_ti, in->target_lane_info, (size_t)P * 12 * sizeof(float));
+    memcpy(h + o_rpos, in->raw_pos, (size_t)a * OBS * 2 * sizeof(float));
+    memcpy(h + o_rang, in->raw_ang, (size_t)a * OBS * sizeof(float));
+    memcpy(h + o_rvel, in->raw_vel, (size_t)a * OBS * 2 * sizeof(float));
+    memcpy(h + o_rpad, in->raw_pad, (size_t)a * OBS * sizeof(float));
+    memcpy(h + o_lpts, in->lane_pts, (size_t)l * 22 * sizeof(double));
+    memcpy(h + o_lfl, in->lane_flags, (size_t)l * 6 * sizeof(int));
+    // one copy: [types .. lane flags] (the slots before o_types are produced on the device)
+    HIPCHK(c, hipMemcpyAsync((float *)c->pl_root.p + o_types, h + o_types, (n_root - o_types) * sizeof(float), hipMemcpyHostToDevice, st));
+    float *d = (float *)c->pl_root.p;
+    RebaseArgs R;
+    R.a = a; R.l = 0; R.n_lane = P; R.pad_ones = 0;
+    R.pos = d + o_rpos; R.ang = d + o_rang; R.vel = d + o_rvel; R.types = d + o_types; R.pad = d + o_rpad;
+    R.lane_ctrs0 = nullptr; R.lane_vecs0 = nullptr; R.tlane = d + o_tl; R.tinfo = d + o_ti;
+    R.time_ahead = in->time_ahead; R.min_vel = in->min_vel; R.travel0 = in->travel0;
+    R.actors = d + o_actors; R.actor_ctrs = d + o_ctrs; R.actor_vecs = d + o_vecs; R.lane_ctrs = nullptr; R.lane_vecs = nullptr;
+    R.tgt_nodes = d + o_tn; R.tgt_rpe = d + o_tr; R.frames = d + o_fr;
+    hipLaunchKernelGGL(k_aime_rebase, dim3(1), dim3(RB_THREADS), 5 * (size_t)a * sizeof(float), st, R);
+    hipLaunchKernelGGL(k_aime_root_lanes, dim3(l), dim3(64), 0, st, (const double *)(d + o_lpts), (const int *)(d + o_lfl), (const float *)(d + o_fr),
+                       d + o_lc, d + o_lv, d + o_lanes);
+    hipLaunchKernelGGL(k_aime_root_hist, dim3(a), dim3(64), 0, st, (const float *)(d + o_rpos), (const float *)(d + o_rang), (const float *)(d + o_rvel),
+                       (const float *)(d + o_fr), (const float *)(d + o_ctrs), (const float *)(d + o_vecs), d + o_wpos, d + o_wang, d + o_wvel, d + o_cov);
+    HIPCHK(c, hipGetLastError());
+    if ((rc = pl_pin(c, 3, 28 * sizeof(float)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pl_pin[3], d + o_fr, 28 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(c->ev_pl, st));
+  } else {
     float *h = (float *)c->pl_pin[0];
     memcpy(h + o_actors, in->actors, (size_t)a * 14 * 48 * sizeof(float));
     memcpy(h + o_ctrs, in->actor_ctrs, (size_t)a * 2 * sizeof(float));
@@ -100,12 +136,12 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   {
     PlScene &s = batch[0];
     s.node = 0; s.prob = 1.f; s.cur_t = 0; s.end_t = HZ;
-    memcpy(s.rot, in->rot, 4 * sizeof(float)); memcpy(s.orig, in->orig, 2 * sizeof(float)); memcpy(s.tgt, in->tgt_pts, 22 * sizeof(float));
+    if (!raw) { memcpy(s.rot, in->rot, 4 * sizeof(float)); memcpy(s.orig, in->orig, 2 * sizeof(float)); memcpy(s.tgt, in->tgt_pts, 22 * sizeof(float)); }
   }
   const float *prev_pos = droot + o_wpos, *prev_ang = droot + o_wang, *prev_vel = droot + o_wvel;
   const float *cov_last_dev = droot + o_cov;
   int cur_in = -1;                 // which pl_in holds the current round's predictor inputs (-1: the root upload)
-  bool frames_pending = false;
+  bool frames_pending = raw;       // device-built root: its frame (ROT, ORIG, TGT_PTS) comes back while the first predictor call runs
   int n_expanded = 0, round = 0;
   float pair_ms = 0.f;
   int pair_launches = 0;
@@ -276,7 +312,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     R.a = a; R.l = l; R.n_lane = P; R.pad_ones = 1;
     R.pos = w_pos; R.ang = w_ang; R.vel = w_vel; R.types = droot + o_types; R.pad = nullptr;
     R.lane_ctrs0 = droot + o_lc; R.lane_vecs0 = droot + o_lv; R.tlane = droot + o_tl; R.tinfo = droot + o_ti;
-    R.time_ahead = in->time_ahead; R.min_vel = in->min_vel;
+    R.time_ahead = in->time_ahead; R.min_vel = in->min_vel; R.travel0 = -1.f;
     R.actors = d_in + q.actors; R.actor_ctrs = d_in + q.ctrs; R.actor_vecs = d_in + q.vecs; R.lane_ctrs = d_in + q.lc; R.lane_vecs = d_in + q.lv;
     R.tgt_nodes = d_in + q.tn; R.tgt_rpe = d_in + q.tr; R.frames = d_in + q.fr;
     hipLaunchKernelGGL(k_aime_rebase, dim3((unsigned)S), dim3(RB_THREADS), 5 * (size_t)a * sizeof(float), st, R);

@@ -1640,7 +1640,7 @@ extern "C" int mind_aime_rebase(mind_ctx *c, const mind_rebase_in *in, const min
   A.a = (int)a; A.l = (int)l; A.n_lane = (int)P; A.pad_ones = in->pad ? 0 : 1;
   A.pos = d + o_pos; A.ang = d + o_ang; A.vel = d + o_vel; A.types = d + o_types; A.pad = in->pad ? d + o_pad : nullptr;
   A.lane_ctrs0 = d + o_lc; A.lane_vecs0 = d + o_lv; A.tlane = d + o_tl; A.tinfo = d + o_ti;
-  A.time_ahead = in->time_ahead; A.min_vel = in->min_vel;
+  A.time_ahead = in->time_ahead; A.min_vel = in->min_vel; A.travel0 = -1.f;
   A.actors = out->actors; A.actor_ctrs = out->actor_ctrs; A.actor_vecs = out->actor_vecs; A.lane_ctrs = out->lane_ctrs;
   A.lane_vecs = out->lane_vecs; A.tgt_nodes = out->tgt_nodes; A.tgt_rpe = out->tgt_rpe; A.frames = out->frames;
   hipLaunchKernelGGL(k_aime_rebase, dim3((unsigned)S), dim3(RB_THREADS), 5 * a * sizeof(float), st, A);

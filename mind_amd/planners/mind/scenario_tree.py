@@ -207,6 +207,10 @@ class ScenarioTreeGenerator:
         # the whole AIME loop in ONE native call (mind_aime_plan: per-round bookkeeping in C++, one small read-back per round) when the
         # network is the HIP predictor itself; MIND_NATIVE_AIME=0 / the attribute keep the round-by-round path (same kernels, same trees)
         self.native_aime = os.environ.get("MIND_NATIVE_AIME", "1") != "0"
+        # ... with the root scene featurised on the device as well (process_data / prepare_root_data as kernels: k_aime_rebase on the
+        # raw windows, k_aime_root_lanes, k_aime_root_hist); MIND_DEVICE_ROOT=0 / the attribute: the host featuriser feeds the native plan
+        self.device_root = os.environ.get("MIND_DEVICE_ROOT", "1") != "0"
+        self.n_lanes = None
         self.n_native_plans = 0
         self.branch_depth = 0
         self.n_expanded = 0           # scenes pushed through the predictor (metric: nodes expanded)
@@ -240,15 +244,34 @@ class ScenarioTreeGenerator:
                 and (self.shard is None or not self.shard.sharded) and self.ego_idx == 0 and self.target_lane is not None
                 and len(self.target_lane) >= 12 and self.config is not None)
 
-    def _branch_aime_native(self, root):
+    def _branch_aime_native(self, lcl_smp, agent_obs):
         """branch_aime through mind_aime_plan; None = the library left this plan to the round-by-round path."""
-        self.prepare_root_data(root)
-        hist = np.concatenate([root["TRAJS_POS_HIST"], root["TRAJS_VEL_HIST"], root["TRAJS_ANG_HIST"][..., None], root["TRAJS_COV_HIST"]], axis=2)
-        if hist.shape[1] != self.obs_len or self.obs_len != 50 or not (2 <= self.pred_len <= 60) or root["LANES"].shape[0] == 0:
+        cfg = self.config
+        if self.obs_len != 50 or not (2 <= self.pred_len <= 60):
             return None
-        res = self.network.rt.aime_plan(root, hist, self.lane_graph["lane_ctrs"], self.lane_graph["lane_vecs"], self.target_lane,
-                                        self.target_lane_info, self.config.tar_time_ahead, self.config.tar_dist_thres, self.config.max_depth,
-                                        pred_len=self.pred_len)
+        if self.device_root:
+            # process_data's host part is reduced to get_agent_trajectories (Track lists -> padded arrays); frames, actor features,
+            # lane graph, high-level command and the root's world-frame histories are computed by the library on the device
+            pos, ang, vel, types, flags, tids, cats = U.get_agent_trajectories(agent_obs)
+            st = U._static_lane_pieces(lcl_smp.map_data, 15.0, 10)
+            if st["num_lanes"] == 0 or pos.shape[1] != self.obs_len:
+                return None
+            cur_vel = lcl_smp.ego_agent.state[2]
+            raw = dict(pos=pos, ang=ang, vel=vel, pad=flags, types=types, lane_pts=st["pts"], lane_flags=st["flags"],
+                       travel0=F32(max(cur_vel, 0.5) * cfg.tar_time_ahead))
+            root = {"TRAJS_TYPE": types, "TRAJS_TID": tids, "TRAJS_CAT": cats}
+            self.n_lanes = int(st["num_lanes"])
+            res = self.network.rt.aime_plan(None, None, None, None, self.target_lane, self.target_lane_info, cfg.tar_time_ahead,
+                                            cfg.tar_dist_thres, cfg.max_depth, pred_len=self.pred_len, raw=raw)
+        else:
+            root = self.process_data(lcl_smp, agent_obs)
+            self.prepare_root_data(root)
+            hist = np.concatenate([root["TRAJS_POS_HIST"], root["TRAJS_VEL_HIST"], root["TRAJS_ANG_HIST"][..., None], root["TRAJS_COV_HIST"]], axis=2)
+            if hist.shape[1] != self.obs_len or root["LANES"].shape[0] == 0:
+                return None
+            self.n_lanes = int(root["LANES"].shape[0])
+            res = self.network.rt.aime_plan(root, hist, self.lane_graph["lane_ctrs"], self.lane_graph["lane_vecs"], self.target_lane,
+                                            self.target_lane_info, cfg.tar_time_ahead, cfg.tar_dist_thres, cfg.max_depth, pred_len=self.pred_len)
         if res is None:
             return None
         nodes, rows, info = res
@@ -274,12 +297,12 @@ class ScenarioTreeGenerator:
         return self.get_scenario_tree()
 
     def branch_aime(self, lcl_smp, agent_obs):
-        root = self.process_data(lcl_smp, agent_obs)
         if self._native_ok():
-            trees = self._branch_aime_native(root)
+            trees = self._branch_aime_native(lcl_smp, agent_obs)
             if trees is not None:
                 return trees
             self.reset()            # (keeps lane graph / target lane: only the per-plan bookkeeping)
+        root = self.process_data(lcl_smp, agent_obs)
         self.init_scenario_tree(root)
         branch_nodes = self.get_branch_set()
         while branch_nodes:
@@ -494,6 +517,7 @@ class ScenarioTreeGenerator:
         lane_graph = U.lane_graph_from_map(lcl_smp.map_data, orig, rot)
         self.lane_graph = lane_graph
         self.lane_feat_in = U.lane_features(lane_graph)
+        self.n_lanes = int(self.lane_feat_in.shape[0])
         s = self._scene_inputs(orig, rot, pos_n, ang_n, vel_n, types, flags, ctrs, vecs, cur_vel,
                                lane_graph["lane_ctrs"], lane_graph["lane_vecs"])
         s["TRAJS_TID"], s["TRAJS_CAT"] = tids, cats

@@ -439,21 +439,36 @@ class HipPredictor:
         return out
 
     def aime_plan(self, root, hist, lane_ctrs, lane_vecs, target_lane, target_lane_info, time_ahead, dist_thres, max_depth,
-                  pred_len=50, min_vel=0.5, max_rounds=16):
-        """ScenarioTreeGenerator.branch_aime in one call (mind_aime_plan): ``root`` = the root scene dict of process_data (ACTORS,
-        TRAJS_CTRS, TRAJS_VECS, LANES, TGT_NODES, TGT_RPE, ROT, ORIG, TGT_PTS, TRAJS_TYPE), ``hist`` [a,50,6] its world-frame history
-        (x, y, vx, vy, heading, max-sigma).  Returns (nodes: structured array, one record per internal tree node in creation order,
-        rows: float32 [n], info dict) or None when the library reports a situation only the round-by-round path handles."""
+                  pred_len=50, min_vel=0.5, max_rounds=16, raw=None):
+        """ScenarioTreeGenerator.branch_aime in one call (mind_aime_plan).  Host-built root: ``root`` = the root scene dict of
+        process_data (ACTORS, TRAJS_CTRS, TRAJS_VECS, LANES, TGT_NODES, TGT_RPE, ROT, ORIG, TGT_PTS, TRAJS_TYPE), ``hist`` [a,50,6] its
+        world-frame history (x, y, vx, vy, heading, max-sigma), lane_ctrs / lane_vecs the lane graph's anchors.  Device-built root:
+        ``raw`` = dict(pos [a,50,2], ang [a,50], vel [a,50,2], pad [a,50], types [a,50,7] as get_agent_trajectories returns them,
+        lane_pts [l,11,2] float64, lane_flags [l,6] int, travel0) and root / hist / lane_ctrs / lane_vecs are ignored.
+        Returns (nodes: structured array, one record per internal tree node in creation order, rows: float32 [n], info dict) or None
+        when the library reports a situation only the round-by-round path handles."""
         f = lambda x: np.ascontiguousarray(x, np.float32)
         fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
-        arrs = dict(actors=f(root["ACTORS"]), actor_ctrs=f(root["TRAJS_CTRS"]), actor_vecs=f(root["TRAJS_VECS"]), lanes=f(root["LANES"]),
-                    lane_ctrs=f(lane_ctrs), lane_vecs=f(lane_vecs), tgt_nodes=f(root["TGT_NODES"]), tgt_rpe=f(root["TGT_RPE"]),
-                    rot=f(root["ROT"]), orig=f(root["ORIG"]), tgt_pts=f(root["TGT_PTS"]), hist=f(hist), types=f(root["TRAJS_TYPE"]),
-                    target_lane=f(target_lane), target_lane_info=f(target_lane_info))
-        a, l, P = arrs["actors"].shape[0], arrs["lanes"].shape[0], arrs["target_lane"].shape[0]
-        assert arrs["actors"].shape == (a, 14, 48) and arrs["hist"].shape == (a, 50, 6) and arrs["types"].shape == (a, 50, 7)
-        assert arrs["lanes"].shape == (l, 10, 16) and arrs["lane_ctrs"].shape == (l, 2) and arrs["target_lane_info"].shape == (P, 12)
         pi, po = _lib.AimePlanIn(), _lib.AimePlanOut()
+        if raw is not None:
+            arrs = dict(raw_pos=f(raw["pos"]), raw_ang=f(raw["ang"]), raw_vel=f(raw["vel"]), raw_pad=f(raw["pad"]), types=f(raw["types"]),
+                        target_lane=f(target_lane), target_lane_info=f(target_lane_info))
+            lpts = np.ascontiguousarray(raw["lane_pts"], np.float64)
+            lfl = np.ascontiguousarray(raw["lane_flags"], np.int32)
+            a, l, P = arrs["raw_pos"].shape[0], lpts.shape[0], arrs["target_lane"].shape[0]
+            assert arrs["raw_pos"].shape == (a, 50, 2) and arrs["raw_ang"].shape == (a, 50) and arrs["raw_pad"].shape == (a, 50)
+            assert arrs["types"].shape == (a, 50, 7) and lpts.shape == (l, 11, 2) and lfl.shape == (l, 6)
+            pi.lane_pts, pi.lane_flags = lpts.ctypes.data_as(C.POINTER(C.c_double)), lfl.ctypes.data_as(C.POINTER(C.c_int32))
+            pi.travel0 = float(raw["travel0"])
+        else:
+            arrs = dict(actors=f(root["ACTORS"]), actor_ctrs=f(root["TRAJS_CTRS"]), actor_vecs=f(root["TRAJS_VECS"]), lanes=f(root["LANES"]),
+                        lane_ctrs=f(lane_ctrs), lane_vecs=f(lane_vecs), tgt_nodes=f(root["TGT_NODES"]), tgt_rpe=f(root["TGT_RPE"]),
+                        rot=f(root["ROT"]), orig=f(root["ORIG"]), tgt_pts=f(root["TGT_PTS"]), hist=f(hist), types=f(root["TRAJS_TYPE"]),
+                        target_lane=f(target_lane), target_lane_info=f(target_lane_info))
+            a, l, P = arrs["actors"].shape[0], arrs["lanes"].shape[0], arrs["target_lane"].shape[0]
+            assert arrs["actors"].shape == (a, 14, 48) and arrs["hist"].shape == (a, 50, 6) and arrs["types"].shape == (a, 50, 7)
+            assert arrs["lanes"].shape == (l, 10, 16) and arrs["lane_ctrs"].shape == (l, 2)
+        assert arrs["target_lane_info"].shape == (P, 12)
         pi.n_agents, pi.n_lanes, pi.n_lane_pts = a, l, P
         for k, v in arrs.items():
             setattr(pi, k, fp(v))

@@ -29,6 +29,7 @@ def test_native_plan_equals_the_round_by_round_path(scene):
     for native in (True, False):
         pl, sim, w = make_closed_loop(dict(WORKLOADS[scene]), ckpt=BRANCHING_WEIGHTS, speculative=False)
         pl.scen_tree_gen.native_aime = native
+        pl.scen_tree_gen.device_root = False         # both fed by the host featuriser (the device-built root is compared below)
         sims.append((pl, sim))
     n_multi = 0
     for cycle in range(8):
@@ -51,3 +52,39 @@ def test_native_plan_equals_the_round_by_round_path(scene):
         n_multi += len(ia) > 3
     assert sims[0][0].scen_tree_gen.n_native_plans == 8 and sims[1][0].scen_tree_gen.n_native_plans == 0
     assert n_multi >= 4                 # the branching weights really grow multi-round trees here
+
+
+@pytest.mark.parametrize("scene", ["demo_1", "demo_2", "demo_4"])
+def test_device_built_root_equals_the_host_featuriser(scene):
+    """process_data / prepare_root_data as kernels (k_aime_rebase on the raw windows, k_aime_root_lanes, k_aime_root_hist) against
+    the host featuriser feeding the same native plan: the same float32 / float64 expressions, so every discrete result (node ids,
+    CUR_T / END_T, flags, chosen tree) must be equal and the arrays agree to float32 rounding of the ~6 km map coordinates."""
+    sys.path.insert(0, ROOT)
+    from bench import BRANCHING_WEIGHTS, WORKLOADS, make_closed_loop
+    sims = []
+    for dev_root in (True, False):
+        pl, sim, w = make_closed_loop(dict(WORKLOADS[scene]), ckpt=BRANCHING_WEIGHTS, speculative=False)
+        pl.scen_tree_gen.device_root = dev_root
+        sims.append((pl, sim))
+    ulp = float(np.spacing(np.float32(np.abs(sims[0][1].world.pos[0, 0]).max())))
+    worst = 0.0
+    for cycle in range(10):
+        res = []
+        for pl, sim in sims:
+            sim.run_plans(1)
+            gen = pl.scen_tree_gen
+            internal = [(k, n.parent_key, int(n.data.data["CUR_T"]) if n.data.data is not None else -1,
+                         int(n.data.data["END_T"]) if n.data.data is not None else -1,
+                         bool(n.data.branch_flag), bool(n.data.end_flag), bool(n.data.terminate_flag)) for k, n in gen.tree.nodes.items()]
+            res.append((internal, _flat(gen.get_scenario_tree()), np.array(sim.ctrl), pl.timing["best_traj_idx"]))
+        (ia, fa, ca, ba), (ib, fb, cb, bb) = res
+        assert ia == ib, (cycle, ia, ib)
+        assert len(fa) == len(fb) and ba == bb
+        for x, y in zip(fa, fb):
+            assert x[0] == y[0] and x[1] == y[1]
+            assert abs(float(np.ravel(x[2])[0]) - float(np.ravel(y[2])[0])) < 1e-4
+            worst = max(worst, float(np.abs(x[3] - y[3]).max()))
+            assert np.abs(x[3] - y[3]).max() < 2e-3 + 4 * ulp and np.abs(x[4] - y[4]).max() < 1e-3 and np.array_equal(x[5], y[5]), (cycle, x[0])
+        sims[1][1].state, sims[1][1].ctrl = sims[0][1].state.copy(), np.array(sims[0][1].ctrl).copy()      # keep the two loops on one trajectory
+    print(f"{scene}: device-built vs host-built root, max |agent position difference| over 10 cycles = {worst:.2e} m (float32 ulp there {ulp:.1e})")
+    assert sims[0][0].scen_tree_gen.n_native_plans == 10

@@ -256,7 +256,7 @@ def test_recorded_demo_scenes_branching_weights_whole_run(scene):
     A cycle with another choice is therefore accepted only if this planner's best cost is at least as good as the reference's,
     or if the candidate whose cost disagrees is one where this solver's OWN answer moves by more than the parity tolerance
     when its inputs are perturbed by their rounding resolution (the criterion of the plain-weights whole-run test).  At least
-    80 % of the cycles must choose the reference's tree outright."""
+    the observed number of cycles (minus one) must choose the reference's tree outright: 58 / 53 / 59 / 59 of 60."""
     sys.path.insert(0, ROOT)
     from bench import WORKLOADS, make_closed_loop
     from mind_amd.planners.mind.trajectory_tree import flatten_scenario_tree, ilqr_cfg_from
@@ -314,7 +314,9 @@ def test_recorded_demo_scenes_branching_weights_whole_run(scene):
         ill.append(pi)
     print(f"{scene}: 60/60 cycles with the reference's AIME tree ({min(n_nodes)}..{max(n_nodes)} nodes); same tree chosen in "
           f"{same_choice}, better optimum in {better}, ill-conditioned candidate in {ill}")
-    assert max(n_nodes) > 1 and same_choice >= 48
+    # floor = the count observed on the MI355X minus one (profiles/r03n_whole_runs.txt: 59 / 54 / 60 / 60 of 60 = 233 of 240; round 2:
+    # 221); the waived cycles are listed in the line printed above
+    assert max(n_nodes) > 1 and same_choice >= {"demo_1": 58, "demo_2": 53, "demo_3": 59, "demo_4": 59}[scene], same_choice
 
 
 def test_full_tree_plan_is_identical_with_device_assembled_windows():
@@ -393,6 +395,9 @@ def test_four_recorded_scenes_fused_in_one_process_equal_separate_runs(ckpt):
     alone = []
     for sc in scenes:
         pl, sim, w = make_closed_loop(dict(WORKLOADS[sc]), scripted=False, speculative=False, ckpt=ckpt)
+        # the fused rounds are fed by the host featuriser; a scene planned alone builds its root on the device by default, which agrees
+        # with the host featuriser to float32 rounding only (tests/test_gpu_aime_native.py): same featuriser on both sides here
+        pl.scen_tree_gen.device_root = False
         snaps = []
         for _ in range(3):
             sim.run_plans(1)
@@ -481,8 +486,8 @@ def test_recorded_demo_scenes_whole_run_teacher_forced(scene):
     cell lookups and an LM schedule amplify 1e-16 differences into different local minima, DESIGN 2 "chaotic cases").
     A cycle whose ego plan differs by more than the tolerance must therefore be one where this solver's OWN answer moves
     by more than the tolerance when its inputs are perturbed by their rounding resolution (+-1 float32 ulp of the agent
-    means, 1e-13 relative on the initial state); otherwise the test fails.  At least 80 % of the cycles must agree
-    outright."""
+    means, 1e-13 relative on the initial state); otherwise the test fails.  The observed number of cycles (minus one) must
+    agree outright: 59 / 49 / 57 / 55 of 60."""
     sys.path.insert(0, ROOT)
     from bench import WORKLOADS, make_closed_loop
     D = np.load(os.path.join(ROOT, "tests", "golden", "demo_runs.npz"))
@@ -539,7 +544,9 @@ def test_recorded_demo_scenes_whole_run_teacher_forced(scene):
         assert moved > tol, (pi, d_ego, d_ctrl, moved)       # a well-conditioned cycle that disagrees is a real failure
         ill.append(pi)
     assert worst_agents < tol, worst_agents
-    assert agree >= 0.8 * n, (agree, ill)
+    # floor = the count observed on the MI355X minus one (profiles/r03n_whole_runs.txt: 60 / 50 / 58 / 56 of 60 = 224 of 240 with the root
+    # scene built on the device; 60 / 50 / 59 / 58 with the host featuriser: the chaotic cycles move with float32 rounding of the inputs)
+    assert agree >= {"demo_1": 59, "demo_2": 49, "demo_3": 57, "demo_4": 55}[scene], (agree, ill)
     # these scenes grow one chain-shaped tree every cycle: from the second cycle on the warm-start fit is the one that ran
     # beside the predictor (speculate_warm) -- the comparisons above therefore cover that path
     assert opt.counters["warm_hits"] >= n - 2, opt.counters
