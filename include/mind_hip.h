@@ -316,12 +316,28 @@ typedef struct {
   int round_scenes[32];        /* scenes of every round (for the caller's throughput accounting)                          */
   float pair_ms;               /* summed duration of the pair-kernel launches (HIP events; 0 unless profiling is on)      */
   int pair_launches;
+  /* The cost trees TrajectoryTreeOptimizer builds from the returned scenario trees (trajectory_tree.py:19-124: LIFO depth-first
+   * order, every even step of a node's window = one trajectory node), ready for mind_ilqr_contingency: one per root child on a
+   * finished branch, in the order get_scenario_tree returns them.  Library-owned, same lifetime as `nodes`. */
+  int n_trees;                 /* scenario trees                                                                          */
+  const int32_t *tree_top;     /* [n_trees] index in `nodes` of every tree's top node                                     */
+  const int32_t *tree_off;     /* [n_trees+1] trajectory-node offsets of the trees in the arrays below                    */
+  const int32_t *flat_parent;  /* [M_total] parent key inside its tree, -1 for a tree's node 0                            */
+  const float *flat_prob;      /* [M_total] sibling-normalised scenario probability (float32 arithmetic)                   */
+  const float *flat_mean;      /* [M_total, a, 2]                                                                         */
+  const float *flat_cov;       /* [M_total, a]                                                                            */
 } mind_aime_plan_out;
 
 /* Returns MIND_ESTATE ("unsupported: ...") for the situations only the round-by-round host path handles -- a node re-expanded in a
  * later round than the one that created it, no finished branch (the host path raises the reference's assertion), more than
  * max_rounds rounds -- in which case the caller runs that path instead. */
 int mind_aime_plan(mind_ctx *ctx, const mind_aime_plan_in *in, mind_aime_plan_out *out);
+
+/* MINDPlanner.evaluate_traj_tree (planners/mind/planner.py:180-198) for every candidate trajectory tree of a plan (host arithmetic,
+ * float64, numpy's operation and summation order): states [sum counts, 6], ctrls [sum counts, 2] = the trees' nodes in key order, root
+ * (x0, zero control) first; lane [P,2] float32 (lane_is_f32 != 0) or float64; out[n_trees] = mean node cost.  Needs no context. */
+int mind_eval_traj_trees(const double *states, const double *ctrls, const int32_t *counts, int n_trees, const void *lane,
+                         int lane_is_f32, int n_lane_pts, double target_vel, double *out);
 
 /* ------------------------------------------------------------------------------------------------
  * planners/ilqr call surface (iLQR.fit over a TreeCost of arbitrary PotentialField / StatePotential /

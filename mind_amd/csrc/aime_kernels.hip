@@ -281,6 +281,21 @@ __global__ __launch_bounds__(64) void k_aime_gather(const AimeGather *__restrict
   o[0] = r[0]; o[1] = r[1]; o[2] = r[5];
 }
 
+// Flattened cost-tree rows (trajectory_tree.py:58-124 reads every even step of a scenario node's window): for the listed nodes the
+// steps 0, 2, 4 ... < dur of every agent, mean [n, a, 2] and max-sigma [n, a] at the node's offset.  One block per (job, agent).
+struct AimeFlat { int row0, n, dst, a; };
+__global__ __launch_bounds__(64) void k_aime_flat(const AimeFlat *__restrict__ jobs, const int *__restrict__ job_of_block,
+                                                  const int *__restrict__ agent_of_block, const float *const *__restrict__ world_of_job,
+                                                  float *__restrict__ mean, float *__restrict__ cov) {
+  const AimeFlat J = jobs[job_of_block[blockIdx.x]];
+  const int i = agent_of_block[blockIdx.x], m = threadIdx.x;
+  if (m >= J.n) return;
+  const float *r = world_of_job[job_of_block[blockIdx.x]] + (((size_t)J.row0 + (size_t)i * AIME_K) * AIME_T + 2 * m) * AIME_PK;
+  const size_t o = (size_t)(J.dst + m) * J.a + i;
+  mean[2 * o] = r[0]; mean[2 * o + 1] = r[1];
+  cov[o] = r[5];
+}
+
 // rows [n,128] repeated `times` times (LaneNet's output shared by every scene of a round)
 __global__ void k_repeat_rows(const float *__restrict__ src, size_t n, int times, float *__restrict__ dst) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

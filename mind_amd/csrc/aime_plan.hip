@@ -372,6 +372,78 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       n_rows += (int64_t)a * dur * 3;
     }
   }
+  // ---- the cost trees of the finished branches, flattened as TrajectoryTreeOptimizer would (trajectory_tree.py:19-124 / get_scenario_tree
+  //      :208-272): sibling-normalised probabilities in float64, LIFO depth-first creation order, every even step = one trajectory node
+  std::vector<std::vector<int>> kids(nodes.size());
+  for (int i = 1; i < (int)nodes.size(); ++i) kids[nodes[i].parent].push_back(i);
+  c->pl_tree_top.clear(); c->pl_tree_off.assign(1, 0); c->pl_flat_parent.clear(); c->pl_flat_prob.clear();
+  std::vector<AimeFlat> fjobs;
+  std::vector<const float *> fworld;
+  std::vector<int> fjob_of_block, fagent_of_block;
+  for (int top : kids[0]) {
+    if (!nodes[top].end) continue;
+    // probabilities: breadth-first renormalisation over the siblings that lie on finished branches
+    // (float32 throughout: SCEN_PROB is a float32 scalar and the Python literals 0.0 / 1.0 it meets are weak scalars under numpy >= 2,
+    // which is what the host path -- pinned against the reference's sibling probabilities in tests/golden/aime.npz -- computes with)
+    std::vector<float> pr(nodes.size(), 0.f);
+    pr[top] = 1.f;
+    std::vector<int> queue(1, top);
+    for (size_t qh = 0; qh < queue.size(); ++qh) {
+      const int cur = queue[qh];
+      float total = 0.f;
+      for (int ch : kids[cur]) if (nodes[ch].end) total = total + nodes[ch].prob;
+      for (int ch : kids[cur]) if (nodes[ch].end) { pr[ch] = nodes[ch].prob / total * pr[cur]; queue.push_back(ch); }
+    }
+    // flatten: stack pop() = the last child first; a node's trajectory nodes are chained, the first hangs off its parent's last
+    const int base = c->pl_tree_off.back();
+    int count = 0;
+    std::vector<int> last(nodes.size(), -1), stack(1, top);
+    while (!stack.empty()) {
+      const int q = stack.back();
+      stack.pop_back();
+      const PlNode &n = nodes[q];
+      const int dur = n.end_t - n.cur_t, nn = (dur + 1) / 2;
+      const int up = q == top ? -1 : last[n.parent];
+      if (nn > 0) {
+        for (int m = 0; m < nn; ++m) {
+          c->pl_flat_parent.push_back(m == 0 ? up : count + m - 1);
+          c->pl_flat_prob.push_back(pr[q]);
+        }
+        AimeFlat J;
+        J.row0 = n.scene * a * AIME_K + n.mode; J.n = nn; J.dst = base + count; J.a = a;
+        for (int e = 0; e < a; ++e) { fjob_of_block.push_back((int)fjobs.size()); fagent_of_block.push_back(e); }
+        fjobs.push_back(J);
+        fworld.push_back((const float *)c->pl_world[n.round].p);
+        count += nn;
+        last[q] = count - 1;
+      } else {
+        last[q] = up;
+      }
+      for (int ch : kids[q]) if (nodes[ch].end) stack.push_back(ch);
+    }
+    c->pl_tree_top.push_back(top - 1);
+    c->pl_tree_off.push_back(base + count);
+  }
+  const size_t Mtot = (size_t)c->pl_tree_off.back();
+  c->pl_flat_mean.resize(Mtot * a * 2); c->pl_flat_cov.resize(Mtot * a);
+  float *d_fmean = nullptr, *d_fcov = nullptr;
+  if (!fjobs.empty()) {
+    const size_t bJ = (fjobs.size() * sizeof(AimeFlat) + 15) & ~(size_t)15, bW = (fjobs.size() * sizeof(float *) + 15) & ~(size_t)15;
+    const size_t bB = (fjob_of_block.size() * sizeof(int) + 15) & ~(size_t)15, bM = (Mtot * a * 2 * sizeof(float) + 15) & ~(size_t)15;
+    if ((rc = ensure(c, c->pl_flat, bJ + bW + 2 * bB + bM + Mtot * a * sizeof(float)))) return rc;
+    if ((rc = pl_pin(c, 0, bJ + bW + 2 * bB))) return rc;          // (the root upload of this plan completed rounds ago)
+    char *h = (char *)c->pl_pin[0];
+    memcpy(h, fjobs.data(), fjobs.size() * sizeof(AimeFlat));
+    memcpy(h + bJ, fworld.data(), fjobs.size() * sizeof(float *));
+    memcpy(h + bJ + bW, fjob_of_block.data(), fjob_of_block.size() * sizeof(int));
+    memcpy(h + bJ + bW + bB, fagent_of_block.data(), fagent_of_block.size() * sizeof(int));
+    HIPCHK(c, hipMemcpyAsync(c->pl_flat.p, h, bJ + bW + 2 * bB, hipMemcpyHostToDevice, st));
+    char *d = (char *)c->pl_flat.p;
+    d_fmean = (float *)(d + bJ + bW + 2 * bB); d_fcov = (float *)(d + bJ + bW + 2 * bB + bM);
+    hipLaunchKernelGGL(k_aime_flat, dim3((unsigned)fjob_of_block.size()), dim3(64), 0, st, (const AimeFlat *)d, (const int *)(d + bJ + bW),
+                       (const int *)(d + bJ + bW + bB), (const float *const *)(d + bJ), d_fmean, d_fcov);
+    HIPCHK(c, hipGetLastError());
+  }
   c->pl_rows_host.resize((size_t)n_rows);
   if (!jobs.empty()) {
     const size_t bJ = (jobs.size() * sizeof(AimeGather) + 15) & ~(size_t)15, bW = (jobs.size() * sizeof(float *) + 15) & ~(size_t)15;
@@ -389,15 +461,30 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     hipLaunchKernelGGL(k_aime_gather, dim3((unsigned)job_of_block.size()), dim3(64), 0, st, (const AimeGather *)d, (const int *)(d + bJ + bW),
                        (const int *)(d + bJ + bW + bB), (const float *const *)(d + bJ), (float *)c->pl_rows.p);
     HIPCHK(c, hipGetLastError());
-    if ((rc = pl_pin(c, 2, (size_t)n_rows * sizeof(float)))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->pl_pin[2], c->pl_rows.p, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToHost, st));
+    const size_t n_flat = Mtot * a * 3;
+    if ((rc = pl_pin(c, 2, ((size_t)n_rows + n_flat) * sizeof(float)))) return rc;
+    float *hp = (float *)c->pl_pin[2];
+    HIPCHK(c, hipMemcpyAsync(hp, c->pl_rows.p, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (d_fmean) {
+      HIPCHK(c, hipMemcpyAsync(hp + n_rows, d_fmean, Mtot * a * 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipMemcpyAsync(hp + n_rows + Mtot * a * 2, d_fcov, Mtot * a * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(c, hipStreamSynchronize(st));
-    memcpy(c->pl_rows_host.data(), c->pl_pin[2], (size_t)n_rows * sizeof(float));
+    memcpy(c->pl_rows_host.data(), hp, (size_t)n_rows * sizeof(float));
+    if (d_fmean) {
+      memcpy(c->pl_flat_mean.data(), hp + n_rows, Mtot * a * 2 * sizeof(float));
+      memcpy(c->pl_flat_cov.data(), hp + n_rows + Mtot * a * 2, Mtot * a * sizeof(float));
+    }
+  } else {
+    HIPCHK(c, hipStreamSynchronize(st));
   }
   out->nodes = c->pl_nodes.data(); out->n_nodes = N;
   out->rows = c->pl_rows_host.data(); out->n_row_floats = n_rows;
   out->n_expanded = n_expanded; out->n_rounds = round;
   out->root_flags = (nodes[0].branch ? MIND_AIME_BRANCH : 0) | (nodes[0].end ? MIND_AIME_END : 0) | (nodes[0].term ? MIND_AIME_TERMINATE : 0);
   out->pair_ms = pair_ms; out->pair_launches = pair_launches;
+  out->n_trees = (int)c->pl_tree_top.size(); out->tree_top = c->pl_tree_top.data(); out->tree_off = c->pl_tree_off.data();
+  out->flat_parent = c->pl_flat_parent.data(); out->flat_prob = c->pl_flat_prob.data();
+  out->flat_mean = c->pl_flat_mean.data(); out->flat_cov = c->pl_flat_cov.data();
   return MIND_OK;
 }

@@ -101,7 +101,9 @@ struct mind_ctx {
   size_t pl_pin_cap[4] = {0, 0, 0, 0};
   hipEvent_t ev_pl = nullptr;
   std::vector<mind_aime_node> pl_nodes;
-  std::vector<float> pl_rows_host;
+  std::vector<float> pl_rows_host, pl_flat_prob, pl_flat_mean, pl_flat_cov;
+  std::vector<int32_t> pl_tree_top, pl_tree_off, pl_flat_parent;
+  DevBuf pl_flat;
   bool dec_overlap = true;      // actor_proj of the decoder on the side stream beside k_dec_scene (mind_set_tuning("dec_overlap"))
   int rb_cur = 0, rb_gen = 0;     // re-basing arenas: which one the last call filled, its generation and geometry
   size_t rb_S = 0, rb_a = 0;
@@ -223,7 +225,7 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
       if (b->p) (void)hipFree(b->p);
   if (c->wdev) (void)hipFree(c->wdev);
   for (DevBuf *b : {&c->pl_root, &c->pl_in[0], &c->pl_in[1], &c->pl_lf, &c->pl_lrep, &c->pl_pred, &c->pl_small, &c->pl_tab, &c->pl_win[0],
-                    &c->pl_win[1], &c->pl_gather, &c->pl_rows})
+                    &c->pl_win[1], &c->pl_gather, &c->pl_rows, &c->pl_flat})
     if (b->p) (void)hipFree(b->p);
   for (DevBuf &b : c->pl_world)
     if (b.p) (void)hipFree(b.p);
@@ -1650,6 +1652,73 @@ extern "C" int mind_aime_rebase(mind_ctx *c, const mind_rebase_in *in, const min
 }
 
 #include "aime_plan.hip"
+
+// ---- MINDPlanner.evaluate_traj_tree (planner.py:180-198) for all candidate trajectory trees of a plan: mean over a tree's nodes of
+//      .1 jerk^2 + 5 steer_rate^2 + .01 (v_tgt - v)^2 + .01 dist(target lane).  Host only (a few 10^4 point-segment pairs); float64 with
+//      numpy's operation order (per-node terms left to right, the per-tree sum as np.add.reduceat forms it: first element + pairwise
+//      sum of the rest, blocks of 8 / 128), so that the strict `<` scan over the candidates sees the costs numpy computes.
+namespace {
+double np_pairwise(const double *a, long n) {
+  if (n < 8) {
+    double r = 0.0;
+    for (long i = 0; i < n; ++i) r += a[i];
+    return r;
+  }
+  if (n <= 128) {
+    double r[8];
+    long i;
+    for (i = 0; i < 8; ++i) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  long n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+}
+template <class T>
+void eval_nodes(const double *st, const double *ct, long N, const T *lane, int P, double tv, double *per_node) {
+  std::vector<T> dx(P - 1), dy(P - 1), l2(P - 1);
+  for (int q = 0; q < P - 1; ++q) {
+    dx[q] = lane[2 * q + 2] - lane[2 * q];
+    dy[q] = lane[2 * q + 3] - lane[2 * q + 1];
+    l2[q] = dx[q] * dx[q] + dy[q] * dy[q];                      // in the lane's own dtype, as numpy computes it
+  }
+  for (long i = 0; i < N; ++i) {
+    const double px = st[6 * i], py = st[6 * i + 1];
+    double dmin = INFINITY;
+    for (int q = 0; q < P - 1; ++q) {
+      const double sx = (double)lane[2 * q], sy = (double)lane[2 * q + 1], ddx = (double)dx[q], ddy = (double)dy[q];
+      double t = ((px - sx) * ddx + (py - sy) * ddy) / (double)l2[q];
+      t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+      const double ex = px - (sx + t * ddx), ey = py - (sy + t * ddy);
+      const double d = sqrt(ex * ex + ey * ey);
+      dmin = d < dmin ? d : dmin;
+    }
+    const double c0 = ct[2 * i], c1 = ct[2 * i + 1], dv = tv - st[6 * i + 2];
+    per_node[i] = ((0.1 * (c0 * c0) + 5.0 * (c1 * c1)) + 0.01 * (dv * dv)) + 0.01 * dmin;
+  }
+}
+}  // namespace
+
+extern "C" int mind_eval_traj_trees(const double *states, const double *ctrls, const int32_t *counts, int n_trees, const void *lane,
+                                    int lane_is_f32, int n_lane_pts, double target_vel, double *out) {
+  if (!states || !ctrls || !counts || n_trees <= 0 || !lane || n_lane_pts < 2 || !out) return MIND_EINVAL;
+  long N = 0;
+  for (int t = 0; t < n_trees; ++t) { if (counts[t] <= 0) return MIND_EINVAL; N += counts[t]; }
+  std::vector<double> per(N);
+  if (lane_is_f32) eval_nodes<float>(states, ctrls, N, (const float *)lane, n_lane_pts, target_vel, per.data());
+  else eval_nodes<double>(states, ctrls, N, (const double *)lane, n_lane_pts, target_vel, per.data());
+  long o = 0;
+  for (int t = 0; t < n_trees; ++t) {
+    const long n = counts[t];
+    out[t] = (n > 1 ? per[o] + np_pairwise(per.data() + o + 1, n - 1) : per[o]) / (double)n;
+    o += n;
+  }
+  return MIND_OK;
+}
 
 // ---- debug taps (tests only): run only the first n fusion layers; read back internal buffers
 extern "C" int mind_debug_set_layers(mind_ctx *c, int n) {

@@ -48,6 +48,7 @@ class MINDPlanner:
         self.last_ctrl_seq = []
         self.timing = {}
         self.timing_sum = {"plans": 0, "aime_s": 0.0, "ilqr_s": 0.0, "total_s": 0.0}   # running totals over all plans
+        self._native_eval = os.environ.get("MIND_NATIVE_EVAL", "1") != "0"
         if isinstance(config_dir, dict):
             self.planner_cfg = config_dir
         else:
@@ -121,12 +122,21 @@ class MINDPlanner:
             if len(tr.object_states) > self.obs_len:
                 tr.object_states.pop(0)
             # array mirror of the track [n, (observed, x, y, heading, vx, vy)] used by the featuriser
+            # (a window into a per-track buffer that is compacted every 3 x obs_len appends: no allocation / concatenation per frame)
             s = tr.object_states[-1]
-            row = np.array([[float(s.observed), s.position[0], s.position[1], s.heading, s.velocity[0], s.velocity[1]]])
-            arr = getattr(tr, "_arr", None)
-            arr = row if arr is None else np.concatenate([arr, row])[-self.obs_len:]
             try:
-                tr._arr = arr
+                buf = getattr(tr, "_buf", None)
+                if buf is None:
+                    buf, tr._i, tr._n = np.empty((4 * self.obs_len, 6)), 0, 0
+                    tr._buf = buf
+                i = tr._i
+                if i == len(buf):
+                    keep = self.obs_len - 1
+                    buf[:keep] = buf[i - keep:i]
+                    i = keep
+                buf[i, 0], buf[i, 1], buf[i, 2], buf[i, 3], buf[i, 4], buf[i, 5] = s.observed, s.position[0], s.position[1], s.heading, s.velocity[0], s.velocity[1]
+                tr._i, tr._n = i + 1, min(tr._n + 1, self.obs_len)
+                tr._arr = buf[i + 1 - tr._n:i + 1]
             except AttributeError:      # immutable Track type: the featuriser falls back to the object list
                 pass
 
@@ -224,6 +234,20 @@ class MINDPlanner:
         st = np.concatenate([p[0] for p in packs])
         ct = np.concatenate([p[1] for p in packs])
         counts = np.array([len(p[0]) for p in packs])
+        lane = np.asarray(lcl_smp.target_lane)
+        if getattr(self, "_native_eval", True) and lane.dtype in (np.float32, np.float64) and lane.ndim == 2 and st.dtype == np.float64 and ct.dtype == np.float64:
+            # the same arithmetic in native code (mind_eval_traj_trees: numpy's operation and summation order)
+            import ctypes as C
+            from ... import _lib
+            lib = _lib.load()
+            st, ct, lane = np.ascontiguousarray(st), np.ascontiguousarray(ct), np.ascontiguousarray(lane)
+            cnt = np.ascontiguousarray(counts, np.int32)
+            out = np.zeros(len(packs))
+            dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+            rc = lib.mind_eval_traj_trees(dp(st), dp(ct), cnt.ctypes.data_as(C.POINTER(C.c_int32)), len(packs), C.c_void_p(lane.ctypes.data),
+                                          int(lane.dtype == np.float32), len(lane), C.c_double(float(lcl_smp.target_velocity)), dp(out))
+            if rc == 0:
+                return list(out)
         starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
         lane = np.asarray(lcl_smp.target_lane)
         # x / y kept as separate [nodes, segments] arrays (same arithmetic per element as the [.., 2] form, a

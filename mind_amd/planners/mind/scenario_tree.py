@@ -294,7 +294,13 @@ class ScenarioTreeGenerator:
         self.n_expanded += info["n_expanded"]
         self.branch_depth = info["n_rounds"]
         self.n_native_plans += 1
-        return self.get_scenario_tree()
+        trees = self.get_scenario_tree()
+        # the library flattened the same trees already (TrajectoryTreeOptimizer.solve_batch takes `_flat` instead of walking the nodes)
+        by_top = {keys[top]: flat for top, flat in info["flats"]}
+        for t in trees:
+            t._flat = by_top.get(t.get_root_key())
+        self.last_trees = trees
+        return trees
 
     def branch_aime(self, lcl_smp, agent_obs):
         if self._native_ok():

@@ -44,8 +44,21 @@ def flatten_scenario_tree(scen_tree):
                 cov=np.ascontiguousarray(np.concatenate(cov), np.float32))
 
 
+_CFG_CACHE = {}
+
+
 def ilqr_cfg_from(config, block, max_iter=100):
-    """TrajTreeCfg (w_opt_cfg / opt_cfg dict) -> C struct."""
+    """TrajTreeCfg (w_opt_cfg / opt_cfg dict) -> C struct (built once per config object and block: it is read-only afterwards)."""
+    key = (id(config), block, max_iter)
+    hit = _CFG_CACHE.get(key)
+    if hit is not None and hit[0] is config:
+        return hit[1]
+    c = _ilqr_cfg_build(config, block, max_iter)
+    _CFG_CACHE[key] = (config, c)
+    return c
+
+
+def _ilqr_cfg_build(config, block, max_iter):
     o = getattr(config, block)
     for name in ("w_des_state", "w_state_con", "w_ctrl"):
         m = np.asarray(o[name], np.float64)
@@ -238,7 +251,7 @@ class TrajectoryTreeOptimizer:
 
     # all scenario trees of one plan: 2 launches (warm start, full) instead of 2 x n_trees solves
     def solve_batch(self, scen_trees, init_state, init_ctrl, target_lane, target_vel):
-        flats = [flatten_scenario_tree(t) for t in scen_trees]
+        flats = [getattr(t, "_flat", None) or flatten_scenario_tree(t) for t in scen_trees]     # `_flat`: built by mind_aime_plan already
         x0 = self._get_init_state(init_state, init_ctrl)
         lane = np.asarray(target_lane, np.float64)
         solve = self.solver if self.solver is not None else self._runtime().ilqr_solve

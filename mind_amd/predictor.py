@@ -485,7 +485,20 @@ class HipPredictor:
         nodes = np.frombuffer(C.string_at(po.nodes, n * C.sizeof(_lib.AimeNode)), dtype=AIME_NODE_DTYPE) if n else np.zeros(0, AIME_NODE_DTYPE)
         nf = int(po.n_row_floats)
         rows = np.frombuffer(C.string_at(po.rows, nf * 4), dtype=np.float32) if nf else np.zeros(0, np.float32)
-        info = dict(n_expanded=po.n_expanded, n_rounds=po.n_rounds, root_flags=po.root_flags, a=a, l=l,
+        # the flattened cost trees (what flatten_scenario_tree builds from the returned scenario trees), one dict per scenario tree
+        flats, nt = [], po.n_trees
+        if nt:
+            off = np.frombuffer(C.string_at(po.tree_off, (nt + 1) * 4), dtype=np.int32)
+            top = np.frombuffer(C.string_at(po.tree_top, nt * 4), dtype=np.int32)
+            Mt = int(off[-1])
+            par = np.frombuffer(C.string_at(po.flat_parent, Mt * 4), dtype=np.int32)
+            prob = np.frombuffer(C.string_at(po.flat_prob, Mt * 4), dtype=np.float32)
+            mean = np.frombuffer(C.string_at(po.flat_mean, Mt * a * 8), dtype=np.float32).reshape(Mt, a, 2)
+            cov = np.frombuffer(C.string_at(po.flat_cov, Mt * a * 4), dtype=np.float32).reshape(Mt, a)
+            for t in range(nt):
+                lo, hi = int(off[t]), int(off[t + 1])
+                flats.append((int(top[t]), dict(parent=par[lo:hi], prob=prob[lo:hi], mean=mean[lo:hi], cov=cov[lo:hi])))
+        info = dict(n_expanded=po.n_expanded, n_rounds=po.n_rounds, root_flags=po.root_flags, a=a, l=l, flats=flats,
                     round_scenes=[po.round_scenes[i] for i in range(po.n_rounds)], pair_ms=po.pair_ms, pair_launches=po.pair_launches)
         self.last_aime_info = info
         return nodes, rows, info

@@ -41,6 +41,12 @@ def test_native_plan_equals_the_round_by_round_path(scene):
                          int(n.data.data["END_T"]) if n.data.data is not None else -1,
                          bool(n.data.branch_flag), bool(n.data.end_flag), bool(n.data.terminate_flag)) for k, n in gen.tree.nodes.items()]
             res.append((internal, _flat(gen.get_scenario_tree()), np.array(sim.ctrl), pl.timing["nodes_expanded"], pl.timing["best_traj_idx"]))
+            if gen.native_aime:
+                # the cost trees the library flattened (trajectory_tree.py:19-124) = what flatten_scenario_tree builds from the returned trees
+                from mind_amd.planners.mind.trajectory_tree import flatten_scenario_tree
+                for t in gen.last_trees:
+                    f, g_ = flatten_scenario_tree(t), t._flat
+                    assert g_ is not None and all(np.array_equal(f[k], g_[k]) and f[k].dtype == g_[k].dtype for k in ("parent", "prob", "mean", "cov")), cycle
         (ia, fa, ca, ea, ba), (ib, fb, cb, eb, bb) = res
         assert ia == ib, (cycle, ia, ib)
         assert len(fa) == len(fb) and ea == eb and ba == bb
