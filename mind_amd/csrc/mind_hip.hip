@@ -16,6 +16,7 @@
 #include "encdec_kernels.hip"
 #include "fusion_kernels.hip"
 #include "pair_bf16_kernels.hip"
+#include "token_mfma_kernels.hip"
 #include "actor_mfma_kernels.hip"
 #include "dec_mfma_kernels.hip"
 #include "ilqr_kernels.hip"
@@ -74,6 +75,12 @@ struct mind_ctx {
   AmW actorBW;   // the same convolutions as bf16 hi / lo MFMA fragments (actor_mfma_kernels.hip)
   DecW decW;
   TokWeights tokW[7];  // [L]: epilogue of layer L-1 (L>=1) + prologue of layer L (L<=5); [0] = init
+  TokWeightsM tokWM[7]; // the same matrices as fp32 MFMA A fragments (k_token_mfma)
+  // token kernel on the fp32 MFMA (k_token_mfma; MIND_TOK_MFMA=1 / mind_set_tuning("tok_mfma")).  Opt-in: measured on the MI355X it is
+  // SLOWER than the VALU kernel -- 41 vs 30 us per launch at demo size (6 workgroups), 315 vs 282 us average on the full cfg4 tree
+  // (profiles/r03o_*, r03p_*): 640 fp32 MFMAs of 32 cycles per wave and launch are 8.5 us by themselves and the weight stream (64 KB per
+  // projection and workgroup) is the same; a bf16-split variant would cut the MFMA time, not the rest
+  bool tok_mfma = false;
   const float *WAe[6], *WAp[6], *vtab[6], *rtab = nullptr;
   const u32 *WBe[6], *WBp[6];   // bf16 hi / lo fragments of the same matrices (pair_bf16_kernels.hip)
   // job / token tables of recent mind_predict_batch calls (least-recently-used of MIND_TABLE_SETS): a call whose scene sizes
@@ -203,6 +210,8 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *me = getenv("MIND_ENC_MFMA")) c->enc_mfma = !(me[0] == '0');
   if (const char *de = getenv("MIND_DEC_MFMA_MIN")) c->dec_mfma_min = atoi(de);
   if (const char *oe = getenv("MIND_DEC_OVERLAP")) c->dec_overlap = !(oe[0] == '0');
+  if (const char *te = getenv("MIND_TOK_MFMA")) c->tok_mfma = !(te[0] == '0');
+  (void)hipFuncSetAttribute((const void *)k_token_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_token_mfma_lds_bytes());
   if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_actor<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
@@ -260,6 +269,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "actor_split") c->actor_np = value == 3 ? 3 : 6;
   else if (n == "xcd_order") c->xcd_order = value != 0;
   else if (n == "dec_overlap") c->dec_overlap = value != 0;
+  else if (n == "tok_mfma") c->tok_mfma = value != 0;
   else if (n == "ilqr_wgs") c->ilqr_wgs = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (n == "ilqr_multi_min") c->ilqr_multi_min = value;
   else if (n == "ilqr_test_starve") c->ilqr_test_starve = value != 0;   // tests: launch a wide tree without its last workgroups
@@ -353,6 +363,19 @@ std::vector<float> pack_afrag(const float *w, int row_stride) {
         for (int k = 0; k < 4; ++k)
           t[((size_t)(ob * 8 + s4) * 64 + lane) * 4 + k] =
               w[(size_t)(16 * ob + (lane & 15)) * row_stride + 16 * s4 + 4 * (lane >> 4) + k];
+  return t;
+}
+
+// folded-K-query fragments of k_token_mfma: per head hd and output block ob the A operand [16 features] x [16 d]:
+// [hd 8][ob 8][lane 64][w 4] = Wk[hd * 16 + 4 (lane >> 4) + w][16 ob + (lane & 15)]   (Wk = rows 128..255 of in_proj_weight)
+std::vector<float> pack_wk_frag(const float *wk) {
+  std::vector<float> t(16384, 0.f);
+  if (!wk) return t;
+  for (int hd = 0; hd < 8; ++hd)
+    for (int ob = 0; ob < 8; ++ob)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int k = 0; k < 4; ++k)
+          t[((size_t)(hd * 8 + ob) * 64 + lane) * 4 + k] = wk[(size_t)(hd * 16 + 4 * (lane >> 4) + k) * 128 + 16 * ob + (lane & 15)];
   return t;
 }
 
@@ -534,6 +557,8 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
   // ---- fusion_net
   lin_ln("fus.pa", "fusion_net.proj_actor", 0, 128, 128);
   lin_ln("fus.pl", "fusion_net.proj_lane", 0, 128, 128);
+  B.add("fus.pa.WM", pack_afrag(sd.get("fusion_net.proj_actor.0.weight", 128 * 128), 128));      // the same as fp32 MFMA A fragments (k_token_mfma)
+  B.add("fus.pl.WM", pack_afrag(sd.get("fusion_net.proj_lane.0.weight", 128 * 128), 128));
   {
     // rpe table [32 chunks][8][4]: k<5 W_r[f][k], 5 bias, 6 gamma, 7 beta, f = 4 chunk + w
     const float *W = sd.get("fusion_net.proj_rpe_scene.0.weight", 128 * 5);
@@ -585,6 +610,21 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
     B.add(k + ".vtab", vt);
     const float *Win = sd.get(p + ".multihead_attn.in_proj_weight", 384 * 128);
     const float *bin = sd.get(p + ".multihead_attn.in_proj_bias", 384);
+    {
+      // the token kernel's projections as fp32 MFMA A fragments (k_token_mfma)
+      const float *Wo_ = sd.get(p + ".multihead_attn.out_proj.weight", 128 * 128);
+      const float *W1_ = sd.get(p + ".linear1.weight", 256 * 128), *W2_ = sd.get(p + ".linear2.weight", 128 * 256);
+      B.add(k + ".WsM", pack_afrag(Wm + 128, 384));
+      B.add(k + ".WtM", pack_afrag(Wm + 256, 384));
+      B.add(k + ".WqM", pack_afrag(Win, 128));
+      B.add(k + ".WkM", pack_wk_frag(Win ? Win + 128 * 128 : nullptr));
+      B.add(k + ".WvM", pack_afrag(Win ? Win + 2 * 128 * 128 : nullptr, 128));
+      B.add(k + ".WoM", pack_afrag(Wo_, 128));
+      B.add(k + ".W1aM", pack_afrag(W1_, 128));
+      B.add(k + ".W1bM", pack_afrag(W1_ ? W1_ + 128 * 128 : nullptr, 128));
+      B.add(k + ".W2aM", pack_afrag(W2_, 256));
+      B.add(k + ".W2bM", pack_afrag(W2_ ? W2_ + 128 : nullptr, 256));
+    }
     B.add(k + ".WqT", transpose(Win, 128, 128));
     B.add(k + ".Wk", vec(Win ? Win + 128 * 128 : nullptr, 128 * 128));
     B.add(k + ".WvT", transpose(Win ? Win + 2 * 128 * 128 : nullptr, 128, 128));
@@ -725,6 +765,17 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
     }
     w.WpaT = P("fus.pa.W"); w.bpa = P("fus.pa.b"); w.gpa = P("fus.pa.g"); w.bepa = P("fus.pa.be");
     w.WplT = P("fus.pl.W"); w.bpl = P("fus.pl.b"); w.gpl = P("fus.pl.g"); w.bepl = P("fus.pl.be");
+    TokWeightsM &m = c->tokWM[L];
+    memset(&m, 0, sizeof(m));
+    if (L >= 1) {
+      std::string k = "fus.L" + std::to_string(L - 1);
+      m.Wv = P(k + ".WvM"); m.Wo = P(k + ".WoM"); m.W1a = P(k + ".W1aM"); m.W1b = P(k + ".W1bM"); m.W2a = P(k + ".W2aM"); m.W2b = P(k + ".W2bM");
+    }
+    if (L <= 5) {
+      std::string k = "fus.L" + std::to_string(L);
+      m.Ws = P(k + ".WsM"); m.Wt = P(k + ".WtM"); m.Wq = P(k + ".WqM"); m.Wkf = P(k + ".WkM");
+    }
+    m.Wpa = P("fus.pa.WM"); m.Wpl = P("fus.pl.WM");
   }
   DecW &d = c->decW;
   d.rpeW = P("dec.rpe.W"); d.rpeb = P("dec.rpe.b"); d.rpeg = P("dec.rpe.g"); d.rpebe = P("dec.rpe.be");
@@ -969,8 +1020,14 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   // ---- fusion: init tokens + 6 x (pair kernel, token kernel)
   const int tok_blocks = (ntok + TPW - 1) / TPW;
   const int qsplit = c->pair_prec != 0 ? 16 : 0;      // the bf16 pair kernels read the folded query as hi / lo fragments
-  hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok, 1 | 4 | qsplit, actor_feat, lane_feat, x, part, ST, QK,
-                     c->tokW[0]);
+  const int tokm_blocks = (ntok + TM_TOK - 1) / TM_TOK;
+  const size_t tokm_lds = mind_token_mfma_lds_bytes();
+  if (c->tok_mfma)
+    hipLaunchKernelGGL(k_token_mfma, dim3(tokm_blocks), dim3(TM_THREADS), tokm_lds, st, dmeta, ntok, 1 | 4 | qsplit, actor_feat, lane_feat, x, part, ST, QK,
+                       c->tokW[0], c->tokWM[0]);
+  else
+    hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok, 1 | 4 | qsplit, actor_feat, lane_feat, x, part, ST, QK,
+                       c->tokW[0]);
   int grid = njobs < c->n_cu ? njobs : c->n_cu;      // jobs are dealt wave-major over the workgroups
   const size_t lds = mind_pair_lds_bytes();
   c->n_pair_launch = 0;
@@ -1007,8 +1064,12 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
     c->n_pair_launch++;
     c->pairs_done += (L == 5) ? pairs_l5 : pairs_full;
     const int mode = 2 | (L < 5 ? 4 : 8) | qsplit;
-    hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok, mode, actor_feat, lane_feat, x, part, ST, QK,
-                       c->tokW[L + 1]);
+    if (c->tok_mfma)
+      hipLaunchKernelGGL(k_token_mfma, dim3(tokm_blocks), dim3(TM_THREADS), tokm_lds, st, dmeta, ntok, mode, actor_feat, lane_feat, x, part, ST, QK,
+                         c->tokW[L + 1], c->tokWM[L + 1]);
+    else
+      hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok, mode, actor_feat, lane_feat, x, part, ST, QK,
+                         c->tokW[L + 1]);
   }
   // ---- decoder
   const int *d_actor_row = (const int *)ts->rows.p;

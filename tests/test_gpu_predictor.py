@@ -215,3 +215,24 @@ def test_decoder_halves_on_two_streams_are_bit_identical(a, l, B, seed, hip_pred
         hip_predictor.set_tuning("dec_overlap", 1)
     for k in ("cls", "reg", "vel"):
         assert torch.equal(two[0][k], one[k]) and torch.equal(two[1][k], one[k]), k
+
+
+@pytest.mark.parametrize("a,l,B,seed", [(3, 4, 1, 1), (17, 30, 3, 4), (40, 55, 1, 1)])
+def test_token_kernel_on_the_fp32_mfma(a, l, B, seed, hip_predictor, formula_sd):
+    """k_token_mfma (opt-in, mind_set_tuning("tok_mfma")): every projection of the per-token epilogue / prologue of the fusion layers on
+    v_mfma_f32_16x16x4_f32, 16 tokens per workgroup (ragged last tile at these sizes), against the oracle and against the fp32 VALU
+    kernel it replaces (network.py:177-179, 205-232)."""
+    pb = predictor_batch(a, l, B, seed=seed)
+    oc, orr, ov = op.forward(formula_sd, to_t(pb))
+    ref = hip_predictor.predict_numpy_batch(pb)
+    try:
+        hip_predictor.set_tuning("tok_mfma", 1)
+        out = hip_predictor.predict_numpy_batch(pb)
+    finally:
+        hip_predictor.set_tuning("tok_mfma", 0)
+    reg, vel = out["reg"].cpu().numpy(), out["vel"].cpu().numpy()
+    for b in range(B):
+        assert np.abs(reg[b * a:(b + 1) * a] - orr[b].numpy()).max() < TOL
+        assert np.abs(vel[b * a:(b + 1) * a] - ov[b].numpy()).max() < TOL
+    assert (out["reg"] - ref["reg"]).abs().max().item() < 5e-5
+    assert not torch.equal(out["reg"], ref["reg"])          # it really was the other kernel
