@@ -530,6 +530,8 @@ def run_concurrent(args):
     GPU work of one scene overlaps the host bookkeeping and the GPU work of the others."""
     import threading
     P = args.concurrent
+    if os.environ.get("MIND_SWITCH_INTERVAL"):
+        sys.setswitchinterval(float(os.environ["MIND_SWITCH_INTERVAL"]))
     loops, errs = [None] * P, []
     ready, go = threading.Barrier(P + 1), threading.Barrier(P + 1)
     done_steps = [0] * P
@@ -537,7 +539,7 @@ def run_concurrent(args):
     def worker(i):
         try:
             with torch.cuda.stream(torch.cuda.Stream()):
-                pl, sim, w = make_closed_loop(scene_workload(args.workload, i), full_tree=args.workload in FULL_TREE, speculative=P <= 4)
+                pl, sim, w = make_closed_loop(scene_workload(args.workload, i), full_tree=args.workload in FULL_TREE, speculative=P <= 4, ckpt=args.ckpt)
                 sim.run_plans(max(args.warmup, 1))
                 torch.cuda.current_stream().synchronize()
                 loops[i] = (pl, sim)

@@ -25,7 +25,7 @@ struct PlNode {
   float tgt[22];
 };
 
-int pl_pin(mind_ctx *c, int which, size_t bytes) {
+int pl_pin(mind_ctx *c, int which, size_t bytes) {      // (declared ahead of ilqr_impl in mind_hip.hip)
   if (bytes <= c->pl_pin_cap[which]) return MIND_OK;
   if (c->pl_pin[which]) (void)hipHostFree(c->pl_pin[which]);
   c->pl_pin[which] = nullptr; c->pl_pin_cap[which] = 0;

@@ -104,8 +104,8 @@ struct mind_ctx {
   // source makes hipMemcpyAsync wait for the stream to drain first), host result tables
   DevBuf pl_root, pl_in[2], pl_lf, pl_lrep, pl_pred, pl_small, pl_tab, pl_win[2], pl_gather, pl_rows;
   std::vector<DevBuf> pl_world;
-  void *pl_pin[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t pl_pin_cap[4] = {0, 0, 0, 0};
+  void *pl_pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // [4], [5]: upload / read-back staging of the tree-iLQR calls
+  size_t pl_pin_cap[6] = {0, 0, 0, 0, 0, 0};
   hipEvent_t ev_pl = nullptr;
   std::vector<mind_aime_node> pl_nodes;
   std::vector<float> pl_rows_host, pl_flat_prob, pl_flat_mean, pl_flat_cov;
@@ -210,6 +210,9 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *me = getenv("MIND_ENC_MFMA")) c->enc_mfma = !(me[0] == '0');
   if (const char *de = getenv("MIND_DEC_MFMA_MIN")) c->dec_mfma_min = atoi(de);
   if (const char *oe = getenv("MIND_DEC_OVERLAP")) c->dec_overlap = !(oe[0] == '0');
+  (void)hipFuncSetAttribute((const void *)k_ilqr<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
+  (void)hipFuncSetAttribute((const void *)k_ilqr<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
+  (void)hipFuncSetAttribute((const void *)k_ilqr<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
   if (const char *te = getenv("MIND_TOK_MFMA")) c->tok_mfma = !(te[0] == '0');
   (void)hipFuncSetAttribute((const void *)k_token_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_token_mfma_lds_bytes());
   if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
@@ -1170,6 +1173,7 @@ extern "C" int mind_lane_dist_field(mind_ctx *c, const double *ego_xy, const dou
 }
 
 struct IlqrEvalReq { int nq; const int32_t *node; const double *x, *u; double *out; };
+namespace { int pl_pin(mind_ctx *c, int which, size_t bytes); }     // page-locked staging buffers of the context (aime_plan.hip)
 
 // Shared host side of mind_ilqr_solve_trees / mind_ilqr_solve_fields / mind_cost_eval: build the device
 // arena, then either run the solver (ev == nullptr) or evaluate node costs at the requested points.
@@ -1406,14 +1410,18 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
       return fail(c, MIND_EINVAL, "mind_ilqr_contingency: both configurations must share dt / wheelbase / grid");
   }
   // one staged copy of everything the host provides (`up` lives until the stream has been synchronised below)
-  std::vector<char> up(o_work, 0);
+  // (page-locked staging: a pageable source makes hipMemcpyAsync a blocking staged copy that also stalls the other contexts of the
+  // process -- several planner threads on one GPU then run slower together than one alone)
+  if ((rc = pl_pin(c, 4, o_work))) return rc;
+  char *up = (char *)c->pl_pin[4];
   {
-    memcpy(up.data(), hD.data(), bytesIn);
-    if (bytesF) memcpy(up.data() + bytesIn, hF.data(), bytesF);
-    if (bytesI) memcpy(up.data() + bytesIn + bytesF, hI.data(), bytesI);
-    memcpy(up.data() + o_structs, hT.data(), (size_t)n_trees * sizeof(IlqrTreeDev));
-    memcpy(up.data() + o_consts, K2, 2 * sizeof(IlqrConst));
-    HIPCHK(c, hipMemcpyAsync(base, up.data(), o_work, hipMemcpyHostToDevice, st));
+    memset(up, 0, o_work);
+    memcpy(up, hD.data(), bytesIn);
+    if (bytesF) memcpy(up + bytesIn, hF.data(), bytesF);
+    if (bytesI) memcpy(up + bytesIn + bytesF, hI.data(), bytesI);
+    memcpy(up + o_structs, hT.data(), (size_t)n_trees * sizeof(IlqrTreeDev));
+    memcpy(up + o_consts, K2, 2 * sizeof(IlqrConst));
+    HIPCHK(c, hipMemcpyAsync(base, up, o_work, hipMemcpyHostToDevice, st));
   }
   const IlqrConst *dK = (const IlqrConst *)(base + o_consts);
   if (!gen) hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, K.gx.p, K.gy.p, W, H, Dp(o_lane), n_lane_pts, Dp(o_quad));
@@ -1449,16 +1457,13 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   c->ilqr_trees = n_trees; c->ilqr_multi = multi ? G : 1; c->ilqr_ms = 0.f;
   auto launch = [&](bool multi_) {
     if (gen) {
-      (void)hipFuncSetAttribute((const void *)k_ilqr<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
       hipLaunchKernelGGL((k_ilqr<true, false>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
     } else if (multi_) {
-      (void)hipFuncSetAttribute((const void *)k_ilqr<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
       // (ilqr_test_starve: the last eight workgroups are withheld, as if the device could not hold the whole launch: their peers wait
       // at the first barrier, raise the abort word and the call falls back to the one-workgroup kernel below)
       hipLaunchKernelGGL((k_ilqr<false, true>), dim3(((n_trees + 7) / 8) * 8 * G - (c->ilqr_test_starve ? 8 : 0)), dim3(IL_THREADS), il_lds, st, dT, dK,
                          n_phases, n_trees, G, dBars);
     } else {
-      (void)hipFuncSetAttribute((const void *)k_ilqr<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds);
       hipLaunchKernelGGL((k_ilqr<false, false>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
     }
   };
@@ -1468,30 +1473,34 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   std::vector<double> hs((size_t)2 * IL_NSTAT * n_trees);
   // xs of all trees and, right behind them, the stats of all trees: one copy; us lives in the uploaded region
   const size_t n_xs = (size_t)(tl[0].stats - tl[0].xs);
-  std::vector<double> hx(n_xs + hs.size());
-  HIPCHK(c, hipMemcpyAsync(hx.data(), Dp(tl[0].xs), hx.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(us, Dp(tl[0].us), (size_t)Mtot * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  const size_t n_hx = n_xs + hs.size(), n_us = (size_t)Mtot * 2;
+  if ((rc = pl_pin(c, 5, (n_hx + n_us + 2) * sizeof(double)))) return rc;
+  double *hx = (double *)c->pl_pin[5], *hus = hx + n_hx;
+  unsigned *h_abort = (unsigned *)(hus + n_us);
+  HIPCHK(c, hipMemcpyAsync(hx, Dp(tl[0].xs), n_hx * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(hus, Dp(tl[0].us), n_us * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (multi) HIPCHK(c, hipMemcpyAsync(h_abort, dBars + 4 * (size_t)n_trees, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   if (c->profiling) HIPCHK(c, hipEventElapsedTime(&c->ilqr_ms, c->ev_il0, c->ev_il1));
   if (multi) {
-    unsigned aborted = 0;
-    HIPCHK(c, hipMemcpy(&aborted, dBars + 4 * (size_t)n_trees, sizeof(unsigned), hipMemcpyDeviceToHost));
+    const unsigned aborted = *h_abort;
     if (aborted) {
       // the workgroups of a wide tree did not meet at a barrier within ~2 s: the launch was not fully resident (another context or
       // stream held CUs -- several planners on one GPU).  The one-workgroup-per-tree kernel needs no co-residency: the upload (initial
       // controls, zeroed barrier words) is repeated and the call solved with it -- same arithmetic, same results, just slower.
       c->n_ilqr_fallbacks++;
-      HIPCHK(c, hipMemcpyAsync(base, up.data(), o_work, hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(base, up, o_work, hipMemcpyHostToDevice, st));
       launch(false);
       HIPCHK(c, hipGetLastError());
       c->ilqr_multi = 1;
-      HIPCHK(c, hipMemcpyAsync(hx.data(), Dp(tl[0].xs), hx.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-      HIPCHK(c, hipMemcpyAsync(us, Dp(tl[0].us), (size_t)Mtot * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipMemcpyAsync(hx, Dp(tl[0].xs), n_hx * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipMemcpyAsync(hus, Dp(tl[0].us), n_us * sizeof(double), hipMemcpyDeviceToHost, st));
       HIPCHK(c, hipStreamSynchronize(st));
     }
   }
-  memcpy(xs, hx.data(), (size_t)Mtot * 6 * sizeof(double));
-  memcpy(hs.data(), hx.data() + n_xs, hs.size() * sizeof(double));
+  memcpy(xs, hx, (size_t)Mtot * 6 * sizeof(double));
+  memcpy(us, hus, n_us * sizeof(double));
+  memcpy(hs.data(), hx + n_xs, hs.size() * sizeof(double));
   {
     // phase cycles of the launch's critical tree (the one with the most cycles over all its fits): what bounds the launch
     double best = -1.0;
