@@ -20,4 +20,3 @@ for P in (1, 2):
     for i in range(P): print(P, "threads, thread", i, round(res[i][0], 3), "s;", {k: round(v, 2) for k, v in res[i][1].items()}, flush=True)
 PY
 timeout 200 python /tmp/thr2.py 2>/dev/null
-MIND_POLL_SYNC=1 timeout 200 python /tmp/thr2.py 2>/dev/null | sed "s/^/[poll] /"
