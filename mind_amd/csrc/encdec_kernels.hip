@@ -567,8 +567,8 @@ __global__ __launch_bounds__(AT) void k_actor_net(const float *__restrict__ acto
 extern "C" size_t mind_actor_lds_bytes() { return (size_t)ACT_LDS_FLOATS * sizeof(float); }
 
 // =================================================================================================
-// SceneDecoder, scene part: target embedding, 6 mode tokens through ctx_proj + 2 encoder layers,
-// mode probabilities.  One workgroup per scene.
+// SceneDecoder, scene part: target embedding (k_dec_tgt), 6 mode tokens through ctx_proj + 2 encoder layers,
+// mode probabilities (k_dec_scene).  One workgroup per scene.
 // =================================================================================================
 struct DecW {
   const float *rpeW, *rpeb, *rpeg, *rpebe;                       // proj_rpe 20(->pad 20)->128
@@ -584,27 +584,17 @@ struct DecW {
 
 #define DEC_SCENE_PART 24576
 #define DEC_SCENE_LDS_FLOATS (256 + 768 + 768 + 2304 + 768 + 9216 + 768 + 144 + DEC_SCENE_PART)
-__global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*[tokens,128]*/,
-                                                  const int *__restrict__ cls_row /*[B]*/,
-                                                  const float *__restrict__ tgt_feat /*[B,128]*/,
-                                                  const float *__restrict__ tgt_rpe /*[B,20]*/,
-                                                  float *__restrict__ Cout /*[B,6,128]*/,
-                                                  float *__restrict__ tgt_out /*[B,128]*/,
-                                                  float *__restrict__ cls_out /*[B,6]*/, DecW W) {
+// target embedding (network.py:491-495): needs only the target polyline's LaneNet feature and its RPE, so it runs on the side stream
+// right behind that LaneNet launch, off the critical path of the fusion layers.  One workgroup per scene.
+__global__ __launch_bounds__(DT) void k_dec_tgt(const float *__restrict__ tgt_feat /*[B,128]*/, const float *__restrict__ tgt_rpe /*[B,20]*/,
+                                                float *__restrict__ tgt_out /*[B,128]*/, DecW W) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   float (*v0)[256] = (float (*)[256])(dsm);
   float (*v1)[768] = (float (*)[768])(dsm + 256);
-  float (*C)[128] = (float (*)[128])(dsm + 1024);
-  float (*qkv)[384] = (float (*)[384])(dsm + 1792);
-  float (*att)[128] = (float (*)[128])(dsm + 4096);
-  float (*ff)[1536] = (float (*)[1536])(dsm + 4864);
-  float (*t2)[128] = (float (*)[128])(dsm + 14080);
-  float (*sc)[6][6] = (float (*)[6][6])(dsm + 14848);
   float *part = dsm + 14992;
   const int PF = DEC_SCENE_PART;
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
-  // ---- target embedding (network.py:491-495)
   if (tid < 20) v1[0][tid] = tgt_rpe[(size_t)b * 20 + tid];
   __syncthreads();
   dense<1>(&v1[0][0], 768, 20, W.rpeW, W.rpeb, 128, &v0[0][128], 256, part, PF);
@@ -621,7 +611,25 @@ __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*
   ln_rows(&v0[0][0], 256, 1, 128, W.t3g, W.t3be, true);
   __syncthreads();
   if (tid < 128) tgt_out[(size_t)b * 128 + tid] = v0[0][tid];
-  __syncthreads();
+}
+
+__global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*[tokens,128]*/,
+                                                  const int *__restrict__ cls_row /*[B]*/,
+                                                  float *__restrict__ Cout /*[B,6,128]*/,
+                                                  float *__restrict__ cls_out /*[B,6]*/, DecW W) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  float (*v0)[256] = (float (*)[256])(dsm);
+  float (*v1)[768] = (float (*)[768])(dsm + 256);
+  float (*C)[128] = (float (*)[128])(dsm + 1024);
+  float (*qkv)[384] = (float (*)[384])(dsm + 1792);
+  float (*att)[128] = (float (*)[128])(dsm + 4096);
+  float (*ff)[1536] = (float (*)[1536])(dsm + 4864);
+  float (*t2)[128] = (float (*)[128])(dsm + 14080);
+  float (*sc)[6][6] = (float (*)[6][6])(dsm + 14848);
+  float *part = dsm + 14992;
+  const int PF = DEC_SCENE_PART;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
   // ---- ctx_proj: cls token -> 6 mode tokens (network.py:501)
   if (tid < 128) v0[0][tid] = x[(size_t)cls_row[b] * 128 + tid];
   __syncthreads();

@@ -535,7 +535,8 @@ extern "C" size_t mind_pair_lds_bytes() { return (size_t)LDS_TOTAL * sizeof(floa
 // 512 threads = 4 k-groups x 128 output features; weights are stored transposed [in][out] so that a
 // wave reads 64 consecutive floats per k.
 // =================================================================================================
-#define TPW 8
+#define TOK_TPW_BIG 8      // tokens per k_token workgroup: big batches
+#define TOK_TPW_SMALL 4    // ... small batches (same arithmetic, see k_token)
 
 struct TokMeta {
   int type;      // 0 actor, 1 lane, 2 cls
@@ -563,8 +564,8 @@ struct TokWeights {
 #define TT_THREADS (TKG * 128)
 
 // partial y[t] = sum_{k in this group's quarter} WT[k*ldo + col] * xin[t][k]   (K/4 <= 64 weights in registers)
-template <int K>
-__device__ __forceinline__ void matvec_part(float (&acc)[TPW], const float *__restrict__ WT, int ldo, int col,
+template <int K, int TP>
+__device__ __forceinline__ void matvec_part(float (&acc)[TP], const float *__restrict__ WT, int ldo, int col,
                                             const float *xin, int ldx, int kg) {
   constexpr int KQ = K / TKG;
   const int k0 = kg * KQ;
@@ -572,11 +573,11 @@ __device__ __forceinline__ void matvec_part(float (&acc)[TPW], const float *__re
 #pragma unroll
   for (int k = 0; k < KQ; ++k) w[k] = WT[(size_t)(k0 + k) * ldo + col];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) acc[t] = 0.f;
+  for (int t = 0; t < TP; ++t) acc[t] = 0.f;
 #pragma unroll
   for (int k = 0; k < KQ; k += 4)
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
+    for (int t = 0; t < TP; ++t) {
       const float4 xv = *reinterpret_cast<const float4 *>(xin + t * ldx + k0 + k);
       acc[t] = fmaf(w[k], xv.x, acc[t]);
       acc[t] = fmaf(w[k + 1], xv.y, acc[t]);
@@ -585,18 +586,22 @@ __device__ __forceinline__ void matvec_part(float (&acc)[TPW], const float *__re
     }
 }
 
-// meet the four partials: on return r0/r1 = bias + full sums for this thread's tokens 2kg, 2kg+1 (fixed order).
-// Contains two barriers; rk is [TKG][TPW][128].
-__device__ __forceinline__ void ksum(const float (&acc)[TPW], float bias, float *rk, int kg, int col, float &r0, float &r1) {
+// meet the four partials: on return r0/r1 = bias + full sums for this thread's tokens (fixed order): 2kg, 2kg+1 of a workgroup of
+// eight tokens, kg alone (r1 unused) of a workgroup of four.  Contains two barriers; rk is [TKG][TP][128].
+template <int TP>
+__device__ __forceinline__ void ksum(const float (&acc)[TP], float bias, float *rk, int kg, int col, float &r0, float &r1) {
+  constexpr int TPW = TP;
   __syncthreads();                      // previous users of rk are done
 #pragma unroll
   for (int t = 0; t < TPW; ++t) rk[(kg * TPW + t) * 128 + col] = acc[t];
   __syncthreads();
-  const int t0 = 2 * kg;
+  const int t0 = (TP / TKG) * kg;
   r0 = ((rk[(0 * TPW + t0) * 128 + col] + rk[(1 * TPW + t0) * 128 + col]) +
         (rk[(2 * TPW + t0) * 128 + col] + rk[(3 * TPW + t0) * 128 + col])) + bias;
-  r1 = ((rk[(0 * TPW + t0 + 1) * 128 + col] + rk[(1 * TPW + t0 + 1) * 128 + col]) +
-        (rk[(2 * TPW + t0 + 1) * 128 + col] + rk[(3 * TPW + t0 + 1) * 128 + col])) + bias;
+  r1 = 0.f;
+  if (TP / TKG == 2)
+    r1 = ((rk[(0 * TPW + t0 + 1) * 128 + col] + rk[(1 * TPW + t0 + 1) * 128 + col]) +
+          (rk[(2 * TPW + t0 + 1) * 128 + col] + rk[(3 * TPW + t0 + 1) * 128 + col])) + bias;
 }
 
 // sum over the 128 features of this k-group's two tokens (two waves per group); rd is [TKG][2][2]
@@ -624,6 +629,10 @@ __device__ __forceinline__ void ln2tok(float &p0, float &p1, float g, float be, 
 
 // mode bits: 1 = init (x0 from actor/lane features), 2 = has epilogue, 4 = has prologue, 8 = only flagged,
 // 16 = write the folded query as bf16 hi / lo A fragments (for k_pair_bf) instead of fp32
+// TPW = 8 tokens per workgroup (big batches: every weight fetched from L2 serves eight tokens) or 4 (small batches: twice the
+// workgroups, half the LDS operand traffic in each -- the per-stage time of a lone scene's launch).  The k split and every
+// summation order are the same, so the two instantiations give bit-identical results.
+template <int TPW>
 __global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_token(const TokMeta *__restrict__ meta, int n_tok, int mode,
                                                       const float *__restrict__ actor_feat,
                                                       const float *__restrict__ lane_feat, float *__restrict__ x,
@@ -638,8 +647,9 @@ __global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const int tid = threadIdx.x, kg = tid >> 7, col = tid & 127;
   const int tok0 = blockIdx.x * TPW;
   const int nt = min(TPW, n_tok - tok0);
-  const int ta = 2 * kg, tb = 2 * kg + 1;          // the two tokens this thread owns after a ksum
-  const bool va = ta < nt, vb = tb < nt;
+  constexpr bool TWO = TPW / TKG == 2;
+  const int ta = (TPW / TKG) * kg, tb = TWO ? ta + 1 : ta;          // the token(s) this thread owns after a ksum
+  const bool va = ta < nt, vb = TWO && tb < nt;
 #ifdef MIND_TOKEN_TRACE
   long long tt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq_ = clock64();
 #define TT(i) do { const long long n_ = clock64(); tt_[i] += n_ - tq_; tq_ = n_; } while (0)
@@ -664,13 +674,13 @@ __global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       if (m.type == 0) fb = actor_feat[(size_t)m.src * 128 + col];
       else if (m.type == 1) fb = lane_feat[(size_t)m.src * 128 + col];
     }
-    tmp[ta][col] = fa; tmp[tb][col] = fb;
+    tmp[ta][col] = fa; if (TWO) tmp[tb][col] = fb;
     __syncthreads();
     float acc[TPW], a0, a1, l0, l1;
-    matvec_part<128>(acc, W.WpaT, 128, col, &tmp[0][0], 260, kg);
-    ksum(acc, W.bpa[col], rk, kg, col, a0, a1);
-    matvec_part<128>(acc, W.WplT, 128, col, &tmp[0][0], 260, kg);
-    ksum(acc, W.bpl[col], rk, kg, col, l0, l1);
+    matvec_part<128, TPW>(acc, W.WpaT, 128, col, &tmp[0][0], 260, kg);
+    ksum<TPW>(acc, W.bpa[col], rk, kg, col, a0, a1);
+    matvec_part<128, TPW>(acc, W.WplT, 128, col, &tmp[0][0], 260, kg);
+    ksum<TPW>(acc, W.bpl[col], rk, kg, col, l0, l1);
     float p0 = tya == 0 ? a0 : l0, p1 = tyb == 0 ? a1 : l1;
     {
       // LN with per-token (type-dependent) affine: normalise first, then scale
@@ -685,11 +695,11 @@ __global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       if (tya == 2) p0 = 0.f;
       if (tyb == 2) p1 = 0.f;
     }
-    xs[ta][col] = p0; xs[tb][col] = p1;
+    xs[ta][col] = p0; if (TWO) xs[tb][col] = p1;
     __syncthreads();
   } else {
     xs[ta][col] = va ? x[(size_t)(tok0 + ta) * 128 + col] : 0.f;
-    xs[tb][col] = vb ? x[(size_t)(tok0 + tb) * 128 + col] : 0.f;
+    if (TWO) xs[tb][col] = vb ? x[(size_t)(tok0 + tb) * 128 + col] : 0.f;
     __syncthreads();
   }
   TT(0);
@@ -722,7 +732,7 @@ __global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     __syncthreads();
     TT(1);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < TPW / TKG; ++q) {
       const int t = ta + q;
       int ns = 0, slot0 = 0;
       if (t < nt) {
@@ -750,41 +760,41 @@ __global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     // ---- o = W_v,h mbar_h + b_v  (output feature f = hd*16+d uses head hd = f>>4)
     {
       float acc[TPW], o0, o1;
-      matvec_part<128>(acc, W.WvT, 128, col, &mb[0][col >> 4][0], 8 * 132, kg);
-      ksum(acc, W.bv[col], rk, kg, col, o0, o1);
-      tmp[ta][col] = o0; tmp[tb][col] = o1;
+      matvec_part<128, TPW>(acc, W.WvT, 128, col, &mb[0][col >> 4][0], 8 * 132, kg);
+      ksum<TPW>(acc, W.bv[col], rk, kg, col, o0, o1);
+      tmp[ta][col] = o0; if (TWO) tmp[tb][col] = o1;
       __syncthreads();
     }
     TT(3);
     // ---- att = W_o o + b_o ; x1 = LN2(x + att)
     {
       float acc[TPW], p0, p1;
-      matvec_part<128>(acc, W.WoT, 128, col, &tmp[0][0], 260, kg);
-      ksum(acc, W.bo[col], rk, kg, col, p0, p1);
+      matvec_part<128, TPW>(acc, W.WoT, 128, col, &tmp[0][0], 260, kg);
+      ksum<TPW>(acc, W.bo[col], rk, kg, col, p0, p1);
       p0 += xs[ta][col]; p1 += xs[tb][col];
       ln2tok(p0, p1, W.g2[col], W.b2[col], rd, kg, tid);
       __syncthreads();                  // every k-group has finished reading xs
-      xs[ta][col] = p0; xs[tb][col] = p1;
+      xs[ta][col] = p0; if (TWO) xs[tb][col] = p1;
       __syncthreads();
     }
     TT(4);
     // ---- FFN 128 -> 256 -> 128, x2 = LN3(x1 + ff)
     {
       float acc[TPW], h0, h1;
-      matvec_part<128>(acc, W.W1T, 256, col, &xs[0][0], 132, kg);
-      ksum(acc, W.b1[col], rk, kg, col, h0, h1);
-      tmp[ta][col] = fmaxf(h0, 0.f); tmp[tb][col] = fmaxf(h1, 0.f);
-      matvec_part<128>(acc, W.W1T, 256, 128 + col, &xs[0][0], 132, kg);
-      ksum(acc, W.b1[128 + col], rk, kg, col, h0, h1);
-      tmp[ta][128 + col] = fmaxf(h0, 0.f); tmp[tb][128 + col] = fmaxf(h1, 0.f);
+      matvec_part<128, TPW>(acc, W.W1T, 256, col, &xs[0][0], 132, kg);
+      ksum<TPW>(acc, W.b1[col], rk, kg, col, h0, h1);
+      tmp[ta][col] = fmaxf(h0, 0.f); if (TWO) tmp[tb][col] = fmaxf(h1, 0.f);
+      matvec_part<128, TPW>(acc, W.W1T, 256, 128 + col, &xs[0][0], 132, kg);
+      ksum<TPW>(acc, W.b1[128 + col], rk, kg, col, h0, h1);
+      tmp[ta][128 + col] = fmaxf(h0, 0.f); if (TWO) tmp[tb][128 + col] = fmaxf(h1, 0.f);
       __syncthreads();
       float p0, p1;
-      matvec_part<256>(acc, W.W2T, 128, col, &tmp[0][0], 260, kg);
-      ksum(acc, W.bb2[col], rk, kg, col, p0, p1);
+      matvec_part<256, TPW>(acc, W.W2T, 128, col, &tmp[0][0], 260, kg);
+      ksum<TPW>(acc, W.bb2[col], rk, kg, col, p0, p1);
       p0 += xs[ta][col]; p1 += xs[tb][col];
       ln2tok(p0, p1, W.g3[col], W.b3[col], rd, kg, tid);
       __syncthreads();
-      xs[ta][col] = p0; xs[tb][col] = p1;
+      xs[ta][col] = p0; if (TWO) xs[tb][col] = p1;
       __syncthreads();
     }
   }
@@ -797,17 +807,17 @@ __global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     // ---- prologue of the next layer: S = W_s x, T = W_t x + b_m, q = W_q x + b_q,
     //      qk[hd][f] = sum_d q[hd*16+d] W_k[hd*16+d][f] / 4      (scale 1/sqrt(16))
     float acc[TPW], r0, r1;
-    matvec_part<128>(acc, W.WsT, 128, col, &xs[0][0], 132, kg);
-    ksum(acc, 0.f, rk, kg, col, r0, r1);
+    matvec_part<128, TPW>(acc, W.WsT, 128, col, &xs[0][0], 132, kg);
+    ksum<TPW>(acc, 0.f, rk, kg, col, r0, r1);
     if (va) ST[(size_t)(tok0 + ta) * 256 + col] = r0;
     if (vb) ST[(size_t)(tok0 + tb) * 256 + col] = r1;
-    matvec_part<128>(acc, W.WtT, 128, col, &xs[0][0], 132, kg);
-    ksum(acc, W.bm[col], rk, kg, col, r0, r1);
+    matvec_part<128, TPW>(acc, W.WtT, 128, col, &xs[0][0], 132, kg);
+    ksum<TPW>(acc, W.bm[col], rk, kg, col, r0, r1);
     if (va) ST[(size_t)(tok0 + ta) * 256 + 128 + col] = r0;
     if (vb) ST[(size_t)(tok0 + tb) * 256 + 128 + col] = r1;
-    matvec_part<128>(acc, W.WqT, 128, col, &xs[0][0], 132, kg);
-    ksum(acc, W.bq[col], rk, kg, col, r0, r1);
-    tmp[ta][col] = r0; tmp[tb][col] = r1;
+    matvec_part<128, TPW>(acc, W.WqT, 128, col, &xs[0][0], 132, kg);
+    ksum<TPW>(acc, W.bq[col], rk, kg, col, r0, r1);
+    tmp[ta][col] = r0; if (TWO) tmp[tb][col] = r1;
     __syncthreads();
     TT(6);
     // each k-group takes two of the eight heads, all tokens

@@ -61,7 +61,7 @@ struct mind_ctx {
   // internal side stream: the lane encoders run beside the actor encoder; always fenced against `stream` with
   // events on both sides, so callers only ever see work ordered on `stream`
   hipStream_t side = nullptr;
-  hipEvent_t ev_side = nullptr, ev_main = nullptr, ev_stage = nullptr;
+  hipEvent_t ev_side = nullptr, ev_main = nullptr, ev_stage = nullptr, ev_tgt = nullptr;
   std::vector<char> aime_stage;   // host staging of mind_aime_world's small tables (guarded by ev_stage)
   bool aime_stage_busy = false;
   std::string err;
@@ -81,6 +81,8 @@ struct mind_ctx {
   // (profiles/r03o_*, r03p_*): 640 fp32 MFMAs of 32 cycles per wave and launch are 8.5 us by themselves and the weight stream (64 KB per
   // projection and workgroup) is the same; a bf16-split variant would cut the MFMA time, not the rest
   bool tok_mfma = false;
+  bool tgt_side = true;         // the target polyline's encoder + embedding stay on the side stream through the fusion layers ("tgt_side")
+  int tok_small_max = 2048;     // batches of at most this many tokens run k_token with 4 tokens per workgroup ("tok_small_max")
   const float *WAe[6], *WAp[6], *vtab[6], *rtab = nullptr;
   const u32 *WBe[6], *WBp[6];   // bf16 hi / lo fragments of the same matrices (pair_bf16_kernels.hip)
   // job / token tables of recent mind_predict_batch calls (least-recently-used of MIND_TABLE_SETS): a call whose scene sizes
@@ -182,6 +184,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
   if (c->side && hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
   if (c->side && hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
+  if (c->side && hipEventCreateWithFlags(&c->ev_tgt, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
   if (hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming) != hipSuccess) { *out = nullptr; delete c; return MIND_EHIP; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
@@ -214,9 +217,12 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   (void)hipFuncSetAttribute((const void *)k_ilqr<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
   (void)hipFuncSetAttribute((const void *)k_ilqr<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
   if (const char *te = getenv("MIND_TOK_MFMA")) c->tok_mfma = !(te[0] == '0');
+  if (const char *te = getenv("MIND_TOK_SMALL_MAX")) c->tok_small_max = atoi(te);
+  if (const char *te = getenv("MIND_TGT_SIDE")) c->tgt_side = !(te[0] == '0');
   (void)hipFuncSetAttribute((const void *)k_token_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_token_mfma_lds_bytes());
   if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_dec_tgt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_actor<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_actor<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_actor<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
@@ -247,6 +253,7 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->ev_side) (void)hipEventDestroy(c->ev_side);
   if (c->ev_main) (void)hipEventDestroy(c->ev_main);
+  if (c->ev_tgt) (void)hipEventDestroy(c->ev_tgt);
   if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
   if (c->ev_il0) (void)hipEventDestroy(c->ev_il0);
   if (c->ev_il1) (void)hipEventDestroy(c->ev_il1);
@@ -273,6 +280,8 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "xcd_order") c->xcd_order = value != 0;
   else if (n == "dec_overlap") c->dec_overlap = value != 0;
   else if (n == "tok_mfma") c->tok_mfma = value != 0;
+  else if (n == "tok_small_max") c->tok_small_max = (int)value;
+  else if (n == "tgt_side") c->tgt_side = value != 0;
   else if (n == "ilqr_wgs") c->ilqr_wgs = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (n == "ilqr_multi_min") c->ilqr_multi_min = value;
   else if (n == "ilqr_test_starve") c->ilqr_test_starve = value != 0;   // tests: launch a wide tree without its last workgroups
@@ -1012,16 +1021,24 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   } else if (out->lane_feat && out->lane_feat != in->lane_feat && Ltot > 0) {
     HIPCHK(c, hipMemcpyAsync(out->lane_feat, in->lane_feat, (size_t)Ltot * 128 * sizeof(float), hipMemcpyDeviceToDevice, ss));
   }
-  hipLaunchKernelGGL(k_lane_net, dim3((Bn + PL - 1) / PL), dim3(DT), 0, ss, in->tgt_nodes, Bn, (float *)c->tgt_feat.p, c->laneW);
   hipLaunchKernelGGL(k_tokpos, dim3((ntok + 255) / 256), dim3(256), 0, ss, dmeta, ntok, in->actor_ctrs, in->actor_vecs,
                      in->lane_ctrs, in->lane_vecs, tokpos);
   if (c->side) {
     HIPCHK(c, hipEventRecord(c->ev_side, c->side));
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_side, 0));
   }
+  // the target polyline's encoder + embedding feed the decoder only: they stay on the side stream while the fusion layers run
+  hipLaunchKernelGGL(k_lane_net, dim3((Bn + PL - 1) / PL), dim3(DT), 0, ss, in->tgt_nodes, Bn, (float *)c->tgt_feat.p, c->laneW);
+  hipLaunchKernelGGL(k_dec_tgt, dim3(Bn), dim3(DT), mind_dec_scene_lds_bytes(), ss, (const float *)c->tgt_feat.p, in->tgt_rpe, (float *)c->tgt_emb.p,
+                     c->decW);
+  if (c->side) HIPCHK(c, hipEventRecord(c->ev_tgt, c->side));
+  if (c->side && !c->tgt_side) HIPCHK(c, hipStreamWaitEvent(st, c->ev_tgt, 0));
 
   // ---- fusion: init tokens + 6 x (pair kernel, token kernel)
-  const int tok_blocks = (ntok + TPW - 1) / TPW;
+  // small batches: four tokens per k_token workgroup (more workgroups, half the LDS operand traffic each; bit-identical results)
+  const bool tok_small = ntok <= c->tok_small_max;
+  const int tok_tpw = tok_small ? TOK_TPW_SMALL : TOK_TPW_BIG;
+  const int tok_blocks = (ntok + tok_tpw - 1) / tok_tpw;
   const int qsplit = c->pair_prec != 0 ? 16 : 0;      // the bf16 pair kernels read the folded query as hi / lo fragments
   const int tokm_blocks = (ntok + TM_TOK - 1) / TM_TOK;
   const size_t tokm_lds = mind_token_mfma_lds_bytes();
@@ -1029,8 +1046,8 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
     hipLaunchKernelGGL(k_token_mfma, dim3(tokm_blocks), dim3(TM_THREADS), tokm_lds, st, dmeta, ntok, 1 | 4 | qsplit, actor_feat, lane_feat, x, part, ST, QK,
                        c->tokW[0], c->tokWM[0]);
   else
-    hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok, 1 | 4 | qsplit, actor_feat, lane_feat, x, part, ST, QK,
-                       c->tokW[0]);
+    hipLaunchKernelGGL(tok_small ? k_token<TOK_TPW_SMALL> : k_token<TOK_TPW_BIG>, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok,
+                       1 | 4 | qsplit, actor_feat, lane_feat, x, part, ST, QK, c->tokW[0]);
   int grid = njobs < c->n_cu ? njobs : c->n_cu;      // jobs are dealt wave-major over the workgroups
   const size_t lds = mind_pair_lds_bytes();
   c->n_pair_launch = 0;
@@ -1071,8 +1088,8 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
       hipLaunchKernelGGL(k_token_mfma, dim3(tokm_blocks), dim3(TM_THREADS), tokm_lds, st, dmeta, ntok, mode, actor_feat, lane_feat, x, part, ST, QK,
                          c->tokW[L + 1], c->tokWM[L + 1]);
     else
-      hipLaunchKernelGGL(k_token, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok, mode, actor_feat, lane_feat, x, part, ST, QK,
-                         c->tokW[L + 1]);
+      hipLaunchKernelGGL(tok_small ? k_token<TOK_TPW_SMALL> : k_token<TOK_TPW_BIG>, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok,
+                         mode, actor_feat, lane_feat, x, part, ST, QK, c->tokW[L + 1]);
   }
   // ---- decoder
   const int *d_actor_row = (const int *)ts->rows.p;
@@ -1090,8 +1107,8 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
                        (const float *)nullptr, (const float *)nullptr, (float *)nullptr, (float *)nullptr, c->decW, (float *)c->dec_h2.p);
     HIPCHK(c, hipEventRecord(c->ev_side, c->side));
   }
-  hipLaunchKernelGGL(k_dec_scene, dim3(Bn), dim3(DT), mind_dec_scene_lds_bytes(), st, x, d_cls_row, (const float *)c->tgt_feat.p, in->tgt_rpe,
-                     (float *)c->cmode.p, (float *)c->tgt_emb.p, out->cls, c->decW);
+  hipLaunchKernelGGL(k_dec_scene, dim3(Bn), dim3(DT), mind_dec_scene_lds_bytes(), st, x, d_cls_row, (float *)c->cmode.p, out->cls, c->decW);
+  if (c->side) HIPCHK(c, hipStreamWaitEvent(st, c->ev_tgt, 0));      // the decoder's actor part reads the target embedding
   // actor part of the decoder: the K-split fp32 kernel (a handful of workgroups, bound by the latency of one pass over the weights:
   // 62 us at 40 agents), or -- opt-in, mind_set_tuning("dec_mfma_min") -- the MFMA kernel (16 agents per workgroup: 104 us at 40
   // agents, 209 vs 277 us at 13.8 k).  Off by default: a plan's result must not depend on what else is in the batch.

@@ -236,3 +236,21 @@ def test_token_kernel_on_the_fp32_mfma(a, l, B, seed, hip_predictor, formula_sd)
         assert np.abs(vel[b * a:(b + 1) * a] - ov[b].numpy()).max() < TOL
     assert (out["reg"] - ref["reg"]).abs().max().item() < 5e-5
     assert not torch.equal(out["reg"], ref["reg"])          # it really was the other kernel
+
+
+@pytest.mark.parametrize("a,l,B,seed", [(3, 4, 1, 1), (17, 30, 3, 4), (40, 55, 1, 1), (9, 21, 5, 2)])
+def test_token_kernel_tokens_per_workgroup_do_not_change_results(a, l, B, seed, hip_predictor):
+    """k_token has two instantiations -- eight tokens per workgroup for big batches, four for small ones (mind_set_tuning
+    "tok_small_max") -- with the same k split and summation order: a scene's result is the same bits whichever one its batch gets
+    (the property the sharded / fused paths rely on)."""
+    pb = predictor_batch(a, l, B, seed=seed)
+    try:
+        hip_predictor.set_tuning("tok_small_max", 0)          # everything on the eight-token kernel
+        big = hip_predictor.predict_numpy_batch(pb)
+        big = {k: v.clone() for k, v in big.items() if torch.is_tensor(v)}
+        hip_predictor.set_tuning("tok_small_max", 1 << 30)    # everything on the four-token kernel
+        small = hip_predictor.predict_numpy_batch(pb)
+    finally:
+        hip_predictor.set_tuning("tok_small_max", 2048)
+    for k in ("cls", "reg", "vel"):
+        assert torch.equal(big[k], small[k]), k
