@@ -70,6 +70,14 @@ struct IlqrTreeDev {
   GP<const int> seg_nodes;     // [M]
   GP<const int> slevel_start;  // [n_slevels+1] into slevel_segs (segments grouped by depth in the segment tree)
   GP<const int> slevel_segs;   // [n_segs]
+  // forward steps of the line search: a step = the segments of one segment level cut into chunks of at most `ilqr_chunk` nodes
+  // (host), so that the cost pass of step s - 1 runs on the idle waves while the state chains of step s advance
+  int n_fsteps, padf;
+  GP<const int> fstep_start;   // [n_fsteps+1] into fstep_q0 / fstep_q1
+  GP<const int> fstep_q0;      // per item: first position in seg_nodes ...
+  GP<const int> fstep_q1;      // ... and one past the last
+  GP<const int> fstep_nstart;  // [n_fsteps+1] into fstep_nodes
+  GP<const int> fstep_nodes;   // [M] nodes in step order
   GP<const float> prob;        // [M]
   GP<const float> mean;        // [M,a,2]
   GP<const float> cov;         // [M,a]
@@ -554,17 +562,17 @@ __device__ __forceinline__ void il_dyn_sc(const IlqrConst &C, const double *x, c
 // registers: the addresses are wave-uniform, every lane holds the full set.
 struct IlKv { double K[12], k[2], us[2], xs[6]; };
 
-// Phase 1: states/controls of ALL 10 line-search candidates along one chain segment, one wave, candidate
+// Phase 1: states/controls of ALL 10 line-search candidates along (a piece of) one chain segment -- positions [s0, s1) of
+// T.seg_nodes; the first node continues from its parent's candidate state in T.xs_new --, one wave, candidate
 // a = lane % 10 (lanes >= 10 mirror lanes < 10 and do not store).  init != 0: nominal rollout (alpha = 0,
 // gains are zero).  Writes T.xs_new / T.us_new.  Base pointers live in VGPRs (the tree struct's would be re-read from
 // spilled SGPRs in every node), the node index travels two nodes ahead, the node's operands one node ahead.
-__device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const IlqrTreeDev &T, int seg, int init IL_PROF_ARG) {
+__device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const IlqrTreeDev &T, int s0, int s1, int init IL_PROF_ARG) {
   const int lane = threadIdx.x & 63;
   const int M = T.M;
   const int a = lane % IL_NA;
   const bool writer = lane < IL_NA;
   const double alpha = init ? 0.0 : C.alphas[a];
-  const int s0 = T.seg_start[seg], s1 = T.seg_start[seg + 1];
   const int IL_AS1 *pSeg = T.seg_nodes.g();
   const double IL_AS1 *pK = T.K.g(), *pk = T.k.g(), *pUs = T.us.g(), *pXs = T.xs.g();
   double IL_AS1 *pXn = T.xs_new.g() + (size_t)a * M * 6, *pUn = T.us_new.g() + (size_t)a * M * 2;
@@ -683,10 +691,13 @@ __device__ __forceinline__ void il_window_axes(int xi, int yi, int W, int H, int
 // the records in ascending agent order (the oracle's summation order with provably-zero terms dropped).
 // A candidate outside the validity region of its node's list (or a node whose list overflowed) walks all
 // agents from global memory instead.
+// `nodes` / `cnt`: the nodes to evaluate (a forward step's list); `wave` = this wave's position in the chunk deal (the caller rotates
+// it so that the waves without a state chain this step come first).
 template <bool GEN>
-__device__ __forceinline__ void il_cost_pass(const IlqrConst &C, const IlqrTreeDev &T, int nuse, double *recs, int wave0, int nwaves IL_PROF_ARG) {
-  const int lane = threadIdx.x & 63, wave = wave0 + (threadIdx.x >> 6);
-  const int M = T.M, P = nuse * M;
+__device__ __forceinline__ void il_cost_pass(const IlqrConst &C, const IlqrTreeDev &T, int nuse, double *recs, int wave, int nwaves,
+                                             GP<const int> nodes, int cnt IL_PROF_ARG) {
+  const int lane = threadIdx.x & 63;
+  const int M = T.M, P = nuse * cnt;
   const int nchunk = (P + 5) / 6;
   const int a = lane % IL_NA, pl = lane / IL_NA;
   for (int ch = wave; ch < nchunk; ch += nwaves) {
@@ -694,7 +705,7 @@ __device__ __forceinline__ void il_cost_pass(const IlqrConst &C, const IlqrTreeD
     const int pi = ch * 6 + pl;
     const bool valid = lane < 60 && pi < P;
     const int pic = pi < P ? pi : P - 1;
-    const int slot = pic / M, c = pic % M;
+    const int slot = pic / cnt, c = nodes[pic % cnt];
     // issue every independent load first: the records of the chunk's 6 nodes, the candidate's state/control,
     // the node's probability / list length / nominal position
     double rr[6];
@@ -702,7 +713,7 @@ __device__ __forceinline__ void il_cost_pass(const IlqrConst &C, const IlqrTreeD
 #pragma unroll
       for (int p = 0; p < 6; ++p) {
         const int pp = ch * 6 + p < P ? ch * 6 + p : P - 1;
-        rr[p] = T.relag[(size_t)(pp % M) * IL_RA + lane];
+        rr[p] = T.relag[(size_t)nodes[pp % cnt] * IL_RA + lane];
       }
     }
     const size_t eo = (size_t)(slot * IL_NA + a) * M + c;
@@ -1196,7 +1207,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
   IL_SYNC();
   for (int d = 0; d < T.n_slevels; ++d) {
     for (int q = T.slevel_start[d] + gw; q < T.slevel_start[d + 1]; q += nw)
-      il_rollout_segment(C, T, T.slevel_segs[q], 1 IL_PROF_PASS);
+      { const int seg = T.slevel_segs[q]; il_rollout_segment(C, T, T.seg_start[seg], T.seg_start[seg + 1], 1 IL_PROF_PASS); }
     IL_SYNC();
   }
   long long t_der = 0, t_bw = 0, t_ls = 0, t_sel = 0, t_roll = 0, t_mark = clock64();
@@ -1300,20 +1311,29 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
     int nuse = nspec;
     for (int e = 1; e < nspec; ++e) if ((sh_sing >> e) & 1) { nuse = e; break; }
     // ---------------- line search: 10 alphas in lane groups, `nuse` mu slots in parallel waves ----------------
-    for (int d = 0; d < T.n_slevels; ++d) {
-      const int lo = T.slevel_start[d], hi = T.slevel_start[d + 1];
-      for (int w = gw; w < (hi - lo) * nuse; w += nw) {
-        const int slot = w / (hi - lo), seg = T.slevel_segs[lo + w % (hi - lo)];
-        IlqrTreeDev Ts = T;
-        Ts.k += (size_t)slot * M * 2; Ts.K += (size_t)slot * M * 12;
-        Ts.xs_new += (size_t)slot * IL_NA * M * 6; Ts.us_new += (size_t)slot * IL_NA * M * 2; Ts.L_new += (size_t)slot * IL_NA * M;
-        il_rollout_segment(C, Ts, seg, 0 IL_PROF_PASS);
+    // forward steps: the state chains of step s on the first waves, the costs of the nodes step s - 1 reached on the others (and on
+    // the chain waves once they are through); one more step for the costs of the last nodes
+    for (int s = 0; s <= T.n_fsteps; ++s) {
+      int R = 0;
+      if (s < T.n_fsteps) {
+        const int lo = T.fstep_start[s], ni = T.fstep_start[s + 1] - lo;
+        R = ni * nuse;
+        for (int w = gw; w < R; w += nw) {
+          const int slot = w / ni, it = lo + w % ni;
+          IlqrTreeDev Ts = T;
+          Ts.k += (size_t)slot * M * 2; Ts.K += (size_t)slot * M * 12;
+          Ts.xs_new += (size_t)slot * IL_NA * M * 6; Ts.us_new += (size_t)slot * IL_NA * M * 2; Ts.L_new += (size_t)slot * IL_NA * M;
+          il_rollout_segment(C, Ts, T.fstep_q0[it], T.fstep_q1[it], 0 IL_PROF_PASS);
+        }
+      } else {
+        IL_MARK(t_roll);
+      }
+      if (s > 0) {
+        const int n0 = T.fstep_nstart[s - 1], cnt = T.fstep_nstart[s] - n0;
+        il_cost_pass<GEN>(C, T, nuse, recs, (gw + nw - R % nw) % nw, nw, T.fstep_nodes + (size_t)n0, cnt IL_PROF_PASS);
       }
       IL_SYNC();
     }
-    IL_MARK(t_roll);
-    il_cost_pass<GEN>(C, T, nuse, recs, MULTI ? wg * IL_WAVES : 0, nw IL_PROF_PASS);
-    IL_SYNC();
     IL_MARK(t_ls);
     if (M * IL_NA * nuse <= IL_LSUM) {
       for (int q = tid; q < M * IL_NA * nuse; q += IL_THREADS) lsum[q] = T.L_new[q];

@@ -92,6 +92,10 @@ struct mind_ctx {
   long long tab_clock = 0;
   long long n_table_hits = 0;
   int actor_np = 6;             // partial products per term of the MFMA ActorNet under bf16x3: 6 (three-way split, fp32-class) or 3 (MIND_ACTOR_SPLIT=3)
+  // nodes per forward step of a narrow tree's line search ("ilqr_chunk"; 0: whole segments, the default).  Measured on the recorded
+  // demo_1 loop: chunks of 6 / 8 / 12 nodes cost 2.10 / 2.05 / 2.04 ms per launch against 1.99 for whole segments -- the cost waves
+  // share the SIMDs' float64 pipe with the state-chain waves and slow the chain down by more than the tail they hide
+  int ilqr_chunk = 0;
   int ilqr_wgs = 8, ilqr_multi_min = 192;   // wide cost trees: workgroups per tree, node count from which they are used (mind_set_tuning)
   int dec_mfma_min = 1 << 30;   // agents per call from which the decoder's actor part runs on the MFMA kernel (MIND_DEC_MFMA_MIN; default: never)
   bool enc_mfma = true;         // MFMA ActorNet under the bf16x3 / bf16 settings (MIND_ENC_MFMA=0: the fp32 VALU kernel, for A/B)
@@ -220,6 +224,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *te = getenv("MIND_TOK_SMALL_MAX")) c->tok_small_max = atoi(te);
   if (const char *te = getenv("MIND_TGT_SIDE")) c->tgt_side = !(te[0] == '0');
   (void)hipFuncSetAttribute((const void *)k_token_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_token_mfma_lds_bytes());
+  if (const char *we = getenv("MIND_ILQR_CHUNK")) c->ilqr_chunk = atoi(we) < 0 ? 0 : atoi(we);
   if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_tgt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
@@ -282,6 +287,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "tok_mfma") c->tok_mfma = value != 0;
   else if (n == "tok_small_max") c->tok_small_max = (int)value;
   else if (n == "tgt_side") c->tgt_side = value != 0;
+  else if (n == "ilqr_chunk") c->ilqr_chunk = value < 0 ? 0 : (int)value;
   else if (n == "ilqr_wgs") c->ilqr_wgs = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (n == "ilqr_multi_min") c->ilqr_multi_min = value;
   else if (n == "ilqr_test_starve") c->ilqr_test_starve = value != 0;   // tests: launch a wide tree without its last workgroups
@@ -1240,7 +1246,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   const size_t o_evx = takeD(ev ? (size_t)ev->nq * 6 : 0), o_evu = takeD(ev ? (size_t)ev->nq * 2 : 0);
   const size_t o_evn = takeI(ev ? ev->nq : 0);
   const size_t o_bars = takeI(4 * (size_t)n_trees + 4);   // barrier words of the multi-workgroup launch + its abort word (zero at upload)
-  struct TL { size_t nodew, field, relag; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel; int M, a, nl, nseg, nsl, maxls; };
+  struct TL { size_t nodew, field, relag; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel, fsstart, fsq0, fsq1, fsnstart, fsnodes; int M, a, nl, nseg, nsl, maxls, nfs; };
   std::vector<TL> tl(n_trees);
   long Mtot = 0;
   for (int t = 0; t < n_trees; ++t) tl[t].us = takeD(2 * (size_t)(trees[t].n_nodes > 0 ? trees[t].n_nodes : 0));
@@ -1269,6 +1275,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   // levels need the depth first
   std::vector<std::vector<int>> lvl_start(n_trees), lvl_nodes(n_trees), cst(n_trees), cls(n_trees);
   std::vector<std::vector<int>> sg_start(n_trees), sg_nodes(n_trees), sl_start(n_trees), sl_segs(n_trees);
+  std::vector<std::vector<int>> fs_start(n_trees), fs_q0(n_trees), fs_q1(n_trees), fs_nstart(n_trees), fs_nodes(n_trees);
   for (int t = 0; t < n_trees; ++t) {
     const mind_cost_tree &tr = trees[t];
     const int M = tr.n_nodes;
@@ -1325,6 +1332,27 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     tl[t].maxls = 1;
     for (int d = 0; d <= maxsd; ++d) tl[t].maxls = std::max(tl[t].maxls, sl_start[t][d + 1] - sl_start[t][d]);
     tl[t].sstart = takeI(nseg + 1); tl[t].snodes = takeI(M); tl[t].slstart = takeI(maxsd + 2); tl[t].slsegs = takeI(nseg);
+    // forward steps of the line search: the segments of a level, cut into chunks of ilqr_chunk nodes when only a few chains run
+    // side by side (the other waves then price the nodes the previous step reached); wide levels stay whole
+    const int chunk = (c->ilqr_chunk > 0 && tl[t].maxls <= 4) ? c->ilqr_chunk : M;
+    fs_start[t].assign(1, 0); fs_nstart[t].assign(1, 0);
+    fs_q0[t].clear(); fs_q1[t].clear(); fs_nodes[t].clear();
+    for (int d = 0; d <= maxsd; ++d) {
+      int maxlen = 0;
+      for (int e = sl_start[t][d]; e < sl_start[t][d + 1]; ++e) { const int sgi = sl_segs[t][e]; maxlen = std::max(maxlen, sg_start[t][sgi + 1] - sg_start[t][sgi]); }
+      for (int k0 = 0; k0 < maxlen; k0 += chunk) {
+        for (int e = sl_start[t][d]; e < sl_start[t][d + 1]; ++e) {
+          const int sgi = sl_segs[t][e], q0 = sg_start[t][sgi] + k0, q1 = std::min(sg_start[t][sgi + 1], q0 + chunk);
+          if (q0 >= q1) continue;
+          fs_q0[t].push_back(q0); fs_q1[t].push_back(q1);
+          for (int q = q0; q < q1; ++q) fs_nodes[t].push_back(sg_nodes[t][q]);
+        }
+        fs_start[t].push_back((int)fs_q0[t].size()); fs_nstart[t].push_back((int)fs_nodes[t].size());
+      }
+    }
+    tl[t].nfs = (int)fs_start[t].size() - 1;
+    tl[t].fsstart = takeI(fs_start[t].size()); tl[t].fsq0 = takeI(fs_q0[t].size()); tl[t].fsq1 = takeI(fs_q1[t].size());
+    tl[t].fsnstart = takeI(fs_nstart[t].size()); tl[t].fsnodes = takeI(M);
   }
   // arena: [uploaded doubles (nd_in) | floats | ints | tree structs | constants] = ONE host->device copy, then the doubles the
   // kernels produce (workspace + results), then (generic mode) the materialised fields
@@ -1376,6 +1404,11 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     memcpy(hI.data() + L.snodes, sg_nodes[t].data(), sg_nodes[t].size() * sizeof(int));
     memcpy(hI.data() + L.slstart, sl_start[t].data(), sl_start[t].size() * sizeof(int));
     memcpy(hI.data() + L.slsegs, sl_segs[t].data(), sl_segs[t].size() * sizeof(int));
+    memcpy(hI.data() + L.fsstart, fs_start[t].data(), fs_start[t].size() * sizeof(int));
+    memcpy(hI.data() + L.fsq0, fs_q0[t].data(), fs_q0[t].size() * sizeof(int));
+    memcpy(hI.data() + L.fsq1, fs_q1[t].data(), fs_q1[t].size() * sizeof(int));
+    memcpy(hI.data() + L.fsnstart, fs_nstart[t].data(), fs_nstart[t].size() * sizeof(int));
+    memcpy(hI.data() + L.fsnodes, fs_nodes[t].data(), fs_nodes[t].size() * sizeof(int));
     IlqrTreeDev &D = hT[t];
     D.M = L.M; D.n_agents = L.a; D.n_levels = L.nl; D.pad = 0;
     D.parent = dI + L.parent; D.level_start = dI + L.lstart; D.level_nodes = dI + L.lnodes;
@@ -1386,6 +1419,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     D.node_w = gen ? Dp(L.nodew) : nullptr;
     D.n_segs = L.nseg; D.n_slevels = L.nsl; D.max_level_segs = L.maxls; D.pad2 = 0;
     D.seg_start = dI + L.sstart; D.seg_nodes = dI + L.snodes; D.slevel_start = dI + L.slstart; D.slevel_segs = dI + L.slsegs;
+    D.n_fsteps = L.nfs; D.padf = 0;
+    D.fstep_start = dI + L.fsstart; D.fstep_q0 = dI + L.fsq0; D.fstep_q1 = dI + L.fsq1; D.fstep_nstart = dI + L.fsnstart; D.fstep_nodes = dI + L.fsnodes;
     D.prob = dF + L.prob; D.mean = dF + L.mean; D.cov = dF + L.cov;
     D.xs = Dp(L.xs); D.us = Dp(L.us); D.Fx = Dp(L.Fx); D.L = Dp(L.L); D.Lx = Dp(L.Lx); D.Lxx = Dp(L.Lxx);
     D.k = Dp(L.k); D.K = Dp(L.K); D.Vx = Dp(L.Vx); D.Vxx = Dp(L.Vxx);
