@@ -21,6 +21,13 @@
 #include <stdint.h>
 
 #define AM_T 1024
+#ifdef MIND_ACTOR_TRACE
+__device__ long long am_tr_[64];
+__device__ int am_trn_;
+#define AM_MARK() do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long n_ = clock64(); am_tr_[am_trn_ & 63] = n_; ++am_trn_; } } while (0)
+#else
+#define AM_MARK() do {} while (0)
+#endif
 #define AM_WAVES 16
 #define AM_MAXT 2                           // output tiles per wave (24 tiles of the 128 x 48 layers / 16 waves)
 #define AM_RSD(C) (3 * (C) / 2 + 4)         // row length of a split image in dwords
@@ -80,6 +87,10 @@ __device__ __forceinline__ f32x4 am_load_split(const u32 *rowp, int plane) {
 // NP = number of partial products per term: 6 = both operands split three ways (hi.hi + hi.mid + mid.hi + mid.mid + hi.lo +
 // lo.hi: ~2^-24 relative, fp32-class), 3 = two-way split (hi.hi + hi.mid + mid.hi: ~2^-16), 1 = plain bf16 operands.  The
 // leading products and the corrections run in two accumulators (two independent MFMA chains), summed at the end.
+// Measured (tools/gpu_actor_trace.sh, profiles/r03ad): the convolutions are bound by this weight-fragment stream -- 3 KB per tile and
+// k-step (hi / mid / lo), 9.1 MB per actor through ONE CU's 64 B/clk L2 port = 59 us of the kernel's 140, the GroupNorm stages
+// (two block reductions + three barriers each, 26 of them) are another 55 us.  Requesting the fragments four k-steps ahead in a
+// register ring changed nothing (144 vs 142 us): it is the port's bandwidth, not the round trips.
 template <int NP, int LGC /*log2 Cin_pad*/, int KSZ, int STRIDE>
 __device__ __forceinline__ void am_conv(const u32 *in, int Tin, const u32 *__restrict__ Wf, int Cout, int Tout,
                                         f32x4 (&acc)[AM_MAXT]) {
@@ -211,15 +222,21 @@ __device__ __forceinline__ void am_res(const u32 *in, int Tin, const AmRes &W, u
   const int Tout = Tin / STRIDE;
   f32x4 acc[AM_MAXT];
   am_conv<NP, LGCI, 3, STRIDE>(in, Tin, W.c1, Cout, Tout, acc);
+  AM_MARK();
   am_gn<NP>(acc, Cout, Tout, W.g1, W.b1, nullptr, nullptr, true, t1, nullptr, nullptr, red);
+  AM_MARK();
   const u32 *resid = in;
   if (DS) {
     am_conv<NP, LGCI, 1, STRIDE>(in, Tin, W.ds, Cout, Tout, acc);
+    AM_MARK();
     am_gn<NP>(acc, Cout, Tout, W.gd, W.bd, nullptr, nullptr, false, t2, nullptr, nullptr, red);
+    AM_MARK();
     resid = t2;
   }
   am_conv<NP, LGCO, 3, 1>(t1, Tout, W.c2, Cout, Tout, acc);
+  AM_MARK();
   am_gn<NP>(acc, Cout, Tout, W.g2, W.b2, resid, nullptr, true, out, nullptr, nullptr, red);
+  AM_MARK();
 }
 
 // FPN level (network.py:55-58): lateral conv + GroupNorm of `src` ([T] x AM_RSD(C)) plus the upsampled level above (`up`, fp32
@@ -229,7 +246,9 @@ __device__ __forceinline__ void am_lateral(const u32 *src, int T, const AmLat &W
                                            float *red) {
   f32x4 acc[AM_MAXT];
   am_conv<NP, LGC, 3, 1>(src, T, W.w, 128, T, acc);
+  AM_MARK();
   am_gn<NP>(acc, 128, T, W.g, W.b, nullptr, up, false, dsts, dstf, nullptr, red);
+  AM_MARK();
 }
 
 template <int NP>
@@ -256,6 +275,10 @@ __global__ __launch_bounds__(AM_T) void k_actor_mfma(const float *__restrict__ a
     p[0] = h; p[8] = m; p[16] = pk_bf16(r0 - bf_lo_f32(m), r1 - bf_hi_f32(m));
   }
   __syncthreads();
+#ifdef MIND_ACTOR_TRACE
+  if (blockIdx.x == 0 && tid == 0) am_trn_ = 0;
+#endif
+  AM_MARK();
   am_res<NP, 4, 5, 1, true>(xin, 48, W.res[0], ta, tb, tc, red);
   am_res<NP, 5, 5, 1, false>(ta, 48, W.res[1], o0, tb, tc, red);
   am_res<NP, 5, 6, 2, true>(o0, 48, W.res[2], ta, tb, tc, red);
@@ -274,9 +297,20 @@ __global__ __launch_bounds__(AM_T) void k_actor_mfma(const float *__restrict__ a
     const AmRes &R = W.res[8];
     f32x4 acc[AM_MAXT];
     am_conv<NP, 7, 3, 1>(fa, 48, R.c1, 128, 48, acc);
+    AM_MARK();
     am_gn<NP>(acc, 128, 48, R.g1, R.b1, nullptr, nullptr, true, o0, nullptr, nullptr, red);
+    AM_MARK();
     am_conv<NP, 7, 3, 1>(o0, 48, R.c2, 128, 48, acc);
+    AM_MARK();
     am_gn<NP>(acc, 128, 48, R.g2, R.b2, fa, nullptr, true, nullptr, nullptr, out + (size_t)a * 128, red);
+    AM_MARK();
   }
+#ifdef MIND_ACTOR_TRACE
+  if (blockIdx.x == 0 && tid == 0) {
+    printf("[k_actor_mfma<%d>] cycles conv/gn per stage:", NP);
+    for (int q = 1; q < am_trn_ && q < 64; ++q) printf(" %lld", am_tr_[q] - am_tr_[q - 1]);
+    printf("\n");
+  }
+#endif
 }
 extern "C" size_t mind_actor_mfma_lds_bytes() { return (size_t)AM_LDS_DWORDS * sizeof(u32); }
