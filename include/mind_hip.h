@@ -90,6 +90,14 @@ int mind_last_ilqr_stats(mind_ctx *ctx, float *kernel_ms, int *n_trees, int *wor
  * out9 = { nodes M, serial depth (levels), passes of the iteration loop, cycles of the derivative pass, the backward (Riccati) sweep,
  * the line search's state chain, its cost pass, the selection, cost trees in the launch }. */
 int mind_last_ilqr_profile(mind_ctx *ctx, double *out9);
+/* Per-iteration trace of one fit of the last mind_ilqr_* call on this context (iLQR.fit's loop, planners/ilqr/solver.py:133-158): row k
+ * = reference iteration k = { mu the backward pass ran with, J of the nominal trajectory (the reference's J_opt when the line search
+ * starts), index of the accepted step size among the ten candidates (-1: every candidate rejected, mu raised; -2: Q_uu singular, the
+ * iteration is retried), J of the accepted candidate (J of the nominal trajectory otherwise) }.  tree: index in the call's tree array;
+ * phase: 0, or 1 for the full fit of mind_ilqr_contingency.  Writes min(rows, cap_rows) rows of 4 doubles to out and the number of
+ * iterations to *n_rows.  MIND_ESTATE when the last call holds no such fit.  Parity diagnostics: the tests compare this trace with the
+ * reference's own, iteration by iteration. */
+int mind_last_ilqr_trace(mind_ctx *ctx, int tree, int phase, double *out, int cap_rows, int *n_rows);
 /* enable/disable event timing (off by default: events add a little latency) */
 int mind_set_profiling(mind_ctx *ctx, int enable);
 

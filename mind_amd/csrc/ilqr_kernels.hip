@@ -93,6 +93,10 @@ struct IlqrTreeDev {
   GP<const double> node_w;     // [M, IL_NW]: w_des[6] w_con[6] lb[6] ub[6] w_ctrl[2] des[6], or null
   // outputs
   GP<double> stats;            // [IL_NSTAT]: iterations, converged, J, mu, phase cycles, profile slots
+  // per-iteration trace of the fit (mind_last_ilqr_trace): IL_TRACE_W doubles per reference iteration {mu the backward pass ran with,
+  // J of the nominal trajectory, accepted alpha index (-1: step rejected, -2: singular Q_uu), J of the accepted candidate}
+  GP<double> trace;            // [phases 2][trace_cap][IL_TRACE_W], or null
+  int trace_cap, padt;
 };
 
 struct IlqrConst {
@@ -121,6 +125,7 @@ struct IlqrConst {
 #else
 #define IL_WFENCE() asm volatile("" ::: "memory")
 #endif
+#define IL_TRACE_W 4
 #define IL_NSTAT 25   // doubles per tree in T.stats: 4 results + 4 phase cycle counters + 16 profile slots + passes
 
 // fine-grained cycle attribution (diagnostic build only: -DIL_PROFILE); slots: 0-1 chain-rollout node (stage,
@@ -1166,7 +1171,7 @@ __device__ __forceinline__ void il_reject_update(double &mu, double &delta) {
 // over the G workgroups (il_tree_sync), the control variables (mu, delta, J, accepted slot ...) are recomputed identically by
 // every workgroup from the same global data.  Same arithmetic per item, same results.
 template <bool GEN, bool MULTI>
-__device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C, double *stats, int wg, int G, unsigned *bar, unsigned *abort_word) {
+__device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C, double *stats, double *trace, int wg, int G, unsigned *bar, unsigned *abort_word) {
   extern __shared__ double il_dsm[];
   // LDS carve: per-wave scratch [IL_WAVES][IL_SCR] | cost sums [IL_LSUM] | compact records [IL_RECS] | staging [IL_DSTG] floats
   double *scr = il_dsm + (size_t)(threadIdx.x >> 6) * IL_SCR;
@@ -1300,7 +1305,13 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       __syncthreads();
     }
     if (sh_sing & 1) {   // LinAlgError at the current mu: retry without raising mu (Q9) -- burns one iteration
-      if (tid == 0) sh_it += 1;
+      if (tid == 0) {
+        if (trace && sh_it < T.trace_cap && (!MULTI || wg == 0)) {
+          double *tr = trace + (size_t)sh_it * IL_TRACE_W;
+          tr[0] = sh_mu; tr[1] = sh_J; tr[2] = -2.0; tr[3] = sh_J;
+        }
+        sh_it += 1;
+      }
       __syncthreads();
       // wide trees: every workgroup must have read this pass's singular word before workgroup 0 clears it again (it is the word of
       // the pass after next, cleared at the top of the NEXT pass -- and this path has no other barrier in between)
@@ -1355,6 +1366,10 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
         int pick = -1;
         for (int a = 0; a < IL_NA; ++a)
           if (Jnew[slot][a] < sh_J) { pick = a; break; }
+        if (trace && it < T.trace_cap && (!MULTI || wg == 0)) {
+          double *tr = trace + (size_t)it * IL_TRACE_W;
+          tr[0] = mu; tr[1] = sh_J; tr[2] = (double)pick; tr[3] = pick >= 0 ? Jnew[slot][pick] : sh_J;
+        }
         it += 1;
         if (pick >= 0) {
           sh_pick = pick; sh_slot = slot;
@@ -1418,7 +1433,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
   }
   const IlqrTreeDev T = trees[t];
   for (int ph = 0; ph < n_phases; ++ph)
-    il_fit<GEN, MULTI>(T, consts[ph], (T.stats + (size_t)ph * IL_NSTAT).p, wg, G, MULTI ? bars + 4 * t : nullptr, MULTI ? bars + 4 * n_trees : nullptr);
+    il_fit<GEN, MULTI>(T, consts[ph], (T.stats + (size_t)ph * IL_NSTAT).p, T.trace ? (T.trace + (size_t)ph * T.trace_cap * IL_TRACE_W).p : nullptr, wg, G, MULTI ? bars + 4 * t : nullptr, MULTI ? bars + 4 * n_trees : nullptr);
 }
 
 static inline size_t il_lds_bytes(int /*amax*/) {

@@ -126,6 +126,10 @@ struct mind_ctx {
   float ilqr_ms = 0.f;
   int ilqr_multi = 0, ilqr_trees = 0;
   bool ilqr_test_starve = false;
+  // per-iteration traces of the last tree-iLQR call (mind_last_ilqr_trace): device address per tree, rows per phase, iterations run
+  std::vector<const double *> il_trace_dev;
+  std::vector<int> il_trace_its;      // [tree][phase 2]
+  int il_trace_cap = 0, il_trace_phases = 0;
   double il_prof[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // critical tree of the last launch: M, depth, passes, cycles of the five phases, trees
   long long n_ilqr_fallbacks = 0;   // wide-tree launches that were not fully resident and were re-run on one workgroup per tree
   int n_pair_launch = 0;
@@ -324,6 +328,22 @@ extern "C" int mind_last_ilqr_stats(mind_ctx *c, float *kernel_ms, int *n_trees,
   if (kernel_ms) *kernel_ms = c->ilqr_ms;
   if (n_trees) *n_trees = c->ilqr_trees;
   if (workgroups_per_tree) *workgroups_per_tree = c->ilqr_multi;
+  return MIND_OK;
+}
+
+extern "C" int mind_last_ilqr_trace(mind_ctx *c, int tree, int phase, double *out, int cap_rows, int *n_rows) {
+  if (!c || !n_rows || (cap_rows > 0 && !out)) return MIND_EINVAL;
+  if (tree < 0 || tree >= (int)c->il_trace_dev.size() || phase < 0 || phase >= c->il_trace_phases || !c->il_trace_dev[tree])
+    return fail(c, MIND_ESTATE, "mind_last_ilqr_trace: no trace for tree %d phase %d (the last tree-iLQR call had %d trees, %d phases)", tree, phase,
+                (int)c->il_trace_dev.size(), c->il_trace_phases);
+  const int rows = std::min(c->il_trace_its[2 * tree + phase], c->il_trace_cap);
+  *n_rows = rows;
+  const int take = std::min(rows, cap_rows);
+  if (take > 0) {
+    HIPCHK(c, hipMemcpyAsync(out, c->il_trace_dev[tree] + (size_t)phase * c->il_trace_cap * IL_TRACE_W, (size_t)take * IL_TRACE_W * sizeof(double),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   return MIND_OK;
 }
 
@@ -1246,7 +1266,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   const size_t o_evx = takeD(ev ? (size_t)ev->nq * 6 : 0), o_evu = takeD(ev ? (size_t)ev->nq * 2 : 0);
   const size_t o_evn = takeI(ev ? ev->nq : 0);
   const size_t o_bars = takeI(4 * (size_t)n_trees + 4);   // barrier words of the multi-workgroup launch + its abort word (zero at upload)
-  struct TL { size_t nodew, field, relag; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel, fsstart, fsq0, fsq1, fsnstart, fsnodes; int M, a, nl, nseg, nsl, maxls, nfs; };
+  const int trace_cap = std::min(256, std::max(cfg->max_iter, cfg2 ? cfg2->max_iter : 0));      // rows of the per-iteration trace, per phase
+  struct TL { size_t nodew, field, relag; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel, fsstart, fsq0, fsq1, fsnstart, fsnodes, trace; int M, a, nl, nseg, nsl, maxls, nfs; };
   std::vector<TL> tl(n_trees);
   long Mtot = 0;
   for (int t = 0; t < n_trees; ++t) tl[t].us = takeD(2 * (size_t)(trees[t].n_nodes > 0 ? trees[t].n_nodes : 0));
@@ -1265,6 +1286,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     TL &L = tl[t];
     L.M = (int)M; L.a = gen ? 1 : tr.n_agents;
     L.relag = takeD(use_exo ? M * IL_RA : 0);
+    L.trace = takeD((size_t)2 * trace_cap * IL_TRACE_W);
     L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M);
     L.Lxx = takeD(36 * M); L.k = takeD(IL_SPEC * 2 * M); L.K = takeD(IL_SPEC * 12 * M); L.Vx = takeD(IL_SPEC * 6 * M); L.Vxx = takeD(IL_SPEC * 36 * M);
     L.xsn = takeD(IL_SPEC * 60 * M); L.usn = takeD(IL_SPEC * 20 * M); L.Ln = takeD(IL_SPEC * 10 * M);
@@ -1420,6 +1442,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     D.n_segs = L.nseg; D.n_slevels = L.nsl; D.max_level_segs = L.maxls; D.pad2 = 0;
     D.seg_start = dI + L.sstart; D.seg_nodes = dI + L.snodes; D.slevel_start = dI + L.slstart; D.slevel_segs = dI + L.slsegs;
     D.n_fsteps = L.nfs; D.padf = 0;
+    D.trace = trace_cap > 0 ? Dp(L.trace) : nullptr; D.trace_cap = trace_cap; D.padt = 0;
     D.fstep_start = dI + L.fsstart; D.fstep_q0 = dI + L.fsq0; D.fstep_q1 = dI + L.fsq1; D.fstep_nstart = dI + L.fsnstart; D.fstep_nodes = dI + L.fsnodes;
     D.prob = dF + L.prob; D.mean = dF + L.mean; D.cov = dF + L.cov;
     D.xs = Dp(L.xs); D.us = Dp(L.us); D.Fx = Dp(L.Fx); D.L = Dp(L.L); D.Lx = Dp(L.Lx); D.Lxx = Dp(L.Lxx);
@@ -1553,6 +1576,13 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   memcpy(xs, hx, (size_t)Mtot * 6 * sizeof(double));
   memcpy(us, hus, n_us * sizeof(double));
   memcpy(hs.data(), hx + n_xs, hs.size() * sizeof(double));
+  c->il_trace_dev.assign(n_trees, nullptr);
+  c->il_trace_its.assign((size_t)2 * n_trees, 0);
+  c->il_trace_cap = trace_cap; c->il_trace_phases = n_phases;
+  for (int t = 0; t < n_trees; ++t) {
+    c->il_trace_dev[t] = trace_cap > 0 ? Dp(tl[t].trace) : nullptr;
+    for (int ph = 0; ph < n_phases; ++ph) c->il_trace_its[2 * t + ph] = (int)hs[(size_t)2 * IL_NSTAT * t + (size_t)ph * IL_NSTAT];
+  }
   {
     // phase cycles of the launch's critical tree (the one with the most cycles over all its fits): what bounds the launch
     double best = -1.0;

@@ -159,6 +159,15 @@ class HipPredictor:
         keys = ("nodes", "depth", "passes", "derivatives", "backward", "state_chain", "cost_pass", "selection", "trees")
         return dict(zip(keys, [float(x) for x in v]))
 
+    def ilqr_trace(self, tree, phase=0):
+        """[iterations, 4] float64 per-iteration trace of one fit of the last tree-iLQR call (mind_last_ilqr_trace): mu, J of the nominal
+        trajectory, accepted step index (-1 rejected, -2 singular Q_uu), J of the accepted candidate"""
+        n = C.c_int()
+        buf = np.zeros((256, 4), np.float64)
+        _lib.check(self.lib, self.ctx, self.lib.mind_last_ilqr_trace(self.ctx, int(tree), int(phase), buf.ctypes.data_as(C.POINTER(C.c_double)), 256,
+                                                                    C.byref(n)), "mind_last_ilqr_trace")
+        return buf[:min(n.value, 256)].copy()
+
     def fusion_stats(self):
         n = C.c_int()
         ms = C.c_float()

@@ -104,6 +104,10 @@ def solve(cfg, flat, x0, lane, target_vel, use_exo, us_init=None, trace=False):
     out = dict(xs=xs, us=us, iterations=st.iterations, converged=st.converged, J=st.J, mu=st.mu)
     if trace:
         out["J_trace"] = jt
+        # per-iteration rows {mu, J_opt, accepted alpha index (-1 rejected, -2 LinAlgError), J of the accepted candidate}
+        tb = np.zeros((256, 4))
+        n = lib().oracle_ilqr_last_trace(dp(tb), C.c_int(256))
+        out["trace"] = tb[:min(n, 256)].copy()
     return out
 
 

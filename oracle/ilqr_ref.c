@@ -457,6 +457,17 @@ static void build_fields(solver_t *S, const mind_cost_tree *t, const double *qua
   }
 }
 
+/* per-iteration trace of the last oracle_ilqr_solve (same rows as mind_last_ilqr_trace, include/mind_hip.h): mu of the backward pass,
+ * J_opt when the line search starts, accepted alpha index (-1 rejected, -2 LinAlgError), J of the accepted candidate */
+#define ORACLE_TRACE_CAP 256
+static double oracle_trace[ORACLE_TRACE_CAP][4];
+static int oracle_trace_rows;
+int oracle_ilqr_last_trace(double *out, int cap_rows) {
+  const int n = oracle_trace_rows < cap_rows ? oracle_trace_rows : cap_rows;
+  if (n > 0) memcpy(out, oracle_trace, (size_t)n * 4 * sizeof(double));
+  return oracle_trace_rows;
+}
+
 int oracle_ilqr_solve(const mind_ilqr_cfg *cfg, const mind_cost_tree *t, const double *x0, const double *lane,
                       int P, double target_vel, int use_exo, const double *us_init, double *xs, double *us,
                       mind_ilqr_stats *st, double *J_trace /* [max_iter] or NULL */) {
@@ -493,13 +504,17 @@ int oracle_ilqr_solve(const mind_ilqr_cfg *cfg, const mind_cost_tree *t, const d
   double alphas[10];
   for (int j = 0; j < 10; j++) alphas[j] = pow(1.1, -(double)(j * j));
   int accepted = 1, converged = 0, it;
+  oracle_trace_rows = 0;
   for (it = 0; it < cfg->max_iter; it++) {
     if (accepted) { forward_rollout(&S, &w); accepted = 0; }
     if (J_trace) J_trace[it] = w.J_opt;
-    if (backward_pass(&S, &w)) continue; /* LinAlgError: continue without raising mu (Q9) */
+    double *tr = it < ORACLE_TRACE_CAP ? oracle_trace[it] : NULL;
+    if (tr) { tr[0] = S.mu; tr[1] = w.J_opt; tr[2] = -1.0; tr[3] = w.J_opt; oracle_trace_rows = it + 1; }
+    if (backward_pass(&S, &w)) { if (tr) tr[2] = -2.0; continue; } /* LinAlgError: continue without raising mu (Q9) */
     for (int j = 0; j < 10; j++) {
       const double Jn = line_search(&S, &w, alphas[j]);
       if (Jn < w.J_opt) {
+        if (tr) { tr[2] = (double)j; tr[3] = Jn; }
         if (fabs((w.J_opt - Jn) / w.J_opt) < 1e-6) converged = 1;
         accepted = 1;
         memcpy(w.xs, w.xs_new, M * NS * sizeof(double));

@@ -2,7 +2,7 @@
 
 The reference Python cannot travel to the GPU box; these small fixtures (inputs are formula
 generated, so only expected outputs are stored) can.  Re-run:  python tests/golden/gen_golden.py [section ...]
-Sections: predictor rpe potential ilqr aime plan scenes demo_plans demo_branch demo_runs
+Sections: predictor rpe potential ilqr aime plan scenes demo_plans demo_branch demo_runs demo_branch_runs demo_traces demo_branch_traces
 """
 import os
 import sys
@@ -482,7 +482,140 @@ def gen_demo_runs(n_plans=60):
     np.savez_compressed(os.path.join(GOLD, "demo_runs.npz"), **out)
 
 
-SECTIONS = {"demo_runs": gen_demo_runs, "demo_plans": gen_demo_plans, "demo_branch": gen_demo_branch, "demo_branch_runs": gen_demo_branch_runs, "scenes": gen_scenes, "predictor": gen_predictor, "ilqr": gen_ilqr, "potential": gen_potential, "aime": gen_aime, "plan": gen_plan}
+def gen_demo_traces(n_plans=60, variant=None, fname="demo_traces.npz"):
+    """G13: per-iteration traces of the reference's tree-iLQR over its whole closed loop on the four recorded scenes (the runs of
+    demo_runs / demo_branch_runs): for every planning cycle, every candidate scenario tree and both fits (warm start, full) the
+    rows {mu the backward pass ran with, J_opt when the line search starts, line-search outcome (1 accepted, -1 rejected, -2
+    LinAlgError)} of iLQR.fit's loop (planners/ilqr/solver.py:133-158), recorded by wrapping _backward_pass /
+    _backtrack_line_search.  Each candidate is then solved twice more from inputs moved by their rounding resolution (the ego state
+    by a relative 1e-13; the predicted means by +-1 float32 ulp): `split` = the first iteration at which one of those runs leaves
+    the unperturbed trace (another line-search outcome or mu, or J off by more than 1e-4 relative) = how far the reference itself is reproducible on
+    that cost tree.  The GPU tests compare this planner's own traces (mind_last_ilqr_trace) with these, iteration by iteration."""
+    import copy
+    import importlib
+    import json
+    import tempfile
+    import types
+    from mind_amd.scene_io import DEMO_SCENES
+    rh.install()
+    os.chdir(rh.REF_ROOT)
+    vis = types.ModuleType("common.visualization")
+    for fn in ("draw_map", "draw_agent", "draw_scen_trees", "reset_ax", "draw_traj_trees", "draw_traj"):
+        setattr(vis, fn, None)
+    sys.modules["common.visualization"] = vis
+    Simulator = importlib.import_module("simulator").Simulator
+    tmp = tempfile.mkdtemp()
+    ck = os.path.join(tmp, "formula.tar")
+    torch.save({"state_dict": formula_state_dict(as_torch=True, variant=variant)}, ck)
+    sol = importlib.import_module("planners.ilqr.solver")
+    plm = importlib.import_module("planners.mind.planner")
+    agent_mod = importlib.import_module("agent")
+    iLQR = sol.iLQR
+    o_bp, o_ls, o_fit, o_gtt, o_plan = iLQR._backward_pass, iLQR._backtrack_line_search, iLQR.fit, plm.MINDPlanner.get_traj_tree, agent_mod.MINDAgent.plan
+    cur = {"fits": None}
+
+    def bp(self):
+        if cur["fits"] is not None:
+            cur["fits"][-1].append([float(self._mu), float(self.J_opt), -2.0])      # stays -2 when the pass raises LinAlgError
+        return o_bp(self)
+
+    def ls(self, alphas):
+        acc, conv = o_ls(self, alphas)
+        if cur["fits"] is not None:
+            cur["fits"][-1][-1][2] = 1.0 if acc else -1.0
+        return acc, conv
+
+    def fit(self, *a, **k):
+        if cur["fits"] is not None:
+            cur["fits"].append([])
+        return o_fit(self, *a, **k)
+
+    def first_split(base, other):
+        for i in range(max(len(base), len(other))):
+            if i >= len(base) or i >= len(other):
+                return i
+            b, o = base[i], other[i]
+            if b[2] != o[2] or abs(b[1] - o[1]) > 1e-4 * abs(b[1]) or abs(b[0] - o[0]) > 1e-9 * abs(b[0]):
+                return i
+        return max(len(base), len(other))
+
+    plans = []
+
+    def get_traj_tree(self, scen_tree, lcl_smp):
+        cur["fits"] = base = []
+        res = o_gtt(self, scen_tree, lcl_smp)
+        split = [len(base[0]), len(base[1])]
+        state0 = self.state
+        for seed in range(2):
+            rng = np.random.default_rng(seed)
+            st2 = scen_tree
+            if seed == 0:
+                self.state = np.asarray(state0, np.float64) * (1.0 + 1e-13 * rng.standard_normal(np.shape(state0)))
+            else:
+                st2 = copy.deepcopy(scen_tree)
+                for k in st2.nodes:
+                    d = st2.nodes[k].data
+                    m = np.asarray(d[1])
+                    up = rng.random(m.shape) < 0.5
+                    d[1] = np.where(up, np.nextafter(m, np.asarray(np.inf, m.dtype)), np.nextafter(m, np.asarray(-np.inf, m.dtype))).astype(m.dtype)
+            cur["fits"] = pert = []
+            o_gtt(self, st2, lcl_smp)
+            self.state = state0
+            for ph in range(2):
+                split[ph] = min(split[ph], first_split(base[ph], pert[ph]))
+        cur["fits"] = None
+        plans[-1].append((base, split))
+        return res
+
+    def plan(self):
+        plans.append([])
+        return o_plan(self)
+
+    iLQR._backward_pass, iLQR._backtrack_line_search, iLQR.fit = bp, ls, fit
+    plm.MINDPlanner.get_traj_tree = get_traj_tree
+    agent_mod.MINDAgent.plan = plan
+    out = {}
+    try:
+        for name in DEMO_SCENES:
+            cfg = json.load(open(os.path.join(rh.REF_ROOT, "configs", name + ".json")))
+            pcfg = json.load(open(os.path.join(rh.REF_ROOT, cfg["cl_agents"][0]["planner_config"])))
+            pcfg.update(use_cuda=False, ckpt_path=ck)
+            pp = os.path.join(tmp, name + "_planner.json")
+            json.dump(pcfg, open(pp, "w"))
+            cfg["cl_agents"][0]["planner_config"] = pp
+            cfg.update(render=False, output_dir=tmp)
+            cp = os.path.join(tmp, name + ".json")
+            json.dump(cfg, open(cp, "w"))
+            del plans[:]
+            sim = Simulator(cp)
+            sim.init_sim()
+            sim.sim_horizon = 201 + 5 * (n_plans - 1)
+            sim.run_sim()
+            assert len(plans) == n_plans, len(plans)
+            rows, index, split = [], [], []
+            for pi, trees in enumerate(plans):
+                for ti, (fits, sp) in enumerate(trees):
+                    for ph in range(2):
+                        index.append((pi, ti, ph, len(rows), len(fits[ph])))
+                        split.append(sp[ph])
+                        rows.extend(fits[ph])
+            out[name + "_trace_rows"] = np.array(rows, np.float64).reshape(-1, 3)
+            out[name + "_trace_index"] = np.array(index, np.int32)
+            out[name + "_trace_split"] = np.array(split, np.int32)
+            nsp = sum(1 for (i, s_) in zip(index, split) if s_ < i[4])
+            print(name, "fits", len(index), "iterations", len(rows), "fits that split under rounding noise", nsp)
+    finally:
+        iLQR._backward_pass, iLQR._backtrack_line_search, iLQR.fit = o_bp, o_ls, o_fit
+        plm.MINDPlanner.get_traj_tree = o_gtt
+        agent_mod.MINDAgent.plan = o_plan
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
+
+
+def gen_demo_branch_traces(n_plans=60):
+    gen_demo_traces(n_plans, variant="branching", fname="demo_branch_traces.npz")
+
+
+SECTIONS = {"demo_traces": gen_demo_traces, "demo_branch_traces": gen_demo_branch_traces, "demo_runs": gen_demo_runs, "demo_plans": gen_demo_plans, "demo_branch": gen_demo_branch, "demo_branch_runs": gen_demo_branch_runs, "scenes": gen_scenes, "predictor": gen_predictor, "ilqr": gen_ilqr, "potential": gen_potential, "aime": gen_aime, "plan": gen_plan}
 
 if __name__ == "__main__":
     torch.manual_seed(0)

@@ -245,3 +245,52 @@ def test_full_size_tree_properties(hip_predictor):
                     prev[:, 2] + prev[:, 4] * dt, prev[:, 3] + prev[:, 2] / wb * np.tan(prev[:, 5]) * dt,
                     prev[:, 4] + u[:, 0] * dt, prev[:, 5] + u[:, 1] * dt], axis=1)
     assert np.abs(nxt - xs[0]).max() < 1e-9
+
+
+@pytest.mark.parametrize("kind,a,max_iter", [("lead", 4, 100), ("branch3", 40, 100), ("deep", 3, 4), ("branch3", 128, 30)])
+def test_iteration_trace_equals_the_oracles(kind, a, max_iter, hip_predictor):
+    """mind_last_ilqr_trace: per reference iteration the Levenberg-Marquardt value, the cost of the nominal trajectory, the accepted
+    step index (-1 rejected, -2 singular) and the accepted candidate's cost -- the rows of the C oracle's loop
+    (oracle/ilqr_ref.c, after planners/ilqr/solver.py:133-158), for both fits of mind_ilqr_contingency and for a plain solve, on
+    one and on several workgroups."""
+    sst = scripted_scenario_tree(kind, a)
+    cfg_w, cfg_f = oi.default_cfg(max_iter=max_iter), oi.default_cfg(max_iter=max_iter)
+    cfg_w.w_ego = cfg_w.w_exo = 0.0
+    flat = oi.flatten(sst["nodes"])
+    flat2 = oi.flatten(scripted_scenario_tree("straight", a, seed=2)["nodes"])
+    x0 = oi.init_state(sst["state"], sst["ctrl"])
+    refs = []
+    for f in (flat, flat2):
+        w = oi.solve(cfg_w, f, x0, sst["target_lane"], sst["target_vel"], 0, trace=True)
+        full = oi.solve(cfg_f, f, x0, sst["target_lane"], sst["target_vel"], 1, us_init=w["us"], trace=True)
+        refs.append((w, full))
+        assert len(w["trace"]) == w["iterations"] and np.array_equal(w["trace"][:, 1], w["J_trace"][:w["iterations"]])
+
+    def same(got, ref, what):
+        # the decisions exactly (Levenberg-Marquardt value, accepted step index), the costs to the last bits (the kernel's node costs
+        # may differ from the oracle's in the last ulp: another FMA contraction, never another decision)
+        assert got.shape == ref.shape, (what, got.shape, ref.shape)
+        assert np.array_equal(got[:, [0, 2]], ref[:, [0, 2]]), (what, got[:, [0, 2]], ref[:, [0, 2]])
+        assert np.allclose(got[:, [1, 3]], ref[:, [1, 3]], rtol=1e-13, atol=0.0), (what, np.abs(got[:, [1, 3]] / ref[:, [1, 3]] - 1).max())
+
+    def check():
+        hip_predictor.ilqr_contingency(cfg_w, cfg_f, [flat, flat2], x0, sst["target_lane"], sst["target_vel"])
+        for t in range(2):
+            for ph in range(2):
+                got, ref = hip_predictor.ilqr_trace(t, ph), refs[t][ph]["trace"]
+                same(got, ref, (t, ph))
+        hip_predictor.ilqr_solve(cfg_f, [flat2], x0, sst["target_lane"], sst["target_vel"], 1, us_init=[refs[1][0]["us"]])
+        same(hip_predictor.ilqr_trace(0, 0), refs[1][1]["trace"], "plain solve")
+        with pytest.raises(Exception):
+            hip_predictor.ilqr_trace(0, 1)                  # a plain solve has one fit
+        with pytest.raises(Exception):
+            hip_predictor.ilqr_trace(1, 0)
+
+    check()
+    try:
+        hip_predictor.set_tuning("ilqr_multi_min", 8)
+        hip_predictor.set_tuning("ilqr_wgs", 4)
+        check()
+    finally:
+        hip_predictor.set_tuning("ilqr_multi_min", 192)
+        hip_predictor.set_tuning("ilqr_wgs", 8)
