@@ -51,6 +51,8 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = c->stream;
   if (!c->ev_pl) HIPCHK(c, hipEventCreateWithFlags(&c->ev_pl, hipEventDisableTiming));
+  if (!c->ev_tab) HIPCHK(c, hipEventCreateWithFlags(&c->ev_tab, hipEventDisableTiming));
+  if (!c->pl_copy) HIPCHK(c, hipStreamCreateWithFlags(&c->pl_copy, hipStreamNonBlocking));
   int rc;
   const int T = AIME_T, OBS = RB_T, HZ = in->pred_len;     // predicted steps per mode, history window, planning horizon
   // ---- root upload (one page-locked staging buffer -> one async copy), floats
@@ -204,7 +206,10 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     const size_t bS = ((size_t)B * sizeof(AimeScene) + 15) & ~(size_t)15, bI = ((size_t)A * sizeof(int) + 15) & ~(size_t)15;
     const size_t bP = ((size_t)B * sizeof(float) + 15) & ~(size_t)15;
     const size_t tab_bytes = bS + bI + bP;
-    if ((rc = ensure(c, c->pl_tab, tab_bytes + 3 * (size_t)6 * B * sizeof(int) + 64))) return rc;
+    // (two table buffers, by round parity: this round's tables are uploaded on the copy stream while the predictor runs -- the stream
+    // may still hold the previous round's windows kernel, which reads the index lists behind that round's tables)
+    DevBuf &tabb = c->pl_tab[round & 1];
+    if ((rc = ensure(c, tabb, tab_bytes + 3 * (size_t)6 * B * sizeof(int) + 64))) return rc;
     if ((rc = pl_pin(c, 1, tab_bytes + 3 * (size_t)6 * B * sizeof(int) + 64))) return rc;
     {
       char *h = (char *)c->pl_pin[1];
@@ -221,9 +226,15 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
         for (int i = S.a0; i < S.a1; ++i) as[i] = b;
         sp[b] = q.prob;
       }
-      HIPCHK(c, hipMemcpyAsync(c->pl_tab.p, h, tab_bytes, hipMemcpyHostToDevice, st));
+      if (c->pl_tab_side) {
+        HIPCHK(c, hipMemcpyAsync(tabb.p, h, tab_bytes, hipMemcpyHostToDevice, c->pl_copy));
+        HIPCHK(c, hipEventRecord(c->ev_tab, c->pl_copy));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_tab, 0));
+      } else {
+        HIPCHK(c, hipMemcpyAsync(tabb.p, h, tab_bytes, hipMemcpyHostToDevice, st));
+      }
     }
-    const char *dtab = (const char *)c->pl_tab.p;
+    const char *dtab = (const char *)tabb.p;
     if ((int)c->pl_world.size() <= round) c->pl_world.resize(round + 1);
     if ((rc = ensure(c, c->pl_world[round], (size_t)A * 6 * T * 6 * sizeof(float)))) return rc;
     float *d_world = (float *)c->pl_world[round].p;
@@ -296,9 +307,9 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
         hi[S + s] = n.scene * a * AIME_K + n.mode;        // first row (agent 0) of the node's mode in d_world
         hi[2 * S + s] = n.end_t - n.cur_t;                // steps kept
       }
-      HIPCHK(c, hipMemcpyAsync((char *)c->pl_tab.p + tab_bytes, hi, 3 * (size_t)S * sizeof(int), hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync((char *)tabb.p + tab_bytes, hi, 3 * (size_t)S * sizeof(int), hipMemcpyHostToDevice, st));
     }
-    const int *d_idx = (const int *)((const char *)c->pl_tab.p + tab_bytes);
+    const int *d_idx = (const int *)((const char *)tabb.p + tab_bytes);
     const int nxt = cur_in < 0 ? 0 : cur_in ^ 1;
     const InOff q = in_off(S);
     if ((rc = ensure(c, c->pl_in[nxt], q.total * sizeof(float)))) return rc;
@@ -426,52 +437,48 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   }
   const size_t Mtot = (size_t)c->pl_tree_off.back();
   c->pl_flat_mean.resize(Mtot * a * 2); c->pl_flat_cov.resize(Mtot * a);
-  float *d_fmean = nullptr, *d_fcov = nullptr;
-  if (!fjobs.empty()) {
-    const size_t bJ = (fjobs.size() * sizeof(AimeFlat) + 15) & ~(size_t)15, bW = (fjobs.size() * sizeof(float *) + 15) & ~(size_t)15;
-    const size_t bB = (fjob_of_block.size() * sizeof(int) + 15) & ~(size_t)15, bM = (Mtot * a * 2 * sizeof(float) + 15) & ~(size_t)15;
-    if ((rc = ensure(c, c->pl_flat, bJ + bW + 2 * bB + bM + Mtot * a * sizeof(float)))) return rc;
-    if ((rc = pl_pin(c, 0, bJ + bW + 2 * bB))) return rc;          // (the root upload of this plan completed rounds ago)
-    char *h = (char *)c->pl_pin[0];
-    memcpy(h, fjobs.data(), fjobs.size() * sizeof(AimeFlat));
-    memcpy(h + bJ, fworld.data(), fjobs.size() * sizeof(float *));
-    memcpy(h + bJ + bW, fjob_of_block.data(), fjob_of_block.size() * sizeof(int));
-    memcpy(h + bJ + bW + bB, fagent_of_block.data(), fagent_of_block.size() * sizeof(int));
-    HIPCHK(c, hipMemcpyAsync(c->pl_flat.p, h, bJ + bW + 2 * bB, hipMemcpyHostToDevice, st));
-    char *d = (char *)c->pl_flat.p;
-    d_fmean = (float *)(d + bJ + bW + 2 * bB); d_fcov = (float *)(d + bJ + bW + 2 * bB + bM);
-    hipLaunchKernelGGL(k_aime_flat, dim3((unsigned)fjob_of_block.size()), dim3(64), 0, st, (const AimeFlat *)d, (const int *)(d + bJ + bW),
-                       (const int *)(d + bJ + bW + bB), (const float *const *)(d + bJ), d_fmean, d_fcov);
-    HIPCHK(c, hipGetLastError());
-  }
   c->pl_rows_host.resize((size_t)n_rows);
-  if (!jobs.empty()) {
-    const size_t bJ = (jobs.size() * sizeof(AimeGather) + 15) & ~(size_t)15, bW = (jobs.size() * sizeof(float *) + 15) & ~(size_t)15;
-    const size_t bB = (job_of_block.size() * sizeof(int) + 15) & ~(size_t)15;
-    if ((rc = ensure(c, c->pl_gather, bJ + bW + 2 * bB))) return rc;
-    if ((rc = pl_pin(c, 1, bJ + bW + 2 * bB))) return rc;
-    char *h = (char *)c->pl_pin[1];
-    memcpy(h, jobs.data(), jobs.size() * sizeof(AimeGather));
-    memcpy(h + bJ, job_world.data(), jobs.size() * sizeof(float *));
-    memcpy(h + bJ + bW, job_of_block.data(), job_of_block.size() * sizeof(int));
-    memcpy(h + bJ + bW + bB, agent_of_block.data(), agent_of_block.size() * sizeof(int));
-    HIPCHK(c, hipMemcpyAsync(c->pl_gather.p, h, bJ + bW + 2 * bB, hipMemcpyHostToDevice, st));
-    if ((rc = ensure(c, c->pl_rows, (size_t)n_rows * sizeof(float)))) return rc;
-    const char *d = (const char *)c->pl_gather.p;
-    hipLaunchKernelGGL(k_aime_gather, dim3((unsigned)job_of_block.size()), dim3(64), 0, st, (const AimeGather *)d, (const int *)(d + bJ + bW),
-                       (const int *)(d + bJ + bW + bB), (const float *const *)(d + bJ), (float *)c->pl_rows.p);
-    HIPCHK(c, hipGetLastError());
-    const size_t n_flat = Mtot * a * 3;
-    if ((rc = pl_pin(c, 2, ((size_t)n_rows + n_flat) * sizeof(float)))) return rc;
-    float *hp = (float *)c->pl_pin[2];
-    HIPCHK(c, hipMemcpyAsync(hp, c->pl_rows.p, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToHost, st));
-    if (d_fmean) {
-      HIPCHK(c, hipMemcpyAsync(hp + n_rows, d_fmean, Mtot * a * 2 * sizeof(float), hipMemcpyDeviceToHost, st));
-      HIPCHK(c, hipMemcpyAsync(hp + n_rows + Mtot * a * 2, d_fcov, Mtot * a * sizeof(float), hipMemcpyDeviceToHost, st));
+  // one upload (both job tables), the two gather kernels, one read-back (rows | flat means | flat covariances)
+  const size_t n_flat = fjobs.empty() ? 0 : Mtot * a * 3;
+  if (!jobs.empty() || !fjobs.empty()) {
+    const size_t fJ = (fjobs.size() * sizeof(AimeFlat) + 15) & ~(size_t)15, fW = (fjobs.size() * sizeof(float *) + 15) & ~(size_t)15;
+    const size_t fB = (fjob_of_block.size() * sizeof(int) + 15) & ~(size_t)15;
+    const size_t gJ = (jobs.size() * sizeof(AimeGather) + 15) & ~(size_t)15, gW = (jobs.size() * sizeof(float *) + 15) & ~(size_t)15;
+    const size_t gB = (job_of_block.size() * sizeof(int) + 15) & ~(size_t)15;
+    const size_t o_g = fJ + fW + 2 * fB, n_tab = o_g + gJ + gW + 2 * gB;
+    const size_t o_rows = (n_tab + 255) & ~(size_t)255;
+    const size_t n_res = (size_t)n_rows + n_flat;
+    if ((rc = ensure(c, c->pl_flat, o_rows + n_res * sizeof(float)))) return rc;
+    if ((rc = pl_pin(c, 0, n_tab))) return rc;          // (the root upload of this plan completed rounds ago)
+    char *h = (char *)c->pl_pin[0];
+    if (!fjobs.empty()) {
+      memcpy(h, fjobs.data(), fjobs.size() * sizeof(AimeFlat));
+      memcpy(h + fJ, fworld.data(), fjobs.size() * sizeof(float *));
+      memcpy(h + fJ + fW, fjob_of_block.data(), fjob_of_block.size() * sizeof(int));
+      memcpy(h + fJ + fW + fB, fagent_of_block.data(), fagent_of_block.size() * sizeof(int));
     }
+    if (!jobs.empty()) {
+      memcpy(h + o_g, jobs.data(), jobs.size() * sizeof(AimeGather));
+      memcpy(h + o_g + gJ, job_world.data(), jobs.size() * sizeof(float *));
+      memcpy(h + o_g + gJ + gW, job_of_block.data(), job_of_block.size() * sizeof(int));
+      memcpy(h + o_g + gJ + gW + gB, agent_of_block.data(), agent_of_block.size() * sizeof(int));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->pl_flat.p, h, n_tab, hipMemcpyHostToDevice, st));
+    char *d = (char *)c->pl_flat.p;
+    float *d_rows = (float *)(d + o_rows), *d_fmean = d_rows + n_rows, *d_fcov = d_fmean + Mtot * a * 2;
+    if (!fjobs.empty())
+      hipLaunchKernelGGL(k_aime_flat, dim3((unsigned)fjob_of_block.size()), dim3(64), 0, st, (const AimeFlat *)d, (const int *)(d + fJ + fW),
+                         (const int *)(d + fJ + fW + fB), (const float *const *)(d + fJ), d_fmean, d_fcov);
+    if (!jobs.empty())
+      hipLaunchKernelGGL(k_aime_gather, dim3((unsigned)job_of_block.size()), dim3(64), 0, st, (const AimeGather *)(d + o_g),
+                         (const int *)(d + o_g + gJ + gW), (const int *)(d + o_g + gJ + gW + gB), (const float *const *)(d + o_g + gJ), d_rows);
+    HIPCHK(c, hipGetLastError());
+    if ((rc = pl_pin(c, 2, n_res * sizeof(float)))) return rc;
+    float *hp = (float *)c->pl_pin[2];
+    HIPCHK(c, hipMemcpyAsync(hp, d_rows, n_res * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     memcpy(c->pl_rows_host.data(), hp, (size_t)n_rows * sizeof(float));
-    if (d_fmean) {
+    if (n_flat) {
       memcpy(c->pl_flat_mean.data(), hp + n_rows, Mtot * a * 2 * sizeof(float));
       memcpy(c->pl_flat_cov.data(), hp + n_rows + Mtot * a * 2, Mtot * a * sizeof(float));
     }

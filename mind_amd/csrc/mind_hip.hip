@@ -108,11 +108,15 @@ struct mind_ctx {
   DevBuf ilqr_dev, aime_dev, rebase_dev2[2], dec_h2;
   // mind_aime_plan (aime_plan.hip): device arenas, page-locked staging (uploads / read-backs are true async copies: a pageable
   // source makes hipMemcpyAsync wait for the stream to drain first), host result tables
-  DevBuf pl_root, pl_in[2], pl_lf, pl_lrep, pl_pred, pl_small, pl_tab, pl_win[2], pl_gather, pl_rows;
+  DevBuf pl_root, pl_in[2], pl_lf, pl_lrep, pl_pred, pl_small, pl_tab[2], pl_win[2], pl_gather, pl_rows;
   std::vector<DevBuf> pl_world;
   void *pl_pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // [4], [5]: upload / read-back staging of the tree-iLQR calls
   size_t pl_pin_cap[6] = {0, 0, 0, 0, 0, 0};
-  hipEvent_t ev_pl = nullptr;
+  hipEvent_t ev_pl = nullptr, ev_tab = nullptr;
+  // "pl_tab_side" / MIND_PL_TAB_SIDE=1: the round tables travel on their own stream while the round's predictor runs instead of behind it
+  // on the context stream.  Measured on the recorded demo_1 loop: no difference (AIME 2.00 vs 2.01 ms per plan, profiles/r03ag) -- off.
+  hipStream_t pl_copy = nullptr;
+  bool pl_tab_side = false;
   std::vector<mind_aime_node> pl_nodes;
   std::vector<float> pl_rows_host, pl_flat_prob, pl_flat_mean, pl_flat_cov;
   std::vector<int32_t> pl_tree_top, pl_tree_off, pl_flat_parent;
@@ -227,6 +231,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *te = getenv("MIND_TOK_MFMA")) c->tok_mfma = !(te[0] == '0');
   if (const char *te = getenv("MIND_TOK_SMALL_MAX")) c->tok_small_max = atoi(te);
   if (const char *te = getenv("MIND_TGT_SIDE")) c->tgt_side = !(te[0] == '0');
+  if (const char *te = getenv("MIND_PL_TAB_SIDE")) c->pl_tab_side = !(te[0] == '0');
   (void)hipFuncSetAttribute((const void *)k_token_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_token_mfma_lds_bytes());
   if (const char *we = getenv("MIND_ILQR_CHUNK")) c->ilqr_chunk = atoi(we) < 0 ? 0 : atoi(we);
   if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
@@ -251,7 +256,7 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
     for (DevBuf *b : {&t.meta, &t.jobs, &t.rows})
       if (b->p) (void)hipFree(b->p);
   if (c->wdev) (void)hipFree(c->wdev);
-  for (DevBuf *b : {&c->pl_root, &c->pl_in[0], &c->pl_in[1], &c->pl_lf, &c->pl_lrep, &c->pl_pred, &c->pl_small, &c->pl_tab, &c->pl_win[0],
+  for (DevBuf *b : {&c->pl_root, &c->pl_in[0], &c->pl_in[1], &c->pl_lf, &c->pl_lrep, &c->pl_pred, &c->pl_small, &c->pl_tab[0], &c->pl_tab[1], &c->pl_win[0],
                     &c->pl_win[1], &c->pl_gather, &c->pl_rows, &c->pl_flat})
     if (b->p) (void)hipFree(b->p);
   for (DevBuf &b : c->pl_world)
@@ -259,6 +264,8 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
   for (void *q : c->pl_pin)
     if (q) (void)hipHostFree(q);
   if (c->ev_pl) (void)hipEventDestroy(c->ev_pl);
+  if (c->ev_tab) (void)hipEventDestroy(c->ev_tab);
+  if (c->pl_copy) (void)hipStreamDestroy(c->pl_copy);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->ev_side) (void)hipEventDestroy(c->ev_side);
   if (c->ev_main) (void)hipEventDestroy(c->ev_main);
@@ -291,6 +298,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "tok_mfma") c->tok_mfma = value != 0;
   else if (n == "tok_small_max") c->tok_small_max = (int)value;
   else if (n == "tgt_side") c->tgt_side = value != 0;
+  else if (n == "pl_tab_side") c->pl_tab_side = value != 0;
   else if (n == "ilqr_chunk") c->ilqr_chunk = value < 0 ? 0 : (int)value;
   else if (n == "ilqr_wgs") c->ilqr_wgs = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (n == "ilqr_multi_min") c->ilqr_multi_min = value;
