@@ -36,6 +36,9 @@
 // the staging buffers are private to a wave and one wave's DS instructions execute in order: no s_waitcnt between the passes
 // over a buffer, only a compiler barrier (draining the LDS queue there measured no difference: DESIGN 4)
 #define PBF_FENCE() asm volatile("" ::: "memory")
+#ifndef PBF_QK_FIRST
+#define PBF_QK_FIRST 1
+#endif
 
 #define LB_WE 0                                       // [part 2][ob 8][g 4][lane 64][4 dwords] = 16384 dwords (64 KB)
 #define LB_WP 16384
@@ -372,13 +375,27 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_bf(const PairJob *__re
       }
       SCHED_FENCE();
       PT(4);
-      // ---- next tile's edge rows (late variant): in flight during the attention phase only
+      // ---- the folded query first, THEN the next tile's edge rows: the memory counter retires in order, so the wait for the query
+      //      fragments below leaves the eight edge-row loads issued behind them in flight (vmcnt(8)) through the whole attention
+      //      phase; requested the other way round, that wait drained the prefetch the moment it was issued
+#if PBF_QK_FIRST
+      PBF_LOAD_QK()
+      asm volatile("" ::: "memory");
+#endif
+#if PBF_QK_FIRST
+      // (unconditional: behind a branch the compiler must assume the loads were NOT issued and waits for everything; the job's last tile
+      // asks for its own rows again -- L2 hits that nobody reads)
+      if (MODE == 1 && !PBF_PREFETCH_TOP) { const int nrow0 = tile + 1 < J.t1 ? i0 + 16 : i0; PBF_LOAD_RAW(nrow0, ll) }
+#else
       if (MODE == 1 && !PBF_PREFETCH_TOP && tile + 1 < J.t1) { PBF_LOAD_RAW(i0 + 16, ll) }
+#endif
       // ---- attention scores: S^T[head, pair] = QK_j[head, :] . mem^T[:, pair]; the memory tile is already the B operand
       f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, sb = sa, sc = sa;
       {
         PT(9);               // (trace) next-tile prefetch issue
+#if !PBF_QK_FIRST
         PBF_LOAD_QK()
+#endif
         PT_DRAIN();
         PT(10);              // (trace) wait for the folded-query fragments (and the edge stores / prefetch queued before them)
         if (!qrow) {
