@@ -75,3 +75,57 @@ def test_oracle_matches_imported_reference_live():
     flat, w, f = oi.contingency(oi.default_cfg(), sst["nodes"], sst["state"], sst["ctrl"], sst["target_lane"], sst["target_vel"])
     assert np.abs(w["xs"] - xs_w).max() < 1e-9 and np.abs(f["xs"] - opt.ilqr.xs).max() < 1e-8
     assert f["mu"] == opt.ilqr._mu
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not rh.available(), reason="reference tree not present")
+@pytest.mark.parametrize("kind,a", [("lead", 5), ("branch3", 6)])
+def test_oracle_iteration_trace_equals_the_imported_references(kind, a):
+    """iLQR.fit's loop (planners/ilqr/solver.py:133-158) ITERATION BY ITERATION: the Levenberg-Marquardt value every backward pass runs
+    with, the cost of the nominal trajectory when the line search starts and its outcome, recorded by wrapping the imported reference's
+    _backward_pass / _backtrack_line_search, against the rows of the C oracle's loop (oracle_ilqr_last_trace; the same rows come out of
+    the HIP kernel through mind_last_ilqr_trace: tests/test_gpu_ilqr.py::test_iteration_trace_equals_the_oracles)."""
+    m = rh.ref_modules()
+    Tree, Node = m["planners.basic.tree"].Tree, m["planners.basic.tree"].Node
+    TTO = m["planners.mind.trajectory_tree"].TrajectoryTreeOptimizer
+    iLQR = m["planners.ilqr.solver"].iLQR
+    cfgmod = m["planners.mind.configs.planning.demo_1"]
+    sst = scripted_scenario_tree(kind, a, seed=3)
+    tree = Tree()
+    for k, p, d in sst["nodes"]:
+        tree.add_node(Node(k, p, d))
+    fits = []
+    o_bp, o_ls, o_fit = iLQR._backward_pass, iLQR._backtrack_line_search, iLQR.fit
+
+    def bp(self):
+        fits[-1].append([float(self._mu), float(self.J_opt), -2.0])
+        return o_bp(self)
+
+    def ls(self, alphas):
+        acc, conv = o_ls(self, alphas)
+        fits[-1][-1][2] = 1.0 if acc else -1.0
+        return acc, conv
+
+    def fit(self, *args, **kw):
+        fits.append([])
+        return o_fit(self, *args, **kw)
+
+    iLQR._backward_pass, iLQR._backtrack_line_search, iLQR.fit = bp, ls, fit
+    try:
+        opt = TTO(cfgmod.TrajTreeCfg())
+        opt.init_warm_start_cost_tree(tree, sst["state"], sst["ctrl"], sst["target_lane"], sst["target_vel"])
+        xs_w, us_w = opt.warm_start_solve()
+        opt.init_cost_tree(tree, sst["state"], sst["ctrl"], sst["target_lane"], sst["target_vel"])
+        opt.solve(us_w)
+    finally:
+        iLQR._backward_pass, iLQR._backtrack_line_search, iLQR.fit = o_bp, o_ls, o_fit
+    cfg = oi.default_cfg()
+    flat = oi.flatten(sst["nodes"])
+    x0 = oi.init_state(sst["state"], sst["ctrl"])
+    w = oi.solve(cfg, flat, x0, sst["target_lane"], sst["target_vel"], 0, trace=True)
+    f = oi.solve(cfg, flat, x0, sst["target_lane"], sst["target_vel"], 1, us_init=w["us"], trace=True)
+    for got, ref in ((w["trace"], np.array(fits[0])), (f["trace"], np.array(fits[1]))):
+        assert len(got) == len(ref) and len(ref) > 3
+        assert np.array_equal(got[:, 0], ref[:, 0])                                           # the Levenberg-Marquardt schedule
+        assert np.array_equal(np.where(got[:, 2] >= 0, 1.0, got[:, 2]), ref[:, 2])            # accepted / rejected / singular
+        assert np.allclose(got[:, 1], ref[:, 1], rtol=1e-9, atol=0.0)                         # cost of the nominal trajectory
