@@ -298,6 +298,11 @@ typedef struct {
   const int32_t *lane_flags;                 /* [l,6]: lane type (0 vehicle, 1 bike, 2 bus), intersection, left / right mark   */
                                              /*   class (0 crossable, 1 not, 2 other), has left / right neighbour              */
   float travel0;                             /* max(ego speed, min_vel) * time_ahead (float32), scenario_tree.py:131,620-624   */
+  /* Test / benchmark hook (mind_amd/synth.py ScriptedBranching, ScriptedFullTree: the reference ships no trained checkpoint and the
+   * formula weights collapse every plan to a node or two, so the full-tree workloads of BASELINE configs 4 / 5 script the modes): when
+   * script_cls != NULL the predictor still runs on every scene of every round, and these DEVICE arrays then take the place of its
+   * outputs for every scene: cls [6], reg [a,6,60,5], vel [a,6,60,2]. */
+  const float *script_cls, *script_reg, *script_vel;
 } mind_aime_plan_in;
 
 #define MIND_AIME_BRANCH 1

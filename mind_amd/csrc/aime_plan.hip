@@ -48,6 +48,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
            : (!in->actors || !in->actor_ctrs || !in->actor_vecs || !in->lanes || !in->lane_ctrs || !in->lane_vecs || !in->tgt_nodes ||
               !in->tgt_rpe || !in->rot || !in->orig || !in->tgt_pts || !in->hist)) || in->max_depth < 0 || in->max_rounds <= 0 || in->max_rounds > 32 || in->pred_len < 2 || in->pred_len > AIME_T)
     return fail(c, MIND_EINVAL, "mind_aime_plan: bad argument");
+  if (in->script_cls && (!in->script_reg || !in->script_vel)) return fail(c, MIND_EINVAL, "mind_aime_plan: scripted modes need cls, reg and vel");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = c->stream;
   if (!c->ev_pl) HIPCHK(c, hipEventCreateWithFlags(&c->ev_pl, hipEventDisableTiming));
@@ -191,6 +192,13 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     if ((rc = mind_predict_batch(c, &sb, &po))) return rc;
     n_expanded += B;
     if (c->profiling) { pair_ms += c->pair_ms; pair_launches += c->n_pair_launch; }
+    if (in->script_cls) {
+      // scripted modes (benchmark hook): the forward above was the timed work, its outputs are replaced scene by scene
+      const size_t nr = (size_t)a * 6 * T * 5, nv = (size_t)a * 6 * T * 2;
+      hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((6 * (size_t)B + 255) / 256)), dim3(256), 0, st, in->script_cls, (size_t)6, B, d_cls);
+      hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((nr * B + 255) / 256)), dim3(256), 0, st, in->script_reg, nr, B, d_reg);
+      hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((nv * B + 255) / 256)), dim3(256), 0, st, in->script_vel, nv, B, d_vel);
+    }
     // ---- the frames of the re-based scenes (queued behind k_aime_rebase, before this round's predictor): ROT, ORIG, TGT_PTS
     if (frames_pending) {
       HIPCHK(c, hipEventSynchronize(c->ev_pl));

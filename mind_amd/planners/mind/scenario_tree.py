@@ -239,6 +239,8 @@ class ScenarioTreeGenerator:
     # ------------------------------------------------------------------------------------------
     def _native_ok(self):
         net = self.network
+        if type(net).__name__ in ("ScriptedBranching", "ScriptedFullTree"):      # scripted modes on top of the real forward (mind_amd/synth.py)
+            net = net.net
         return (self.native_aime and self.device_glue and self.device_select and type(net).__name__ == "ScenePredNet"
                 and getattr(net, "rt", None) is not None and getattr(net, "_loaded", False) and hasattr(net.rt, "aime_plan")
                 and (self.shard is None or not self.shard.sharded) and self.ego_idx == 0 and self.target_lane is not None
@@ -249,6 +251,8 @@ class ScenarioTreeGenerator:
         cfg = self.config
         if self.obs_len != 50 or not (2 <= self.pred_len <= 60):
             return None
+        scripted = type(self.network).__name__ in ("ScriptedBranching", "ScriptedFullTree")
+        modes = (lambda n_agents: self.network._modes(n_agents, self.network.rt.device)) if scripted else (lambda n_agents: None)
         if self.device_root:
             # process_data's host part is reduced to get_agent_trajectories (Track lists -> padded arrays); frames, actor features,
             # lane graph, high-level command and the root's world-frame histories are computed by the library on the device
@@ -262,7 +266,7 @@ class ScenarioTreeGenerator:
             root = {"TRAJS_TYPE": types, "TRAJS_TID": tids, "TRAJS_CAT": cats}
             self.n_lanes = int(st["num_lanes"])
             res = self.network.rt.aime_plan(None, None, None, None, self.target_lane, self.target_lane_info, cfg.tar_time_ahead,
-                                            cfg.tar_dist_thres, cfg.max_depth, pred_len=self.pred_len, raw=raw)
+                                            cfg.tar_dist_thres, cfg.max_depth, pred_len=self.pred_len, raw=raw, script=modes(pos.shape[0]))
         else:
             root = self.process_data(lcl_smp, agent_obs)
             self.prepare_root_data(root)
@@ -271,7 +275,8 @@ class ScenarioTreeGenerator:
                 return None
             self.n_lanes = int(root["LANES"].shape[0])
             res = self.network.rt.aime_plan(root, hist, self.lane_graph["lane_ctrs"], self.lane_graph["lane_vecs"], self.target_lane,
-                                            self.target_lane_info, cfg.tar_time_ahead, cfg.tar_dist_thres, cfg.max_depth, pred_len=self.pred_len)
+                                            self.target_lane_info, cfg.tar_time_ahead, cfg.tar_dist_thres, cfg.max_depth, pred_len=self.pred_len,
+                                            script=modes(root["ACTORS"].shape[0]))
         if res is None:
             return None
         nodes, rows, info = res
@@ -280,15 +285,16 @@ class ScenarioTreeGenerator:
         a = info["a"]
         keys = []
         types, tids, cats = root["TRAJS_TYPE"], root["TRAJS_TID"], root["TRAJS_CAT"]
-        for n in nodes:
-            key = "{}_{}_{}".format(int(n["round"]), int(n["scene"]), int(n["mode"]))
-            pkey = "root" if n["parent"] < 0 else keys[int(n["parent"])]
-            dur, off = int(n["dur"]), int(n["row_off"])
+        # the node table column by column (one conversion per field instead of one numpy scalar per field and node)
+        col = {f: nodes[f].tolist() for f in ("round", "scene", "mode", "parent", "dur", "row_off", "flags", "cur_t", "end_t")}
+        probs, tgt = nodes["prob"], nodes["tgt_pts"].reshape(-1, 11, 2)
+        for i in range(len(nodes)):
+            key = "{}_{}_{}".format(col["round"][i], col["scene"][i], col["mode"][i])
+            pkey = "root" if col["parent"][i] < 0 else keys[col["parent"][i]]
+            dur, off, fl = col["dur"][i], col["row_off"][i], col["flags"][i]
             packed = rows[off:off + a * dur * 3].reshape(a, dur, 3) if off >= 0 else None
-            fl = int(n["flags"])
-            d = NativeScene({"SCEN_PROB": F32(n["prob"]), "CUR_T": int(n["cur_t"]), "END_T": int(n["end_t"]), "PARENT_ID": pkey, "SCEN_ID": key,
-                             "TRAJS_TYPE": types, "TRAJS_TID": tids, "TRAJS_CAT": cats,
-                             "TGT_PTS": np.array(n["tgt_pts"], F32).reshape(11, 2)}, packed, self.obs_len)
+            d = NativeScene({"SCEN_PROB": probs[i], "CUR_T": col["cur_t"][i], "END_T": col["end_t"][i], "PARENT_ID": pkey, "SCEN_ID": key,
+                             "TRAJS_TYPE": types, "TRAJS_TID": tids, "TRAJS_CAT": cats, "TGT_PTS": tgt[i]}, packed, self.obs_len)
             self.tree.add_node(Node(key, pkey, ScenarioData(d, None, branch_flag=bool(fl & 1), end_flag=bool(fl & 2), terminate_flag=bool(fl & 4))))
             keys.append(key)
         self.n_expanded += info["n_expanded"]

@@ -448,14 +448,14 @@ class HipPredictor:
         return out
 
     def aime_plan(self, root, hist, lane_ctrs, lane_vecs, target_lane, target_lane_info, time_ahead, dist_thres, max_depth,
-                  pred_len=50, min_vel=0.5, max_rounds=16, raw=None):
+                  pred_len=50, min_vel=0.5, max_rounds=16, raw=None, script=None):
         """ScenarioTreeGenerator.branch_aime in one call (mind_aime_plan).  Host-built root: ``root`` = the root scene dict of
         process_data (ACTORS, TRAJS_CTRS, TRAJS_VECS, LANES, TGT_NODES, TGT_RPE, ROT, ORIG, TGT_PTS, TRAJS_TYPE), ``hist`` [a,50,6] its
         world-frame history (x, y, vx, vy, heading, max-sigma), lane_ctrs / lane_vecs the lane graph's anchors.  Device-built root:
         ``raw`` = dict(pos [a,50,2], ang [a,50], vel [a,50,2], pad [a,50], types [a,50,7] as get_agent_trajectories returns them,
         lane_pts [l,11,2] float64, lane_flags [l,6] int, travel0) and root / hist / lane_ctrs / lane_vecs are ignored.
         Returns (nodes: structured array, one record per internal tree node in creation order, rows: float32 [n], info dict) or None
-        when the library reports a situation only the round-by-round path handles."""
+        when the library reports a situation only the round-by-round path handles.  ``script``: see mind_aime_plan_in.script_cls."""
         f = lambda x: np.ascontiguousarray(x, np.float32)
         fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
         pi, po = _lib.AimePlanIn(), _lib.AimePlanOut()
@@ -483,6 +483,11 @@ class HipPredictor:
             setattr(pi, k, fp(v))
         pi.time_ahead, pi.min_vel, pi.dist_thres = float(time_ahead), float(min_vel), float(dist_thres)
         pi.max_depth, pi.max_rounds, pi.pred_len = int(max_depth), int(max_rounds), int(pred_len)
+        if script is not None:        # (cls [1,6], reg [a,6,60,5], vel [a,6,60,2]) float32 device tensors: scripted modes (synth.ScriptedBranching)
+            sc, sr, sv = script
+            assert tuple(sr.shape) == (a, 6, 60, 5) and tuple(sv.shape) == (a, 6, 60, 2) and sc.numel() == 6
+            assert all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 for t in script)
+            pi.script_cls, pi.script_reg, pi.script_vel = sc.data_ptr(), sr.data_ptr(), sv.data_ptr()
         rc = self.lib.mind_aime_plan(self.ctx, C.byref(pi), C.byref(po))
         if rc == _lib.MIND_ESTATE:
             msg = self.lib.mind_last_error_string(self.ctx) or b""

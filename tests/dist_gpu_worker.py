@@ -23,6 +23,9 @@ def main(out_path, n_plans):
         else:
             dist.init_process_group("gloo")
     pl, sim, w = make_closed_loop(dict(WORKLOADS["demo1"]))
+    # the sharded ranks run the round-by-round path over the host featuriser; the one-process run (the native plan) is fed by the same one,
+    # so that the comparison is bit for bit (device-built root vs host featuriser: tests/test_gpu_aime_native.py)
+    pl.scen_tree_gen.device_root = False
     sh = None
     if world > 1 or forced:
         sh = pl.enable_sharding()

@@ -21,18 +21,25 @@ def _flat(trees):
     return out
 
 
-@pytest.mark.parametrize("scene", ["demo_1", "demo_3"])
+@pytest.mark.parametrize("scene", ["demo_1", "demo_3", "demo1", "small_full_tree"])
 def test_native_plan_equals_the_round_by_round_path(scene):
+    """demo_1 / demo_3: recorded scenes, the predictor's own modes (branching formula weights).  demo1 / small_full_tree: synthetic
+    worlds with SCRIPTED modes on top of the real forward (mind_amd/synth.py; mind_aime_plan_in.script_*: the bench's demo-like
+    branching and the full 6-ary depth-4 tree of BASELINE config 4 -- 259 expansions, rounds of 1 / 6 / 36 / 216 scenes -- on a
+    16-agent world)."""
     sys.path.insert(0, ROOT)
     from bench import BRANCHING_WEIGHTS, WORKLOADS, make_closed_loop
     sims = []
+    synthetic = scene in ("demo1", "small_full_tree")
+    wkw = dict(n_agents=16, n_lanes=4, n_segs=8, seed=4) if scene == "small_full_tree" else dict(WORKLOADS[scene])
     for native in (True, False):
-        pl, sim, w = make_closed_loop(dict(WORKLOADS[scene]), ckpt=BRANCHING_WEIGHTS, speculative=False)
+        pl, sim, w = make_closed_loop(wkw, ckpt=None if synthetic else BRANCHING_WEIGHTS, speculative=False, full_tree=scene == "small_full_tree")
         pl.scen_tree_gen.native_aime = native
         pl.scen_tree_gen.device_root = False         # both fed by the host featuriser (the device-built root is compared below)
         sims.append((pl, sim))
     n_multi = 0
-    for cycle in range(8):
+    n_cycles = 3 if scene == "small_full_tree" else 8
+    for cycle in range(n_cycles):
         res = []
         for pl, sim in sims:
             sim.run_plans(1)
@@ -56,8 +63,10 @@ def test_native_plan_equals_the_round_by_round_path(scene):
                 assert u.dtype == v.dtype and u.shape == v.shape and np.array_equal(u, v), (cycle, x[0])
         assert np.array_equal(ca, cb)
         n_multi += len(ia) > 3
-    assert sims[0][0].scen_tree_gen.n_native_plans == 8 and sims[1][0].scen_tree_gen.n_native_plans == 0
-    assert n_multi >= 4                 # the branching weights really grow multi-round trees here
+    assert sims[0][0].scen_tree_gen.n_native_plans == n_cycles and sims[1][0].scen_tree_gen.n_native_plans == 0
+    assert n_multi >= n_cycles // 2     # the branching weights / scripted modes really grow multi-round trees here
+    if scene == "small_full_tree":
+        assert sims[0][0].timing["nodes_expanded"] >= 250          # 1 + 6 + 36 + 216 when no mode is pruned
 
 
 @pytest.mark.parametrize("scene", ["demo_1", "demo_2", "demo_4"])

@@ -332,6 +332,7 @@ def test_full_tree_plan_is_identical_with_device_assembled_windows():
     for dev_win in (True, False):
         pl, sim, w = make_closed_loop(dict(WORKLOADS["cfg4tree"]), full_tree=True, speculative=False)
         pl.scen_tree_gen.device_windows = dev_win
+        pl.scen_tree_gen.native_aime = False      # the round-by-round path is what has the two window sources (mind_aime_plan: always device)
         sim.run_plans(2)
         trees = pl.scen_tree_gen.get_scenario_tree()
         flat = []
