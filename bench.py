@@ -452,7 +452,9 @@ def summarize(m, prec):
            "ilqr_solves_per_s": ctr["solves"] / m["dt"], "ilqr_iterations_per_s": ctr["iterations"] / m["dt"],
            "k_ilqr_ms_per_launch": (m["ilqr_kernel"]["ms"] / m["ilqr_kernel"]["launches"]) if m["ilqr_kernel"]["launches"] else None,
            "k_ilqr_workgroups_per_tree": m["ilqr_kernel"]["wgs"],
-           "breakdown_ms": m["breakdown_ms"], "k_ilqr": ilqr_block(m)}
+           "breakdown_ms": m["breakdown_ms"], "k_ilqr": ilqr_block(m),
+           # plans (warm-up included) whose whole AIME loop ran inside mind_aime_plan; 0 = the round-by-round path (sharded / wrapped networks)
+           "aime_native_plans": getattr(m["pl"].scen_tree_gen, "n_native_plans", 0)}
     if r is not None:
         out["k_pair"] = {"bound": r["bound"], "frac": r["frac"], "mfma_frac": r["mfma"]["frac"], "hbm_frac": r["hbm"]["frac"],
                          "tflops": r["mfma"]["achieved_tflops"], "gbs": r["hbm"]["achieved_gbs"], "avg_launch_ms": r["avg_launch_ms"],

@@ -113,7 +113,7 @@ int mind_set_pair_precision(mind_ctx *ctx, int mode);
 
 /* Kernel-selection knobs (A/B measurements and tests; the defaults are the measured winners, the results are the same within the
  * arithmetic's accuracy): "dec_mfma_min" (agents per call from which the decoder's actor part uses the MFMA kernel; default: never),
- * "ilqr_wgs" (workgroups per wide cost tree, default 8; 1 = the one-workgroup kernel), "ilqr_multi_min" (node count from which a
+ * "ilqr_wgs" (workgroups per wide cost tree, default 16, halved until the launch is resident; 1 = the one-workgroup kernel), "ilqr_multi_min" (node count from which a
  * tree is "wide", default 192; a wide-tree launch that is not fully resident -- another context holds CUs -- aborts at its first
  * barrier and the call is solved again by the one-workgroup kernel: mind_last_ilqr_stats then reports 1 workgroup per tree), "enc_mfma" (0: the fp32 VALU ActorNet / decoder kernels under every precision), "actor_split" (6: three-way operand split,
  * fp32-class; 3: two-way), "xcd_order" (XCD-aware job order of the pair kernel), "tok_mfma" (1: the per-token epilogue / prologue of the fusion layers on the fp32 MFMA kernel k_token_mfma instead of the fp32 VALU one; off by default: measured slower), "tok_small_max" (batches of at most this many tokens run k_token with four tokens per workgroup instead of eight; same bits), "tgt_side" (0: the context stream waits for the target embedding before the fusion layers), "dec_overlap" (0: the decoder's actor part as one kernel behind

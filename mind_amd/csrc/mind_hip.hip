@@ -96,7 +96,9 @@ struct mind_ctx {
   // demo_1 loop: chunks of 6 / 8 / 12 nodes cost 2.10 / 2.05 / 2.04 ms per launch against 1.99 for whole segments -- the cost waves
   // share the SIMDs' float64 pipe with the state-chain waves and slow the chain down by more than the tail they hide
   int ilqr_chunk = 0;
-  int ilqr_wgs = 8, ilqr_multi_min = 192;   // wide cost trees: workgroups per tree, node count from which they are used (mind_set_tuning)
+  // wide cost trees: workgroups per tree (halved until every workgroup of the launch is resident; cfg4 full tree, six trees per launch:
+  // 8.33 / 7.40 / 7.37 / 7.63 ms per plan with 8 / 16 / 24 / 32, profiles/r03an), node count from which they are used (mind_set_tuning)
+  int ilqr_wgs = 16, ilqr_multi_min = 192;
   int dec_mfma_min = 1 << 30;   // agents per call from which the decoder's actor part runs on the MFMA kernel (MIND_DEC_MFMA_MIN; default: never)
   bool enc_mfma = true;         // MFMA ActorNet under the bf16x3 / bf16 settings (MIND_ENC_MFMA=0: the fp32 VALU kernel, for A/B)
   bool xcd_order = true;        // XCD-aware job order for big batches (MIND_XCD_ORDER=0 switches it off, for A/B measurements)

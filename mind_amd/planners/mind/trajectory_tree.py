@@ -278,13 +278,6 @@ class TrajectoryTreeOptimizer:
                 hit_idx = sorted(hits)
                 miss_idx = [i for i in range(len(sub)) if i not in hits]
                 rt = self._runtime()
-                if self.shard is not None and self.shard.sharded:
-                    # a rank of a sharded plan solves at most a tree or two: a wide tree then gets 16 workgroups instead of 8 (cfg4tree, one
-                    # launch: 8.5 vs 12.8 ms, profiles/r02z_ilqr_workgroups_per_tree.txt); same arithmetic, same results
-                    want = 16 if len(sub) <= 2 else 8
-                    if getattr(rt, "_ilqr_wgs_user", None) is None and getattr(rt, "_ilqr_wgs_now", 8) != want:
-                        rt.lib.mind_set_tuning(rt.ctx, b"ilqr_wgs", want)
-                        rt._ilqr_wgs_now = want
                 miss_call = miss_fut = None
                 if miss_idx:             # both fits, as without speculation
                     miss_call = IlqrCall(rt.lib, cfg_w, [sub[i] for i in miss_idx], x0, lane, target_vel, cfg_full=cfg_f)

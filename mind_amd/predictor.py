@@ -61,7 +61,7 @@ class IlqrCall:
             self.lib.mind_set_tuning(rt.ctx, b"ilqr_wgs", 1)
             rt._ilqr_wgs_now = 1
         elif not self.background and now == 1:          # back to what the user (or the library default) asked for
-            rt._ilqr_wgs_now = getattr(rt, "_ilqr_wgs_user", int(os.environ.get("MIND_ILQR_WGS", "8")))
+            rt._ilqr_wgs_now = getattr(rt, "_ilqr_wgs_user", int(os.environ.get("MIND_ILQR_WGS", "16")))
             self.lib.mind_set_tuning(rt.ctx, b"ilqr_wgs", rt._ilqr_wgs_now)
         if self.cfg_full is not None:
             self.rc = self.lib.mind_ilqr_contingency(rt.ctx, C.byref(self.cfg), C.byref(self.cfg_full), self.trees, self.n, dp(self.x0),

@@ -124,7 +124,7 @@ def test_wide_trees_on_several_workgroups_are_bit_identical(hip_predictor):
             hip_predictor.set_tuning("ilqr_wgs", G)
             res[G] = hip_predictor.ilqr_contingency(cfg_w, cfg_f, flats, x0, lane, 4.0)
     finally:
-        hip_predictor.set_tuning("ilqr_wgs", 8)
+        hip_predictor.set_tuning("ilqr_wgs", 16)
     xs1, us1, sw1, sf1 = res[1]
     for G in (2, 8, 16):
         xs, us, sw, sf = res[G]
@@ -163,7 +163,7 @@ def test_singular_q_uu_path_on_one_and_on_several_workgroups(hip_predictor):
                     assert np.array_equal(got[0][t], one[0][0]) and np.array_equal(got[1][t], one[1][0]) and got[2][t] == one[2][0], G
     finally:
         hip_predictor.set_tuning("ilqr_multi_min", 192)
-        hip_predictor.set_tuning("ilqr_wgs", 8)
+        hip_predictor.set_tuning("ilqr_wgs", 16)
 
 
 def test_wide_tree_launch_that_is_not_resident_falls_back_to_one_workgroup(hip_predictor):
@@ -187,7 +187,7 @@ def test_wide_tree_launch_that_is_not_resident_falls_back_to_one_workgroup(hip_p
     finally:
         hip_predictor.set_tuning("ilqr_test_starve", 0)
         hip_predictor.set_tuning("ilqr_multi_min", 192)
-        hip_predictor.set_tuning("ilqr_wgs", 8)
+        hip_predictor.set_tuning("ilqr_wgs", 16)
     for r in (ok, got):
         assert np.array_equal(r[0][0], ref[0][0]) and np.array_equal(r[1][0], ref[1][0]) and r[2] == ref[2]
 
@@ -293,4 +293,4 @@ def test_iteration_trace_equals_the_oracles(kind, a, max_iter, hip_predictor):
         check()
     finally:
         hip_predictor.set_tuning("ilqr_multi_min", 192)
-        hip_predictor.set_tuning("ilqr_wgs", 8)
+        hip_predictor.set_tuning("ilqr_wgs", 16)
