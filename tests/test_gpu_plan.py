@@ -279,7 +279,7 @@ def test_recorded_demo_scenes_branching_weights_whole_run(scene):
     steps = list(D[scene + "_plan_steps"])
     state_in, ctrl_in = D[scene + "_state_in"], D[scene + "_ctrl_in"]
     assert len(steps) == 60
-    same_choice, better, ill, n_nodes = 0, [], [], []
+    same_choice, better, ill, n_nodes, margins = 0, [], [], [], []
     for pi, step in enumerate(steps):
         while sim.n_plans <= pi:
             will_plan = sim.sim_time >= sim.enable_time and (sim.last_trigger is None or
@@ -303,6 +303,9 @@ def test_recorded_demo_scenes_branching_weights_whole_run(scene):
         if keys == list(D[f"{scene}_p{pi}_scen_keys"]):
             same_choice += 1
             continue
+        # cost margins of a cycle with another choice: this planner's cost of its own choice and of the reference's, the reference's of both
+        ri, oi_ = int(np.argmin(ref_costs)), int(np.argmin(costs))
+        margins.append((pi, round(float(costs[oi_]), 4), round(float(costs[ri]), 4), round(float(ref_costs[ri]), 4), round(float(ref_costs[oi_]), 4)))
         if costs.min() <= ref_costs.min() + 1e-3:
             better.append(pi)
             continue
@@ -313,7 +316,8 @@ def test_recorded_demo_scenes_branching_weights_whole_run(scene):
         assert moved > tol, (pi, j, costs, ref_costs, moved)                 # a well-conditioned candidate that disagrees is a real failure
         ill.append(pi)
     print(f"{scene}: 60/60 cycles with the reference's AIME tree ({min(n_nodes)}..{max(n_nodes)} nodes); same tree chosen in "
-          f"{same_choice}, better optimum in {better}, ill-conditioned candidate in {ill}")
+          f"{same_choice}, better optimum in {better}, ill-conditioned candidate in {ill}; (cycle, own cost of own / of the reference's choice, "
+          f"reference's cost of its own / of this planner's choice): {margins}")
     # floor = the count observed on the MI355X minus one (profiles/r03n_whole_runs.txt: 59 / 54 / 60 / 60 of 60 = 233 of 240; round 2:
     # 221); the waived cycles are listed in the line printed above
     assert max(n_nodes) > 1 and same_choice >= {"demo_1": 58, "demo_2": 53, "demo_3": 59, "demo_4": 59}[scene], same_choice
