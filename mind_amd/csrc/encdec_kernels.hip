@@ -215,10 +215,43 @@ __device__ __forceinline__ void dense(const float *in, int ldi, int K, const flo
 }
 
 // LayerNorm (+ReLU) over `n` features of each of R rows, in place; one wave per row (4 waves).
+#define LN_REGS 12      // elements per lane held in registers: rows of up to 768 features
 __device__ __forceinline__ void ln_rows(float *buf, int ld, int R, int n, const float *__restrict__ g,
                                         const float *__restrict__ be, bool relu) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int r = wave; r < R; r += nw) {
+    if (n <= 64 * LN_REGS) {
+      // the lane's elements and their affine parameters in registers: gamma / beta are requested BEFORE the two reductions instead of
+      // one dependent L2 round trip per element behind them (k_dec_scene's stage trace: 10 k cycles for the 768-wide row, 4 k for a
+      // 128-wide one).  Same accumulation order as the loop form below: same bits.
+      float xv[LN_REGS], gv[LN_REGS], bv[LN_REGS];
+#pragma unroll
+      for (int i = 0; i < LN_REGS; ++i) {
+        const int k = lane + 64 * i;
+        const bool in = k < n;
+        xv[i] = in ? buf[r * ld + k] : 0.f;
+        gv[i] = in ? g[k] : 0.f;
+        bv[i] = in ? be[k] : 0.f;
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_REGS; ++i) if (lane + 64 * i < n) s += xv[i];
+      const float mean = wave_sum(s) / (float)n;
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_REGS; ++i) if (lane + 64 * i < n) { const float d = xv[i] - mean; v = fmaf(d, d, v); }
+      const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)n + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < LN_REGS; ++i) {
+        const int k = lane + 64 * i;
+        if (k < n) {
+          float y = (xv[i] - mean) * rstd * gv[i] + bv[i];
+          if (relu) y = fmaxf(y, 0.f);
+          buf[r * ld + k] = y;
+        }
+      }
+      continue;
+    }
     float s = 0.f;
     for (int k = lane; k < n; k += 64) s += buf[r * ld + k];
     const float mean = wave_sum(s) / (float)n;
@@ -613,6 +646,13 @@ __global__ __launch_bounds__(DT) void k_dec_tgt(const float *__restrict__ tgt_fe
   if (tid < 128) tgt_out[(size_t)b * 128 + tid] = v0[0][tid];
 }
 
+#ifdef MIND_DEC_TRACE
+__device__ long long dec_tr_[64];
+__device__ int dec_trn_;
+#define DEC_MARK() do { if (blockIdx.x == 0 && threadIdx.x == 0) { dec_tr_[dec_trn_ & 63] = clock64(); ++dec_trn_; } } while (0)
+#else
+#define DEC_MARK() do {} while (0)
+#endif
 __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*[tokens,128]*/,
                                                   const int *__restrict__ cls_row /*[B]*/,
                                                   float *__restrict__ Cout /*[B,6,128]*/,
@@ -630,22 +670,31 @@ __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*
   const int PF = DEC_SCENE_PART;
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
+#ifdef MIND_DEC_TRACE
+  if (blockIdx.x == 0 && tid == 0) dec_trn_ = 0;
+#endif
+  DEC_MARK();
   // ---- ctx_proj: cls token -> 6 mode tokens (network.py:501)
   if (tid < 128) v0[0][tid] = x[(size_t)cls_row[b] * 128 + tid];
   __syncthreads();
   dense<1>(&v0[0][0], 256, 128, W.c0W, W.c0b, 384, &v1[0][0], 768, part, PF);
+  DEC_MARK();
   __syncthreads();
   ln_rows(&v1[0][0], 768, 1, 384, W.c0g, W.c0be, true);
+  DEC_MARK();
   __syncthreads();
   dense<1>(&v1[0][0], 768, 384, W.c3W, W.c3b, 768, &ff[0][0], 1536, part, PF);
+  DEC_MARK();
   __syncthreads();
   ln_rows(&ff[0][0], 1536, 1, 768, W.c3g, W.c3be, true);
+  DEC_MARK();
   __syncthreads();
   for (int i = tid; i < 768; i += blockDim.x) C[i / 128][i % 128] = ff[0][i];
   __syncthreads();
   // ---- 2 post-norm encoder layers over the 6 mode tokens (4 heads x 32, ffn 1536)
   for (int L = 0; L < 2; ++L) {
     dense<6>(&C[0][0], 128, 128, W.inW[L], W.inb[L], 384, &qkv[0][0], 384, part, PF);
+  DEC_MARK();
     __syncthreads();
     if (tid < 4 * 36) {
       const int hd = tid / 36, s = (tid % 36) / 6, t = tid % 6;
@@ -671,31 +720,40 @@ __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*
     }
     __syncthreads();
     dense<6>(&att[0][0], 128, 128, W.outW[L], W.outb[L], 128, &t2[0][0], 128, part, PF);
+  DEC_MARK();
     __syncthreads();
     for (int i = tid; i < 768; i += blockDim.x) C[i / 128][i % 128] += t2[i / 128][i % 128];
     __syncthreads();
     ln_rows(&C[0][0], 128, 6, 128, W.n1g[L], W.n1b[L], false);
+  DEC_MARK();
     __syncthreads();
     dense<6>(&C[0][0], 128, 128, W.l1W[L], W.l1b[L], 1536, &ff[0][0], 1536, part, PF);
+  DEC_MARK();
     __syncthreads();
     for (int i = tid; i < 6 * 1536; i += blockDim.x) ff[i / 1536][i % 1536] = fmaxf(ff[i / 1536][i % 1536], 0.f);
     __syncthreads();
     dense<6>(&ff[0][0], 1536, 1536, W.l2W[L], W.l2b[L], 128, &t2[0][0], 128, part, PF);
+  DEC_MARK();
     __syncthreads();
     for (int i = tid; i < 768; i += blockDim.x) C[i / 128][i % 128] += t2[i / 128][i % 128];
     __syncthreads();
     ln_rows(&C[0][0], 128, 6, 128, W.n2g[L], W.n2b[L], false);
+  DEC_MARK();
     __syncthreads();
   }
   for (int i = tid; i < 768; i += blockDim.x) Cout[(size_t)b * 768 + i] = C[i / 128][i % 128];
   // ---- cls head on the mode tokens only (network.py:512, Q6), softmax over the 6 modes
   dense<6>(&C[0][0], 128, 128, W.k0W, W.k0b, 128, &att[0][0], 128, part, PF);
+  DEC_MARK();
   __syncthreads();
   ln_rows(&att[0][0], 128, 6, 128, W.k0g, W.k0be, true);
+  DEC_MARK();
   __syncthreads();
   dense<6>(&att[0][0], 128, 128, W.k3W, W.k3b, 128, &t2[0][0], 128, part, PF);
+  DEC_MARK();
   __syncthreads();
   ln_rows(&t2[0][0], 128, 6, 128, W.k3g, W.k3be, true);
+  DEC_MARK();
   __syncthreads();
   for (int k = tid >> 6; k < 6; k += (int)(blockDim.x >> 6)) {
     const int lane = tid & 63;
@@ -711,6 +769,14 @@ __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*
     for (int k = 0; k < 6; ++k) { e[k] = expf(sc[0][0][k] - m); sum += e[k]; }
     for (int k = 0; k < 6; ++k) cls_out[(size_t)b * 6 + k] = e[k] / sum;
   }
+  DEC_MARK();
+#ifdef MIND_DEC_TRACE
+  if (blockIdx.x == 0 && tid == 0) {
+    printf("[k_dec_scene] cycles between marks (dense / LayerNorm stages in program order):");
+    for (int q = 1; q < dec_trn_ && q < 64; ++q) printf(" %lld", dec_tr_[q] - dec_tr_[q - 1]);
+    printf("\n");
+  }
+#endif
 }
 
 // =================================================================================================
