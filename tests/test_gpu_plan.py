@@ -760,4 +760,7 @@ def test_tree_ilqr_follows_the_reference_iteration_by_iteration(scene, variant):
           f"perturbed runs part, {own_noise} where this solver's own perturbed runs part, {behind_warm} full fits behind such a warm start, "
           f"unexplained: {early}")
     assert not early, early
-    assert same >= 0.8 * n_fits, (same, n_fits)
+    # every fit on which the reference reproduces ITSELF under rounding noise is followed iteration by iteration, up to the few that only
+    # this solver's own noise runs explain (the golden holds two perturbed reference runs per fit; observed: <= 2.3 % of a scene's fits)
+    n_ref_split = int(sum(1 for (r_, sp_) in fits.values() if sp_ < len(r_)))
+    assert same + own_noise + behind_warm >= n_fits - n_ref_split and own_noise <= max(3, 0.03 * n_fits), (same, own_noise, n_ref_split, n_fits)
