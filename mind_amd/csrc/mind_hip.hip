@@ -110,7 +110,7 @@ struct mind_ctx {
   DevBuf ilqr_dev, aime_dev, rebase_dev2[2], dec_h2;
   // mind_aime_plan (aime_plan.hip): device arenas, page-locked staging (uploads / read-backs are true async copies: a pageable
   // source makes hipMemcpyAsync wait for the stream to drain first), host result tables
-  DevBuf pl_root, pl_in[2], pl_lf, pl_lrep, pl_pred, pl_small, pl_tab[2], pl_win[2], pl_gather, pl_rows;
+  DevBuf pl_root, pl_in[2], pl_lf, pl_lrep, pl_pred, pl_small, pl_tab[2], pl_win[2];
   std::vector<DevBuf> pl_world;
   void *pl_pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // [4], [5]: upload / read-back staging of the tree-iLQR calls
   size_t pl_pin_cap[6] = {0, 0, 0, 0, 0, 0};
@@ -259,7 +259,7 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
       if (b->p) (void)hipFree(b->p);
   if (c->wdev) (void)hipFree(c->wdev);
   for (DevBuf *b : {&c->pl_root, &c->pl_in[0], &c->pl_in[1], &c->pl_lf, &c->pl_lrep, &c->pl_pred, &c->pl_small, &c->pl_tab[0], &c->pl_tab[1], &c->pl_win[0],
-                    &c->pl_win[1], &c->pl_gather, &c->pl_rows, &c->pl_flat})
+                    &c->pl_win[1], &c->pl_flat})
     if (b->p) (void)hipFree(b->p);
   for (DevBuf &b : c->pl_world)
     if (b.p) (void)hipFree(b.p);

@@ -154,6 +154,7 @@ def test_devscene_lazily_materialises_host_inputs():
     from bench import WORKLOADS, make_closed_loop
     from mind_amd.planners.mind.scenario_tree import DevScene
     pl, sim, w = make_closed_loop(dict(WORKLOADS["demo1"]))
+    pl.scen_tree_gen.native_aime = False         # DevScene is the round-by-round path's node type (mind_aime_plan keeps no host-side scene at all)
     sim.run_plans(1)
     gen = pl.scen_tree_gen
     devs = [n.data.obs_data for n in gen.tree.nodes.values() if isinstance(n.data.obs_data, DevScene)]
