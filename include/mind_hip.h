@@ -186,6 +186,16 @@ int mind_ilqr_contingency(mind_ctx *ctx, const mind_ilqr_cfg *cfg_warm, const mi
                           const mind_cost_tree *trees, int n_trees, const double *x0,
                           const double *target_lane, int n_lane_pts, double target_vel, double *xs,
                           double *us, mind_ilqr_stats *stats_warm, mind_ilqr_stats *stats_full);
+/* The same call in two halves, for a caller that has host work of its own while the kernel runs (the planner builds the scenario
+ * trees' Python objects meanwhile): _begin uploads, launches and queues the read-backs on the context stream and returns without
+ * waiting (trees / x0 / target_lane are consumed before it returns); mind_ilqr_finish waits and writes xs / us / stats_* -- those
+ * arrays must stay valid until then.  One call can be pending per context; another mind_ilqr_* call in between returns MIND_ESTATE,
+ * as does mind_ilqr_finish with nothing pending. */
+int mind_ilqr_contingency_begin(mind_ctx *ctx, const mind_ilqr_cfg *cfg_warm, const mind_ilqr_cfg *cfg_full,
+                                const mind_cost_tree *trees, int n_trees, const double *x0,
+                                const double *target_lane, int n_lane_pts, double target_vel, double *xs,
+                                double *us, mind_ilqr_stats *stats_warm, mind_ilqr_stats *stats_full);
+int mind_ilqr_finish(mind_ctx *ctx);
 
 /* ------------------------------------------------------------------------------------------------
  * AIME glue (k7): the arithmetic of ScenarioTreeGenerator.prune_merge (planners/mind/scenario_tree.py:

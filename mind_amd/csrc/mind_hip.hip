@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/mind_hip.h"
@@ -133,6 +134,8 @@ struct mind_ctx {
   int ilqr_multi = 0, ilqr_trees = 0;
   bool ilqr_test_starve = false;
   // per-iteration traces of the last tree-iLQR call (mind_last_ilqr_trace): device address per tree, rows per phase, iterations run
+  std::function<int()> il_finish;     // the pending half of a call begun with mind_ilqr_contingency_begin
+  bool il_begin_only = false;
   std::vector<const double *> il_trace_dev;
   std::vector<int> il_trace_its;      // [tree][phase 2]
   int il_trace_cap = 0, il_trace_phases = 0;
@@ -1242,6 +1245,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   const int use_exo_first = cfg2 ? 0 : use_exo;
   if (cfg2) use_exo = 1;
   if (!c || !cfg || !trees || n_trees <= 0 || !x0) return fail(c, MIND_EINVAL, "iLQR: bad argument");
+  if (c->il_finish) return fail(c, MIND_ESTATE, "a tree-iLQR call begun with mind_ilqr_contingency_begin has not been finished (mind_ilqr_finish)");
   if (!ev && (!xs || !us)) return fail(c, MIND_EINVAL, "iLQR: null output");
   if (!gen && (!target_lane || n_lane_pts < 2)) return fail(c, MIND_EINVAL, "iLQR: target lane needs >= 2 points");
   if (gen) { use_exo = 0; n_lane_pts = 0; }
@@ -1399,7 +1403,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   char *base = (char *)c->ilqr_dev.p;
   double *dD = (double *)base;                 // uploaded doubles: offsets < nd_in
   double *dW = (double *)(base + o_work);      // produced doubles: offsets >= nd_in
-  auto Dp = [&](size_t o) -> double * { return o < nd_in ? dD + o : dW + (o - nd_in); };
+  auto Dp = [=](size_t o) -> double * { return o < nd_in ? dD + o : dW + (o - nd_in); };
   float *dF = (float *)(base + bytesIn);
   int *dI = (int *)(base + bytesIn + bytesF);
   // host staging of the read-only part
@@ -1540,7 +1544,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     HIPCHK(c, hipEventRecord(c->ev_il0, st));
   }
   c->ilqr_trees = n_trees; c->ilqr_multi = multi ? G : 1; c->ilqr_ms = 0.f;
-  auto launch = [&](bool multi_) {
+  auto launch = [=](bool multi_) {
     if (gen) {
       hipLaunchKernelGGL((k_ilqr<true, false>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
     } else if (multi_) {
@@ -1565,6 +1569,11 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   HIPCHK(c, hipMemcpyAsync(hx, Dp(tl[0].xs), n_hx * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(hus, Dp(tl[0].us), n_us * sizeof(double), hipMemcpyDeviceToHost, st));
   if (multi) HIPCHK(c, hipMemcpyAsync(h_abort, dBars + 4 * (size_t)n_trees, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  // everything behind the launch -- the wait, the fallback of a launch that was not resident, the outputs -- as one closure over values:
+  // run at once, or kept in the context by mind_ilqr_contingency_begin and run by mind_ilqr_finish (the caller's thread is free meanwhile)
+  const size_t hs_size = hs.size();
+  std::function<int()> fin = [=]() -> int {
+  std::vector<double> hs(hs_size);
   HIPCHK(c, hipStreamSynchronize(st));
   if (c->profiling) HIPCHK(c, hipEventElapsedTime(&c->ilqr_ms, c->ev_il0, c->ev_il1));
   if (multi) {
@@ -1636,6 +1645,33 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     }
   }
   return MIND_OK;
+  };
+  if (c->il_begin_only) {
+    c->il_begin_only = false;
+    c->il_finish = std::move(fin);
+    return MIND_OK;
+  }
+  return fin();
+}
+
+extern "C" int mind_ilqr_contingency_begin(mind_ctx *c, const mind_ilqr_cfg *cfg_warm, const mind_ilqr_cfg *cfg_full,
+                                           const mind_cost_tree *trees, int n_trees, const double *x0, const double *target_lane,
+                                           int n_lane_pts, double target_vel, double *xs, double *us,
+                                           mind_ilqr_stats *stats_warm, mind_ilqr_stats *stats_full) {
+  if (!c || !cfg_full) return fail(c, MIND_EINVAL, "mind_ilqr_contingency_begin: null configuration");
+  c->il_begin_only = true;
+  const int rc = ilqr_impl(c, cfg_warm, nullptr, trees, n_trees, x0, target_lane, n_lane_pts, target_vel, 0, nullptr, xs, us, stats_warm, nullptr,
+                           cfg_full, stats_full);
+  c->il_begin_only = false;
+  return rc;
+}
+
+extern "C" int mind_ilqr_finish(mind_ctx *c) {
+  if (!c) return MIND_EINVAL;
+  if (!c->il_finish) return fail(c, MIND_ESTATE, "mind_ilqr_finish: no tree-iLQR call was begun on this context");
+  std::function<int()> fin = std::move(c->il_finish);
+  c->il_finish = nullptr;
+  return fin();
 }
 
 extern "C" int mind_ilqr_contingency(mind_ctx *c, const mind_ilqr_cfg *cfg_warm, const mind_ilqr_cfg *cfg_full,

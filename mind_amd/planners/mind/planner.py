@@ -157,7 +157,12 @@ class MINDPlanner:
         n0 = self.scen_tree_gen.n_expanded
         # warm-start fits of the previous cycle's tree shapes start now, beside the predictor (trajectory_tree.py)
         self.traj_tree_opt.speculate_warm(self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)
-        scen_trees = self.scen_tree_gen.branch_aime(lcl_smp, self.agent_obs)
+        # the native AIME plan hands its flattened cost trees over before the scenario trees exist as Python objects: the contingency
+        # solves start there, on a worker thread, and run while this thread builds the trees (solve_batch below collects them)
+        opt = self.traj_tree_opt
+        ahead = (lambda flats: opt.solve_batch_begin(flats, self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)) \
+            if hasattr(opt, "solve_batch_begin") else None
+        scen_trees = self.scen_tree_gen.branch_aime(lcl_smp, self.agent_obs, on_flats=ahead)
         t1 = time.perf_counter()
         if len(scen_trees) < 0:
             return False, None, None

@@ -246,8 +246,10 @@ class ScenarioTreeGenerator:
                 and (self.shard is None or not self.shard.sharded) and self.ego_idx == 0 and self.target_lane is not None
                 and len(self.target_lane) >= 12 and self.config is not None)
 
-    def _branch_aime_native(self, lcl_smp, agent_obs):
-        """branch_aime through mind_aime_plan; None = the library left this plan to the round-by-round path."""
+    def _branch_aime_native(self, lcl_smp, agent_obs, on_flats=None):
+        """branch_aime through mind_aime_plan; None = the library left this plan to the round-by-round path.  ``on_flats``: called
+        with the plan's flattened cost trees (in get_scenario_tree's order) as soon as the native call returns, BEFORE the tree's
+        Python objects are built -- the planner starts the contingency solves there (TrajectoryTreeOptimizer.solve_batch_begin)."""
         cfg = self.config
         if self.obs_len != 50 or not (2 <= self.pred_len <= 60):
             return None
@@ -280,6 +282,8 @@ class ScenarioTreeGenerator:
         if res is None:
             return None
         nodes, rows, info = res
+        if on_flats is not None:
+            on_flats([flat for _, flat in info["flats"]])
         rf = info["root_flags"]
         self.tree.add_node(Node("root", None, ScenarioData(None, root, branch_flag=bool(rf & 1), end_flag=bool(rf & 2), terminate_flag=bool(rf & 4))))
         a = info["a"]
@@ -308,9 +312,9 @@ class ScenarioTreeGenerator:
         self.last_trees = trees
         return trees
 
-    def branch_aime(self, lcl_smp, agent_obs):
+    def branch_aime(self, lcl_smp, agent_obs, on_flats=None):
         if self._native_ok():
-            trees = self._branch_aime_native(lcl_smp, agent_obs)
+            trees = self._branch_aime_native(lcl_smp, agent_obs, on_flats)
             if trees is not None:
                 return trees
             self.reset()            # (keeps lane graph / target lane: only the per-plan bookkeeping)

@@ -152,6 +152,10 @@ class TrajectoryTreeOptimizer:
         self._last_structs = []
         self._spec = None
         self._spec_skip, self._spec_backoff, self._spec_last = 0, 4, None     # back-off doubles after every failed probe (4 .. 256 cycles)
+        # contingency solves started ahead of solve_batch (solve_batch_begin): the kernel runs while the caller builds the scenario
+        # trees' Python objects
+        self.overlap = os.environ.get("MIND_ILQR_OVERLAP", "1") != "0"
+        self._pending = None
         self.counters = {"solves": 0, "iterations": 0, "warm_speculated": 0, "warm_hits": 0}
 
     def _runtime(self):
@@ -249,6 +253,39 @@ class TrajectoryTreeOptimizer:
                 hits[i] = (us[j], st[j])
         return hits
 
+    def solve_batch_begin(self, flats, init_state, init_ctrl, target_lane, target_vel):
+        """Start the contingency solves of a plan BEFORE its scenario trees exist as Python objects: `flats` are the flattened cost
+        trees mind_aime_plan returned with the plan.  mind_ilqr_contingency_begin queues upload, launch (warm-start + full fit of every
+        tree) and read-backs on this planner's own context and returns; the kernel runs while the caller builds the trees, and the next
+        solve_batch() with the same arguments collects it (mind_ilqr_finish) instead of launching.  (A worker thread for the blocking
+        call was measured first: 1 033 vs 1 083 sim steps/s -- the hand-over through the interpreter lock costs more than it hides.)  Only the plain case is taken ahead (no speculated warm start waiting, no shard,
+        no injected solver); returns whether a launch was started."""
+        self._drop_pending()
+        if not self.overlap or self.solver is not None or self.shard is not None or self._spec is not None or not flats:
+            return False
+        from ...predictor import IlqrCall
+        rt = self._runtime()
+        x0 = self._get_init_state(init_state, init_ctrl)
+        lane = np.asarray(target_lane, np.float64)
+        call = IlqrCall(rt.lib, ilqr_cfg_from(self.config, "w_opt_cfg"), flats, x0, lane, target_vel, cfg_full=ilqr_cfg_from(self.config, "opt_cfg"))
+        call.begin(rt)            # returns with the kernel queued; a failed begin is reported by the collecting solve_batch (call.finish)
+        self._pending = dict(call=call, flats=flats, x0=x0, lane=lane, tv=float(target_vel))
+        return True
+
+    def _drop_pending(self):
+        pend, self._pending = self._pending, None
+        if pend is not None:
+            pend["call"].wait()          # (a begun call must be finished before the context takes another one)
+
+    def _take_pending(self, flats, x0, lane, target_vel):
+        pend, self._pending = self._pending, None
+        if pend is None:
+            return None
+        pend["call"].wait()
+        same = (len(pend["flats"]) == len(flats) and np.array_equal(pend["x0"], x0) and np.array_equal(pend["lane"], lane) and pend["tv"] == float(target_vel)
+                and all(pf is f or all(np.array_equal(pf[k], f[k]) for k in ("parent", "prob", "mean", "cov")) for pf, f in zip(pend["flats"], flats)))
+        return pend["call"] if same else None
+
     # all scenario trees of one plan: 2 launches (warm start, full) instead of 2 x n_trees solves
     def solve_batch(self, scen_trees, init_state, init_ctrl, target_lane, target_vel):
         flats = [getattr(t, "_flat", None) or flatten_scenario_tree(t) for t in scen_trees]     # `_flat`: built by mind_aime_plan already
@@ -279,7 +316,10 @@ class TrajectoryTreeOptimizer:
                 miss_idx = [i for i in range(len(sub)) if i not in hits]
                 rt = self._runtime()
                 miss_call = miss_fut = None
-                if miss_idx:             # both fits, as without speculation
+                ahead = self._take_pending(sub, x0, lane, target_vel) if self.shard is None else None
+                if ahead is not None and not hit_idx:      # started by solve_batch_begin while the trees were being built
+                    miss_call = ahead
+                elif miss_idx:             # both fits, as without speculation
                     miss_call = IlqrCall(rt.lib, cfg_w, [sub[i] for i in miss_idx], x0, lane, target_vel, cfg_full=cfg_f)
                     if hit_idx:          # ... on the side context, beside the full fits of the guessed trees
                         miss_fut = self._side().submit(miss_call)

@@ -71,6 +71,26 @@ class IlqrCall:
                                                      len(self.lane), self.tv, self.use_exo, dp(self.ui), dp(self.xs), dp(self.us), self.st)
         return self
 
+    def begin(self, rt):
+        """upload + launch + queued read-backs of a contingency call (mind_ilqr_contingency_begin): returns without waiting for the
+        kernel; ``wait`` collects it.  The caller's thread is free in between (the planner builds its Python trees there)."""
+        assert self.cfg_full is not None and not self.background
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+        self.ctx = rt.ctx
+        if getattr(rt, "_ilqr_wgs_now", None) == 1:
+            rt._ilqr_wgs_now = getattr(rt, "_ilqr_wgs_user", int(os.environ.get("MIND_ILQR_WGS", "16")))
+            self.lib.mind_set_tuning(rt.ctx, b"ilqr_wgs", rt._ilqr_wgs_now)
+        self.rc = self.lib.mind_ilqr_contingency_begin(rt.ctx, C.byref(self.cfg), C.byref(self.cfg_full), self.trees, self.n, dp(self.x0),
+                                                       dp(self.lane), len(self.lane), self.tv, dp(self.xs), dp(self.us), self.st, self.st_full)
+        self._begun = self.rc == 0
+        return self
+
+    def wait(self):
+        if getattr(self, "_begun", False):
+            self._begun = False
+            self.rc = self.lib.mind_ilqr_finish(self.ctx)
+        return self
+
     def finish(self):
         name = "mind_ilqr_contingency" if self.cfg_full is not None else "mind_ilqr_solve_trees"
         _lib.check(self.lib, self.ctx, self.rc, name)

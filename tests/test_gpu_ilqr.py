@@ -294,3 +294,26 @@ def test_iteration_trace_equals_the_oracles(kind, a, max_iter, hip_predictor):
     finally:
         hip_predictor.set_tuning("ilqr_multi_min", 192)
         hip_predictor.set_tuning("ilqr_wgs", 16)
+
+
+def test_contingency_in_two_halves_equals_the_one_call(hip_predictor):
+    """mind_ilqr_contingency_begin / mind_ilqr_finish (the planner builds its scenario trees' Python objects between the two): the same
+    results as the blocking call, bit for bit; one call pending per context, and nothing to finish without a begin."""
+    from mind_amd import _lib
+    from mind_amd.predictor import IlqrCall
+    sst = scripted_scenario_tree("branch3", 40)
+    cfg_w, cfg_f = oi.default_cfg(max_iter=100), oi.default_cfg(max_iter=100)
+    cfg_w.w_ego = cfg_w.w_exo = 0.0
+    flats = [oi.flatten(sst["nodes"]), oi.flatten(scripted_scenario_tree("straight", 40, seed=2)["nodes"])]
+    x0 = oi.init_state(sst["state"], sst["ctrl"])
+    ref = hip_predictor.ilqr_contingency(cfg_w, cfg_f, flats, x0, sst["target_lane"], sst["target_vel"])
+    call = IlqrCall(hip_predictor.lib, cfg_w, flats, x0, sst["target_lane"], sst["target_vel"], cfg_full=cfg_f)
+    call.begin(hip_predictor)
+    with pytest.raises(_lib.MindError):                       # the context holds a begun call: no other tree-iLQR call in between
+        hip_predictor.ilqr_contingency(cfg_w, cfg_f, flats, x0, sst["target_lane"], sst["target_vel"])
+    xs, us, sw, sf = call.wait().finish()
+    for t in range(2):
+        assert np.array_equal(xs[t], ref[0][t]) and np.array_equal(us[t], ref[1][t]) and sw[t] == ref[2][t] and sf[t] == ref[3][t]
+    assert hip_predictor.lib.mind_ilqr_finish(hip_predictor.ctx) == _lib.MIND_ESTATE
+    again = hip_predictor.ilqr_contingency(cfg_w, cfg_f, flats, x0, sst["target_lane"], sst["target_vel"])      # the context is free again
+    assert np.array_equal(again[0][0], ref[0][0])
