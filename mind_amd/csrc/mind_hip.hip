@@ -76,13 +76,19 @@ struct mind_ctx {
   AmW actorBW;   // the same convolutions as bf16 hi / lo MFMA fragments (actor_mfma_kernels.hip)
   DecW decW;
   TokWeights tokW[7];  // [L]: epilogue of layer L-1 (L>=1) + prologue of layer L (L<=5); [0] = init
-  TokWeightsM tokWM[7]; // the same matrices as fp32 MFMA A fragments (k_token_mfma)
+  TokWeightsM tokWM[7]; // the same matrices as fp32 MFMA A fragments (k_token_mfma<0>)
+  TokWeightsM tokWB[7]; // ... and as bf16 hi / lo A fragments (k_token_mfma<1>: scenes of >= tok_bf_min_n tokens)
   // token kernel on the fp32 MFMA (k_token_mfma; MIND_TOK_MFMA=1 / mind_set_tuning("tok_mfma")).  Opt-in: measured on the MI355X it is
   // SLOWER than the VALU kernel -- 41 vs 30 us per launch at demo size (6 workgroups), 315 vs 282 us average on the full cfg4 tree
   // (profiles/r03o_*, r03p_*): 640 fp32 MFMAs of 32 cycles per wave and launch are 8.5 us by themselves and the weight stream (64 KB per
   // projection and workgroup) is the same; a bf16-split variant would cut the MFMA time, not the rest
   bool tok_mfma = false;
   bool tgt_side = true;         // the target polyline's encoder + embedding stay on the side stream through the fusion layers ("tgt_side")
+  // scenes of at least this many tokens run k_token_mfma<1> (bf16 hi + lo split operands) under the bf16 arithmetics ("tok_bf_min_n";
+  // 0 = never, the default).  Measured on the cfg4 full tree (N = 321, launches of up to 69 k tokens): 221 us per launch on average and
+  // 0.80 ms for the largest, the same as the VALU kernel (which is LDS-bound there) -- with 97 KB of LDS the MFMA kernel keeps one
+  // four-wave workgroup per CU and waits on its partial-sum and fragment loads instead (profiles/r03bb); opt-in until it is faster
+  int tok_bf_min_n = 0;
   int tok_small_max = 2048;     // batches of at most this many tokens run k_token with 4 tokens per workgroup ("tok_small_max")
   const float *WAe[6], *WAp[6], *vtab[6], *rtab = nullptr;
   const u32 *WBe[6], *WBp[6];   // bf16 hi / lo fragments of the same matrices (pair_bf16_kernels.hip)
@@ -235,9 +241,11 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   (void)hipFuncSetAttribute((const void *)k_ilqr<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
   if (const char *te = getenv("MIND_TOK_MFMA")) c->tok_mfma = !(te[0] == '0');
   if (const char *te = getenv("MIND_TOK_SMALL_MAX")) c->tok_small_max = atoi(te);
+  if (const char *te = getenv("MIND_TOK_BF_MIN_N")) c->tok_bf_min_n = atoi(te);
   if (const char *te = getenv("MIND_TGT_SIDE")) c->tgt_side = !(te[0] == '0');
   if (const char *te = getenv("MIND_PL_TAB_SIDE")) c->pl_tab_side = !(te[0] == '0');
-  (void)hipFuncSetAttribute((const void *)k_token_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_token_mfma_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_token_mfma<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_token_mfma_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_token_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_token_mfma_lds_bytes());
   if (const char *we = getenv("MIND_ILQR_CHUNK")) c->ilqr_chunk = atoi(we) < 0 ? 0 : atoi(we);
   if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
@@ -302,6 +310,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "dec_overlap") c->dec_overlap = value != 0;
   else if (n == "tok_mfma") c->tok_mfma = value != 0;
   else if (n == "tok_small_max") c->tok_small_max = (int)value;
+  else if (n == "tok_bf_min_n") c->tok_bf_min_n = (int)value;
   else if (n == "tgt_side") c->tgt_side = value != 0;
   else if (n == "pl_tab_side") c->pl_tab_side = value != 0;
   else if (n == "ilqr_chunk") c->ilqr_chunk = value < 0 ? 0 : (int)value;
@@ -473,6 +482,33 @@ std::vector<float> pack_bfrag(const std::vector<float> &w, int row_stride) {
   return out;
 }
 
+// k_token_mfma<1> (bf16 hi + lo split operands): A fragments of a [128 out] x [128 in] block of w (row stride row_stride) for the bf16 MFMA
+// 16x16x32 in NATURAL k order -- the B operand is read from an fp32 LDS tile, 8 consecutive features per lane --:
+// [ob 8][s 8 = part * 4 + g][lane 64][dword 4]; dword d of lane (r = lane & 15, q = lane >> 4) packs W[16 ob + r][32 g + 8 q + 2 d (+ 1)].
+// Same addressing as pack_afrag's (tm_load reads both), returned as float bit patterns (16384 dwords).
+std::vector<float> pack_tok_bfrag(const float *w, int row_stride) {
+  std::vector<uint32_t> t(16384, 0u);
+  if (w)
+    for (int ob = 0; ob < 8; ++ob)
+      for (int g = 0; g < 4; ++g)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int d = 0; d < 4; ++d) {
+            uint32_t hi = 0, lo = 0;
+            for (int e = 0; e < 2; ++e) {
+              const float x = w[(size_t)(16 * ob + (lane & 15)) * row_stride + 32 * g + 8 * (lane >> 4) + 2 * d + e];
+              const uint16_t h = bf16_rne(x);
+              const uint16_t l = bf16_rne(x - bf16_to_f32(h));
+              hi |= (uint32_t)h << (16 * e);
+              lo |= (uint32_t)l << (16 * e);
+            }
+            t[((size_t)(ob * 8 + g) * 64 + lane) * 4 + d] = hi;
+            t[((size_t)(ob * 8 + 4 + g) * 64 + lane) * 4 + d] = lo;
+          }
+  std::vector<float> f(16384);
+  memcpy(f.data(), t.data(), 16384 * sizeof(float));
+  return f;
+}
+
 // LayerNorm is invariant to a shift along the features: fold the mean subtraction of the LayerNorm that follows a Linear
 // into the Linear ((I - 11^T/n) W, (I - 11^T/n) b).  W is [n_out][n_in] row-major.
 void center_outputs(std::vector<float> &W, std::vector<float> &b, int n_out, int n_in) {
@@ -610,6 +646,8 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
   lin_ln("fus.pl", "fusion_net.proj_lane", 0, 128, 128);
   B.add("fus.pa.WM", pack_afrag(sd.get("fusion_net.proj_actor.0.weight", 128 * 128), 128));      // the same as fp32 MFMA A fragments (k_token_mfma)
   B.add("fus.pl.WM", pack_afrag(sd.get("fusion_net.proj_lane.0.weight", 128 * 128), 128));
+  B.add("fus.pa.WB", pack_tok_bfrag(sd.get("fusion_net.proj_actor.0.weight", 128 * 128), 128));     // ... and as bf16 hi / lo fragments (k_token_mfma<1>)
+  B.add("fus.pl.WB", pack_tok_bfrag(sd.get("fusion_net.proj_lane.0.weight", 128 * 128), 128));
   {
     // rpe table [32 chunks][8][4]: k<5 W_r[f][k], 5 bias, 6 gamma, 7 beta, f = 4 chunk + w
     const float *W = sd.get("fusion_net.proj_rpe_scene.0.weight", 128 * 5);
@@ -675,6 +713,16 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
       B.add(k + ".W1bM", pack_afrag(W1_ ? W1_ + 128 * 128 : nullptr, 128));
       B.add(k + ".W2aM", pack_afrag(W2_, 256));
       B.add(k + ".W2bM", pack_afrag(W2_ ? W2_ + 128 : nullptr, 256));
+      // ... and as bf16 hi / lo A fragments (k_token_mfma<1>; the folded K query keeps the fp32 fragments)
+      B.add(k + ".WsB", pack_tok_bfrag(Wm + 128, 384));
+      B.add(k + ".WtB", pack_tok_bfrag(Wm + 256, 384));
+      B.add(k + ".WqB", pack_tok_bfrag(Win, 128));
+      B.add(k + ".WvB", pack_tok_bfrag(Win ? Win + 2 * 128 * 128 : nullptr, 128));
+      B.add(k + ".WoB", pack_tok_bfrag(Wo_, 128));
+      B.add(k + ".W1aB", pack_tok_bfrag(W1_, 128));
+      B.add(k + ".W1bB", pack_tok_bfrag(W1_ ? W1_ + 128 * 128 : nullptr, 128));
+      B.add(k + ".W2aB", pack_tok_bfrag(W2_, 256));
+      B.add(k + ".W2bB", pack_tok_bfrag(W2_ ? W2_ + 128 : nullptr, 256));
     }
     B.add(k + ".WqT", transpose(Win, 128, 128));
     B.add(k + ".Wk", vec(Win ? Win + 128 * 128 : nullptr, 128 * 128));
@@ -827,6 +875,17 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
       m.Ws = P(k + ".WsM"); m.Wt = P(k + ".WtM"); m.Wq = P(k + ".WqM"); m.Wkf = P(k + ".WkM");
     }
     m.Wpa = P("fus.pa.WM"); m.Wpl = P("fus.pl.WM");
+    TokWeightsM &bm = c->tokWB[L];
+    memset(&bm, 0, sizeof(bm));
+    if (L >= 1) {
+      std::string k = "fus.L" + std::to_string(L - 1);
+      bm.Wv = P(k + ".WvB"); bm.Wo = P(k + ".WoB"); bm.W1a = P(k + ".W1aB"); bm.W1b = P(k + ".W1bB"); bm.W2a = P(k + ".W2aB"); bm.W2b = P(k + ".W2bB");
+    }
+    if (L <= 5) {
+      std::string k = "fus.L" + std::to_string(L);
+      bm.Ws = P(k + ".WsB"); bm.Wt = P(k + ".WtB"); bm.Wq = P(k + ".WqB"); bm.Wkf = P(k + ".WkM");
+    }
+    bm.Wpa = P("fus.pa.WB"); bm.Wpl = P("fus.pl.WB");
   }
   DecW &d = c->decW;
   d.rpeW = P("dec.rpe.W"); d.rpeb = P("dec.rpe.b"); d.rpeg = P("dec.rpe.g"); d.rpebe = P("dec.rpe.be");
@@ -1074,19 +1133,43 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   if (c->side && !c->tgt_side) HIPCHK(c, hipStreamWaitEvent(st, c->ev_tgt, 0));
 
   // ---- fusion: init tokens + 6 x (pair kernel, token kernel)
-  // small batches: four tokens per k_token workgroup (more workgroups, half the LDS operand traffic each; bit-identical results)
-  const bool tok_small = ntok <= c->tok_small_max;
-  const int tok_tpw = tok_small ? TOK_TPW_SMALL : TOK_TPW_BIG;
-  const int tok_blocks = (ntok + tok_tpw - 1) / tok_tpw;
+  // The token kernel by SCENE (a scene's result must not depend on what else is in its batch): scenes of at least tok_bf_min_n tokens
+  // under the bf16 pair-kernel arithmetics run k_token_mfma<1> (bf16 hi + lo split operands on the MFMA, 16 tokens per workgroup: the
+  // VALU kernel is LDS-bound at those sizes), every other scene the VALU kernel -- consecutive scenes of one class share a launch, small
+  // launches take four tokens per workgroup (more workgroups, half the LDS operand traffic each; bit-identical to eight)
   const int qsplit = c->pair_prec != 0 ? 16 : 0;      // the bf16 pair kernels read the folded query as hi / lo fragments
-  const int tokm_blocks = (ntok + TM_TOK - 1) / TM_TOK;
   const size_t tokm_lds = mind_token_mfma_lds_bytes();
-  if (c->tok_mfma)
-    hipLaunchKernelGGL(k_token_mfma, dim3(tokm_blocks), dim3(TM_THREADS), tokm_lds, st, dmeta, ntok, 1 | 4 | qsplit, actor_feat, lane_feat, x, part, ST, QK,
-                       c->tokW[0], c->tokWM[0]);
-  else
-    hipLaunchKernelGGL(tok_small ? k_token<TOK_TPW_SMALL> : k_token<TOK_TPW_BIG>, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok,
-                       1 | 4 | qsplit, actor_feat, lane_feat, x, part, ST, QK, c->tokW[0]);
+  struct TokRun { int t0, n, kind; };                  // kind 0: VALU, 1: fp32 MFMA (opt-in), 2: bf16 split MFMA
+  std::vector<TokRun> tok_runs;
+  {
+    int t0 = 0;
+    for (int b = 0; b < Bn; ++b) {
+      const int N = (in->actor_off[b + 1] - in->actor_off[b]) + (in->lane_off[b + 1] - in->lane_off[b]) + 1;
+      const int kind = c->tok_mfma ? 1 : (c->pair_prec != 0 && c->tok_bf_min_n > 0 && N >= c->tok_bf_min_n) ? 2 : 0;
+      if (!tok_runs.empty() && tok_runs.back().kind == kind) tok_runs.back().n += N;
+      else tok_runs.push_back({t0, N, kind});
+      t0 += N;
+    }
+  }
+  auto launch_tokens = [&](int mode, int Lw) {
+    for (const TokRun &r : tok_runs) {
+      const TokMeta *m_ = dmeta + r.t0;
+      float *x_ = x + (size_t)r.t0 * 128, *ST_ = ST + (size_t)r.t0 * 256, *QK_ = QK + (size_t)r.t0 * 1024;
+      if (r.kind == 0) {
+        const bool small = r.n <= c->tok_small_max;
+        const int tpw = small ? TOK_TPW_SMALL : TOK_TPW_BIG;
+        hipLaunchKernelGGL(small ? k_token<TOK_TPW_SMALL> : k_token<TOK_TPW_BIG>, dim3((r.n + tpw - 1) / tpw), dim3(TT_THREADS), 0, st, m_, r.n, mode,
+                           actor_feat, lane_feat, x_, part, ST_, QK_, c->tokW[Lw]);
+      } else if (r.kind == 1) {
+        hipLaunchKernelGGL(k_token_mfma<0>, dim3((r.n + TM_TOK - 1) / TM_TOK), dim3(TM_THREADS), tokm_lds, st, m_, r.n, mode, actor_feat, lane_feat, x_,
+                           part, ST_, QK_, c->tokW[Lw], c->tokWM[Lw]);
+      } else {
+        hipLaunchKernelGGL(k_token_mfma<1>, dim3((r.n + TM_TOK - 1) / TM_TOK), dim3(TM_THREADS), tokm_lds, st, m_, r.n, mode, actor_feat, lane_feat, x_,
+                           part, ST_, QK_, c->tokW[Lw], c->tokWB[Lw]);
+      }
+    }
+  };
+  launch_tokens(1 | 4 | qsplit, 0);
   int grid = njobs < c->n_cu ? njobs : c->n_cu;      // jobs are dealt wave-major over the workgroups
   const size_t lds = mind_pair_lds_bytes();
   c->n_pair_launch = 0;
@@ -1123,12 +1206,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
     c->n_pair_launch++;
     c->pairs_done += (L == 5) ? pairs_l5 : pairs_full;
     const int mode = 2 | (L < 5 ? 4 : 8) | qsplit;
-    if (c->tok_mfma)
-      hipLaunchKernelGGL(k_token_mfma, dim3(tokm_blocks), dim3(TM_THREADS), tokm_lds, st, dmeta, ntok, mode, actor_feat, lane_feat, x, part, ST, QK,
-                         c->tokW[L + 1], c->tokWM[L + 1]);
-    else
-      hipLaunchKernelGGL(tok_small ? k_token<TOK_TPW_SMALL> : k_token<TOK_TPW_BIG>, dim3(tok_blocks), dim3(TT_THREADS), 0, st, dmeta, ntok,
-                         mode, actor_feat, lane_feat, x, part, ST, QK, c->tokW[L + 1]);
+    launch_tokens(mode, L + 1);
   }
   // ---- decoder
   const int *d_actor_row = (const int *)ts->rows.p;

@@ -34,7 +34,41 @@ __device__ __forceinline__ void tm_load(TmFrag &F, const float *__restrict__ Wf,
 }
 // acc[t] (+)= W[16 (ob0 + t) .. +16][0..128) x X^T, t = 0, 1.  xb: this lane's B row = token (lane & 15) of a [16][ldb] tile; a non-zero
 // ob_stride selects a different tile per output block (the V projection reads head ob's normalised sum)
+template <int BF>
 __device__ __forceinline__ void tm_mma(tm_f4 (&acc)[2], const TmFrag &F, int ob0, const float *xb, int ob_stride, int lane) {
+  if (BF) {
+    // bf16 hi + lo split operands on v_mfma_f32_16x16x32_bf16 (the three significant products, fp32 accumulate: the arithmetic of
+    // k_pair_bf): F.a?[g] = hi fragment of k-group g, F.a?[4 + g] = lo (pack_tok_bfrag); the B operand of a lane = 8 consecutive
+    // features 32 g + 8 q .. of its token, split here
+    const float *b0p = xb + 8 * (lane >> 4) + (size_t)ob0 * ob_stride;
+    const float *b1p = b0p + ob_stride;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      u32x4 bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t == 1 && !ob_stride) { bh[1] = bh[0]; bl[1] = bl[0]; break; }
+        const float *bp = (t ? b1p : b0p) + 32 * g;
+        const tm_f4 x0 = *reinterpret_cast<const tm_f4 *>(bp), x1 = *reinterpret_cast<const tm_f4 *>(bp + 4);
+        const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const u32 h = pk_bf16(v[2 * d], v[2 * d + 1]);
+          bh[t][d] = h;
+          bl[t][d] = pk_bf16(v[2 * d] - bf_lo_f32(h), v[2 * d + 1] - bf_hi_f32(h));
+        }
+      }
+      const u32x4 a0h = __builtin_bit_cast(u32x4, F.a0[g]), a0l = __builtin_bit_cast(u32x4, F.a0[4 + g]);
+      const u32x4 a1h = __builtin_bit_cast(u32x4, F.a1[g]), a1l = __builtin_bit_cast(u32x4, F.a1[4 + g]);
+      acc[0] = MFMA_BF(a0l, bh[0], acc[0]);
+      acc[1] = MFMA_BF(a1l, bh[1], acc[1]);
+      acc[0] = MFMA_BF(a0h, bl[0], acc[0]);
+      acc[1] = MFMA_BF(a1h, bl[1], acc[1]);
+      acc[0] = MFMA_BF(a0h, bh[0], acc[0]);
+      acc[1] = MFMA_BF(a1h, bh[1], acc[1]);
+    }
+    return;
+  }
   const float *b0p = xb + 4 * (lane >> 4) + (size_t)ob0 * ob_stride;
   const float *b1p = b0p + ob_stride;
 #pragma unroll
@@ -48,10 +82,11 @@ __device__ __forceinline__ void tm_mma(tm_f4 (&acc)[2], const TmFrag &F, int ob0
     }
   }
 }
+template <int BF>
 __device__ __forceinline__ void tm_gemm(tm_f4 (&acc)[2], const float *__restrict__ Wf, int ob0, const float *xb, int ob_stride, int lane) {
   TmFrag F;
   tm_load(F, Wf, ob0, lane);
-  tm_mma(acc, F, ob0, xb, ob_stride, lane);
+  tm_mma<BF>(acc, F, ob0, xb, ob_stride, lane);
 }
 
 // D element i of a lane: feature 16 ob + 4 (lane >> 4) + i of token lane & 15
@@ -81,6 +116,9 @@ __device__ __forceinline__ void tm_layernorm(float *tile, int ld, const float *_
   }
 }
 
+// BF = 0: fp32 MFMA (opt-in, mind_set_tuning("tok_mfma")); BF = 1: bf16 hi + lo split operands, the token kernel of scenes of at least
+// tok_bf_min_n tokens under the bf16 pair-kernel arithmetics (the folded K query stays on the fp32 MFMA: 16-wide contractions)
+template <int BF>
 __global__ __launch_bounds__(TM_THREADS) void k_token_mfma(const TokMeta *__restrict__ meta, int n_tok, int mode, const float *__restrict__ actor_feat,
                                                            const float *__restrict__ lane_feat, float *__restrict__ x, const float *__restrict__ part,
                                                            float *__restrict__ ST, float *__restrict__ QK, TokWeights W, TokWeightsM WM) {
@@ -114,8 +152,8 @@ __global__ __launch_bounds__(TM_THREADS) void k_token_mfma(const TokMeta *__rest
     __syncthreads();
     const int ty = tk_ok ? meta[tok0 + tk].type : 2;
     tm_f4 aa[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, al[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    tm_gemm(aa, WM.Wpa, ob0, tmp + tk * TM_LDT, 0, lane);
-    tm_gemm(al, WM.Wpl, ob0, tmp + tk * TM_LDT, 0, lane);
+    tm_gemm<BF>(aa, WM.Wpa, ob0, tmp + tk * TM_LDT, 0, lane);
+    tm_gemm<BF>(al, WM.Wpl, ob0, tmp + tk * TM_LDT, 0, lane);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -206,7 +244,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_token_mfma(const TokMeta *__rest
     TmFrag F1a, F1b;
     {
       tm_f4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-      tm_mma(acc, Fv, ob0, mb + (size_t)tk * 8 * TM_LDX, TM_LDX, lane);
+      tm_mma<BF>(acc, Fv, ob0, mb + (size_t)tk * 8 * TM_LDX, TM_LDX, lane);
       tm_load(Fo, WM.Wo, ob0, lane);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -217,7 +255,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_token_mfma(const TokMeta *__rest
     // ---- att = W_o o + b_o ; x1 = LN2(x + att)
     {
       tm_f4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-      tm_mma(acc, Fo, ob0, tmp + tk * TM_LDT, 0, lane);
+      tm_mma<BF>(acc, Fo, ob0, tmp + tk * TM_LDT, 0, lane);
       tm_load(F1a, WM.W1a, ob0, lane);
       tm_load(F1b, WM.W1b, ob0, lane);
 #pragma unroll
@@ -231,9 +269,9 @@ __global__ __launch_bounds__(TM_THREADS) void k_token_mfma(const TokMeta *__rest
     // ---- FFN 128 -> 256 -> 128, x2 = LN3(x1 + ff)
     {
       tm_f4 h0[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, h1[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-      tm_mma(h0, F1a, ob0, xs + tk * TM_LDX, 0, lane);
+      tm_mma<BF>(h0, F1a, ob0, xs + tk * TM_LDX, 0, lane);
       tm_load(F1a, WM.W2a, ob0, lane);                  // (the fragment registers of W1a now carry W2a, those of W1b W2b)
-      tm_mma(h1, F1b, ob0, xs + tk * TM_LDX, 0, lane);
+      tm_mma<BF>(h1, F1b, ob0, xs + tk * TM_LDX, 0, lane);
       tm_load(F1b, WM.W2b, ob0, lane);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -247,8 +285,8 @@ __global__ __launch_bounds__(TM_THREADS) void k_token_mfma(const TokMeta *__rest
     __syncthreads();
     {
       tm_f4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-      tm_mma(acc, F1a, ob0, tmp + tk * TM_LDT, 0, lane);
-      tm_mma(acc, F1b, ob0, tmp + tk * TM_LDT + 128, 0, lane);
+      tm_mma<BF>(acc, F1a, ob0, tmp + tk * TM_LDT, 0, lane);
+      tm_mma<BF>(acc, F1b, ob0, tmp + tk * TM_LDT + 128, 0, lane);
       if (mode & 4) { tm_load(Fv, WM.Ws, ob0, lane); tm_load(Fo, WM.Wt, ob0, lane); }      // the prologue's first two projections
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -270,9 +308,9 @@ __global__ __launch_bounds__(TM_THREADS) void k_token_mfma(const TokMeta *__rest
       TmFrag Fq;
       tm_load(Fq, WM.Wq, ob0, lane);
       if (!pre) { tm_load(Fv, WM.Ws, ob0, lane); tm_load(Fo, WM.Wt, ob0, lane); }
-      tm_mma(as, Fv, ob0, xs + tk * TM_LDX, 0, lane);
-      tm_mma(at, Fo, ob0, xs + tk * TM_LDX, 0, lane);
-      tm_mma(aq, Fq, ob0, xs + tk * TM_LDX, 0, lane);
+      tm_mma<BF>(as, Fv, ob0, xs + tk * TM_LDX, 0, lane);
+      tm_mma<BF>(at, Fo, ob0, xs + tk * TM_LDX, 0, lane);
+      tm_mma<BF>(aq, Fq, ob0, xs + tk * TM_LDX, 0, lane);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll

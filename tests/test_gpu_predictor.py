@@ -254,3 +254,35 @@ def test_token_kernel_tokens_per_workgroup_do_not_change_results(a, l, B, seed, 
         hip_predictor.set_tuning("tok_small_max", 2048)
     for k in ("cls", "reg", "vel"):
         assert torch.equal(big[k], small[k]), k
+
+
+def test_token_kernel_of_big_scenes_on_the_bf16_split_mfma(hip_predictor, formula_sd):
+    """With mind_set_tuning("tok_bf_min_n", 256) scenes of >= 256 tokens run their per-token epilogue / prologue on k_token_mfma<1> (bf16
+    hi + lo split operands, the pair kernel's arithmetic): against the oracle at the cfg4 scene size, against the VALU kernel it
+    replaces there, and -- the kernel is chosen scene by scene -- a big scene's result is the same bits whether it is predicted alone
+    or in a batch with a small scene (which keeps the VALU kernel)."""
+    big = predictor_batch(64, 256, 1, seed=21)
+    small = predictor_batch(9, 21, 1, seed=2)
+    oc, orr, ov = op.forward(formula_sd, to_t(big))
+    valu = {k: v.clone() for k, v in hip_predictor.predict_numpy_batch(big).items() if torch.is_tensor(v)}
+    try:
+        hip_predictor.set_tuning("tok_bf_min_n", 256)          # (opt-in: measured no faster than the VALU kernel at this size)
+        out = {k: v.clone() for k, v in hip_predictor.predict_numpy_batch(big).items() if torch.is_tensor(v)}
+        alone_small = {k: v.clone() for k, v in hip_predictor.predict_numpy_batch(small).items() if torch.is_tensor(v)}
+        _mixed_check(hip_predictor, small, big, alone_small, out)
+    finally:
+        hip_predictor.set_tuning("tok_bf_min_n", 0)
+    assert np.abs(out["reg"].cpu().numpy() - orr[0].numpy()).max() < TOL and np.abs(out["vel"].cpu().numpy() - ov[0].numpy()).max() < TOL
+    assert (out["reg"] - valu["reg"]).abs().max().item() < 5e-5
+    assert not torch.equal(out["reg"], valu["reg"])                      # it really was the other kernel
+
+
+def _mixed_check(hip_predictor, small, big, alone_small, out):
+    # mixed batch: [small scene, big scene] -> two token launches per layer, the big scene's bits unchanged
+    mixed = {"ACTORS": np.concatenate([small["ACTORS"], big["ACTORS"]]), "LANES": np.concatenate([small["LANES"], big["LANES"]]),
+             "ACTOR_IDCS": [np.arange(9), np.arange(9, 73)], "LANE_IDCS": [np.arange(21), np.arange(21, 277)],
+             "CTRS": small["CTRS"] + big["CTRS"], "VECS": small["VECS"] + big["VECS"],
+             "TGT_NODES": np.concatenate([small["TGT_NODES"], big["TGT_NODES"]]), "TGT_RPE": np.concatenate([small["TGT_RPE"], big["TGT_RPE"]])}
+    both = hip_predictor.predict_numpy_batch(mixed)
+    assert torch.equal(both["reg"][:9], alone_small["reg"]) and torch.equal(both["reg"][9:], out["reg"])
+    assert torch.equal(both["cls"][0], alone_small["cls"][0]) and torch.equal(both["cls"][1], out["cls"][0])
