@@ -744,7 +744,20 @@ __global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       float v[8];
 #pragma unroll
       for (int hd = 0; hd < 8; ++hd) v[hd] = 0.f;
-      for (int s = 0; s < ns; ++s) {
+      // two splits' loads in flight at a time (the partials of a big batch come from HBM: one round trip per split was the longest
+      // stage of a big launch, MIND_TOKEN_TRACE); the accumulation order over the splits is unchanged
+      int s = 0;
+      for (; s + 2 <= ns; s += 2) {
+        const float *ps = part + (size_t)(slot0 + s) * PART_STRIDE + 16 + col;
+        float pv[8], pw[8];
+#pragma unroll
+        for (int hd = 0; hd < 8; ++hd) { pv[hd] = ps[hd * 128]; pw[hd] = ps[PART_STRIDE + hd * 128]; }
+#pragma unroll
+        for (int hd = 0; hd < 8; ++hd) v[hd] = fmaf(cw[t][hd][s], pv[hd], v[hd]);
+#pragma unroll
+        for (int hd = 0; hd < 8; ++hd) v[hd] = fmaf(cw[t][hd][s + 1], pw[hd], v[hd]);
+      }
+      if (s < ns) {
         const float *ps = part + (size_t)(slot0 + s) * PART_STRIDE + 16 + col;
         float pv[8];
 #pragma unroll

@@ -15,6 +15,8 @@
 #define TM_THREADS 256
 #define TM_LDX 132     // row stride of the 128-wide token tiles (floats)
 #define TM_LDT 260     // row stride of the 256-wide scratch tile
+#define TM_HP 2        // heads per pass of the partial-sum merge / V projection: the merged sums of TM_HP heads live in LDS at a time
+                       // (all eight: 68 KB of the kernel's 97 KB = one four-wave workgroup per CU; two: 46 KB = three workgroups)
 
 struct TokWeightsM {   // A-fragment packings (pack_afrag) of the matrices TokWeights holds transposed
   const float *Wv, *Wo, *W1a, *W1b, *W2a, *W2b;     // epilogue of layer L-1 (W1: output halves; W2: input halves)
@@ -125,8 +127,8 @@ __global__ __launch_bounds__(TM_THREADS) void k_token_mfma(const TokMeta *__rest
   extern __shared__ __attribute__((aligned(16))) float tm_sm[];
   float *xs = tm_sm;                              // [16][132]  current token vectors
   float *tmp = xs + TM_TOK * TM_LDX;              // [16][260]  scratch (o / h1 / q)
-  float *mb = tmp + TM_TOK * TM_LDT;              // [16][8][132] normalised sum p*mem per head
-  float *cw = mb + TM_TOK * 8 * TM_LDX;           // [16][8][8]  combine weights per (token, head, split)
+  float *mb = tmp + TM_TOK * TM_LDT;              // [16][TM_HP][132] normalised sum p*mem per head, TM_HP heads per pass
+  float *cw = mb + TM_TOK * TM_HP * TM_LDX;       // [16][8][8]  combine weights per (token, head, split)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tok0 = blockIdx.x * TM_TOK;
   const int nt = min(TM_TOK, n_tok - tok0);
@@ -208,50 +210,53 @@ __global__ __launch_bounds__(TM_THREADS) void k_token_mfma(const TokMeta *__rest
     }
     __syncthreads();
     tm_load(Fv, WM.Wv, ob0, lane);       // the V projection's weights travel while the partials are combined
-    {
-      // mb[t][hd][col] = sum_s cw[t][hd][s] part[slot0 + s][16 + hd * 128 + col]: thread = (token, group of 8 columns); the sixteen
-      // float4 of a split (8 heads x 2) are requested together
-      const int t = tid >> 4, c8 = (tid & 15) * 8;
-      int ns = 0, slot0 = 0;
-      if (t < nt) {
-        const TokMeta m = meta[tok0 + t];
-        ns = ((mode & 8) && !(m.flags & 1)) ? 0 : m.nsplit;
-        slot0 = m.slot0;
-      }
-      tm_f4 v[8][2];
+    TmFrag F1a, F1b;
+    // TM_HP heads per pass: merge their partial sums into mb, then the waves whose output blocks (= heads) they are run the V projection
+    // o = W_v,h mbar_h + b_v  (output block ob = head ob reads that head's normalised sum)
+    for (int h0_ = 0; h0_ < 8; h0_ += TM_HP) {
+      {
+        // mb[t][hd - h0_][col] = sum_s cw[t][hd][s] part[slot0 + s][16 + hd * 128 + col]: thread = (token, group of 8 columns); the
+        // float4 pairs of a split's TM_HP heads are requested together
+        const int t = tid >> 4, c8 = (tid & 15) * 8;
+        int ns = 0, slot0 = 0;
+        if (t < nt) {
+          const TokMeta m = meta[tok0 + t];
+          ns = ((mode & 8) && !(m.flags & 1)) ? 0 : m.nsplit;
+          slot0 = m.slot0;
+        }
+        tm_f4 v[TM_HP][2];
 #pragma unroll
-      for (int hd = 0; hd < 8; ++hd) { v[hd][0] = tm_f4{0, 0, 0, 0}; v[hd][1] = tm_f4{0, 0, 0, 0}; }
-      for (int sp = 0; sp < ns; ++sp) {
-        const tm_f4 *ps = reinterpret_cast<const tm_f4 *>(part + (size_t)(slot0 + sp) * PART_STRIDE + 16 + c8);
-        tm_f4 pv[8][2];
+        for (int hd = 0; hd < TM_HP; ++hd) { v[hd][0] = tm_f4{0, 0, 0, 0}; v[hd][1] = tm_f4{0, 0, 0, 0}; }
+        for (int sp = 0; sp < ns; ++sp) {
+          const tm_f4 *ps = reinterpret_cast<const tm_f4 *>(part + (size_t)(slot0 + sp) * PART_STRIDE + 16 + (size_t)h0_ * 128 + c8);
+          tm_f4 pv[TM_HP][2];
 #pragma unroll
-        for (int hd = 0; hd < 8; ++hd) { pv[hd][0] = ps[hd * 32]; pv[hd][1] = ps[hd * 32 + 1]; }
+          for (int hd = 0; hd < TM_HP; ++hd) { pv[hd][0] = ps[hd * 32]; pv[hd][1] = ps[hd * 32 + 1]; }
 #pragma unroll
-        for (int hd = 0; hd < 8; ++hd) {
-          const float wgt = cw[(t * 8 + hd) * 8 + sp];
+          for (int hd = 0; hd < TM_HP; ++hd) {
+            const float wgt = cw[(t * 8 + h0_ + hd) * 8 + sp];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { v[hd][0][k] = fmaf(wgt, pv[hd][0][k], v[hd][0][k]); v[hd][1][k] = fmaf(wgt, pv[hd][1][k], v[hd][1][k]); }
+            for (int k = 0; k < 4; ++k) { v[hd][0][k] = fmaf(wgt, pv[hd][0][k], v[hd][0][k]); v[hd][1][k] = fmaf(wgt, pv[hd][1][k], v[hd][1][k]); }
+          }
+        }
+#pragma unroll
+        for (int hd = 0; hd < TM_HP; ++hd) {
+          *reinterpret_cast<tm_f4 *>(mb + (t * TM_HP + hd) * TM_LDX + c8) = v[hd][0];
+          *reinterpret_cast<tm_f4 *>(mb + (t * TM_HP + hd) * TM_LDX + c8 + 4) = v[hd][1];
         }
       }
+      __syncthreads();
+      if (ob0 >= h0_ && ob0 < h0_ + TM_HP) {       // (wave-uniform: this wave's two output blocks are heads ob0, ob0 + 1)
+        tm_f4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        tm_mma<BF>(acc, Fv, ob0 - h0_, mb + (size_t)tk * TM_HP * TM_LDX, TM_LDX, lane);
 #pragma unroll
-      for (int hd = 0; hd < 8; ++hd) {
-        *reinterpret_cast<tm_f4 *>(mb + (t * 8 + hd) * TM_LDX + c8) = v[hd][0];
-        *reinterpret_cast<tm_f4 *>(mb + (t * 8 + hd) * TM_LDX + c8 + 4) = v[hd][1];
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const int f = TM_FEAT(ob0 + t, i); tmp[tk * TM_LDT + f] = acc[t][i] + W.bv[f]; }
       }
+      __syncthreads();
     }
-    __syncthreads();
-    // ---- o = W_v,h mbar_h + b_v  (output block ob = head ob reads that head's normalised sum)
-    TmFrag F1a, F1b;
-    {
-      tm_f4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-      tm_mma<BF>(acc, Fv, ob0, mb + (size_t)tk * 8 * TM_LDX, TM_LDX, lane);
-      tm_load(Fo, WM.Wo, ob0, lane);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const int f = TM_FEAT(ob0 + t, i); tmp[tk * TM_LDT + f] = acc[t][i] + W.bv[f]; }
-    }
-    __syncthreads();
+    tm_load(Fo, WM.Wo, ob0, lane);
     // ---- att = W_o o + b_o ; x1 = LN2(x + att)
     {
       tm_f4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -361,5 +366,5 @@ __global__ __launch_bounds__(TM_THREADS) void k_token_mfma(const TokMeta *__rest
 }
 
 static inline size_t mind_token_mfma_lds_bytes() {
-  return (size_t)(TM_TOK * TM_LDX + TM_TOK * TM_LDT + TM_TOK * 8 * TM_LDX + TM_TOK * 64) * sizeof(float);
+  return (size_t)(TM_TOK * TM_LDX + TM_TOK * TM_LDT + TM_TOK * TM_HP * TM_LDX + TM_TOK * 64) * sizeof(float);
 }
