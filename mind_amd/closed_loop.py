@@ -45,6 +45,13 @@ class ClosedLoopSim:
         gt_lane = getattr(world, "gt_tgt_lane", None)
         planner.update_target_lane(np.asarray(world.target_lane[::2], dtype=np.float64) if gt_lane is None else gt_lane)
         self._valid = getattr(world, "is_valid", None)
+        self._exo_ahead = None
+        import os
+        if os.environ.get("MIND_PREFETCH_OBS", "1") != "0" and hasattr(planner, "plan") and not callable(getattr(planner, "idle_hook", None)):
+            try:
+                planner.idle_hook = self._prefetch_observation      # (MINDPlanner calls it while the device computes; other planners ignore it)
+            except AttributeError:
+                pass
         self._start_episode()
 
     def _start_episode(self):
@@ -55,6 +62,7 @@ class ClosedLoopSim:
         self.ctrl = np.array([0.0, 0.0])
         self.timestep = 0.0
         self.last_result = None
+        self._exo_ahead = None
         self._episode_plan0 = self.n_plans
         if hasattr(self.planner, "agent_obs"):
             self.planner.agent_obs.clear()
@@ -68,14 +76,33 @@ class ClosedLoopSim:
         self.run_until(self.enable_time)
         self.n_steps = n
 
+    def _exo_observation(self, t):
+        w = self.world
+        return [SimpleNamespace(state=w.agent_state(i, t), type=w.object_type(i), id=w.agent_ids[i],
+                                timestep=int(round(t / 0.1))) for i in range(1, w.n_agents)
+                if self._valid is None or self._valid(i, t)]
+
+    def _prefetch_observation(self):
+        """planner idle hook (MINDPlanner.idle_hook: called while the device computes the contingency solves): the replayed agents of the
+        NEXT planning step do not depend on this plan -- their observation list is built now and picked up by _observation() if the
+        simulator time it was built for is exactly the one that comes (the same float additions are replayed here)."""
+        t = self.sim_time
+        for _ in range(int(round(self.PLAN_STEP / self.SIM_STEP))):
+            t += self.SIM_STEP
+        exo = self._exo_observation(t)
+        to_state = getattr(self.planner, "to_object_state", None)
+        if to_state is not None:
+            for a in exo:
+                a.obj_state = to_state(a)
+        self._exo_ahead = (t, exo)
+
     def _observation(self):
         t = self.sim_time
         w = self.world
         ego_state = self.state if self.enabled else w.agent_state(0, t)
         ego = SimpleNamespace(state=ego_state, type=w.object_type(0), id="AV", timestep=int(round(t / 0.1)))
-        exo = [SimpleNamespace(state=w.agent_state(i, t), type=w.object_type(i), id=w.agent_ids[i],
-                               timestep=int(round(t / 0.1))) for i in range(1, w.n_agents)
-               if self._valid is None or self._valid(i, t)]
+        ahead, self._exo_ahead = getattr(self, "_exo_ahead", None), None
+        exo = ahead[1] if ahead is not None and ahead[0] == t else self._exo_observation(t)
         return SimpleNamespace(ego_agent=ego, exo_agents=exo, map_data=w, target_lane=w.target_lane,
                                target_lane_info=w.target_lane_info, target_velocity=w.target_velocity)
 

@@ -113,7 +113,8 @@ class MINDPlanner:
         for agent in lcl_smp.exo_agents:
             if agent.id not in self.agent_obs:
                 self.agent_obs[agent.id] = Track(agent.id, [], agent.type, TrackCategory.TRACK_FRAGMENT)
-            self.agent_obs[agent.id].object_states.append(self.to_object_state(agent))
+            # (a driver that builds the replayed agents ahead of time -- ClosedLoopSim's idle hook -- may attach their ObjectState)
+            self.agent_obs[agent.id].object_states.append(getattr(agent, "obj_state", None) or self.to_object_state(agent))
             seen.add(agent.id)
         for tr in self.agent_obs.values():
             if tr.track_id not in seen:
@@ -163,6 +164,11 @@ class MINDPlanner:
         ahead = (lambda flats: opt.solve_batch_begin(flats, self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)) \
             if hasattr(opt, "solve_batch_begin") else None
         scen_trees = self.scen_tree_gen.branch_aime(lcl_smp, self.agent_obs, on_flats=ahead)
+        # the device is busy with the contingency solves begun above: a caller's hook runs here (the closed-loop driver prefetches the next
+        # replayed observation), the solves are collected afterwards
+        hook = getattr(self, "idle_hook", None)
+        if hook is not None and getattr(opt, "_pending", None) is not None:
+            hook()
         t1 = time.perf_counter()
         if len(scen_trees) < 0:
             return False, None, None
@@ -210,7 +216,15 @@ class MINDPlanner:
         return self._solve_and_select(lcl_smp, scen_trees, t0, t1, n0)
 
     def resample_target_lane(self, lcl_smp):
-        """1 m resampling of the target lane and its per-point info (planner.py:147-171)."""
+        """1 m resampling of the target lane and its per-point info (planner.py:147-171).  A replayed scene hands over the SAME lane /
+        info objects every cycle: the result is kept while they are (the arrays are only read downstream)."""
+        key = getattr(self, "_rtl_key", None)
+        if key is not None and key[0] is lcl_smp.target_lane and key[1] is lcl_smp.target_lane_info:
+            return self._rtl_val
+        self._rtl_key, self._rtl_val = (lcl_smp.target_lane, lcl_smp.target_lane_info), self._resample_target_lane(lcl_smp)
+        return self._rtl_val
+
+    def _resample_target_lane(self, lcl_smp):
         lane = np.asarray(lcl_smp.target_lane)
         infos = lcl_smp.target_lane_info
         seg = lane[1:] - lane[:-1]
