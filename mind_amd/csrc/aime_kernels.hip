@@ -196,6 +196,7 @@ __global__ __launch_bounds__(64) void k_aime_select(const AimeScene *__restrict_
 // them.  One workgroup per child scene; float32 like the reference.
 // -------------------------------------------------------------------------------------------------
 #define RB_THREADS 256
+#define RB_FEAT_BLOCKS(a) ((int)(((size_t)(a) * 48 + RB_THREADS - 1) / RB_THREADS))     // feature blocks per scene (k_aime_rebase grid y = 1 + this)
 #define RB_T 50
 
 struct RebaseArgs {
@@ -329,12 +330,18 @@ __global__ __launch_bounds__(RB_THREADS) void k_aime_rebase(RebaseArgs A) {
     const float ci = cosf(thi), si = sinf(thi);
     float *o = rb_sm + 5 * i;
     o[0] = cx; o[1] = cy; o[2] = thi; o[3] = ci; o[4] = si;
-    A.actor_ctrs[((size_t)sc * a + i) * 2] = cx; A.actor_ctrs[((size_t)sc * a + i) * 2 + 1] = cy;
-    A.actor_vecs[((size_t)sc * a + i) * 2] = ci; A.actor_vecs[((size_t)sc * a + i) * 2 + 1] = si;
+    if (blockIdx.y == 0) {
+      A.actor_ctrs[((size_t)sc * a + i) * 2] = cx; A.actor_ctrs[((size_t)sc * a + i) * 2 + 1] = cy;
+      A.actor_vecs[((size_t)sc * a + i) * 2] = ci; A.actor_vecs[((size_t)sc * a + i) * 2 + 1] = si;
+    }
   }
   __syncthreads();
+  // grid (scenes, 1 + RB_FEAT_BLOCKS(a)): block y = 0 of a scene writes its frames, lane anchors and target window, blocks y >= 1 one slice
+  // of the [a,14,48] actor features each (every block derives the per-agent frames it needs itself: same expressions, same bits) -- the
+  // kernel sits on the plan's critical path between two AIME rounds (34 us as one workgroup per scene)
+  const int fb = (int)blockIdx.y - 1, nfb = (int)gridDim.y - 1;
   // ---- actor features [a,14,48]: displacement, heading cos/sin, velocity, type one-hot, pad flag; steps 2..49
-  for (int e = tid; e < a * 48; e += RB_THREADS) {
+  for (int e = (nfb > 0 ? fb * RB_THREADS : 0) + tid; nfb > 0 ? (fb >= 0 && e < min(a * 48, (fb + 1) * RB_THREADS)) : e < a * 48; e += RB_THREADS) {
     const int i = e / 48, t = e % 48 + 2;
     const float *f = rb_sm + 5 * i;
     float pn[2][2];
@@ -360,6 +367,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_aime_rebase(RebaseArgs A) {
     for (int k = 0; k < 7; ++k) o[(6 + k) * 48] = A.types[(i * RB_T + t) * 7 + k];
     o[13 * 48] = A.pad ? A.pad[((size_t)sc * a + i) * RB_T + t] : 1.0f;
   }
+  if (fb >= 0) return;
   // ---- lane anchors in the new frame (utils.py:171-177)
   for (int q = tid; q < A.l; q += RB_THREADS) {
     const float dx = A.lane_ctrs0[2 * q] - ox, dy = A.lane_ctrs0[2 * q + 1] - oy;

@@ -91,7 +91,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     R.time_ahead = in->time_ahead; R.min_vel = in->min_vel; R.travel0 = in->travel0;
     R.actors = d + o_actors; R.actor_ctrs = d + o_ctrs; R.actor_vecs = d + o_vecs; R.lane_ctrs = nullptr; R.lane_vecs = nullptr;
     R.tgt_nodes = d + o_tn; R.tgt_rpe = d + o_tr; R.frames = d + o_fr;
-    hipLaunchKernelGGL(k_aime_rebase, dim3(1), dim3(RB_THREADS), 5 * (size_t)a * sizeof(float), st, R);
+    hipLaunchKernelGGL(k_aime_rebase, dim3(1, 1 + RB_FEAT_BLOCKS(a)), dim3(RB_THREADS), 5 * (size_t)a * sizeof(float), st, R);
     hipLaunchKernelGGL(k_aime_root_lanes, dim3(l), dim3(64), 0, st, (const double *)(d + o_lpts), (const int *)(d + o_lfl), (const float *)(d + o_fr),
                        d + o_lc, d + o_lv, d + o_lanes);
     hipLaunchKernelGGL(k_aime_root_hist, dim3(a), dim3(64), 0, st, (const float *)(d + o_rpos), (const float *)(d + o_rang), (const float *)(d + o_rvel),
@@ -334,7 +334,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     R.time_ahead = in->time_ahead; R.min_vel = in->min_vel; R.travel0 = -1.f;
     R.actors = d_in + q.actors; R.actor_ctrs = d_in + q.ctrs; R.actor_vecs = d_in + q.vecs; R.lane_ctrs = d_in + q.lc; R.lane_vecs = d_in + q.lv;
     R.tgt_nodes = d_in + q.tn; R.tgt_rpe = d_in + q.tr; R.frames = d_in + q.fr;
-    hipLaunchKernelGGL(k_aime_rebase, dim3((unsigned)S), dim3(RB_THREADS), 5 * (size_t)a * sizeof(float), st, R);
+    hipLaunchKernelGGL(k_aime_rebase, dim3((unsigned)S, 1 + RB_FEAT_BLOCKS(a)), dim3(RB_THREADS), 5 * (size_t)a * sizeof(float), st, R);
     if (S > 1) {
       if ((rc = ensure(c, c->pl_lrep, (size_t)S * l * 128 * sizeof(float)))) return rc;
       const size_t n = (size_t)l * 128;

@@ -1921,7 +1921,7 @@ extern "C" int mind_aime_rebase(mind_ctx *c, const mind_rebase_in *in, const min
   A.time_ahead = in->time_ahead; A.min_vel = in->min_vel; A.travel0 = -1.f;
   A.actors = out->actors; A.actor_ctrs = out->actor_ctrs; A.actor_vecs = out->actor_vecs; A.lane_ctrs = out->lane_ctrs;
   A.lane_vecs = out->lane_vecs; A.tgt_nodes = out->tgt_nodes; A.tgt_rpe = out->tgt_rpe; A.frames = out->frames;
-  hipLaunchKernelGGL(k_aime_rebase, dim3((unsigned)S), dim3(RB_THREADS), 5 * a * sizeof(float), st, A);
+  hipLaunchKernelGGL(k_aime_rebase, dim3((unsigned)S, 1 + RB_FEAT_BLOCKS(a)), dim3(RB_THREADS), 5 * a * sizeof(float), st, A);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(st));     // the caller's host arrays may be reused after return
   return MIND_OK;
