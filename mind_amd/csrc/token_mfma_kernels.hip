@@ -15,8 +15,9 @@
 #define TM_THREADS 256
 #define TM_LDX 132     // row stride of the 128-wide token tiles (floats)
 #define TM_LDT 260     // row stride of the 256-wide scratch tile
-#define TM_HP 2        // heads per pass of the partial-sum merge / V projection: the merged sums of TM_HP heads live in LDS at a time
-                       // (all eight: 68 KB of the kernel's 97 KB = one four-wave workgroup per CU; two: 46 KB = three workgroups)
+#define TM_HP 8        // heads per pass of the partial-sum merge / V projection: the merged sums of TM_HP heads live in LDS at a time (all
+                       // eight: 68 KB of the kernel's 97 KB = one four-wave workgroup per CU; two at a time = 46 KB = three workgroups
+                       // per CU measured no faster on the cfg4 tree -- 234 vs 221 us per launch -- so one pass it is)
 
 struct TokWeightsM {   // A-fragment packings (pack_afrag) of the matrices TokWeights holds transposed
   const float *Wv, *Wo, *W1a, *W1b, *W2a, *W2b;     // epilogue of layer L-1 (W1: output halves; W2: input halves)
