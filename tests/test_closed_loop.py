@@ -56,6 +56,52 @@ def test_trigger_schedule_matches_reference_counts():
     assert abs(sim.state[2] - (w.agent_speed[0] + 0.5 * 0.02 * 300)) < 0.2 or sim.state[2] == 15.0    # accelerating ego
 
 
+class _HookPlanner(_StubPlanner):
+    """a planner that calls its idle hook once per plan, as MINDPlanner does while the device computes; records every observation"""
+
+    def __init__(self, call_hook):
+        super().__init__()
+        self.call_hook, self.seen = call_hook, []
+
+    def to_object_state(self, agent):
+        return ("state", agent.id, tuple(np.asarray(agent.state).tolist()), agent.timestep)
+
+    def update_observation(self, lcl):
+        super().update_observation(lcl)
+        self.seen.append([(a.id, tuple(np.asarray(a.state).tolist()), a.timestep, getattr(a, "obj_state", None)) for a in lcl.exo_agents])
+
+    def plan(self, lcl):
+        res = super().plan(lcl)
+        hook = getattr(self, "idle_hook", None)
+        if self.call_hook and hook is not None:
+            hook()
+        return res
+
+
+def test_observation_built_ahead_in_the_idle_hook_is_the_observation_that_comes():
+    """ClosedLoopSim registers MINDPlanner.idle_hook: the replayed agents of the NEXT planning step (and their ObjectStates) are built
+    while the device computes and used only if the simulator reaches exactly the time they were built for -- every observation the
+    planner sees must be the one it would have seen without the hook, episode restarts included."""
+    runs = []
+    for call_hook in (True, False):
+        w = SynthWorld(n_agents=5, n_lanes=2, n_segs=6, seed=2)
+        p = _HookPlanner(call_hook)
+        sim = ClosedLoopSim(w, p, episode_plans=20)
+        assert callable(getattr(p, "idle_hook", None))
+        sim.run_plans(45)                                   # two episode restarts on the way
+        runs.append(p)
+    a, b = runs
+    assert len(a.seen) == len(b.seen) > 45 and a.plans == b.plans
+    used = 0
+    for fa, fb in zip(a.seen, b.seen):
+        assert [x[:3] for x in fa] == [x[:3] for x in fb]
+        for x in fa:
+            if x[3] is not None:                             # built ahead: the attached ObjectState is the planner's own conversion
+                assert x[3] == ("state", x[0], x[1], x[2])
+                used += 1
+    assert used > 100 and all(x[3] is None for f in b.seen for x in f)
+
+
 @pytest.mark.gpu
 def test_closed_loop_with_real_planner():
     import os
