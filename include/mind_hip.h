@@ -356,6 +356,12 @@ typedef struct {
  * max_rounds rounds -- in which case the caller runs that path instead. */
 int mind_aime_plan(mind_ctx *ctx, const mind_aime_plan_in *in, mind_aime_plan_out *out);
 
+/* The array part of get_agent_trajectories (planners/mind/utils.py:245-342): raw [a,T,6] float64 rows (observed flag, x, y, heading, vx,
+ * vy; T = 50) of the kept tracks, slot [a] = the type one-hot position of every track -> pos [a,T,2], ang [a,T], vel [a,T,2] float32 with the
+ * positions / headings of unobserved steps taken from the nearest earlier observed step (the first observed one before it), velocities zero
+ * there, typ [a,T,7] int16 one-hot on observed steps, have [a,T] int16.  Host arithmetic (copies and casts), no context needed. */
+int mind_fill_tracks(const double *raw, int a, int T, const int32_t *slot, float *pos, float *ang, float *vel, int16_t *typ, int16_t *have);
+
 /* MINDPlanner.evaluate_traj_tree (planners/mind/planner.py:180-198) for every candidate trajectory tree of a plan (host arithmetic,
  * float64, numpy's operation and summation order): states [sum counts, 6], ctrls [sum counts, 2] = the trees' nodes in key order, root
  * (x0, zero control) first; lane [P,2] float32 (lane_is_f32 != 0) or float64; out[n_trees] = mean node cost.  Needs no context. */

@@ -1979,6 +1979,37 @@ void eval_nodes(const double *st, const double *ct, long N, const T *lane, int P
 }
 }  // namespace
 
+// get_agent_trajectories' array part (planners/mind/utils.py:245-342 of the reference: per track the observed flags, positions and headings
+// of unobserved steps taken from the nearest earlier observed one -- the first observed one before it --, velocities zero there, the type
+// one-hot on observed steps) for all tracks at once; host arithmetic, plain copies and float64 -> float32 casts.
+extern "C" int mind_fill_tracks(const double *raw /*[a,T,6]: observed, x, y, heading, vx, vy*/, int a, int T, const int32_t *slot /*[a]*/,
+                                float *pos /*[a,T,2]*/, float *ang /*[a,T]*/, float *vel /*[a,T,2]*/, int16_t *typ /*[a,T,7]*/,
+                                int16_t *have /*[a,T]*/) {
+  if (!raw || !slot || !pos || !ang || !vel || !typ || !have || a < 0 || T <= 0) return MIND_EINVAL;
+  for (int i = 0; i < a; ++i) {
+    const double *r = raw + (size_t)i * T * 6;
+    int first = 0;
+    for (int t = 0; t < T; ++t)
+      if (r[t * 6] != 0.0) { first = t; break; }       // np.argmax(have): the first observed step (0 when none is)
+    int src = -1;
+    for (int t = 0; t < T; ++t) {
+      const bool h = r[t * 6] != 0.0;
+      if (h) src = t;
+      const int f = src < 0 ? first : src;
+      const bool hf = r[f * 6] != 0.0;                  // (a track without any observed step fills with zeros, as np.where(have, raw, 0) does)
+      const size_t o = (size_t)i * T + t;
+      pos[2 * o] = hf ? (float)r[f * 6 + 1] : 0.f;
+      pos[2 * o + 1] = hf ? (float)r[f * 6 + 2] : 0.f;
+      ang[o] = hf ? (float)r[f * 6 + 3] : 0.f;
+      vel[2 * o] = h ? (float)r[t * 6 + 4] : 0.f;
+      vel[2 * o + 1] = h ? (float)r[t * 6 + 5] : 0.f;
+      have[o] = h ? 1 : 0;
+      for (int k = 0; k < 7; ++k) typ[o * 7 + k] = (h && k == slot[i]) ? 1 : 0;
+    }
+  }
+  return MIND_OK;
+}
+
 extern "C" int mind_eval_traj_trees(const double *states, const double *ctrls, const int32_t *counts, int n_trees, const void *lane,
                                     int lane_is_f32, int n_lane_pts, double target_vel, double *out) {
   if (!states || !ctrls || !counts || n_trees <= 0 || !lane || n_lane_pts < 2 || !out) return MIND_EINVAL;

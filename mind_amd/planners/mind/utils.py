@@ -61,6 +61,36 @@ def _nn_fill(vals, have):
     return vals[fwd]
 
 
+_FILL_LIB = []
+
+
+def _fill_lib():
+    """libmind_hip.so for its host-side track routine, or None (MIND_NATIVE_TRACKS=0, library not built): the numpy form below is the same arithmetic"""
+    if not _FILL_LIB:
+        import os
+        lib = None
+        if os.environ.get("MIND_NATIVE_TRACKS", "1") != "0":
+            try:
+                from ... import _lib
+                lib = _lib.load()
+            except Exception:      # noqa: BLE001
+                lib = None
+        _FILL_LIB.append(lib)
+    return _FILL_LIB[0]
+
+
+def _track_slot(tr):
+    """one-hot slot of a track's object type (constant per track: kept on the Track object when it takes attributes)"""
+    slot = getattr(tr, "_type_slot", None)
+    if slot is None:
+        slot = _TYPE_SLOT.get(_name(tr.object_type), 6)
+        try:
+            tr._type_slot = slot
+        except AttributeError:
+            pass
+    return slot
+
+
 def _agent_trajectories_full_windows(agent_obs, keys, order):
     """Same result as the per-agent loop of get_agent_trajectories, all agents in one set of array ops.  Needs the
     array mirror of every kept track (maintained by MINDPlanner.update_observation); tracks shorter than OBS_LEN
@@ -81,6 +111,16 @@ def _agent_trajectories_full_windows(agent_obs, keys, order):
         raws.append(raw)
     raw = np.stack(raws)                                   # [a,50,6] float64
     a = len(sel)
+    lib = _fill_lib()
+    if lib is not None and raw.dtype == np.float64:
+        # the same arrays from the library's host routine (mind_fill_tracks: copies and casts, no device involved)
+        raw = np.ascontiguousarray(raw)
+        slot = np.array([_track_slot(tr) for _, _, tr in sel], np.int32)
+        pos, ang, vel = np.empty((a, OBS_LEN, 2), F32), np.empty((a, OBS_LEN), F32), np.empty((a, OBS_LEN, 2), F32)
+        typ, have = np.empty((a, OBS_LEN, 7), np.int16), np.empty((a, OBS_LEN), np.int16)
+        if lib.mind_fill_tracks(raw.ctypes.data, a, OBS_LEN, slot.ctypes.data, pos.ctypes.data, ang.ctypes.data, vel.ctypes.data, typ.ctypes.data,
+                                have.ctypes.data) == 0:
+            return pos, ang, vel, typ, have, [k for _, k, _ in sel], ["av" if r == 0 else "exo" for r, _, _ in sel]
     have = raw[..., 0] != 0
     pos = np.where(have[..., None], raw[..., 1:3], 0.0)
     ang = np.where(have, raw[..., 3], 0.0)
@@ -91,7 +131,7 @@ def _agent_trajectories_full_windows(agent_obs, keys, order):
     fwd = np.where(fwd < 0, first[:, None], fwd)
     rows = np.arange(a)[:, None]
     pos, ang = pos[rows, fwd], ang[rows, fwd]
-    slot = np.array([_TYPE_SLOT.get(_name(tr.object_type), 6) for _, _, tr in sel])
+    slot = np.array([_track_slot(tr) for _, _, tr in sel])
     typ = np.zeros((a, OBS_LEN, 7), np.int16)
     typ[rows, np.arange(OBS_LEN)[None, :], slot[:, None]] = have
     return (pos.astype(F32), ang.astype(F32), vel.astype(F32), typ, have.astype(np.int16),
