@@ -195,6 +195,11 @@ int mind_ilqr_contingency_begin(mind_ctx *ctx, const mind_ilqr_cfg *cfg_warm, co
                                 const mind_cost_tree *trees, int n_trees, const double *x0,
                                 const double *target_lane, int n_lane_pts, double target_vel, double *xs,
                                 double *us, mind_ilqr_stats *stats_warm, mind_ilqr_stats *stats_full);
+/* ... on the cost trees the last mind_aime_plan of this context flattened (mind_aime_plan_out.flat_*: n_trees trees of tree_off[t+1] -
+ * tree_off[t] nodes): the tree arrays stay inside the library.  xs / us: [tree_off[n_trees], 6 / 2], stats_*: [n_trees]. */
+int mind_ilqr_contingency_begin_plan(mind_ctx *ctx, const mind_ilqr_cfg *cfg_warm, const mind_ilqr_cfg *cfg_full, const double *x0,
+                                     const double *target_lane, int n_lane_pts, double target_vel, double *xs, double *us,
+                                     mind_ilqr_stats *stats_warm, mind_ilqr_stats *stats_full);
 int mind_ilqr_finish(mind_ctx *ctx);
 
 /* ------------------------------------------------------------------------------------------------

@@ -51,6 +51,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   if (in->script_cls && (!in->script_reg || !in->script_vel)) return fail(c, MIND_EINVAL, "mind_aime_plan: scripted modes need cls, reg and vel");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = c->stream;
+  c->pl_plan_agents = 0; c->pl_tree_top.clear();      // (the previous plan's cost trees are gone whatever happens below)
   if (!c->ev_pl) HIPCHK(c, hipEventCreateWithFlags(&c->ev_pl, hipEventDisableTiming));
   if (!c->ev_tab) HIPCHK(c, hipEventCreateWithFlags(&c->ev_tab, hipEventDisableTiming));
   if (!c->pl_copy) HIPCHK(c, hipStreamCreateWithFlags(&c->pl_copy, hipStreamNonBlocking));
@@ -444,6 +445,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     c->pl_tree_off.push_back(base + count);
   }
   const size_t Mtot = (size_t)c->pl_tree_off.back();
+  c->pl_plan_agents = a;
   c->pl_flat_mean.resize(Mtot * a * 2); c->pl_flat_cov.resize(Mtot * a);
   c->pl_rows_host.resize((size_t)n_rows);
   // one upload (both job tables), the two gather kernels, one read-back (rows | flat means | flat covariances)

@@ -129,6 +129,7 @@ struct mind_ctx {
   std::vector<mind_aime_node> pl_nodes;
   std::vector<float> pl_rows_host, pl_flat_prob, pl_flat_mean, pl_flat_cov;
   std::vector<int32_t> pl_tree_top, pl_tree_off, pl_flat_parent;
+  int pl_plan_agents = 0;       // agents per scene of the plan those tables belong to
   DevBuf pl_flat;
   bool dec_overlap = true;      // actor_proj of the decoder on the side stream beside k_dec_scene (mind_set_tuning("dec_overlap"))
   int rb_cur = 0, rb_gen = 0;     // re-basing arenas: which one the last call filled, its generation and geometry
@@ -1739,6 +1740,31 @@ extern "C" int mind_ilqr_contingency_begin(mind_ctx *c, const mind_ilqr_cfg *cfg
   if (!c || !cfg_full) return fail(c, MIND_EINVAL, "mind_ilqr_contingency_begin: null configuration");
   c->il_begin_only = true;
   const int rc = ilqr_impl(c, cfg_warm, nullptr, trees, n_trees, x0, target_lane, n_lane_pts, target_vel, 0, nullptr, xs, us, stats_warm, nullptr,
+                           cfg_full, stats_full);
+  c->il_begin_only = false;
+  return rc;
+}
+
+// mind_ilqr_contingency_begin on the cost trees the last mind_aime_plan of this context flattened (its library-owned tables: no tree
+// arrays cross the boundary again)
+extern "C" int mind_ilqr_contingency_begin_plan(mind_ctx *c, const mind_ilqr_cfg *cfg_warm, const mind_ilqr_cfg *cfg_full, const double *x0,
+                                                const double *target_lane, int n_lane_pts, double target_vel, double *xs, double *us,
+                                                mind_ilqr_stats *stats_warm, mind_ilqr_stats *stats_full) {
+  if (!c || !cfg_full) return fail(c, MIND_EINVAL, "mind_ilqr_contingency_begin_plan: null configuration");
+  const int nt = (int)c->pl_tree_top.size();
+  if (nt <= 0 || c->pl_plan_agents <= 0) return fail(c, MIND_ESTATE, "mind_ilqr_contingency_begin_plan: the context holds no planned cost trees");
+  const int a = c->pl_plan_agents;
+  std::vector<mind_cost_tree> trees(nt);
+  for (int t = 0; t < nt; ++t) {
+    const size_t lo = (size_t)c->pl_tree_off[t];
+    mind_cost_tree &T = trees[t];
+    memset(&T, 0, sizeof(T));
+    T.n_nodes = c->pl_tree_off[t + 1] - c->pl_tree_off[t];
+    T.parent = c->pl_flat_parent.data() + lo; T.prob = c->pl_flat_prob.data() + lo;
+    T.n_agents = a; T.agent_mean = c->pl_flat_mean.data() + lo * a * 2; T.agent_cov = c->pl_flat_cov.data() + lo * a;
+  }
+  c->il_begin_only = true;
+  const int rc = ilqr_impl(c, cfg_warm, nullptr, trees.data(), nt, x0, target_lane, n_lane_pts, target_vel, 0, nullptr, xs, us, stats_warm, nullptr,
                            cfg_full, stats_full);
   c->il_begin_only = false;
   return rc;

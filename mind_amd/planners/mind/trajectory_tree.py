@@ -263,12 +263,18 @@ class TrajectoryTreeOptimizer:
         self._drop_pending()
         if not self.overlap or self.solver is not None or self.shard is not None or self._spec is not None or not flats:
             return False
-        from ...predictor import IlqrCall
+        from ...predictor import PlanIlqrCall
         rt = self._runtime()
         x0 = self._get_init_state(init_state, init_ctrl)
         lane = np.asarray(target_lane, np.float64)
-        call = IlqrCall(rt.lib, ilqr_cfg_from(self.config, "w_opt_cfg"), flats, x0, lane, target_vel, cfg_full=ilqr_cfg_from(self.config, "opt_cfg"))
+        # (the flats are the library's own tables of the plan it just returned: the call names them instead of passing them back)
+        call = PlanIlqrCall(rt.lib, ilqr_cfg_from(self.config, "w_opt_cfg"), ilqr_cfg_from(self.config, "opt_cfg"), [len(f["parent"]) for f in flats],
+                            x0, lane, target_vel)
         call.begin(rt)            # returns with the kernel queued; a failed begin is reported by the collecting solve_batch (call.finish)
+        if call.rc == _lib.MIND_ESTATE:      # this runtime is not the one that planned (no tables there): pass the trees themselves
+            from ...predictor import IlqrCall
+            call = IlqrCall(rt.lib, ilqr_cfg_from(self.config, "w_opt_cfg"), flats, x0, lane, target_vel, cfg_full=ilqr_cfg_from(self.config, "opt_cfg"))
+            call.begin(rt)
         self._pending = dict(call=call, flats=flats, x0=x0, lane=lane, tv=float(target_vel))
         return True
 

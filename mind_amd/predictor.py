@@ -104,6 +104,36 @@ class IlqrCall:
         return xs, us, stats(self.st)
 
 
+class PlanIlqrCall(IlqrCall):
+    """The contingency call on the cost trees the context's last mind_aime_plan flattened (mind_ilqr_contingency_begin_plan): the tree
+    arrays never leave the library, only the node counts are needed here to size and split the results."""
+
+    def __init__(self, lib, cfg, cfg_full, node_counts, x0, lane, target_vel):
+        self.lib, self.cfg, self.cfg_full, self.use_exo, self.background = lib, cfg, cfg_full, 1, False
+        self.Ms = [int(m) for m in node_counts]
+        n = self.n = len(self.Ms)
+        Mt = int(sum(self.Ms))
+        self.x0 = np.ascontiguousarray(x0, np.float64)
+        self.lane = np.ascontiguousarray(lane, np.float64)
+        self.tv = float(target_vel)
+        self.xs, self.us = np.zeros((Mt, 6)), np.zeros((Mt, 2))
+        self.st, self.st_full = (_lib.IlqrStats * n)(), (_lib.IlqrStats * n)()
+        self.ui, self.rc, self.ctx = None, None, None
+
+    def begin(self, rt):
+        self.ctx = rt.ctx
+        if getattr(rt, "_ilqr_wgs_now", None) == 1:
+            rt._ilqr_wgs_now = getattr(rt, "_ilqr_wgs_user", int(os.environ.get("MIND_ILQR_WGS", "16")))
+            self.lib.mind_set_tuning(rt.ctx, b"ilqr_wgs", rt._ilqr_wgs_now)
+        self.rc = self.lib.mind_ilqr_contingency_begin_plan(rt.ctx, C.byref(self.cfg), C.byref(self.cfg_full), self.x0.ctypes.data, self.lane.ctypes.data,
+                                                            len(self.lane), self.tv, self.xs.ctypes.data, self.us.ctypes.data, self.st, self.st_full)
+        self._begun = self.rc == 0
+        return self
+
+    def run(self, rt):
+        return self.begin(rt).wait()
+
+
 class HipPredictor:
     """Owns a ``mind_ctx`` bound to ``device`` and the current torch stream; ``load_state_dict`` mirrors
     ``ScenePredNet.load_state_dict`` (reference planners/mind/planner.py:46-48), ``predict`` mirrors
