@@ -1353,7 +1353,16 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
     if (tid < IL_NA * nuse) {
       double J = 0.0;   // python sum(): sequential
       const double *Ln = (M * IL_NA * nuse <= IL_LSUM) ? lsum + (size_t)tid * M : (T.L_new + (size_t)tid * M).p;
-      for (int c = 0; c < M; ++c) J += Ln[c];
+      // eight values requested together, added in node order (one dependent LDS round trip per node otherwise)
+      int c = 0;
+      for (; c + 8 <= M; c += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = Ln[c + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) J += v[k];
+      }
+      for (; c < M; ++c) J += Ln[c];
       Jnew[tid / IL_NA][tid % IL_NA] = J;
     }
     __syncthreads();
