@@ -895,7 +895,7 @@ __device__ __forceinline__ void il_node_derivs(const IlqrConst &C, const IlqrTre
 #define IL_RECS (64 * IL_RA)   // doubles of LDS for compact records: 64 nodes (derivative pass) >= 8 waves x 6 nodes (cost pass)
 template <bool GEN>
 __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTreeDev &T, double *gcell, float *stg, double *drec,
-                                              unsigned *dmask, int wg, int G IL_PROF_ARG) {
+                                              unsigned *dmask, int wg, int G, bool &staged IL_PROF_ARG) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = T.M, A = T.n_agents;
   const bool exo = !GEN && C.use_exo;
@@ -906,13 +906,17 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
   for (int n0 = wg * nb; n0 < M; n0 += G * nb) {
     IL_PT0();
     const int nn = M - n0 < nb ? M - n0 : nb;
-    if (exo) {
+    // the agents' means / sigmas of this workgroup's block do not change during a fit and nobody else writes the staging region: a
+    // workgroup with ONE block (every demo-size tree) stages them in its first derivative pass only
+    const bool one_block = wg * nb + G * nb >= M;
+    if (exo && !(staged && one_block)) {
       for (int q = tid; q < nn * A; q += IL_THREADS) {
         const int n = q / A, e = q - n * A;
         const il_f2 m = T.mean.as<const il_f2>()[(size_t)(n0 + n) * A + e];
         smx[e * nbp + n] = m.x; smy[e * nbp + n] = m.y; scv[e * nbp + n] = T.cov[(size_t)(n0 + n) * A + e];
       }
       __syncthreads();
+      staged = one_block;
     }
     const bool valid = lane < nn;
     const int n = valid ? lane : nn - 1;
@@ -1215,6 +1219,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       { const int seg = T.slevel_segs[q]; il_rollout_segment(C, T, T.seg_start[seg], T.seg_start[seg + 1], 1 IL_PROF_PASS); }
     IL_SYNC();
   }
+  bool staged = false;          // il_deriv_pass: this fit's agent rows are in the staging region already
   long long t_der = 0, t_bw = 0, t_ls = 0, t_sel = 0, t_roll = 0, t_mark = clock64();
 #define IL_MARK(acc) do { long long now_ = clock64(); acc += now_ - t_mark; t_mark = now_; } while (0)
   // Each pass of this loop consumes 1..IL_SPEC reference iterations: the backward pass and line search are
@@ -1231,7 +1236,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       for (int q = gt; q < M * 6; q += nt) T.xs[q] = xn[q];
       for (int q = gt; q < M * 2; q += nt) T.us[q] = un[q];
       IL_SYNC();
-      il_deriv_pass<GEN>(C, T, lsum, dstg, recs0, reinterpret_cast<unsigned *>(lsum + 9 * 64), MULTI ? wg : 0, MULTI ? G : 1 IL_PROF_PASS);
+      il_deriv_pass<GEN>(C, T, lsum, dstg, recs0, reinterpret_cast<unsigned *>(lsum + 9 * 64), MULTI ? wg : 0, MULTI ? G : 1, staged IL_PROF_PASS);
       IL_SYNC();
       if (M <= IL_LSUM) {
         for (int q = tid; q < M; q += IL_THREADS) lsum[q] = T.L[q];
