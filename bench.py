@@ -108,7 +108,7 @@ def make_planner(wkw, scripted=True):
     return pl, lcl, w
 
 
-def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True, ckpt=None):
+def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True, ckpt=None, own_context=False):
     """planner + closed-loop simulator advanced to the enable time (t = 4.0 s: 40 observation updates).
     ckpt: override of the planner config's ckpt_path (e.g. "formula_branching:20240121", mind_amd/weights.py)."""
     from mind_amd.closed_loop import ClosedLoopSim
@@ -123,6 +123,8 @@ def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True, ckpt
         w = SynthWorld(**wkw)
     if ckpt is not None:
         cfg = dict(cfg if isinstance(cfg, dict) else json.load(open(cfg)), ckpt_path=ckpt)
+    if own_context:       # a HIP context + stream of its own for this planner (several planners driven from one thread: mind_amd/pipelined.py)
+        cfg = dict(cfg if isinstance(cfg, dict) else json.load(open(cfg)), own_context=True)
     pl = MINDPlanner(cfg)
     # recorded scenes run the predictor's own modes, as the reference does with the same weights (its AIME tree then
     # collapses to a few nodes); the scripted modes are straight-line motions in the agent frame and would leave a
@@ -578,6 +580,30 @@ def run_concurrent(args):
         "ms_per_plan_aggregate": dt / (args.steps * P) * 1e3}))
 
 
+def run_pipelined(args):
+    """P closed loops in ONE process and ONE host thread, every planner on its own HIP context / stream, scene i's contingency solves on
+    the device beside scene i + 1's AIME rounds (mind_amd.pipelined)."""
+    from mind_amd.pipelined import PipelinedClosedLoops
+    P = args.concurrent
+    loops = [make_closed_loop(scene_workload(args.workload, i), scripted="scene" not in scene_workload(args.workload, i), speculative=False, ckpt=args.ckpt,
+                              own_context=True) for i in range(P)]
+    pc = PipelinedClosedLoops([l[1] for l in loops])
+    pc.run_plans(max(args.warmup, 1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = pc.run_plans(args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": METRIC, "value": steps / dt, "unit": "sim steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16x3 pair kernel / f32 predictor / f64 iLQR", "data": _concurrent_label(args.workload, P)[1],
+        "config": {"workload": f"{_concurrent_label(args.workload, P)[0]} planned from ONE host thread, one HIP context + stream per scene, "
+                               f"scene i's tree-iLQR on the device beside scene i + 1's AIME rounds, {args.steps} planning cycles each",
+                   "concurrent_scenes": P, "sim_steps_timed": steps},
+        "ms_per_plan_aggregate": dt / (args.steps * P) * 1e3}))
+
+
 def run_fused(args):
     """BASELINE config 3 as written: P closed loops in ONE process, the AIME rounds of all scenes merged into one predictor
     batch per round (mind_amd.fused); to be compared with --concurrent P --processes (one process per scene)."""
@@ -641,6 +667,8 @@ def main():
                          "HIP context and stream per scene); prints the aggregate rate")
     ap.add_argument("--processes", action="store_true",
                     help="with --concurrent: one host PROCESS per scene instead of one thread (host bookkeeping in parallel too)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="with --concurrent P: one process, one host thread, a context per scene, scene i's tree-iLQR beside scene i + 1's AIME rounds")
     ap.add_argument("--fused", action="store_true",
                     help="with --concurrent: ONE process, the scenes' AIME rounds fused into one predictor batch (BASELINE config 3 as written)")
     ap.add_argument("--ckpt", default=None, help='planner ckpt_path override, e.g. "formula_branching:20240121" (mind_amd/weights.py) or a .tar')
@@ -669,6 +697,8 @@ def main():
     if args.concurrent > 1:
         if args.fused:
             return run_fused(args)
+        if args.pipelined:
+            return run_pipelined(args)
         return run_concurrent_processes(args) if args.processes else run_concurrent(args)
     shard = world > 1 and not args.replicas and (args.shard or args.workload in FULL_TREE)
     m = measure(dist, args.workload, args.steps, args.warmup, shard, replica=0 if shard else rank, ckpt=args.ckpt)

@@ -10,11 +10,16 @@ from ....runtime import get_runtime
 class ScenePredNet:
     computes_rpe_in_kernel = True   # RPE (mind/utils.py:193-212) is evaluated inside the fusion kernel
 
-    def __init__(self, cfg=None, device=None):
+    def __init__(self, cfg=None, device=None, own_context=False):
         self.cfg = cfg or {}
         self.device = device
         idx = device.index if isinstance(device, torch.device) and device.index is not None else 0
-        self.rt = get_runtime(idx)
+        # own_context: a context / stream of its own instead of the thread's (several planners driven from one thread, runtime.new_runtime)
+        if own_context:
+            from ....runtime import new_runtime
+            self.rt = new_runtime(idx)
+        else:
+            self.rt = get_runtime(idx)
         self.last_lane_feat = None
         self.last_packed = None
         self._loaded = False

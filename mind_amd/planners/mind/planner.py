@@ -69,7 +69,7 @@ class MINDPlanner:
         self.network_cfg = _import_cfg(self.planner_cfg["network_config"]).NetCfg()
         net_cfg = self.network_cfg.get_net_cfg()
         from .networks.network import ScenePredNet
-        self.network = ScenePredNet(net_cfg, self.device)
+        self.network = ScenePredNet(net_cfg, self.device, own_context=bool(self.planner_cfg.get("own_context", False)))
         path = self.planner_cfg["ckpt_path"]
         m = re.fullmatch(r"formula(?:_(\w+))?:(\d+)", str(path))     # "formula:<seed>" or "formula_<variant>:<seed>" (mind_amd/weights.py);
         if m is not None:                                            # anything else -- "formula_runs/x.tar" included -- is a checkpoint file
@@ -150,6 +150,13 @@ class MINDPlanner:
 
     # ------------------------------------------------------------------------------------------
     def plan(self, lcl_smp):
+        return self.plan_end(self.plan_begin(lcl_smp))
+
+    def plan_begin(self, lcl_smp):
+        """First half of plan(): the AIME rounds, the start of the contingency solves (when the native plan hands over its flattened cost
+        trees) and the scenario trees' Python objects.  A driver that plans several scenes from one thread -- each planner on its own
+        context, planner config "own_context" -- calls the next scene's plan_begin before this scene's plan_end: the device then runs
+        this scene's tree-iLQR beside the next scene's predictor."""
         import time
         t0 = time.perf_counter()
         self.scen_tree_gen.reset()
@@ -170,6 +177,11 @@ class MINDPlanner:
         if hook is not None and getattr(opt, "_pending", None) is not None:
             hook()
         t1 = time.perf_counter()
+        return (lcl_smp, scen_trees, t0, t1, n0)
+
+    def plan_end(self, begun):
+        """Second half of plan(): collects (or runs) the contingency solves, evaluates the candidates, returns plan()'s result."""
+        lcl_smp, scen_trees, t0, t1, n0 = begun
         if len(scen_trees) < 0:
             return False, None, None
         return self._solve_and_select(lcl_smp, scen_trees, t0, t1, n0)

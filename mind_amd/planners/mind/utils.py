@@ -341,7 +341,8 @@ def _static_lane_pieces(static_map, seg_length, n_sub):
         intersect=np.repeat(flags[:, 1:2], n_sub, 1).astype(np.int16),
         left=np.repeat(flags[:, 4:5], n_sub, 1).astype(np.int16), right=np.repeat(flags[:, 5:6], n_sub, 1).astype(np.int16),
         num_lanes=L, flags=np.ascontiguousarray(flags, np.int32))      # flags [l,6]: lane type, intersection, left / right mark class, neighbours
-    _LANE_CACHE.clear()
+    if len(_LANE_CACHE) >= 16:          # a handful of maps live side by side (several scenes planned by one process: one entry each)
+        _LANE_CACHE.clear()
     _LANE_CACHE[key] = (static_map, static)
     return static
 

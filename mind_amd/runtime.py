@@ -25,6 +25,22 @@ def get_runtime(device=None):
     return rt
 
 
+def new_runtime(device=None):
+    """A further ``HipPredictor`` of this thread: its own ``mind_ctx`` on its own (new) torch stream.  For a driver that plans several
+    scenes from ONE thread and wants their kernels to overlap on the device (bench.py --concurrent P --pipelined: scene i's contingency
+    solves run while scene i + 1's AIME rounds do); the caller owns it (``close()``)."""
+    import torch
+    from .predictor import HipPredictor
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", int(device))
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        rt = HipPredictor(int(device))
+    rt.torch_stream = stream            # kept alive with the runtime; work the caller does through torch for this scene belongs on it
+    return rt
+
+
 def reset_runtime():
     rt = getattr(_local, "rt", None)
     if rt is not None:

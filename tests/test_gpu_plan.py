@@ -424,6 +424,44 @@ def test_four_recorded_scenes_fused_in_one_process_equal_separate_runs(ckpt):
         assert fl.fused.n_scenes >= 3 * (4 + 4)         # branching weights: at least a second round per scene and plan
 
 
+def test_four_recorded_scenes_pipelined_from_one_thread_equal_separate_runs():
+    """BASELINE config 3 from ONE host thread (mind_amd.pipelined): every planner on its own HIP context / stream, scene i + 1's
+    plan_begin (AIME rounds, start of the contingency solves) before scene i's plan_end, so that one scene's tree-iLQR runs on the device
+    beside the next scene's predictor.  The scenes stay independent closed loops: over four cycles every scene plans bit for bit what it
+    plans alone (branch ids, trajectories, controls, ego states), the native AIME plan and the solves started ahead included."""
+    sys.path.insert(0, ROOT)
+    from bench import BRANCHING_WEIGHTS, WORKLOADS, make_closed_loop
+    from mind_amd.pipelined import PipelinedClosedLoops
+    scenes = ["demo_1", "demo_2", "demo_3", "demo_4"]
+
+    def snapshot(pl, sim):
+        st = sim.last_result[0][0]
+        return (list(st.nodes.keys()), np.concatenate([st.nodes[k].data[1].ravel() for k in st.nodes]), np.array(sim.ctrl), np.array(sim.state),
+                pl.timing["best_traj_idx"], sim.n_steps)
+
+    alone = []
+    for sc in scenes:
+        pl, sim, w = make_closed_loop(dict(WORKLOADS[sc]), scripted=False, speculative=False, ckpt=BRANCHING_WEIGHTS)
+        snaps = []
+        for _ in range(4):
+            sim.run_plans(1)
+            snaps.append(snapshot(pl, sim))
+        alone.append(snaps)
+    loops = [make_closed_loop(dict(WORKLOADS[sc]), scripted=False, speculative=False, ckpt=BRANCHING_WEIGHTS, own_context=True) for sc in scenes]
+    assert len({id(l[0].network.rt) for l in loops}) == 4 and len({l[0].network.rt.ctx.value for l in loops}) == 4      # four contexts
+    pc = PipelinedClosedLoops([l[1] for l in loops])
+    for c in range(4):
+        pc.run_plans(1)
+        for i, (pl, sim, w) in enumerate(loops):
+            a, b = alone[i][c], snapshot(pl, sim)
+            assert a[0] == b[0] and a[4] == b[4] and a[5] == b[5], (scenes[i], c)
+            for x, y in zip(a[1:4], b[1:4]):
+                assert np.array_equal(x, y), (scenes[i], c)
+    assert all(l[0].scen_tree_gen.n_native_plans == 4 for l in loops)
+    for pl, sim, w in loops:
+        pl.network.rt.close()
+
+
 @pytest.mark.parametrize("scene", ["demo_1", "demo_4"])
 def test_aime_tree_does_not_depend_on_the_pair_kernel_arithmetic(scene):
     """The discrete AIME result (node ids, branch times, chosen tree) of a branching closed loop is the same whether the pair
