@@ -102,6 +102,59 @@ def test_observation_built_ahead_in_the_idle_hook_is_the_observation_that_comes(
     assert used > 100 and all(x[3] is None for f in b.seen for x in f)
 
 
+class _TwoHalfPlanner(_StubPlanner):
+    """plan() in two halves, logging the order in which a driver calls them"""
+
+    def __init__(self, name, log):
+        super().__init__()
+        self.name, self.log = name, log
+
+    def plan_begin(self, lcl):
+        self.log.append(("begin", self.name))
+        return lcl
+
+    def plan_end(self, begun):
+        self.log.append(("end", self.name))
+        return _StubPlanner.plan(self, begun)
+
+    def plan(self, lcl):
+        return self.plan_end(self.plan_begin(lcl))
+
+
+def test_pipelined_driver_keeps_one_plan_in_flight_and_plans_what_the_scenes_plan_alone():
+    """mind_amd.pipelined.PipelinedClosedLoops (CPU, stub planners): scene i + 1's plan_begin is called before scene i's plan_end -- one
+    plan in flight --, every scene gets exactly n plans per run_plans(n), at the simulator times it plans at alone (episode restarts
+    included), and a single scene degenerates to begin / end pairs."""
+    from mind_amd.pipelined import PipelinedClosedLoops
+    log = []
+    sims = [ClosedLoopSim(SynthWorld(n_agents=3, n_lanes=2, n_segs=6, seed=s), _TwoHalfPlanner("s%d" % s, log), episode_plans=7) for s in (1, 2, 3)]
+    pc = PipelinedClosedLoops(sims)
+    steps = pc.run_plans(5) + pc.run_plans(6)               # 11 plans per scene: one episode restart each
+    assert [s.n_plans for s in sims] == [11, 11, 11] and steps == sum(s.n_steps for s in sims)
+    alone = ClosedLoopSim(SynthWorld(n_agents=3, n_lanes=2, n_segs=6, seed=1), _StubPlanner(), episode_plans=7)
+    alone.run_plans(11)
+    assert sims[0].planner.plans == alone.planner.plans and sims[0].n_steps == alone.n_steps and np.array_equal(sims[0].state, alone.state)
+    # order: never two ends in a row without a begin between them except when a run drains, every begin of scene X is followed by X's end
+    # only after the NEXT scene's begin (within a run of run_plans)
+    first = log[:2 * 3 * 5]
+    assert first[0] == ("begin", "s1") and first[1] == ("begin", "s2") and first[2] == ("end", "s1") and first[3] == ("begin", "s3") and first[4] == ("end", "s2")
+    open_ = []
+    for kind, name in log:
+        if kind == "begin":
+            open_.append(name)
+            assert len(open_) <= 2                          # one plan in flight behind the one being started
+        else:
+            assert open_ and open_[0] == name               # plans complete in the order they were started
+            open_.pop(0)
+    assert not open_
+    log.clear()
+    one = PipelinedClosedLoops([ClosedLoopSim(SynthWorld(n_agents=3, n_lanes=2, n_segs=6, seed=4), _TwoHalfPlanner("x", log))])
+    one.run_plans(3)
+    assert log == [("begin", "x"), ("end", "x")] * 3
+    with pytest.raises(TypeError):
+        PipelinedClosedLoops([ClosedLoopSim(SynthWorld(n_agents=3, n_lanes=2, n_segs=6, seed=5), _StubPlanner())])
+
+
 @pytest.mark.gpu
 def test_closed_loop_with_real_planner():
     import os
