@@ -30,6 +30,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+if "--pipelined" in sys.argv:
+    # one thread drives P contexts of three streams each: more than the ROCm runtime's default four hardware queues per process, and
+    # streams that share a queue run in order (measured: 3 134 -> 3 959 sim steps/s at P = 4 with eight queues).  Read at runtime start.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np
 import torch
 
