@@ -47,9 +47,11 @@ class ClosedLoopSim:
         self._valid = getattr(world, "is_valid", None)
         self._exo_ahead = None
         import os
-        if os.environ.get("MIND_PREFETCH_OBS", "1") != "0" and hasattr(planner, "plan") and not callable(getattr(planner, "idle_hook", None)):
+        if os.environ.get("MIND_PREFETCH_OBS", "1") != "0" and hasattr(planner, "plan"):
             try:
-                planner.idle_hook = self._prefetch_observation      # (MINDPlanner calls it while the device computes; other planners ignore it)
+                # (MINDPlanner calls it while the device computes; other planners ignore it.)  Always THIS simulator's method: a second
+                # simulator around the same planner must not leave the first one's hook -- and its world -- behind
+                planner.idle_hook = self._prefetch_observation
             except AttributeError:
                 pass
         self._start_episode()

@@ -47,7 +47,7 @@ struct PairJob {
   int slot;             // partial-result slot
   int flags;            // bit0: column is an actor or the cls token
   int scene;
-  int pad0, pad1;
+  long long edge_base_t;  // the same for the tile-native layout of k_pair_t (pair_tile_kernels.hip): columns padded to whole 16-row tiles
 };
 
 // per-layer small vectors, staged in LDS (floats): 7 x 128

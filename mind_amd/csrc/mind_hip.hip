@@ -17,6 +17,7 @@
 #include "encdec_kernels.hip"
 #include "fusion_kernels.hip"
 #include "pair_bf16_kernels.hip"
+#include "pair_tile_kernels.hip"
 #include "token_mfma_kernels.hip"
 #include "actor_mfma_kernels.hip"
 #include "dec_mfma_kernels.hip"
@@ -47,10 +48,10 @@ struct WeightBlob {
 // job / token tables of one batch shape (scene sizes), resident on the device
 struct TableSet {
   std::vector<int> key;               // Bn, actor_off[0..Bn], lane_off[0..Bn]
-  DevBuf meta, jobs, rows;
-  std::vector<int> actor_row, cls_row;
-  long long edge_pairs = 0, stamp = 0;
-  int ntok = 0, slot = 0, njobs = 0;
+  DevBuf meta, jobs, jobs5, rows;      // jobs5: the columns the last fusion layer runs (actors + cls), for k_pair_t
+  std::vector<int> actor_row, cls_row, scene_n;
+  long long edge_pairs = 0, edge_pairs_t = 0, stamp = 0;     // edge_pairs_t: with every column padded to whole 16-row tiles
+  int ntok = 0, slot = 0, njobs = 0, njobs5 = 0;
   double pairs_full = 0, pairs_l5 = 0;
 };
 #define MIND_TABLE_SETS 8
@@ -110,6 +111,11 @@ struct mind_ctx {
   bool enc_mfma = true;         // MFMA ActorNet under the bf16x3 / bf16 settings (MIND_ENC_MFMA=0: the fp32 VALU kernel, for A/B)
   bool xcd_order = true;        // XCD-aware job order for big batches (MIND_XCD_ORDER=0 switches it off, for A/B measurements)
   int pair_prec = 1;            // arithmetic of the pair kernel: 0 = fp32 MFMA, 1 = bf16x3 (split operands, default), 2 = bf16
+  // bf16 arithmetics: k_pair_t (tile-native edge tensor, pair_tile_kernels.hip; default) or the row-major k_pair_bf of rounds 2-3
+  // (mind_set_tuning("pair_tile", 0) / MIND_PAIR_TILE=0, kept for same-box A/B measurements)
+  bool pair_tile = true;
+  std::vector<int> last_scene_n;   // tokens per scene of the last predictor call (mind_debug_read("edge") un-permutes with it)
+  bool last_edge_tiled = false, last_edge_bf16 = false;
   // workspaces (grow only)
   DevBuf edge, x, ST, QK, part, tokpos, meta, jobs, actor_feat, lane_feat, tgt_feat, cmode, tgt_emb,
       rows, rpe_ptrs;
@@ -218,6 +224,11 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   (void)hipFuncSetAttribute((const void *)k_pair_bf<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_pair_bf<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_pair_bf<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_pair_t<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_pair_t<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_pair_t<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_pair_t<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
+  if (const char *te = getenv("MIND_PAIR_TILE")) c->pair_tile = !(te[0] == '0');
   if (const char *xe = getenv("MIND_XCD_ORDER")) c->xcd_order = !(xe[0] == '0');
 
   if (const char *pe = getenv("MIND_PAIR_PREC")) {
@@ -267,7 +278,7 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (TableSet &t : c->tabs)
-    for (DevBuf *b : {&t.meta, &t.jobs, &t.rows})
+    for (DevBuf *b : {&t.meta, &t.jobs, &t.jobs5, &t.rows})
       if (b->p) (void)hipFree(b->p);
   if (c->wdev) (void)hipFree(c->wdev);
   for (DevBuf *b : {&c->pl_root, &c->pl_in[0], &c->pl_in[1], &c->pl_lf, &c->pl_lrep, &c->pl_pred, &c->pl_small, &c->pl_tab[0], &c->pl_tab[1], &c->pl_win[0],
@@ -308,6 +319,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "enc_mfma") c->enc_mfma = value != 0;
   else if (n == "actor_split") c->actor_np = value == 3 ? 3 : 6;
   else if (n == "xcd_order") c->xcd_order = value != 0;
+  else if (n == "pair_tile") c->pair_tile = value != 0;
   else if (n == "dec_overlap") c->dec_overlap = value != 0;
   else if (n == "tok_mfma") c->tok_mfma = value != 0;
   else if (n == "tok_small_max") c->tok_small_max = (int)value;
@@ -969,8 +981,8 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   if (!tab_hit) {
     std::vector<TokMeta> meta;
     std::vector<PairJob> jobs;
-    std::vector<int> actor_row(A), actor_scene(A), cls_row(Bn);
-    long long edge_pairs = 0;
+    std::vector<int> actor_row(A), actor_scene(A), cls_row(Bn), scene_n(Bn);
+    long long edge_pairs = 0, edge_pairs_t = 0;
     int ntok = 0;
     for (int b = 0; b < Bn; ++b) {
       const int a = in->actor_off[b + 1] - in->actor_off[b], l = in->lane_off[b + 1] - in->lane_off[b];
@@ -1001,6 +1013,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
           PairJob J;
           memset(&J, 0, sizeof(J));
           J.edge_base = edge_pairs;
+          J.edge_base_t = edge_pairs_t;
           J.N = N;
           J.j = j;
           J.t0 = (int)((long long)tiles * s_ / ns);
@@ -1014,8 +1027,10 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
         if (j < a) { actor_row[in->actor_off[b] + j] = ntok + j; actor_scene[in->actor_off[b] + j] = b; }
       }
       cls_row[b] = ntok + N - 1;
+      scene_n[b] = N;
       ntok += N;
       edge_pairs += (long long)N * N;
+      edge_pairs_t += (long long)N * tiles * 16;
       pairs_full += (double)N * N;
       pairs_l5 += (double)N * (a + 1);
     }
@@ -1023,11 +1038,16 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
     // jobs are interleaved such that job index = scene (mod 8): all column jobs of a scene then run on one XCD, whose L2 keeps
     // that scene's T rows (re-read by every tile of every column; PMC: they missed the per-XCD L2 40 % of the time when a
     // scene's jobs were spread over all XCDs).  Lanes of unequal length are padded with empty jobs (t0 == t1).
-    {
-      const int grid_ = (int)jobs.size() < c->n_cu ? (int)jobs.size() : c->n_cu;
-      if (c->xcd_order && Bn >= 8 && grid_ % 8 == 0 && (int)jobs.size() >= 4 * grid_) {
+    // The last fusion layer runs the consumed columns only (actors + cls): k_pair_t walks a list of its own instead of
+    // skipping the other jobs after a dependent load each.
+    std::vector<PairJob> jobs5;
+    for (const PairJob &J : jobs)
+      if (J.flags & 1) jobs5.push_back(J);
+    auto xcd_order_jobs = [&](std::vector<PairJob> &jl) {
+      const int grid_ = (int)jl.size() < c->n_cu ? (int)jl.size() : c->n_cu;
+      if (c->xcd_order && Bn >= 8 && grid_ % 8 == 0 && (int)jl.size() >= 4 * grid_) {
         std::vector<std::vector<PairJob>> lanes(8);
-        for (const PairJob &J : jobs) lanes[J.scene % 8].push_back(J);
+        for (const PairJob &J : jl) lanes[J.scene % 8].push_back(J);
         size_t mx = 0;
         for (const auto &l_ : lanes) mx = std::max(mx, l_.size());
         PairJob nullj;
@@ -1037,15 +1057,19 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
         re.reserve(8 * mx);
         for (size_t i = 0; i < mx; ++i)
           for (int x = 0; x < 8; ++x) re.push_back(i < lanes[x].size() ? lanes[x][i] : nullj);
-        jobs.swap(re);
+        jl.swap(re);
       }
-    }
+    };
+    xcd_order_jobs(jobs);
+    xcd_order_jobs(jobs5);
     ts->key.clear();                    // invalid until the upload below has completed
     if ((rc = ensure(c, ts->meta, meta.size() * sizeof(TokMeta)))) return rc;
     if ((rc = ensure(c, ts->jobs, jobs.size() * sizeof(PairJob)))) return rc;
+    if ((rc = ensure(c, ts->jobs5, jobs5.size() * sizeof(PairJob)))) return rc;
     if ((rc = ensure(c, ts->rows, (size_t)(2 * A + Bn) * sizeof(int)))) return rc;
     HIPCHK(c, hipMemcpyAsync(ts->meta.p, meta.data(), meta.size() * sizeof(TokMeta), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(ts->jobs.p, jobs.data(), jobs.size() * sizeof(PairJob), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(ts->jobs5.p, jobs5.data(), jobs5.size() * sizeof(PairJob), hipMemcpyHostToDevice, st));
     std::vector<int> rows(2 * A + Bn);
     memcpy(rows.data(), actor_row.data(), A * sizeof(int));
     memcpy(rows.data() + A, actor_scene.data(), A * sizeof(int));
@@ -1055,7 +1079,9 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
     HIPCHK(c, hipStreamSynchronize(st));
     ts->actor_row.swap(actor_row);
     ts->cls_row.swap(cls_row);
-    ts->edge_pairs = edge_pairs; ts->ntok = ntok; ts->slot = slot; ts->njobs = (int)jobs.size();
+    ts->scene_n.swap(scene_n);
+    ts->edge_pairs = edge_pairs; ts->edge_pairs_t = edge_pairs_t; ts->ntok = ntok; ts->slot = slot; ts->njobs = (int)jobs.size();
+    ts->njobs5 = (int)jobs5.size();
     ts->pairs_full = pairs_full; ts->pairs_l5 = pairs_l5;
     ts->key.swap(key);
   } else {
@@ -1064,10 +1090,12 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   const std::vector<int> &actor_row = ts->actor_row, &cls_row = ts->cls_row;
   const long long edge_pairs = ts->edge_pairs;
   const int ntok = ts->ntok, slot = ts->slot, njobs = ts->njobs;
+  const bool tiled = c->pair_prec != 0 && c->pair_tile;      // k_pair_t: the edge tensor in its tile-native layout
   const double pairs_full = ts->pairs_full, pairs_l5 = ts->pairs_l5;
 
   // ---- workspaces
-  if ((rc = ensure(c, c->edge, (size_t)edge_pairs * 128 * sizeof(float)))) return rc;
+  // (k_pair_t<*, 1> keeps the tensor in bf16: the fp32-sized buffer is simply half used)
+  if ((rc = ensure(c, c->edge, (size_t)(tiled ? ts->edge_pairs_t : edge_pairs) * 128 * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->x, (size_t)ntok * 128 * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->ST, (size_t)ntok * 256 * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->QK, (size_t)ntok * 1024 * sizeof(float)))) return rc;
@@ -1183,6 +1211,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
     }
   }
   c->last_ntok = ntok; c->last_edge_pairs = edge_pairs; c->last_slots = slot; c->last_A = A; c->last_B = Bn;
+  c->last_scene_n = ts->scene_n; c->last_edge_tiled = tiled; c->last_edge_bf16 = tiled && c->pair_prec == 2;
   for (int L = 0; L < c->debug_layers; ++L) {
     const int um = L < 4 ? 0 : (L == 4 ? 1 : 2);
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2 * L], st));
@@ -1193,6 +1222,18 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
       else
         hipLaunchKernelGGL(k_pair<1>, dim3(grid), dim3(PAIR_THREADS), lds, st, djobs, njobs, edge, ST, QK, part, c->WAe[L],
                            L == 5 ? c->WAe[L] : c->WAp[L], c->vtab[L], c->rtab, tokpos, rpe_dev, um);
+    } else if (tiled) {
+      const size_t ldsb = mind_pair_bf_lds_bytes();
+      const u32 *we = c->WBe[L], *wp = L == 5 ? c->WBe[L] : c->WBp[L];
+      const PairJob *jl = L == 5 ? (const PairJob *)ts->jobs5.p : djobs;
+      const int nj = L == 5 ? ts->njobs5 : njobs;
+      const int grid_t = nj < c->n_cu ? nj : c->n_cu;
+#define LAUNCH_T(M, NPV)                                                                                                       \
+  hipLaunchKernelGGL((k_pair_t<M, NPV>), dim3(grid_t), dim3(PAIR_THREADS), ldsb, st, jl, nj, edge, ST, QK, part, we, wp,       \
+                     c->vtab[L], c->rtab, tokpos, rpe_dev, um)
+      if (c->pair_prec == 1) { if (L == 0) LAUNCH_T(0, 3); else LAUNCH_T(1, 3); }
+      else { if (L == 0) LAUNCH_T(0, 1); else LAUNCH_T(1, 1); }
+#undef LAUNCH_T
     } else {
       const size_t ldsb = mind_pair_bf_lds_bytes();
       const u32 *we = c->WBe[L], *wp = L == 5 ? c->WBe[L] : c->WBp[L];
@@ -2088,6 +2129,34 @@ extern "C" int64_t mind_debug_read(mind_ctx *c, const char *name, float *host, i
   if (!host) return n;
   if (n > max_floats) n = max_floats;
   if (hipStreamSynchronize(c->stream) != hipSuccess) return MIND_EHIP;
+  if (k == "edge" && c->last_edge_tiled) {
+    // k_pair_t keeps the tensor as [scene][column j][tile][chunk b 8][lane 64][4]: hand back the logical [scene][j][i][128]
+    long long pt = 0;
+    for (int N : c->last_scene_n) pt += (long long)N * (((N + 15) / 16) * 16);
+    const bool eb = c->last_edge_bf16;      // plain bf16 arithmetic: [k-group 4][lane 64][4 dwords of two bf16], 64 dwords per pair
+    std::vector<float> raw((size_t)pt * (eb ? 64 : 128));
+    if (hipMemcpy(raw.data(), src, raw.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return MIND_EHIP;
+    int64_t o = 0;
+    size_t sb = 0;
+    for (int N : c->last_scene_n) {
+      const int rows = ((N + 15) / 16) * 16;
+      for (int j = 0; j < N; ++j)
+        for (int i = 0; i < N; ++i)
+          for (int f = 0; f < 128 && o < n; ++f, ++o) {
+            const int t = i >> 4, pp = i & 15, b = f >> 4, qq = (f >> 2) & 3, r = f & 3;
+            const size_t tile0 = sb + (size_t)j * rows + (size_t)t * 16;
+            if (!eb) host[o] = raw[tile0 * 128 + ((b * 64 + qq * 16 + pp) * 4 + r)];
+            else {
+              uint32_t w;
+              memcpy(&w, &raw[tile0 * 64 + (((b >> 1) * 64 + qq * 16 + pp) * 4 + 2 * (b & 1) + (r >> 1))], 4);
+              w = (r & 1) ? (w & 0xffff0000u) : (w << 16);
+              memcpy(&host[o], &w, 4);
+            }
+          }
+      sb += (size_t)N * rows;
+    }
+    return n;
+  }
   if (hipMemcpy(host, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return MIND_EHIP;
   return n;
 }

@@ -152,7 +152,25 @@ class MINDPlanner:
     def plan(self, lcl_smp):
         return self.plan_end(self.plan_begin(lcl_smp))
 
-    def plan_begin(self, lcl_smp):
+    def _on_own_stream(self):
+        """A planner with a context of its own (planner config "own_context", runtime.new_runtime) runs its kernels on that context's
+        stream; whatever the plan does through torch (the round-by-round AIME path: index_select / pruning tensors / the predictor's
+        output buffers) must be ordered on the same stream, not on the thread's current one."""
+        ts = getattr(self.network.rt, "torch_stream", None)
+        if ts is None:
+            import contextlib
+            return contextlib.nullcontext()
+        return torch.cuda.stream(ts)
+
+    def plan_begin(self, lcl_smp, idle_hook=None):
+        with self._on_own_stream():
+            return self._plan_begin(lcl_smp, idle_hook)
+
+    def plan_end(self, begun):
+        with self._on_own_stream():
+            return self._plan_end(begun)
+
+    def _plan_begin(self, lcl_smp, idle_hook=None):
         """First half of plan(): the AIME rounds, the start of the contingency solves (when the native plan hands over its flattened cost
         trees) and the scenario trees' Python objects.  A driver that plans several scenes from one thread -- each planner on its own
         context, planner config "own_context" -- calls the next scene's plan_begin before this scene's plan_end: the device then runs
@@ -173,26 +191,29 @@ class MINDPlanner:
         scen_trees = self.scen_tree_gen.branch_aime(lcl_smp, self.agent_obs, on_flats=ahead)
         # the device is busy with the contingency solves begun above: a caller's hook runs here (the closed-loop driver prefetches the next
         # replayed observation), the solves are collected afterwards
-        hook = getattr(self, "idle_hook", None)
+        hook = idle_hook if idle_hook is not None else getattr(self, "idle_hook", None)
         if hook is not None and getattr(opt, "_pending", None) is not None:
             hook()
         t1 = time.perf_counter()
         return (lcl_smp, scen_trees, t0, t1, n0)
 
-    def plan_end(self, begun):
+    def _plan_end(self, begun):
         """Second half of plan(): collects (or runs) the contingency solves, evaluates the candidates, returns plan()'s result."""
         lcl_smp, scen_trees, t0, t1, n0 = begun
         if len(scen_trees) < 0:
             return False, None, None
-        return self._solve_and_select(lcl_smp, scen_trees, t0, t1, n0)
+        import time
+        # (a pipelined driver runs other scenes' plan_begin between the two halves: their time is not this plan's)
+        return self._solve_and_select(lcl_smp, scen_trees, t0, t1, n0, t_collect=time.perf_counter())
 
-    def _solve_and_select(self, lcl_smp, scen_trees, t0, t1, n0):
+    def _solve_and_select(self, lcl_smp, scen_trees, t0, t1, n0, t_collect=None):
         """planner.py:120-145: contingency solve of every scenario tree, evaluation, the reference's strict `<` scan for the
         cheapest tree (the first minimum; a NaN cost never wins), first control.  Shared by plan() and plan_rounds()."""
         import time
         traj_trees = self.traj_tree_opt.solve_batch(scen_trees, self.state, self.ctrl, self.gt_tgt_lane,
                                                     lcl_smp.target_velocity)
         t2 = time.perf_counter()
+        gap = 0.0 if t_collect is None else max(t_collect - t1, 0.0)      # time between plan_begin's return and plan_end's entry
         best, min_cost = None, np.inf
         costs = self.evaluate_traj_trees(lcl_smp, traj_trees)
         for i, cost in enumerate(costs):
@@ -201,7 +222,7 @@ class MINDPlanner:
         opt = traj_trees[best]
         nxt = opt.get_node(opt.get_root().children_keys[0])
         ret_ctrl = nxt.data[0][-2:]          # (a, delta) of the first rolled-out state (Q15)
-        self.timing = {"aime_s": t1 - t0, "ilqr_s": t2 - t1, "total_s": time.perf_counter() - t0,
+        self.timing = {"aime_s": t1 - t0, "ilqr_s": t2 - t1 - gap, "total_s": time.perf_counter() - t0 - gap,
                        "nodes_expanded": self.scen_tree_gen.n_expanded - n0, "n_scen_trees": len(scen_trees),
                        "best_traj_idx": best, "tree_costs": [float(c) for c in costs]}
         self._accumulate_timing()
@@ -231,10 +252,19 @@ class MINDPlanner:
         """1 m resampling of the target lane and its per-point info (planner.py:147-171).  A replayed scene hands over the SAME lane /
         info objects every cycle: the result is kept while they are (the arrays are only read downstream)."""
         key = getattr(self, "_rtl_key", None)
-        if key is not None and key[0] is lcl_smp.target_lane and key[1] is lcl_smp.target_lane_info:
+        fp = self._lane_fingerprint(lcl_smp)
+        if key is not None and key[0] is lcl_smp.target_lane and key[1] is lcl_smp.target_lane_info and key[2] == fp:
             return self._rtl_val
-        self._rtl_key, self._rtl_val = (lcl_smp.target_lane, lcl_smp.target_lane_info), self._resample_target_lane(lcl_smp)
+        self._rtl_key, self._rtl_val = (lcl_smp.target_lane, lcl_smp.target_lane_info, fp), self._resample_target_lane(lcl_smp)
         return self._rtl_val
+
+    @staticmethod
+    def _lane_fingerprint(lcl_smp):
+        """content hash of the target lane and its info arrays (a few KB): an in-place edit of the same objects is a new lane"""
+        try:
+            return hash((np.asarray(lcl_smp.target_lane).tobytes(),) + tuple(np.asarray(i).tobytes() for i in lcl_smp.target_lane_info))
+        except Exception:
+            return None
 
     def _resample_target_lane(self, lcl_smp):
         lane = np.asarray(lcl_smp.target_lane)
@@ -266,7 +296,8 @@ class MINDPlanner:
         ct = np.concatenate([p[1] for p in packs])
         counts = np.array([len(p[0]) for p in packs])
         lane = np.asarray(lcl_smp.target_lane)
-        if getattr(self, "_native_eval", True) and lane.dtype in (np.float32, np.float64) and lane.ndim == 2 and st.dtype == np.float64 and ct.dtype == np.float64:
+        if getattr(self, "_native_eval", True) and lane.dtype in (np.float32, np.float64) and lane.ndim == 2 and st.dtype == np.float64 and ct.dtype == np.float64 \
+                and not np.any(np.all(lane[1:] == lane[:-1], axis=1)):      # (a zero-length segment: the numpy path raises the reference's assertion)
             # the same arithmetic in native code (mind_eval_traj_trees: numpy's operation and summation order)
             import ctypes as C
             from ... import _lib

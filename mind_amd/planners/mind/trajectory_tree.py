@@ -50,12 +50,18 @@ _CFG_CACHE = {}
 def ilqr_cfg_from(config, block, max_iter=100):
     """TrajTreeCfg (w_opt_cfg / opt_cfg dict) -> C struct (built once per config object and block: it is read-only afterwards)."""
     key = (id(config), block, max_iter)
+    fp = _cfg_fingerprint(config, block)       # the reference re-reads the weights on every plan: an in-place edit must not be ignored
     hit = _CFG_CACHE.get(key)
-    if hit is not None and hit[0] is config:
+    if hit is not None and hit[0] is config and hit[2] == fp:
         return hit[1]
     c = _ilqr_cfg_build(config, block, max_iter)
-    _CFG_CACHE[key] = (config, c)
+    _CFG_CACHE[key] = (config, c, fp)
     return c
+
+
+def _cfg_fingerprint(config, block):
+    o = getattr(config, block)
+    return (config.dt,) + tuple(np.asarray(v, np.float64).tobytes() if isinstance(v, (list, tuple, np.ndarray)) else v for _, v in sorted(o.items()))
 
 
 def _ilqr_cfg_build(config, block, max_iter):

@@ -77,6 +77,7 @@ class IlqrCall:
         assert self.cfg_full is not None and not self.background
         dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
         self.ctx = rt.ctx
+        self._rt = rt
         if getattr(rt, "_ilqr_wgs_now", None) == 1:
             rt._ilqr_wgs_now = getattr(rt, "_ilqr_wgs_user", int(os.environ.get("MIND_ILQR_WGS", "16")))
             self.lib.mind_set_tuning(rt.ctx, b"ilqr_wgs", rt._ilqr_wgs_now)
@@ -88,7 +89,12 @@ class IlqrCall:
     def wait(self):
         if getattr(self, "_begun", False):
             self._begun = False
-            self.rc = self.lib.mind_ilqr_finish(self.ctx)
+            rt = getattr(self, "_rt", None)
+            if rt is not None and (rt.ctx is None or rt.ctx.value != self.ctx.value):
+                # the runtime was closed (mind_ctx_destroy drained the stream and dropped the pending half): nothing to collect
+                self.rc = _lib.MIND_ESTATE
+            else:
+                self.rc = self.lib.mind_ilqr_finish(self.ctx)
         return self
 
     def finish(self):

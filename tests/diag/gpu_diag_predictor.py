@@ -1,6 +1,7 @@
 """GPU-box diagnostic: stage-by-stage comparison of the HIP predictor with the CPU oracle, for every arithmetic of the pair
 kernel (f32 / bf16x3 / bf16), and pair-kernel timings.
-Usage (on the GPU box): python tests/diag/gpu_diag_predictor.py [--big] [--prec f32,bf16x3,bf16]
+Usage (on the GPU box): python tests/diag/gpu_diag_predictor.py [--big] [--prec f32,bf16x3,bf16] [--tile 0,1] [--timing-only]
+--tile: the bf16 arithmetics with the row-major pair kernel of rounds 2-3 (0) and / or the tile-native one (1), same box.
 """
 import os
 import sys
@@ -34,12 +35,17 @@ def main():
     if "--prec" in sys.argv:
         precs = sys.argv[sys.argv.index("--prec") + 1].split(",")
     ok = True
+    tiles = [1]
+    if "--tile" in sys.argv:
+        tiles = [int(v) for v in sys.argv[sys.argv.index("--tile") + 1].split(",")]
     for prec in precs:
         hp.set_pair_precision(prec)
-        print(f"######## pair kernel arithmetic: {prec}")
-        if "--timing-only" not in sys.argv:
-            ok = run_parity(hp, sd, prec) and ok
-        run_timing(hp)
+        for tile in (tiles if prec != "f32" else [1]):
+            hp.set_tuning("pair_tile", tile)
+            print(f"######## pair kernel arithmetic: {prec}" + ("" if prec == "f32" else f", pair_tile = {tile}"))
+            if "--timing-only" not in sys.argv:
+                ok = run_parity(hp, sd, prec) and ok
+            run_timing(hp)
     print("DIAG_OK" if ok else "DIAG_FAIL")
 
 
