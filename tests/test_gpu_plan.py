@@ -794,10 +794,26 @@ def test_tree_ilqr_follows_the_reference_iteration_by_iteration(scene, variant):
             best = min(best, len(ref) if k2 is None else k2)
         return best
 
+    def oracle_view(ti, ph, dev_trace, ref):
+        """The same fit through the C oracle (glibc's sin / cos / tan; the kernel computes the same float64 operations in the same order
+        with the device math library's): (the oracle follows the reference's trace at least as far as the device does, the oracle's
+        trace equals the device's iteration by iteration).  Tells the two possible causes of an `own_noise` fit apart: last-bit
+        differences of the device's trigonometric functions (oracle follows the reference, device does not) or the cost tree's own
+        sensitivity to rounding noise in its inputs (the oracle leaves the reference's trace where the device does)."""
+        from oracle import ilqr as oi
+        cw, cf, flats, x0, lane, tv = got["args"]
+        wsol = oi.solve(cw, flats[ti], x0, lane, tv, 0, trace=True)
+        sol = wsol if ph == 0 else oi.solve(cf, flats[ti], x0, lane, tv, 1, us_init=wsol["us"], trace=True)
+        ko, kd = _first_divergence(sol["trace"], ref), _first_divergence(dev_trace, ref)
+        far = lambda k: 10 ** 9 if k is None else k
+        same_as_dev = len(sol["trace"]) == len(dev_trace) and np.array_equal(sol["trace"][:, [0, 2]], dev_trace[:, [0, 2]]) \
+            and np.allclose(sol["trace"][:, 1], dev_trace[:, 1], rtol=1e-12, atol=0)
+        return far(ko) > far(kd), same_as_dev
+
     opt.solve_batch = capture
     state_in, ctrl_in = D[scene + "_state_in"], D[scene + "_ctrl_in"]
     n_fits = same = behind_split = behind_warm = own_noise = iters = 0
-    early = []
+    early, noise_cause = [], []
     for pi in range(60):
         while sim.n_plans <= pi:
             will_plan = sim.sim_time >= sim.enable_time and (sim.last_trigger is None or sim.sim_time - sim.last_trigger >= sim.PLAN_STEP)
@@ -821,6 +837,7 @@ def test_tree_ilqr_follows_the_reference_iteration_by_iteration(scene, variant):
                     behind_split += 1
                 elif own_split(ti, ph, tr[ph]) <= k + 2:
                     own_noise += 1          # the two perturbed reference runs of the golden did not part that early, this solver's own do
+                    noise_cause.append((pi, ti, ph, k) + oracle_view(ti, ph, tr[ph], ref))
                 else:
                     early.append((pi, ti, ph, k, sp, len(ref), len(tr[ph])))
                 if ph == 0 and k is not None:
@@ -828,8 +845,17 @@ def test_tree_ilqr_follows_the_reference_iteration_by_iteration(scene, variant):
     print(f"[{scene} {variant}] {n_fits} fits / {iters} reference iterations: {same} identical traces, {behind_split} part where the reference's own "
           f"perturbed runs part, {own_noise} where this solver's own perturbed runs part, {behind_warm} full fits behind such a warm start, "
           f"unexplained: {early}")
+    if noise_cause:
+        print(f"[{scene} {variant}] the {own_noise} own-noise fits through the C oracle (glibc trigonometry): the oracle's trace equals the device's in "
+              f"{sum(1 for c in noise_cause if c[5])}, the oracle follows the reference further than the device in {sum(1 for c in noise_cause if c[4])} "
+              f"(= candidates for a last-bit difference of the device's sin / cos / tan); (cycle, tree, phase, first parting iteration, oracle further, "
+              f"oracle == device): {noise_cause}")
     assert not early, early
     # every fit on which the reference reproduces ITSELF under rounding noise is followed iteration by iteration, up to the few that only
     # this solver's own noise runs explain (the golden holds two perturbed reference runs per fit; observed: <= 2.3 % of a scene's fits)
     n_ref_split = int(sum(1 for (r_, sp_) in fits.values() if sp_ < len(r_)))
-    assert same + own_noise + behind_warm >= n_fits - n_ref_split and own_noise <= max(3, 0.03 * n_fits), (same, own_noise, n_ref_split, n_fits)
+    # own-noise fits: observed 0 / 4 / 1 / 5 / 0 / 2 / 0 / 1 over the eight (scene, weights) runs = 13 of 2 178 (profiles/r04j_*); through
+    # the C oracle (glibc trigonometry) none of them follows the reference further than the device does and 10 give the device's trace
+    # exactly: the cost trees' own sensitivity to rounding noise in their inputs, not the device's sin / cos / tan
+    assert same + own_noise + behind_warm >= n_fits - n_ref_split and own_noise <= max(2, 0.015 * n_fits), (same, own_noise, n_ref_split, n_fits)
+    assert not any(c[4] for c in noise_cause), noise_cause      # (a fit only the oracle follows would point at the device math library)
