@@ -356,6 +356,30 @@ typedef struct {
   const float *flat_cov;       /* [M_total, a]                                                                            */
 } mind_aime_plan_out;
 
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU: one process (one mind_ctx) per GPU plans the SAME scene; the scenes of every AIME round of mind_aime_plan are
+ * block-distributed over the ranks.  (The reference has no distributed code; the independence this rests on: the predictor loops
+ * per scene, planners/mind/networks/network.py:318,497, and prune_merge works scene by scene, scenario_tree.py:281-412.)
+ * Per round: every rank runs predictor + pruning + branch-time test on its block -> ONE all-gather of the decisions (96 B per
+ * scene) -> every rank replays create_nodes / decide_branch on the same table (the tree is replicated, 0.2 ms at 1 555 nodes) ->
+ * the rank that holds a branching node's parent scene re-bases it (update_obser, on the device) -> ONE all-gather of the next
+ * round's predictor inputs + history windows (packed and unpacked by the library).  At the end every rank packs the rows / cost
+ * tree entries of the nodes whose predicted rows it holds and ONE all-reduce (sum over zero-filled buffers) completes them
+ * everywhere.  With world == 1 the same code runs without exchanges.
+ *
+ * The transport is the caller's: a function that performs a collective on DEVICE buffers of this context's device,
+ *   MIND_XCHG_ALLGATHER:  recv [world][bytes] <- every rank's send [bytes], in rank order;
+ *   MIND_XCHG_ALLREDUCE:  recv [bytes / 4 floats] <- sum over the ranks of send (send may equal recv).
+ * It is called with everything the library queued on the context's stream complete, and must return with the result complete
+ * (mind_amd/parallel.py: torch.distributed -- RCCL over xGMI on a node, gloo in the tests).  world <= 1 or fn == NULL switches
+ * the sharding off; force != 0 runs the exchanges of a one-rank group too (tests: RCCL on a one-GPU box). */
+#define MIND_XCHG_ALLGATHER 0
+#define MIND_XCHG_ALLREDUCE 1
+typedef int (*mind_exchange_fn)(void *user, int op, void *send, void *recv, int64_t bytes);
+int mind_set_exchange(mind_ctx *ctx, int rank, int world, mind_exchange_fn fn, void *user, int force);
+/* collectives run and bytes received by this context's sharded plans so far */
+int mind_last_exchange_stats(mind_ctx *ctx, long long *collectives, long long *bytes);
+
 /* Returns MIND_ESTATE ("unsupported: ...") for the situations only the round-by-round host path handles -- a node re-expanded in a
  * later round than the one that created it, no finished branch (the host path raises the reference's assertion), more than
  * max_rounds rounds -- in which case the caller runs that path instead. */

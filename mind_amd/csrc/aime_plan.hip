@@ -7,6 +7,12 @@
 // and the parents' windows, k_aime_rebase) and the next predictor call is queued before the host looks at anything else.  Every
 // small table goes through page-locked staging, so no copy waits for the stream to drain.  At the end one gather kernel packs the
 // rows get_scenario_tree (scenario_tree.py:208-272) attaches to the nodes of finished branches.
+//
+// Sharded (mind_set_exchange, include/mind_hip.h): the scenes of a round are block-distributed over the ranks; a rank runs the device
+// part of the round on its block only, the decisions (96 B per scene) are all-gathered, the bookkeeping below is replayed identically on
+// every rank, the rank that holds a branching node's parent scene re-bases it and the next round's inputs + history windows are
+// all-gathered (packed / unpacked by k_copy_segs); the final rows / cost-tree entries are completed by one all-reduce over zero-filled
+// buffers.  world == 1 runs the same code without the exchanges.
 namespace {
 
 struct PlScene {            // an observation pushed through the predictor: the root or a re-based branch node
@@ -18,6 +24,7 @@ struct PlScene {            // an observation pushed through the predictor: the 
 
 struct PlNode {
   int round, scene, mode, parent, depth;
+  int owner, lscene;        // sharded: the rank whose pl_world[round] holds the node's predicted rows, its scene index there
   float prob;
   int cur_t, end_t;
   bool branch, end, term, rebased;
@@ -33,6 +40,53 @@ int pl_pin(mind_ctx *c, int which, size_t bytes) {      // (declared ahead of il
   if (hipHostMalloc(&c->pl_pin[which], want, hipHostMallocDefault) != hipSuccess)
     return fail(c, MIND_ENOMEM, "hipHostMalloc(%zu) failed", want);
   c->pl_pin_cap[which] = want;
+  return MIND_OK;
+}
+
+// contiguous block [lo, hi) of n items for rank r of w (the first ranks take the remainder: parallel.Shard.block)
+inline void pl_block(int n, int r, int w, int &lo, int &hi) {
+  const int base = n / w, rem = n % w;
+  lo = r * base + (r < rem ? r : rem);
+  hi = lo + base + (r < rem ? 1 : 0);
+}
+inline int pl_owner(int n, int w, int b) {
+  for (int r = 0; r < w; ++r) { int lo, hi; pl_block(n, r, w, lo, hi); if (b >= lo && b < hi) return r; }
+  return w - 1;
+}
+
+struct CopySeg { const float *src; float *dst; long long n; };
+// segment copies of the exchange packing: blockIdx.y = segment, blockIdx.x = 2048-float chunk of it
+__global__ __launch_bounds__(256) void k_copy_segs(const CopySeg *__restrict__ segs) {
+  const CopySeg S = segs[blockIdx.y];
+  const long long i0 = (long long)blockIdx.x * 2048 + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const long long i = i0 + k * 256;
+    if (i < S.n) S.dst[i] = S.src[i];
+  }
+}
+
+int pl_exchange(mind_ctx *c, int op, void *send, void *recv, size_t bytes) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int rc = c->xfn(c->xuser, op, send, recv, (int64_t)bytes);
+  if (rc) return fail(c, MIND_EHIP, "mind_aime_plan: the exchange callback failed (%d)", rc);
+  c->x_collectives += 1;
+  c->x_bytes += op == MIND_XCHG_ALLGATHER ? (long long)bytes * c->xw : (long long)bytes;
+  return MIND_OK;
+}
+
+int pl_copy_segs(mind_ctx *c, const std::vector<CopySeg> &segs) {
+  if (segs.empty()) return MIND_OK;
+  long long mx = 0;
+  for (const CopySeg &s : segs) mx = std::max(mx, s.n);
+  if (mx == 0) return MIND_OK;
+  int rc;
+  if ((rc = ensure(c, c->x_seg, segs.size() * sizeof(CopySeg)))) return rc;
+  if ((rc = pl_pin(c, 6, segs.size() * sizeof(CopySeg)))) return rc;      // (the previous table's copy completed: an exchange = a stream synchronisation lies between two uses)
+  memcpy(c->pl_pin[6], segs.data(), segs.size() * sizeof(CopySeg));
+  HIPCHK(c, hipMemcpyAsync(c->x_seg.p, c->pl_pin[6], segs.size() * sizeof(CopySeg), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_copy_segs, dim3((unsigned)((mx + 2047) / 2048), (unsigned)segs.size()), dim3(256), 0, c->stream, (const CopySeg *)c->x_seg.p);
+  HIPCHK(c, hipGetLastError());
   return MIND_OK;
 }
 
@@ -161,46 +215,58 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     return q;
   };
 
+  const int XW = c->xfn ? c->xw : 1, XR = c->xfn ? c->xr : 0;
+  const bool dist = c->xfn && (XW > 1 || c->xforce);       // exchanges run (a forced one-rank group included)
+  std::vector<int> my_lo_of_round;                          // first scene of this rank's block, per round
+
   for (;; ++round) {
-    const int B = (int)batch.size(), A = B * a;
+    const int B = (int)batch.size();
     if (round >= in->max_rounds) return fail(c, MIND_ESTATE, "unsupported: more than %d AIME rounds", in->max_rounds);
-    out->round_scenes[round] = B;
-    // ---- predictor on the round's scenes
-    std::vector<int32_t> ao(B + 1), lo(B + 1);
-    for (int b = 0; b <= B; ++b) { ao[b] = a * b; lo[b] = l * b; }
-    if ((rc = ensure(c, c->pl_pred, ((size_t)B * 6 + (size_t)A * 6 * T * 7) * sizeof(float)))) return rc;
-    float *d_cls = (float *)c->pl_pred.p, *d_reg = d_cls + (((size_t)B * 6 + 3) & ~(size_t)3), *d_vel = d_reg + (size_t)A * 6 * T * 5;
-    if ((rc = ensure(c, c->pl_pred, ((size_t)(d_vel - d_cls) + (size_t)A * 6 * T * 2) * sizeof(float)))) return rc;
-    d_cls = (float *)c->pl_pred.p; d_reg = d_cls + (((size_t)B * 6 + 3) & ~(size_t)3); d_vel = d_reg + (size_t)A * 6 * T * 5;
-    mind_scene_batch sb;
-    memset(&sb, 0, sizeof(sb));
-    mind_pred_out po;
-    memset(&po, 0, sizeof(po));
-    sb.n_scenes = B; sb.actor_off = ao.data(); sb.lane_off = lo.data();
-    const float *d_ctrs, *d_vecs;
-    if (cur_in < 0) {
-      sb.actors = droot + o_actors; sb.lanes = droot + o_lanes; sb.actor_ctrs = d_ctrs = droot + o_ctrs; sb.actor_vecs = d_vecs = droot + o_vecs;
-      sb.lane_ctrs = droot + o_lc; sb.lane_vecs = droot + o_lv; sb.tgt_nodes = droot + o_tn; sb.tgt_rpe = droot + o_tr;
-      po.lane_feat = (float *)c->pl_lf.p;
-    } else {
-      const InOff q = in_off(B);
-      const float *d = (const float *)c->pl_in[cur_in].p;
-      sb.actors = d + q.actors; sb.actor_ctrs = d_ctrs = d + q.ctrs; sb.actor_vecs = d_vecs = d + q.vecs; sb.lane_ctrs = d + q.lc; sb.lane_vecs = d + q.lv;
-      sb.tgt_nodes = d + q.tn; sb.tgt_rpe = d + q.tr;
-      sb.lane_feat = B == 1 ? (const float *)c->pl_lf.p : (const float *)c->pl_lrep.p;
+    int lo, hi;
+    pl_block(B, XR, XW, lo, hi);
+    const int Bk = hi - lo, A = Bk * a;                     // this rank's scenes [lo, hi) of the round, their agent rows
+    const int Bmax = (B + XW - 1) / XW;                     // the largest block (the decision buffers are laid out for it)
+    my_lo_of_round.push_back(lo);
+    out->round_scenes[round] = Bk;
+    // ---- predictor on this rank's scenes of the round
+    float *d_cls = nullptr, *d_reg = nullptr, *d_vel = nullptr;
+    const float *d_ctrs = nullptr, *d_vecs = nullptr;
+    if (Bk > 0) {
+      std::vector<int32_t> ao(Bk + 1), lof(Bk + 1);
+      for (int b = 0; b <= Bk; ++b) { ao[b] = a * b; lof[b] = l * b; }
+      const size_t n_cls = ((size_t)Bk * 6 + 3) & ~(size_t)3;
+      if ((rc = ensure(c, c->pl_pred, (n_cls + (size_t)A * 6 * T * 7) * sizeof(float)))) return rc;
+      d_cls = (float *)c->pl_pred.p; d_reg = d_cls + n_cls; d_vel = d_reg + (size_t)A * 6 * T * 5;
+      mind_scene_batch sb;
+      memset(&sb, 0, sizeof(sb));
+      mind_pred_out po;
+      memset(&po, 0, sizeof(po));
+      sb.n_scenes = Bk; sb.actor_off = ao.data(); sb.lane_off = lof.data();
+      if (cur_in < 0) {
+        sb.actors = droot + o_actors; sb.lanes = droot + o_lanes; sb.actor_ctrs = d_ctrs = droot + o_ctrs; sb.actor_vecs = d_vecs = droot + o_vecs;
+        sb.lane_ctrs = droot + o_lc; sb.lane_vecs = droot + o_lv; sb.tgt_nodes = droot + o_tn; sb.tgt_rpe = droot + o_tr;
+        po.lane_feat = (float *)c->pl_lf.p;
+      } else {
+        const InOff q = in_off(B);
+        const float *d = (const float *)c->pl_in[cur_in].p;
+        sb.actors = d + q.actors + (size_t)lo * a * 14 * 48; sb.actor_ctrs = d_ctrs = d + q.ctrs + (size_t)lo * a * 2; sb.actor_vecs = d_vecs = d + q.vecs + (size_t)lo * a * 2;
+        sb.lane_ctrs = d + q.lc + (size_t)lo * l * 2; sb.lane_vecs = d + q.lv + (size_t)lo * l * 2;
+        sb.tgt_nodes = d + q.tn + (size_t)lo * 160; sb.tgt_rpe = d + q.tr + (size_t)lo * 20;
+        sb.lane_feat = Bk == 1 ? (const float *)c->pl_lf.p : (const float *)c->pl_lrep.p;
+      }
+      po.cls = d_cls; po.reg = d_reg; po.vel = d_vel;
+      if ((rc = mind_predict_batch(c, &sb, &po))) return rc;
+      n_expanded += Bk;
+      if (c->profiling) { pair_ms += c->pair_ms; pair_launches += c->n_pair_launch; }
+      if (in->script_cls) {
+        // scripted modes (benchmark hook): the forward above was the timed work, its outputs are replaced scene by scene
+        const size_t nr = (size_t)a * 6 * T * 5, nv = (size_t)a * 6 * T * 2;
+        hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((6 * (size_t)Bk + 255) / 256)), dim3(256), 0, st, in->script_cls, (size_t)6, Bk, d_cls);
+        hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((nr * Bk + 255) / 256)), dim3(256), 0, st, in->script_reg, nr, Bk, d_reg);
+        hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((nv * Bk + 255) / 256)), dim3(256), 0, st, in->script_vel, nv, Bk, d_vel);
+      }
     }
-    po.cls = d_cls; po.reg = d_reg; po.vel = d_vel;
-    if ((rc = mind_predict_batch(c, &sb, &po))) return rc;
-    n_expanded += B;
-    if (c->profiling) { pair_ms += c->pair_ms; pair_launches += c->n_pair_launch; }
-    if (in->script_cls) {
-      // scripted modes (benchmark hook): the forward above was the timed work, its outputs are replaced scene by scene
-      const size_t nr = (size_t)a * 6 * T * 5, nv = (size_t)a * 6 * T * 2;
-      hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((6 * (size_t)B + 255) / 256)), dim3(256), 0, st, in->script_cls, (size_t)6, B, d_cls);
-      hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((nr * B + 255) / 256)), dim3(256), 0, st, in->script_reg, nr, B, d_reg);
-      hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((nv * B + 255) / 256)), dim3(256), 0, st, in->script_vel, nv, B, d_vel);
-    }
-    // ---- the frames of the re-based scenes (queued behind k_aime_rebase, before this round's predictor): ROT, ORIG, TGT_PTS
+    // ---- the frames of the re-based scenes (queued behind k_aime_rebase / the unpacking, before this round's predictor): ROT, ORIG, TGT_PTS
     if (frames_pending) {
       HIPCHK(c, hipEventSynchronize(c->ev_pl));
       const float *fr = (const float *)c->pl_pin[3];
@@ -211,23 +277,30 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       }
       frames_pending = false;
     }
-    // ---- prune_merge arithmetic + decisions + branch-time bits on the device
-    const size_t bS = ((size_t)B * sizeof(AimeScene) + 15) & ~(size_t)15, bI = ((size_t)A * sizeof(int) + 15) & ~(size_t)15;
-    const size_t bP = ((size_t)B * sizeof(float) + 15) & ~(size_t)15;
-    const size_t tab_bytes = bS + bI + bP;
-    // (two table buffers, by round parity: this round's tables are uploaded on the copy stream while the predictor runs -- the stream
-    // may still hold the previous round's windows kernel, which reads the index lists behind that round's tables)
+    // ---- prune_merge arithmetic + decisions + branch-time bits on the device (this rank's scenes)
+    // small outputs: topo [A,6] | ego_end [Bk,6,4] | decisions laid out for Bmax scenes: sel [Bmax,6] | sel_prob [Bmax,6] | hit [Bmax,6,2]
+    const size_t n_topo = ((size_t)A * 6 + 3) & ~(size_t)3, n_ego = (size_t)Bk * 24, n_back = (size_t)Bmax * 6 * 4;
+    if ((rc = ensure(c, c->pl_small, (n_topo + n_ego + n_back) * sizeof(float)))) return rc;
+    float *d_topo = (float *)c->pl_small.p, *d_ego = d_topo + n_topo, *d_sel = d_ego + n_ego, *d_selp = d_sel + (size_t)Bmax * 6;
+    unsigned *d_hit = (unsigned *)(d_selp + (size_t)Bmax * 6);
     DevBuf &tabb = c->pl_tab[round & 1];
-    if ((rc = ensure(c, tabb, tab_bytes + 3 * (size_t)6 * B * sizeof(int) + 64))) return rc;
-    if ((rc = pl_pin(c, 1, tab_bytes + 3 * (size_t)6 * B * sizeof(int) + 64))) return rc;
-    {
+    const size_t bS = ((size_t)Bk * sizeof(AimeScene) + 15) & ~(size_t)15, bI = ((size_t)A * sizeof(int) + 15) & ~(size_t)15;
+    const size_t bP = ((size_t)Bk * sizeof(float) + 15) & ~(size_t)15;
+    const size_t tab_bytes = bS + bI + bP;
+    // (two table buffers, by round parity: the stream may still hold the previous round's windows kernel, which reads the index lists behind
+    // that round's tables)
+    if ((rc = ensure(c, tabb, tab_bytes + 3 * (size_t)6 * Bmax * sizeof(int) + 64))) return rc;
+    if ((rc = pl_pin(c, 1, tab_bytes + 3 * (size_t)6 * Bmax * sizeof(int) + 64))) return rc;
+    if ((int)c->pl_world.size() <= round) c->pl_world.resize(round + 1);
+    float *d_world = nullptr;
+    if (Bk > 0) {
       char *h = (char *)c->pl_pin[1];
       AimeScene *hs = (AimeScene *)h;
       int *as = (int *)(h + bS);
       float *sp = (float *)(h + bS + bI);
-      for (int b = 0; b < B; ++b) {
+      for (int b = 0; b < Bk; ++b) {
         AimeScene &S = hs[b];
-        const PlScene &q = batch[b];
+        const PlScene &q = batch[lo + b];
         S.a0 = a * b; S.a1 = a * (b + 1); S.last = HZ - 1;     /* seq_len - 1 - history length */ S.cmp = q.cur_t == 0 ? 1 : q.cur_t; S.pad2 = 0.f;
         S.r00 = q.rot[0]; S.r01 = q.rot[1]; S.r10 = q.rot[2]; S.r11 = q.rot[3];
         S.ox = q.orig[0]; S.oy = q.orig[1];
@@ -242,37 +315,47 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       } else {
         HIPCHK(c, hipMemcpyAsync(tabb.p, h, tab_bytes, hipMemcpyHostToDevice, st));
       }
+      const char *dtab = (const char *)tabb.p;
+      if ((rc = ensure(c, c->pl_world[round], (size_t)A * 6 * T * 6 * sizeof(float)))) return rc;
+      d_world = (float *)c->pl_world[round].p;
+      hipLaunchKernelGGL(k_aime_world, dim3(A * AIME_K), dim3(64), 0, st, (const AimeScene *)dtab, (const int *)(dtab + bS), d_reg, d_vel, d_ctrs, d_vecs,
+                         cov_last_dev + (size_t)lo * a, d_world, d_topo, d_ego, droot + o_tl, P);
+      hipLaunchKernelGGL(k_aime_select, dim3(Bk), dim3(64), 0, st, (const AimeScene *)dtab, d_cls, (const float *)(dtab + bS + bI), d_topo, d_ego, 1,
+                         in->dist_thres, d_sel, d_selp);
+      hipLaunchKernelGGL(k_aime_branch, dim3(Bk * AIME_K), dim3(64), 0, st, (const AimeScene *)dtab, d_sel, d_world, d_hit);
+      HIPCHK(c, hipGetLastError());
     }
-    const char *dtab = (const char *)tabb.p;
-    if ((int)c->pl_world.size() <= round) c->pl_world.resize(round + 1);
-    if ((rc = ensure(c, c->pl_world[round], (size_t)A * 6 * T * 6 * sizeof(float)))) return rc;
-    float *d_world = (float *)c->pl_world[round].p;
-    // small outputs: topo [A,6] | ego_end [B,6,4] | sel [B,6] | sel_prob [B,6] | hit [B,6,2] (the last three are read back)
-    const size_t n_topo = ((size_t)A * 6 + 3) & ~(size_t)3, n_ego = (size_t)B * 24, n_back = (size_t)B * 6 * 4;
-    if ((rc = ensure(c, c->pl_small, (n_topo + n_ego + n_back) * sizeof(float)))) return rc;
-    float *d_topo = (float *)c->pl_small.p, *d_ego = d_topo + n_topo, *d_sel = d_ego + n_ego, *d_selp = d_sel + (size_t)B * 6;
-    unsigned *d_hit = (unsigned *)(d_selp + (size_t)B * 6);
-    hipLaunchKernelGGL(k_aime_world, dim3(A * AIME_K), dim3(64), 0, st, (const AimeScene *)dtab, (const int *)(dtab + bS), d_reg, d_vel, d_ctrs, d_vecs,
-                       cov_last_dev, d_world, d_topo, d_ego, droot + o_tl, P);
-    hipLaunchKernelGGL(k_aime_select, dim3(B), dim3(64), 0, st, (const AimeScene *)dtab, d_cls, (const float *)(dtab + bS + bI), d_topo, d_ego, 1,
-                       in->dist_thres, d_sel, d_selp);
-    hipLaunchKernelGGL(k_aime_branch, dim3(B * AIME_K), dim3(64), 0, st, (const AimeScene *)dtab, d_sel, d_world, d_hit);
-    HIPCHK(c, hipGetLastError());
-    if ((rc = pl_pin(c, 2, n_back * sizeof(float)))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->pl_pin[2], d_sel, n_back * sizeof(float), hipMemcpyDeviceToHost, st));
+    // ---- the round's decisions on the host: this rank's block, or (sharded) every rank's through one all-gather
+    const float *h_dec;             // [ranks][Bmax x 24 floats]
+    if (dist) {
+      if ((rc = ensure(c, c->x_recv, (size_t)XW * n_back * sizeof(float)))) return rc;
+      if ((rc = pl_exchange(c, MIND_XCHG_ALLGATHER, d_sel, c->x_recv.p, n_back * sizeof(float)))) return rc;
+      if ((rc = pl_pin(c, 2, (size_t)XW * n_back * sizeof(float)))) return rc;
+      HIPCHK(c, hipMemcpyAsync(c->pl_pin[2], c->x_recv.p, (size_t)XW * n_back * sizeof(float), hipMemcpyDeviceToHost, st));
+    } else {
+      if ((rc = pl_pin(c, 2, n_back * sizeof(float)))) return rc;
+      HIPCHK(c, hipMemcpyAsync(c->pl_pin[2], d_sel, n_back * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(c, hipStreamSynchronize(st));
-    const float *h_sel = (const float *)c->pl_pin[2], *h_selp = h_sel + (size_t)B * 6;
-    const unsigned *h_hit = (const unsigned *)(h_selp + (size_t)B * 6);
+    h_dec = (const float *)c->pl_pin[2];
     // ---- create_nodes (scenario_tree.py:73-80): the kept modes scene by scene, visiting order within a scene
-    for (int b = 0; b < B; ++b)
+    for (int b = 0; b < B; ++b) {
+      const int owner = dist ? pl_owner(B, XW, b) : 0;
+      int olo, ohi;
+      pl_block(B, owner, XW, olo, ohi);
+      if (!dist) { olo = 0; }
+      const float *h_sel = h_dec + (size_t)owner * n_back, *h_selp = h_sel + (size_t)Bmax * 6;
+      const unsigned *h_hit = (const unsigned *)(h_selp + (size_t)Bmax * 6);
+      const int bl = b - olo;
       for (int j = 0; j < AIME_K; ++j) {
-        const int k = (int)h_sel[(size_t)b * 6 + j];
+        const int k = (int)h_sel[(size_t)bl * 6 + j];
         if (k < 0) continue;
         PlNode n;
         memset(&n, 0, sizeof(n));
         n.round = round; n.scene = b; n.mode = k; n.parent = batch[b].node; n.depth = nodes[n.parent].depth + 1;
-        n.prob = h_selp[(size_t)b * 6 + j]; n.cur_t = batch[b].cur_t; n.end_t = batch[b].end_t;
-        n.hit = (unsigned long long)h_hit[2 * ((size_t)b * 6 + j)] | ((unsigned long long)h_hit[2 * ((size_t)b * 6 + j) + 1] << 32);
+        n.owner = owner; n.lscene = bl;
+        n.prob = h_selp[(size_t)bl * 6 + j]; n.cur_t = batch[b].cur_t; n.end_t = batch[b].end_t;
+        n.hit = (unsigned long long)h_hit[2 * ((size_t)bl * 6 + j)] | ((unsigned long long)h_hit[2 * ((size_t)bl * 6 + j) + 1] << 32);
         memcpy(n.tgt, batch[b].tgt, sizeof(n.tgt));
         const int idx = (int)nodes.size();
         nodes.push_back(n);
@@ -280,6 +363,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
           if (leaves[q] == n.parent) { leaves.erase(leaves.begin() + q); break; }
         leaves.push_back(idx);
       }
+    }
     // ---- decide_branch (scenario_tree.py:82-100) over the leaves in insertion order
     std::vector<int> cand, todo;
     for (int li : leaves) {
@@ -304,21 +388,19 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       else n.end = true;
     }
     if (todo.empty()) { ++round; break; }
-    // ---- update_obser (:467-567) of the branching nodes: windows + predictor inputs of the next round, on the device
+    // ---- update_obser (:467-567) of the branching nodes: windows + predictor inputs of the next round, on the device.  Sharded: a rank
+    //      re-bases the children of ITS scenes (the parent windows and the predicted rows are there); the branch set is in leaf order =
+    //      parent-scene order, so a rank's children are one contiguous range [s0, s0 + Sm) of the next round's scenes
     const int S = (int)todo.size();
     for (int li : todo)
       if (nodes[li].round != round) return fail(c, MIND_ESTATE, "unsupported: a node of round %d is expanded again in round %d", nodes[li].round, round + 1);
-    {
-      int *hi = (int *)((char *)c->pl_pin[1] + tab_bytes);
-      for (int s = 0; s < S; ++s) {
-        const PlNode &n = nodes[todo[s]];
-        hi[s] = n.scene;                                  // parent window: the scene of this round the node was predicted from
-        hi[S + s] = n.scene * a * AIME_K + n.mode;        // first row (agent 0) of the node's mode in d_world
-        hi[2 * S + s] = n.end_t - n.cur_t;                // steps kept
-      }
-      HIPCHK(c, hipMemcpyAsync((char *)tabb.p + tab_bytes, hi, 3 * (size_t)S * sizeof(int), hipMemcpyHostToDevice, st));
+    std::vector<int> cnt_r(XW, 0), s0_r(XW + 1, 0);
+    for (int s = 0; s < S; ++s) {
+      if (s > 0 && nodes[todo[s]].scene < nodes[todo[s - 1]].scene) return fail(c, MIND_ESTATE, "unsupported: branch set out of scene order");
+      cnt_r[nodes[todo[s]].owner] += 1;
     }
-    const int *d_idx = (const int *)((const char *)tabb.p + tab_bytes);
+    for (int r = 0; r < XW; ++r) s0_r[r + 1] = s0_r[r] + cnt_r[r];
+    const int s0 = s0_r[XR], Sm = cnt_r[XR];
     const int nxt = cur_in < 0 ? 0 : cur_in ^ 1;
     const InOff q = in_off(S);
     if ((rc = ensure(c, c->pl_in[nxt], q.total * sizeof(float)))) return rc;
@@ -326,22 +408,70 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     if ((rc = ensure(c, c->pl_win[nxt], (2 * n_wpos + n_wang) * sizeof(float)))) return rc;
     float *w_pos = (float *)c->pl_win[nxt].p, *w_ang = w_pos + n_wpos, *w_vel = w_ang + n_wang;
     float *d_in = (float *)c->pl_in[nxt].p;
-    hipLaunchKernelGGL(k_aime_windows, dim3((unsigned)(S * a)), dim3(64), 0, st, prev_pos, prev_ang, prev_vel, (const float *)d_world, d_idx, d_idx + S,
-                       d_idx + 2 * S, a, w_pos, w_ang, w_vel, AIME_K, d_in + q.cov);
-    RebaseArgs R;
-    R.a = a; R.l = l; R.n_lane = P; R.pad_ones = 1;
-    R.pos = w_pos; R.ang = w_ang; R.vel = w_vel; R.types = droot + o_types; R.pad = nullptr;
-    R.lane_ctrs0 = droot + o_lc; R.lane_vecs0 = droot + o_lv; R.tlane = droot + o_tl; R.tinfo = droot + o_ti;
-    R.time_ahead = in->time_ahead; R.min_vel = in->min_vel; R.travel0 = -1.f;
-    R.actors = d_in + q.actors; R.actor_ctrs = d_in + q.ctrs; R.actor_vecs = d_in + q.vecs; R.lane_ctrs = d_in + q.lc; R.lane_vecs = d_in + q.lv;
-    R.tgt_nodes = d_in + q.tn; R.tgt_rpe = d_in + q.tr; R.frames = d_in + q.fr;
-    hipLaunchKernelGGL(k_aime_rebase, dim3((unsigned)S, 1 + RB_FEAT_BLOCKS(a)), dim3(RB_THREADS), 5 * (size_t)a * sizeof(float), st, R);
-    if (S > 1) {
-      if ((rc = ensure(c, c->pl_lrep, (size_t)S * l * 128 * sizeof(float)))) return rc;
-      const size_t n = (size_t)l * 128;
-      hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((n * S + 255) / 256)), dim3(256), 0, st, (const float *)c->pl_lf.p, n, S, (float *)c->pl_lrep.p);
+    if (Sm > 0) {
+      int *hi_ = (int *)((char *)c->pl_pin[1] + tab_bytes);
+      for (int s = 0; s < Sm; ++s) {
+        const PlNode &n = nodes[todo[s0 + s]];
+        hi_[s] = n.scene;                                  // parent window: the scene of this round the node was predicted from (global index)
+        hi_[Sm + s] = n.lscene * a * AIME_K + n.mode;      // first row (agent 0) of the node's mode in this rank's d_world
+        hi_[2 * Sm + s] = n.end_t - n.cur_t;               // steps kept
+      }
+      HIPCHK(c, hipMemcpyAsync((char *)tabb.p + tab_bytes, hi_, 3 * (size_t)Sm * sizeof(int), hipMemcpyHostToDevice, st));
+      const int *d_idx = (const int *)((const char *)tabb.p + tab_bytes);
+      hipLaunchKernelGGL(k_aime_windows, dim3((unsigned)(Sm * a)), dim3(64), 0, st, prev_pos, prev_ang, prev_vel, (const float *)d_world, d_idx, d_idx + Sm,
+                         d_idx + 2 * Sm, a, w_pos + (size_t)s0 * a * OBS * 2, w_ang + (size_t)s0 * a * OBS, w_vel + (size_t)s0 * a * OBS * 2, AIME_K,
+                         d_in + q.cov + (size_t)s0 * a);
+      RebaseArgs R;
+      R.a = a; R.l = l; R.n_lane = P; R.pad_ones = 1;
+      R.pos = w_pos + (size_t)s0 * a * OBS * 2; R.ang = w_ang + (size_t)s0 * a * OBS; R.vel = w_vel + (size_t)s0 * a * OBS * 2; R.types = droot + o_types; R.pad = nullptr;
+      R.lane_ctrs0 = droot + o_lc; R.lane_vecs0 = droot + o_lv; R.tlane = droot + o_tl; R.tinfo = droot + o_ti;
+      R.time_ahead = in->time_ahead; R.min_vel = in->min_vel; R.travel0 = -1.f;
+      R.actors = d_in + q.actors + (size_t)s0 * a * 14 * 48; R.actor_ctrs = d_in + q.ctrs + (size_t)s0 * a * 2; R.actor_vecs = d_in + q.vecs + (size_t)s0 * a * 2;
+      R.lane_ctrs = d_in + q.lc + (size_t)s0 * l * 2; R.lane_vecs = d_in + q.lv + (size_t)s0 * l * 2;
+      R.tgt_nodes = d_in + q.tn + (size_t)s0 * 160; R.tgt_rpe = d_in + q.tr + (size_t)s0 * 20; R.frames = d_in + q.fr + (size_t)s0 * 28;
+      hipLaunchKernelGGL(k_aime_rebase, dim3((unsigned)Sm, 1 + RB_FEAT_BLOCKS(a)), dim3(RB_THREADS), 5 * (size_t)a * sizeof(float), st, R);
+      HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipGetLastError());
+    if (dist) {
+      // ---- one all-gather completes the next round's inputs + windows everywhere: per rank [header | the twelve array slices of its
+      //      children, each laid out for the largest child count]; the header is LaneNet's output after the root round (rank 0 ran it)
+      struct Arr { float *base; size_t per; };
+      const Arr arrs[12] = {{d_in + q.actors, (size_t)a * 14 * 48}, {d_in + q.ctrs, (size_t)a * 2}, {d_in + q.vecs, (size_t)a * 2}, {d_in + q.lc, (size_t)l * 2},
+                            {d_in + q.lv, (size_t)l * 2}, {d_in + q.tn, 160}, {d_in + q.tr, 20}, {d_in + q.fr, 28}, {d_in + q.cov, (size_t)a},
+                            {w_pos, (size_t)a * OBS * 2}, {w_ang, (size_t)a * OBS}, {w_vel, (size_t)a * OBS * 2}};
+      int cmax = 0;
+      for (int r = 0; r < XW; ++r) cmax = std::max(cmax, cnt_r[r]);
+      const size_t n_hdr = round == 0 ? (size_t)l * 128 : 0;
+      size_t off[13];
+      off[0] = n_hdr;
+      for (int k = 0; k < 12; ++k) off[k + 1] = off[k] + arrs[k].per * (size_t)cmax;
+      const size_t n_pay = (off[12] + 3) & ~(size_t)3;
+      if ((rc = ensure(c, c->x_send, n_pay * sizeof(float)))) return rc;
+      if ((rc = ensure(c, c->x_recv, (size_t)XW * n_pay * sizeof(float)))) return rc;
+      float *snd = (float *)c->x_send.p, *rcv = (float *)c->x_recv.p;
+      std::vector<CopySeg> segs;
+      if (n_hdr && XR == 0) segs.push_back({(const float *)c->pl_lf.p, snd, (long long)n_hdr});
+      for (int k = 0; k < 12 && Sm > 0; ++k) segs.push_back({arrs[k].base + arrs[k].per * (size_t)s0, snd + off[k], (long long)(arrs[k].per * (size_t)Sm)});
+      if ((rc = pl_copy_segs(c, segs))) return rc;
+      if ((rc = pl_exchange(c, MIND_XCHG_ALLGATHER, snd, rcv, n_pay * sizeof(float)))) return rc;
+      segs.clear();
+      if (n_hdr && XR != 0) segs.push_back({rcv, (float *)c->pl_lf.p, (long long)n_hdr});
+      for (int r = 0; r < XW; ++r) {
+        if (r == XR || cnt_r[r] == 0) continue;
+        for (int k = 0; k < 12; ++k)
+          segs.push_back({rcv + (size_t)r * n_pay + off[k], arrs[k].base + arrs[k].per * (size_t)s0_r[r], (long long)(arrs[k].per * (size_t)cnt_r[r])});
+      }
+      if ((rc = pl_copy_segs(c, segs))) return rc;
+    }
+    // LaneNet's output repeated for this rank's scenes of the next round
+    int nlo, nhi;
+    pl_block(S, XR, XW, nlo, nhi);
+    if (nhi - nlo > 1) {
+      if ((rc = ensure(c, c->pl_lrep, (size_t)(nhi - nlo) * l * 128 * sizeof(float)))) return rc;
+      const size_t n = (size_t)l * 128;
+      hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((n * (nhi - nlo) + 255) / 256)), dim3(256), 0, st, (const float *)c->pl_lf.p, n, nhi - nlo, (float *)c->pl_lrep.p);
+      HIPCHK(c, hipGetLastError());
+    }
     if ((rc = pl_pin(c, 3, (size_t)S * 28 * sizeof(float)))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->pl_pin[3], d_in + q.fr, (size_t)S * 28 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipEventRecord(c->ev_pl, st));
@@ -382,9 +512,9 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     if (n.end) {
       const int dur = n.end_t - n.cur_t;
       p.dur = dur; p.row_off = n_rows;
-      if (dur > 0) {
+      if (dur > 0 && (!dist || n.owner == XR)) {            // (sharded: the rank that holds the node's predicted rows packs them)
         AimeGather J;
-        J.row0 = n.scene * a * AIME_K + n.mode; J.dur = dur; J.dst = (int)n_rows; J.a = a;
+        J.row0 = n.lscene * a * AIME_K + n.mode; J.dur = dur; J.dst = (int)n_rows; J.a = a;
         for (int e = 0; e < a; ++e) { job_of_block.push_back((int)jobs.size()); agent_of_block.push_back(e); }
         jobs.push_back(J);
         job_world.push_back((const float *)c->pl_world[n.round].p);
@@ -429,11 +559,13 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
           c->pl_flat_parent.push_back(m == 0 ? up : count + m - 1);
           c->pl_flat_prob.push_back(pr[q]);
         }
-        AimeFlat J;
-        J.row0 = n.scene * a * AIME_K + n.mode; J.n = nn; J.dst = base + count; J.a = a;
-        for (int e = 0; e < a; ++e) { fjob_of_block.push_back((int)fjobs.size()); fagent_of_block.push_back(e); }
-        fjobs.push_back(J);
-        fworld.push_back((const float *)c->pl_world[n.round].p);
+        if (!dist || n.owner == XR) {
+          AimeFlat J;
+          J.row0 = n.lscene * a * AIME_K + n.mode; J.n = nn; J.dst = base + count; J.a = a;
+          for (int e = 0; e < a; ++e) { fjob_of_block.push_back((int)fjobs.size()); fagent_of_block.push_back(e); }
+          fjobs.push_back(J);
+          fworld.push_back((const float *)c->pl_world[n.round].p);
+        }
         count += nn;
         last[q] = count - 1;
       } else {
@@ -449,8 +581,8 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   c->pl_flat_mean.resize(Mtot * a * 2); c->pl_flat_cov.resize(Mtot * a);
   c->pl_rows_host.resize((size_t)n_rows);
   // one upload (both job tables), the two gather kernels, one read-back (rows | flat means | flat covariances)
-  const size_t n_flat = fjobs.empty() ? 0 : Mtot * a * 3;
-  if (!jobs.empty() || !fjobs.empty()) {
+  const size_t n_flat = Mtot * a * 3;
+  if (n_rows + (int64_t)n_flat > 0) {
     const size_t fJ = (fjobs.size() * sizeof(AimeFlat) + 15) & ~(size_t)15, fW = (fjobs.size() * sizeof(float *) + 15) & ~(size_t)15;
     const size_t fB = (fjob_of_block.size() * sizeof(int) + 15) & ~(size_t)15;
     const size_t gJ = (jobs.size() * sizeof(AimeGather) + 15) & ~(size_t)15, gW = (jobs.size() * sizeof(float *) + 15) & ~(size_t)15;
@@ -473,9 +605,10 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       memcpy(h + o_g + gJ + gW, job_of_block.data(), job_of_block.size() * sizeof(int));
       memcpy(h + o_g + gJ + gW + gB, agent_of_block.data(), agent_of_block.size() * sizeof(int));
     }
-    HIPCHK(c, hipMemcpyAsync(c->pl_flat.p, h, n_tab, hipMemcpyHostToDevice, st));
+    if (n_tab) HIPCHK(c, hipMemcpyAsync(c->pl_flat.p, h, n_tab, hipMemcpyHostToDevice, st));
     char *d = (char *)c->pl_flat.p;
     float *d_rows = (float *)(d + o_rows), *d_fmean = d_rows + n_rows, *d_fcov = d_fmean + Mtot * a * 2;
+    if (dist) HIPCHK(c, hipMemsetAsync(d_rows, 0, n_res * sizeof(float), st));      // every entry is written by exactly one rank: the sum completes it
     if (!fjobs.empty())
       hipLaunchKernelGGL(k_aime_flat, dim3((unsigned)fjob_of_block.size()), dim3(64), 0, st, (const AimeFlat *)d, (const int *)(d + fJ + fW),
                          (const int *)(d + fJ + fW + fB), (const float *const *)(d + fJ), d_fmean, d_fcov);
@@ -483,6 +616,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       hipLaunchKernelGGL(k_aime_gather, dim3((unsigned)job_of_block.size()), dim3(64), 0, st, (const AimeGather *)(d + o_g),
                          (const int *)(d + o_g + gJ + gW), (const int *)(d + o_g + gJ + gW + gB), (const float *const *)(d + o_g + gJ), d_rows);
     HIPCHK(c, hipGetLastError());
+    if (dist && (rc = pl_exchange(c, MIND_XCHG_ALLREDUCE, d_rows, d_rows, n_res * sizeof(float)))) return rc;
     if ((rc = pl_pin(c, 2, n_res * sizeof(float)))) return rc;
     float *hp = (float *)c->pl_pin[2];
     HIPCHK(c, hipMemcpyAsync(hp, d_rows, n_res * sizeof(float), hipMemcpyDeviceToHost, st));

@@ -125,9 +125,16 @@ struct mind_ctx {
   // source makes hipMemcpyAsync wait for the stream to drain first), host result tables
   DevBuf pl_root, pl_in[2], pl_lf, pl_lrep, pl_pred, pl_small, pl_tab[2], pl_win[2];
   std::vector<DevBuf> pl_world;
-  void *pl_pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // [4], [5]: upload / read-back staging of the tree-iLQR calls
-  size_t pl_pin_cap[6] = {0, 0, 0, 0, 0, 0};
+  void *pl_pin[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // [4], [5]: upload / read-back staging of the tree-iLQR calls; [6], [7]: sharded plan
+  size_t pl_pin_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t ev_pl = nullptr, ev_tab = nullptr;
+  // mind_set_exchange: the sharded mind_aime_plan (rank, world, the caller's transport, packing buffers, collectives of the last plan)
+  int xr = 0, xw = 1;
+  mind_exchange_fn xfn = nullptr;
+  void *xuser = nullptr;
+  bool xforce = false;
+  DevBuf x_send, x_recv, x_seg;
+  long long x_collectives = 0, x_bytes = 0;
   // "pl_tab_side" / MIND_PL_TAB_SIDE=1: the round tables travel on their own stream while the round's predictor runs instead of behind it
   // on the context stream.  Measured on the recorded demo_1 loop: no difference (AIME 2.00 vs 2.01 ms per plan, profiles/r03ag) -- off.
   hipStream_t pl_copy = nullptr;
@@ -282,7 +289,7 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
       if (b->p) (void)hipFree(b->p);
   if (c->wdev) (void)hipFree(c->wdev);
   for (DevBuf *b : {&c->pl_root, &c->pl_in[0], &c->pl_in[1], &c->pl_lf, &c->pl_lrep, &c->pl_pred, &c->pl_small, &c->pl_tab[0], &c->pl_tab[1], &c->pl_win[0],
-                    &c->pl_win[1], &c->pl_flat})
+                    &c->pl_win[1], &c->pl_flat, &c->x_send, &c->x_recv, &c->x_seg})
     if (b->p) (void)hipFree(b->p);
   for (DevBuf &b : c->pl_world)
     if (b.p) (void)hipFree(b.p);
@@ -331,6 +338,21 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "ilqr_multi_min") c->ilqr_multi_min = value;
   else if (n == "ilqr_test_starve") c->ilqr_test_starve = value != 0;   // tests: launch a wide tree without its last workgroups
   else return fail(c, MIND_EINVAL, "mind_set_tuning: unknown knob '%s'", name);
+  return MIND_OK;
+}
+
+extern "C" int mind_set_exchange(mind_ctx *c, int rank, int world, mind_exchange_fn fn, void *user, int force) {
+  if (!c) return MIND_EINVAL;
+  if (fn && (world < 1 || rank < 0 || rank >= world)) return fail(c, MIND_EINVAL, "mind_set_exchange: rank %d of %d", rank, world);
+  c->xfn = fn; c->xuser = user;
+  c->xr = fn ? rank : 0; c->xw = fn ? world : 1; c->xforce = fn && force != 0;
+  return MIND_OK;
+}
+
+extern "C" int mind_last_exchange_stats(mind_ctx *c, long long *collectives, long long *bytes) {
+  if (!c) return MIND_EINVAL;
+  if (collectives) *collectives = c->x_collectives;
+  if (bytes) *bytes = c->x_bytes;
   return MIND_OK;
 }
 

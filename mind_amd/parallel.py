@@ -39,6 +39,7 @@ class Shard:
         # one-GPU box) runs them for real, so the RCCL code path is executed even where a second device is missing
         import os
         self.force = os.environ.get("MIND_FORCE_COLLECTIVES", "0") == "1"
+        self.native = False       # attach(): the runtime's mind_aime_plan is sharded through this group
 
     @property
     def sharded(self):
@@ -85,6 +86,62 @@ class Shard:
             else:
                 out.append(torch.cat([full[r * mx:r * mx + cnts[r][i]] for r in range(W)]))
         return out
+
+    # ---- transport of the sharded native AIME plan (mind_set_exchange, include/mind_hip.h) ---------------------------------
+    def attach(self, rt):
+        """Hand this group's collectives to the runtime's context: mind_aime_plan then block-distributes every round's scenes over the
+        ranks and calls back here for its (two per round + one per plan) fixed-size exchanges on device buffers -- RCCL moves them where
+        they are (`nccl`), gloo (tests) through host copies."""
+        from . import _lib
+        import ctypes as C
+
+        def dev_bytes(ptr, n):
+            """torch uint8 view of n bytes of device memory at ptr (no copy)"""
+            class _P:
+                __cuda_array_interface__ = {"shape": (int(n),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+            return torch.as_tensor(_P(), device=torch.device("cuda", torch.cuda.current_device()))
+
+        def cb(user, op, send, recv, nbytes):
+            try:
+                dist, W = self.dist, self.world
+                if op == _lib.XCHG_ALLGATHER:
+                    s, r = dev_bytes(send, nbytes), dev_bytes(recv, nbytes * W)
+                    if self.backend == "nccl":
+                        dist.all_gather_into_tensor(r, s, group=self.group)
+                        torch.cuda.current_stream().synchronize()
+                    else:
+                        out = torch.empty(nbytes * W, dtype=torch.uint8)
+                        dist.all_gather_into_tensor(out, s.cpu(), group=self.group)
+                        r.copy_(out)
+                        torch.cuda.current_stream().synchronize()
+                    self.bytes_gathered += nbytes * W
+                else:
+                    t = dev_bytes(recv, nbytes).view(torch.float32)
+                    if send != recv:
+                        t.copy_(dev_bytes(send, nbytes).view(torch.float32))
+                    if self.backend == "nccl":
+                        dist.all_reduce(t, group=self.group)
+                        torch.cuda.current_stream().synchronize()
+                    else:
+                        h = t.cpu()
+                        dist.all_reduce(h, group=self.group)
+                        t.copy_(h)
+                        torch.cuda.current_stream().synchronize()
+                    self.bytes_gathered += nbytes
+                self.n_collectives += 1
+                return 0
+            except Exception as e:      # (an exception must not cross the C boundary)
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = _lib.EXCHANGE_FN(cb)         # kept alive with the shard
+        self._rt = rt
+        on = self.active and (self.world > 1 or self.force)
+        rc = rt.lib.mind_set_exchange(rt.ctx, self.rank if on else 0, self.world if on else 1, self._cb if on else _lib.EXCHANGE_FN(0), None, 1 if self.force else 0)
+        _lib.check(rt.lib, rt.ctx, rc, "mind_set_exchange")
+        self.native = on
+        return self
 
     def broadcast(self, t, src=0):
         """In-place broadcast of a tensor on ``self.device`` from ``src``."""

@@ -95,6 +95,10 @@ class MINDPlanner:
         torch.distributed process group (one process per GPU)."""
         from ...parallel import Shard
         sh = Shard(group)
+        # the native plan (mind_aime_plan) distributes its rounds itself through the group's collectives (MIND_NATIVE_SHARD=0: the
+        # round-by-round host path of rounds 1-3, kept for wrapped networks and as the comparison)
+        if os.environ.get("MIND_NATIVE_SHARD", "1") != "0":
+            sh.attach(self.network.rt)
         self.scen_tree_gen.shard = sh
         self.traj_tree_opt.shard = sh
         return sh
@@ -156,7 +160,7 @@ class MINDPlanner:
         """A planner with a context of its own (planner config "own_context", runtime.new_runtime) runs its kernels on that context's
         stream; whatever the plan does through torch (the round-by-round AIME path: index_select / pruning tensors / the predictor's
         output buffers) must be ordered on the same stream, not on the thread's current one."""
-        ts = getattr(self.network.rt, "torch_stream", None)
+        ts = getattr(getattr(self.network, "rt", None), "torch_stream", None)      # (a wrapped / injected network has no runtime of its own)
         if ts is None:
             import contextlib
             return contextlib.nullcontext()

@@ -243,7 +243,7 @@ class ScenarioTreeGenerator:
             net = net.net
         return (self.native_aime and self.device_glue and self.device_select and type(net).__name__ == "ScenePredNet"
                 and getattr(net, "rt", None) is not None and getattr(net, "_loaded", False) and hasattr(net.rt, "aime_plan")
-                and (self.shard is None or not self.shard.sharded) and self.ego_idx == 0 and self.target_lane is not None
+                and (self.shard is None or not self.shard.sharded or getattr(self.shard, "native", False)) and self.ego_idx == 0 and self.target_lane is not None
                 and len(self.target_lane) >= 12 and self.config is not None)
 
     def _branch_aime_native(self, lcl_smp, agent_obs, on_flats=None):

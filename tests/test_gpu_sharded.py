@@ -15,11 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_gpu_worker.py")
 
 
-def _run(world, tmp_path, n_plans=3, port=29531):
+def _run(world, tmp_path, n_plans=3, port=29531, extra_env=None):
     procs, outs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
         out = os.path.join(tmp_path, f"w{world}_r{r}.pkl")
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, WORKER, out, str(n_plans)], env=env, stdout=subprocess.PIPE,
@@ -46,6 +46,35 @@ def test_two_sharded_ranks_plan_what_one_process_plans(tmp_path):
     assert len(single["res"][0]["keys"]) >= 2                                    # there was something to shard
     # every rank expanded only its block of each round's scenes
     assert r0["expanded"] + r1["expanded"] == single["expanded"] and 0 < r1["expanded"] < single["expanded"]
+    # one code path for every rank count: the native plan (mind_aime_plan), its rounds sharded through mind_set_exchange
+    assert single["native_plans"] == 3 and r0["native_plans"] == 3 and r1["native_plans"] == 3 and r0["collectives"] >= 3 * 4
+
+
+def test_three_ranks_and_the_full_tree_sharded_natively(tmp_path):
+    """The full scripted 6-ary tree of BASELINE configs[3] (rounds of 1 / 6 / 36 / 216 scenes, six cost trees) through the sharded native
+    plan on three ranks (ragged blocks: 216 = 72 x 3, 36 = 12 x 3, 6 = 2 x 3, the root round on rank 0 alone): every rank returns the plan the
+    single process returns, bit for bit, and expands its share of the 259 scenes."""
+    env = {"MIND_TEST_WORKLOAD": "cfg4tree"}
+    single = _run(1, tmp_path, n_plans=1, port=29571, extra_env=env)[0]
+    ranks = _run(3, tmp_path, n_plans=1, port=29572, extra_env=env)
+    assert single["expanded"] == 259 and sum(r["expanded"] for r in ranks) == 259 and [r["expanded"] for r in ranks] == [87, 86, 86]
+    for b in ranks:
+        assert b["native_plans"] == 1
+        for pa, pb in zip(single["res"], b["res"]):
+            assert pa["keys"] == pb["keys"] and pa["best"] == pb["best"] and pa["n_trees"] == pb["n_trees"] == 6
+            assert np.array_equal(pa["pos0"], pb["pos0"]) and np.array_equal(pa["xs"], pb["xs"]) and np.array_equal(pa["ctrl"], pb["ctrl"])
+
+
+def test_round_by_round_host_path_still_shards(tmp_path):
+    """MIND_NATIVE_SHARD=0: the sharded rounds of rounds 1-3 (round-by-round host path over parallel.Shard.all_gather_rows, kept for
+    wrapped networks) against the native one-process plan fed by the same host featuriser."""
+    env = {"MIND_NATIVE_SHARD": "0"}
+    single = _run(1, tmp_path, port=29581, extra_env=env)[0]
+    r0, r1 = _run(2, tmp_path, port=29582, extra_env=env)
+    for a, b in ((single, r0), (r0, r1)):
+        for pa, pb in zip(a["res"], b["res"]):
+            assert pa["keys"] == pb["keys"] and pa["best"] == pb["best"] and np.array_equal(pa["pos0"], pb["pos0"]) and np.array_equal(pa["xs"], pb["xs"])
+    assert r0["native_plans"] == 0 and r0["expanded"] + r1["expanded"] == single["expanded"]
 
 
 def _bench_ranks(world, extra, port):
