@@ -53,8 +53,11 @@ WORKLOADS = {
     # the agent count of BASELINE config 5 (128 agents x 256 lane polylines, N = 385) on the largest tree the
     # reference's probability floor lets grow (6-ary, 259 expansions)
     "stress128tree": dict(n_agents=128, n_lanes=8, n_segs=32, seed=5),
+    # the same scene under the scripted 6-ary depth-5 tree with the probability floor lifted (mind_amd.synth.ScriptedDeepTree): rounds of
+    # 1 / 6 / 36 / 216 / 1 296 scenes = 1 555 expansions per plan -- what K = 6 modes and max_depth = 5 leave of BASELINE configs[4]'s tree
+    "stressdeep": dict(n_agents=128, n_lanes=8, n_segs=32, seed=5),
 }
-FULL_TREE = ("cfg4tree", "stress128tree")
+FULL_TREE = ("cfg4tree", "stress128tree", "stressdeep")
 BRANCHING_WEIGHTS, PLAIN_WEIGHTS = "formula_branching:20240121", "formula:20240121"
 
 # ---- algorithmic work of the pair kernel ----------------------------------------------------------
@@ -117,7 +120,7 @@ def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True, ckpt
     ckpt: override of the planner config's ckpt_path (e.g. "formula_branching:20240121", mind_amd/weights.py)."""
     from mind_amd.closed_loop import ClosedLoopSim
     from mind_amd.planners.mind.planner import MINDPlanner
-    from mind_amd.synth import ScriptedBranching, ScriptedFullTree, SynthWorld
+    from mind_amd.synth import ScriptedBranching, ScriptedDeepTree, ScriptedFullTree, SynthWorld
     cfg = os.path.join(ROOT, "mind_amd", "planners", "mind", "configs", "synthetic.json")
     if "scene" in wkw:
         from mind_amd.scene_io import ReplayWorld, scene_fixture_path
@@ -134,7 +137,13 @@ def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True, ckpt
     # collapses to a few nodes); the scripted modes are straight-line motions in the agent frame and would leave a
     # curved recorded target lane, so they are kept for the synthetic worlds only
     if scripted and "scene" not in wkw:
-        pl.scen_tree_gen.network = (ScriptedFullTree if full_tree else ScriptedBranching)(pl.network)
+        pl.scen_tree_gen.network = (ScriptedDeepTree if full_tree == "deep" else ScriptedFullTree if full_tree else ScriptedBranching)(pl.network)
+        if full_tree == "deep":
+            # five rounds of expansions: the nodes of the fifth (depth 5) must still be examined to END their branches -- ScenTreeCfg.max_depth
+            # (configs/planning/demo_1.py:5: 5) is a planning-config value; with it every branch would stop at the cap unfinished
+            import copy
+            pl.scen_tree_gen.config = copy.copy(pl.scen_tree_gen.config)
+            pl.scen_tree_gen.config.max_depth = 6
     # speculative warm start = a second HIP context per planner: a latency lever for a GPU that one closed loop leaves idle;
     # with many scenes sharing the device the extra contexts cost more than they hide (measured: 8 processes 3150 -> 2010)
     pl.traj_tree_opt.speculative = speculative and pl.traj_tree_opt.speculative      # MIND_SPECULATIVE_WARM_START=0 switches it off
@@ -188,7 +197,7 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None, pair_pre
     wkw = scene_workload(workload, replica)
     if ckpt is None and "scene" in wkw:
         ckpt = BRANCHING_WEIGHTS
-    pl, sim, w = make_closed_loop(wkw, full_tree=workload in FULL_TREE, ckpt=ckpt)
+    pl, sim, w = make_closed_loop(wkw, full_tree="deep" if workload == "stressdeep" else workload in FULL_TREE, ckpt=ckpt)
     sh = None
     if shard and dist.world > 1:
         sh = pl.enable_sharding()
@@ -792,6 +801,15 @@ def main():
                                           plans_timed=6)
             except Exception as e:       # noqa: BLE001
                 out["stress"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            try:
+                # the deepest tree K = 6 modes allow (ScriptedDeepTree: floor lifted, five rounds, the last one 1 296 scenes = 51 GB of bf16
+                # edges, through the predictor in chunks under the default 96 GB budget only if it had to)
+                dm = measure(dist, "stressdeep", 2, 1, False, pair_prec="bf16")
+                out["stress_deep"] = dict(summarize(dm, "bf16"), workload="stressdeep: 128 agents x 256 lane polylines (N = 385), scripted 6-ary depth-5 AIME tree with "
+                                          "the path-probability floor lifted (rounds of 1 / 6 / 36 / 216 / 1 296 scenes = 1 555 expansions, 7 776 leaves per "
+                                          "plan), plain bf16 (edge tensor in bf16)", plans_timed=2)
+            except Exception as e:       # noqa: BLE001
+                out["stress_deep"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if rank == 0:
         print(json.dumps(out))
     dist.close()

@@ -74,7 +74,7 @@ class AimePlanIn(C.Structure):
                [("time_ahead", C.c_float), ("min_vel", C.c_float), ("dist_thres", C.c_float), ("max_depth", C.c_int), ("max_rounds", C.c_int), ("pred_len", C.c_int),
                 ("raw_pos", C.POINTER(C.c_float)), ("raw_ang", C.POINTER(C.c_float)), ("raw_vel", C.POINTER(C.c_float)), ("raw_pad", C.POINTER(C.c_float)),
                 ("lane_pts", C.POINTER(C.c_double)), ("lane_flags", C.POINTER(C.c_int32)), ("travel0", C.c_float),
-                ("script_cls", C.c_void_p), ("script_reg", C.c_void_p), ("script_vel", C.c_void_p)]
+                ("script_cls", C.c_void_p), ("script_reg", C.c_void_p), ("script_vel", C.c_void_p), ("prob_floor", C.c_float)]
 
 
 class AimeNode(C.Structure):

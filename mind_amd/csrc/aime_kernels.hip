@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64) void k_aime_world(const AimeScene *__restrict__
 __global__ __launch_bounds__(64) void k_aime_select(const AimeScene *__restrict__ scenes, const float *__restrict__ cls,
                                                     const float *__restrict__ scen_prob, const float *__restrict__ topo,
                                                     const float *__restrict__ ego_end, int lane_check, float dist_thres,
-                                                    float *__restrict__ sel, float *__restrict__ sel_prob) {
+                                                    float *__restrict__ sel, float *__restrict__ sel_prob, float prob_floor) {
   const int b = blockIdx.x, t = threadIdx.x;
   const AimeScene S = scenes[b];
   float cl[AIME_K], pr[AIME_K];
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void k_aime_select(const AimeScene *__restrict_
   for (int k = 0; k < AIME_K; ++k) {
     cl[k] = cls[b * AIME_K + k];
     pr[k] = cl[k] * sp;
-    keep[k] = !(pr[k] < 0.001f);
+    keep[k] = !(pr[k] < prob_floor);
     if (lane_check) {
       const float *e = ego_end + ((size_t)b * AIME_K + k) * 4;
       if ((e[3] - e[2]) > dist_thres) keep[k] = false;

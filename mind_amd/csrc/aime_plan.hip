@@ -228,56 +228,8 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     const int Bmax = (B + XW - 1) / XW;                     // the largest block (the decision buffers are laid out for it)
     my_lo_of_round.push_back(lo);
     out->round_scenes[round] = Bk;
-    // ---- predictor on this rank's scenes of the round
-    float *d_cls = nullptr, *d_reg = nullptr, *d_vel = nullptr;
-    const float *d_ctrs = nullptr, *d_vecs = nullptr;
-    if (Bk > 0) {
-      std::vector<int32_t> ao(Bk + 1), lof(Bk + 1);
-      for (int b = 0; b <= Bk; ++b) { ao[b] = a * b; lof[b] = l * b; }
-      const size_t n_cls = ((size_t)Bk * 6 + 3) & ~(size_t)3;
-      if ((rc = ensure(c, c->pl_pred, (n_cls + (size_t)A * 6 * T * 7) * sizeof(float)))) return rc;
-      d_cls = (float *)c->pl_pred.p; d_reg = d_cls + n_cls; d_vel = d_reg + (size_t)A * 6 * T * 5;
-      mind_scene_batch sb;
-      memset(&sb, 0, sizeof(sb));
-      mind_pred_out po;
-      memset(&po, 0, sizeof(po));
-      sb.n_scenes = Bk; sb.actor_off = ao.data(); sb.lane_off = lof.data();
-      if (cur_in < 0) {
-        sb.actors = droot + o_actors; sb.lanes = droot + o_lanes; sb.actor_ctrs = d_ctrs = droot + o_ctrs; sb.actor_vecs = d_vecs = droot + o_vecs;
-        sb.lane_ctrs = droot + o_lc; sb.lane_vecs = droot + o_lv; sb.tgt_nodes = droot + o_tn; sb.tgt_rpe = droot + o_tr;
-        po.lane_feat = (float *)c->pl_lf.p;
-      } else {
-        const InOff q = in_off(B);
-        const float *d = (const float *)c->pl_in[cur_in].p;
-        sb.actors = d + q.actors + (size_t)lo * a * 14 * 48; sb.actor_ctrs = d_ctrs = d + q.ctrs + (size_t)lo * a * 2; sb.actor_vecs = d_vecs = d + q.vecs + (size_t)lo * a * 2;
-        sb.lane_ctrs = d + q.lc + (size_t)lo * l * 2; sb.lane_vecs = d + q.lv + (size_t)lo * l * 2;
-        sb.tgt_nodes = d + q.tn + (size_t)lo * 160; sb.tgt_rpe = d + q.tr + (size_t)lo * 20;
-        sb.lane_feat = Bk == 1 ? (const float *)c->pl_lf.p : (const float *)c->pl_lrep.p;
-      }
-      po.cls = d_cls; po.reg = d_reg; po.vel = d_vel;
-      if ((rc = mind_predict_batch(c, &sb, &po))) return rc;
-      n_expanded += Bk;
-      if (c->profiling) { pair_ms += c->pair_ms; pair_launches += c->n_pair_launch; }
-      if (in->script_cls) {
-        // scripted modes (benchmark hook): the forward above was the timed work, its outputs are replaced scene by scene
-        const size_t nr = (size_t)a * 6 * T * 5, nv = (size_t)a * 6 * T * 2;
-        hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((6 * (size_t)Bk + 255) / 256)), dim3(256), 0, st, in->script_cls, (size_t)6, Bk, d_cls);
-        hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((nr * Bk + 255) / 256)), dim3(256), 0, st, in->script_reg, nr, Bk, d_reg);
-        hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((nv * Bk + 255) / 256)), dim3(256), 0, st, in->script_vel, nv, Bk, d_vel);
-      }
-    }
-    // ---- the frames of the re-based scenes (queued behind k_aime_rebase / the unpacking, before this round's predictor): ROT, ORIG, TGT_PTS
-    if (frames_pending) {
-      HIPCHK(c, hipEventSynchronize(c->ev_pl));
-      const float *fr = (const float *)c->pl_pin[3];
-      for (int b = 0; b < B; ++b) {
-        memcpy(batch[b].rot, fr + (size_t)b * 28, 4 * sizeof(float));
-        memcpy(batch[b].orig, fr + (size_t)b * 28 + 4, 2 * sizeof(float));
-        memcpy(batch[b].tgt, fr + (size_t)b * 28 + 6, 22 * sizeof(float));
-      }
-      frames_pending = false;
-    }
-    // ---- prune_merge arithmetic + decisions + branch-time bits on the device (this rank's scenes)
+    // ---- this rank's scenes of the round through predictor -> k_aime_world -> k_aime_select -> k_aime_branch, in chunks of scenes when the
+    //      round's edge tensor would not fit the budget (mind_set_tuning "plan_chunk_mb"): the scenes are independent, a chunk is a smaller launch
     // small outputs: topo [A,6] | ego_end [Bk,6,4] | decisions laid out for Bmax scenes: sel [Bmax,6] | sel_prob [Bmax,6] | hit [Bmax,6,2]
     const size_t n_topo = ((size_t)A * 6 + 3) & ~(size_t)3, n_ego = (size_t)Bk * 24, n_back = (size_t)Bmax * 6 * 4;
     if ((rc = ensure(c, c->pl_small, (n_topo + n_ego + n_back) * sizeof(float)))) return rc;
@@ -293,7 +245,29 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     if ((rc = pl_pin(c, 1, tab_bytes + 3 * (size_t)6 * Bmax * sizeof(int) + 64))) return rc;
     if ((int)c->pl_world.size() <= round) c->pl_world.resize(round + 1);
     float *d_world = nullptr;
+    const int Ntok = a + l + 1;
+    const double edge_mb = (double)Ntok * (((Ntok + 15) / 16) * 16) * (c->pair_prec == 2 && c->pair_tile ? 256.0 : 512.0) / (1024.0 * 1024.0);
+    const int chunk = std::max(1, (int)std::min<double>((double)(Bk > 0 ? Bk : 1), (double)c->plan_chunk_mb / edge_mb));
     if (Bk > 0) {
+      if ((rc = ensure(c, c->pl_world[round], (size_t)A * 6 * T * 6 * sizeof(float)))) return rc;
+      d_world = (float *)c->pl_world[round].p;
+      const int cbm = std::min(chunk, Bk);
+      const size_t n_cls = ((size_t)cbm * 6 + 3) & ~(size_t)3;
+      if ((rc = ensure(c, c->pl_pred, (n_cls + (size_t)cbm * a * 6 * T * 7) * sizeof(float)))) return rc;
+    }
+    // ---- the frames of the re-based scenes (ROT, ORIG, TGT_PTS; queued behind k_aime_rebase / the unpacking): needed by the scene tables
+    if (frames_pending) {
+      HIPCHK(c, hipEventSynchronize(c->ev_pl));
+      const float *fr = (const float *)c->pl_pin[3];
+      for (int b = 0; b < B; ++b) {
+        memcpy(batch[b].rot, fr + (size_t)b * 28, 4 * sizeof(float));
+        memcpy(batch[b].orig, fr + (size_t)b * 28 + 4, 2 * sizeof(float));
+        memcpy(batch[b].tgt, fr + (size_t)b * 28 + 6, 22 * sizeof(float));
+      }
+      frames_pending = false;
+    }
+    if (Bk > 0) {
+      // the scene tables of the whole block, one upload; agent rows are counted from the start of a scene's chunk
       char *h = (char *)c->pl_pin[1];
       AimeScene *hs = (AimeScene *)h;
       int *as = (int *)(h + bS);
@@ -301,11 +275,12 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       for (int b = 0; b < Bk; ++b) {
         AimeScene &S = hs[b];
         const PlScene &q = batch[lo + b];
-        S.a0 = a * b; S.a1 = a * (b + 1); S.last = HZ - 1;     /* seq_len - 1 - history length */ S.cmp = q.cur_t == 0 ? 1 : q.cur_t; S.pad2 = 0.f;
+        const int bc = b % chunk;
+        S.a0 = a * bc; S.a1 = a * (bc + 1); S.last = HZ - 1;     /* seq_len - 1 - history length */ S.cmp = q.cur_t == 0 ? 1 : q.cur_t; S.pad2 = 0.f;
         S.r00 = q.rot[0]; S.r01 = q.rot[1]; S.r10 = q.rot[2]; S.r11 = q.rot[3];
         S.ox = q.orig[0]; S.oy = q.orig[1];
         S.theta_g = atan2f(S.r10, S.r00);
-        for (int i = S.a0; i < S.a1; ++i) as[i] = b;
+        for (int i = 0; i < a; ++i) as[(size_t)b * a + i] = bc;
         sp[b] = q.prob;
       }
       if (c->pl_tab_side) {
@@ -315,14 +290,51 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       } else {
         HIPCHK(c, hipMemcpyAsync(tabb.p, h, tab_bytes, hipMemcpyHostToDevice, st));
       }
-      const char *dtab = (const char *)tabb.p;
-      if ((rc = ensure(c, c->pl_world[round], (size_t)A * 6 * T * 6 * sizeof(float)))) return rc;
-      d_world = (float *)c->pl_world[round].p;
-      hipLaunchKernelGGL(k_aime_world, dim3(A * AIME_K), dim3(64), 0, st, (const AimeScene *)dtab, (const int *)(dtab + bS), d_reg, d_vel, d_ctrs, d_vecs,
-                         cov_last_dev + (size_t)lo * a, d_world, d_topo, d_ego, droot + o_tl, P);
-      hipLaunchKernelGGL(k_aime_select, dim3(Bk), dim3(64), 0, st, (const AimeScene *)dtab, d_cls, (const float *)(dtab + bS + bI), d_topo, d_ego, 1,
-                         in->dist_thres, d_sel, d_selp);
-      hipLaunchKernelGGL(k_aime_branch, dim3(Bk * AIME_K), dim3(64), 0, st, (const AimeScene *)dtab, d_sel, d_world, d_hit);
+    }
+    const char *dtab = (const char *)tabb.p;
+    for (int c0 = 0; c0 < Bk; c0 += chunk) {
+      const int cb = std::min(chunk, Bk - c0), g0 = lo + c0, Ac = cb * a;      // scenes [g0, g0 + cb) of the round
+      std::vector<int32_t> ao(cb + 1), lof(cb + 1);
+      for (int b = 0; b <= cb; ++b) { ao[b] = a * b; lof[b] = l * b; }
+      const size_t n_cls = ((size_t)cb * 6 + 3) & ~(size_t)3;
+      float *d_cls = (float *)c->pl_pred.p, *d_reg = d_cls + n_cls, *d_vel = d_reg + (size_t)Ac * 6 * T * 5;
+      const float *d_ctrs, *d_vecs;
+      mind_scene_batch sb;
+      memset(&sb, 0, sizeof(sb));
+      mind_pred_out po;
+      memset(&po, 0, sizeof(po));
+      sb.n_scenes = cb; sb.actor_off = ao.data(); sb.lane_off = lof.data();
+      if (cur_in < 0) {
+        sb.actors = droot + o_actors; sb.lanes = droot + o_lanes; sb.actor_ctrs = d_ctrs = droot + o_ctrs; sb.actor_vecs = d_vecs = droot + o_vecs;
+        sb.lane_ctrs = droot + o_lc; sb.lane_vecs = droot + o_lv; sb.tgt_nodes = droot + o_tn; sb.tgt_rpe = droot + o_tr;
+        po.lane_feat = (float *)c->pl_lf.p;
+      } else {
+        const InOff q = in_off(B);
+        const float *d = (const float *)c->pl_in[cur_in].p;
+        sb.actors = d + q.actors + (size_t)g0 * a * 14 * 48; sb.actor_ctrs = d_ctrs = d + q.ctrs + (size_t)g0 * a * 2; sb.actor_vecs = d_vecs = d + q.vecs + (size_t)g0 * a * 2;
+        sb.lane_ctrs = d + q.lc + (size_t)g0 * l * 2; sb.lane_vecs = d + q.lv + (size_t)g0 * l * 2;
+        sb.tgt_nodes = d + q.tn + (size_t)g0 * 160; sb.tgt_rpe = d + q.tr + (size_t)g0 * 20;
+        sb.lane_feat = cb == 1 ? (const float *)c->pl_lf.p : (const float *)c->pl_lrep.p;
+      }
+      po.cls = d_cls; po.reg = d_reg; po.vel = d_vel;
+      if ((rc = mind_predict_batch(c, &sb, &po))) return rc;
+      n_expanded += cb;
+      if (c->profiling) { pair_ms += c->pair_ms; pair_launches += c->n_pair_launch; }
+      if (in->script_cls) {
+        // scripted modes (benchmark hook): the forward above was the timed work, its outputs are replaced scene by scene
+        const size_t nr = (size_t)a * 6 * T * 5, nv = (size_t)a * 6 * T * 2;
+        hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((6 * (size_t)cb + 255) / 256)), dim3(256), 0, st, in->script_cls, (size_t)6, cb, d_cls);
+        hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((nr * cb + 255) / 256)), dim3(256), 0, st, in->script_reg, nr, cb, d_reg);
+        hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((nv * cb + 255) / 256)), dim3(256), 0, st, in->script_vel, nv, cb, d_vel);
+      }
+      // prune_merge arithmetic + decisions + branch-time bits of the chunk, written at the chunk's place in the block's buffers
+      const AimeScene *t_sc = (const AimeScene *)dtab + c0;
+      float *w_c = d_world + (size_t)c0 * a * 6 * T * 6;
+      hipLaunchKernelGGL(k_aime_world, dim3(Ac * AIME_K), dim3(64), 0, st, t_sc, (const int *)(dtab + bS) + (size_t)c0 * a, d_reg, d_vel, d_ctrs, d_vecs,
+                         cov_last_dev + (size_t)g0 * a, w_c, d_topo + (size_t)c0 * a * 6, d_ego + (size_t)c0 * 24, droot + o_tl, P);
+      hipLaunchKernelGGL(k_aime_select, dim3(cb), dim3(64), 0, st, t_sc, d_cls, (const float *)(dtab + bS + bI) + c0, d_topo + (size_t)c0 * a * 6,
+                         d_ego + (size_t)c0 * 24, 1, in->dist_thres, d_sel + (size_t)c0 * 6, d_selp + (size_t)c0 * 6, in->prob_floor > 0.f ? in->prob_floor : 0.001f);
+      hipLaunchKernelGGL(k_aime_branch, dim3(cb * AIME_K), dim3(64), 0, st, t_sc, d_sel + (size_t)c0 * 6, w_c, d_hit + (size_t)c0 * 12);
       HIPCHK(c, hipGetLastError());
     }
     // ---- the round's decisions on the host: this rank's block, or (sharded) every rank's through one all-gather

@@ -114,6 +114,9 @@ struct mind_ctx {
   // bf16 arithmetics: k_pair_t (tile-native edge tensor, pair_tile_kernels.hip; default) or the row-major k_pair_bf of rounds 2-3
   // (mind_set_tuning("pair_tile", 0) / MIND_PAIR_TILE=0, kept for same-box A/B measurements)
   bool pair_tile = true;
+  // mind_aime_plan: a round whose edge tensor would exceed this many MB goes through the predictor in chunks of scenes ("plan_chunk_mb";
+  // 96 GB by default: a third of the MI355X's HBM; the scenes of a round are independent, so chunking changes nothing but the launch sizes)
+  int plan_chunk_mb = 96 * 1024;
   std::vector<int> last_scene_n;   // tokens per scene of the last predictor call (mind_debug_read("edge") un-permutes with it)
   bool last_edge_tiled = false, last_edge_bf16 = false;
   // workspaces (grow only)
@@ -327,6 +330,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "actor_split") c->actor_np = value == 3 ? 3 : 6;
   else if (n == "xcd_order") c->xcd_order = value != 0;
   else if (n == "pair_tile") c->pair_tile = value != 0;
+  else if (n == "plan_chunk_mb") c->plan_chunk_mb = value < 1 ? 1 : value;
   else if (n == "dec_overlap") c->dec_overlap = value != 0;
   else if (n == "tok_mfma") c->tok_mfma = value != 0;
   else if (n == "tok_small_max") c->tok_small_max = (int)value;
@@ -1930,7 +1934,7 @@ extern "C" int mind_aime_world(mind_ctx *c, const mind_world_in *in, const mind_
                      (const float *)(base + bS + bI + bC + bP), n_lane);
   if (select)
     hipLaunchKernelGGL(k_aime_select, dim3(B), dim3(64), 0, st, (const AimeScene *)base, in->cls, (const float *)(base + bS + bI + bC),
-                       out->topo, out->ego_end, in->lane_check ? 1 : 0, in->dist_thres, out->sel, out->sel_prob);
+                       out->topo, out->ego_end, in->lane_check ? 1 : 0, in->dist_thres, out->sel, out->sel_prob, 0.001f);
   HIPCHK(c, hipGetLastError());
   return MIND_OK;
 }

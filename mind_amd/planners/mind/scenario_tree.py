@@ -239,7 +239,7 @@ class ScenarioTreeGenerator:
     # ------------------------------------------------------------------------------------------
     def _native_ok(self):
         net = self.network
-        if type(net).__name__ in ("ScriptedBranching", "ScriptedFullTree"):      # scripted modes on top of the real forward (mind_amd/synth.py)
+        if type(net).__name__ in ("ScriptedBranching", "ScriptedFullTree", "ScriptedDeepTree"):      # scripted modes on top of the real forward (mind_amd/synth.py)
             net = net.net
         return (self.native_aime and self.device_glue and self.device_select and type(net).__name__ == "ScenePredNet"
                 and getattr(net, "rt", None) is not None and getattr(net, "_loaded", False) and hasattr(net.rt, "aime_plan")
@@ -253,7 +253,8 @@ class ScenarioTreeGenerator:
         cfg = self.config
         if self.obs_len != 50 or not (2 <= self.pred_len <= 60):
             return None
-        scripted = type(self.network).__name__ in ("ScriptedBranching", "ScriptedFullTree")
+        scripted = type(self.network).__name__ in ("ScriptedBranching", "ScriptedFullTree", "ScriptedDeepTree")
+        floor = getattr(self.network, "prob_floor", None) if scripted else None
         modes = (lambda n_agents: self.network._modes(n_agents, self.network.rt.device)) if scripted else (lambda n_agents: None)
         if self.device_root:
             # process_data's host part is reduced to get_agent_trajectories (Track lists -> padded arrays); frames, actor features,
@@ -268,7 +269,7 @@ class ScenarioTreeGenerator:
             root = {"TRAJS_TYPE": types, "TRAJS_TID": tids, "TRAJS_CAT": cats}
             self.n_lanes = int(st["num_lanes"])
             res = self.network.rt.aime_plan(None, None, None, None, self.target_lane, self.target_lane_info, cfg.tar_time_ahead,
-                                            cfg.tar_dist_thres, cfg.max_depth, pred_len=self.pred_len, raw=raw, script=modes(pos.shape[0]))
+                                            cfg.tar_dist_thres, cfg.max_depth, pred_len=self.pred_len, raw=raw, script=modes(pos.shape[0]), prob_floor=floor)
         else:
             root = self.process_data(lcl_smp, agent_obs)
             self.prepare_root_data(root)
@@ -278,7 +279,7 @@ class ScenarioTreeGenerator:
             self.n_lanes = int(root["LANES"].shape[0])
             res = self.network.rt.aime_plan(root, hist, self.lane_graph["lane_ctrs"], self.lane_graph["lane_vecs"], self.target_lane,
                                             self.target_lane_info, cfg.tar_time_ahead, cfg.tar_dist_thres, cfg.max_depth, pred_len=self.pred_len,
-                                            script=modes(root["ACTORS"].shape[0]))
+                                            script=modes(root["ACTORS"].shape[0]), prob_floor=floor)
         if res is None:
             return None
         nodes, rows, info = res

@@ -504,7 +504,7 @@ class HipPredictor:
         return out
 
     def aime_plan(self, root, hist, lane_ctrs, lane_vecs, target_lane, target_lane_info, time_ahead, dist_thres, max_depth,
-                  pred_len=50, min_vel=0.5, max_rounds=16, raw=None, script=None):
+                  pred_len=50, min_vel=0.5, max_rounds=16, raw=None, script=None, prob_floor=None):
         """ScenarioTreeGenerator.branch_aime in one call (mind_aime_plan).  Host-built root: ``root`` = the root scene dict of
         process_data (ACTORS, TRAJS_CTRS, TRAJS_VECS, LANES, TGT_NODES, TGT_RPE, ROT, ORIG, TGT_PTS, TRAJS_TYPE), ``hist`` [a,50,6] its
         world-frame history (x, y, vx, vy, heading, max-sigma), lane_ctrs / lane_vecs the lane graph's anchors.  Device-built root:
@@ -539,6 +539,7 @@ class HipPredictor:
             setattr(pi, k, fp(v))
         pi.time_ahead, pi.min_vel, pi.dist_thres = float(time_ahead), float(min_vel), float(dist_thres)
         pi.max_depth, pi.max_rounds, pi.pred_len = int(max_depth), int(max_rounds), int(pred_len)
+        pi.prob_floor = 0.0 if prob_floor is None else float(prob_floor)      # (0 = the reference's 0.001)
         if script is not None:        # (cls [1,6], reg [a,6,60,5], vel [a,6,60,2]) float32 device tensors: scripted modes (synth.ScriptedBranching)
             sc, sr, sv = script
             assert tuple(sr.shape) == (a, 6, 60, 5) and tuple(sv.shape) == (a, 6, 60, 2) and sc.numel() == 6

@@ -59,3 +59,66 @@ def test_stress_workload_end_to_end_in_both_arithmetics():
     d = float(np.abs(a[0]["xs"][:, :2] - b[0]["xs"][:, :2]).max()) if a[0]["best"] == b[0]["best"] and a[0]["xs"].shape == b[0]["xs"].shape else float("nan")
     print(f"stress128tree, first plan: max |ego xy (bf16x3) - ego xy (bf16)| = {d:.3e} m, chosen trees {a[0]['best']} / {b[0]['best']}")
     assert not (d > 5.0)
+
+
+def test_chunked_rounds_plan_what_whole_rounds_plan():
+    """mind_aime_plan sends a round whose edge tensor would exceed the budget (mind_set_tuning "plan_chunk_mb") through the predictor in
+    chunks of scenes (the scenes of a round are independent: network.py:318,497).  The full cfg4 tree with a 2 GB budget (the 216-scene
+    round in six chunks of 37 scenes, the 36-scene round whole) must plan bit for bit what the unchunked plan plans."""
+    sys.path.insert(0, ROOT)
+    from bench import WORKLOADS, make_closed_loop
+    outs = []
+    for mb in (96 * 1024, 2048):
+        pl, sim, w = make_closed_loop(dict(WORKLOADS["cfg4tree"]), full_tree=True, speculative=False)
+        rt = pl.network.rt
+        try:
+            rt.set_tuning("plan_chunk_mb", mb)
+            e0 = pl.scen_tree_gen.n_expanded
+            sim.run_plans(1)
+        finally:
+            rt.set_tuning("plan_chunk_mb", 96 * 1024)
+        scen, traj = sim.last_result
+        trees = pl.scen_tree_gen.get_scenario_tree()
+        outs.append(dict(expanded=pl.scen_tree_gen.n_expanded - e0, native=pl.scen_tree_gen.n_native_plans, keys=[list(t.nodes.keys()) for t in trees],
+                         pos=[np.asarray(n.data[1]) for t in trees for n in t.nodes.values()], xs=np.array([n_.data[0] for k, n_ in traj[0].nodes.items() if k != -1]),
+                         costs=np.array(pl.timing["tree_costs"])))
+    a, b = outs
+    assert a["expanded"] == b["expanded"] == 259 and a["native"] >= 1 and b["native"] >= 1 and a["keys"] == b["keys"]
+    assert all(np.array_equal(x, y) for x, y in zip(a["pos"], b["pos"])) and np.array_equal(a["xs"], b["xs"]) and np.array_equal(a["costs"], b["costs"])
+
+
+def test_deep_tree_stress_workload_one_plan():
+    """`stressdeep`: 128 agents x 256 lane polylines under the scripted 6-ary depth-5 tree with the probability floor lifted (rounds of 1 / 6 /
+    36 / 216 / 1 296 scenes = 1 555 expansions, 7 776 leaves -- what K = 6 modes and max_depth = 5 leave of BASELINE configs[4]'s 8-ary depth-6
+    tree), in the plain bf16 arithmetic the config names, the 1 296-scene round in chunks under a 24 GB edge budget: the size-independent properties
+    of one plan (no oracle finishes here)."""
+    sys.path.insert(0, ROOT)
+    from bench import WORKLOADS, make_closed_loop
+    pl, sim, w = make_closed_loop(dict(WORKLOADS["stressdeep"]), full_tree="deep", speculative=False)
+    rt = pl.network.rt
+    before = rt.pair_precision()
+    try:
+        rt.set_pair_precision("bf16")
+        rt.set_tuning("plan_chunk_mb", 24 * 1024)
+        e0 = pl.scen_tree_gen.n_expanded
+        sim.run_plans(1)
+    finally:
+        rt.set_pair_precision(before)
+        rt.set_tuning("plan_chunk_mb", 96 * 1024)
+    info = rt.last_aime_info
+    assert pl.scen_tree_gen.n_expanded - e0 == 1555 and info["round_scenes"] == [1, 6, 36, 216, 1296]
+    trees = pl.scen_tree_gen.get_scenario_tree()
+    assert len(trees) == 6 and sum(len(t.nodes) for t in trees) == 6 + 36 + 216 + 1296 + 7776
+    for t in trees:
+        for k, n in t.nodes.items():
+            pos, cov = np.asarray(n.data[1]), np.asarray(n.data[2])
+            assert pos.shape[0] == 128 and np.isfinite(pos).all() and np.isfinite(cov).all() and (cov > 0).all()
+            ch = [t.nodes[c] for c in n.children_keys]
+            if ch:
+                assert abs(sum(float(np.ravel(c.data[0])[0]) for c in ch) - float(np.ravel(n.data[0])[0])) < 1e-5
+    scen, traj = sim.last_result
+    xs = np.array([n_.data[0] for k, n_ in traj[0].nodes.items() if k != -1])
+    assert np.isfinite(xs).all() and len(pl.timing["tree_costs"]) == 6 and np.isfinite(pl.timing["tree_costs"]).all()
+    assert all(s["iterations"] >= 1 and np.isfinite(s["J"]) for s in pl.traj_tree_opt.debug["full"])
+    print(f"stressdeep: 1 555 expansions, {sum(len(t.nodes) for t in trees)} scenario-tree nodes, cost trees of {[len(t.nodes) for t in traj[:1]]} .. trajectory nodes; "
+          f"aime {pl.timing['aime_s'] * 1e3:.0f} ms, tree-iLQR {pl.timing['ilqr_s'] * 1e3:.0f} ms")
