@@ -17,7 +17,7 @@
 //   * the folded query (W_k^T q / 4, bf16 hi / lo fragments written by k_token) stays in 16 registers for the whole
 //     column: rows 0..7 of the 16-row A operand carry the hi parts of the 8 heads, rows 8..15 the lo parts, so the scores
 //     take 2 MFMAs per k-group instead of 3 and no per-tile reload (the row halves meet through one cross-lane exchange;
-//     the lo.lo product is now included).
+//     the three partial products are summed in k_pair_bf's order: the two kernels give the same bits).
 //   * the last layer's launch walks a job list that only holds the consumed columns (actors + cls) instead of skipping
 //     four jobs out of five after a dependent load each.
 #include <hip/hip_runtime.h>
@@ -350,7 +350,9 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_t(const PairJob *__res
         for (int g = 0; g < 4; ++g) { asm volatile("" ::"v"(mhi[g])); asm volatile("" ::"v"(mlo[g])); }
         continue;
       }
-      // ---- attention scores: S^T[row, pair] = qa[row, :] . mem^T[:, pair]; rows 0..7 hi query parts, rows 8..15 lo parts
+      // ---- attention scores: S^T[row, pair] = qa[row, :] . mem^T[:, pair]; rows 0..7 = hi query parts, rows 8..15 = lo parts: the first
+      //      chain gives q_hi.m_hi (rows 0..7) and q_lo.m_hi (rows 8..15), the second q_hi.m_lo; summed as k_pair_bf sums its three chains,
+      //      hi.hi + (hi.lo + lo.hi), so that the two kernels agree bit for bit (lane quarters 2, 3 carry the padding rows: zero scores)
       f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, sb = sa;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -358,9 +360,11 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_t(const PairJob *__res
         if (NP == 3) sb = MFMA_BF(qa[g], mlo[g], sb);
       }
       if (NP == 3) {
-        sa += sb;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sa[r] += __shfl_xor(sa[r], 32, 64);      // row 4 q + r meets row 4 (q ^ 2) + r: hi + lo query parts
+        for (int r = 0; r < 4; ++r) {
+          const float lo_hi = __shfl_xor(sa[r], 32, 64);      // row 4 (q + 2) + r of the first chain: the lo query part of head 4 q + r
+          sa[r] = lq < 2 ? sa[r] + (sb[r] + lo_hi) : 0.f;
+        }
       }
       // ---- online softmax over i: lanes of quarter q (and q ^ 2) own heads 4 (q & 1) .. + 3
       float pr[4], scl[4];

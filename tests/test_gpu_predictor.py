@@ -290,11 +290,12 @@ def _mixed_check(hip_predictor, small, big, alone_small, out):
 
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("a,l,B,seed", [(1, 1, 1, 5), (16, 15, 3, 2), (17, 30, 3, 4), (40, 55, 2, 1), (64, 256, 1, 21)])
-def test_tile_native_pair_kernel_agrees_with_the_row_major_one(prec, a, l, B, seed, hip_predictor):
+def test_tile_native_pair_kernel_equals_the_row_major_one(prec, a, l, B, seed, hip_predictor):
     """k_pair_t (edge tensor in 8 KB tile chunks of the MFMA C/D layout, next tile and its T rows requested across job boundaries, folded
     query in registers: the default under the bf16 arithmetics) against k_pair_bf (row-major tensor through LDS staging: rounds 2-3,
-    mind_set_tuning("pair_tile", 0)): the same contractions in the same arithmetic; only the summation order of the hi / lo query parts
-    of the scores differs (N = 3, 32, 48, 96, 321: one-tile columns, whole tiles, ragged last tiles, split columns)."""
+    mind_set_tuning("pair_tile", 0)).  bf16x3: the same contractions, the same summation orders -- the same bits (N = 3, 32, 48, 96, 321:
+    one-tile columns, whole tiles, ragged last tiles, split columns).  Plain bf16: k_pair_t keeps the edge tensor in bf16 too, so the two
+    differ by that rounding (both are 6e-3 .. 3e-2 away from the oracle)."""
     pb = predictor_batch(a, l, B, seed=seed)
     before = hip_predictor.pair_precision()
     try:
@@ -306,11 +307,14 @@ def test_tile_native_pair_kernel_agrees_with_the_row_major_one(prec, a, l, B, se
     finally:
         hip_predictor.set_tuning("pair_tile", 1)
         hip_predictor.set_pair_precision(before)
-    tol = 2e-5 if prec == "bf16x3" else 3e-2        # (plain bf16 is 6e-3 .. 3e-2 away from the oracle itself)
     for k in ("cls", "reg", "vel"):
         assert torch.isfinite(out[k]).all()
-        assert (out[k] - ref[k]).abs().max().item() < tol, k
-    assert not torch.equal(out["reg"], ref["reg"])          # it really was the other kernel
+        if prec == "bf16x3":
+            assert torch.equal(out[k], ref[k]), k
+        else:
+            assert (out[k] - ref[k]).abs().max().item() < 3e-2, k
+    if prec == "bf16":
+        assert not torch.equal(out["reg"], ref["reg"])          # it really was the other kernel
 
 
 @pytest.mark.parametrize("a,l,B,seed", [(5, 1, 2, 5), (17, 30, 2, 4)])
