@@ -31,11 +31,15 @@
 
 // ABL: timing-only ablation switches of tools/micro/pair_bench.hip (results are wrong with any bit set; the library instantiates 0)
 //   1 no second GEMM | 2 no LayerNorms | 4 no edge store | 8 no attention phase | 16 no T loads | 32 no edge loads | 64 no first GEMM
-//   128 phase timers (printed by workgroup 0) | 256 no operand splits | 512 no sum_p_mem pass
+//   128 phase timers (printed by workgroup 0) | 256 no operand splits | 512 no sum_p_mem pass | 1024 layer 0 without its edge build
+//   2048 only waves 0..3 work (one per SIMD, half the jobs) | 4096 only the even waves work
 // Measured with the same harness and dropped (profiles/r04d_pair_bench_experiments.txt; 24 x N = 321, base 0.723 ms): s_setprio 1 for the
 // younger wave of every SIMD 0.748, around the GEMMs 0.731, around the VALU phases 0.731; waves 4..7 starting late 0.823; the next tile
 // requested behind the second GEMM, before the edge store 0.970 (64 more live registers through two LayerNorms); non-temporal edge loads
-// 0.746, stores 0.753; cross-lane reductions on DPP / v_permlane*_swap instead of ds_bpermute 0.735.
+// 0.746, stores 0.753; cross-lane reductions on DPP / v_permlane*_swap instead of ds_bpermute 0.735.  Round-4 occupancy probes (same harness,
+// profiles/r04t_pair_bench_occupancy.txt): half the jobs on waves 0..3 alone (one wave per SIMD) take 0.541 ms against 0.812 for all jobs on
+// eight waves -- a wave runs 1.5 x faster without its SIMD partner, the second wave adds 33 % of throughput; starting waves 4..7 6 k cycles
+// late or passing a GEMM token between the two waves of a SIMD (so that their MFMA phases never coincide) gains 4 % (0.762 vs 0.79).
 #ifdef MIND_PAIR_ABL
 #define PT_ABL(bit) ((ABL & (bit)) != 0)
 #define PT_TIME(i) do { if (PT_ABL(128)) { const long long n_ = clock64(); pt_[i] += n_ - pt_t; pt_t = n_; } } while (0)
@@ -92,6 +96,8 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_t(const PairJob *__res
 
 #ifdef MIND_PAIR_ABL
   long long pt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_t = clock64();
+  if (PT_ABL(2048) && __builtin_amdgcn_readfirstlane(wave) >= 4) return;      // (timing: one wave per SIMD, half the jobs)
+  if (PT_ABL(4096) && (__builtin_amdgcn_readfirstlane(wave) & 1)) return;     // (timing: waves 0, 2, 4, 6 = two per SIMD on two SIMDs)
 #endif
   const int stride = gridDim.x * PAIR_WAVES;
   int job = __builtin_amdgcn_readfirstlane(wave * (int)gridDim.x + (int)blockIdx.x);
@@ -192,6 +198,9 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_t(const PairJob *__res
 #pragma unroll
           for (int b = 0; b < 8; ++b) ef[b] = raw[b];
         }
+      } else if (PT_ABL(1024)) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) ef[b] = (f32x4){0.25f, 0.5f, 0.f, 1.f} * (float)(lp + 1);      // (timing: no edge build)
       } else {
         // ---- layer 0: edge0 = ReLU(LN(W_r rpe + b_r)), zeros on the cls row / column (network.py:326-330)
         float r5[5];
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_t(const PairJob *__res
 #pragma unroll
           for (int g = 0; g < 4; ++g) { up[2 * g] += __builtin_bit_cast(f32x4, mhi[g]); up[2 * g + 1] += __builtin_bit_cast(f32x4, mlo[g]); }
         }
-        PT_TIME(4);            // (timers) second GEMM
+          PT_TIME(4);            // (timers) second GEMM
       }
       // ---- request the next tile (unconditionally: behind a branch the compiler must assume the loads were not issued and
       //      drains the memory counter): the next tile of this column, the first tile of this wave's next job, or -- at the

@@ -109,8 +109,18 @@ int main(int argc, char **argv) {
   add("  - GEMMs only (no LN / split / attention)", k_pair_t<1, 3, 2 + 8 + 256>, true);
   add("  - memory only (no GEMM / LN / split / attention)", k_pair_t<1, 3, 1 + 2 + 8 + 64 + 256>, true);
   add("  - timers", k_pair_t<1, 3, 128>, true);
+  add("  * half the jobs on waves 0..3 (one wave per SIMD)", k_pair_t<1, 3, 2048>, true);
+  add("  * half the jobs on the even waves", k_pair_t<1, 3, 4096>, true);
+  add("  * half the jobs, one wave per SIMD, GEMMs only", k_pair_t<1, 3, 2048 + 2 + 8 + 256>, true);
+  add("  * half the jobs, one wave per SIMD, memory only", k_pair_t<1, 3, 2048 + 1 + 2 + 8 + 64 + 256>, true);
   add("  - memory only, no T loads", k_pair_t<1, 3, 1 + 2 + 8 + 16 + 64 + 256>, true);
   add("  - memory only, no store", k_pair_t<1, 3, 1 + 2 + 4 + 8 + 64 + 256>, true);
+#endif
+  add("k_pair_bf<0,3> layer 0 (row-major)", k_pair_bf<0, 3>, false);
+  add("k_pair_t<0,3> layer 0", k_pair_t<0, 3, 0>, true);
+#ifdef MIND_PAIR_ABL
+  add("  - layer 0 without the edge build (RPE, projection, LayerNorm)", k_pair_t<0, 3, 1024>, true);
+  add("  - layer 0, memory only", k_pair_t<0, 3, 1 + 2 + 8 + 64 + 256 + 1024>, true);
 #endif
   add("k_pair_bf<1,1> plain bf16 (row-major)", k_pair_bf<1, 1>, false);
   add("k_pair_t<1,1> plain bf16", k_pair_t<1, 1, 0>, true);
