@@ -87,7 +87,7 @@ __device__ __forceinline__ f32x4 am_load_split(const u32 *rowp, int plane) {
 // NP = number of partial products per term: 6 = both operands split three ways (hi.hi + hi.mid + mid.hi + mid.mid + hi.lo +
 // lo.hi: ~2^-24 relative, fp32-class), 3 = two-way split (hi.hi + hi.mid + mid.hi: ~2^-16), 1 = plain bf16 operands.  The
 // leading products and the corrections run in two accumulators (two independent MFMA chains), summed at the end.
-// Measured (tools/gpu_actor_trace.sh, profiles/r03ad): the convolutions are bound by this weight-fragment stream -- 3 KB per tile and
+// Measured (tools/gpu.sh trace actor, profiles/r03ad): the convolutions are bound by this weight-fragment stream -- 3 KB per tile and
 // k-step (hi / mid / lo), 9.1 MB per actor through ONE CU's 64 B/clk L2 port = 59 us of the kernel's 140, the GroupNorm stages
 // (two block reductions + three barriers each, 26 of them) are another 55 us.  Requesting the fragments four k-steps ahead in a
 // register ring changed nothing (144 vs 142 us): it is the port's bandwidth, not the round trips.
