@@ -318,7 +318,7 @@ typedef struct {
    * script_cls != NULL the predictor still runs on every scene of every round, and these DEVICE arrays then take the place of its
    * outputs for every scene: cls [6], reg [a,6,60,5], vel [a,6,60,2]. */
   const float *script_cls, *script_reg, *script_vel;
-  /* path-probability floor of prune_merge (scenario_tree.py:293-296).  0 = the reference's 0.001; the scripted stress workload lifts it
+  /* path-probability floor of prune_merge (scenario_tree.py:368-370).  0 = the reference's 0.001; the scripted stress workload lifts it
    * (a small positive value) so that a full 6-ary depth-5 tree can grow: 6^-4 is already below 0.001. */
   float prob_floor;
 } mind_aime_plan_in;

@@ -567,88 +567,101 @@ __device__ __forceinline__ void il_dyn_sc(const IlqrConst &C, const double *x, c
 // registers: the addresses are wave-uniform, every lane holds the full set.
 struct IlKv { double K[12], k[2], us[2], xs[6]; };
 
-// Phase 1: states/controls of ALL 10 line-search candidates along (a piece of) one chain segment -- positions [s0, s1) of
-// T.seg_nodes; the first node continues from its parent's candidate state in T.xs_new --, one wave, candidate
-// a = lane % 10 (lanes >= 10 mirror lanes < 10 and do not store).  init != 0: nominal rollout (alpha = 0,
-// gains are zero).  Writes T.xs_new / T.us_new.  Base pointers live in VGPRs (the tree struct's would be re-read from
-// spilled SGPRs in every node), the node index travels two nodes ahead, the node's operands one node ahead.
-__device__ __forceinline__ void il_rollout_segment(const IlqrConst &C, const IlqrTreeDev &T, int s0, int s1, int init IL_PROF_ARG) {
+// Phase 1: states/controls of ALL 10 line-search candidates along the chain pieces of one forward step, IL_PACK pieces per wave:
+// lane = (piece g = lane / 10, candidate a = lane % 10).  The recursion is lane-wise (a lane carries its own state), so every piece
+// of a level -- and every speculative mu slot of it -- rides in the lanes of ONE instruction stream instead of a wave each: two
+// busy waves on one SIMD share its float64 pipe and run at 2.4 k cycles per node instead of 1.5 k (tools/micro/ric_bench.hip), and
+// the demo trees have five branches per level on four SIMDs.  Item `w * IL_PACK + g` of the R = ni x slots items of the step:
+// slot = item / ni, piece = lo + item % ni = positions [fstep_q0, fstep_q1) of T.seg_nodes; the first node of a piece continues
+// from its parent's candidate state in T.xs_new.  Lanes without an item (and lanes whose piece is shorter than the wave's longest)
+// shadow a valid node with frozen state and do not store.  init != 0: nominal rollout (alpha = 0, gains are zero).  Writes
+// T.xs_new / T.us_new of the item's slot.  Base pointers live in VGPRs, the node index travels two nodes ahead, the node's operands
+// one node ahead (loads and stores share one in-order counter: a node's results are stored at the top of the NEXT node, behind
+// that node's operand loads).
+#define IL_PACK 6
+__device__ __forceinline__ void il_rollout_packed(const IlqrConst &C, const IlqrTreeDev &T, int lo, int ni, int R, int w, int init IL_PROF_ARG) {
   const int lane = threadIdx.x & 63;
   const int M = T.M;
-  const int a = lane % IL_NA;
-  const bool writer = lane < IL_NA;
+  const int a = lane % IL_NA, g = lane / IL_NA;
+  const int item = w * IL_PACK + g;
+  const bool valid = g < IL_PACK && item < R;
+  const int ic = valid ? item : w * IL_PACK;
+  const int slot = ic / ni, it = lo + (ic - slot * ni);
   const double alpha = init ? 0.0 : C.alphas[a];
   const int IL_AS1 *pSeg = T.seg_nodes.g();
-  const double IL_AS1 *pK = T.K.g(), *pk = T.k.g(), *pUs = T.us.g(), *pXs = T.xs.g();
-  double IL_AS1 *pXn = T.xs_new.g() + (size_t)a * M * 6, *pUn = T.us_new.g() + (size_t)a * M * 2;
+  const double IL_AS1 *pK = T.K.g() + (size_t)slot * M * 12, *pk = T.k.g() + (size_t)slot * M * 2, *pUs = T.us.g(), *pXs = T.xs.g();
+  double IL_AS1 *pXn = T.xs_new.g() + ((size_t)slot * IL_NA + a) * M * 6, *pUn = T.us_new.g() + ((size_t)slot * IL_NA + a) * M * 2;
   asm volatile("" : "+v"(pSeg), "+v"(pK), "+v"(pk), "+v"(pUs), "+v"(pXs), "+v"(pXn), "+v"(pUn));
+  int q = T.fstep_q0[it];
+  const int s1 = T.fstep_q1[it];
+  int nmax = s1 - q;                      // the wave runs as many nodes as its longest piece has
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(nmax, d); nmax = o > nmax ? o : nmax; }
+  nmax = __builtin_amdgcn_readfirstlane(nmax);
   auto prefetch = [&](int c, IlKv &P) {
     const auto qK = (const il_d2 IL_AS1 *)(pK + (size_t)c * 12);
     const auto qx = (const il_d2 IL_AS1 *)(pXs + (size_t)c * 6);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) { const il_d2 v = qK[q]; P.K[2 * q] = v.x; P.K[2 * q + 1] = v.y; }
+    for (int e = 0; e < 6; ++e) { const il_d2 v = qK[e]; P.K[2 * e] = v.x; P.K[2 * e + 1] = v.y; }
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { const il_d2 v = qx[q]; P.xs[2 * q] = v.x; P.xs[2 * q + 1] = v.y; }
+    for (int e = 0; e < 3; ++e) { const il_d2 v = qx[e]; P.xs[2 * e] = v.x; P.xs[2 * e + 1] = v.y; }
     const il_d2 vk = *(const il_d2 IL_AS1 *)(pk + (size_t)c * 2);
     const il_d2 vu = *(const il_d2 IL_AS1 *)(pUs + (size_t)c * 2);
     P.k[0] = vk.x; P.k[1] = vk.y; P.us[0] = vu.x; P.us[1] = vu.y;
   };
-  int c = __builtin_amdgcn_readfirstlane(pSeg[s0]);
-  int cn_v = pSeg[s0 + 1 < s1 ? s0 + 1 : s1 - 1];
-  const int p0 = c == 0 ? -1 : __builtin_amdgcn_readfirstlane(T.parent[c]);      // node 0 is the only child of the x0 root (checked on the host)
+  int c = pSeg[q];
+  int cn = pSeg[q + 1 < s1 ? q + 1 : s1 - 1];
+  const int p0 = c == 0 ? -1 : T.parent[c];      // node 0 is the only child of the x0 root (checked on the host)
   double xp[6], xo[6];
-  if (p0 < 0) {
+  {
+    const size_t pp = (size_t)(p0 < 0 ? 0 : p0) * 6;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { xp[k] = C.x0[k]; xo[k] = C.x0[k]; }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { xp[k] = pXn[(size_t)p0 * 6 + k]; xo[k] = pXs[(size_t)p0 * 6 + k]; }
+    for (int k = 0; k < 6; ++k) { const double vn = pXn[pp + k], vs = pXs[pp + k]; xp[k] = p0 < 0 ? C.x0[k] : vn; xo[k] = p0 < 0 ? C.x0[k] : vs; }
   }
-  // Two nodes per loop trip (the operand sets swap roles instead of being copied).  A node's results are stored at the top of the
-  // NEXT node, behind that node's operand loads: loads and stores share one in-order counter, so a store issued at the end of a
-  // node would be waited for (several hundred cycles) by the next wait for a load.
   IlKv PA, PB;
   prefetch(c, PA);
-  double sx[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, su[2] = {0.0, 0.0};
+  double su[2] = {0.0, 0.0};
   int sc = c;
+  bool sact = false;                      // the previous node of this lane was one of its piece (its state is to be stored)
   auto store = [&]() {
-    if (writer) {
+    if (sact) {
       const auto xn = (il_d2 IL_AS1 *)(pXn + (size_t)sc * 6);
-      xn[0] = il_d2{sx[0], sx[1]}; xn[1] = il_d2{sx[2], sx[3]}; xn[2] = il_d2{sx[4], sx[5]};
+      xn[0] = il_d2{xp[0], xp[1]}; xn[1] = il_d2{xp[2], xp[3]}; xn[2] = il_d2{xp[4], xp[5]};
       *(il_d2 IL_AS1 *)(pUn + (size_t)sc * 2) = il_d2{su[0], su[1]};
     }
   };
-  auto node = [&](const IlKv &Pc, IlKv &Pn, int q) {
+  // Two nodes per loop trip (the operand sets swap roles instead of being copied).
+  auto node = [&](const IlKv &Pc, IlKv &Pn) {
     IL_PT0();
-    const int cn = __builtin_amdgcn_readfirstlane(cn_v);
-    cn_v = pSeg[q + 2 < s1 ? q + 2 : s1 - 1];
+    const int cnn = pSeg[q + 2 < s1 ? q + 2 : s1 - 1];
     prefetch(cn, Pn);
-    if (q != s0) store();
+    store();
     IL_PT(0);
     double u[2], x[6];
-    if (c == 0) {
-      u[0] = Pc.us[0] + alpha * Pc.k[0];
-      u[1] = Pc.us[1] + alpha * Pc.k[1];
-    } else {
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        double sm = 0.0;
+    for (int b = 0; b < 2; ++b) {
+      double sm = 0.0;
 #pragma unroll
-        for (int jj = 0; jj < 6; ++jj) sm += Pc.K[b * 6 + jj] * (xp[jj] - xo[jj]);
-        u[b] = Pc.us[b] + alpha * Pc.k[b] + sm;
-      }
+      for (int jj = 0; jj < 6; ++jj) sm += Pc.K[b * 6 + jj] * (xp[jj] - xo[jj]);
+      const double t = Pc.us[b] + alpha * Pc.k[b];
+      u[b] = c == 0 ? t : t + sm;
     }
     il_dyn_sc(C, xp, u, x);
+    const bool act = valid && q < s1;
+    if (act) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { xp[k] = x[k]; xo[k] = Pc.xs[k]; sx[k] = x[k]; }
-    su[0] = u[0]; su[1] = u[1];
-    sc = c;
-    c = cn;
+      for (int k = 0; k < 6; ++k) { xp[k] = x[k]; xo[k] = Pc.xs[k]; }
+      su[0] = u[0]; su[1] = u[1];
+      sc = c;
+    }
+    sact = act;
+    c = cn; cn = cnn;
+    ++q;
     IL_PT(1); IL_PCNT(5);
   };
-  for (int q = s0; q < s1; q += 2) {
-    node(PA, PB, q);
-    if (q + 1 < s1) node(PB, PA, q + 1);
+  for (int n = 0; n < nmax; n += 2) {
+    node(PA, PB);
+    if (n + 1 < nmax) node(PB, PA);
   }
   store();
 }
@@ -1214,9 +1227,9 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
     T.Lxx[q] = 0.0;
   }
   IL_SYNC();
-  for (int d = 0; d < T.n_slevels; ++d) {
-    for (int q = T.slevel_start[d] + gw; q < T.slevel_start[d + 1]; q += nw)
-      { const int seg = T.slevel_segs[q]; il_rollout_segment(C, T, T.seg_start[seg], T.seg_start[seg + 1], 1 IL_PROF_PASS); }
+  for (int s = 0; s < T.n_fsteps; ++s) {
+    const int lo = T.fstep_start[s], ni = T.fstep_start[s + 1] - lo;
+    for (int w = gw; w * IL_PACK < ni; w += nw) il_rollout_packed(C, T, lo, ni, ni, w, 1 IL_PROF_PASS);
     IL_SYNC();
   }
   bool staged = false;          // il_deriv_pass: this fit's agent rows are in the staging region already
@@ -1333,20 +1346,22 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       int R = 0;
       if (s < T.n_fsteps) {
         const int lo = T.fstep_start[s], ni = T.fstep_start[s + 1] - lo;
-        R = ni * nuse;
-        for (int w = gw; w < R; w += nw) {
-          const int slot = w / ni, it = lo + w % ni;
-          IlqrTreeDev Ts = T;
-          Ts.k += (size_t)slot * M * 2; Ts.K += (size_t)slot * M * 12;
-          Ts.xs_new += (size_t)slot * IL_NA * M * 6; Ts.us_new += (size_t)slot * IL_NA * M * 2; Ts.L_new += (size_t)slot * IL_NA * M;
-          il_rollout_segment(C, Ts, T.fstep_q0[it], T.fstep_q1[it], 0 IL_PROF_PASS);
-        }
+        R = (ni * nuse + IL_PACK - 1) / IL_PACK;            // waves' worth of (slot, piece) items
+        for (int w = gw; w < R; w += nw) il_rollout_packed(C, T, lo, ni, ni * nuse, w, 0 IL_PROF_PASS);
       } else {
         IL_MARK(t_roll);
       }
       if (s > 0) {
         const int n0 = T.fstep_nstart[s - 1], cnt = T.fstep_nstart[s] - n0;
-        il_cost_pass<GEN>(C, T, nuse, recs, (gw + nw - R % nw) % nw, nw, T.fstep_nodes + (size_t)n0, cnt IL_PROF_PASS);
+        // order in which the waves take cost chunks while R waves roll chains: the waves of a SIMD without a chain wave first (wave w
+        // sits on SIMD w & 3; two busy waves on a SIMD share its float64 pipe and would slow the chain), the chain waves' SIMD
+        // partners next, the chain waves themselves last
+        int rank = (gw + nw - R % nw) % nw;
+        if (!MULTI && R < 4) {
+          const int fr = 4 - R;             // SIMDs without a chain wave
+          rank = wave < R ? 2 * fr + R + wave : (wave < 4 ? wave - R : (wave < 4 + R ? 2 * fr + wave - 4 : fr + wave - 4 - R));
+        }
+        il_cost_pass<GEN>(C, T, nuse, recs, rank, nw, T.fstep_nodes + (size_t)n0, cnt IL_PROF_PASS);
       }
       IL_SYNC();
     }

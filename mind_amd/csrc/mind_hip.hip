@@ -101,8 +101,10 @@ struct mind_ctx {
   long long n_table_hits = 0;
   int actor_np = 6;             // partial products per term of the MFMA ActorNet under bf16x3: 6 (three-way split, fp32-class) or 3 (MIND_ACTOR_SPLIT=3)
   // nodes per forward step of a narrow tree's line search ("ilqr_chunk"; 0: whole segments, the default).  Measured on the recorded
-  // demo_1 loop: chunks of 6 / 8 / 12 nodes cost 2.10 / 2.05 / 2.04 ms per launch against 1.99 for whole segments -- the cost waves
-  // share the SIMDs' float64 pipe with the state-chain waves and slow the chain down by more than the tail they hide
+  // demo_1 loop: chunks of 6 / 8 / 12 nodes cost 2.10 / 2.05 / 2.04 ms per launch against 1.99 for whole segments (round 3: the cost
+  // waves shared the SIMDs' float64 pipe with five state-chain waves); with the chains of a level packed into ONE wave and the cost
+  // chunks kept off its SIMD (round 4) still 2.12 / 2.00 / 2.02 against 1.89: every extra forward step pays a rollout prologue (parent
+  // state, first operands: two dependent round trips) and a barrier, more than the shorter cost tail saves (profiles/r04x_*)
   int ilqr_chunk = 0;
   // wide cost trees: workgroups per tree (halved until every workgroup of the launch is resident; cfg4 full tree, six trees per launch:
   // 8.33 / 7.40 / 7.37 / 7.63 ms per plan with 8 / 16 / 24 / 32, profiles/r03an), node count from which they are used (mind_set_tuning)
@@ -1516,7 +1518,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     tl[t].sstart = takeI(nseg + 1); tl[t].snodes = takeI(M); tl[t].slstart = takeI(maxsd + 2); tl[t].slsegs = takeI(nseg);
     // forward steps of the line search: the segments of a level, cut into chunks of ilqr_chunk nodes when only a few chains run
     // side by side (the other waves then price the nodes the previous step reached); wide levels stay whole
-    const int chunk = (c->ilqr_chunk > 0 && tl[t].maxls <= 4) ? c->ilqr_chunk : M;
+    const int chunk = (c->ilqr_chunk > 0 && tl[t].maxls <= 6) ? c->ilqr_chunk : M;
     fs_start[t].assign(1, 0); fs_nstart[t].assign(1, 0);
     fs_q0[t].clear(); fs_q1[t].clear(); fs_nodes[t].clear();
     for (int d = 0; d <= maxsd; ++d) {

@@ -34,7 +34,7 @@ for l in sys.stdin:
 
 case $cmd in
 final)
-  ( time timeout 2400 python -m pytest tests -m gpu -q -x -s ) > $O/pytest_gpu_full.txt 2>&1; grep -n "passed\|failed\|^real" $O/pytest_gpu_full.txt | tail -3
+  ( time timeout 2400 python -m pytest tests -m gpu -q -s ) > $O/pytest_gpu_full.txt 2>&1; grep -n "passed\|failed\|^real" $O/pytest_gpu_full.txt | tail -3
   grep "^\[demo\|^\.\[demo\|same tree chosen\|cycles agree outright\|^demo_\|^\.demo_\|^stress" $O/pytest_gpu_full.txt | sed 's/^\.*//' > $O/pytest_gpu_parity_lines.txt
   tail -25 $O/pytest_gpu_full.txt > $O/pytest_gpu.txt
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2

@@ -6,7 +6,7 @@
 #include <vector>
 #include <cmath>
 #define NN 64
-__global__ __launch_bounds__(IL_THREADS) void k_bench(const IlqrTreeDev *tp, const IlqrConst *cp, long long *cyc, int reps, int active_waves) {
+__global__ __launch_bounds__(IL_THREADS) void k_bench(const IlqrTreeDev *tp, const IlqrConst *cp, long long *cyc, int reps, int active_waves, int pack) {
   extern __shared__ double il_dsm[];
   const IlqrTreeDev T = *tp;
   const IlqrConst &C = *cp;
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_bench(const IlqrTreeDev *tp, con
     long long t0 = clock64();
     int sing = il_backward_segment<false>(C, T, T, 0, NN, 1.0, scr);
     long long t1 = clock64();
-    il_rollout_segment(C, T, 0, 0);
+    il_rollout_packed(C, T, 0, 1, pack, 0, 0);      // `pack` (slot, piece) items in the wave's lanes: the same chain under `pack` mu slots
     long long t2 = clock64();
     t_ric += t1 - t0; t_roll += t2 - t1;
     if (sing) break;
@@ -46,6 +46,7 @@ int main(int argc, char **argv) {
   T.M = M; T.n_agents = 1; T.n_levels = M; T.n_segs = 1; T.n_slevels = 1; T.max_level_segs = 1;
   T.parent = (const int *)up(parent.data(), M * 4); T.seg_start = (const int *)up(seg_start.data(), 8); T.seg_nodes = (const int *)up(seg_nodes.data(), M * 4);
   T.prob = (const float *)up(prob.data(), M * 4);
+  { const int q0 = 0, q1 = M; T.fstep_q0 = (const int *)up(&q0, 4); T.fstep_q1 = (const int *)up(&q1, 4); }
   T.xs = (double *)up(xs.data(), M * 48); T.us = (double *)up(us.data(), M * 16); T.Fx = (double *)up(Fx.data(), M * 288); T.Lx = (double *)up(Lx.data(), M * 48);
   T.Lxx = (double *)up(Lxx.data(), M * 288); T.K = (double *)up(K.data(), K.size() * 8); T.k = (double *)up(k.data(), k.size() * 8);
   void *w; hipMalloc(&w, 4 * 10 * M * 64); hipMemset(w, 0, 4 * 10 * M * 64); T.xs_new = (double *)w;
@@ -56,11 +57,12 @@ int main(int argc, char **argv) {
   IlqrTreeDev *dT = (IlqrTreeDev *)up(&T, sizeof(T)); IlqrConst *dC = (IlqrConst *)up(&C, sizeof(C));
   long long *cyc; hipMalloc(&cyc, 16 * 8);
   const size_t lds = (size_t)IL_WAVES * IL_SCR * 8;
-  for (int aw : {1, 4, 5, 8}) {
-    const int reps = 20;
-    for (int it = 0; it < 2; ++it) { hipLaunchKernelGGL(k_bench, dim3(1), dim3(IL_THREADS), lds, 0, dT, dC, cyc, reps, aw); hipDeviceSynchronize(); }
+  for (int aw : {1, 4, 5, 8, -1, -4}) {
+    const int reps = 20, pack = aw < 0 ? -aw : 1;
+    if (aw < 0) aw = 1;
+    for (int it = 0; it < 2; ++it) { hipLaunchKernelGGL(k_bench, dim3(1), dim3(IL_THREADS), lds, 0, dT, dC, cyc, reps, aw, pack); hipDeviceSynchronize(); }
     long long h[16]; hipMemcpy(h, cyc, 16 * 8, hipMemcpyDeviceToHost);
-    printf("%d active wave(s): wave 0 Riccati %.0f cycles / node, rollout %.0f cycles / node", aw, (double)h[0] / reps / NN, (double)h[1] / reps / NN);
+    printf("%d active wave(s), %d item(s) per rollout wave: wave 0 Riccati %.0f cycles / node, rollout %.0f cycles / node", aw, pack, (double)h[0] / reps / NN, (double)h[1] / reps / NN);
     if (aw > 4) printf(" | wave 4 (shares a SIMD with wave 0): %.0f, %.0f", (double)h[8] / reps / NN, (double)h[9] / reps / NN);
     printf("\n");
   }
