@@ -90,18 +90,25 @@ __device__ __forceinline__ void gemm_bf(frag8 &acc, const u32 *wa, const u32x4 (
   for (int st = 0; st < 8; ++st) {
     const int g = st >> 1, o0 = (st & 1) * 4, cur = st & 1, nxt = cur ^ 1;
     const int gn = (st + 1) >> 1, on = ((st + 1) & 1) * 4;
+#ifdef MIND_GEMM_NO_RELOAD      // (timing-only build of tools/micro/pair_bench: the weight fragments of the first step serve all eight)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ah[nxt][k] = ah[cur][k]; asm volatile("" : "+v"(ah[nxt][k])); }
+#else
     if (st < 7) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) ah[nxt][k] = *(const u32x4 *)(wl + (((on + k) * 4 + gn) * 256));
     }
+#endif
     if (NP == 3) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[o0 + k] = MFMA_BF(al[k], bhi[g], acc[o0 + k]);
       SCHED_FENCE();
+#ifndef MIND_GEMM_NO_RELOAD
       if (st < 7) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) al[k] = *(const u32x4 *)(wl + 8192 + (((on + k) * 4 + gn) * 256));
       }
+#endif
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[o0 + k] = MFMA_BF(ah[cur][k], bhi[g], acc[o0 + k]);
