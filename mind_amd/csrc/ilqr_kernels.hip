@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #pragma clang fp contract(off)
+#include "mind_trig.h"      // sin / cos / tan shared with oracle/ilqr_ref.c (same operations => same bits)
 
 #define IL_NS 6
 #define IL_NU 2
@@ -70,12 +71,13 @@ struct IlqrTreeDev {
   GP<const int> seg_nodes;     // [M]
   GP<const int> slevel_start;  // [n_slevels+1] into slevel_segs (segments grouped by depth in the segment tree)
   GP<const int> slevel_segs;   // [n_segs]
+  GP<const int> seg_rec;       // [n_segs][16]: s0, s1, last node, first node, node before the last, the last node's child count, its child_list start, -, six children
   // forward steps of the line search: a step = the segments of one segment level cut into chunks of at most `ilqr_chunk` nodes
   // (host), so that the cost pass of step s - 1 runs on the idle waves while the state chains of step s advance
   int n_fsteps, padf;
   GP<const int> fstep_start;   // [n_fsteps+1] into fstep_q0 / fstep_q1
-  GP<const int> fstep_q0;      // per item: first position in seg_nodes ...
-  GP<const int> fstep_q1;      // ... and one past the last
+  GP<const int> fstep_q0;      // per item a record of 8 ints: first position in seg_nodes, one past the last, the first two nodes, the first node's parent
+  GP<const int> fstep_q1;      // per item: one past the last position
   GP<const int> fstep_nstart;  // [n_fsteps+1] into fstep_nodes
   GP<const int> fstep_nodes;   // [M] nodes in step order
   GP<const float> prob;        // [M]
@@ -329,10 +331,12 @@ __device__ __forceinline__ void il_field(const IlqrConst &C, const IlqrTreeDev &
 }
 
 __device__ __forceinline__ void il_dyn(const IlqrConst &C, const double *x, const double *u, double *o) {
-  o[0] = x[0] + x[2] * cos(x[3]) * C.dt;
-  o[1] = x[1] + x[2] * sin(x[3]) * C.dt;
+  double s3, c3;
+  mind_sincos(x[3], &s3, &c3);
+  o[0] = x[0] + x[2] * c3 * C.dt;
+  o[1] = x[1] + x[2] * s3 * C.dt;
   o[2] = x[2] + x[4] * C.dt;
-  o[3] = x[3] + x[2] / C.wb * tan(x[5]) * C.dt;
+  o[3] = x[3] + x[2] / C.wb * mind_tan(x[5]) * C.dt;
   o[4] = x[4] + u[0] * C.dt;
   o[5] = x[5] + u[1] * C.dt;
 }
@@ -405,7 +409,7 @@ __device__ double il_np_sum(const double *a, long n) {
 // ahead.  Returns (wave-uniform) 1 if a Q_uu is singular.
 template <bool GEN>
 __device__ __forceinline__ int il_backward_segment(const IlqrConst &C, const IlqrTreeDev &T, const IlqrTreeDev &Ts, int s0, int s1,
-                                                   double mu, double *scr IL_PROF_ARG) {
+                                                   int c_last, int c_prev, double mu, double *scr IL_PROF_ARG) {
   const int lane = threadIdx.x & 63;
   const int i = lane / 6, j = lane % 6;
   const bool mat = lane < 36, vxl = lane >= 36 && lane < 42;
@@ -460,8 +464,8 @@ __device__ __forceinline__ int il_backward_segment(const IlqrConst &C, const Ilq
     else { const double pp = (double)pProb[c]; P.w0 = C.w_ctrl[0] * pp; P.w1 = C.w_ctrl[1] * pp; }
   };
   int r = s1 - 1;
-  int c = __builtin_amdgcn_readfirstlane(pSeg[r]);
-  int cn_v = pSeg[r > s0 ? r - 1 : r];          // node indices travel two nodes ahead, in a VGPR until they are needed
+  int c = c_last;                               // (the segment's last node and the one before it come with the segment record)
+  int cn_v = c_prev;                            // node indices travel two nodes ahead, in a VGPR until they are needed
   Pre P, N;
   request(c, P);
   // gains of the node before (loads and stores share one in-order counter: a store issued at the end of a node would be waited for at
@@ -549,11 +553,11 @@ __device__ __forceinline__ int il_backward_segment(const IlqrConst &C, const Ilq
 // x' = f(x, u) (trajectory_tree.py:168-175)
 __device__ __forceinline__ void il_dyn_sc(const IlqrConst &C, const double *x, const double *u, double *o) {
   double s3, c3;
-  sincos(x[3], &s3, &c3);
+  mind_sincos(x[3], &s3, &c3);
   o[0] = x[0] + x[2] * c3 * C.dt;
   o[1] = x[1] + x[2] * s3 * C.dt;
   o[2] = x[2] + x[4] * C.dt;
-  o[3] = x[3] + x[2] / C.wb * tan(x[5]) * C.dt;
+  o[3] = x[3] + x[2] / C.wb * mind_tan(x[5]) * C.dt;
   o[4] = x[4] + u[0] * C.dt;
   o[5] = x[5] + u[1] * C.dt;
 }
@@ -592,8 +596,12 @@ __device__ __forceinline__ void il_rollout_packed(const IlqrConst &C, const Ilqr
   const double IL_AS1 *pK = T.K.g() + (size_t)slot * M * 12, *pk = T.k.g() + (size_t)slot * M * 2, *pUs = T.us.g(), *pXs = T.xs.g();
   double IL_AS1 *pXn = T.xs_new.g() + ((size_t)slot * IL_NA + a) * M * 6, *pUn = T.us_new.g() + ((size_t)slot * IL_NA + a) * M * 2;
   asm volatile("" : "+v"(pSeg), "+v"(pK), "+v"(pk), "+v"(pUs), "+v"(pXs), "+v"(pXn), "+v"(pUn));
-  int q = T.fstep_q0[it];
-  const int s1 = T.fstep_q1[it];
+  const int IL_AS1 *rec = T.fstep_q0.g() + (size_t)it * 8;       // {q0, q1, first node, second node, the first node's parent}
+  int q = rec[0];
+  const int s1 = rec[1];
+  int c = rec[2];
+  int cn = rec[3];
+  const int p0 = rec[4];                    // -1: node 0, the only child of the x0 root (checked on the host)
   int nmax = s1 - q;                      // the wave runs as many nodes as its longest piece has
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(nmax, d); nmax = o > nmax ? o : nmax; }
@@ -609,9 +617,6 @@ __device__ __forceinline__ void il_rollout_packed(const IlqrConst &C, const Ilqr
     const il_d2 vu = *(const il_d2 IL_AS1 *)(pUs + (size_t)c * 2);
     P.k[0] = vk.x; P.k[1] = vk.y; P.us[0] = vu.x; P.us[1] = vu.y;
   };
-  int c = pSeg[q];
-  int cn = pSeg[q + 1 < s1 ? q + 1 : s1 - 1];
-  const int p0 = c == 0 ? -1 : T.parent[c];      // node 0 is the only child of the x0 root (checked on the host)
   double xp[6], xo[6];
   {
     const size_t pp = (size_t)(p0 < 0 ? 0 : p0) * 6;
@@ -859,9 +864,9 @@ __device__ __forceinline__ void il_node_derivs(const IlqrConst &C, const IlqrTre
   FieldOut fe;
   il_field<GEN>(C, T, c, x[0], x[1], scr, ag, true, fe);
   double s3, c3;
-  sincos(x[3], &s3, &c3);
-  const double c5 = cos(x[5]);
-  const double t5 = tan(x[5]);
+  mind_sincos(x[3], &s3, &c3);
+  double c5, t5;
+  mind_tan_cos(x[5], &t5, &c5);
   if (lane < 36) {
     const int i = lane / 6, j = lane % 6;
     // l_xx = field Hessian (xy block) + 2 W_des + 2 W_con on violated bounds
@@ -1056,9 +1061,9 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
       } else {
         // ---- f_x at the POST state (Q1); constant entries were written at kernel start
         double s3, c3;
-        sincos(x[3], &s3, &c3);
-        const double c5 = cos(x[5]);
-        const double t5 = tan(x[5]);
+        mind_sincos(x[3], &s3, &c3);
+        double c5, t5;
+        mind_tan_cos(x[5], &t5, &c5);
         if (valid) {
           auto F = T.Fx + (size_t)c * 36;
           F[2] = c3 * C.dt;
@@ -1288,21 +1293,38 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
         for (int e = 0; e < slot; ++e) il_reject_update(mu, de);
         IlqrTreeDev Ts = T;
         Ts.k += (size_t)slot * M * 2; Ts.K += (size_t)slot * M * 12; Ts.Vx += (size_t)slot * M * 6; Ts.Vxx += (size_t)slot * M * 36;
-        const int s0 = T.seg_start[seg], s1 = T.seg_start[seg + 1];
+        int rec[14];
         {
-          const int c = T.seg_nodes[s1 - 1];
+          const int IL_AS1 *sr = T.seg_rec.g() + (size_t)seg * 16;
+#pragma unroll
+          for (int e = 0; e < 14; ++e) rec[e] = __builtin_amdgcn_readfirstlane(sr[e]);
+        }
+        const int s0 = rec[0], s1 = rec[1];
+        {
+          // value function entering the segment = sum over the last node's children, in child order; the first six children's rows
+          // are requested together (one round trip instead of two per child)
+          const int nch = rec[5];
           double acc = 0.0;
-          if (lane < 42)
-            for (int e = T.child_start[c]; e < T.child_start[c + 1]; ++e) {
+          if (lane < 42) {
+            double v[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+              const int ch = rec[8 + e];
+              v[e] = lane < 36 ? Ts.Vxx[(size_t)ch * 36 + lane] : Ts.Vx[(size_t)ch * 6 + (lane - 36)];      // (unused slots name node 0: a valid row nobody adds)
+            }
+#pragma unroll
+            for (int e = 0; e < 6; ++e) if (e < nch) acc += v[e];
+            for (int e = rec[6] + 6; e < rec[6] + nch; ++e) {
               const int ch = T.child_list[e];
               acc += lane < 36 ? Ts.Vxx[(size_t)ch * 36 + lane] : Ts.Vx[(size_t)ch * 6 + (lane - 36)];
             }
+          }
           IL_WFENCE();
           if (lane < 36) scr[36 + lane] = acc;
           else if (lane < 42) scr[176 + lane - 36] = acc;
           IL_WFENCE();
         }
-        const int sing = il_backward_segment<GEN>(C, T, Ts, s0, s1, mu, scr IL_PROF_PASS);
+        const int sing = il_backward_segment<GEN>(C, T, Ts, s0, s1, rec[2], rec[4], mu, scr IL_PROF_PASS);
         if (sing) {
           if (lane == 0) {
             if (MULTI) __hip_atomic_fetch_or(&bar[2 + (n_pass & 1)], 1u << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1310,7 +1332,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
           }
         }
         else {
-          const int c = T.seg_nodes[s0];   // value function of the segment head, for the parent's gather
+          const int c = rec[3];            // value function of the segment head, for the parent's gather
           if (lane < 36) Ts.Vxx[(size_t)c * 36 + lane] = scr[36 + lane];
           else if (lane < 42) Ts.Vx[(size_t)c * 6 + lane - 36] = scr[176 + lane - 36];
         }

@@ -1429,7 +1429,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   const size_t o_evn = takeI(ev ? ev->nq : 0);
   const size_t o_bars = takeI(4 * (size_t)n_trees + 4);   // barrier words of the multi-workgroup launch + its abort word (zero at upload)
   const int trace_cap = std::min(256, std::max(cfg->max_iter, cfg2 ? cfg2->max_iter : 0));      // rows of the per-iteration trace, per phase
-  struct TL { size_t nodew, field, relag; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, rel, fsstart, fsq0, fsq1, fsnstart, fsnodes, trace; int M, a, nl, nseg, nsl, maxls, nfs; };
+  struct TL { size_t nodew, field, relag; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, segrec, rel, fsstart, fsq0, fsq1, fsnstart, fsnodes, trace; int M, a, nl, nseg, nsl, maxls, nfs; };
   std::vector<TL> tl(n_trees);
   long Mtot = 0;
   for (int t = 0; t < n_trees; ++t) tl[t].us = takeD(2 * (size_t)(trees[t].n_nodes > 0 ? trees[t].n_nodes : 0));
@@ -1459,7 +1459,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   // levels need the depth first
   std::vector<std::vector<int>> lvl_start(n_trees), lvl_nodes(n_trees), cst(n_trees), cls(n_trees);
   std::vector<std::vector<int>> sg_start(n_trees), sg_nodes(n_trees), sl_start(n_trees), sl_segs(n_trees);
-  std::vector<std::vector<int>> fs_start(n_trees), fs_q0(n_trees), fs_q1(n_trees), fs_nstart(n_trees), fs_nodes(n_trees);
+  std::vector<std::vector<int>> seg_rec(n_trees), fs_start(n_trees), fs_q0(n_trees), fs_q1(n_trees), fs_nstart(n_trees), fs_nodes(n_trees);
   for (int t = 0; t < n_trees; ++t) {
     const mind_cost_tree &tr = trees[t];
     const int M = tr.n_nodes;
@@ -1516,6 +1516,18 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     tl[t].maxls = 1;
     for (int d = 0; d <= maxsd; ++d) tl[t].maxls = std::max(tl[t].maxls, sl_start[t][d + 1] - sl_start[t][d]);
     tl[t].sstart = takeI(nseg + 1); tl[t].snodes = takeI(M); tl[t].slstart = takeI(maxsd + 2); tl[t].slsegs = takeI(nseg);
+    // segment record of the backward sweep (16 ints): positions [s0, s1) of seg_nodes, last / first node, the node before the last, the
+    // last node's child count, where its children start in child_list and the first six of them -- one round trip instead of the walk
+    // segment -> positions -> node -> child range -> children
+    seg_rec[t].assign((size_t)nseg * 16, 0);
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+      int *r = seg_rec[t].data() + (size_t)sgi * 16;
+      const int s0 = sg_start[t][sgi], s1 = sg_start[t][sgi + 1], cl = sg_nodes[t][s1 - 1];
+      r[0] = s0; r[1] = s1; r[2] = cl; r[3] = sg_nodes[t][s0]; r[4] = sg_nodes[t][s1 - 2 >= s0 ? s1 - 2 : s1 - 1];
+      r[5] = nchild(cl); r[6] = cst[t][cl];
+      for (int e = 0; e < 6 && e < r[5]; ++e) r[8 + e] = cls[t][cst[t][cl] + e];
+    }
+    tl[t].segrec = takeI((size_t)nseg * 16);
     // forward steps of the line search: the segments of a level, cut into chunks of ilqr_chunk nodes when only a few chains run
     // side by side (the other waves then price the nodes the previous step reached); wide levels stay whole
     const int chunk = (c->ilqr_chunk > 0 && tl[t].maxls <= 6) ? c->ilqr_chunk : M;
@@ -1528,10 +1540,14 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
         for (int e = sl_start[t][d]; e < sl_start[t][d + 1]; ++e) {
           const int sgi = sl_segs[t][e], q0 = sg_start[t][sgi] + k0, q1 = std::min(sg_start[t][sgi + 1], q0 + chunk);
           if (q0 >= q1) continue;
-          fs_q0[t].push_back(q0); fs_q1[t].push_back(q1);
+          // item record: positions [q0, q1) of seg_nodes, its first two nodes and the first node's parent (the rollout's prologue
+          // would otherwise walk q0 -> node -> parent -> state through four dependent loads)
+          const int c0 = sg_nodes[t][q0], c1 = sg_nodes[t][q0 + 1 < q1 ? q0 + 1 : q1 - 1];
+          for (int v : {q0, q1, c0, c1, c0 == 0 ? -1 : tr.parent[c0], 0, 0, 0}) fs_q0[t].push_back(v);
+          fs_q1[t].push_back(q1);
           for (int q = q0; q < q1; ++q) fs_nodes[t].push_back(sg_nodes[t][q]);
         }
-        fs_start[t].push_back((int)fs_q0[t].size()); fs_nstart[t].push_back((int)fs_nodes[t].size());
+        fs_start[t].push_back((int)fs_q1[t].size()); fs_nstart[t].push_back((int)fs_nodes[t].size());
       }
     }
     tl[t].nfs = (int)fs_start[t].size() - 1;
@@ -1588,6 +1604,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     memcpy(hI.data() + L.snodes, sg_nodes[t].data(), sg_nodes[t].size() * sizeof(int));
     memcpy(hI.data() + L.slstart, sl_start[t].data(), sl_start[t].size() * sizeof(int));
     memcpy(hI.data() + L.slsegs, sl_segs[t].data(), sl_segs[t].size() * sizeof(int));
+    memcpy(hI.data() + L.segrec, seg_rec[t].data(), seg_rec[t].size() * sizeof(int));
     memcpy(hI.data() + L.fsstart, fs_start[t].data(), fs_start[t].size() * sizeof(int));
     memcpy(hI.data() + L.fsq0, fs_q0[t].data(), fs_q0[t].size() * sizeof(int));
     memcpy(hI.data() + L.fsq1, fs_q1[t].data(), fs_q1[t].size() * sizeof(int));
@@ -1602,7 +1619,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     D.field = gen ? (const double *)(base + L.field) : nullptr;
     D.node_w = gen ? Dp(L.nodew) : nullptr;
     D.n_segs = L.nseg; D.n_slevels = L.nsl; D.max_level_segs = L.maxls; D.pad2 = 0;
-    D.seg_start = dI + L.sstart; D.seg_nodes = dI + L.snodes; D.slevel_start = dI + L.slstart; D.slevel_segs = dI + L.slsegs;
+    D.seg_start = dI + L.sstart; D.seg_nodes = dI + L.snodes; D.slevel_start = dI + L.slstart; D.slevel_segs = dI + L.slsegs; D.seg_rec = dI + L.segrec;
     D.n_fsteps = L.nfs; D.padf = 0;
     D.trace = trace_cap > 0 ? Dp(L.trace) : nullptr; D.trace_cap = trace_cap; D.padt = 0;
     D.fstep_start = dI + L.fsstart; D.fstep_q0 = dI + L.fsq0; D.fstep_q1 = dI + L.fsq1; D.fstep_nstart = dI + L.fsnstart; D.fstep_nodes = dI + L.fsnodes;

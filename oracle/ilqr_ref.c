@@ -13,6 +13,8 @@
  *   bicycle f, f_x, f_u               planners/mind/trajectory_tree.py:153-177 (closed-form Jacobian)
  *   iLQR.fit & friends                planners/ilqr/solver.py:80-421 (Q1 Jacobian at post-state, Q2
  *                                     root aliasing V[-1], Q9, Q10, Q19 reproduced)
+ *   sin / cos / tan                   mind_amd/csrc/mind_trig.h (shared with the kernel: where numpy / glibc would round the last
+ *                                     bit differently in 1-2 % of the arguments, kernel and oracle do not)
  * Pinned by tests/golden/ilqr.npz captured from the imported reference (tools/gen_golden.py).
  */
 #include <math.h>
@@ -21,6 +23,12 @@
 #include <string.h>
 
 #include "../include/mind_hip.h"
+/* sin / cos / tan: the routine k_ilqr uses (<= 0.75 / 0.9 ulp), so that kernel and oracle agree to the bit on every platform; the
+ * oracle stays pinned to the reference (numpy's functions) by the goldens at 1e-9 */
+#include "../mind_amd/csrc/mind_trig.h"
+/* test hooks (tests/test_trig.py) */
+void oracle_sincos(double x, double *s, double *c) { mind_sincos(x, s, c); }
+void oracle_tan_cos(double x, double *t, double *c) { mind_tan_cos(x, t, c); }
 
 #define NS 6
 #define NU 2
@@ -231,10 +239,12 @@ static double node_cost(const solver_t *S, int i, const double *x, const double 
 /* ---- dynamics (trajectory_tree.py:168-175) ---- */
 static void dyn_f(const mind_ilqr_cfg *c, const double *x, const double *u, double *o) {
   const double dt = c->dt, wb = c->wheelbase;
-  o[0] = x[0] + x[2] * cos(x[3]) * dt;
-  o[1] = x[1] + x[2] * sin(x[3]) * dt;
+  double s3, c3;
+  mind_sincos(x[3], &s3, &c3);
+  o[0] = x[0] + x[2] * c3 * dt;
+  o[1] = x[1] + x[2] * s3 * dt;
   o[2] = x[2] + x[4] * dt;
-  o[3] = x[3] + x[2] / wb * tan(x[5]) * dt;
+  o[3] = x[3] + x[2] / wb * mind_tan(x[5]) * dt;
   o[4] = x[4] + u[0] * dt;
   o[5] = x[5] + u[1] * dt;
 }
@@ -242,13 +252,16 @@ static void dyn_fx(const mind_ilqr_cfg *c, const double *x, double *J) {
   const double dt = c->dt, wb = c->wheelbase;
   memset(J, 0, NS * NS * sizeof(double));
   for (int k = 0; k < NS; k++) J[k * NS + k] = 1.0;
-  J[0 * NS + 2] = cos(x[3]) * dt;
-  J[0 * NS + 3] = -x[2] * sin(x[3]) * dt;
-  J[1 * NS + 2] = sin(x[3]) * dt;
-  J[1 * NS + 3] = x[2] * cos(x[3]) * dt;
+  double s3, c3, t5, c5;
+  mind_sincos(x[3], &s3, &c3);
+  mind_tan_cos(x[5], &t5, &c5);
+  J[0 * NS + 2] = c3 * dt;
+  J[0 * NS + 3] = -x[2] * s3 * dt;
+  J[1 * NS + 2] = s3 * dt;
+  J[1 * NS + 3] = x[2] * c3 * dt;
   J[2 * NS + 4] = dt;
-  J[3 * NS + 2] = tan(x[5]) / wb * dt;
-  J[3 * NS + 5] = x[2] / wb / (cos(x[5]) * cos(x[5])) * dt;
+  J[3 * NS + 2] = t5 / wb * dt;
+  J[3 * NS + 5] = x[2] / wb / (c5 * c5) * dt;
 }
 
 typedef struct {

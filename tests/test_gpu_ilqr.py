@@ -78,10 +78,10 @@ def test_contingency_in_one_launch_equals_two_solves(kind, a, hip_predictor):
 
 def test_wide_cost_tree_matches_oracle(hip_predictor):
     """The biggest scenario tree of the scripted 6-ary depth-4 AIME tree (16 agents): hundreds of trajectory nodes,
-    dozens of chain segments per level (several rounds of waves per level).  The lane-only fit is exact after one
-    iteration; afterwards the only deviations from the C oracle are last-bit differences between the device math
-    library and glibc (sincos / tan) amplified by the iteration: <= 6e-14 after three iterations -- the same
-    numbers, bit for bit, that the first (wave-per-node) version of the kernel produced on this tree."""
+    dozens of chain segments per level (several rounds of waves per level).  Bit-identical to the C oracle after three
+    iterations with and without the exo-agent terms: kernel and oracle run the same float64 operations in the same order,
+    sin / cos / tan included (mind_amd/csrc/mind_trig.h; with the device library's functions in the kernel and glibc's in
+    the oracle this tree differed by <= 6e-14)."""
     from test_aime_host import _full_tree_run
     g, trees = _full_tree_run(True)
     st = max(trees, key=lambda t: len(t.nodes))
@@ -96,7 +96,7 @@ def test_wide_cost_tree_matches_oracle(hip_predictor):
     for use_exo in (0, 1):
         ref = oi.solve(cfg, flat, x0, lane, 4.0, use_exo)
         xs, us, stt = hip_predictor.ilqr_solve(cfg, [flat], x0, lane, 4.0, use_exo)
-        assert np.abs(xs[0] - ref["xs"]).max() < 1e-12 and np.abs(us[0] - ref["us"]).max() < 1e-12
+        assert np.array_equal(xs[0], ref["xs"]) and np.array_equal(us[0], ref["us"])
         assert stt[0]["iterations"] == ref["iterations"] and stt[0]["mu"] == ref["mu"] and stt[0]["J"] == ref["J"]
     cfg1 = oi.default_cfg(max_iter=1)
     ref = oi.solve(cfg1, flat, x0, lane, 4.0, 0)

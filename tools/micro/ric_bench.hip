@@ -21,7 +21,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_bench(const IlqrTreeDev *tp, con
     else if (lane < 42) scr[176 + lane - 36] = 0.1;
     IL_WFENCE();
     long long t0 = clock64();
-    int sing = il_backward_segment<false>(C, T, T, 0, NN, 1.0, scr);
+    int sing = il_backward_segment<false>(C, T, T, 0, NN, NN - 1, NN - 2, 1.0, scr);
     long long t1 = clock64();
     il_rollout_packed(C, T, 0, 1, pack, 0, 0);      // `pack` (slot, piece) items in the wave's lanes: the same chain under `pack` mu slots
     long long t2 = clock64();
@@ -46,7 +46,7 @@ int main(int argc, char **argv) {
   T.M = M; T.n_agents = 1; T.n_levels = M; T.n_segs = 1; T.n_slevels = 1; T.max_level_segs = 1;
   T.parent = (const int *)up(parent.data(), M * 4); T.seg_start = (const int *)up(seg_start.data(), 8); T.seg_nodes = (const int *)up(seg_nodes.data(), M * 4);
   T.prob = (const float *)up(prob.data(), M * 4);
-  { const int q0 = 0, q1 = M; T.fstep_q0 = (const int *)up(&q0, 4); T.fstep_q1 = (const int *)up(&q1, 4); }
+  { const int rec[8] = {0, M, 0, 1, -1, 0, 0, 0}, q1 = M; T.fstep_q0 = (const int *)up(rec, 32); T.fstep_q1 = (const int *)up(&q1, 4); }
   T.xs = (double *)up(xs.data(), M * 48); T.us = (double *)up(us.data(), M * 16); T.Fx = (double *)up(Fx.data(), M * 288); T.Lx = (double *)up(Lx.data(), M * 48);
   T.Lxx = (double *)up(Lxx.data(), M * 288); T.K = (double *)up(K.data(), K.size() * 8); T.k = (double *)up(k.data(), k.size() * 8);
   void *w; hipMalloc(&w, 4 * 10 * M * 64); hipMemset(w, 0, 4 * 10 * M * 64); T.xs_new = (double *)w;
