@@ -15,7 +15,8 @@ rounds and solves 5 scenario trees per plan on demo_1 -- the load a trained chec
 Multi-GPU (one process per GPU; plain `python bench.py --gpus N` spawns the N ranks itself through
 torch.distributed.run, under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE):
   * default workload: every rank runs its own closed loop (independent scenes: weak scaling, no data-path collective),
-    and the line also carries `tree_sharded`: the full cfg4 scenario tree planned ONCE by all ranks together (AIME rounds
+    and the line also carries `tree_replicas` (every rank plans the full cfg4 tree of a scene of its own: weak scaling of the node
+    throughput) and `tree_sharded`: the full cfg4 scenario tree planned ONCE by all ranks together (AIME rounds
     block-sharded, contingency solves round-robin, RCCL all-gather / broadcast per round: strong scaling);
   * --workload cfg4tree / stress128tree (or --shard): that sharded plan is the headline (`scaling: strong`);
     --replicas forces independent replicas.
@@ -768,6 +769,16 @@ def main():
                             scaling="strong" if world > 1 else None, plans_timed=args.tree_steps)
         except Exception as e:       # noqa: BLE001
             out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        if world > 1:
+            # the same full tree planned by every rank for a scene of its own (independent trees, no data-path collective): the node
+            # throughput of the whole job when the scenes, not one scene's branches, are what is spread over the GPUs
+            try:
+                t = measure(dist, "cfg4tree", args.tree_steps, 2, False, replica=rank)
+                out["tree_replicas"] = dict(summarize(t, prec), workload="cfg4tree on every rank, one independent scene per rank (full scripted 6-ary "
+                                            "depth-4 AIME tree on the real predictor forward); nodes_expanded_per_s is the whole job's", n_gpus=world,
+                                            scaling="weak", plans_timed=args.tree_steps)
+            except Exception as e:       # noqa: BLE001
+                out["tree_replicas"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if rank == 0 and world == 1:
         if not args.no_traffic and out.get("roofline"):
             tb, det = measure_traffic(args.workload, out["roofline"]["algorithmic_bytes_per_launch"])

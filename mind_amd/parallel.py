@@ -141,7 +141,18 @@ class Shard:
         rc = rt.lib.mind_set_exchange(rt.ctx, self.rank if on else 0, self.world if on else 1, self._cb if on else _lib.EXCHANGE_FN(0), None, 1 if self.force else 0)
         _lib.check(rt.lib, rt.ctx, rc, "mind_set_exchange")
         self.native = on
+        rt._exchange_owner = self if on else None       # (the exchange belongs to the context: planners sharing it re-attach / detach, see detach)
         return self
+
+    @staticmethod
+    def detach(rt):
+        """Take the exchange off a context: the next mind_aime_plan on it plans alone again.  (A context outlives the planner that
+        attached a group to it -- the per-thread runtime is shared by every planner of the thread -- so a planner without a shard makes
+        sure nobody else's exchange is still on the context it plans with: ScenarioTreeGenerator._sync_exchange.)"""
+        from . import _lib
+        rc = rt.lib.mind_set_exchange(rt.ctx, 0, 1, _lib.EXCHANGE_FN(0), None, 0)
+        _lib.check(rt.lib, rt.ctx, rc, "mind_set_exchange")
+        rt._exchange_owner = None
 
     def broadcast(self, t, src=0):
         """In-place broadcast of a tensor on ``self.device`` from ``src``."""

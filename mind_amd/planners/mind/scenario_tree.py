@@ -246,6 +246,16 @@ class ScenarioTreeGenerator:
                 and (self.shard is None or not self.shard.sharded or getattr(self.shard, "native", False)) and self.ego_idx == 0 and self.target_lane is not None
                 and len(self.target_lane) >= 12 and self.config is not None)
 
+    def _sync_exchange(self, rt):
+        """the context's exchange (mind_set_exchange) is this planner's group or none: contexts are shared by the planners of a thread"""
+        want = self.shard if (self.shard is not None and getattr(self.shard, "native", False)) else None
+        if getattr(rt, "_exchange_owner", None) is not want:
+            if want is None:
+                from ...parallel import Shard
+                Shard.detach(rt)
+            else:
+                want.attach(rt)
+
     def _branch_aime_native(self, lcl_smp, agent_obs, on_flats=None):
         """branch_aime through mind_aime_plan; None = the library left this plan to the round-by-round path.  ``on_flats``: called
         with the plan's flattened cost trees (in get_scenario_tree's order) as soon as the native call returns, BEFORE the tree's
@@ -253,6 +263,7 @@ class ScenarioTreeGenerator:
         cfg = self.config
         if self.obs_len != 50 or not (2 <= self.pred_len <= 60):
             return None
+        self._sync_exchange(self.network.rt)
         scripted = type(self.network).__name__ in ("ScriptedBranching", "ScriptedFullTree", "ScriptedDeepTree")
         floor = getattr(self.network, "prob_floor", None) if scripted else None
         modes = (lambda n_agents: self.network._modes(n_agents, self.network.rt.device)) if scripted else (lambda n_agents: None)

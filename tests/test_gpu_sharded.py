@@ -128,6 +128,8 @@ def test_bench_spawns_its_own_ranks_and_checks_the_world_size():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "recorded scene demo_1" in d["config"]["workload"]
     t = d["tree_sharded"]
     assert t["n_gpus"] == 2 and t["scaling"] == "strong" and t["expansions_per_plan"] == 259 and t["collectives_per_plan"] >= 9
+    w = d["tree_replicas"]          # the same tree, one independent scene per rank: twice the expansions in the same plan time
+    assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["expansions_per_plan"] == 2 * 259 and "collectives_per_plan" not in w
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
