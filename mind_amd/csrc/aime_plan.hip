@@ -204,6 +204,11 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   float pair_ms = 0.f;
   int pair_launches = 0;
   memset(out, 0, sizeof(*out));
+  // profiling (bench.py's live pair-kernel durations): the predictor calls of the plan record into an event pool that is read once at
+  // the end, instead of draining the stream after every call
+  struct DeferGuard { mind_ctx *c; ~DeferGuard() { c->ev_defer = false; c->ev_pending.clear(); c->ev_pool_used = 0; } } defer_guard{c};
+  c->ev_defer = c->profiling;
+  c->ev_pending.clear(); c->ev_pool_used = 0;
 
   // layout of one re-based input set (floats): actors | actor_ctrs | actor_vecs | lane_ctrs | lane_vecs | tgt_nodes | tgt_rpe | frames | cov_last
   struct InOff { size_t actors, ctrs, vecs, lc, lv, tn, tr, fr, cov, total; };
@@ -319,7 +324,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       po.cls = d_cls; po.reg = d_reg; po.vel = d_vel;
       if ((rc = mind_predict_batch(c, &sb, &po))) return rc;
       n_expanded += cb;
-      if (c->profiling) { pair_ms += c->pair_ms; pair_launches += c->n_pair_launch; }
+      if (c->profiling) pair_launches += c->n_pair_launch;
       if (in->script_cls) {
         // scripted modes (benchmark hook): the forward above was the timed work, its outputs are replaced scene by scene
         const size_t nr = (size_t)a * 6 * T * 5, nv = (size_t)a * 6 * T * 2;
@@ -645,6 +650,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   out->rows = c->pl_rows_host.data(); out->n_row_floats = n_rows;
   out->n_expanded = n_expanded; out->n_rounds = round;
   out->root_flags = (nodes[0].branch ? MIND_AIME_BRANCH : 0) | (nodes[0].end ? MIND_AIME_END : 0) | (nodes[0].term ? MIND_AIME_TERMINATE : 0);
+  if (c->profiling && (rc = mind_pair_events_resolve(c, &pair_ms))) return rc;      // (the stream is drained: every exit above synchronised)
   out->pair_ms = pair_ms; out->pair_launches = pair_launches;
   out->n_trees = (int)c->pl_tree_top.size(); out->tree_top = c->pl_tree_top.data(); out->tree_off = c->pl_tree_off.data();
   out->flat_parent = c->pl_flat_parent.data(); out->flat_prob = c->pl_flat_prob.data();

@@ -170,6 +170,12 @@ struct mind_ctx {
   float pair_ms = 0.f;
   double pairs_done = 0.0;
   std::vector<hipEvent_t> ev;
+  // mind_aime_plan with profiling on: the pair-kernel events of its predictor calls are taken from this pool and read once, behind the
+  // plan's last synchronisation (a stream drain per predictor call to read twelve events cost ~30 us per round of the timed plan)
+  bool ev_defer = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_pool_used = 0;
+  std::vector<size_t> ev_pending;      // first pool index of every predictor call not read yet
   int n_cu = 256;
   int debug_layers = 6;
   int last_ntok = 0;
@@ -304,6 +310,7 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
   if (c->ev_tab) (void)hipEventDestroy(c->ev_tab);
   if (c->pl_copy) (void)hipStreamDestroy(c->pl_copy);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->ev_side) (void)hipEventDestroy(c->ev_side);
   if (c->ev_main) (void)hipEventDestroy(c->ev_main);
   if (c->ev_tgt) (void)hipEventDestroy(c->ev_tgt);
@@ -413,6 +420,21 @@ extern "C" int mind_last_ilqr_trace(mind_ctx *c, int tree, int phase, double *ou
 extern "C" int mind_last_ilqr_profile(mind_ctx *c, double *out9) {
   if (!c || !out9) return MIND_EINVAL;
   memcpy(out9, c->il_prof, sizeof(c->il_prof));
+  return MIND_OK;
+}
+
+// deferred pair-kernel events of a plan (ev_defer): summed once the stream has been drained
+static int mind_pair_events_resolve(mind_ctx *c, float *total_ms) {
+  float sum = 0.f;
+  for (size_t base : c->ev_pending)
+    for (int L = 0; L < c->debug_layers; ++L) {
+      float ms = 0.f;
+      HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[base + 2 * L], c->ev_pool[base + 2 * L + 1]));
+      sum += ms;
+    }
+  c->ev_pending.clear();
+  c->ev_pool_used = 0;
+  *total_ms = sum;
   return MIND_OK;
 }
 
@@ -1238,11 +1260,22 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
       c->ev.push_back(e);
     }
   }
+  hipEvent_t *evs = c->ev.data();
+  if (c->profiling && c->ev_defer) {
+    while (c->ev_pool.size() < c->ev_pool_used + 12) {
+      hipEvent_t e;
+      HIPCHK(c, hipEventCreate(&e));
+      c->ev_pool.push_back(e);
+    }
+    evs = c->ev_pool.data() + c->ev_pool_used;
+    c->ev_pending.push_back(c->ev_pool_used);
+    c->ev_pool_used += 12;
+  }
   c->last_ntok = ntok; c->last_edge_pairs = edge_pairs; c->last_slots = slot; c->last_A = A; c->last_B = Bn;
   c->last_scene_n = ts->scene_n; c->last_edge_tiled = tiled; c->last_edge_bf16 = tiled && c->pair_prec == 2;
   for (int L = 0; L < c->debug_layers; ++L) {
     const int um = L < 4 ? 0 : (L == 4 ? 1 : 2);
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2 * L], st));
+    if (c->profiling) HIPCHK(c, hipEventRecord(evs[2 * L], st));
     if (c->pair_prec == 0) {
       if (L == 0)
         hipLaunchKernelGGL(k_pair<0>, dim3(grid), dim3(PAIR_THREADS), lds, st, djobs, njobs, edge, ST, QK, part, c->WAe[L], c->WAp[L],
@@ -1272,7 +1305,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
       else { if (L == 0) LAUNCH_BF(0, 1); else LAUNCH_BF(1, 1); }
 #undef LAUNCH_BF
     }
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2 * L + 1], st));
+    if (c->profiling) HIPCHK(c, hipEventRecord(evs[2 * L + 1], st));
     c->n_pair_launch++;
     c->pairs_done += (L == 5) ? pairs_l5 : pairs_full;
     const int mode = 2 | (L < 5 ? 4 : 8) | qsplit;
@@ -1325,7 +1358,9 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
                                hipMemcpyDeviceToDevice, st));
   }
   HIPCHK(c, hipGetLastError());
-  if (c->profiling) {
+  if (c->profiling && c->ev_defer) {
+    c->pair_ms = 0.f;         // (read by mind_pair_events_resolve behind the plan's last synchronisation)
+  } else if (c->profiling) {
     HIPCHK(c, hipStreamSynchronize(st));
     c->pair_ms = 0.f;
     for (int L = 0; L < c->debug_layers; ++L) {

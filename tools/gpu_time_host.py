@@ -50,6 +50,9 @@ rt.lib.mind_aime_world = _LibTimer(rt.lib.mind_aime_world, "C: mind_aime_world")
 rt.lib.mind_predict_batch = _LibTimer(rt.lib.mind_predict_batch, "C: mind_predict_batch")
 wrap(gen, "_update_obser_device_windows"); wrap(gen, "_branch_aime_native"); wrap(rt, "aime_plan", "rt.aime_plan (C call + marshalling)")
 rt.lib.mind_aime_plan = _LibTimer(rt.lib.mind_aime_plan, "C: mind_aime_plan")
+wrap(opt, "solve_batch_begin", "solve_batch_begin (tables + upload + launch of the contingency solves, returns with the kernel queued)")
+rt.lib.mind_ilqr_contingency_begin_plan = _LibTimer(rt.lib.mind_ilqr_contingency_begin_plan, "C: mind_ilqr_contingency_begin_plan")
+rt.lib.mind_ilqr_finish = _LibTimer(rt.lib.mind_ilqr_finish, "C: mind_ilqr_finish (waits for the kernel)")
 wrap(sim, "step_begin", "sim.step_begin"); wrap(sim, "step_end", "sim.step_end")
 import mind_amd.closed_loop as CLm
 wrap(CLm, "kine_propagate")
