@@ -409,3 +409,46 @@ def test_device_window_bookkeeping_and_lazy_host_windows():
     # not applicable: a parent that is not a re-based scene, or a stale generation -> None (the caller uploads the windows)
     rt._rebase_gen = 99
     assert gen._update_obser_device_windows(curs, rt) is None
+
+
+def test_the_exchange_on_a_shared_context_follows_the_planner_that_plans():
+    """A context (per-thread runtime) outlives the planner that attached a process group to it (mind_set_exchange).  Before its native
+    plan a scenario-tree generator makes the context's exchange its own: a planner without a shard takes a previous planner's group
+    off, a sharded planner puts its group back (bench.py's multi-rank line plans `tree_sharded` and then `tree_replicas` on one
+    context: the replicas must not shard)."""
+    calls = []
+
+    class Lib:
+        def mind_set_exchange(self, ctx, rank, world, fn, user, force):
+            calls.append((rank, world, bool(fn), force))
+            return 0
+
+        def mind_last_error_string(self, ctx):
+            return b""
+
+    class Rt:
+        lib, ctx = Lib(), None
+
+    class Sh:
+        native = True
+
+        def attach(self, rt):
+            calls.append("attach")
+            rt._exchange_owner = self
+
+    rt = Rt()
+    g = ScenarioTreeGenerator.__new__(ScenarioTreeGenerator)
+    g.shard = None
+    g._sync_exchange(rt)                     # nothing attached, nothing wanted: no call
+    assert calls == []
+    g.shard = sh = Sh()
+    g._sync_exchange(rt)
+    assert calls == ["attach"] and rt._exchange_owner is sh
+    g._sync_exchange(rt)                     # already this planner's
+    assert calls == ["attach"]
+    g2 = ScenarioTreeGenerator.__new__(ScenarioTreeGenerator)
+    g2.shard = None
+    g2._sync_exchange(rt)                    # the next planner on the context plans alone: rank 0 of 1, no callback
+    assert calls[-1] == (0, 1, False, 0) and rt._exchange_owner is None
+    g._sync_exchange(rt)
+    assert calls[-1] == "attach"
