@@ -260,42 +260,49 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       const size_t n_cls = ((size_t)cbm * 6 + 3) & ~(size_t)3;
       if ((rc = ensure(c, c->pl_pred, (n_cls + (size_t)cbm * a * 6 * T * 7) * sizeof(float)))) return rc;
     }
-    // ---- the frames of the re-based scenes (ROT, ORIG, TGT_PTS; queued behind k_aime_rebase / the unpacking): needed by the scene tables
-    if (frames_pending) {
-      HIPCHK(c, hipEventSynchronize(c->ev_pl));
-      const float *fr = (const float *)c->pl_pin[3];
-      for (int b = 0; b < B; ++b) {
-        memcpy(batch[b].rot, fr + (size_t)b * 28, 4 * sizeof(float));
-        memcpy(batch[b].orig, fr + (size_t)b * 28 + 4, 2 * sizeof(float));
-        memcpy(batch[b].tgt, fr + (size_t)b * 28 + 6, 22 * sizeof(float));
+    // ---- the frames of the re-based scenes + the scene tables of the block: prepared BEHIND the launch of the round's first predictor
+    //      call (which needs neither): waiting for the frames first put a host round trip between k_aime_rebase and the predictor
+    bool tables_done = false;
+    auto prepare_tables = [&]() -> int {
+      tables_done = true;
+      // ---- the frames of the re-based scenes (ROT, ORIG, TGT_PTS; queued behind k_aime_rebase / the unpacking): needed by the scene tables
+      if (frames_pending) {
+        HIPCHK(c, hipEventSynchronize(c->ev_pl));
+        const float *fr = (const float *)c->pl_pin[3];
+        for (int b = 0; b < B; ++b) {
+          memcpy(batch[b].rot, fr + (size_t)b * 28, 4 * sizeof(float));
+          memcpy(batch[b].orig, fr + (size_t)b * 28 + 4, 2 * sizeof(float));
+          memcpy(batch[b].tgt, fr + (size_t)b * 28 + 6, 22 * sizeof(float));
+        }
+        frames_pending = false;
       }
-      frames_pending = false;
-    }
-    if (Bk > 0) {
-      // the scene tables of the whole block, one upload; agent rows are counted from the start of a scene's chunk
-      char *h = (char *)c->pl_pin[1];
-      AimeScene *hs = (AimeScene *)h;
-      int *as = (int *)(h + bS);
-      float *sp = (float *)(h + bS + bI);
-      for (int b = 0; b < Bk; ++b) {
-        AimeScene &S = hs[b];
-        const PlScene &q = batch[lo + b];
-        const int bc = b % chunk;
-        S.a0 = a * bc; S.a1 = a * (bc + 1); S.last = HZ - 1;     /* seq_len - 1 - history length */ S.cmp = q.cur_t == 0 ? 1 : q.cur_t; S.pad2 = 0.f;
-        S.r00 = q.rot[0]; S.r01 = q.rot[1]; S.r10 = q.rot[2]; S.r11 = q.rot[3];
-        S.ox = q.orig[0]; S.oy = q.orig[1];
-        S.theta_g = atan2f(S.r10, S.r00);
-        for (int i = 0; i < a; ++i) as[(size_t)b * a + i] = bc;
-        sp[b] = q.prob;
+      if (Bk > 0) {
+        // the scene tables of the whole block, one upload; agent rows are counted from the start of a scene's chunk
+        char *h = (char *)c->pl_pin[1];
+        AimeScene *hs = (AimeScene *)h;
+        int *as = (int *)(h + bS);
+        float *sp = (float *)(h + bS + bI);
+        for (int b = 0; b < Bk; ++b) {
+          AimeScene &S = hs[b];
+          const PlScene &q = batch[lo + b];
+          const int bc = b % chunk;
+          S.a0 = a * bc; S.a1 = a * (bc + 1); S.last = HZ - 1;     /* seq_len - 1 - history length */ S.cmp = q.cur_t == 0 ? 1 : q.cur_t; S.pad2 = 0.f;
+          S.r00 = q.rot[0]; S.r01 = q.rot[1]; S.r10 = q.rot[2]; S.r11 = q.rot[3];
+          S.ox = q.orig[0]; S.oy = q.orig[1];
+          S.theta_g = atan2f(S.r10, S.r00);
+          for (int i = 0; i < a; ++i) as[(size_t)b * a + i] = bc;
+          sp[b] = q.prob;
+        }
+        if (c->pl_tab_side) {
+          HIPCHK(c, hipMemcpyAsync(tabb.p, h, tab_bytes, hipMemcpyHostToDevice, c->pl_copy));
+          HIPCHK(c, hipEventRecord(c->ev_tab, c->pl_copy));
+          HIPCHK(c, hipStreamWaitEvent(st, c->ev_tab, 0));
+        } else {
+          HIPCHK(c, hipMemcpyAsync(tabb.p, h, tab_bytes, hipMemcpyHostToDevice, st));
+        }
       }
-      if (c->pl_tab_side) {
-        HIPCHK(c, hipMemcpyAsync(tabb.p, h, tab_bytes, hipMemcpyHostToDevice, c->pl_copy));
-        HIPCHK(c, hipEventRecord(c->ev_tab, c->pl_copy));
-        HIPCHK(c, hipStreamWaitEvent(st, c->ev_tab, 0));
-      } else {
-        HIPCHK(c, hipMemcpyAsync(tabb.p, h, tab_bytes, hipMemcpyHostToDevice, st));
-      }
-    }
+      return MIND_OK;
+    };
     const char *dtab = (const char *)tabb.p;
     for (int c0 = 0; c0 < Bk; c0 += chunk) {
       const int cb = std::min(chunk, Bk - c0), g0 = lo + c0, Ac = cb * a;      // scenes [g0, g0 + cb) of the round
@@ -323,6 +330,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       }
       po.cls = d_cls; po.reg = d_reg; po.vel = d_vel;
       if ((rc = mind_predict_batch(c, &sb, &po))) return rc;
+      if (!tables_done && (rc = prepare_tables())) return rc;
       n_expanded += cb;
       if (c->profiling) pair_launches += c->n_pair_launch;
       if (in->script_cls) {
@@ -342,6 +350,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       hipLaunchKernelGGL(k_aime_branch, dim3(cb * AIME_K), dim3(64), 0, st, t_sc, d_sel + (size_t)c0 * 6, w_c, d_hit + (size_t)c0 * 12);
       HIPCHK(c, hipGetLastError());
     }
+    if (!tables_done && (rc = prepare_tables())) return rc;      // (a rank without scenes in this round still needs the frames)
     // ---- the round's decisions on the host: this rank's block, or (sharded) every rank's through one all-gather
     const float *h_dec;             // [ranks][Bmax x 24 floats]
     if (dist) {
