@@ -57,8 +57,12 @@ WORKLOADS = {
     # the same scene under the scripted 6-ary depth-5 tree with the probability floor lifted (mind_amd.synth.ScriptedDeepTree): rounds of
     # 1 / 6 / 36 / 216 / 1 296 scenes = 1 555 expansions per plan -- what K = 6 modes and max_depth = 5 leave of BASELINE configs[4]'s tree
     "stressdeep": dict(n_agents=128, n_lanes=8, n_segs=32, seed=5),
+    # ... and one level deeper (ScriptedDeeperTree): six rounds, 1 / 6 / 36 / 216 / 1 296 / 7 776 scenes = 9 331 expansions per plan, BASELINE
+    # configs[4]'s depth at the branching K = 6 allows; the last round only runs in chunks (its edge tensor alone is 307 GB in plain bf16)
+    "stressdeeper": dict(n_agents=128, n_lanes=8, n_segs=32, seed=5),
 }
-FULL_TREE = ("cfg4tree", "stress128tree", "stressdeep")
+FULL_TREE = ("cfg4tree", "stress128tree", "stressdeep", "stressdeeper")
+DEEP = {"stressdeep": "deep", "stressdeeper": "deeper"}
 BRANCHING_WEIGHTS, PLAIN_WEIGHTS = "formula_branching:20240121", "formula:20240121"
 
 # ---- algorithmic work of the pair kernel ----------------------------------------------------------
@@ -121,7 +125,7 @@ def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True, ckpt
     ckpt: override of the planner config's ckpt_path (e.g. "formula_branching:20240121", mind_amd/weights.py)."""
     from mind_amd.closed_loop import ClosedLoopSim
     from mind_amd.planners.mind.planner import MINDPlanner
-    from mind_amd.synth import ScriptedBranching, ScriptedDeepTree, ScriptedFullTree, SynthWorld
+    from mind_amd.synth import ScriptedBranching, ScriptedDeepTree, ScriptedDeeperTree, ScriptedFullTree, SynthWorld
     cfg = os.path.join(ROOT, "mind_amd", "planners", "mind", "configs", "synthetic.json")
     if "scene" in wkw:
         from mind_amd.scene_io import ReplayWorld, scene_fixture_path
@@ -138,13 +142,14 @@ def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True, ckpt
     # collapses to a few nodes); the scripted modes are straight-line motions in the agent frame and would leave a
     # curved recorded target lane, so they are kept for the synthetic worlds only
     if scripted and "scene" not in wkw:
-        pl.scen_tree_gen.network = (ScriptedDeepTree if full_tree == "deep" else ScriptedFullTree if full_tree else ScriptedBranching)(pl.network)
-        if full_tree == "deep":
+        pl.scen_tree_gen.network = (ScriptedDeeperTree if full_tree == "deeper" else ScriptedDeepTree if full_tree == "deep" else ScriptedFullTree if full_tree
+                                    else ScriptedBranching)(pl.network)
+        if full_tree in ("deep", "deeper"):
             # five rounds of expansions: the nodes of the fifth (depth 5) must still be examined to END their branches -- ScenTreeCfg.max_depth
             # (configs/planning/demo_1.py:5: 5) is a planning-config value; with it every branch would stop at the cap unfinished
             import copy
             pl.scen_tree_gen.config = copy.copy(pl.scen_tree_gen.config)
-            pl.scen_tree_gen.config.max_depth = 6
+            pl.scen_tree_gen.config.max_depth = 7 if full_tree == "deeper" else 6
     # speculative warm start = a second HIP context per planner: a latency lever for a GPU that one closed loop leaves idle;
     # with many scenes sharing the device the extra contexts cost more than they hide (measured: 8 processes 3150 -> 2010)
     pl.traj_tree_opt.speculative = speculative and pl.traj_tree_opt.speculative      # MIND_SPECULATIVE_WARM_START=0 switches it off
@@ -192,13 +197,13 @@ class Dist:
             self.d.destroy_process_group()
 
 
-def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None, pair_prec=None):
+def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None, pair_prec=None, tuning=None):
     """K timed planning cycles of one closed loop (barrier + synchronize on both sides, max over ranks), with the pair
     kernel's launch durations taken from HIP events on the context stream inside the timed region."""
     wkw = scene_workload(workload, replica)
     if ckpt is None and "scene" in wkw:
         ckpt = BRANCHING_WEIGHTS
-    pl, sim, w = make_closed_loop(wkw, full_tree="deep" if workload == "stressdeep" else workload in FULL_TREE, ckpt=ckpt)
+    pl, sim, w = make_closed_loop(wkw, full_tree=DEEP.get(workload, workload in FULL_TREE), ckpt=ckpt)
     sh = None
     if shard and dist.world > 1:
         sh = pl.enable_sharding()
@@ -206,6 +211,8 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None, pair_pre
     prec_before = rt.pair_precision()
     if pair_prec is not None:
         rt.set_pair_precision(pair_prec)        # every MFMA contraction of the predictor (pair kernel, ActorNet) follows this setting
+    for k, v in (tuning or {}).items():
+        rt.set_tuning(k, v[0])
     if workload in FULL_TREE:
         # thousands of agents per decoder call: the MFMA variant of its actor part pays here (209 vs 277 us at 13.8 k agents);
         # every rank of a sharded run takes the same kernel
@@ -281,6 +288,8 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None, pair_pre
     rt.set_profiling(False)
     if pair_prec is not None:
         rt.set_pair_precision(prec_before)
+    for k, v in (tuning or {}).items():
+        rt.set_tuning(k, v[1])
     dt = dist.reduce(dt, "max")
     ctr = {k: v - ctr0.get(k, 0) for k, v in pl.traj_tree_opt.counters.items()}
     npl = max(pl.timing_sum["plans"] - tsum0["plans"], 1)
@@ -821,6 +830,15 @@ def main():
                                           "plan), plain bf16 (edge tensor in bf16)", plans_timed=2)
             except Exception as e:       # noqa: BLE001
                 out["stress_deep"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            try:
+                # one level deeper (ScriptedDeeperTree): six rounds, the last one 7 776 scenes = 307 GB of bf16 edges, in chunks under a
+                # 64 GB budget (about 200 GB of the 288 GB in use); one plan timed behind one warm-up plan (arena growth)
+                xm = measure(dist, "stressdeeper", 1, 1, False, pair_prec="bf16", tuning={"plan_chunk_mb": (64 * 1024, 96 * 1024)})
+                out["stress_deeper"] = dict(summarize(xm, "bf16"), workload="stressdeeper: the same scene under the scripted 6-ary depth-6 tree (BASELINE configs[4]'s "
+                                            "depth at the branching K = 6 modes allow): rounds of 1 / 6 / 36 / 216 / 1 296 / 7 776 scenes = 9 331 expansions, 46 656 "
+                                            "leaves per plan, the last round in chunks under a 64 GB edge budget, plain bf16", plans_timed=1)
+            except Exception as e:       # noqa: BLE001
+                out["stress_deeper"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if rank == 0:
         print(json.dumps(out))
     dist.close()

@@ -239,7 +239,7 @@ class ScenarioTreeGenerator:
     # ------------------------------------------------------------------------------------------
     def _native_ok(self):
         net = self.network
-        if type(net).__name__ in ("ScriptedBranching", "ScriptedFullTree", "ScriptedDeepTree"):      # scripted modes on top of the real forward (mind_amd/synth.py)
+        if type(net).__name__ in ("ScriptedBranching", "ScriptedFullTree", "ScriptedDeepTree", "ScriptedDeeperTree"):      # scripted modes on top of the real forward (mind_amd/synth.py)
             net = net.net
         return (self.native_aime and self.device_glue and self.device_select and type(net).__name__ == "ScenePredNet"
                 and getattr(net, "rt", None) is not None and getattr(net, "_loaded", False) and hasattr(net.rt, "aime_plan")
@@ -264,7 +264,7 @@ class ScenarioTreeGenerator:
         if self.obs_len != 50 or not (2 <= self.pred_len <= 60):
             return None
         self._sync_exchange(self.network.rt)
-        scripted = type(self.network).__name__ in ("ScriptedBranching", "ScriptedFullTree", "ScriptedDeepTree")
+        scripted = type(self.network).__name__ in ("ScriptedBranching", "ScriptedFullTree", "ScriptedDeepTree", "ScriptedDeeperTree")
         floor = getattr(self.network, "prob_floor", None) if scripted else None
         modes = (lambda n_agents: self.network._modes(n_agents, self.network.rt.device)) if scripted else (lambda n_agents: None)
         if self.device_root:

@@ -117,7 +117,7 @@ def test_bench_prints_one_contract_json_line():
     assert r["traffic"] is None or (r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"] and r["traffic_detail"]["launches_counted"] > 0)
     k = d["k_ilqr"]
     assert 0 < k["share_of_step"] < 1 and k["cycles_per_node_step"]["riccati"] > 100 and abs(sum(k["phase_share"].values()) - 1) < 1e-6
-    assert d["exact_fp32"]["value"] > 83.0 and d["stress"]["expansions_per_plan"] == 259 and d["stress_bf16"]["expansions_per_plan"] == 259 and d["stress_deep"]["expansions_per_plan"] == 1555
+    assert d["exact_fp32"]["value"] > 83.0 and d["stress"]["expansions_per_plan"] == 259 and d["stress_bf16"]["expansions_per_plan"] == 259 and d["stress_deep"]["expansions_per_plan"] == 1555 and d["stress_deeper"]["expansions_per_plan"] == 9331
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["value_1_thread"] > 0
     # extras: the synthetic branching scene, the full cfg4 tree on this GPU, the other recorded scenes
     assert d["config"]["weights"] == "formula_branching:20240121" and d["config"]["expansions_per_plan"] >= 2      # a real AIME tree

@@ -122,3 +122,44 @@ def test_deep_tree_stress_workload_one_plan():
     assert all(s["iterations"] >= 1 and np.isfinite(s["J"]) for s in pl.traj_tree_opt.debug["full"])
     print(f"stressdeep: 1 555 expansions, {sum(len(t.nodes) for t in trees)} scenario-tree nodes, cost trees of {[len(t.nodes) for t in traj[:1]]} .. trajectory nodes; "
           f"aime {pl.timing['aime_s'] * 1e3:.0f} ms, tree-iLQR {pl.timing['ilqr_s'] * 1e3:.0f} ms")
+
+
+def test_deeper_tree_stress_workload_one_plan():
+    """`stressdeeper`: the same scene under the scripted 6-ary depth-6 tree -- six AIME rounds of 1 / 6 / 36 / 216 / 1 296 / 7 776 scenes = 9 331
+    expansions, 46 656 leaves: the depth BASELINE configs[4] names at the branching K = 6 modes allow.  The last round's edge tensor alone
+    (7 776 scenes x 39 MB in plain bf16) exceeds the 288 GB of the device: it runs in chunks under a 64 GB budget with about 200 GB in use.
+    Size-independent properties of the one plan: round sizes, node counts, probabilities of siblings summing to their parent's, finite
+    trajectories / covariances / costs."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from bench import WORKLOADS, make_closed_loop
+    pl, sim, w = make_closed_loop(dict(WORKLOADS["stressdeeper"]), full_tree="deeper", speculative=False)
+    rt = pl.network.rt
+    before = rt.pair_precision()
+    try:
+        rt.set_pair_precision("bf16")
+        rt.set_tuning("plan_chunk_mb", 64 * 1024)
+        e0 = pl.scen_tree_gen.n_expanded
+        sim.run_plans(1)
+    finally:
+        rt.set_pair_precision(before)
+        rt.set_tuning("plan_chunk_mb", 96 * 1024)
+    info = rt.last_aime_info
+    assert pl.scen_tree_gen.n_expanded - e0 == 9331 and info["round_scenes"] == [1, 6, 36, 216, 1296, 7776]
+    trees = pl.scen_tree_gen.get_scenario_tree()
+    assert len(trees) == 6 and sum(len(t.nodes) for t in trees) == 6 + 36 + 216 + 1296 + 7776 + 46656
+    t = trees[0]
+    for k, n in t.nodes.items():
+        ch = [t.nodes[c] for c in n.children_keys]
+        if ch:
+            assert abs(sum(float(np.ravel(c.data[0])[0]) for c in ch) - float(np.ravel(n.data[0])[0])) < 1e-5
+    leaves = [n for n in t.nodes.values() if not n.children_keys][:200]
+    for n in leaves:
+        pos, cov = np.asarray(n.data[1]), np.asarray(n.data[2])
+        assert pos.shape[0] == 128 and np.isfinite(pos).all() and np.isfinite(cov).all() and (cov > 0).all()
+    scen, traj = sim.last_result
+    xs = np.array([n_.data[0] for k, n_ in traj[0].nodes.items() if k != -1])
+    assert np.isfinite(xs).all() and len(pl.timing["tree_costs"]) == 6 and np.isfinite(pl.timing["tree_costs"]).all()
+    free, tot = torch.cuda.mem_get_info()
+    print(f"stressdeeper: 9 331 expansions, {sum(len(t_.nodes) for t_ in trees)} scenario-tree nodes, cost trees of {len(traj[0].nodes)} trajectory nodes; "
+          f"aime {pl.timing['aime_s']:.2f} s (first plan: arenas grow), {(tot - free) / 2 ** 30:.0f} GiB of device memory in use")
