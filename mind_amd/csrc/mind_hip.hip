@@ -277,6 +277,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   (void)hipFuncSetAttribute((const void *)k_token_mfma<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_token_mfma_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_token_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_token_mfma_lds_bytes());
   if (const char *we = getenv("MIND_ILQR_CHUNK")) c->ilqr_chunk = atoi(we) < 0 ? 0 : atoi(we);
+  if (const char *ce = getenv("MIND_PLAN_CHUNK_MB")) { const long v = atol(ce); if (v > 0) c->plan_chunk_mb = v; }
   if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_tgt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());

@@ -65,6 +65,20 @@ def test_three_ranks_and_the_full_tree_sharded_natively(tmp_path):
             assert np.array_equal(pa["pos0"], pb["pos0"]) and np.array_equal(pa["xs"], pb["xs"]) and np.array_equal(pa["ctrl"], pb["ctrl"])
 
 
+def test_sharded_rounds_in_chunks_plan_what_one_process_plans_whole(tmp_path):
+    """Sharding and chunking together: two ranks, the full cfg4 tree, every rank's block of a round through the predictor in chunks under
+    a 2 GB edge budget (the 108-scene blocks of the last round in three chunks of 37) -- the plan of the single process that ran every
+    round whole, bit for bit."""
+    single = _run(1, tmp_path, n_plans=1, port=29591, extra_env={"MIND_TEST_WORKLOAD": "cfg4tree"})[0]
+    ranks = _run(2, tmp_path, n_plans=1, port=29592, extra_env={"MIND_TEST_WORKLOAD": "cfg4tree", "MIND_PLAN_CHUNK_MB": "2048"})
+    assert single["expanded"] == 259 and [r["expanded"] for r in ranks] == [130, 129]
+    for b in ranks:
+        assert b["native_plans"] == 1
+        for pa, pb in zip(single["res"], b["res"]):
+            assert pa["keys"] == pb["keys"] and pa["best"] == pb["best"] and pa["n_trees"] == pb["n_trees"] == 6
+            assert np.array_equal(pa["pos0"], pb["pos0"]) and np.array_equal(pa["xs"], pb["xs"]) and np.array_equal(pa["ctrl"], pb["ctrl"])
+
+
 def test_round_by_round_host_path_still_shards(tmp_path):
     """MIND_NATIVE_SHARD=0: the sharded rounds of rounds 1-3 (round-by-round host path over parallel.Shard.all_gather_rows, kept for
     wrapped networks) against the native one-process plan fed by the same host featuriser."""
