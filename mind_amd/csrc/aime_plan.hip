@@ -604,8 +604,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   }
   const size_t Mtot = (size_t)c->pl_tree_off.back();
   c->pl_plan_agents = a;
-  c->pl_flat_mean.resize(Mtot * a * 2); c->pl_flat_cov.resize(Mtot * a);
-  c->pl_rows_host.resize((size_t)n_rows);
+  c->pl_rows_p = c->pl_fmean_p = c->pl_fcov_p = nullptr;
   // one upload (both job tables), the two gather kernels, one read-back (rows | flat means | flat covariances)
   const size_t n_flat = Mtot * a * 3;
   if (n_rows + (int64_t)n_flat > 0) {
@@ -647,22 +646,20 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     float *hp = (float *)c->pl_pin[2];
     HIPCHK(c, hipMemcpyAsync(hp, d_rows, n_res * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    memcpy(c->pl_rows_host.data(), hp, (size_t)n_rows * sizeof(float));
-    if (n_flat) {
-      memcpy(c->pl_flat_mean.data(), hp + n_rows, Mtot * a * 2 * sizeof(float));
-      memcpy(c->pl_flat_cov.data(), hp + n_rows + Mtot * a * 2, Mtot * a * sizeof(float));
-    }
+    // the plan's rows and flattened cost trees are handed out where the read-back put them (page-locked slot 2: nothing touches it before
+    // the context's next plan, the lifetime mind_aime_plan_out promises); the deep stress trees return 0.9 GB here
+    c->pl_rows_p = hp; c->pl_fmean_p = hp + n_rows; c->pl_fcov_p = hp + n_rows + Mtot * a * 2;
   } else {
     HIPCHK(c, hipStreamSynchronize(st));
   }
   out->nodes = c->pl_nodes.data(); out->n_nodes = N;
-  out->rows = c->pl_rows_host.data(); out->n_row_floats = n_rows;
+  out->rows = c->pl_rows_p; out->n_row_floats = n_rows;
   out->n_expanded = n_expanded; out->n_rounds = round;
   out->root_flags = (nodes[0].branch ? MIND_AIME_BRANCH : 0) | (nodes[0].end ? MIND_AIME_END : 0) | (nodes[0].term ? MIND_AIME_TERMINATE : 0);
   if (c->profiling && (rc = mind_pair_events_resolve(c, &pair_ms))) return rc;      // (the stream is drained: every exit above synchronised)
   out->pair_ms = pair_ms; out->pair_launches = pair_launches;
   out->n_trees = (int)c->pl_tree_top.size(); out->tree_top = c->pl_tree_top.data(); out->tree_off = c->pl_tree_off.data();
   out->flat_parent = c->pl_flat_parent.data(); out->flat_prob = c->pl_flat_prob.data();
-  out->flat_mean = c->pl_flat_mean.data(); out->flat_cov = c->pl_flat_cov.data();
+  out->flat_mean = c->pl_fmean_p; out->flat_cov = c->pl_fcov_p;
   return MIND_OK;
 }

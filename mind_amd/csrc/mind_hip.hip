@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <functional>
 #include <vector>
 
@@ -145,7 +146,8 @@ struct mind_ctx {
   hipStream_t pl_copy = nullptr;
   bool pl_tab_side = false;
   std::vector<mind_aime_node> pl_nodes;
-  std::vector<float> pl_rows_host, pl_flat_prob, pl_flat_mean, pl_flat_cov;
+  std::vector<float> pl_flat_prob;
+  const float *pl_rows_p = nullptr, *pl_fmean_p = nullptr, *pl_fcov_p = nullptr;      // into page-locked slot 2, valid until the next plan
   std::vector<int32_t> pl_tree_top, pl_tree_off, pl_flat_parent;
   int pl_plan_agents = 0;       // agents per scene of the plan those tables belong to
   DevBuf pl_flat;
@@ -1883,7 +1885,7 @@ extern "C" int mind_ilqr_contingency_begin_plan(mind_ctx *c, const mind_ilqr_cfg
     memset(&T, 0, sizeof(T));
     T.n_nodes = c->pl_tree_off[t + 1] - c->pl_tree_off[t];
     T.parent = c->pl_flat_parent.data() + lo; T.prob = c->pl_flat_prob.data() + lo;
-    T.n_agents = a; T.agent_mean = c->pl_flat_mean.data() + lo * a * 2; T.agent_cov = c->pl_flat_cov.data() + lo * a;
+    T.n_agents = a; T.agent_mean = c->pl_fmean_p + lo * a * 2; T.agent_cov = c->pl_fcov_p + lo * a;
   }
   c->il_begin_only = true;
   const int rc = ilqr_impl(c, cfg_warm, nullptr, trees.data(), nt, x0, target_lane, n_lane_pts, target_vel, 0, nullptr, xs, us, stats_warm, nullptr,
@@ -2164,8 +2166,19 @@ extern "C" int mind_eval_traj_trees(const double *states, const double *ctrls, c
   long N = 0;
   for (int t = 0; t < n_trees; ++t) { if (counts[t] <= 0) return MIND_EINVAL; N += counts[t]; }
   std::vector<double> per(N);
-  if (lane_is_f32) eval_nodes<float>(states, ctrls, N, (const float *)lane, n_lane_pts, target_vel, per.data());
-  else eval_nodes<double>(states, ctrls, N, (const double *)lane, n_lane_pts, target_vel, per.data());
+  // the nodes are priced independently (a node = one distance-to-polyline scan): big plans -- the deep stress trees hold 177 k trajectory
+  // nodes -- are spread over a few host threads; the per-tree sums below keep numpy's order either way
+  auto run = [&](long lo, long hi) {
+    if (lane_is_f32) eval_nodes<float>(states + 6 * lo, ctrls + 2 * lo, hi - lo, (const float *)lane, n_lane_pts, target_vel, per.data() + lo);
+    else eval_nodes<double>(states + 6 * lo, ctrls + 2 * lo, hi - lo, (const double *)lane, n_lane_pts, target_vel, per.data() + lo);
+  };
+  const long nth = std::min<long>(std::min<long>(8, (long)std::max(1u, std::thread::hardware_concurrency())), N / 8192);
+  if (nth <= 1) run(0, N);
+  else {
+    std::vector<std::thread> th;
+    for (long k = 0; k < nth; ++k) th.emplace_back(run, N * k / nth, N * (k + 1) / nth);
+    for (std::thread &t : th) t.join();
+  }
   long o = 0;
   for (int t = 0; t < n_trees; ++t) {
     const long n = counts[t];

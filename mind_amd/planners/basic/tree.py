@@ -106,3 +106,48 @@ class Tree:
 
     def print(self):
         self.process_up_down(print)
+
+
+class LazyTree(Tree):
+    """A Tree whose nodes are built on first access.  The native planner returns trees of tens of thousands of nodes whose hot-path
+    consumers (the contingency solver, the candidate evaluation) read the flattened arrays that come with them and never the Python
+    objects; everything that does look (``nodes``, ``leaves``, ``get_node`` ...: the visualiser, tests, the round-by-round code) sees an
+    ordinary Tree.  ``builder(tree)`` fills the tree through ``add_node``; ``root`` may be known before."""
+
+    def __init__(self, builder, root=None):
+        self._builder = builder
+        self._nodes, self._lv = {}, {}
+        self.root = root
+
+    def _materialise(self):
+        b, self._builder = self._builder, None
+        if b is not None:
+            self.root = None          # (add_node sets it again with the first node)
+            b(self)
+
+    @property
+    def nodes(self):
+        self._materialise()
+        return self._nodes
+
+    @nodes.setter
+    def nodes(self, v):
+        self._nodes = v
+
+    @property
+    def _leaves(self):
+        self._materialise()
+        return self._lv
+
+    @_leaves.setter
+    def _leaves(self, v):
+        self._lv = v
+
+    def get_root_key(self):
+        if self.root is None:
+            self._materialise()
+        return super().get_root_key()
+
+    def get_root(self):
+        self._materialise()
+        return super().get_root()

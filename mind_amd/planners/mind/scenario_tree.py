@@ -17,7 +17,7 @@ import os
 import numpy as np
 import torch
 
-from ..basic.tree import Node, Tree
+from ..basic.tree import LazyTree, Node, Tree
 from . import utils as U
 
 F32 = np.float32
@@ -221,6 +221,7 @@ class ScenarioTreeGenerator:
     def reset(self):
         self.branch_depth = 0
         self.tree = Tree()
+        self.last_trees = None
         self.lane_feat_cache = None
         self._plan_round = 0
         self._root_todo = None
@@ -297,30 +298,52 @@ class ScenarioTreeGenerator:
         if on_flats is not None:
             on_flats([flat for _, flat in info["flats"]])
         rf = info["root_flags"]
-        self.tree.add_node(Node("root", None, ScenarioData(None, root, branch_flag=bool(rf & 1), end_flag=bool(rf & 2), terminate_flag=bool(rf & 4))))
         a = info["a"]
-        keys = []
-        types, tids, cats = root["TRAJS_TYPE"], root["TRAJS_TID"], root["TRAJS_CAT"]
-        # the node table column by column (one conversion per field instead of one numpy scalar per field and node)
-        col = {f: nodes[f].tolist() for f in ("round", "scene", "mode", "parent", "dur", "row_off", "flags", "cur_t", "end_t")}
-        probs, tgt = nodes["prob"], nodes["tgt_pts"].reshape(-1, 11, 2)
-        for i in range(len(nodes)):
-            key = "{}_{}_{}".format(col["round"][i], col["scene"][i], col["mode"][i])
-            pkey = "root" if col["parent"][i] < 0 else keys[col["parent"][i]]
-            dur, off, fl = col["dur"][i], col["row_off"][i], col["flags"][i]
-            packed = rows[off:off + a * dur * 3].reshape(a, dur, 3) if off >= 0 else None
-            d = NativeScene({"SCEN_PROB": probs[i], "CUR_T": col["cur_t"][i], "END_T": col["end_t"][i], "PARENT_ID": pkey, "SCEN_ID": key,
-                             "TRAJS_TYPE": types, "TRAJS_TID": tids, "TRAJS_CAT": cats, "TGT_PTS": tgt[i]}, packed, self.obs_len)
-            self.tree.add_node(Node(key, pkey, ScenarioData(d, None, branch_flag=bool(fl & 1), end_flag=bool(fl & 2), terminate_flag=bool(fl & 4))))
-            keys.append(key)
+        col = {f: nodes[f] for f in ("round", "scene", "mode")}
+
+        def node_key(i):
+            return "{}_{}_{}".format(int(col["round"][i]), int(col["scene"][i]), int(col["mode"][i]))
+
+        def build_aime_tree(tree):
+            """the AIME tree as Python objects: built when somebody looks (tests, the visualiser, get_scenario_tree's reference walk)"""
+            tree.add_node(Node("root", None, ScenarioData(None, root, branch_flag=bool(rf & 1), end_flag=bool(rf & 2), terminate_flag=bool(rf & 4))))
+            keys = []
+            types, tids, cats = root["TRAJS_TYPE"], root["TRAJS_TID"], root["TRAJS_CAT"]
+            # the node table column by column (one conversion per field instead of one numpy scalar per field and node)
+            cl = {f: nodes[f].tolist() for f in ("round", "scene", "mode", "parent", "dur", "row_off", "flags", "cur_t", "end_t")}
+            probs, tgt = nodes["prob"], nodes["tgt_pts"].reshape(-1, 11, 2)
+            for i in range(len(nodes)):
+                key = "{}_{}_{}".format(cl["round"][i], cl["scene"][i], cl["mode"][i])
+                pkey = "root" if cl["parent"][i] < 0 else keys[cl["parent"][i]]
+                dur, off, fl = cl["dur"][i], cl["row_off"][i], cl["flags"][i]
+                packed = rows[off:off + a * dur * 3].reshape(a, dur, 3) if off >= 0 else None
+                d = NativeScene({"SCEN_PROB": probs[i], "CUR_T": cl["cur_t"][i], "END_T": cl["end_t"][i], "PARENT_ID": pkey, "SCEN_ID": key,
+                                 "TRAJS_TYPE": types, "TRAJS_TID": tids, "TRAJS_CAT": cats, "TGT_PTS": tgt[i]}, packed, self.obs_len)
+                tree.add_node(Node(key, pkey, ScenarioData(d, None, branch_flag=bool(fl & 1), end_flag=bool(fl & 2), terminate_flag=bool(fl & 4))))
+                keys.append(key)
+
+        self.tree = LazyTree(build_aime_tree, root="root")
         self.n_expanded += info["n_expanded"]
         self.branch_depth = info["n_rounds"]
         self.n_native_plans += 1
-        trees = self.get_scenario_tree()
-        # the library flattened the same trees already (TrajectoryTreeOptimizer.solve_batch takes `_flat` instead of walking the nodes)
-        by_top = {keys[top]: flat for top, flat in info["flats"]}
-        for t in trees:
-            t._flat = by_top.get(t.get_root_key())
+        # The scenario trees handed to the contingency planner: the library flattened them already (TrajectoryTreeOptimizer.solve_batch
+        # takes `_flat` instead of walking the nodes), in get_scenario_tree's order; their Python nodes -- tens of thousands on the deep
+        # stress trees, a third of such a plan's wall time -- are built by the reference walk below only when somebody reads them.
+        shared = {}
+
+        def build_scenario_tree(idx):
+            def build(tree):
+                if "full" not in shared:
+                    shared["full"] = self._scenario_trees_from_tree()
+                src = shared["full"][idx]
+                tree._nodes, tree._lv, tree.root = src.nodes, src._leaves, src.root
+            return build
+
+        trees = []
+        for idx, (top, flat) in enumerate(info["flats"]):
+            t = LazyTree(build_scenario_tree(idx), root=node_key(top))
+            t._flat = flat
+            trees.append(t)
         self.last_trees = trees
         return trees
 
@@ -1081,6 +1104,11 @@ class ScenarioTreeGenerator:
 
     # ------------------------------------------------------------------------------------------
     def get_scenario_tree(self):
+        if getattr(self, "last_trees", None) is not None:      # the trees of the native plan in flight (reset() drops them)
+            return self.last_trees
+        return self._scenario_trees_from_tree()
+
+    def _scenario_trees_from_tree(self):
         root = self.tree.get_root()
         for node in self.get_end_set():              # label every node on a finished branch
             while node.parent_key is not None:

@@ -452,3 +452,33 @@ def test_the_exchange_on_a_shared_context_follows_the_planner_that_plans():
     assert calls[-1] == (0, 1, False, 0) and rt._exchange_owner is None
     g._sync_exchange(rt)
     assert calls[-1] == "attach"
+
+
+def test_lazy_tree_is_a_tree_once_somebody_looks():
+    """LazyTree (planners/basic/tree.py): the native planner's trees are built on first access; every Tree method then sees the same
+    container the eager construction gives, the builder runs once, and the root key is available without building."""
+    from mind_amd.planners.basic.tree import LazyTree
+    built = []
+
+    def fill(t):
+        built.append(1)
+        t.add_node(Node("r", None, 0))
+        t.add_node(Node("a", "r", 1))
+        t.add_node(Node("b", "r", 2))
+        t.add_node(Node("c", "a", 3))
+
+    eager = Tree()
+    fill(eager)
+    built.clear()
+    lz = LazyTree(fill, root="r")
+    assert lz.get_root_key() == "r" and not built                    # known without building
+    assert lz.size() == 4 and built == [1]
+    assert list(lz.nodes) == list(eager.nodes) and lz.leaves == eager.leaves == ["b", "c"]
+    assert [n.key for n in lz.retrieve_nodes_to_root("c")] == ["c", "a", "r"] and lz.get_root().key == "r"
+    assert lz.get_node("a").children_keys == ["c"] and lz.get_node("c").depth == 2
+    lz.add_node(Node("d", "b", 4))
+    assert lz.leaves == ["c", "d"] and built == [1]
+    with pytest.raises(KeyError):
+        lz.get_node("zz")
+    lz2 = LazyTree(fill)                                               # root unknown until built
+    assert lz2.get_root_key() == "r" and lz2.get_leaf_keys() == ["b", "c"]

@@ -37,6 +37,36 @@ def test_native_tree_evaluation_is_bitwise_the_numpy_one(dt):
         assert rc == 0 and np.array_equal(out, ref), trial
 
 
+def test_native_tree_evaluation_over_host_threads_is_bitwise_the_numpy_one():
+    """Plans of tens of thousands of trajectory nodes (the deep stress trees) are priced on several host threads: nodes are independent,
+    the per-tree sums keep numpy's order -- the same bits as the one-thread form and as numpy."""
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    counts = np.array([30000, 1, 25000, 17000], np.int32)
+    N = int(counts.sum())
+    st, ct = rng.standard_normal((N, 6)) * 20, rng.standard_normal((N, 2))
+    P = 90
+    lane = np.cumsum(rng.uniform(0.5, 2, (P, 2)), axis=0).astype(np.float32)
+    tv = 4.0
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    sx, sy = lane[:-1, 0][None], lane[:-1, 1][None]
+    dx, dy = lane[1:, 0][None] - sx, lane[1:, 1][None] - sy
+    l2 = dx ** 2 + dy ** 2
+    per = np.empty(N)
+    for lo in range(0, N, 8000):      # (the [N, P] intermediates in pieces)
+        px, py = st[lo:lo + 8000, 0][:, None], st[lo:lo + 8000, 1][:, None]
+        t = np.clip(((px - sx) * dx + (py - sy) * dy) / l2, 0, 1)
+        dist = np.sqrt((px - (sx + t * dx)) ** 2 + (py - (sy + t * dy)) ** 2).min(axis=1)
+        c = ct[lo:lo + 8000]
+        per[lo:lo + 8000] = (0.1 * c[:, 0] ** 2 + 5.0 * c[:, 1] ** 2) + 0.01 * (tv - st[lo:lo + 8000, 2]) ** 2 + 0.01 * dist
+    ref = np.add.reduceat(per, starts) / counts
+    out = np.zeros(len(counts))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rc = lib.mind_eval_traj_trees(dp(np.ascontiguousarray(st)), dp(np.ascontiguousarray(ct)), counts.ctypes.data_as(C.POINTER(C.c_int32)), len(counts),
+                                  C.c_void_p(lane.ctypes.data), 1, P, C.c_double(tv), dp(out))
+    assert rc == 0 and np.array_equal(out, ref)
+
+
 def test_track_arrays_from_the_library_equal_the_numpy_form():
     """mind_fill_tracks (the array part of get_agent_trajectories, utils.py:245-342, as a host routine of the library) against the numpy
     form it replaces, on the recorded scenes' observation histories: tracks that appeared late (left-padded), tracks with unobserved

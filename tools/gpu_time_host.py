@@ -3,7 +3,7 @@ import os, sys, time, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from bench import FULL_TREE, WORKLOADS, make_closed_loop
+from bench import DEEP, FULL_TREE, WORKLOADS, make_closed_loop
 
 acc = collections.OrderedDict()
 def wrap(obj, name, label=None, sync=False):
@@ -20,9 +20,9 @@ def wrap(obj, name, label=None, sync=False):
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "demo1"
 ckpt = sys.argv[3] if len(sys.argv) > 3 else None
-pl, sim, w = make_closed_loop(dict(WORKLOADS[wl]), full_tree=wl in FULL_TREE, ckpt=ckpt, speculative=os.environ.get("SPEC", "1") == "1")
+pl, sim, w = make_closed_loop(dict(WORKLOADS[wl]), full_tree=DEEP.get(wl, wl in FULL_TREE), ckpt=ckpt, speculative=os.environ.get("SPEC", "1") == "1")
 gen, net, rt, opt = pl.scen_tree_gen, pl.scen_tree_gen.network, pl.network.rt, pl.traj_tree_opt
-sim.run_plans(3)
+sim.run_plans(int(os.environ.get("WARM", "3")))
 wrap(pl, "plan"); wrap(gen, "branch_aime"); wrap(gen, "process_data"); wrap(gen, "collate"); wrap(net, "pre_process")
 wrap(rt, "predict", "rt.predict(launch)"); wrap(rt, "aime_world", "rt.aime_world(sync+launch)"); wrap(gen, "prune_select"); wrap(gen, "assemble_children"); wrap(gen, "predict_inputs"); wrap(rt, "aime_rebase"); wrap(rt, "ilqr_solve"); wrap(opt, "speculate_warm"); wrap(pl, "resample_target_lane")
 wrap(gen, "create_nodes"); wrap(gen, "decide_branch"); wrap(gen, "update_obser_batch"); wrap(gen, "get_scenario_tree")
