@@ -853,7 +853,7 @@ def test_tree_ilqr_follows_the_reference_iteration_by_iteration(scene, variant):
     # this solver's own noise runs explain (the golden holds two perturbed reference runs per fit; observed: <= 2.3 % of a scene's fits)
     n_ref_split = int(sum(1 for (r_, sp_) in fits.values() if sp_ < len(r_)))
     # own-noise fits: which fits these are depends on the last bits of the predictor's output and of sin / cos / tan (three builds: 13, 18
-    # and 18 of 2 178 over the eight (scene, weights) runs, profiles/r04j_*, r04w_*, r04ab_*; the worst run has 10 of 432 = 2.3 %).  Since
+    # and 18 of 2 178 over the eight (scene, weights) runs, profiles/r04j_*, r04w_*, r04aj_*; the worst run has 10 of 432 = 2.3 %).  Since
     # kernel and oracle share their trigonometric routine the C oracle gives the device's trace on every one of them: the cost trees' own
     # sensitivity to rounding noise in their inputs (with the device library's functions in the kernel and glibc's in the oracle, 2 of 18
     # were fits only the oracle followed)
