@@ -619,9 +619,10 @@ def test_recorded_demo_scenes_whole_run_teacher_forced(scene):
         assert moved > tol, (pi, d_ego, d_ctrl, moved)       # a well-conditioned cycle that disagrees is a real failure
         ill.append(pi)
     assert worst_agents < tol, worst_agents
-    # floor = the count observed on the MI355X minus one (profiles/r03n_whole_runs.txt: 60 / 50 / 58 / 56 of 60 = 224 of 240 with the root
-    # scene built on the device; 60 / 50 / 59 / 58 with the host featuriser: the chaotic cycles move with float32 rounding of the inputs)
-    assert agree >= {"demo_1": 59, "demo_2": 49, "demo_3": 57, "demo_4": 55}[scene], (agree, ill)
+    # floor = the count observed on the MI355X minus one (profiles/r04aj_pytest_gpu_parity_lines.txt: 60 / 49 / 58 / 56 of 60 = 223 of 240;
+    # round 3: 60 / 50 / 58 / 56 with the root scene built on the device, 60 / 50 / 59 / 58 with the host featuriser: the chaotic cycles
+    # move with the last bits of their inputs -- every cycle that disagrees is shown ill-conditioned above)
+    assert agree >= {"demo_1": 59, "demo_2": 48, "demo_3": 57, "demo_4": 55}[scene], (agree, ill)
     # these scenes grow one chain-shaped tree every cycle: from the second cycle on the warm-start fit is the one that ran
     # beside the predictor (speculate_warm) -- the comparisons above therefore cover that path
     assert opt.counters["warm_hits"] >= n - 2, opt.counters
