@@ -130,6 +130,11 @@ int mind_debug_pack_bfrag(const float *w, int row_stride, uint32_t *out);
  * (ci_pad = ci rounded up to a power of two >= 16).  Returns the number of dwords written (<= cap) or a negative error. */
 int mind_debug_pack_conv_frag(const float *w, int co, int ci, int ksz, uint32_t *out, size_t cap);
 
+/* Debug tap (tests): the tree-iLQR kernel's sin / cos / tan (mind_amd/csrc/mind_trig.h, the routine oracle/ilqr_ref.c shares) of n host
+ * doubles, evaluated on the device one wave of 64 arguments at a time -- out[4 n] = sin, cos, tan, the cosine that comes with the
+ * tangent.  The oracle's oracle_sincos / oracle_tan_cos must give the same bits (tests/test_gpu_ilqr.py). */
+int mind_debug_trig(mind_ctx *ctx, const double *x, int n, double *out);
+
 /* Debug taps used by the parity tests only: run just the first n (0..6) fusion layers on the next
  * mind_predict_batch calls, and read internal device buffers ("x", "ST", "QK", "edge", "part",
  * "actor_feat", "tokpos") back to the host.  mind_debug_read returns the number of floats copied (or

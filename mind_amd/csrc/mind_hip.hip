@@ -2189,6 +2189,31 @@ extern "C" int mind_eval_traj_trees(const double *states, const double *ctrls, c
 }
 
 // ---- debug taps (tests only): run only the first n fusion layers; read back internal buffers
+// the kernel-side sin / cos / tan on an array (tests: bitwise equality with the oracle's build of the same header)
+__global__ void k_debug_trig(const double *__restrict__ x, int n, double *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double v = i < n ? x[i] : 0.0;          // (the wave-uniform small-argument path needs every lane of the wave in the call)
+  double s, c, t, c2;
+  mind_sincos(v, &s, &c);
+  mind_tan_cos(v, &t, &c2);
+  if (i < n) { out[4 * i] = s; out[4 * i + 1] = c; out[4 * i + 2] = t; out[4 * i + 3] = c2; }
+}
+extern "C" int mind_debug_trig(mind_ctx *c, const double *x, int n, double *out) {
+  if (!c || !x || !out || n <= 0) return MIND_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  double *d = nullptr;
+  HIPCHK(c, hipMalloc((void **)&d, (size_t)n * 5 * sizeof(double)));
+  hipError_t e = hipMemcpy(d, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_debug_trig, dim3((n + 63) / 64), dim3(64), 0, c->stream, d, n, d + n);
+    e = hipStreamSynchronize(c->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d + n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(c, MIND_EHIP, "mind_debug_trig: %s", hipGetErrorString(e));
+  return MIND_OK;
+}
+
 extern "C" int mind_debug_set_layers(mind_ctx *c, int n) {
   if (!c || n < 0 || n > 6) return MIND_EINVAL;
   c->debug_layers = n;

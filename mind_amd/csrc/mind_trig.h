@@ -67,7 +67,7 @@ MT_FN void mt_kernel(double x, double *sh, double *sl, double *ch, double *cl, i
   const double s = r + cs_, c = w + cc_;
   *sh = s; *sl = (r - s) + cs_;                   /* |r| >= |cs_|, |w| >= |cc_|: the dropped parts are exact */
   *ch = c; *cl = (w - c) + cc_;
-  *q = (int)k & 3;
+  *q = (int)(k - 4.0 * floor(0.25 * k));         /* k mod 4 in floating point: a conversion of a huge k would differ between host and device */
 }
 
 MT_FN void mind_sincos(double x, double *sn, double *cs) {

@@ -76,6 +76,34 @@ def test_contingency_in_one_launch_equals_two_solves(kind, a, hip_predictor):
         assert sw[t] == st_w[t] and sf[t] == st_f[t]
 
 
+def test_kernel_and_oracle_trigonometry_are_the_same_bits(hip_predictor):
+    """mind_trig.h compiled for the device (k_ilqr) and for the host (oracle/ilqr_ref.c): sin, cos, tan and the cosine that comes with
+    the tangent of the same arguments agree to the bit -- arguments inside pi/4 (the kernel skips the reduction when a whole wave is
+    there), outside, mixed within one wave, huge, and the special values."""
+    import ctypes as C
+    rt, olib = hip_predictor, oi.lib()
+    for f in (olib.oracle_sincos, olib.oracle_tan_cos):
+        f.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        f.restype = None
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-0.78, 0.78, 640),                   # ten waves that take the short path
+                        rng.uniform(-3.2, 3.2, 640), rng.uniform(-100, 100, 640), rng.uniform(-1e5, 1e5, 640),
+                        np.where(rng.random(640) < 0.9, rng.uniform(-0.5, 0.5, 640), rng.uniform(-50, 50, 640)),      # mixed waves
+                        [0.0, -0.0, 1e-300, np.pi / 4, -np.pi / 4, np.pi / 2, np.pi, 1e15, np.inf, np.nan]])
+    out = np.zeros((len(x), 4))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rc = rt.lib.mind_debug_trig(rt.ctx, dp(x), len(x), dp(out))
+    assert rc == 0
+    ref = np.zeros_like(out)
+    a, b = C.c_double(), C.c_double()
+    for i, v in enumerate(x):
+        olib.oracle_sincos(float(v), C.byref(a), C.byref(b)); ref[i, 0], ref[i, 1] = a.value, b.value
+        olib.oracle_tan_cos(float(v), C.byref(a), C.byref(b)); ref[i, 2], ref[i, 3] = a.value, b.value
+    assert np.array_equal(out.view(np.uint64), ref.view(np.uint64)) or np.array_equal(out[np.isfinite(ref)], ref[np.isfinite(ref)]) \
+        and np.array_equal(np.isnan(out), np.isnan(ref))
+    assert np.array_equal(out[:, 1], out[:, 3]) or np.array_equal(np.isnan(out[:, 1]), np.isnan(out[:, 3]))
+
+
 def test_wide_cost_tree_matches_oracle(hip_predictor):
     """The biggest scenario tree of the scripted 6-ary depth-4 AIME tree (16 agents): hundreds of trajectory nodes,
     dozens of chain segments per level (several rounds of waves per level).  Bit-identical to the C oracle after three
