@@ -392,6 +392,15 @@ int mind_last_exchange_stats(mind_ctx *ctx, long long *collectives, long long *b
  * later round than the one that created it, no finished branch (the host path raises the reference's assertion), more than
  * max_rounds rounds -- in which case the caller runs that path instead. */
 int mind_aime_plan(mind_ctx *ctx, const mind_aime_plan_in *in, mind_aime_plan_out *out);
+/* mind_aime_plan in two halves, for a host thread that plans several scenes (one context each): _begin copies *in (the arrays it
+ * points to must stay valid until _finish) and runs the plan on a thread of the library; _poll returns 1 while it runs, 0 once
+ * _finish will not block; _finish returns what mind_aime_plan would have.  No other call on the context between _begin and _finish.
+ * mind_ctx_busy: 1 while work queued on the context's stream has not completed (e.g. the contingency solves begun with
+ * mind_ilqr_contingency_begin), 0 once collecting it will not block. */
+int mind_aime_plan_begin(mind_ctx *ctx, const mind_aime_plan_in *in);
+int mind_aime_plan_poll(mind_ctx *ctx);
+int mind_aime_plan_finish(mind_ctx *ctx, mind_aime_plan_out *out);
+int mind_ctx_busy(mind_ctx *ctx);
 
 /* The array part of get_agent_trajectories (planners/mind/utils.py:245-342): raw [a,T,6] float64 rows (observed flag, x, y, heading, vx,
  * vy; T = 50) of the kept tracks, slot [a] = the type one-hot position of every track -> pos [a,T,2], ang [a,T], vel [a,T,2] float32 with the

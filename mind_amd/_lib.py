@@ -107,7 +107,7 @@ class IlqrStats(C.Structure):
 EXPORTS = ["mind_ctx_create", "mind_ctx_destroy", "mind_last_error_string", "mind_ctx_synchronize",
            "mind_weights_load", "mind_predict_batch", "mind_last_fusion_stats", "mind_set_profiling",
            "mind_ilqr_solve_trees", "mind_ilqr_contingency", "mind_ilqr_solve_fields", "mind_cost_eval", "mind_lane_dist_field", "mind_aime_world", "mind_aime_rebase", "mind_debug_set_layers",
-           "mind_debug_read", "mind_set_pair_precision", "mind_get_pair_precision", "mind_debug_pack_bfrag", "mind_debug_pack_conv_frag", "mind_set_tuning", "mind_last_ilqr_stats", "mind_aime_plan", "mind_last_ilqr_profile", "mind_eval_traj_trees", "mind_last_ilqr_trace", "mind_ilqr_contingency_begin", "mind_ilqr_finish", "mind_fill_tracks", "mind_ilqr_contingency_begin_plan", "mind_debug_trig",
+           "mind_debug_read", "mind_set_pair_precision", "mind_get_pair_precision", "mind_debug_pack_bfrag", "mind_debug_pack_conv_frag", "mind_set_tuning", "mind_last_ilqr_stats", "mind_aime_plan", "mind_last_ilqr_profile", "mind_eval_traj_trees", "mind_last_ilqr_trace", "mind_ilqr_contingency_begin", "mind_ilqr_finish", "mind_fill_tracks", "mind_ilqr_contingency_begin_plan", "mind_debug_trig", "mind_aime_plan_begin", "mind_aime_plan_poll", "mind_aime_plan_finish", "mind_ctx_busy",
            "mind_set_exchange", "mind_last_exchange_stats"]
 
 # transport of the sharded mind_aime_plan (include/mind_hip.h): int fn(void *user, int op, void *send, void *recv, int64 bytes)
@@ -160,6 +160,10 @@ def load():
     lib.mind_aime_world.argtypes = [C.c_void_p, C.POINTER(WorldIn), C.POINTER(WorldOut)]
     lib.mind_aime_rebase.argtypes = [C.c_void_p, C.POINTER(RebaseIn), C.POINTER(RebaseOut)]
     lib.mind_aime_plan.argtypes = [C.c_void_p, C.POINTER(AimePlanIn), C.POINTER(AimePlanOut)]
+    lib.mind_aime_plan_begin.argtypes = [C.c_void_p, C.POINTER(AimePlanIn)]
+    lib.mind_aime_plan_poll.argtypes = [C.c_void_p]
+    lib.mind_aime_plan_finish.argtypes = [C.c_void_p, C.POINTER(AimePlanOut)]
+    lib.mind_ctx_busy.argtypes = [C.c_void_p]
     lib.mind_set_pair_precision.argtypes = [C.c_void_p, C.c_int]
     lib.mind_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.mind_last_ilqr_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]

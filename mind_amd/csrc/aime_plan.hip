@@ -663,3 +663,48 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   out->flat_mean = c->pl_fmean_p; out->flat_cov = c->pl_fcov_p;
   return MIND_OK;
 }
+
+
+// ---- mind_aime_plan in two halves (a host thread that plans several scenes, one context each: mind_amd/pipelined.py)
+extern "C" int mind_aime_plan_begin(mind_ctx *c, const mind_aime_plan_in *in) {
+  if (!c || !in) return MIND_EINVAL;
+  if (c->pa_state.load(std::memory_order_acquire) != 0) return fail(c, MIND_ESTATE, "mind_aime_plan_begin: a plan is pending on this context");
+  if (c->pa_thread.joinable()) c->pa_thread.join();
+  c->pa_in = *in;
+  memset(&c->pa_out, 0, sizeof(c->pa_out));
+  c->pa_state.store(1, std::memory_order_release);
+  try {
+    c->pa_thread = std::thread([c] {
+      c->pa_rc = mind_aime_plan(c, &c->pa_in, &c->pa_out);
+      c->pa_state.store(2, std::memory_order_release);
+    });
+  } catch (...) {
+    c->pa_state.store(0, std::memory_order_release);
+    return fail(c, MIND_ESTATE, "mind_aime_plan_begin: no thread");
+  }
+  return MIND_OK;
+}
+
+extern "C" int mind_aime_plan_poll(mind_ctx *c) {
+  if (!c) return MIND_EINVAL;
+  return c->pa_state.load(std::memory_order_acquire) == 1 ? 1 : 0;
+}
+
+extern "C" int mind_aime_plan_finish(mind_ctx *c, mind_aime_plan_out *out) {
+  if (!c || !out) return MIND_EINVAL;
+  if (c->pa_state.load(std::memory_order_acquire) == 0) return fail(c, MIND_ESTATE, "mind_aime_plan_finish: no plan was begun");
+  if (c->pa_thread.joinable()) c->pa_thread.join();
+  *out = c->pa_out;
+  c->pa_state.store(0, std::memory_order_release);
+  return c->pa_rc;
+}
+
+extern "C" int mind_ctx_busy(mind_ctx *c) {
+  if (!c) return MIND_EINVAL;
+  if (c->pa_state.load(std::memory_order_acquire) == 1) return 1;
+  (void)hipSetDevice(c->device);
+  const hipError_t e = hipStreamQuery(c->stream);
+  if (e == hipErrorNotReady) return 1;
+  if (e != hipSuccess) return fail(c, MIND_EHIP, "mind_ctx_busy: %s", hipGetErrorString(e));
+  return 0;
+}

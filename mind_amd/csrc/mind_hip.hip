@@ -11,6 +11,7 @@
 #include <map>
 #include <string>
 #include <thread>
+#include <atomic>
 #include <functional>
 #include <vector>
 
@@ -147,6 +148,12 @@ struct mind_ctx {
   bool pl_tab_side = false;
   std::vector<mind_aime_node> pl_nodes;
   std::vector<float> pl_flat_prob;
+  // mind_aime_plan_begin / _finish: the plan on a thread of the library (state 0 idle, 1 running, 2 done)
+  std::thread pa_thread;
+  std::atomic<int> pa_state{0};
+  mind_aime_plan_in pa_in;
+  mind_aime_plan_out pa_out;
+  int pa_rc = 0;
   const float *pl_rows_p = nullptr, *pl_fmean_p = nullptr, *pl_fcov_p = nullptr;      // into page-locked slot 2, valid until the next plan
   std::vector<int32_t> pl_tree_top, pl_tree_off, pl_flat_parent;
   int pl_plan_agents = 0;       // agents per scene of the plan those tables belong to
@@ -292,6 +299,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
 
 extern "C" int mind_ctx_destroy(mind_ctx *c) {
   if (!c) return MIND_EINVAL;
+  if (c->pa_thread.joinable()) c->pa_thread.join();
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf *bufs[] = {&c->edge, &c->x, &c->ST, &c->QK, &c->part, &c->tokpos, &c->meta, &c->jobs, &c->actor_feat,

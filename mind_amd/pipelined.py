@@ -1,10 +1,13 @@
 """Several closed loops planned from ONE host thread with their device work overlapped (BASELINE config 3 in one process).
 
-Every scene's planner owns a HIP context on its own stream (planner config "own_context", runtime.new_runtime).  The driver calls scene
-i + 1's ``plan_begin`` -- AIME rounds, start of the contingency solves -- before scene i's ``plan_end``: scene i's tree-iLQR kernel
-(a handful of workgroups, ~2 ms) runs on the device beside scene i + 1's predictor launches, and the host thread, which waits inside
-scene i + 1's native AIME call anyway, collects scene i's result afterwards.  The scenes stay independent closed loops: every plan is
-bit for bit the plan the scene computes alone (tests/test_gpu_plan.py)."""
+Every scene's planner owns a HIP context on its own stream (planner config "own_context", runtime.new_runtime).  A planning cycle has
+three host pieces -- plan_start (observation, the start of the native AIME plan on a thread of the library), plan_begin_finish (collects
+it, starts the contingency solves on the scene's context) and plan_end (collects them, evaluates, returns the control) -- with device
+work between them.  The driver is an event loop over the scenes: it runs the next piece of whichever scene's device work has finished
+(`plan_started_ready`, `plan_end_ready`: polls, no waits) and only blocks, on the oldest piece in flight, when no scene is ready.  The
+host thread therefore does one scene's Python while the other scenes' predictor rounds and tree-iLQR kernels run.  Planners without
+the three-piece surface (plan_begin / plan_end only) are driven as before: scene i + 1's plan_begin before scene i's plan_end.  The
+scenes stay independent closed loops: every plan is bit for bit the plan the scene computes alone (tests/test_gpu_plan.py)."""
 
 
 class PipelinedClosedLoops:
@@ -13,6 +16,7 @@ class PipelinedClosedLoops:
         for s in self.sims:
             if not hasattr(s.planner, "plan_begin"):
                 raise TypeError("the planner of a pipelined closed loop needs plan_begin / plan_end (MINDPlanner)")
+        self._three = all(hasattr(s.planner, "plan_start") for s in self.sims)
 
     @staticmethod
     def _advance_to_plan(sim):
@@ -25,8 +29,56 @@ class PipelinedClosedLoops:
             sim.step_end(None)
 
     def run_plans(self, n):
-        """n more planning cycles per scene, scene by scene in round-robin order, one plan in flight behind the one being started.
-        Returns the number of simulator steps taken (all scenes)."""
+        """n more planning cycles per scene.  Returns the number of simulator steps taken (all scenes)."""
+        return self._run_event_loop(n) if self._three and len(self.sims) > 1 else self._run_two_halves(n)
+
+    # ---- three pieces per cycle, whichever scene is ready next
+    def _run_event_loop(self, n):
+        s0 = sum(s.n_steps for s in self.sims)
+        target = [s.n_plans + n for s in self.sims]
+        started = [s.n_plans for s in self.sims]
+        state = [None] * len(self.sims)          # None: idle | ("started", token) | ("begun", tuple)
+        order = []                               # scenes with a piece in flight, oldest first
+        while True:
+            progressed = False
+            # 1. collect what is ready (oldest first), keeping every scene's next device work queued as early as possible
+            for i in list(order):
+                kind, tok = state[i]
+                pl = self.sims[i].planner
+                if kind == "started" and pl.plan_started_ready(tok):
+                    state[i] = ("begun", pl.plan_begin_finish(tok))
+                    progressed = True
+                elif kind == "begun" and pl.plan_end_ready(tok):
+                    self.sims[i].step_end(pl.plan_end(tok))
+                    state[i] = None
+                    order.remove(i)
+                    progressed = True
+            # 2. start the next cycle of an idle scene (its simulator steps and observation are host work that hides device time)
+            for i, s in enumerate(self.sims):
+                if state[i] is None and started[i] < target[i]:
+                    state[i] = ("started", s.planner.plan_start(self._advance_to_plan(s)))
+                    started[i] += 1
+                    order.append(i)
+                    progressed = True
+                    break                        # one at a time: look at the ready list again before more host work
+            if progressed:
+                continue
+            if not order:
+                break
+            # 3. nothing is ready and nothing can start: wait for the oldest piece in flight
+            i = order[0]
+            kind, tok = state[i]
+            pl = self.sims[i].planner
+            if kind == "started":
+                state[i] = ("begun", pl.plan_begin_finish(tok))
+            else:
+                self.sims[i].step_end(pl.plan_end(tok))
+                state[i] = None
+                order.remove(i)
+        return sum(s.n_steps for s in self.sims) - s0
+
+    # ---- two halves per cycle, scene by scene in round-robin order, one plan in flight behind the one being started
+    def _run_two_halves(self, n):
         s0 = sum(s.n_steps for s in self.sims)
         target = [s.n_plans + n for s in self.sims]
         started = [s.n_plans for s in self.sims]

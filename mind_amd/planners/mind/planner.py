@@ -201,6 +201,47 @@ class MINDPlanner:
         t1 = time.perf_counter()
         return (lcl_smp, scen_trees, t0, t1, n0)
 
+    # ---- plan() in three pieces, none of which blocks on the device when its *_ready() says so: a driver that plans several scenes from
+    #      one thread (mind_amd/pipelined.py) keeps every scene's native AIME plan (a thread of the library) and contingency solves (queued
+    #      on the scene's context) in flight while it does another scene's host work
+    def plan_start(self, lcl_smp):
+        """host work before the AIME rounds + the start of the native plan; returns a token for plan_started_ready / plan_begin_finish"""
+        with self._on_own_stream():
+            import time
+            t0 = time.perf_counter()
+            self.scen_tree_gen.reset()
+            lane, info = self.resample_target_lane(lcl_smp)
+            self.scen_tree_gen.set_target_lane(lane, info)
+            n0 = self.scen_tree_gen.n_expanded
+            self.traj_tree_opt.speculate_warm(self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)
+            begin = getattr(self.scen_tree_gen, "branch_aime_begin", None)
+            tok = begin(lcl_smp, self.agent_obs) if begin is not None else None
+            return (lcl_smp, tok, t0, n0)
+
+    def plan_started_ready(self, started):
+        """the native plan begun by plan_start has finished (plan_begin_finish will not wait for it)"""
+        tok = started[1]
+        return True if tok is None else self.scen_tree_gen.branch_aime_ready(tok)
+
+    def plan_begin_finish(self, started):
+        """collects the native plan, starts the contingency solves; returns what plan_begin returns"""
+        with self._on_own_stream():
+            import time
+            lcl_smp, tok, t0, n0 = started
+            opt = self.traj_tree_opt
+            ahead = (lambda flats: opt.solve_batch_begin(flats, self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)) \
+                if hasattr(opt, "solve_batch_begin") else None
+            if tok is None:
+                scen_trees = self.scen_tree_gen.branch_aime(lcl_smp, self.agent_obs, on_flats=ahead)
+            else:
+                scen_trees = self.scen_tree_gen.branch_aime_finish(tok, on_flats=ahead)
+            return (lcl_smp, scen_trees, t0, time.perf_counter(), n0)
+
+    def plan_end_ready(self, begun):
+        """the contingency solves begun by plan_begin / plan_begin_finish have finished (plan_end will not wait for them)"""
+        rt = getattr(self.network, "rt", None)
+        return True if rt is None or not hasattr(rt, "busy") else not rt.busy()
+
     def _plan_end(self, begun):
         """Second half of plan(): collects (or runs) the contingency solves, evaluates the candidates, returns plan()'s result."""
         lcl_smp, scen_trees, t0, t1, n0 = begun

@@ -257,10 +257,9 @@ class ScenarioTreeGenerator:
             else:
                 want.attach(rt)
 
-    def _branch_aime_native(self, lcl_smp, agent_obs, on_flats=None):
-        """branch_aime through mind_aime_plan; None = the library left this plan to the round-by-round path.  ``on_flats``: called
-        with the plan's flattened cost trees (in get_scenario_tree's order) as soon as the native call returns, BEFORE the tree's
-        Python objects are built -- the planner starts the contingency solves there (TrajectoryTreeOptimizer.solve_batch_begin)."""
+    def _native_args(self, lcl_smp, agent_obs):
+        """(root dict, positional args, keyword args) of the runtime's aime_plan for this cycle, or None when the native plan does not
+        apply (wrong horizons, no lanes)"""
         cfg = self.config
         if self.obs_len != 50 or not (2 <= self.pred_len <= 60):
             return None
@@ -280,8 +279,8 @@ class ScenarioTreeGenerator:
                        travel0=F32(max(cur_vel, 0.5) * cfg.tar_time_ahead))
             root = {"TRAJS_TYPE": types, "TRAJS_TID": tids, "TRAJS_CAT": cats}
             self.n_lanes = int(st["num_lanes"])
-            res = self.network.rt.aime_plan(None, None, None, None, self.target_lane, self.target_lane_info, cfg.tar_time_ahead,
-                                            cfg.tar_dist_thres, cfg.max_depth, pred_len=self.pred_len, raw=raw, script=modes(pos.shape[0]), prob_floor=floor)
+            return root, (None, None, None, None, self.target_lane, self.target_lane_info, cfg.tar_time_ahead, cfg.tar_dist_thres, cfg.max_depth), \
+                dict(pred_len=self.pred_len, raw=raw, script=modes(pos.shape[0]), prob_floor=floor)
         else:
             root = self.process_data(lcl_smp, agent_obs)
             self.prepare_root_data(root)
@@ -289,9 +288,45 @@ class ScenarioTreeGenerator:
             if hist.shape[1] != self.obs_len or root["LANES"].shape[0] == 0:
                 return None
             self.n_lanes = int(root["LANES"].shape[0])
-            res = self.network.rt.aime_plan(root, hist, self.lane_graph["lane_ctrs"], self.lane_graph["lane_vecs"], self.target_lane,
-                                            self.target_lane_info, cfg.tar_time_ahead, cfg.tar_dist_thres, cfg.max_depth, pred_len=self.pred_len,
-                                            script=modes(root["ACTORS"].shape[0]), prob_floor=floor)
+            return root, (root, hist, self.lane_graph["lane_ctrs"], self.lane_graph["lane_vecs"], self.target_lane, self.target_lane_info,
+                          cfg.tar_time_ahead, cfg.tar_dist_thres, cfg.max_depth), \
+                dict(pred_len=self.pred_len, script=modes(root["ACTORS"].shape[0]), prob_floor=floor)
+
+    def _branch_aime_native(self, lcl_smp, agent_obs, on_flats=None):
+        """branch_aime through mind_aime_plan; None = the library left this plan to the round-by-round path.  ``on_flats``: called
+        with the plan's flattened cost trees (in get_scenario_tree's order) as soon as the native call returns, BEFORE the tree's
+        Python objects are built -- the planner starts the contingency solves there (TrajectoryTreeOptimizer.solve_batch_begin)."""
+        call = self._native_args(lcl_smp, agent_obs)
+        if call is None:
+            return None
+        root, args, kw = call
+        return self._native_trees(self.network.rt.aime_plan(*args, **kw), root, on_flats)
+
+    def branch_aime_begin(self, lcl_smp, agent_obs):
+        """First half of branch_aime for a driver that plans several scenes from one thread (mind_amd/pipelined.py): starts the native
+        plan on a thread of the library (mind_aime_plan_begin) and returns a token, or None when only the blocking paths apply (the caller
+        then calls branch_aime).  branch_aime_ready(token) tells whether branch_aime_finish(token, on_flats) would block."""
+        if not self._native_ok() or not hasattr(self.network.rt, "aime_plan_begin"):
+            return None
+        call = self._native_args(lcl_smp, agent_obs)
+        if call is None:
+            return None
+        root, args, kw = call
+        self.network.rt.aime_plan_begin(*args, **kw)
+        return (root, lcl_smp, agent_obs)
+
+    def branch_aime_ready(self, token):
+        return self.network.rt.aime_plan_ready()
+
+    def branch_aime_finish(self, token, on_flats=None):
+        root, lcl_smp, agent_obs = token
+        trees = self._native_trees(self.network.rt.aime_plan_finish(), root, on_flats)
+        if trees is not None:
+            return trees
+        self.reset()                # the library left this plan to the round-by-round path
+        return self._branch_aime_host(lcl_smp, agent_obs)
+
+    def _native_trees(self, res, root, on_flats):
         if res is None:
             return None
         nodes, rows, info = res
@@ -353,6 +388,9 @@ class ScenarioTreeGenerator:
             if trees is not None:
                 return trees
             self.reset()            # (keeps lane graph / target lane: only the per-plan bookkeeping)
+        return self._branch_aime_host(lcl_smp, agent_obs)
+
+    def _branch_aime_host(self, lcl_smp, agent_obs):
         root = self.process_data(lcl_smp, agent_obs)
         self.init_scenario_tree(root)
         branch_nodes = self.get_branch_set()

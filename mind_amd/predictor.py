@@ -512,9 +512,43 @@ class HipPredictor:
         lane_pts [l,11,2] float64, lane_flags [l,6] int, travel0) and root / hist / lane_ctrs / lane_vecs are ignored.
         Returns (nodes: structured array, one record per internal tree node in creation order, rows: float32 [n], info dict) or None
         when the library reports a situation only the round-by-round path handles.  ``script``: see mind_aime_plan_in.script_cls."""
+        pi, keep, a, l = self._aime_plan_args(root, hist, lane_ctrs, lane_vecs, target_lane, target_lane_info, time_ahead, dist_thres, max_depth,
+                                              pred_len, min_vel, max_rounds, raw, script, prob_floor)
+        po = _lib.AimePlanOut()
+        rc = self.lib.mind_aime_plan(self.ctx, C.byref(pi), C.byref(po))
+        return self._aime_plan_result(rc, po, a, l)
+
+    def aime_plan_begin(self, *args, **kw):
+        """aime_plan in two halves (mind_aime_plan_begin / _finish: the plan runs on a thread of the library, this call returns at once):
+        same arguments as aime_plan; aime_plan_ready() tells whether aime_plan_finish() would block."""
+        pi, keep, a, l = self._aime_plan_args(*args, **kw)
+        rc = self.lib.mind_aime_plan_begin(self.ctx, C.byref(pi))
+        _lib.check(self.lib, self.ctx, rc, "mind_aime_plan_begin")
+        self._aime_pending = (pi, keep, a, l)         # (the input arrays stay alive until the plan is collected)
+
+    def aime_plan_ready(self):
+        return self.lib.mind_aime_plan_poll(self.ctx) == 0
+
+    def aime_plan_finish(self):
+        pi, keep, a, l = self._aime_pending
+        self._aime_pending = None
+        po = _lib.AimePlanOut()
+        rc = self.lib.mind_aime_plan_finish(self.ctx, C.byref(po))
+        return self._aime_plan_result(rc, po, a, l)
+
+    def busy(self):
+        """work queued on this context (a begun plan, begun contingency solves) has not completed yet"""
+        rc = self.lib.mind_ctx_busy(self.ctx)
+        if rc < 0:
+            _lib.check(self.lib, self.ctx, rc, "mind_ctx_busy")
+        return rc == 1
+
+    def _aime_plan_args(self, root, hist, lane_ctrs, lane_vecs, target_lane, target_lane_info, time_ahead, dist_thres, max_depth,
+                        pred_len=50, min_vel=0.5, max_rounds=16, raw=None, script=None, prob_floor=None):
         f = lambda x: np.ascontiguousarray(x, np.float32)
         fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
-        pi, po = _lib.AimePlanIn(), _lib.AimePlanOut()
+        pi = _lib.AimePlanIn()
+        keep = []
         if raw is not None:
             arrs = dict(raw_pos=f(raw["pos"]), raw_ang=f(raw["ang"]), raw_vel=f(raw["vel"]), raw_pad=f(raw["pad"]), types=f(raw["types"]),
                         target_lane=f(target_lane), target_lane_info=f(target_lane_info))
@@ -525,6 +559,7 @@ class HipPredictor:
             assert arrs["types"].shape == (a, 50, 7) and lpts.shape == (l, 11, 2) and lfl.shape == (l, 6)
             pi.lane_pts, pi.lane_flags = lpts.ctypes.data_as(C.POINTER(C.c_double)), lfl.ctypes.data_as(C.POINTER(C.c_int32))
             pi.travel0 = float(raw["travel0"])
+            keep += [lpts, lfl]
         else:
             arrs = dict(actors=f(root["ACTORS"]), actor_ctrs=f(root["TRAJS_CTRS"]), actor_vecs=f(root["TRAJS_VECS"]), lanes=f(root["LANES"]),
                         lane_ctrs=f(lane_ctrs), lane_vecs=f(lane_vecs), tgt_nodes=f(root["TGT_NODES"]), tgt_rpe=f(root["TGT_RPE"]),
@@ -545,7 +580,11 @@ class HipPredictor:
             assert tuple(sr.shape) == (a, 6, 60, 5) and tuple(sv.shape) == (a, 6, 60, 2) and sc.numel() == 6
             assert all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 for t in script)
             pi.script_cls, pi.script_reg, pi.script_vel = sc.data_ptr(), sr.data_ptr(), sv.data_ptr()
-        rc = self.lib.mind_aime_plan(self.ctx, C.byref(pi), C.byref(po))
+            keep += list(script)
+        keep.append(arrs)
+        return pi, keep, a, l
+
+    def _aime_plan_result(self, rc, po, a, l):
         if rc == _lib.MIND_ESTATE:
             msg = self.lib.mind_last_error_string(self.ctx) or b""
             if msg.startswith(b"unsupported"):
