@@ -49,7 +49,7 @@ class PipelinedClosedLoops:
                     state[i] = ("begun", pl.plan_begin_finish(tok))
                     progressed = True
                 elif kind == "begun" and pl.plan_end_ready(tok):
-                    self.sims[i].step_end(pl.plan_end(tok))
+                    self.sims[i].step_end(pl.plan_end_piece(tok))
                     state[i] = None
                     order.remove(i)
                     progressed = True
@@ -72,7 +72,7 @@ class PipelinedClosedLoops:
             if kind == "started":
                 state[i] = ("begun", pl.plan_begin_finish(tok))
             else:
-                self.sims[i].step_end(pl.plan_end(tok))
+                self.sims[i].step_end(pl.plan_end_piece(tok))
                 state[i] = None
                 order.remove(i)
         return sum(s.n_steps for s in self.sims) - s0

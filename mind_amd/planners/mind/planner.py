@@ -37,6 +37,11 @@ def _import_cfg(name):
         return import_module("mind_amd." + name)
 
 
+def contextlib_null():
+    import contextlib
+    return contextlib.nullcontext()
+
+
 class MINDPlanner:
     def __init__(self, config_dir):
         self.obs_len = 50
@@ -204,9 +209,15 @@ class MINDPlanner:
     # ---- plan() in three pieces, none of which blocks on the device when its *_ready() says so: a driver that plans several scenes from
     #      one thread (mind_amd/pipelined.py) keeps every scene's native AIME plan (a thread of the library) and contingency solves (queued
     #      on the scene's context) in flight while it does another scene's host work
+    def _torch_free(self):
+        """this planner's pieces issue no torch operation (native AIME plan, native solves and evaluation): they need not switch torch's
+        current stream to the context's -- torch.cuda.stream() costs 40 us a time, six times a cycle"""
+        ok = getattr(self.scen_tree_gen, "_native_ok", None)
+        return contextlib_null() if (ok is not None and ok() and self.traj_tree_opt.solver is None) else self._on_own_stream()
+
     def plan_start(self, lcl_smp):
         """host work before the AIME rounds + the start of the native plan; returns a token for plan_started_ready / plan_begin_finish"""
-        with self._on_own_stream():
+        with self._torch_free():
             import time
             t0 = time.perf_counter()
             self.scen_tree_gen.reset()
@@ -225,17 +236,22 @@ class MINDPlanner:
 
     def plan_begin_finish(self, started):
         """collects the native plan, starts the contingency solves; returns what plan_begin returns"""
-        with self._on_own_stream():
-            import time
-            lcl_smp, tok, t0, n0 = started
-            opt = self.traj_tree_opt
-            ahead = (lambda flats: opt.solve_batch_begin(flats, self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)) \
-                if hasattr(opt, "solve_batch_begin") else None
-            if tok is None:
+        import time
+        lcl_smp, tok, t0, n0 = started
+        opt = self.traj_tree_opt
+        ahead = (lambda flats: opt.solve_batch_begin(flats, self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)) \
+            if hasattr(opt, "solve_batch_begin") else None
+        if tok is None:
+            with self._on_own_stream():
                 scen_trees = self.scen_tree_gen.branch_aime(lcl_smp, self.agent_obs, on_flats=ahead)
-            else:
-                scen_trees = self.scen_tree_gen.branch_aime_finish(tok, on_flats=ahead)
-            return (lcl_smp, scen_trees, t0, time.perf_counter(), n0)
+        else:       # (a plan the library hands back to the round-by-round path runs that path, torch operations included, on the context's stream)
+            scen_trees = self.scen_tree_gen.branch_aime_finish(tok, on_flats=ahead, host_context=self._on_own_stream)
+        return (lcl_smp, scen_trees, t0, time.perf_counter(), n0)
+
+    def plan_end_piece(self, begun):
+        """plan_end for the three-piece driver (no torch stream switch when the planner issues no torch operation)"""
+        with self._torch_free():
+            return self._plan_end(begun)
 
     def plan_end_ready(self, begun):
         """the contingency solves begun by plan_begin / plan_begin_finish have finished (plan_end will not wait for them)"""

@@ -318,13 +318,15 @@ class ScenarioTreeGenerator:
     def branch_aime_ready(self, token):
         return self.network.rt.aime_plan_ready()
 
-    def branch_aime_finish(self, token, on_flats=None):
+    def branch_aime_finish(self, token, on_flats=None, host_context=None):
         root, lcl_smp, agent_obs = token
         trees = self._native_trees(self.network.rt.aime_plan_finish(), root, on_flats)
         if trees is not None:
             return trees
         self.reset()                # the library left this plan to the round-by-round path
-        return self._branch_aime_host(lcl_smp, agent_obs)
+        import contextlib
+        with (host_context() if host_context is not None else contextlib.nullcontext()):
+            return self._branch_aime_host(lcl_smp, agent_obs)
 
     def _native_trees(self, res, root, on_flats):
         if res is None:

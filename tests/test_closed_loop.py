@@ -155,6 +155,67 @@ def test_pipelined_driver_keeps_one_plan_in_flight_and_plans_what_the_scenes_pla
         PipelinedClosedLoops([ClosedLoopSim(SynthWorld(n_agents=3, n_lanes=2, n_segs=6, seed=5), _StubPlanner())])
 
 
+class _ThreePiecePlanner(_TwoHalfPlanner):
+    """plan() in three pieces whose device work takes a number of readiness polls to finish (a stand-in for the native AIME plan on a
+    library thread and the contingency solves on the scene's stream)"""
+
+    def __init__(self, name, log, aime_polls, solve_polls):
+        super().__init__(name, log)
+        self.aime_polls, self.solve_polls, self.left = aime_polls, solve_polls, 0
+
+    def plan_start(self, lcl):
+        self.log.append(("start", self.name))
+        self.left = self.aime_polls
+        return lcl
+
+    def plan_started_ready(self, started):
+        self.left -= 1
+        return self.left < 0
+
+    def plan_begin_finish(self, started):
+        self.log.append(("mid", self.name, self.left < 0))           # (collected without waiting?)
+        self.left = self.solve_polls
+        return started
+
+    def plan_end_ready(self, begun):
+        self.left -= 1
+        return self.left < 0
+
+    def plan_end_piece(self, begun):
+        self.log.append(("end", self.name, self.left < 0))
+        return _StubPlanner.plan(self, begun)
+
+
+def test_pipelined_event_loop_runs_whichever_scene_is_ready_and_waits_only_when_none_is():
+    """PipelinedClosedLoops over planners with the three-piece surface (CPU, stub planners with scripted readiness): every scene's pieces
+    run in order start -> mid -> end, every scene gets n plans at the simulator times it plans at alone, every scene is in flight early,
+    a slow scene does not hold the others back, and pieces are collected before they are ready (= the loop
+    blocks on the oldest one in flight) only when no scene had anything ready or startable."""
+    from mind_amd.pipelined import PipelinedClosedLoops
+    log = []
+    polls = {"s1": (2, 3), "s2": (0, 0), "s3": (40, 40)}            # s3's device work is slow
+    sims = [ClosedLoopSim(SynthWorld(n_agents=3, n_lanes=2, n_segs=6, seed=k), _ThreePiecePlanner("s%d" % k, log, *polls["s%d" % k]), episode_plans=7)
+            for k in (1, 2, 3)]
+    pc = PipelinedClosedLoops(sims)
+    steps = pc.run_plans(5) + pc.run_plans(6)
+    assert [s.n_plans for s in sims] == [11, 11, 11] and steps == sum(s.n_steps for s in sims)
+    alone = ClosedLoopSim(SynthWorld(n_agents=3, n_lanes=2, n_segs=6, seed=1), _StubPlanner(), episode_plans=7)
+    alone.run_plans(11)
+    assert sims[0].planner.plans == alone.planner.plans and sims[0].n_steps == alone.n_steps and np.array_equal(sims[0].state, alone.state)
+    for name in polls:                                               # per scene: start, mid, end, start, mid, end ...
+        mine = [e[0] for e in log if e[1] == name]
+        assert mine == ["start", "mid", "end"] * 11
+    assert [e[:2] for e in log[:3]] == [("start", "s1"), ("start", "s2"), ("mid", "s2")]       # ready work is collected before more is started
+    assert ("start", "s3") in [e[:2] for e in log[:6]]                                             # ... and every scene is in flight early
+    # the fast scenes finish plans while the slow one is still in its first pieces
+    first_s3_end = next(i for i, e in enumerate(log) if e[:2] == ("end", "s3"))
+    assert sum(1 for e in log[:first_s3_end] if e[:2] == ("end", "s2")) >= 2
+    # pieces collected before they were ready (= the loop blocks on the oldest piece in flight) happen -- the slow scene forces them --
+    # but never for the scene that is always ready, and mostly for the slow one
+    early = [e for e in log if e[0] in ("mid", "end") and not e[2]]
+    assert early and all(e[1] != "s2" for e in early) and sum(e[1] == "s3" for e in early) >= len(early) / 2
+
+
 @pytest.mark.gpu
 def test_closed_loop_with_real_planner():
     import os
