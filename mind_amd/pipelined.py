@@ -65,7 +65,20 @@ class PipelinedClosedLoops:
                 continue
             if not order:
                 break
-            # 3. nothing is ready and nothing can start: wait for the oldest piece in flight
+            # 3. nothing is ready and nothing can start: poll the pieces in flight until one is (whichever scene's device work ends first),
+            #    then go round again; after a while without any, wait for the oldest one (a blocking collect reports a failed call)
+            import time
+            t_spin = time.perf_counter()
+            ready = False
+            while not ready and time.perf_counter() - t_spin < 2.0:
+                for i in order:
+                    kind, tok = state[i]
+                    pl = self.sims[i].planner
+                    if (kind == "started" and pl.plan_started_ready(tok)) or (kind == "begun" and pl.plan_end_ready(tok)):
+                        ready = True
+                        break
+            if ready:
+                continue
             i = order[0]
             kind, tok = state[i]
             pl = self.sims[i].planner

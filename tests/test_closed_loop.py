@@ -189,8 +189,8 @@ class _ThreePiecePlanner(_TwoHalfPlanner):
 def test_pipelined_event_loop_runs_whichever_scene_is_ready_and_waits_only_when_none_is():
     """PipelinedClosedLoops over planners with the three-piece surface (CPU, stub planners with scripted readiness): every scene's pieces
     run in order start -> mid -> end, every scene gets n plans at the simulator times it plans at alone, every scene is in flight early,
-    a slow scene does not hold the others back, and pieces are collected before they are ready (= the loop
-    blocks on the oldest one in flight) only when no scene had anything ready or startable."""
+    a slow scene does not hold the others back, and no piece is collected before it is ready (the loop polls
+    the pieces in flight when no scene has anything ready or startable)."""
     from mind_amd.pipelined import PipelinedClosedLoops
     log = []
     polls = {"s1": (2, 3), "s2": (0, 0), "s3": (40, 40)}            # s3's device work is slow
@@ -210,10 +210,9 @@ def test_pipelined_event_loop_runs_whichever_scene_is_ready_and_waits_only_when_
     # the fast scenes finish plans while the slow one is still in its first pieces
     first_s3_end = next(i for i, e in enumerate(log) if e[:2] == ("end", "s3"))
     assert sum(1 for e in log[:first_s3_end] if e[:2] == ("end", "s2")) >= 2
-    # pieces collected before they were ready (= the loop blocks on the oldest piece in flight) happen -- the slow scene forces them --
-    # but never for the scene that is always ready, and mostly for the slow one
-    early = [e for e in log if e[0] in ("mid", "end") and not e[2]]
-    assert early and all(e[1] != "s2" for e in early) and sum(e[1] == "s3" for e in early) >= len(early) / 2
+    # no piece is collected before its device work has finished: when no scene is ready the loop polls the pieces in flight (it blocks on
+    # the oldest one only after seconds without any becoming ready)
+    assert not [e for e in log if e[0] in ("mid", "end") and not e[2]]
 
 
 @pytest.mark.gpu
