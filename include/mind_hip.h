@@ -326,6 +326,15 @@ typedef struct {
   /* path-probability floor of prune_merge (scenario_tree.py:368-370).  0 = the reference's 0.001; the scripted stress workload lifts it
    * (a small positive value) so that a full 6-ary depth-5 tree can grow: 6^-4 is already below 0.001. */
   float prob_floor;
+  /* Optional: begin the contingency solves of the plan (planner.py:174-178: warm-start fit + full fit of every scenario tree) straight
+   * behind it, before the call returns -- everything they need besides the plan's own cost trees is known when the plan starts (ego
+   * state x0 [6], target lane [solve_n_lane_pts, 2] float64, target velocity, the two configurations).  solve_cfg_full != NULL asks
+   * for it; out->solves_begun tells whether it happened (not on a sharded context, not without a finished branch), and
+   * mind_ilqr_finish_plan collects.  Saves the host round trip between the plan's last kernel and k_ilqr. */
+  const mind_ilqr_cfg *solve_cfg_warm, *solve_cfg_full;
+  const double *solve_x0, *solve_lane;
+  int solve_n_lane_pts;
+  double solve_target_vel;
 } mind_aime_plan_in;
 
 #define MIND_AIME_BRANCH 1
@@ -362,6 +371,7 @@ typedef struct {
   const float *flat_prob;      /* [M_total] sibling-normalised scenario probability (float32 arithmetic)                   */
   const float *flat_mean;      /* [M_total, a, 2]                                                                         */
   const float *flat_cov;       /* [M_total, a]                                                                            */
+  int solves_begun;            /* the contingency solves were begun behind the plan (in->solve_cfg_full): mind_ilqr_finish_plan   */
 } mind_aime_plan_out;
 
 /* ------------------------------------------------------------------------------------------------
@@ -397,6 +407,9 @@ int mind_aime_plan(mind_ctx *ctx, const mind_aime_plan_in *in, mind_aime_plan_ou
  * _finish will not block; _finish returns what mind_aime_plan would have.  No other call on the context between _begin and _finish.
  * mind_ctx_busy: 1 while work queued on the context's stream has not completed (e.g. the contingency solves begun with
  * mind_ilqr_contingency_begin), 0 once collecting it will not block. */
+/* collects the contingency solves a plan began itself (out->solves_begun): waits for them and copies the results of all its
+ * scenario trees, concatenated in tree order: xs [M_total, 6], us [M_total, 2], the warm-start and full fits' statistics [n_trees]. */
+int mind_ilqr_finish_plan(mind_ctx *ctx, double *xs, double *us, mind_ilqr_stats *stats_warm, mind_ilqr_stats *stats_full);
 int mind_aime_plan_begin(mind_ctx *ctx, const mind_aime_plan_in *in);
 int mind_aime_plan_poll(mind_ctx *ctx);
 int mind_aime_plan_finish(mind_ctx *ctx, mind_aime_plan_out *out);

@@ -74,7 +74,9 @@ class AimePlanIn(C.Structure):
                [("time_ahead", C.c_float), ("min_vel", C.c_float), ("dist_thres", C.c_float), ("max_depth", C.c_int), ("max_rounds", C.c_int), ("pred_len", C.c_int),
                 ("raw_pos", C.POINTER(C.c_float)), ("raw_ang", C.POINTER(C.c_float)), ("raw_vel", C.POINTER(C.c_float)), ("raw_pad", C.POINTER(C.c_float)),
                 ("lane_pts", C.POINTER(C.c_double)), ("lane_flags", C.POINTER(C.c_int32)), ("travel0", C.c_float),
-                ("script_cls", C.c_void_p), ("script_reg", C.c_void_p), ("script_vel", C.c_void_p), ("prob_floor", C.c_float)]
+                ("script_cls", C.c_void_p), ("script_reg", C.c_void_p), ("script_vel", C.c_void_p), ("prob_floor", C.c_float),
+                ("solve_cfg_warm", C.c_void_p), ("solve_cfg_full", C.c_void_p), ("solve_x0", C.c_void_p), ("solve_lane", C.c_void_p),
+                ("solve_n_lane_pts", C.c_int), ("solve_target_vel", C.c_double)]
 
 
 class AimeNode(C.Structure):
@@ -88,7 +90,7 @@ class AimePlanOut(C.Structure):
                 ("n_expanded", C.c_int), ("n_rounds", C.c_int), ("root_flags", C.c_int), ("round_scenes", C.c_int * 32),
                 ("pair_ms", C.c_float), ("pair_launches", C.c_int), ("n_trees", C.c_int), ("tree_top", C.POINTER(C.c_int32)),
                 ("tree_off", C.POINTER(C.c_int32)), ("flat_parent", C.POINTER(C.c_int32)), ("flat_prob", C.POINTER(C.c_float)),
-                ("flat_mean", C.POINTER(C.c_float)), ("flat_cov", C.POINTER(C.c_float))]
+                ("flat_mean", C.POINTER(C.c_float)), ("flat_cov", C.POINTER(C.c_float)), ("solves_begun", C.c_int)]
 
 
 class IlqrCfg(C.Structure):
@@ -107,7 +109,7 @@ class IlqrStats(C.Structure):
 EXPORTS = ["mind_ctx_create", "mind_ctx_destroy", "mind_last_error_string", "mind_ctx_synchronize",
            "mind_weights_load", "mind_predict_batch", "mind_last_fusion_stats", "mind_set_profiling",
            "mind_ilqr_solve_trees", "mind_ilqr_contingency", "mind_ilqr_solve_fields", "mind_cost_eval", "mind_lane_dist_field", "mind_aime_world", "mind_aime_rebase", "mind_debug_set_layers",
-           "mind_debug_read", "mind_set_pair_precision", "mind_get_pair_precision", "mind_debug_pack_bfrag", "mind_debug_pack_conv_frag", "mind_set_tuning", "mind_last_ilqr_stats", "mind_aime_plan", "mind_last_ilqr_profile", "mind_eval_traj_trees", "mind_last_ilqr_trace", "mind_ilqr_contingency_begin", "mind_ilqr_finish", "mind_fill_tracks", "mind_ilqr_contingency_begin_plan", "mind_debug_trig", "mind_aime_plan_begin", "mind_aime_plan_poll", "mind_aime_plan_finish", "mind_ctx_busy",
+           "mind_debug_read", "mind_set_pair_precision", "mind_get_pair_precision", "mind_debug_pack_bfrag", "mind_debug_pack_conv_frag", "mind_set_tuning", "mind_last_ilqr_stats", "mind_aime_plan", "mind_last_ilqr_profile", "mind_eval_traj_trees", "mind_last_ilqr_trace", "mind_ilqr_contingency_begin", "mind_ilqr_finish", "mind_fill_tracks", "mind_ilqr_contingency_begin_plan", "mind_debug_trig", "mind_aime_plan_begin", "mind_aime_plan_poll", "mind_aime_plan_finish", "mind_ctx_busy", "mind_ilqr_finish_plan",
            "mind_set_exchange", "mind_last_exchange_stats"]
 
 # transport of the sharded mind_aime_plan (include/mind_hip.h): int fn(void *user, int op, void *send, void *recv, int64 bytes)
@@ -164,6 +166,7 @@ def load():
     lib.mind_aime_plan_poll.argtypes = [C.c_void_p]
     lib.mind_aime_plan_finish.argtypes = [C.c_void_p, C.POINTER(AimePlanOut)]
     lib.mind_ctx_busy.argtypes = [C.c_void_p]
+    lib.mind_ilqr_finish_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mind_set_pair_precision.argtypes = [C.c_void_p, C.c_int]
     lib.mind_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.mind_last_ilqr_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]

@@ -661,6 +661,26 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   out->n_trees = (int)c->pl_tree_top.size(); out->tree_top = c->pl_tree_top.data(); out->tree_off = c->pl_tree_off.data();
   out->flat_parent = c->pl_flat_parent.data(); out->flat_prob = c->pl_flat_prob.data();
   out->flat_mean = c->pl_fmean_p; out->flat_cov = c->pl_fcov_p;
+  // ---- the contingency solves of the plan, begun here when the caller handed their inputs in (no host round trip between the plan's
+  //      read-back and k_ilqr); results stay in the library until mind_ilqr_finish_plan
+  if (in->solve_cfg_full && !dist && out->n_trees > 0 && in->solve_x0 && in->solve_lane && in->solve_n_lane_pts >= 2) {
+    c->pl_sol_xs.resize(Mtot * 6); c->pl_sol_us.resize(Mtot * 2);
+    c->pl_sol_stw.resize((size_t)out->n_trees); c->pl_sol_stf.resize((size_t)out->n_trees);
+    const int rs = mind_ilqr_contingency_begin_plan(c, in->solve_cfg_warm, in->solve_cfg_full, in->solve_x0, in->solve_lane, in->solve_n_lane_pts,
+                                                    in->solve_target_vel, c->pl_sol_xs.data(), c->pl_sol_us.data(), c->pl_sol_stw.data(), c->pl_sol_stf.data());
+    out->solves_begun = rs == MIND_OK ? 1 : 0;      // (a failed begin is not the plan's failure: the caller then solves the usual way)
+  }
+  return MIND_OK;
+}
+
+extern "C" int mind_ilqr_finish_plan(mind_ctx *c, double *xs, double *us, mind_ilqr_stats *stats_warm, mind_ilqr_stats *stats_full) {
+  if (!c || !xs || !us || !stats_full) return MIND_EINVAL;
+  const int rc = mind_ilqr_finish(c);
+  if (rc) return rc;
+  memcpy(xs, c->pl_sol_xs.data(), c->pl_sol_xs.size() * sizeof(double));
+  memcpy(us, c->pl_sol_us.data(), c->pl_sol_us.size() * sizeof(double));
+  if (stats_warm) memcpy(stats_warm, c->pl_sol_stw.data(), c->pl_sol_stw.size() * sizeof(mind_ilqr_stats));
+  memcpy(stats_full, c->pl_sol_stf.data(), c->pl_sol_stf.size() * sizeof(mind_ilqr_stats));
   return MIND_OK;
 }
 

@@ -148,6 +148,8 @@ struct mind_ctx {
   bool pl_tab_side = false;
   std::vector<mind_aime_node> pl_nodes;
   std::vector<float> pl_flat_prob;
+  std::vector<double> pl_sol_xs, pl_sol_us;          // results of the solves a plan began itself (mind_ilqr_finish_plan)
+  std::vector<mind_ilqr_stats> pl_sol_stw, pl_sol_stf;
   // mind_aime_plan_begin / _finish: the plan on a thread of the library (state 0 idle, 1 running, 2 done)
   std::thread pa_thread;
   std::atomic<int> pa_state{0};

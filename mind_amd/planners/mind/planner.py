@@ -195,9 +195,8 @@ class MINDPlanner:
         # the native AIME plan hands its flattened cost trees over before the scenario trees exist as Python objects: the contingency
         # solves start there, on a worker thread, and run while this thread builds the trees (solve_batch below collects them)
         opt = self.traj_tree_opt
-        ahead = (lambda flats: opt.solve_batch_begin(flats, self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)) \
-            if hasattr(opt, "solve_batch_begin") else None
-        scen_trees = self.scen_tree_gen.branch_aime(lcl_smp, self.agent_obs, on_flats=ahead)
+        solve, ahead = self._solve_hooks(lcl_smp)
+        scen_trees = self.scen_tree_gen.branch_aime(lcl_smp, self.agent_obs, on_flats=ahead, **({"solve": solve} if solve is not None else {}))
         # the device is busy with the contingency solves begun above: a caller's hook runs here (the closed-loop driver prefetches the next
         # replayed observation), the solves are collected afterwards
         hook = idle_hook if idle_hook is not None else getattr(self, "idle_hook", None)
@@ -209,6 +208,24 @@ class MINDPlanner:
     # ---- plan() in three pieces, none of which blocks on the device when its *_ready() says so: a driver that plans several scenes from
     #      one thread (mind_amd/pipelined.py) keeps every scene's native AIME plan (a thread of the library) and contingency solves (queued
     #      on the scene's context) in flight while it does another scene's host work
+    def _solve_hooks(self, lcl_smp):
+        """(solve, on_flats) for this cycle's AIME plan: `solve` = what the native plan needs to begin the contingency solves itself,
+        behind its last kernel (mind_aime_plan_in.solve_*; None when they are not the plain case), `on_flats` = the callback that takes
+        the plan's flattened cost trees as soon as the native call returns -- it adopts the solves the library began, or begins them."""
+        opt = self.traj_tree_opt
+        if not hasattr(opt, "solve_batch_begin"):
+            return None, None
+        rt = getattr(self.network, "rt", None)
+        solve = opt.plan_solve_args(self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity) \
+            if (rt is not None and hasattr(opt, "plan_solve_args") and os.environ.get("MIND_PLAN_BEGINS_SOLVES", "1") != "0") else None
+
+        def ahead(flats, begun=False):
+            if begun and solve is not None:
+                return opt.adopt_begun_solves(flats, solve, rt)
+            return opt.solve_batch_begin(flats, self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)
+        ahead.takes_begun = True
+        return solve, ahead
+
     def _torch_free(self):
         """this planner's pieces issue no torch operation (native AIME plan, native solves and evaluation): they need not switch torch's
         current stream to the context's -- torch.cuda.stream() costs 40 us a time, six times a cycle"""
@@ -226,8 +243,9 @@ class MINDPlanner:
             n0 = self.scen_tree_gen.n_expanded
             self.traj_tree_opt.speculate_warm(self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)
             begin = getattr(self.scen_tree_gen, "branch_aime_begin", None)
-            tok = begin(lcl_smp, self.agent_obs) if begin is not None else None
-            return (lcl_smp, tok, t0, n0)
+            solve, ahead = self._solve_hooks(lcl_smp)
+            tok = begin(lcl_smp, self.agent_obs, **({"solve": solve} if solve is not None else {})) if begin is not None else None
+            return (lcl_smp, tok, t0, n0, solve, ahead)
 
     def plan_started_ready(self, started):
         """the native plan begun by plan_start has finished (plan_begin_finish will not wait for it)"""
@@ -237,13 +255,10 @@ class MINDPlanner:
     def plan_begin_finish(self, started):
         """collects the native plan, starts the contingency solves; returns what plan_begin returns"""
         import time
-        lcl_smp, tok, t0, n0 = started
-        opt = self.traj_tree_opt
-        ahead = (lambda flats: opt.solve_batch_begin(flats, self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)) \
-            if hasattr(opt, "solve_batch_begin") else None
+        lcl_smp, tok, t0, n0, solve, ahead = started
         if tok is None:
             with self._on_own_stream():
-                scen_trees = self.scen_tree_gen.branch_aime(lcl_smp, self.agent_obs, on_flats=ahead)
+                scen_trees = self.scen_tree_gen.branch_aime(lcl_smp, self.agent_obs, on_flats=ahead, **({"solve": solve} if solve is not None else {}))
         else:       # (a plan the library hands back to the round-by-round path runs that path, torch operations included, on the context's stream)
             scen_trees = self.scen_tree_gen.branch_aime_finish(tok, on_flats=ahead, host_context=self._on_own_stream)
         return (lcl_smp, scen_trees, t0, time.perf_counter(), n0)

@@ -257,7 +257,7 @@ class ScenarioTreeGenerator:
             else:
                 want.attach(rt)
 
-    def _native_args(self, lcl_smp, agent_obs):
+    def _native_args(self, lcl_smp, agent_obs, solve=None):
         """(root dict, positional args, keyword args) of the runtime's aime_plan for this cycle, or None when the native plan does not
         apply (wrong horizons, no lanes)"""
         cfg = self.config
@@ -280,7 +280,7 @@ class ScenarioTreeGenerator:
             root = {"TRAJS_TYPE": types, "TRAJS_TID": tids, "TRAJS_CAT": cats}
             self.n_lanes = int(st["num_lanes"])
             return root, (None, None, None, None, self.target_lane, self.target_lane_info, cfg.tar_time_ahead, cfg.tar_dist_thres, cfg.max_depth), \
-                dict(pred_len=self.pred_len, raw=raw, script=modes(pos.shape[0]), prob_floor=floor)
+                dict(pred_len=self.pred_len, raw=raw, script=modes(pos.shape[0]), prob_floor=floor, solve=solve)
         else:
             root = self.process_data(lcl_smp, agent_obs)
             self.prepare_root_data(root)
@@ -290,25 +290,25 @@ class ScenarioTreeGenerator:
             self.n_lanes = int(root["LANES"].shape[0])
             return root, (root, hist, self.lane_graph["lane_ctrs"], self.lane_graph["lane_vecs"], self.target_lane, self.target_lane_info,
                           cfg.tar_time_ahead, cfg.tar_dist_thres, cfg.max_depth), \
-                dict(pred_len=self.pred_len, script=modes(root["ACTORS"].shape[0]), prob_floor=floor)
+                dict(pred_len=self.pred_len, script=modes(root["ACTORS"].shape[0]), prob_floor=floor, solve=solve)
 
-    def _branch_aime_native(self, lcl_smp, agent_obs, on_flats=None):
+    def _branch_aime_native(self, lcl_smp, agent_obs, on_flats=None, solve=None):
         """branch_aime through mind_aime_plan; None = the library left this plan to the round-by-round path.  ``on_flats``: called
         with the plan's flattened cost trees (in get_scenario_tree's order) as soon as the native call returns, BEFORE the tree's
         Python objects are built -- the planner starts the contingency solves there (TrajectoryTreeOptimizer.solve_batch_begin)."""
-        call = self._native_args(lcl_smp, agent_obs)
+        call = self._native_args(lcl_smp, agent_obs, solve)
         if call is None:
             return None
         root, args, kw = call
         return self._native_trees(self.network.rt.aime_plan(*args, **kw), root, on_flats)
 
-    def branch_aime_begin(self, lcl_smp, agent_obs):
+    def branch_aime_begin(self, lcl_smp, agent_obs, solve=None):
         """First half of branch_aime for a driver that plans several scenes from one thread (mind_amd/pipelined.py): starts the native
         plan on a thread of the library (mind_aime_plan_begin) and returns a token, or None when only the blocking paths apply (the caller
         then calls branch_aime).  branch_aime_ready(token) tells whether branch_aime_finish(token, on_flats) would block."""
         if not self._native_ok() or not hasattr(self.network.rt, "aime_plan_begin"):
             return None
-        call = self._native_args(lcl_smp, agent_obs)
+        call = self._native_args(lcl_smp, agent_obs, solve)
         if call is None:
             return None
         root, args, kw = call
@@ -332,8 +332,9 @@ class ScenarioTreeGenerator:
         if res is None:
             return None
         nodes, rows, info = res
-        if on_flats is not None:
-            on_flats([flat for _, flat in info["flats"]])
+        if on_flats is not None:      # (solves_begun: the library began the plan's contingency solves itself, behind its last kernel)
+            on_flats([flat for _, flat in info["flats"]], info.get("solves_begun", False)) if getattr(on_flats, "takes_begun", False) \
+                else on_flats([flat for _, flat in info["flats"]])
         rf = info["root_flags"]
         a = info["a"]
         col = {f: nodes[f] for f in ("round", "scene", "mode")}
@@ -384,9 +385,9 @@ class ScenarioTreeGenerator:
         self.last_trees = trees
         return trees
 
-    def branch_aime(self, lcl_smp, agent_obs, on_flats=None):
+    def branch_aime(self, lcl_smp, agent_obs, on_flats=None, solve=None):
         if self._native_ok():
-            trees = self._branch_aime_native(lcl_smp, agent_obs, on_flats)
+            trees = self._branch_aime_native(lcl_smp, agent_obs, on_flats, solve)
             if trees is not None:
                 return trees
             self.reset()            # (keeps lane graph / target lane: only the per-plan bookkeeping)

@@ -284,6 +284,22 @@ class TrajectoryTreeOptimizer:
         self._pending = dict(call=call, flats=flats, x0=x0, lane=lane, tv=float(target_vel))
         return True
 
+    def plan_solve_args(self, init_state, init_ctrl, target_lane, target_vel):
+        """What a native AIME plan needs to begin this cycle's contingency solves itself (mind_aime_plan_in.solve_*), or None when the
+        solves are not the plain case (a speculated warm start waiting, a shard, an injected solver, overlap off)."""
+        self._drop_pending()
+        if not self.overlap or self.solver is not None or self.shard is not None or self._spec is not None:
+            return None
+        return (ilqr_cfg_from(self.config, "w_opt_cfg"), ilqr_cfg_from(self.config, "opt_cfg"), self._get_init_state(init_state, init_ctrl),
+                np.asarray(target_lane, np.float64), float(target_vel))
+
+    def adopt_begun_solves(self, flats, solve, rt):
+        """the native plan on `rt` began the solves of `flats` with `solve` = plan_solve_args(...): the next solve_batch collects them"""
+        from ...predictor import BegunPlanIlqrCall
+        cw, cf, x0, lane, tv = solve
+        call = BegunPlanIlqrCall(rt, cw, cf, [len(f["parent"]) for f in flats], x0, lane, tv)
+        self._pending = dict(call=call, flats=flats, x0=x0, lane=lane, tv=float(tv))
+
     def _drop_pending(self):
         pend, self._pending = self._pending, None
         if pend is not None:

@@ -140,6 +140,29 @@ class PlanIlqrCall(IlqrCall):
         return self.begin(rt).wait()
 
 
+class BegunPlanIlqrCall(PlanIlqrCall):
+    """The contingency call mind_aime_plan began itself behind its plan (mind_aime_plan_in.solve_*, out.solves_begun): nothing to launch
+    here, ``wait`` collects it (mind_ilqr_finish_plan copies the results out of the library)."""
+
+    def __init__(self, rt, cfg, cfg_full, node_counts, x0, lane, target_vel):
+        super().__init__(rt.lib, cfg, cfg_full, node_counts, x0, lane, target_vel)
+        self.ctx, self._rt, self._begun, self.rc = rt.ctx, rt, True, 0
+
+    def begin(self, rt):
+        return self
+
+    def wait(self):
+        if getattr(self, "_begun", False):
+            self._begun = False
+            rt = self._rt
+            if rt.ctx is None or rt.ctx.value != self.ctx.value:
+                self.rc = _lib.MIND_ESTATE
+            else:
+                self.rc = self.lib.mind_ilqr_finish_plan(self.ctx, self.xs.ctypes.data, self.us.ctypes.data, C.cast(self.st, C.c_void_p),
+                                                         C.cast(self.st_full, C.c_void_p))
+        return self
+
+
 class HipPredictor:
     """Owns a ``mind_ctx`` bound to ``device`` and the current torch stream; ``load_state_dict`` mirrors
     ``ScenePredNet.load_state_dict`` (reference planners/mind/planner.py:46-48), ``predict`` mirrors
@@ -504,7 +527,7 @@ class HipPredictor:
         return out
 
     def aime_plan(self, root, hist, lane_ctrs, lane_vecs, target_lane, target_lane_info, time_ahead, dist_thres, max_depth,
-                  pred_len=50, min_vel=0.5, max_rounds=16, raw=None, script=None, prob_floor=None):
+                  pred_len=50, min_vel=0.5, max_rounds=16, raw=None, script=None, prob_floor=None, solve=None):
         """ScenarioTreeGenerator.branch_aime in one call (mind_aime_plan).  Host-built root: ``root`` = the root scene dict of
         process_data (ACTORS, TRAJS_CTRS, TRAJS_VECS, LANES, TGT_NODES, TGT_RPE, ROT, ORIG, TGT_PTS, TRAJS_TYPE), ``hist`` [a,50,6] its
         world-frame history (x, y, vx, vy, heading, max-sigma), lane_ctrs / lane_vecs the lane graph's anchors.  Device-built root:
@@ -513,7 +536,7 @@ class HipPredictor:
         Returns (nodes: structured array, one record per internal tree node in creation order, rows: float32 [n], info dict) or None
         when the library reports a situation only the round-by-round path handles.  ``script``: see mind_aime_plan_in.script_cls."""
         pi, keep, a, l = self._aime_plan_args(root, hist, lane_ctrs, lane_vecs, target_lane, target_lane_info, time_ahead, dist_thres, max_depth,
-                                              pred_len, min_vel, max_rounds, raw, script, prob_floor)
+                                              pred_len, min_vel, max_rounds, raw, script, prob_floor, solve)
         po = _lib.AimePlanOut()
         rc = self.lib.mind_aime_plan(self.ctx, C.byref(pi), C.byref(po))
         return self._aime_plan_result(rc, po, a, l)
@@ -544,7 +567,7 @@ class HipPredictor:
         return rc == 1
 
     def _aime_plan_args(self, root, hist, lane_ctrs, lane_vecs, target_lane, target_lane_info, time_ahead, dist_thres, max_depth,
-                        pred_len=50, min_vel=0.5, max_rounds=16, raw=None, script=None, prob_floor=None):
+                        pred_len=50, min_vel=0.5, max_rounds=16, raw=None, script=None, prob_floor=None, solve=None):
         f = lambda x: np.ascontiguousarray(x, np.float32)
         fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
         pi = _lib.AimePlanIn()
@@ -581,6 +604,13 @@ class HipPredictor:
             assert all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 for t in script)
             pi.script_cls, pi.script_reg, pi.script_vel = sc.data_ptr(), sr.data_ptr(), sv.data_ptr()
             keep += list(script)
+        if solve is not None:         # (cfg_warm, cfg_full, x0 [6], lane [P,2], target velocity): the plan begins its contingency solves itself
+            cw, cf, x0, lane_s, tv = solve
+            x0 = np.ascontiguousarray(x0, np.float64)
+            lane_s = np.ascontiguousarray(lane_s, np.float64)
+            pi.solve_cfg_warm, pi.solve_cfg_full = C.addressof(cw), C.addressof(cf)
+            pi.solve_x0, pi.solve_lane, pi.solve_n_lane_pts, pi.solve_target_vel = x0.ctypes.data, lane_s.ctypes.data, len(lane_s), float(tv)
+            keep += [cw, cf, x0, lane_s]
         keep.append(arrs)
         return pi, keep, a, l
 
@@ -609,7 +639,8 @@ class HipPredictor:
                 lo, hi = int(off[t]), int(off[t + 1])
                 flats.append((int(top[t]), dict(parent=par[lo:hi], prob=prob[lo:hi], mean=mean[lo:hi], cov=cov[lo:hi])))
         info = dict(n_expanded=po.n_expanded, n_rounds=po.n_rounds, root_flags=po.root_flags, a=a, l=l, flats=flats,
-                    round_scenes=[po.round_scenes[i] for i in range(po.n_rounds)], pair_ms=po.pair_ms, pair_launches=po.pair_launches)
+                    round_scenes=[po.round_scenes[i] for i in range(po.n_rounds)], pair_ms=po.pair_ms, pair_launches=po.pair_launches,
+                    solves_begun=bool(po.solves_begun))
         self.last_aime_info = info
         return nodes, rows, info
 
