@@ -315,7 +315,7 @@ def roofline(m, prec):
     f_hbm = p["bytes"] / s / PEAK_HBM
     bound = "hbm" if f_hbm > f_mfma else "mfma"
     return {
-        "kernel": "k_pair (RelaFusionLayer pair kernel, 6 launches per predictor call)", "bound": bound,
+        "kernel": "k_pair_t (RelaFusionLayer pair kernel, 6 launches per predictor call)", "bound": bound,
         "achieved": (p["bytes"] / s / 1e9) if bound == "hbm" else (p["fold"] / s / 1e12),
         "peak": PEAK_HBM / 1e9 if bound == "hbm" else peak / 1e12, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
         "frac": max(f_hbm, f_mfma), "traffic": None,
@@ -432,10 +432,9 @@ def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees):
     return {"value": 5.0 / plan_s, "unit": "sim steps/s", "cores": best_nt, "kind": "port", "cpu": cpu_model(), "hardware_threads": ncpu,
             "value_1_thread": 5.0 / plan_1,
             "predictor_ms_by_threads": {str(k): v * 1e3 for k, v in per_threads.items()},
-            "sample": f"oracle predictor forward (a={a}, l={l}, torch-CPU fp32) timed at {sorted(per_threads)} threads, best "
-                      f"{t_pred*1e3:.0f} ms at {best_nt} threads ({per_threads[1]*1e3:.0f} ms at 1) + "
-                      f"{n_tree} oracle C tree-iLQR contingency solves with materialised 256x256 fields "
-                      f"({t_ilqr*1e3:.0f} ms each, 1 thread); plan = {expansions} expansions + {len(scen_trees)} solves",
+            "sample": f"1 oracle predictor forward (a={a}, l={l}, torch-CPU fp32; best {t_pred*1e3:.0f} ms at {best_nt} threads of {sorted(per_threads)}, "
+                      f"{per_threads[1]*1e3:.0f} ms at 1) + {n_tree} oracle C tree-iLQR contingency solves ({t_ilqr*1e3:.0f} ms each, 1 thread); "
+                      f"plan = {expansions} expansions + {len(scen_trees)} solves",
             "plan_ms": plan_s * 1e3}
 
 
@@ -655,6 +654,79 @@ def run_fused(args):
         "ms_per_plan_aggregate": dt / (args.steps * P) * 1e3}))
 
 
+# ---- the contract line ------------------------------------------------------------------------------------------------------
+EXTRAS_FILE = "bench_extras.json"
+LINE_LIMIT = 4096
+
+
+def _sig(v, n=5):
+    """floats to n significant digits (the line is a record, not an archive); containers recursively"""
+    if isinstance(v, float):
+        return float(f"{v:.{n}g}")
+    if isinstance(v, dict):
+        return {k: _sig(x, n) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, n) for x in v]
+    return v
+
+
+def contract_line(out, args):
+    """ONE compact JSON line (< 4 KB) with the driver's contract keys, `roofline`, `cpu_baseline` and the few scalars of the other
+    measurements a reader needs; every block of the run in full goes to bench_extras.json beside this script (named in the line)."""
+    path = os.environ.get("MIND_BENCH_EXTRAS", os.path.join(ROOT, EXTRAS_FILE))
+    try:
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        extras = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError as e:
+        extras = f"not written ({type(e).__name__})"
+
+    def pick(d, *keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+    line = pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line["config"] = pick(out["config"], "workload", "agents", "lane_polylines", "expansions_per_plan", "scenario_trees_per_plan", "weights", "parallelism", "sim_steps_timed")
+    line["nodes_expanded_per_s"] = out.get("nodes_expanded_per_s")
+    r = out.get("roofline")
+    if r:
+        line["roofline"] = dict(pick(r, "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
+                                     "launches_profiled"), hbm_frac=r["hbm"]["frac"], mfma_frac=r["mfma"]["frac"], arith=r["mfma"]["arith"])
+    else:
+        line["roofline"] = None
+    c = out.get("cpu_baseline")
+    if c:
+        line["cpu_baseline"] = pick(c, "value", "unit", "cores", "kind", "cpu", "hardware_threads", "value_1_thread", "sample")
+    k = out.get("k_ilqr")
+    if k:
+        line["k_ilqr"] = pick(k, "kernel_ms_per_launch", "share_of_step", "cost_trees_per_launch", "cus_busy")
+    line["breakdown_ms"] = pick(out.get("breakdown_ms") or {}, "aime", "ilqr")
+    if "exact_fp32" in out:
+        line["exact_fp32"] = pick(out["exact_fp32"], "value", "ms_per_step")
+    for key in ("tree", "tree_sharded", "tree_replicas", "stress", "stress_bf16", "stress_deep", "stress_deeper"):
+        t = out.get(key)
+        if not isinstance(t, dict):
+            continue
+        if "error" in t:
+            line[key] = {"error": t["error"][:120]}
+            continue
+        b = pick(t, "ms_per_plan", "nodes_expanded_per_s", "k_ilqr_ms_per_launch", "gathered_mb_per_plan", "collectives_per_plan", "speedup_vs_1")
+        if "k_pair" in t:
+            b["k_pair"] = pick(t["k_pair"], "hbm_frac", "avg_launch_ms")
+        line[key] = b
+    for key in ("collectives_per_plan", "gathered_mb_per_plan"):
+        if key in out:
+            line[key] = out[key]
+    line["extras_file"] = extras
+    text = json.dumps(_sig(line), separators=(",", ":"))
+    if len(text) > LINE_LIMIT:          # never let an extra cost the contract line: drop the optional blocks, largest first
+        for key in ("stress_deep", "stress_bf16", "stress", "stress_deeper", "tree_replicas", "breakdown_ms", "k_ilqr", "tree", "tree_sharded"):
+            line.pop(key, None)
+            text = json.dumps(_sig(line), separators=(",", ":"))
+            if len(text) <= LINE_LIMIT:
+                break
+    return text
+
+
 # ---- launch ---------------------------------------------------------------------------------------------------------------
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run (one process per
@@ -735,22 +807,18 @@ def main():
     out = {
         "metric": METRIC, "value": value, "unit": "sim steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": m["dt"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
-        "dtype": {"f32": "f32", "bf16x3": "bf16x3 (bf16 hi+lo split operands, fp32 accumulate: fp32-accurate)", "bf16": "bf16"}[prec]
-                 + " pair kernel, f32 elsewhere in the predictor / f64 iLQR",
-        "data": ("recorded AV2 scene (map + tracks of the reference's %s, tests/golden/scenes) with synthetic formula-initialised "
-                 "weights" % args.workload) if real else "synthetic",
+        "dtype": {"f32": "f32", "bf16x3": "bf16x3 (bf16 hi+lo split operands, fp32 accumulate)", "bf16": "bf16"}[prec]
+                 + " pair kernel + ActorNet, f32 elsewhere in the predictor, f64 iLQR",
+        "data": ("recorded AV2 scene (map + tracks of the reference's %s, tests/golden/scenes), formula-initialised weights" % args.workload) if real else "synthetic",
         "nodes_expanded_per_s": m["expansions_all"] / m["dt"],
         "config": {"workload": (f"BASELINE configs[1]: closed loop on the recorded scene {args.workload}" if real else f"{args.workload}-like synthetic scene") +
-                               f": {a} agents x {l} lane polylines (N={a+l+1} tokens), "
-                               f"one closed-loop planning cycle per step = AIME tree ({exp_plan:.1f} node expansions, "
-                               + (f"the predictor's own modes with the formula weights {m['weights']}, exactly what the reference computes with these weights" if real else
-                                  "scripted mode branching on top of the real predictor forward: no trained checkpoint exists") + ") + "
-                               f"tree-iLQR warm+full solves of {pl.timing['n_scen_trees']} scenario trees; closed loop: {m['sim_steps']} simulator steps "
-                               f"(0.02 s) for {args.steps} plans",
+                               f", {a} agents x {l} lane polylines (N={a+l+1}); step = one planning cycle (5 simulator steps of 0.02 s): AIME tree "
+                               f"({exp_plan:.1f} expansions, " + ("the predictor's own modes" if real else "scripted mode branching on the real predictor forward") +
+                               f") + tree-iLQR warm+full solves of {pl.timing['n_scen_trees']} scenario trees",
                    "agents": a, "lane_polylines": l, "expansions_per_plan": exp_plan, "sim_steps_timed": m["sim_steps"],
                    "scenario_trees_per_plan": pl.timing["n_scen_trees"], "weights": m["weights"],
-                   "parallelism": (f"one plan sharded over {world} GPUs (AIME rounds block-sharded, solves round-robin, RCCL all-gather/broadcast per round)" if shard
-                                   else f"{world} independent closed loops (one per GPU, no data-path collective)")},
+                   "parallelism": (f"one plan sharded over {world} GPUs (AIME rounds block-sharded, solves round-robin)" if shard
+                                   else f"{world} independent closed loop(s), one per GPU, no data-path collective")},
         "roofline": roofline(m, prec),
         # the tree-iLQR kernel is latency-bound (serial depth x iterations): reported as rates, not against a roofline
         "ilqr": {"solves_per_s": ctr["solves"] / m["dt"], "iterations_per_s": ctr["iterations"] / m["dt"],
@@ -786,6 +854,9 @@ def main():
                 out["tree_replicas"] = dict(summarize(t, prec), workload="cfg4tree on every rank, one independent scene per rank (full scripted 6-ary "
                                             "depth-4 AIME tree on the real predictor forward); nodes_expanded_per_s is the whole job's", n_gpus=world,
                                             scaling="weak", plans_timed=args.tree_steps)
+                if "ms_per_plan" in out.get("tree_sharded", {}):
+                    # the same tree on one GPU (a replica's plan) over the plan all ranks share: north_star's strong-scaling figure
+                    out["tree_sharded"]["speedup_vs_1"] = out["tree_replicas"]["ms_per_plan"] / out["tree_sharded"]["ms_per_plan"]
             except Exception as e:       # noqa: BLE001
                 out["tree_replicas"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if rank == 0 and world == 1:
@@ -840,7 +911,7 @@ def main():
             except Exception as e:       # noqa: BLE001
                 out["stress_deeper"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if rank == 0:
-        print(json.dumps(out))
+        print(contract_line(out, args))
     dist.close()
 
 

@@ -127,19 +127,25 @@ def test_bench_multi_rank_contract_weak_and_strong():
     assert abs(s["value"] - 20 / (s["ms_per_step"] * 4e-3)) < 1e-6 * s["value"]   # one scene: steps are not multiplied by N
 
 
-def test_bench_spawns_its_own_ranks_and_checks_the_world_size():
+def test_bench_spawns_its_own_ranks_and_checks_the_world_size(tmp_path):
     """`python bench.py --gpus 2` with no launcher in the environment starts the two ranks itself (torch.distributed.run on
     127.0.0.1) and reports n_gpus = 2; the default multi-rank line carries the sharded cfg4-tree plan next to the replicas;
     a launcher world that disagrees with --gpus is refused."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["MIND_BENCH_EXTRAS"] = str(tmp_path / "bench_extras.json")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
                           "--tree-steps", "1"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "recorded scene demo_1" in d["config"]["workload"]
+    assert len(lines[0]) < 4096
+    c = json.loads(lines[0])
+    assert c["n_gpus"] == 2 and c["scaling"] == "weak" and "recorded scene demo_1" in c["config"]["workload"]
+    # the compact line carries north_star's strong-scaling figures of the sharded tree; the blocks in full are in the extras file
+    assert c["tree_sharded"]["nodes_expanded_per_s"] > 0 and c["tree_sharded"]["speedup_vs_1"] > 0 and c["tree_sharded"]["gathered_mb_per_plan"] > 0
+    assert c["tree_replicas"]["nodes_expanded_per_s"] > 0
+    d = json.load(open(env["MIND_BENCH_EXTRAS"]))
     t = d["tree_sharded"]
     assert t["n_gpus"] == 2 and t["scaling"] == "strong" and t["expansions_per_plan"] == 259 and t["collectives_per_plan"] >= 9
     w = d["tree_replicas"]          # the same tree, one independent scene per rank: twice the expansions in the same plan time

@@ -28,7 +28,7 @@ for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); r = d.get('roofline') or {}
         print('$1', round(d['value'], 1), d['unit'], '|', round(d['ms_per_step'], 3), 'ms per step | aime', round(d['breakdown_ms']['aime'], 2), 'ilqr', round(d['breakdown_ms']['ilqr'], 2),
-              '| pair hbm_frac', round((r.get('hbm') or {}).get('frac', 0), 3), 'avg launch ms', round(r.get('avg_launch_ms', 0), 3))
+              '| pair hbm_frac', round(r.get('hbm_frac', 0), 3), 'avg launch ms', round(r.get('avg_launch_ms', 0), 3), '| k_ilqr ms', round((d.get('k_ilqr') or {}).get('kernel_ms_per_launch', 0), 3))
 "
 }
 
@@ -38,11 +38,11 @@ final)
   grep "^\[demo\|^\.\[demo\|same tree chosen\|cycles agree outright\|^demo_\|^\.demo_\|^stress" $O/pytest_gpu_full.txt | sed 's/^\.*//' > $O/pytest_gpu_parity_lines.txt
   tail -25 $O/pytest_gpu_full.txt > $O/pytest_gpu.txt
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-  ( time timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err ) 2>&1 | grep real
-  tail -2 $O/bench.err
+  ( time MIND_BENCH_EXTRAS=$ROOT/$O/bench_extras.json timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err ) 2>&1 | grep real
+  tail -2 $O/bench.err; wc -c $O/bench.json
   python - <<PY
 import json
-d = json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
+d = json.load(open("$O/bench_extras.json"))
 print(d["value"], d["ms_per_step"], d["breakdown_ms"]["aime"], d["breakdown_ms"]["ilqr"])
 print("roofline", {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "frac", "traffic")})
 print("k_ilqr", d["k_ilqr"]["kernel_ms_per_launch"], d["k_ilqr"]["phase_share"])
