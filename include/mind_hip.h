@@ -387,7 +387,9 @@ typedef struct {
  *
  * The transport is the caller's: a function that performs a collective on DEVICE buffers of this context's device,
  *   MIND_XCHG_ALLGATHER:  recv [world][bytes] <- every rank's send [bytes], in rank order;
- *   MIND_XCHG_ALLREDUCE:  recv [bytes / 4 floats] <- sum over the ranks of send (send may equal recv).
+ *   MIND_XCHG_ALLREDUCE:  recv [bytes / 4 words] <- sum over the ranks of send (send may equal recv).  Every word is non-zero on at most
+ *                         one rank (its owner), so the transport should sum 32-bit INTEGERS: the owner's bits then arrive unchanged
+ *                         (a float sum would turn an owner's -0.0 into +0.0).
  * It is called with everything the library queued on the context's stream complete, and must return with the result complete
  * (mind_amd/parallel.py: torch.distributed -- RCCL over xGMI on a node, gloo in the tests).  world <= 1 or fn == NULL switches
  * the sharding off; force != 0 runs the exchanges of a one-rank group too (tests: RCCL on a one-GPU box). */
@@ -404,12 +406,17 @@ int mind_last_exchange_stats(mind_ctx *ctx, long long *collectives, long long *b
 int mind_aime_plan(mind_ctx *ctx, const mind_aime_plan_in *in, mind_aime_plan_out *out);
 /* mind_aime_plan in two halves, for a host thread that plans several scenes (one context each): _begin copies *in (the arrays it
  * points to must stay valid until _finish) and runs the plan on a thread of the library; _poll returns 1 while it runs, 0 once
- * _finish will not block; _finish returns what mind_aime_plan would have.  No other call on the context between _begin and _finish.
+ * _finish will not block; _finish returns what mind_aime_plan would have.  No other call on the context between _begin and _finish
+ * (a second _begin while the plan runs returns MIND_ESTATE; a finished plan that was never collected is dropped by the next _begin).
  * mind_ctx_busy: 1 while work queued on the context's stream has not completed (e.g. the contingency solves begun with
  * mind_ilqr_contingency_begin), 0 once collecting it will not block. */
 /* collects the contingency solves a plan began itself (out->solves_begun): waits for them and copies the results of all its
- * scenario trees, concatenated in tree order: xs [M_total, 6], us [M_total, 2], the warm-start and full fits' statistics [n_trees]. */
-int mind_ilqr_finish_plan(mind_ctx *ctx, double *xs, double *us, mind_ilqr_stats *stats_warm, mind_ilqr_stats *stats_full);
+ * scenario trees, concatenated in tree order: xs [n_nodes, 6], us [n_nodes, 2], the warm-start and full fits' statistics [n_trees].
+ * n_nodes / n_trees = out->tree_off[out->n_trees] / out->n_trees of the plan the caller collects for: MIND_EINVAL (nothing copied) when
+ * the pending solves belong to a plan of another shape, MIND_ESTATE when none is pending.  Solves that are never collected are
+ * drained and dropped by the context's next mind_aime_plan. */
+int mind_ilqr_finish_plan(mind_ctx *ctx, int n_nodes, int n_trees, double *xs, double *us, mind_ilqr_stats *stats_warm,
+                          mind_ilqr_stats *stats_full);
 int mind_aime_plan_begin(mind_ctx *ctx, const mind_aime_plan_in *in);
 int mind_aime_plan_poll(mind_ctx *ctx);
 int mind_aime_plan_finish(mind_ctx *ctx, mind_aime_plan_out *out);

@@ -166,7 +166,7 @@ def load():
     lib.mind_aime_plan_poll.argtypes = [C.c_void_p]
     lib.mind_aime_plan_finish.argtypes = [C.c_void_p, C.POINTER(AimePlanOut)]
     lib.mind_ctx_busy.argtypes = [C.c_void_p]
-    lib.mind_ilqr_finish_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mind_ilqr_finish_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mind_set_pair_precision.argtypes = [C.c_void_p, C.c_int]
     lib.mind_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.mind_last_ilqr_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]

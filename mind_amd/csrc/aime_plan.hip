@@ -95,6 +95,16 @@ int pl_copy_segs(mind_ctx *c, const std::vector<CopySeg> &segs) {
 extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aime_plan_out *out) {
   if (!c || !in || !out) return MIND_EINVAL;
   if (!c->have_weights) return fail(c, MIND_ESTATE, "weights not loaded");
+  if (c->il_finish) {
+    // A tree-iLQR call is pending on this context.  The solves a plan began itself write into the library's own pl_sol_* vectors and
+    // staging tables, which this plan is about to resize: they are drained and dropped here (their caller gave them up -- an exception
+    // between plan_start and plan_end, a planner that was reset).  A call begun by the caller (mind_ilqr_contingency_begin) writes into
+    // the caller's arrays, whose lifetime the library cannot know: that one is refused.
+    if (!c->il_finish_owned)
+      return fail(c, MIND_ESTATE, "mind_aime_plan: a tree-iLQR call begun with mind_ilqr_contingency_begin is pending on this context (mind_ilqr_finish first)");
+    (void)mind_ilqr_finish(c);
+    c->pl_sol_xs.clear(); c->pl_sol_us.clear(); c->pl_sol_stw.clear(); c->pl_sol_stf.clear();
+  }
   const int a = in->n_agents, l = in->n_lanes, P = in->n_lane_pts;
   const bool raw = in->raw_pos != nullptr;      // root scene featurised on the device
   if (a <= 0 || l <= 0 || P < 12 || !in->types || !in->target_lane || !in->target_lane_info ||
@@ -669,14 +679,21 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     const int rs = mind_ilqr_contingency_begin_plan(c, in->solve_cfg_warm, in->solve_cfg_full, in->solve_x0, in->solve_lane, in->solve_n_lane_pts,
                                                     in->solve_target_vel, c->pl_sol_xs.data(), c->pl_sol_us.data(), c->pl_sol_stw.data(), c->pl_sol_stf.data());
     out->solves_begun = rs == MIND_OK ? 1 : 0;      // (a failed begin is not the plan's failure: the caller then solves the usual way)
+    c->il_finish_owned = rs == MIND_OK;
   }
   return MIND_OK;
 }
 
-extern "C" int mind_ilqr_finish_plan(mind_ctx *c, double *xs, double *us, mind_ilqr_stats *stats_warm, mind_ilqr_stats *stats_full) {
+extern "C" int mind_ilqr_finish_plan(mind_ctx *c, int n_nodes, int n_trees, double *xs, double *us, mind_ilqr_stats *stats_warm, mind_ilqr_stats *stats_full) {
   if (!c || !xs || !us || !stats_full) return MIND_EINVAL;
+  if (!c->il_finish || !c->il_finish_owned) return fail(c, MIND_ESTATE, "mind_ilqr_finish_plan: no plan-begun tree-iLQR call is pending on this context");
   const int rc = mind_ilqr_finish(c);
   if (rc) return rc;
+  // the caller sized xs / us / stats_* from ITS plan's tree table: refuse to copy another plan's results into them
+  if ((size_t)n_nodes * 6 != c->pl_sol_xs.size() || (size_t)n_trees != c->pl_sol_stf.size() || (size_t)n_trees + 1 != c->pl_tree_off.size() ||
+      c->pl_tree_off[(size_t)n_trees] != n_nodes)
+    return fail(c, MIND_EINVAL, "mind_ilqr_finish_plan: the caller expects %d nodes in %d trees, the pending solves hold %zu in %zu", n_nodes, n_trees,
+                c->pl_sol_xs.size() / 6, c->pl_sol_stf.size());
   memcpy(xs, c->pl_sol_xs.data(), c->pl_sol_xs.size() * sizeof(double));
   memcpy(us, c->pl_sol_us.data(), c->pl_sol_us.size() * sizeof(double));
   if (stats_warm) memcpy(stats_warm, c->pl_sol_stw.data(), c->pl_sol_stw.size() * sizeof(mind_ilqr_stats));
@@ -688,7 +705,8 @@ extern "C" int mind_ilqr_finish_plan(mind_ctx *c, double *xs, double *us, mind_i
 // ---- mind_aime_plan in two halves (a host thread that plans several scenes, one context each: mind_amd/pipelined.py)
 extern "C" int mind_aime_plan_begin(mind_ctx *c, const mind_aime_plan_in *in) {
   if (!c || !in) return MIND_EINVAL;
-  if (c->pa_state.load(std::memory_order_acquire) != 0) return fail(c, MIND_ESTATE, "mind_aime_plan_begin: a plan is pending on this context");
+  // a plan that is still RUNNING must be collected first; one that finished and was never collected (its caller gave it up) is dropped
+  if (c->pa_state.load(std::memory_order_acquire) == 1) return fail(c, MIND_ESTATE, "mind_aime_plan_begin: a plan is running on this context");
   if (c->pa_thread.joinable()) c->pa_thread.join();
   c->pa_in = *in;
   memset(&c->pa_out, 0, sizeof(c->pa_out));

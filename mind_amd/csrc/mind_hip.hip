@@ -171,6 +171,7 @@ struct mind_ctx {
   bool ilqr_test_starve = false;
   // per-iteration traces of the last tree-iLQR call (mind_last_ilqr_trace): device address per tree, rows per phase, iterations run
   std::function<int()> il_finish;     // the pending half of a call begun with mind_ilqr_contingency_begin
+  bool il_finish_owned = false;       // ... whose outputs are library buffers (the solves a plan began itself): may be drained and dropped
   bool il_begin_only = false;
   std::vector<const double *> il_trace_dev;
   std::vector<int> il_trace_its;      // [tree][phase 2]
@@ -1909,6 +1910,7 @@ extern "C" int mind_ilqr_finish(mind_ctx *c) {
   if (!c->il_finish) return fail(c, MIND_ESTATE, "mind_ilqr_finish: no tree-iLQR call was begun on this context");
   std::function<int()> fin = std::move(c->il_finish);
   c->il_finish = nullptr;
+  c->il_finish_owned = false;
   return fin();
 }
 

@@ -116,9 +116,11 @@ class Shard:
                         torch.cuda.current_stream().synchronize()
                     self.bytes_gathered += nbytes * W
                 else:
-                    t = dev_bytes(recv, nbytes).view(torch.float32)
+                    # the plan completes buffers whose entries every rank but the owner left zero: summed as INTEGERS the owner's bits arrive
+                    # unchanged whatever the transport's arithmetic (a float sum turns an owner's -0.0 into +0.0)
+                    t = dev_bytes(recv, nbytes).view(torch.int32)
                     if send != recv:
-                        t.copy_(dev_bytes(send, nbytes).view(torch.float32))
+                        t.copy_(dev_bytes(send, nbytes).view(torch.int32))
                     if self.backend == "nccl":
                         dist.all_reduce(t, group=self.group)
                         torch.cuda.current_stream().synchronize()

@@ -230,7 +230,10 @@ class MINDPlanner:
         """this planner's pieces issue no torch operation (native AIME plan, native solves and evaluation): they need not switch torch's
         current stream to the context's -- torch.cuda.stream() costs 40 us a time, six times a cycle"""
         ok = getattr(self.scen_tree_gen, "_native_ok", None)
-        return contextlib_null() if (ok is not None and ok() and self.traj_tree_opt.solver is None) else self._on_own_stream()
+        # (a scripted network -- mind_amd/synth.py -- builds and uploads its mode tensors through torch before the native plan reads them on
+        # the context's stream: those planners keep the stream switch)
+        scripted = hasattr(getattr(self.scen_tree_gen, "network", None), "_modes")
+        return contextlib_null() if (ok is not None and ok() and not scripted and self.traj_tree_opt.solver is None) else self._on_own_stream()
 
     def plan_start(self, lcl_smp):
         """host work before the AIME rounds + the start of the native plan; returns a token for plan_started_ready / plan_begin_finish"""

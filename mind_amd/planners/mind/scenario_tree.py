@@ -368,11 +368,12 @@ class ScenarioTreeGenerator:
         # takes `_flat` instead of walking the nodes), in get_scenario_tree's order; their Python nodes -- tens of thousands on the deep
         # stress trees, a third of such a plan's wall time -- are built by the reference walk below only when somebody reads them.
         shared = {}
+        plan_tree = self.tree         # THIS plan's AIME tree: a scenario tree first read after the next reset() / plan must not see another one's
 
         def build_scenario_tree(idx):
             def build(tree):
                 if "full" not in shared:
-                    shared["full"] = self._scenario_trees_from_tree()
+                    shared["full"] = self._scenario_trees_from_tree(plan_tree)
                 src = shared["full"][idx]
                 tree._nodes, tree._lv, tree.root = src.nodes, src._leaves, src.root
             return build
@@ -1149,16 +1150,18 @@ class ScenarioTreeGenerator:
             return self.last_trees
         return self._scenario_trees_from_tree()
 
-    def _scenario_trees_from_tree(self):
-        root = self.tree.get_root()
-        for node in self.get_end_set():              # label every node on a finished branch
+    def _scenario_trees_from_tree(self, tree=None):
+        """tree: the AIME tree to walk (default: the generator's current one)"""
+        src = self.tree if tree is None else tree
+        root = src.get_root()
+        for node in [n for n in src.get_leaf_nodes() if n.data.end_flag]:              # (get_end_set) label every node on a finished branch
             while node.parent_key is not None:
                 node.data.end_flag = True
-                node = self.tree.get_node(node.parent_key)
+                node = src.get_node(node.parent_key)
         probs = {}
         order = {}
         for key in root.children_keys:
-            top = self.tree.get_node(key)
+            top = src.get_node(key)
             if not top.data.end_flag:
                 continue
             probs[key] = 1.0
@@ -1166,7 +1169,7 @@ class ScenarioTreeGenerator:
             queue = [top]
             while queue:
                 cur = queue.pop(0)
-                ch = [self.tree.get_node(k) for k in cur.children_keys]
+                ch = [src.get_node(k) for k in cur.children_keys]
                 ch = [c for c in ch if c.data.end_flag]
                 total = 0.0
                 for c in ch:
@@ -1180,7 +1183,7 @@ class ScenarioTreeGenerator:
         for key, keys in order.items():
             t = Tree()
             for k in keys:
-                n = self.tree.get_node(k)
+                n = src.get_node(k)
                 d = n.data.data
                 dur = d["END_T"] - d["CUR_T"]
                 t.add_node(Node(k, None if k == key else n.parent_key,

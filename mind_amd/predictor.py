@@ -128,6 +128,7 @@ class PlanIlqrCall(IlqrCall):
 
     def begin(self, rt):
         self.ctx = rt.ctx
+        self._rt = rt              # (wait() refuses to collect from a runtime that was closed meanwhile)
         if getattr(rt, "_ilqr_wgs_now", None) == 1:
             rt._ilqr_wgs_now = getattr(rt, "_ilqr_wgs_user", int(os.environ.get("MIND_ILQR_WGS", "16")))
             self.lib.mind_set_tuning(rt.ctx, b"ilqr_wgs", rt._ilqr_wgs_now)
@@ -158,8 +159,8 @@ class BegunPlanIlqrCall(PlanIlqrCall):
             if rt.ctx is None or rt.ctx.value != self.ctx.value:
                 self.rc = _lib.MIND_ESTATE
             else:
-                self.rc = self.lib.mind_ilqr_finish_plan(self.ctx, self.xs.ctypes.data, self.us.ctypes.data, C.cast(self.st, C.c_void_p),
-                                                         C.cast(self.st_full, C.c_void_p))
+                self.rc = self.lib.mind_ilqr_finish_plan(self.ctx, int(sum(self.Ms)), self.n, self.xs.ctypes.data, self.us.ctypes.data,
+                                                         C.cast(self.st, C.c_void_p), C.cast(self.st_full, C.c_void_p))
         return self
 
 

@@ -103,3 +103,30 @@ def test_device_built_root_equals_the_host_featuriser(scene):
         sims[1][1].state, sims[1][1].ctrl = sims[0][1].state.copy(), np.array(sims[0][1].ctrl).copy()      # keep the two loops on one trajectory
     print(f"{scene}: device-built vs host-built root, max |agent position difference| over 10 cycles = {worst:.2e} m (float32 ulp there {ulp:.1e})")
     assert sims[0][0].scen_tree_gen.n_native_plans == 10
+
+
+def test_lazy_scenario_tree_read_after_the_next_plan_is_still_its_own_plans():
+    """The drop-in path stores frame['scen_tree'] = res[0] and reads it at render time (the reference's simulator.py:92-107): the LazyTree a plan
+    returns must materialise from THAT plan's AIME tree even when it is first touched after the generator has planned (or been reset) again."""
+    sys.path.insert(0, ROOT)
+    from bench import BRANCHING_WEIGHTS, WORKLOADS, make_closed_loop
+    runs = []
+    for late in (False, True):
+        pl, sim, w = make_closed_loop(dict(WORKLOADS["demo_1"]), ckpt=BRANCHING_WEIGHTS, speculative=False)
+        kept = []
+        for cycle in range(4):
+            sim.run_plans(1)
+            trees = pl.scen_tree_gen.last_trees
+            assert trees is not None
+            if not late:
+                kept.append(_flat(trees))                 # materialised at once
+            else:
+                kept.append(trees)                        # ... or only after every later plan and a reset
+        if late:
+            pl.scen_tree_gen.reset()
+            kept = [_flat(t) for t in kept]
+        runs.append(kept)
+    for a, b in zip(*runs):
+        assert len(a) == len(b) > 0
+        for x, y in zip(a, b):
+            assert x[0] == y[0] and x[1] == y[1] and all(np.array_equal(p, q) for p, q in zip(x[2:], y[2:]))

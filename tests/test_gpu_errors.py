@@ -62,3 +62,47 @@ def test_context_creation_rejects_bad_device():
     ctx = C.c_void_p()
     assert lib.mind_ctx_create(999, None, C.byref(ctx)) == _lib.MIND_EINVAL
     assert lib.mind_ctx_create(0, None, None) == _lib.MIND_EINVAL
+
+
+def test_plan_begun_solves_that_are_never_collected_do_not_outlive_their_plan():
+    """The native plan begins its contingency solves itself (mind_aime_plan_in.solve_*) and keeps their outputs in library vectors until
+    mind_ilqr_finish_plan.  A caller that gives such a plan up (an exception between plan_start and plan_end) must not leave the next plan a
+    dangling closure: the next mind_aime_plan drains and drops it, mind_ilqr_finish_plan refuses to copy a plan of another shape into the
+    caller's arrays, and a finished-but-uncollected mind_aime_plan_begin does not block the next one."""
+    import ctypes as C
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    from bench import BRANCHING_WEIGHTS, WORKLOADS, make_closed_loop
+    ref_pl, ref_sim, _ = make_closed_loop(dict(WORKLOADS["demo_1"]), ckpt=BRANCHING_WEIGHTS, speculative=False)
+    pl, sim, _ = make_closed_loop(dict(WORKLOADS["demo_1"]), ckpt=BRANCHING_WEIGHTS, speculative=False, own_context=True)
+    rt = pl.network.rt
+    for cycle in range(3):
+        lcl_ref, lcl = None, None
+        while lcl is None:
+            lcl_ref, lcl = ref_sim.step_begin(), sim.step_begin()
+            if lcl is None:
+                ref_sim.step_end(None); sim.step_end(None)
+        want = ref_pl.plan(lcl_ref)
+        # 1. a plan begun in three pieces and abandoned after its solves were begun by the library
+        begun = pl.plan_begin_finish(pl.plan_start(lcl))
+        assert pl.timing is not None and len(begun[1]) > 0
+        if cycle == 0:
+            # 2. collecting with the wrong shape copies nothing and says so; the pending half is gone afterwards
+            xs, us = np.zeros((3, 6)), np.zeros((3, 2))
+            st = (_lib.IlqrStats * 1)()
+            rc = rt.lib.mind_ilqr_finish_plan(rt.ctx, 3, 1, xs.ctypes.data, us.ctypes.data, None, C.cast(st, C.c_void_p))
+            assert rc == _lib.MIND_EINVAL and not xs.any()
+            rc = rt.lib.mind_ilqr_finish_plan(rt.ctx, 3, 1, xs.ctypes.data, us.ctypes.data, None, C.cast(st, C.c_void_p))
+            assert rc == _lib.MIND_ESTATE
+        if cycle == 1:
+            # 3. a native plan that ran to its end on the library's thread and is never collected
+            started = pl.plan_start(lcl)
+            while not pl.plan_started_ready(started):
+                pass
+        pl.traj_tree_opt._pending = None                # (what an exception handler around the pieces would leave behind)
+        got = pl.plan(lcl)
+        assert got[0] and want[0] and np.array_equal(np.asarray(got[1]), np.asarray(want[1])), cycle
+        assert pl.timing["best_traj_idx"] == ref_pl.timing["best_traj_idx"]
+        ref_sim.step_end(want); sim.step_end(got)

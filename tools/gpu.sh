@@ -13,6 +13,7 @@
 #   trace <tag> actor|dec|token         diagnostic build with -DMIND_{ACTOR,DEC,TOKEN}_TRACE: per-stage cycles printed by block 0
 #   timeline <tag>                      GPU timeline (kernels + copies) of one planning cycle of the headline loop
 #   config3 <tag>                       BASELINE config 3: demo_1..4 on one GPU as threads / fused rounds / pipelined / processes
+#   ilqr-phase <tag> [workload] [plans] k_ilqr's own phase cycle counters per tree (and wave 0's fine-grained slots with a -DIL_PROFILE build)
 #   shard-overhead <tag>                the sharded native plan on ONE rank: plain process vs a one-rank nccl group with every exchange executed
 set -u
 cmd=${1:?command}; tag=${2:?tag}; shift 2
@@ -138,6 +139,15 @@ w = d["wall_ms"][2:]
 print("$mode: ms per plan", w, "mean", round(sum(w) / len(w), 2), "| collectives", d["collectives"], "gathered MB", round(d["gathered"] / 1e6, 1), "| aime ms/plan", round(d["timing"]["aime_s"] / d["timing"]["plans"] * 1e3, 2))
 PY
   done | tee $O/summary.txt
+  ;;
+ilqr-phase)
+  # per-phase cycle counters of k_ilqr (stats of every tree of a plan) on the headline loop; with a -DIL_PROFILE build (diag_build/libmind_hip_ilprof.so,
+  # compiled in the build container: hipcc ... -DIL_PROFILE) also the fine-grained slots of wave 0
+  wl=${1:-demo_1}; n=${2:-2}
+  timeout 300 python tools/gpu_ilqr_phase.py $wl $n formula_branching:20240121 2>&1 | grep "^\[k_ilqr" > $O/ilqr_phase.txt; tail -12 $O/ilqr_phase.txt
+  if [ -f diag_build/libmind_hip_ilprof.so ]; then
+    MIND_HIP_LIB=$ROOT/diag_build/libmind_hip_ilprof.so timeout 300 python tools/gpu_ilqr_phase.py $wl $n formula_branching:20240121 2>&1 | grep "^\[k_ilqr" > $O/ilqr_phase_prof.txt; tail -24 $O/ilqr_phase_prof.txt
+  fi
   ;;
 *) echo "unknown command $cmd"; exit 2;;
 esac
