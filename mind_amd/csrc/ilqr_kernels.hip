@@ -29,7 +29,9 @@
 #ifndef IL_SPEC_OVERSUB
 #define IL_SPEC_OVERSUB 1   // (slot, segment) items per wave tolerated at the widest segment level
 #endif
-#define IL_SPEC 4     // Levenberg-Marquardt values evaluated speculatively per step (see k_ilqr)
+#define IL_SPEC 4     // Levenberg-Marquardt values evaluated speculatively per step INSIDE one workgroup (see k_ilqr)
+#define IL_SLOTS 8    // ... and by the follower workgroups of a tree (k_ilqr<GEN, 2>: one Levenberg-Marquardt value per workgroup); per-slot arrays
+                      // hold IL_SLOTS sets in that mode
 #define IL_MAXA 128   // agents per scene staged in LDS (cfg4: 64, stress: 128)
 #define IL_REL 15     // relevant-agent list length per node
 #define IL_RA 64      // doubles per node in T.relag: (1 + IL_REL) records x 4
@@ -58,6 +60,20 @@ template <class T> struct GP {
   __host__ __device__ __forceinline__ GP &operator+=(size_t o) { p += o; return *this; }
   __host__ __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
 };
+// Control block of one cost tree whose Levenberg-Marquardt slots are spread over workgroups (k_ilqr<GEN, 2>): workgroup 0 (the master) runs
+// iLQR.fit as a single workgroup does and evaluates slot 0 of every pass itself; workgroup s > 0 (a follower) waits for the master's command and
+// evaluates slot s -- backward sweep at the mu the LM schedule reaches after s rejections, line search, candidate costs -- from the same nominal
+// trajectory.  One exchange per pass: the master publishes {mu, delta, slot count, phase} (release, then gen + 1), a follower publishes its ten
+// candidate costs and its singular flag (release, then done[s] = gen).  The master looks at a follower's result only when every earlier slot
+// was rejected, so a pass whose slot 0 is accepted never waits.  Zeroed by the host with the upload.
+struct IlSlotCtl {
+  unsigned gen, cmd, alive, pad;         // cmd = slots | phase << 8 | exit << 16; alive = bit s set once workgroup s runs
+  double mu, delta;
+  unsigned done[IL_SLOTS];
+  unsigned sing[IL_SLOTS];
+  double Jnew[IL_SLOTS][IL_NA];
+};
+
 struct IlqrTreeDev {
   int M, n_agents, n_levels, pad;
   GP<const int> parent;        // [M]
@@ -99,6 +115,7 @@ struct IlqrTreeDev {
   // J of the nominal trajectory, accepted alpha index (-1: step rejected, -2: singular Q_uu), J of the accepted candidate}
   GP<double> trace;            // [phases 2][trace_cap][IL_TRACE_W], or null
   int trace_cap, padt;
+  IlSlotCtl *ctl;              // slots spread over workgroups (k_ilqr<GEN, 2>), or null
 };
 
 struct IlqrConst {
@@ -583,14 +600,14 @@ struct IlKv { double K[12], k[2], us[2], xs[6]; };
 // one node ahead (loads and stores share one in-order counter: a node's results are stored at the top of the NEXT node, behind
 // that node's operand loads).
 #define IL_PACK 6
-__device__ __forceinline__ void il_rollout_packed(const IlqrConst &C, const IlqrTreeDev &T, int lo, int ni, int R, int w, int init IL_PROF_ARG) {
+__device__ __forceinline__ void il_rollout_packed(const IlqrConst &C, const IlqrTreeDev &T, int lo, int ni, int R, int w, int init, int slot0 IL_PROF_ARG) {
   const int lane = threadIdx.x & 63;
   const int M = T.M;
   const int a = lane % IL_NA, g = lane / IL_NA;
   const int item = w * IL_PACK + g;
   const bool valid = g < IL_PACK && item < R;
   const int ic = valid ? item : w * IL_PACK;
-  const int slot = ic / ni, it = lo + (ic - slot * ni);
+  const int sl_ = ic / ni, it = lo + (ic - sl_ * ni), slot = slot0 + sl_;      // (slot0: the slot a follower workgroup evaluates)
   const double alpha = init ? 0.0 : C.alphas[a];
   const int IL_AS1 *pSeg = T.seg_nodes.g();
   const double IL_AS1 *pK = T.K.g() + (size_t)slot * M * 12, *pk = T.k.g() + (size_t)slot * M * 2, *pUs = T.us.g(), *pXs = T.xs.g();
@@ -718,7 +735,7 @@ __device__ __forceinline__ void il_window_axes(int xi, int yi, int W, int H, int
 // it so that the waves without a state chain this step come first).
 template <bool GEN>
 __device__ __forceinline__ void il_cost_pass(const IlqrConst &C, const IlqrTreeDev &T, int nuse, double *recs, int wave, int nwaves,
-                                             GP<const int> nodes, int cnt IL_PROF_ARG) {
+                                             GP<const int> nodes, int cnt, int slot0 IL_PROF_ARG) {
   const int lane = threadIdx.x & 63;
   const int M = T.M, P = nuse * cnt;
   const int nchunk = (P + 5) / 6;
@@ -728,7 +745,7 @@ __device__ __forceinline__ void il_cost_pass(const IlqrConst &C, const IlqrTreeD
     const int pi = ch * 6 + pl;
     const bool valid = lane < 60 && pi < P;
     const int pic = pi < P ? pi : P - 1;
-    const int slot = pic / cnt, c = nodes[pic % cnt];
+    const int slot = slot0 + pic / cnt, c = nodes[pic % cnt];
     // issue every independent load first: the records of the chunk's 6 nodes, the candidate's state/control,
     // the node's probability / list length / nominal position
     double rr[6];
@@ -1192,8 +1209,11 @@ __device__ __forceinline__ void il_reject_update(double &mu, double &delta) {
 // chunks, node blocks of the derivative pass, array copies) is dealt over the G x 8 waves, every phase boundary is a barrier
 // over the G workgroups (il_tree_sync), the control variables (mu, delta, J, accepted slot ...) are recomputed identically by
 // every workgroup from the same global data.  Same arithmetic per item, same results.
-template <bool GEN, bool MULTI>
-__device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C, double *stats, double *trace, int wg, int G, unsigned *bar, unsigned *abort_word) {
+// SLOTS (k_ilqr<GEN, 2>, this workgroup = the master of its tree, T.ctl != null): every pass is published to the tree's follower workgroups,
+// which evaluate the Levenberg-Marquardt slots 1 .. n - 1 on their own CUs (il_follow) while this workgroup evaluates slot 0 as a single workgroup
+// would: a run of rejections costs one pass per n iterations and the accepted iterations cost what they always did.
+template <bool GEN, bool MULTI, bool SLOTS>
+__device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C, int ph, double *stats, double *trace, int wg, int G, unsigned *bar, unsigned *abort_word) {
   extern __shared__ double il_dsm[];
   // LDS carve: per-wave scratch [IL_WAVES][IL_SCR] | cost sums [IL_LSUM] | compact records [IL_RECS] | staging [IL_DSTG] floats
   double *scr = il_dsm + (size_t)(threadIdx.x >> 6) * IL_SCR;
@@ -1205,9 +1225,10 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
     const int l = threadIdx.x & 63;
     scr[IL_CST + l] = l == 0 ? 1.0 : (l == 6 ? C.dt : 0.0);
   }
-  __shared__ double Jnew[IL_SPEC][IL_NA];
+  __shared__ double Jnew[IL_SLOTS][IL_NA];
   __shared__ double sh_mu, sh_delta, sh_J;
-  __shared__ int sh_accepted, sh_converged, sh_stop, sh_sing, sh_pick, sh_slot, sh_it, sh_nspec, sh_hint;
+  __shared__ int sh_accepted, sh_converged, sh_stop, sh_sing, sh_pick, sh_slot, sh_it, sh_nspec, sh_hint, sh_ntot;
+  __shared__ unsigned sh_gen;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = T.M;
   const int gw = MULTI ? wg * IL_WAVES + wave : wave, nw = MULTI ? G * IL_WAVES : IL_WAVES;      // this wave among the tree's waves
@@ -1216,7 +1237,10 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
 #ifdef IL_PROFILE
   long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  if (tid == 0) { sh_mu = 1.0; sh_delta = 2.0; sh_accepted = 1; sh_converged = 0; sh_stop = 0; sh_J = 0.0; sh_pick = 0; sh_slot = 0; sh_it = 0; sh_hint = 1; }
+  if (tid == 0) {
+    sh_mu = 1.0; sh_delta = 2.0; sh_accepted = 1; sh_converged = 0; sh_stop = 0; sh_J = 0.0; sh_pick = 0; sh_slot = 0; sh_it = 0; sh_hint = 1; sh_ntot = 1;
+    if (SLOTS) sh_gen = __hip_atomic_load(&T.ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (this workgroup is its only writer)
+  }
   if (MULTI && wg == 0 && tid == 0) {       // singular-slot words of both pass parities (read behind the barriers below)
     __hip_atomic_store(&bar[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&bar[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1234,7 +1258,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
   IL_SYNC();
   for (int s = 0; s < T.n_fsteps; ++s) {
     const int lo = T.fstep_start[s], ni = T.fstep_start[s + 1] - lo;
-    for (int w = gw; w * IL_PACK < ni; w += nw) il_rollout_packed(C, T, lo, ni, ni, w, 1 IL_PROF_PASS);
+    for (int w = gw; w * IL_PACK < ni; w += nw) il_rollout_packed(C, T, lo, ni, ni, w, 1, 0 IL_PROF_PASS);
     IL_SYNC();
   }
   bool staged = false;          // il_deriv_pass: this fit's agent rows are in the staging region already
@@ -1271,12 +1295,26 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       int ns = sh_hint;
       const int maxseg = T.max_level_segs > 0 ? T.max_level_segs : 1;   // widest segment level
       while (ns > 1 && ns * maxseg > IL_SPEC_OVERSUB * nw) --ns;
+      // followers: every pass carries as many slots as there are workgroups (their CUs would idle otherwise), this one evaluates slot 0.  They
+      // are used only once ALL of them run (a launch that is not fully resident keeps its slots in this workgroup: nobody waits for a
+      // workgroup that has not started)
+      const bool fol = SLOTS && G > 1 && (__hip_atomic_load(&T.ctl->alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | 1u) == (1u << G) - 1u;
+      if (fol) ns = G < IL_SLOTS ? G : IL_SLOTS;
       if (ns > C.max_iter - sh_it) ns = C.max_iter - sh_it;
       double mu = sh_mu, de = sh_delta;
       int cnt = 1;
       for (; cnt < ns; ++cnt) { il_reject_update(mu, de); if (mu >= 1e10) break; }   // slot cnt would never be reached
-      sh_nspec = cnt < ns ? cnt : ns;
+      sh_ntot = cnt < ns ? cnt : ns;
+      sh_nspec = fol ? 1 : sh_ntot;
       sh_sing = 0;
+      if (SLOTS) {
+        // the command of this pass (the derivative pass above ended with a workgroup barrier: its writes are ordered before this release)
+        IlSlotCtl *ctl = T.ctl;
+        ctl->mu = sh_mu; ctl->delta = sh_delta;
+        __hip_atomic_store(&ctl->cmd, (unsigned)(fol ? sh_ntot : 1) | ((unsigned)ph << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_gen += 1u;
+        __hip_atomic_store(&ctl->gen, sh_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
       // wide trees: the singular-slot mask is a global word, one per pass parity (this pass's word was cleared during the
       // previous pass, behind several barriers)
       if (MULTI && wg == 0) __hip_atomic_store(&bar[2 + ((n_pass + 1) & 1)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1369,7 +1407,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       if (s < T.n_fsteps) {
         const int lo = T.fstep_start[s], ni = T.fstep_start[s + 1] - lo;
         R = (ni * nuse + IL_PACK - 1) / IL_PACK;            // waves' worth of (slot, piece) items
-        for (int w = gw; w < R; w += nw) il_rollout_packed(C, T, lo, ni, ni * nuse, w, 0 IL_PROF_PASS);
+        for (int w = gw; w < R; w += nw) il_rollout_packed(C, T, lo, ni, ni * nuse, w, 0, 0 IL_PROF_PASS);
       } else {
         IL_MARK(t_roll);
       }
@@ -1383,7 +1421,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
           const int fr = 4 - R;             // SIMDs without a chain wave
           rank = wave < R ? 2 * fr + R + wave : (wave < 4 ? wave - R : (wave < 4 + R ? 2 * fr + wave - 4 : fr + wave - 4 - R));
         }
-        il_cost_pass<GEN>(C, T, nuse, recs, rank, nw, T.fstep_nodes + (size_t)n0, cnt IL_PROF_PASS);
+        il_cost_pass<GEN>(C, T, nuse, recs, rank, nw, T.fstep_nodes + (size_t)n0, cnt, 0 IL_PROF_PASS);
       }
       IL_SYNC();
     }
@@ -1412,7 +1450,17 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       double mu = sh_mu, de = sh_delta;
       int it = sh_it;
       bool done = false;
-      for (int slot = 0; slot < nuse && !done; ++slot) {
+      const int nsel = (SLOTS && sh_ntot > nspec) ? sh_ntot : nuse;      // with followers: their slots behind this workgroup's
+      for (int slot = 0; slot < nsel && !done; ++slot) {
+        if (SLOTS && slot >= nuse) {
+          // a follower's slot, looked at only because every earlier slot was rejected: wait for its result (it started a command latency
+          // behind this workgroup's own slot and has had the selection's time to catch up)
+          IlSlotCtl *ctl = T.ctl;
+          while (__hip_atomic_load(&ctl->done[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sh_gen) __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          if (__hip_atomic_load(&ctl->sing[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;     // slots behind a singular slot cannot be used this pass
+          for (int a = 0; a < IL_NA; ++a) Jnew[slot][a] = ctl->Jnew[slot][a];
+        }
         // (mu, de) is the LM state the reference holds when it runs this iteration
         int pick = -1;
         for (int a = 0; a < IL_NA; ++a)
@@ -1437,6 +1485,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       }
       sh_mu = mu; sh_delta = de; sh_it = it;
       sh_hint = (sh_accepted && sh_slot == 0) ? 1 : IL_SPEC;
+      // (an accepted candidate of a follower's slot is adopted from that slot's arrays: make its writes visible to this CU's loads)
     }
     __syncthreads();
     IL_MARK(t_sel);
@@ -1466,25 +1515,185 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
 #undef IL_SYNC
 }
 
+// A follower workgroup of a tree whose Levenberg-Marquardt slots are spread over workgroups (IlSlotCtl): waits for the master's command, evaluates
+// slot `wg` of that pass -- the backward sweep at the mu the schedule reaches after `wg` rejections, the state chains of the ten step sizes,
+// their costs, the ten sums in the reference's order -- with the code the master runs for its own slot (il_backward_segment, il_rollout_packed,
+// il_cost_pass: same arithmetic per item), publishes them and waits again.  It only ever READS the nominal trajectory and its derivatives; a
+// command it picks up late (the master accepted an earlier slot and moved on) yields a result nobody reads.
+template <bool GEN>
+__device__ __forceinline__ void il_follow(const IlqrTreeDev &T, const IlqrConst *consts, int wg) {
+  extern __shared__ double il_dsm[];
+  double *scr = il_dsm + (size_t)(threadIdx.x >> 6) * IL_SCR;
+  double *lsum = il_dsm + (size_t)IL_WAVES * IL_SCR;
+  double *recs0 = lsum + IL_LSUM;
+  double *recs = recs0 + (size_t)(threadIdx.x >> 6) * 6 * IL_RA;
+  __shared__ unsigned f_gen, f_cmd;
+  __shared__ double f_mu, f_de;
+  __shared__ int f_sing;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = T.M;
+  IlSlotCtl *ctl = T.ctl;
+  if (tid == 0) __hip_atomic_fetch_or(&ctl->alive, 1u << wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned last = 0;
+  int ph_cst = -1;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) {
+      unsigned g;
+      while ((g = __hip_atomic_load(&ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == last) __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      f_gen = g; f_cmd = __hip_atomic_load(&ctl->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      f_mu = ctl->mu; f_de = ctl->delta; f_sing = 0;
+    }
+    __syncthreads();
+    const unsigned g = f_gen, cmd = f_cmd;
+    last = g;
+    if (cmd >> 16) return;
+    const int ns = (int)(cmd & 0xffu), ph = (int)((cmd >> 8) & 0xffu);
+    if (wg >= ns) continue;
+    const IlqrConst &C = consts[ph];
+    if (ph != ph_cst) {          // the Riccati sweep's constant operands {1,0,..} / {dt,0,..} (il_fit writes them at its start)
+      if (lane < 12) scr[IL_CST + lane] = lane == 0 ? 1.0 : (lane == 6 ? C.dt : 0.0);
+      ph_cst = ph;
+    }
+    double mu = f_mu, de = f_de;
+    for (int e = 0; e < wg; ++e) il_reject_update(mu, de);
+    IlqrTreeDev Ts = T;
+    Ts.k += (size_t)wg * M * 2; Ts.K += (size_t)wg * M * 12; Ts.Vx += (size_t)wg * M * 6; Ts.Vxx += (size_t)wg * M * 36;
+    // ---- backward pass of this slot (solver.py:332-373), as in il_fit
+    for (int d = T.n_slevels - 1; d >= 0; --d) {
+      const int lo = T.slevel_start[d], hi = T.slevel_start[d + 1];
+      for (int w = wave; w < hi - lo; w += IL_WAVES) {
+        const int seg = T.slevel_segs[lo + w];
+        int rec[14];
+        {
+          const int IL_AS1 *sr = T.seg_rec.g() + (size_t)seg * 16;
+#pragma unroll
+          for (int e = 0; e < 14; ++e) rec[e] = __builtin_amdgcn_readfirstlane(sr[e]);
+        }
+        {
+          const int nch = rec[5];
+          double acc = 0.0;
+          if (lane < 42) {
+            double v[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+              const int ch = rec[8 + e];
+              v[e] = lane < 36 ? Ts.Vxx[(size_t)ch * 36 + lane] : Ts.Vx[(size_t)ch * 6 + (lane - 36)];
+            }
+#pragma unroll
+            for (int e = 0; e < 6; ++e) if (e < nch) acc += v[e];
+            for (int e = rec[6] + 6; e < rec[6] + nch; ++e) {
+              const int ch = T.child_list[e];
+              acc += lane < 36 ? Ts.Vxx[(size_t)ch * 36 + lane] : Ts.Vx[(size_t)ch * 6 + (lane - 36)];
+            }
+          }
+          IL_WFENCE();
+          if (lane < 36) scr[36 + lane] = acc;
+          else if (lane < 42) scr[176 + lane - 36] = acc;
+          IL_WFENCE();
+        }
+#ifdef IL_PROFILE
+        long long prof[16];
+#endif
+        const int sing = il_backward_segment<GEN>(C, T, Ts, rec[0], rec[1], rec[2], rec[4], mu, scr IL_PROF_PASS);
+        if (sing) {
+          if (lane == 0) f_sing = 1;
+        } else {
+          const int c = rec[3];
+          if (lane < 36) Ts.Vxx[(size_t)c * 36 + lane] = scr[36 + lane];
+          else if (lane < 42) Ts.Vx[(size_t)c * 6 + lane - 36] = scr[176 + lane - 36];
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    if (!f_sing) {
+      // ---- line search of this slot (solver.py:202-240): state chains, then candidate costs, as in il_fit with one slot
+      for (int s = 0; s <= T.n_fsteps; ++s) {
+        int R = 0;
+        if (s < T.n_fsteps) {
+          const int lo = T.fstep_start[s], ni = T.fstep_start[s + 1] - lo;
+          R = (ni + IL_PACK - 1) / IL_PACK;
+#ifdef IL_PROFILE
+          long long prof[16];
+#endif
+          for (int w = wave; w < R; w += IL_WAVES) il_rollout_packed(C, T, lo, ni, ni, w, 0, wg IL_PROF_PASS);
+        }
+        if (s > 0) {
+          const int n0 = T.fstep_nstart[s - 1], cnt = T.fstep_nstart[s] - n0;
+          int rank = (wave + IL_WAVES - R % IL_WAVES) % IL_WAVES;
+          if (R < 4) {
+            const int fr = 4 - R;
+            rank = wave < R ? 2 * fr + R + wave : (wave < 4 ? wave - R : (wave < 4 + R ? 2 * fr + wave - 4 : fr + wave - 4 - R));
+          }
+#ifdef IL_PROFILE
+          long long prof[16];
+#endif
+          il_cost_pass<GEN>(C, T, 1, recs, rank, IL_WAVES, T.fstep_nodes + (size_t)n0, cnt, wg IL_PROF_PASS);
+        }
+        __threadfence_block();
+        __syncthreads();
+      }
+      // ---- the ten sums J(alpha) = sum over the nodes in node order (python sum(): sequential), as il_fit adds them
+      const GP<double> Lg = T.L_new + (size_t)wg * IL_NA * M;
+      if (M * IL_NA <= IL_LSUM) {
+        for (int q = tid; q < M * IL_NA; q += IL_THREADS) lsum[q] = Lg[q];
+        __syncthreads();
+      }
+      if (tid < IL_NA) {
+        double J = 0.0;
+        const double *Ln = (M * IL_NA <= IL_LSUM) ? lsum + (size_t)tid * M : (Lg + (size_t)tid * M).p;
+        int c = 0;
+        for (; c + 8 <= M; c += 8) {
+          double v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = Ln[c + k];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) J += v[k];
+        }
+        for (; c < M; ++c) J += Ln[c];
+        ctl->Jnew[wg][tid] = J;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(&ctl->sing[wg], (unsigned)f_sing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ctl->done[wg], g, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // n_phases == 1: one fit with consts[0].  n_phases == 2: the contingency planner's sequence (planner.py:174-178) in
 // one launch -- the warm-start fit (consts[0]: lane term only) and then, from its controls, the full fit (consts[1]).
 // T.stats receives IL_NSTAT doubles per phase.
-// MULTI: G workgroups per tree; block b -> tree 8 (b / 8G) + b % 8, workgroup (b % 8G) / 8 of it: the hardware deals consecutive
-// blocks round-robin over the 8 XCDs, so the workgroups of one tree share an XCD (one L2).  bars: 4 words per tree + one abort word
+// MODE 1 (wide trees): G workgroups share a tree's items; MODE 2 (narrow trees): G workgroups take a tree's Levenberg-Marquardt slots (workgroup 0
+// = the master, il_fit; the others il_follow).  Both: block b -> tree 8 (b / 8G) + b % 8, workgroup (b % 8G) / 8 of it: the hardware deals
+// consecutive blocks round-robin over the 8 XCDs, so the workgroups of one tree share an XCD (one L2).  bars: 4 words per tree + one abort word
 // for the launch, zeroed by the host.
-template <bool GEN, bool MULTI>
+template <bool GEN, int MODE>
 __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restrict__ trees, const IlqrConst *__restrict__ consts,
                                                      int n_phases, int n_trees, int G, unsigned *__restrict__ bars) {
+  constexpr bool MULTI = MODE == 1, SLOTS = MODE == 2;
   int t = blockIdx.x, wg = 0;
-  if (MULTI) {
+  if (MODE != 0) {
     const int r = blockIdx.x % (8 * G);
     t = 8 * (blockIdx.x / (8 * G)) + (r & 7);
     wg = r >> 3;
     if (t >= n_trees) return;
   }
   const IlqrTreeDev T = trees[t];
+  if (SLOTS && wg > 0) {
+    il_follow<GEN>(T, consts, wg);
+    return;
+  }
   for (int ph = 0; ph < n_phases; ++ph)
-    il_fit<GEN, MULTI>(T, consts[ph], (T.stats + (size_t)ph * IL_NSTAT).p, T.trace ? (T.trace + (size_t)ph * T.trace_cap * IL_TRACE_W).p : nullptr, wg, G, MULTI ? bars + 4 * t : nullptr, MULTI ? bars + 4 * n_trees : nullptr);
+    il_fit<GEN, MULTI, SLOTS>(T, consts[ph], ph, (T.stats + (size_t)ph * IL_NSTAT).p, T.trace ? (T.trace + (size_t)ph * T.trace_cap * IL_TRACE_W).p : nullptr, wg, G, MULTI ? bars + 4 * t : nullptr, MULTI ? bars + 4 * n_trees : nullptr);
+  if (SLOTS && threadIdx.x == 0) {          // the followers leave
+    __hip_atomic_store(&T.ctl->cmd, 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&T.ctl->gen, __hip_atomic_load(&T.ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 static inline size_t il_lds_bytes(int /*amax*/) {

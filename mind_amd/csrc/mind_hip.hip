@@ -111,6 +111,9 @@ struct mind_ctx {
   // wide cost trees: workgroups per tree (halved until every workgroup of the launch is resident; cfg4 full tree, six trees per launch:
   // 8.33 / 7.40 / 7.37 / 7.63 ms per plan with 8 / 16 / 24 / 32, profiles/r03an), node count from which they are used (mind_set_tuning)
   int ilqr_wgs = 16, ilqr_multi_min = 192;
+  // narrow cost trees (below ilqr_multi_min nodes): workgroups per tree that take the fit's Levenberg-Marquardt slots (k_ilqr<GEN, 2>: a master +
+  // ilqr_slots - 1 followers, one slot each; 1 = everything in one workgroup).  "ilqr_slots" / MIND_ILQR_SLOTS
+  int ilqr_slots = 8;
   int dec_mfma_min = 1 << 30;   // agents per call from which the decoder's actor part runs on the MFMA kernel (MIND_DEC_MFMA_MIN; default: never)
   bool enc_mfma = true;         // MFMA ActorNet under the bf16x3 / bf16 settings (MIND_ENC_MFMA=0: the fp32 VALU kernel, for A/B)
   bool xcd_order = true;        // XCD-aware job order for big batches (MIND_XCD_ORDER=0 switches it off, for A/B measurements)
@@ -278,9 +281,10 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *me = getenv("MIND_ENC_MFMA")) c->enc_mfma = !(me[0] == '0');
   if (const char *de = getenv("MIND_DEC_MFMA_MIN")) c->dec_mfma_min = atoi(de);
   if (const char *oe = getenv("MIND_DEC_OVERLAP")) c->dec_overlap = !(oe[0] == '0');
-  (void)hipFuncSetAttribute((const void *)k_ilqr<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
-  (void)hipFuncSetAttribute((const void *)k_ilqr<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
-  (void)hipFuncSetAttribute((const void *)k_ilqr<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
+  (void)hipFuncSetAttribute((const void *)k_ilqr<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
+  (void)hipFuncSetAttribute((const void *)k_ilqr<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
+  (void)hipFuncSetAttribute((const void *)k_ilqr<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
+  (void)hipFuncSetAttribute((const void *)k_ilqr<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
   if (const char *te = getenv("MIND_TOK_MFMA")) c->tok_mfma = !(te[0] == '0');
   if (const char *te = getenv("MIND_TOK_SMALL_MAX")) c->tok_small_max = atoi(te);
   if (const char *te = getenv("MIND_TOK_BF_MIN_N")) c->tok_bf_min_n = atoi(te);
@@ -291,6 +295,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *we = getenv("MIND_ILQR_CHUNK")) c->ilqr_chunk = atoi(we) < 0 ? 0 : atoi(we);
   if (const char *ce = getenv("MIND_PLAN_CHUNK_MB")) { const long v = atol(ce); if (v > 0) c->plan_chunk_mb = v; }
   if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
+  if (const char *we = getenv("MIND_ILQR_SLOTS")) { const int v = atoi(we); c->ilqr_slots = v < 1 ? 1 : (v > IL_SLOTS ? IL_SLOTS : v); }
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_tgt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_actor<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
@@ -363,6 +368,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "ilqr_chunk") c->ilqr_chunk = value < 0 ? 0 : (int)value;
   else if (n == "ilqr_wgs") c->ilqr_wgs = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (n == "ilqr_multi_min") c->ilqr_multi_min = value;
+  else if (n == "ilqr_slots") c->ilqr_slots = value < 1 ? 1 : (value > IL_SLOTS ? IL_SLOTS : value);
   else if (n == "ilqr_test_starve") c->ilqr_test_starve = value != 0;   // tests: launch a wide tree without its last workgroups
   else return fail(c, MIND_EINVAL, "mind_set_tuning: unknown knob '%s'", name);
   return MIND_OK;
@@ -1466,6 +1472,18 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     double ox, oy;
     il_make_grid(W, H, grid_res, x0, gx.data(), gy.data(), ox, oy);
   }
+  // ---- launch mode: one workgroup per tree | wide trees: G workgroups share a tree's items | narrow trees: G workgroups take a tree's LM slots
+  int maxM = 0;
+  for (int t = 0; t < n_trees; ++t) maxM = trees[t].n_nodes > maxM ? trees[t].n_nodes : maxM;
+  int G = c->ilqr_wgs;
+  while (G > 1 && ((n_trees + 7) / 8) * 8 * G > c->n_cu) G >>= 1;     // every workgroup of the launch must be resident (1 per CU)
+  const bool multi = !gen && !ev && G > 1 && maxM >= c->ilqr_multi_min;
+  int GS = multi ? 1 : c->ilqr_slots;
+  // (c->ilqr_wgs == 1 is the caller's "stay on few CUs": the speculative warm start beside the predictor)
+  if (gen || ev || c->ilqr_wgs <= 1) GS = 1;
+  while (GS > 1 && ((n_trees + 7) / 8) * 8 * GS > c->n_cu) --GS;
+  const bool slots = GS > 1;
+  const size_t nslot = slots ? IL_SLOTS : IL_SPEC;                   // sets of per-slot arrays (gains, value functions, candidates)
   // ---- layout of one device arena: [doubles | floats | ints | tree structs]
   size_t nd = 0, nf = 0, ni = 0;
   auto takeD = [&](size_t n) { size_t o = nd; nd += (n + 1) & ~(size_t)1; return o; };
@@ -1477,6 +1495,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   const size_t o_evx = takeD(ev ? (size_t)ev->nq * 6 : 0), o_evu = takeD(ev ? (size_t)ev->nq * 2 : 0);
   const size_t o_evn = takeI(ev ? ev->nq : 0);
   const size_t o_bars = takeI(4 * (size_t)n_trees + 4);   // barrier words of the multi-workgroup launch + its abort word (zero at upload)
+  const size_t ctl_ints = (sizeof(IlSlotCtl) + 15) / 16 * 4;
+  const size_t o_ctl = takeI(slots ? ctl_ints * (size_t)n_trees : 0);      // slot control blocks (zero at upload; 16-byte aligned: the ints region is)
   const int trace_cap = std::min(256, std::max(cfg->max_iter, cfg2 ? cfg2->max_iter : 0));      // rows of the per-iteration trace, per phase
   struct TL { size_t nodew, field, relag; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, segrec, rel, fsstart, fsq0, fsq1, fsnstart, fsnodes, trace; int M, a, nl, nseg, nsl, maxls, nfs; };
   std::vector<TL> tl(n_trees);
@@ -1499,8 +1519,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     L.relag = takeD(use_exo ? M * IL_RA : 0);
     L.trace = takeD((size_t)2 * trace_cap * IL_TRACE_W);
     L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M);
-    L.Lxx = takeD(36 * M); L.k = takeD(IL_SPEC * 2 * M); L.K = takeD(IL_SPEC * 12 * M); L.Vx = takeD(IL_SPEC * 6 * M); L.Vxx = takeD(IL_SPEC * 36 * M);
-    L.xsn = takeD(IL_SPEC * 60 * M); L.usn = takeD(IL_SPEC * 20 * M); L.Ln = takeD(IL_SPEC * 10 * M);
+    L.Lxx = takeD(36 * M); L.k = takeD(nslot * 2 * M); L.K = takeD(nslot * 12 * M); L.Vx = takeD(nslot * 6 * M); L.Vxx = takeD(nslot * 36 * M);
+    L.xsn = takeD(nslot * 60 * M); L.usn = takeD(nslot * 20 * M); L.Ln = takeD(nslot * 10 * M);
     L.prob = takeF(M); L.mean = takeF(M * L.a * 2); L.cov = takeF(M * L.a);
     L.parent = takeI(M); L.lnodes = takeI(M); L.cstart = takeI(M + 1); L.clist = takeI(M); L.rel = takeI(M);
     Mtot += (long)M;
@@ -1676,6 +1696,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     D.xs = Dp(L.xs); D.us = Dp(L.us); D.Fx = Dp(L.Fx); D.L = Dp(L.L); D.Lx = Dp(L.Lx); D.Lxx = Dp(L.Lxx);
     D.k = Dp(L.k); D.K = Dp(L.K); D.Vx = Dp(L.Vx); D.Vxx = Dp(L.Vxx);
     D.xs_new = Dp(L.xsn); D.us_new = Dp(L.usn); D.L_new = Dp(L.Ln); D.stats = Dp(L.stats);
+    D.ctl = slots ? (IlSlotCtl *)(dI + o_ctl + ctl_ints * (size_t)t) : nullptr;
     moff += (long)M;
   }
   for (int t = 0; t < n_trees && gen; ++t)
@@ -1747,27 +1768,25 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   }
   const size_t il_lds = il_lds_bytes(amax);
   // wide trees (hundreds of nodes, dozens of chain segments per level): several workgroups per tree (ilqr_kernels.hip il_fit<.., true>)
-  int maxM = 0;
-  for (int t = 0; t < n_trees; ++t) maxM = tl[t].M > maxM ? tl[t].M : maxM;
-  int G = c->ilqr_wgs;
-  while (G > 1 && ((n_trees + 7) / 8) * 8 * G > c->n_cu) G >>= 1;     // every workgroup of the launch must be resident (1 per CU)
-  const bool multi = !gen && G > 1 && maxM >= c->ilqr_multi_min;
   unsigned *dBars = (unsigned *)(dI + o_bars);
   if (c->profiling) {
     if (!c->ev_il0) { HIPCHK(c, hipEventCreate(&c->ev_il0)); HIPCHK(c, hipEventCreate(&c->ev_il1)); }
     HIPCHK(c, hipEventRecord(c->ev_il0, st));
   }
-  c->ilqr_trees = n_trees; c->ilqr_multi = multi ? G : 1; c->ilqr_ms = 0.f;
+  c->ilqr_trees = n_trees; c->ilqr_multi = multi ? G : (slots ? GS : 1); c->ilqr_ms = 0.f;
   auto launch = [=](bool multi_) {
     if (gen) {
-      hipLaunchKernelGGL((k_ilqr<true, false>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
+      hipLaunchKernelGGL((k_ilqr<true, 0>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
+    } else if (slots) {
+      // a master + GS - 1 followers per tree; a follower that is not resident yet is simply not used (IlSlotCtl.alive): no co-residency needed
+      hipLaunchKernelGGL((k_ilqr<false, 2>), dim3(((n_trees + 7) / 8) * 8 * GS), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, GS, dBars);
     } else if (multi_) {
       // (ilqr_test_starve: the last eight workgroups are withheld, as if the device could not hold the whole launch: their peers wait
       // at the first barrier, raise the abort word and the call falls back to the one-workgroup kernel below)
-      hipLaunchKernelGGL((k_ilqr<false, true>), dim3(((n_trees + 7) / 8) * 8 * G - (c->ilqr_test_starve ? 8 : 0)), dim3(IL_THREADS), il_lds, st, dT, dK,
+      hipLaunchKernelGGL((k_ilqr<false, 1>), dim3(((n_trees + 7) / 8) * 8 * G - (c->ilqr_test_starve ? 8 : 0)), dim3(IL_THREADS), il_lds, st, dT, dK,
                          n_phases, n_trees, G, dBars);
     } else {
-      hipLaunchKernelGGL((k_ilqr<false, false>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
+      hipLaunchKernelGGL((k_ilqr<false, 0>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
     }
   };
   launch(multi);

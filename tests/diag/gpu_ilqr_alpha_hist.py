@@ -1,0 +1,35 @@
+"""GPU-box diagnostic: which line-search candidate the tree-iLQR fits of the headline loop accept (step index 0 = alpha 1) and how the
+Levenberg-Marquardt runs end -- decides what a speculative derivative pass for candidate 0 would hit."""
+import collections
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from bench import BRANCHING_WEIGHTS, WORKLOADS, make_closed_loop
+wl = sys.argv[1] if len(sys.argv) > 1 else "demo_1"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+pl, sim, w = make_closed_loop(dict(WORKLOADS[wl]), ckpt=BRANCHING_WEIGHTS)
+rt, opt = pl.network.rt, pl.traj_tree_opt
+opt.speculative = False
+hist = [collections.Counter(), collections.Counter()]
+mus = [collections.Counter(), collections.Counter()]
+orig = opt.solve_batch
+
+
+def cap(scen_trees, *a):
+    r = orig(scen_trees, *a)
+    for t in range(len(scen_trees)):
+        for ph in (0, 1):
+            tr = rt.ilqr_trace(t, ph)
+            for row in tr:
+                hist[ph][int(row[2])] += 1
+                if row[2] >= 0:
+                    mus[ph]["mu=0" if row[0] == 0 else ("mu<=1e-3" if row[0] <= 1e-3 else "mu>1e-3")] += 1
+    return r
+
+
+opt.solve_batch = cap
+sim.run_plans(n)
+for ph in (0, 1):
+    tot = sum(hist[ph].values())
+    print("phase", ph, "iterations", tot, "accepted step index histogram", sorted(hist[ph].items()), "mu at accepted", dict(mus[ph]))

@@ -120,11 +120,11 @@ def test_bench_multi_rank_contract_weak_and_strong():
     --shard: both ranks plan the same scene."""
     d = _bench_ranks(2, ["--workload", "demo1", "--no-extras"], 29541)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4 and "cpu_baseline" not in d
-    assert d["config"]["sim_steps_timed"] == 20 and abs(d["value"] - 2 * 20 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+    assert d["config"]["sim_steps_timed"] == 20 and abs(d["value"] - 2 * 20 / (d["ms_per_step"] * 4e-3)) < 1e-3 * d["value"]      # (the line rounds to 5 significant digits)
     assert d["nodes_expanded_per_s"] > 0 and 0 < d["roofline"]["frac"] <= 1
     s = _bench_ranks(2, ["--workload", "demo1", "--shard"], 29542)
     assert s["n_gpus"] == 2 and s["scaling"] == "strong" and s["collectives_per_plan"] >= 3
-    assert abs(s["value"] - 20 / (s["ms_per_step"] * 4e-3)) < 1e-6 * s["value"]   # one scene: steps are not multiplied by N
+    assert abs(s["value"] - 20 / (s["ms_per_step"] * 4e-3)) < 1e-3 * s["value"]   # one scene: steps are not multiplied by N
 
 
 def test_bench_spawns_its_own_ranks_and_checks_the_world_size(tmp_path):
