@@ -1685,6 +1685,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
   }
   const IlqrTreeDev T = trees[t];
   if (SLOTS && wg > 0) {
+    if (bars[4 * n_trees + 1]) return;      // (tests: followers withheld -- the master then keeps its slots to itself)
     il_follow<GEN>(T, consts, wg);
     return;
   }

@@ -1743,6 +1743,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     memcpy(up, hD.data(), bytesIn);
     if (bytesF) memcpy(up + bytesIn, hF.data(), bytesF);
     if (bytesI) memcpy(up + bytesIn + bytesF, hI.data(), bytesI);
+    // (tests: "ilqr_test_starve" with slots on follower workgroups = the followers leave at once, as if they were never scheduled)
+    if (slots && c->ilqr_test_starve) ((unsigned *)(up + bytesIn + bytesF))[o_bars + 4 * (size_t)n_trees + 1] = 1u;
     memcpy(up + o_structs, hT.data(), (size_t)n_trees * sizeof(IlqrTreeDev));
     memcpy(up + o_consts, K2, 2 * sizeof(IlqrConst));
     HIPCHK(c, hipMemcpyAsync(base, up, o_work, hipMemcpyHostToDevice, st));

@@ -345,3 +345,78 @@ def test_contingency_in_two_halves_equals_the_one_call(hip_predictor):
     assert hip_predictor.lib.mind_ilqr_finish(hip_predictor.ctx) == _lib.MIND_ESTATE
     again = hip_predictor.ilqr_contingency(cfg_w, cfg_f, flats, x0, sst["target_lane"], sst["target_vel"])      # the context is free again
     assert np.array_equal(again[0][0], ref[0][0])
+
+
+def _contingency_cases():
+    cases = []
+    for name, depth in (("lead", 4), ("branch3", 6), ("deep", 5)):
+        sst = scripted_scenario_tree(name, depth)
+        cases.append((name, sst, oi.flatten(sst["nodes"]), oi.init_state(sst["state"], sst["ctrl"])))
+    return cases
+
+
+def test_levenberg_marquardt_slots_on_follower_workgroups_equal_one_workgroup(hip_predictor):
+    """k_ilqr<GEN, 2>: the master workgroup of a tree evaluates slot 0 of every pass, follower workgroups the slots the LM schedule reaches after
+    1 .. n - 1 rejections (solver.py:133-158 is sequential: the first slot with an improving step is what it would have reached).  Every
+    slot count must return the single workgroup's bits -- trajectories, statistics and the per-iteration traces of both fits -- and so
+    must a launch whose followers never start (the master then keeps its slots)."""
+    cw, cf = oi.default_cfg(), oi.default_cfg()
+    for name, sst, flat, x0 in _contingency_cases():
+        try:
+            hip_predictor.set_tuning("ilqr_slots", 1)
+            ref = hip_predictor.ilqr_contingency(cw, cf, [flat, flat, flat], x0, sst["target_lane"], sst["target_vel"])
+            assert hip_predictor.ilqr_stats()[2] == 1
+            ref_tr = [(hip_predictor.ilqr_trace(t, 0), hip_predictor.ilqr_trace(t, 1)) for t in range(3)]
+            assert sum(int((tr[:, 2] < 0).sum()) for tr, _ in ref_tr) + sum(int((tr[:, 2] < 0).sum()) for _, tr in ref_tr) > 0, name   # rejections happen
+            for slots, starve in ((2, 0), (3, 0), (4, 0), (8, 0), (8, 1)):
+                hip_predictor.set_tuning("ilqr_slots", slots)
+                hip_predictor.set_tuning("ilqr_test_starve", starve)
+                for rep in range(2):
+                    got = hip_predictor.ilqr_contingency(cw, cf, [flat, flat, flat], x0, sst["target_lane"], sst["target_vel"])
+                    assert hip_predictor.ilqr_stats()[2] == slots
+                    for t in range(3):
+                        assert np.array_equal(got[0][t], ref[0][t]) and np.array_equal(got[1][t], ref[1][t]), (name, slots, starve, t)
+                        assert got[2][t] == ref[2][t] and got[3][t] == ref[3][t], (name, slots, starve, t)
+                        for ph in (0, 1):
+                            assert np.array_equal(hip_predictor.ilqr_trace(t, ph), ref_tr[t][ph]), (name, slots, starve, t, ph)
+        finally:
+            hip_predictor.set_tuning("ilqr_test_starve", 0)
+            hip_predictor.set_tuning("ilqr_slots", 8)
+    # the oracle's result, for good measure (the other tests of this file run with the default slot count)
+    name, sst, flat, x0 = _contingency_cases()[0]
+    w = oi.solve(cw, flat, x0, sst["target_lane"], sst["target_vel"], 0)
+    f = oi.solve(cf, flat, x0, sst["target_lane"], sst["target_vel"], 1, us_init=w["us"])
+    got = hip_predictor.ilqr_contingency(cw, cf, [flat], x0, sst["target_lane"], sst["target_vel"])
+    assert np.array_equal(got[0][0], f["xs"]) and got[3][0]["iterations"] == f["iterations"]
+
+
+def test_singular_q_uu_in_a_followers_slot(hip_predictor):
+    """Quirk Q9 where a FOLLOWER meets it: with control weights -dt^2 / 2 the leaf's Q_uu = 2 w p + dt^2 mu is exactly zero at mu = 1.  On this
+    tree the lane-only fit accepts two steps, then rejects seven in a row while the LM schedule climbs from 2^-6 back to mu = 1 -- the singular
+    value, met right behind a rejection (found by tests/diag/gpu_find_follower_singular.py): with 2 / 4 / 8 slots per pass it falls into a
+    follower's slot.  Slots behind a singular slot are not used; the fit then sits at mu = 1 in the singular-retry path.  Must equal the oracle
+    and the single workgroup, trace row by trace row."""
+    sst = scripted_scenario_tree("branch3", 6)
+    flat = oi.flatten(sst["nodes"])
+    x0 = oi.init_state(sst["state"], sst["ctrl"])
+    cfg = oi.default_cfg(max_iter=30)
+    cfg.w_ctrl[:] = [-0.2 * 0.2 / 2, -0.2 * 0.2 / 2]
+    ref = oi.solve(cfg, flat, x0, sst["target_lane"], sst["target_vel"], 0)
+    res = {}
+    try:
+        for slots in (1, 2, 4, 8):
+            hip_predictor.set_tuning("ilqr_slots", slots)
+            out = hip_predictor.ilqr_solve(cfg, [flat, flat], x0, sst["target_lane"], sst["target_vel"], 0)
+            res[slots] = (out, hip_predictor.ilqr_trace(0, 0), hip_predictor.ilqr_trace(1, 0))
+    finally:
+        hip_predictor.set_tuning("ilqr_slots", 8)
+    one, tr1, _ = res[1]
+    picks = tr1[:, 2]
+    first = int(np.argmax(picks == -2))
+    assert (picks == -2).any() and picks[first - 1] == -1 and (picks[first:] == -2).all(), picks       # singular right behind a rejection, then stuck
+    for slots in (2, 4, 8):
+        many, tra, trb = res[slots]
+        assert np.array_equal(tr1, tra) and np.array_equal(tr1, trb), slots
+        for t in range(2):
+            assert np.array_equal(one[0][0], many[0][t]) and np.array_equal(one[1][0], many[1][t]) and one[2][0] == many[2][t], (slots, t)
+    assert np.array_equal(one[0][0], ref["xs"]) and np.array_equal(one[1][0], ref["us"]) and one[2][0]["iterations"] == ref["iterations"] and one[2][0]["mu"] == ref["mu"]
