@@ -404,6 +404,101 @@ __device__ double il_np_sum(const double *a, long n) {
   return il_np_sum(a, n2) + il_np_sum(a + n2, n - n2);
 }
 
+// The same value for a tree too big for one thread to walk: the recursion above splits [0, n) into leaves of <= 128 elements (in order) and adds
+// their sums pairwise -- every leaf sum is independent, so the workgroup's threads take a leaf each (the leaf's eight strided accumulators
+// and its tail exactly as above) and one thread then folds the partial sums along the same recursion.  tab: >= 2 x leaves doubles of LDS.
+__device__ inline int il_np_leaves(long lo, long n, double *tab, int idx) {          // leaf table: tab[2 i] = offset, tab[2 i + 1] = length
+  if (n <= 128) { tab[2 * idx] = (double)lo; tab[2 * idx + 1] = (double)n; return idx + 1; }
+  long n2 = n / 2;
+  n2 -= n2 % 8;
+  idx = il_np_leaves(lo, n2, tab, idx);
+  return il_np_leaves(lo + n2, n - n2, tab, idx);
+}
+__device__ inline double il_np_fold(long n, const double *part, int &idx) {
+  if (n <= 128) return part[idx++];
+  long n2 = n / 2;
+  n2 -= n2 % 8;
+  const double l = il_np_fold(n2, part, idx);
+  return l + il_np_fold(n - n2, part, idx);
+}
+// all threads of the workgroup; the result is valid in thread 0.  n <= 128 * (IL_LSUM / 3) elements (the host keeps M below that).
+__device__ __forceinline__ double il_np_sum_wg(GP<const double> a, long n, double *tab) {
+  __shared__ int sh_leaves;
+  if (threadIdx.x == 0) sh_leaves = il_np_leaves(0, n, tab, 0);
+  __syncthreads();
+  const int nl = sh_leaves;
+  double *part = tab + 2 * (size_t)nl;
+  for (int i = threadIdx.x; i < nl; i += IL_THREADS) {
+    const long lo = (long)tab[2 * i], len = (long)tab[2 * i + 1];
+    const auto q = a + (size_t)lo;
+    double res;
+    if (len < 8) {
+      res = 0.0;
+      for (long k = 0; k < len; ++k) res += q[k];
+    } else {
+      double r[8];
+      long k;
+      for (k = 0; k < 8; ++k) r[k] = q[k];
+      for (k = 8; k < len - (len % 8); k += 8)
+        for (int j = 0; j < 8; ++j) r[j] += q[k + j];
+      res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+      for (; k < len; ++k) res += q[k];
+    }
+    part[i] = res;
+  }
+  __syncthreads();
+  double out = 0.0;
+  if (threadIdx.x == 0) { int idx = 0; out = il_np_fold(n, part, idx); }
+  __syncthreads();
+  return out;
+}
+
+// J(candidate) = python sum() over the nodes in node order, for `rows` candidates whose node costs lie in rows of M doubles at Lg: strictly
+// sequential per candidate, so thread r < rows walks row r -- but through LDS tiles the whole workgroup loads (coalesced, the next tile
+// requested while this one is added) instead of one dependent global round trip per eight nodes.  The result is valid in threads < rows.
+__device__ __forceinline__ double il_seq_sums_tiled(GP<const double> Lg, int M, int rows, double *lsum) {
+  const int tid = threadIdx.x;
+  const int tile = IL_LSUM / rows;                      // nodes per tile
+  const int per = (rows * tile + IL_THREADS - 1) / IL_THREADS;      // elements per thread and tile (<= 4: IL_LSUM / IL_THREADS)
+  double pre[IL_LSUM / IL_THREADS];
+  auto request = [&](int n0) {
+    const int nn = M - n0 < tile ? M - n0 : tile;
+#pragma unroll
+    for (int e = 0; e < IL_LSUM / IL_THREADS; ++e) {
+      const int q = tid + e * IL_THREADS;
+      const int r = q / nn, c = q - r * nn;
+      pre[e] = (e < per && q < rows * nn) ? Lg[(size_t)r * M + n0 + c] : 0.0;
+    }
+  };
+  double J = 0.0;
+  request(0);
+  for (int n0 = 0; n0 < M; n0 += tile) {
+    const int nn = M - n0 < tile ? M - n0 : tile;
+#pragma unroll
+    for (int e = 0; e < IL_LSUM / IL_THREADS; ++e) {
+      const int q = tid + e * IL_THREADS;
+      const int r = q / nn, c = q - r * nn;
+      if (e < per && q < rows * nn) lsum[r * tile + c] = pre[e];
+    }
+    __syncthreads();
+    if (n0 + tile < M) request(n0 + tile);
+    if (tid < rows) {
+      const double *Ln = lsum + (size_t)tid * tile;
+      int c = 0;
+      for (; c + 8 <= nn; c += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = Ln[c + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) J += v[k];
+      }
+      for (; c < nn; ++c) J += Ln[c];
+    }
+    __syncthreads();
+  }
+  return J;
+}
+
 // ---- Riccati sweep of one chain segment, one wave (solver.py:344-421) -----------------------------------------------------
 // Per-wave LDS scratch (doubles): fx 0 | Vxx 36 | Tm 72 | Vr 108 (dt (V_xx[4+a][r] + mu [r == 4+a]), a < 2) | Vxr 120 (dt V_x[4+a]) |
 // U 124 (2 x 7: Q_ux rows with Q_u in column 6) | KK 138 (2 x 7: K rows with k in column 6) | Quu 152 | Vx 176 | constants IL_CST |
@@ -1284,6 +1379,11 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
         for (int q = tid; q < M; q += IL_THREADS) lsum[q] = T.L[q];
         __syncthreads();
         if (tid == 0) { sh_J = il_np_sum(lsum, M); sh_accepted = 0; }
+      } else if (M <= 64 * (IL_LSUM / 3)) {
+        // a big tree: leaf sums of numpy's pairwise recursion by all threads, folded by one (il_np_sum walked 30 k nodes through dependent
+        // global round trips: milliseconds per accepted step at stress scale); a leaf holds > 64 elements, the table 3 doubles per leaf
+        const double Jn = il_np_sum_wg(T.L, M, lsum);
+        if (tid == 0) { sh_J = Jn; sh_accepted = 0; }
       } else if (tid == 0) { sh_J = il_np_sum(T.L.p, M); sh_accepted = 0; }
       __syncthreads();
     }
@@ -1429,10 +1529,13 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
     if (M * IL_NA * nuse <= IL_LSUM) {
       for (int q = tid; q < M * IL_NA * nuse; q += IL_THREADS) lsum[q] = T.L_new[q];
       __syncthreads();
+    } else {
+      const double J = il_seq_sums_tiled(T.L_new, M, IL_NA * nuse, lsum);
+      if (tid < IL_NA * nuse) Jnew[tid / IL_NA][tid % IL_NA] = J;
     }
-    if (tid < IL_NA * nuse) {
+    if (M * IL_NA * nuse <= IL_LSUM && tid < IL_NA * nuse) {
       double J = 0.0;   // python sum(): sequential
-      const double *Ln = (M * IL_NA * nuse <= IL_LSUM) ? lsum + (size_t)tid * M : (T.L_new + (size_t)tid * M).p;
+      const double *Ln = lsum + (size_t)tid * M;
       // eight values requested together, added in node order (one dependent LDS round trip per node otherwise)
       int c = 0;
       for (; c + 8 <= M; c += 8) {
@@ -1640,10 +1743,13 @@ __device__ __forceinline__ void il_follow(const IlqrTreeDev &T, const IlqrConst 
       if (M * IL_NA <= IL_LSUM) {
         for (int q = tid; q < M * IL_NA; q += IL_THREADS) lsum[q] = Lg[q];
         __syncthreads();
+      } else {
+        const double J = il_seq_sums_tiled(Lg, M, IL_NA, lsum);
+        if (tid < IL_NA) ctl->Jnew[wg][tid] = J;
       }
-      if (tid < IL_NA) {
+      if (M * IL_NA <= IL_LSUM && tid < IL_NA) {
         double J = 0.0;
-        const double *Ln = (M * IL_NA <= IL_LSUM) ? lsum + (size_t)tid * M : (Lg + (size_t)tid * M).p;
+        const double *Ln = lsum + (size_t)tid * M;
         int c = 0;
         for (; c + 8 <= M; c += 8) {
           double v[8];

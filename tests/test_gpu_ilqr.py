@@ -420,3 +420,42 @@ def test_singular_q_uu_in_a_followers_slot(hip_predictor):
         for t in range(2):
             assert np.array_equal(one[0][0], many[0][t]) and np.array_equal(one[1][0], many[1][t]) and one[2][0] == many[2][t], (slots, t)
     assert np.array_equal(one[0][0], ref["xs"]) and np.array_equal(one[1][0], ref["us"]) and one[2][0]["iterations"] == ref["iterations"] and one[2][0]["mu"] == ref["mu"]
+
+
+def test_cost_tree_beyond_the_lds_sums_matches_oracle(hip_predictor):
+    """A cost tree of ~2 400 trajectory nodes (a short trunk, 300 branches): more nodes than the LDS staging of the cost sums holds, so the
+    nominal cost (numpy's pairwise L.sum(): leaf sums by all threads, folded along the same recursion) and the ten candidate costs (python
+    sum(): sequential, walked through LDS tiles) take their big-tree paths.  Bit-identical to the C oracle on one workgroup and on several."""
+    rng = np.random.default_rng(11)
+    trunk, nb, blen, a = 10, 300, 8, 3
+    parent = list(range(-1, trunk - 1))
+    prob = [1.0] * trunk
+    for b in range(nb):
+        for k in range(blen):
+            parent.append(trunk - 1 if k == 0 else len(parent) - 1)
+            prob.append(1.0 / nb)
+    M = len(parent)
+    assert M > 2048
+    depth = np.zeros(M, int)
+    for i in range(1, M):
+        depth[i] = depth[parent[i]] + 1
+    mean = np.zeros((M, a, 2), np.float32)
+    mean[:, 0, 0] = 0.8 * (depth + 1)                                                 # the ego's own prediction: straight ahead at 4 m/s
+    mean[:, 1] = np.stack([0.8 * (depth + 1) + 6.0, 0.2 + 0.3 * rng.standard_normal(M)], 1)       # a lead vehicle
+    mean[:, 2] = np.stack([0.8 * (depth + 1) - 1.0, 3.5 + 0.2 * rng.standard_normal(M)], 1)       # a neighbour
+    cov = (0.4 + 0.05 * depth[:, None] + 0.02 * rng.random((M, a))).astype(np.float32)
+    flat = dict(parent=np.asarray(parent, np.int32), prob=np.asarray(prob, np.float32), mean=mean, cov=cov)
+    lane = np.stack([np.linspace(-5.0, 60.0, 40), np.zeros(40)], 1)
+    x0 = oi.init_state(np.array([0.0, 0.1, 4.0, 0.0]), np.array([0.0, 0.0]))
+    cfg = oi.default_cfg(max_iter=4)
+    ref = oi.solve(cfg, flat, x0, lane, 4.0, 1, trace=True)
+    assert ref["iterations"] >= 2
+    try:
+        for wgs in (1, 4):
+            hip_predictor.set_tuning("ilqr_wgs", wgs)
+            xs, us, stt = hip_predictor.ilqr_solve(cfg, [flat], x0, lane, 4.0, 1)
+            assert hip_predictor.ilqr_stats()[2] == wgs
+            assert np.array_equal(xs[0], ref["xs"]) and np.array_equal(us[0], ref["us"]), wgs
+            assert stt[0]["iterations"] == ref["iterations"] and stt[0]["mu"] == ref["mu"] and stt[0]["J"] == ref["J"], wgs
+    finally:
+        hip_predictor.set_tuning("ilqr_wgs", 16)
