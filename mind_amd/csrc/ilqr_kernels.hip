@@ -27,10 +27,10 @@
 #define IL_THREADS 512
 #define IL_WAVES (IL_THREADS / 64)
 #ifndef IL_SPEC_OVERSUB
-#define IL_SPEC_OVERSUB 1   // (slot, segment) items per wave tolerated at the widest segment level
+#define IL_SPEC_OVERSUB 3   // (slot, segment) items per wave tolerated at the widest segment level
 #endif
 #define IL_SPEC 4     // Levenberg-Marquardt values evaluated speculatively per step INSIDE one workgroup (see k_ilqr)
-#define IL_SLOTS 8    // ... and by the follower workgroups of a tree (k_ilqr<GEN, 2>: one Levenberg-Marquardt value per workgroup); per-slot arrays
+#define IL_SLOTS 12   // ... and by the follower workgroups of a tree (k_ilqr<GEN, 2>: one Levenberg-Marquardt value per workgroup); per-slot arrays
                       // hold IL_SLOTS sets in that mode
 #define IL_MAXA 128   // agents per scene staged in LDS (cfg4: 64, stress: 128)
 #define IL_REL 15     // relevant-agent list length per node
@@ -521,7 +521,8 @@ __device__ __forceinline__ double il_seq_sums_tiled(GP<const double> Lg, int M, 
 // ahead.  Returns (wave-uniform) 1 if a Q_uu is singular.
 template <bool GEN>
 __device__ __forceinline__ int il_backward_segment(const IlqrConst &C, const IlqrTreeDev &T, const IlqrTreeDev &Ts, int s0, int s1,
-                                                   int c_last, int c_prev, double mu, double *scr IL_PROF_ARG) {
+                                                   int c_last, int c_prev, double mu, double *scr IL_PROF_ARG, const unsigned *watch = nullptr,
+                                                   unsigned watch_gen = 0u) {
   const int lane = threadIdx.x & 63;
   const int i = lane / 6, j = lane % 6;
   const bool mat = lane < 36, vxl = lane >= 36 && lane < 42;
@@ -584,8 +585,14 @@ __device__ __forceinline__ int il_backward_segment(const IlqrConst &C, const Ilq
   // the top of the next one, so it is issued behind the next node's loads instead and has a whole node to retire)
   double g0 = 0.0, g1 = 0.0;
   int gc = c;
+  // (a follower: the master's command word, read one node ahead -- when it has moved on, this slot's result is of no use to anybody: 2)
+  unsigned wnow = watch_gen;
   for (; r >= s0; --r) {
     IL_PT0();
+    if (watch) {
+      if ((unsigned)__builtin_amdgcn_readfirstlane((int)wnow) != watch_gen) return 2;
+      wnow = __hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const int cn = __builtin_amdgcn_readfirstlane(cn_v);
     cn_v = pSeg[r - 2 >= s0 ? r - 2 : s0];
     request(cn, N);
@@ -695,7 +702,8 @@ struct IlKv { double K[12], k[2], us[2], xs[6]; };
 // one node ahead (loads and stores share one in-order counter: a node's results are stored at the top of the NEXT node, behind
 // that node's operand loads).
 #define IL_PACK 6
-__device__ __forceinline__ void il_rollout_packed(const IlqrConst &C, const IlqrTreeDev &T, int lo, int ni, int R, int w, int init, int slot0 IL_PROF_ARG) {
+__device__ __forceinline__ int il_rollout_packed(const IlqrConst &C, const IlqrTreeDev &T, int lo, int ni, int R, int w, int init, int slot0 IL_PROF_ARG,
+                                                 const unsigned *watch = nullptr, unsigned watch_gen = 0u) {
   const int lane = threadIdx.x & 63;
   const int M = T.M;
   const int a = lane % IL_NA, g = lane / IL_NA;
@@ -776,11 +784,17 @@ __device__ __forceinline__ void il_rollout_packed(const IlqrConst &C, const Ilqr
     ++q;
     IL_PT(1); IL_PCNT(5);
   };
+  unsigned wnow = watch_gen;
   for (int n = 0; n < nmax; n += 2) {
+    if (watch) {          // (a follower whose master has moved on leaves: see il_backward_segment)
+      if ((unsigned)__builtin_amdgcn_readfirstlane((int)wnow) != watch_gen) return 1;
+      wnow = __hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     node(PA, PB);
     if (n + 1 < nmax) node(PB, PA);
   }
   store();
+  return 0;
 }
 
 // 3x3 window as separable axes: source column of window column c, source row of window row r, -1 = the
@@ -830,13 +844,18 @@ __device__ __forceinline__ void il_window_axes(int xi, int yi, int W, int H, int
 // it so that the waves without a state chain this step come first).
 template <bool GEN>
 __device__ __forceinline__ void il_cost_pass(const IlqrConst &C, const IlqrTreeDev &T, int nuse, double *recs, int wave, int nwaves,
-                                             GP<const int> nodes, int cnt, int slot0 IL_PROF_ARG) {
+                                             GP<const int> nodes, int cnt, int slot0 IL_PROF_ARG, const unsigned *watch = nullptr, unsigned watch_gen = 0u) {
   const int lane = threadIdx.x & 63;
   const int M = T.M, P = nuse * cnt;
   const int nchunk = (P + 5) / 6;
   const int a = lane % IL_NA, pl = lane / IL_NA;
+  unsigned wnow = watch_gen;
   for (int ch = wave; ch < nchunk; ch += nwaves) {
     IL_PT0();
+    if (watch) {          // (a follower whose master has moved on skips the chunks that are left)
+      if ((unsigned)__builtin_amdgcn_readfirstlane((int)wnow) != watch_gen) return;
+      wnow = __hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const int pi = ch * 6 + pl;
     const bool valid = lane < 60 && pi < P;
     const int pic = pi < P ? pi : P - 1;
@@ -1632,7 +1651,7 @@ __device__ __forceinline__ void il_follow(const IlqrTreeDev &T, const IlqrConst 
   double *recs = recs0 + (size_t)(threadIdx.x >> 6) * 6 * IL_RA;
   __shared__ unsigned f_gen, f_cmd;
   __shared__ double f_mu, f_de;
-  __shared__ int f_sing;
+  __shared__ int f_sing, f_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = T.M;
   IlSlotCtl *ctl = T.ctl;
@@ -1646,7 +1665,7 @@ __device__ __forceinline__ void il_follow(const IlqrTreeDev &T, const IlqrConst 
       while ((g = __hip_atomic_load(&ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == last) __builtin_amdgcn_s_sleep(8);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       f_gen = g; f_cmd = __hip_atomic_load(&ctl->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      f_mu = ctl->mu; f_de = ctl->delta; f_sing = 0;
+      f_mu = ctl->mu; f_de = ctl->delta; f_sing = 0; f_abort = 0;
     }
     __syncthreads();
     const unsigned g = f_gen, cmd = f_cmd;
@@ -1699,9 +1718,9 @@ __device__ __forceinline__ void il_follow(const IlqrTreeDev &T, const IlqrConst 
 #ifdef IL_PROFILE
         long long prof[16];
 #endif
-        const int sing = il_backward_segment<GEN>(C, T, Ts, rec[0], rec[1], rec[2], rec[4], mu, scr IL_PROF_PASS);
+        const int sing = il_backward_segment<GEN>(C, T, Ts, rec[0], rec[1], rec[2], rec[4], mu, scr IL_PROF_PASS, &ctl->gen, g);
         if (sing) {
-          if (lane == 0) f_sing = 1;
+          if (lane == 0) { if (sing == 2) f_abort = 1; else f_sing = 1; }
         } else {
           const int c = rec[3];
           if (lane < 36) Ts.Vxx[(size_t)c * 36 + lane] = scr[36 + lane];
@@ -1710,7 +1729,9 @@ __device__ __forceinline__ void il_follow(const IlqrTreeDev &T, const IlqrConst 
       }
       __threadfence_block();
       __syncthreads();
+      if (f_abort) break;
     }
+    if (f_abort) continue;          // the master has published its next command: this one's result would not be read
     if (!f_sing) {
       // ---- line search of this slot (solver.py:202-240): state chains, then candidate costs, as in il_fit with one slot
       for (int s = 0; s <= T.n_fsteps; ++s) {
@@ -1721,7 +1742,8 @@ __device__ __forceinline__ void il_follow(const IlqrTreeDev &T, const IlqrConst 
 #ifdef IL_PROFILE
           long long prof[16];
 #endif
-          for (int w = wave; w < R; w += IL_WAVES) il_rollout_packed(C, T, lo, ni, ni, w, 0, wg IL_PROF_PASS);
+          for (int w = wave; w < R; w += IL_WAVES)
+            if (il_rollout_packed(C, T, lo, ni, ni, w, 0, wg IL_PROF_PASS, &ctl->gen, g) && lane == 0) f_abort = 1;
         }
         if (s > 0) {
           const int n0 = T.fstep_nstart[s - 1], cnt = T.fstep_nstart[s] - n0;
@@ -1733,11 +1755,15 @@ __device__ __forceinline__ void il_follow(const IlqrTreeDev &T, const IlqrConst 
 #ifdef IL_PROFILE
           long long prof[16];
 #endif
-          il_cost_pass<GEN>(C, T, 1, recs, rank, IL_WAVES, T.fstep_nodes + (size_t)n0, cnt, wg IL_PROF_PASS);
+          il_cost_pass<GEN>(C, T, 1, recs, rank, IL_WAVES, T.fstep_nodes + (size_t)n0, cnt, wg IL_PROF_PASS, &ctl->gen, g);
         }
         __threadfence_block();
         __syncthreads();
+        if (f_abort) break;
       }
+      if (tid == 0 && !f_abort && __hip_atomic_load(&ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g) f_abort = 1;   // (cost chunks were skipped)
+      __syncthreads();
+      if (f_abort) continue;
       // ---- the ten sums J(alpha) = sum over the nodes in node order (python sum(): sequential), as il_fit adds them
       const GP<double> Lg = T.L_new + (size_t)wg * IL_NA * M;
       if (M * IL_NA <= IL_LSUM) {

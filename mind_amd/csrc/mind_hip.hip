@@ -110,10 +110,10 @@ struct mind_ctx {
   int ilqr_chunk = 0;
   // wide cost trees: workgroups per tree (halved until every workgroup of the launch is resident; cfg4 full tree, six trees per launch:
   // 8.33 / 7.40 / 7.37 / 7.63 ms per plan with 8 / 16 / 24 / 32, profiles/r03an), node count from which they are used (mind_set_tuning)
-  int ilqr_wgs = 16, ilqr_multi_min = 192;
+  int ilqr_wgs = 16, ilqr_multi_min = 192, ilqr_wgs_big = 32, ilqr_big_min = 12288;
   // narrow cost trees (below ilqr_multi_min nodes): workgroups per tree that take the fit's Levenberg-Marquardt slots (k_ilqr<GEN, 2>: a master +
   // ilqr_slots - 1 followers, one slot each; 1 = everything in one workgroup).  "ilqr_slots" / MIND_ILQR_SLOTS
-  int ilqr_slots = 8;
+  int ilqr_slots = 10;
   int dec_mfma_min = 1 << 30;   // agents per call from which the decoder's actor part runs on the MFMA kernel (MIND_DEC_MFMA_MIN; default: never)
   bool enc_mfma = true;         // MFMA ActorNet under the bf16x3 / bf16 settings (MIND_ENC_MFMA=0: the fp32 VALU kernel, for A/B)
   bool xcd_order = true;        // XCD-aware job order for big batches (MIND_XCD_ORDER=0 switches it off, for A/B measurements)
@@ -368,6 +368,8 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "ilqr_chunk") c->ilqr_chunk = value < 0 ? 0 : (int)value;
   else if (n == "ilqr_wgs") c->ilqr_wgs = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (n == "ilqr_multi_min") c->ilqr_multi_min = value;
+  else if (n == "ilqr_wgs_big") c->ilqr_wgs_big = value < 1 ? 1 : (value > 32 ? 32 : value);
+  else if (n == "ilqr_big_min") c->ilqr_big_min = value;
   else if (n == "ilqr_slots") c->ilqr_slots = value < 1 ? 1 : (value > IL_SLOTS ? IL_SLOTS : value);
   else if (n == "ilqr_test_starve") c->ilqr_test_starve = value != 0;   // tests: launch a wide tree without its last workgroups
   else return fail(c, MIND_EINVAL, "mind_set_tuning: unknown knob '%s'", name);
@@ -1476,6 +1478,9 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   int maxM = 0;
   for (int t = 0; t < n_trees; ++t) maxM = trees[t].n_nodes > maxM ? trees[t].n_nodes : maxM;
   int G = c->ilqr_wgs;
+  // trees of tens of thousands of nodes (the deep stress trees: 29.5 k) keep twice the workgroups busy: 55 -> 35 ms per launch at 32 per tree,
+  // while the cfg4 trees (6.5 k nodes) are best at 16-24 (profiles/r03an_*)
+  if (G > 1 && G < c->ilqr_wgs_big && maxM >= c->ilqr_big_min) G = c->ilqr_wgs_big;
   while (G > 1 && ((n_trees + 7) / 8) * 8 * G > c->n_cu) G >>= 1;     // every workgroup of the launch must be resident (1 per CU)
   const bool multi = !gen && !ev && G > 1 && maxM >= c->ilqr_multi_min;
   int GS = multi ? 1 : c->ilqr_slots;

@@ -368,7 +368,7 @@ def test_levenberg_marquardt_slots_on_follower_workgroups_equal_one_workgroup(hi
             assert hip_predictor.ilqr_stats()[2] == 1
             ref_tr = [(hip_predictor.ilqr_trace(t, 0), hip_predictor.ilqr_trace(t, 1)) for t in range(3)]
             assert sum(int((tr[:, 2] < 0).sum()) for tr, _ in ref_tr) + sum(int((tr[:, 2] < 0).sum()) for _, tr in ref_tr) > 0, name   # rejections happen
-            for slots, starve in ((2, 0), (3, 0), (4, 0), (8, 0), (8, 1)):
+            for slots, starve in ((2, 0), (3, 0), (4, 0), (8, 0), (12, 0), (10, 1)):
                 hip_predictor.set_tuning("ilqr_slots", slots)
                 hip_predictor.set_tuning("ilqr_test_starve", starve)
                 for rep in range(2):
@@ -381,7 +381,7 @@ def test_levenberg_marquardt_slots_on_follower_workgroups_equal_one_workgroup(hi
                             assert np.array_equal(hip_predictor.ilqr_trace(t, ph), ref_tr[t][ph]), (name, slots, starve, t, ph)
         finally:
             hip_predictor.set_tuning("ilqr_test_starve", 0)
-            hip_predictor.set_tuning("ilqr_slots", 8)
+            hip_predictor.set_tuning("ilqr_slots", 10)
     # the oracle's result, for good measure (the other tests of this file run with the default slot count)
     name, sst, flat, x0 = _contingency_cases()[0]
     w = oi.solve(cw, flat, x0, sst["target_lane"], sst["target_vel"], 0)
@@ -404,17 +404,17 @@ def test_singular_q_uu_in_a_followers_slot(hip_predictor):
     ref = oi.solve(cfg, flat, x0, sst["target_lane"], sst["target_vel"], 0)
     res = {}
     try:
-        for slots in (1, 2, 4, 8):
+        for slots in (1, 2, 4, 8, 12):
             hip_predictor.set_tuning("ilqr_slots", slots)
             out = hip_predictor.ilqr_solve(cfg, [flat, flat], x0, sst["target_lane"], sst["target_vel"], 0)
             res[slots] = (out, hip_predictor.ilqr_trace(0, 0), hip_predictor.ilqr_trace(1, 0))
     finally:
-        hip_predictor.set_tuning("ilqr_slots", 8)
+        hip_predictor.set_tuning("ilqr_slots", 10)
     one, tr1, _ = res[1]
     picks = tr1[:, 2]
     first = int(np.argmax(picks == -2))
     assert (picks == -2).any() and picks[first - 1] == -1 and (picks[first:] == -2).all(), picks       # singular right behind a rejection, then stuck
-    for slots in (2, 4, 8):
+    for slots in (2, 4, 8, 12):
         many, tra, trb = res[slots]
         assert np.array_equal(tr1, tra) and np.array_equal(tr1, trb), slots
         for t in range(2):
