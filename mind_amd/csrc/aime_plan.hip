@@ -13,6 +13,7 @@
 // every rank, the rank that holds a branching node's parent scene re-bases it and the next round's inputs + history windows are
 // all-gathered (packed / unpacked by k_copy_segs); the final rows / cost-tree entries are completed by one all-reduce over zero-filled
 // buffers.  world == 1 runs the same code without the exchanges.
+#include <chrono>
 namespace {
 
 struct PlScene {            // an observation pushed through the predictor: the root or a re-based branch node
@@ -214,6 +215,12 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   float pair_ms = 0.f;
   int pair_launches = 0;
   memset(out, 0, sizeof(*out));
+  // MIND_PLAN_TRACE=1: host time stamps of this call's sections on stderr (diagnostic: where the host stands between the kernels)
+  static const bool plan_trace = getenv("MIND_PLAN_TRACE") != nullptr;
+  const auto tr_t0 = std::chrono::steady_clock::now();
+  auto TR = [&](const char *what) {
+    if (plan_trace) fprintf(stderr, "[plan] %8.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr_t0).count(), what);
+  };
   // profiling (bench.py's live pair-kernel durations): the predictor calls of the plan record into an event pool that is read once at
   // the end, instead of draining the stream after every call
   struct DeferGuard { mind_ctx *c; ~DeferGuard() { c->ev_defer = false; c->ev_pending.clear(); c->ev_pool_used = 0; } } defer_guard{c};
@@ -339,8 +346,11 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
         sb.lane_feat = cb == 1 ? (const float *)c->pl_lf.p : (const float *)c->pl_lrep.p;
       }
       po.cls = d_cls; po.reg = d_reg; po.vel = d_vel;
+      TR("round: predictor launch begins");
       if ((rc = mind_predict_batch(c, &sb, &po))) return rc;
+      TR("round: predictor launched");
       if (!tables_done && (rc = prepare_tables())) return rc;
+      TR("round: tables prepared");
       n_expanded += cb;
       if (c->profiling) pair_launches += c->n_pair_launch;
       if (in->script_cls) {
@@ -372,7 +382,9 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       if ((rc = pl_pin(c, 2, n_back * sizeof(float)))) return rc;
       HIPCHK(c, hipMemcpyAsync(c->pl_pin[2], d_sel, n_back * sizeof(float), hipMemcpyDeviceToHost, st));
     }
+    TR("round: glue launched, waiting for the decisions");
     HIPCHK(c, hipStreamSynchronize(st));
+    TR("round: decisions on the host");
     h_dec = (const float *)c->pl_pin[2];
     // ---- create_nodes (scenario_tree.py:73-80): the kept modes scene by scene, visiting order within a scene
     for (int b = 0; b < B; ++b) {
@@ -525,6 +537,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     cur_in = nxt;
   }
   // ---- get_scenario_tree, first step (:208-216): every node on a finished branch is labelled; their rows are packed by one kernel
+  TR("rounds done");
   bool any_end = false;
   for (int li : leaves) any_end |= nodes[li].end;
   if (!any_end) return fail(c, MIND_ESTATE, "unsupported: no end node found in the scenario tree");
@@ -615,6 +628,19 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   const size_t Mtot = (size_t)c->pl_tree_off.back();
   c->pl_plan_agents = a;
   c->pl_rows_p = c->pl_fmean_p = c->pl_fcov_p = nullptr;
+  c->pl_dev_fmean = c->pl_dev_fcov = nullptr;
+  const bool want_solves = in->solve_cfg_full && !dist && !c->pl_tree_top.empty() && in->solve_x0 && in->solve_lane && in->solve_n_lane_pts >= 2;
+  bool solves_tried = false;
+  int solves_rc = MIND_OK;
+  auto begin_solves = [&]() {
+    // the contingency solves of the plan, begun by the plan itself: results stay in the library until mind_ilqr_finish_plan
+    solves_tried = true;
+    c->pl_sol_xs.resize(Mtot * 6); c->pl_sol_us.resize(Mtot * 2);
+    c->pl_sol_stw.resize(c->pl_tree_top.size()); c->pl_sol_stf.resize(c->pl_tree_top.size());
+    solves_rc = mind_ilqr_contingency_begin_plan(c, in->solve_cfg_warm, in->solve_cfg_full, in->solve_x0, in->solve_lane, in->solve_n_lane_pts,
+                                                 in->solve_target_vel, c->pl_sol_xs.data(), c->pl_sol_us.data(), c->pl_sol_stw.data(), c->pl_sol_stf.data());
+    c->il_finish_owned = solves_rc == MIND_OK;
+  };
   // one upload (both job tables), the two gather kernels, one read-back (rows | flat means | flat covariances)
   const size_t n_flat = Mtot * a * 3;
   if (n_rows + (int64_t)n_flat > 0) {
@@ -640,6 +666,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       memcpy(h + o_g + gJ + gW, job_of_block.data(), job_of_block.size() * sizeof(int));
       memcpy(h + o_g + gJ + gW + gB, agent_of_block.data(), agent_of_block.size() * sizeof(int));
     }
+    TR("end: trees flattened on the host");
     if (n_tab) HIPCHK(c, hipMemcpyAsync(c->pl_flat.p, h, n_tab, hipMemcpyHostToDevice, st));
     char *d = (char *)c->pl_flat.p;
     float *d_rows = (float *)(d + o_rows), *d_fmean = d_rows + n_rows, *d_fcov = d_fmean + Mtot * a * 2;
@@ -652,10 +679,27 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
                          (const int *)(d + o_g + gJ + gW), (const int *)(d + o_g + gJ + gW + gB), (const float *const *)(d + o_g + gJ), d_rows);
     HIPCHK(c, hipGetLastError());
     if (dist && (rc = pl_exchange(c, MIND_XCHG_ALLREDUCE, d_rows, d_rows, n_res * sizeof(float)))) return rc;
+    c->pl_dev_fmean = d_fmean; c->pl_dev_fcov = d_fcov;
     if ((rc = pl_pin(c, 2, n_res * sizeof(float)))) return rc;
     float *hp = (float *)c->pl_pin[2];
-    HIPCHK(c, hipMemcpyAsync(hp, d_rows, n_res * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    if (want_solves) {
+      // k_ilqr right behind k_aime_flat: the cost trees' agent arrays stay where that kernel wrote them (ilqr_impl reads them on the device),
+      // the host builds the solver's tables while the two packing kernels run, and the plan's read-back (rows | flat means | sigmas: what
+      // the caller's tree objects and the candidate evaluation want) travels on the copy stream BESIDE the solve instead of in front of it.
+      if (!c->ev_rows) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming));
+      HIPCHK(c, hipEventRecord(c->ev_tab, st));
+      HIPCHK(c, hipStreamWaitEvent(c->pl_copy, c->ev_tab, 0));
+      HIPCHK(c, hipMemcpyAsync(hp, d_rows, n_res * sizeof(float), hipMemcpyDeviceToHost, c->pl_copy));
+      HIPCHK(c, hipEventRecord(c->ev_rows, c->pl_copy));
+      TR("end: packing kernels + read-back queued");
+      begin_solves();
+      TR("end: solves begun");
+      HIPCHK(c, hipEventSynchronize(c->ev_rows));
+      TR("end: read-back on the host");
+    } else {
+      HIPCHK(c, hipMemcpyAsync(hp, d_rows, n_res * sizeof(float), hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipStreamSynchronize(st));
+    }
     // the plan's rows and flattened cost trees are handed out where the read-back put them (page-locked slot 2: nothing touches it before
     // the context's next plan, the lifetime mind_aime_plan_out promises); the deep stress trees return 0.9 GB here
     c->pl_rows_p = hp; c->pl_fmean_p = hp + n_rows; c->pl_fcov_p = hp + n_rows + Mtot * a * 2;
@@ -666,20 +710,16 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   out->rows = c->pl_rows_p; out->n_row_floats = n_rows;
   out->n_expanded = n_expanded; out->n_rounds = round;
   out->root_flags = (nodes[0].branch ? MIND_AIME_BRANCH : 0) | (nodes[0].end ? MIND_AIME_END : 0) | (nodes[0].term ? MIND_AIME_TERMINATE : 0);
-  if (c->profiling && (rc = mind_pair_events_resolve(c, &pair_ms))) return rc;      // (the stream is drained: every exit above synchronised)
+  if (c->profiling && (rc = mind_pair_events_resolve(c, &pair_ms))) return rc;      // (the plan's kernels have completed: every exit above waited for the read-back behind them)
   out->pair_ms = pair_ms; out->pair_launches = pair_launches;
   out->n_trees = (int)c->pl_tree_top.size(); out->tree_top = c->pl_tree_top.data(); out->tree_off = c->pl_tree_off.data();
   out->flat_parent = c->pl_flat_parent.data(); out->flat_prob = c->pl_flat_prob.data();
   out->flat_mean = c->pl_fmean_p; out->flat_cov = c->pl_fcov_p;
   // ---- the contingency solves of the plan, begun here when the caller handed their inputs in (no host round trip between the plan's
   //      read-back and k_ilqr); results stay in the library until mind_ilqr_finish_plan
-  if (in->solve_cfg_full && !dist && out->n_trees > 0 && in->solve_x0 && in->solve_lane && in->solve_n_lane_pts >= 2) {
-    c->pl_sol_xs.resize(Mtot * 6); c->pl_sol_us.resize(Mtot * 2);
-    c->pl_sol_stw.resize((size_t)out->n_trees); c->pl_sol_stf.resize((size_t)out->n_trees);
-    const int rs = mind_ilqr_contingency_begin_plan(c, in->solve_cfg_warm, in->solve_cfg_full, in->solve_x0, in->solve_lane, in->solve_n_lane_pts,
-                                                    in->solve_target_vel, c->pl_sol_xs.data(), c->pl_sol_us.data(), c->pl_sol_stw.data(), c->pl_sol_stf.data());
-    out->solves_begun = rs == MIND_OK ? 1 : 0;      // (a failed begin is not the plan's failure: the caller then solves the usual way)
-    c->il_finish_owned = rs == MIND_OK;
+  if (want_solves) {
+    if (!solves_tried) begin_solves();
+    out->solves_begun = solves_rc == MIND_OK ? 1 : 0;      // (a failed begin is not the plan's failure: the caller then solves the usual way)
   }
   return MIND_OK;
 }

@@ -175,6 +175,11 @@ struct mind_ctx {
   // per-iteration traces of the last tree-iLQR call (mind_last_ilqr_trace): device address per tree, rows per phase, iterations run
   std::function<int()> il_finish;     // the pending half of a call begun with mind_ilqr_contingency_begin
   bool il_finish_owned = false;       // ... whose outputs are library buffers (the solves a plan began itself): may be drained and dropped
+  // the cost trees' agent means / sigmas of the context's last plan where k_aime_flat wrote them (device): a tree-iLQR call on the plan's own
+  // trees (mind_ilqr_contingency_begin_plan) reads them there instead of taking them through the host
+  const float *pl_dev_fmean = nullptr, *pl_dev_fcov = nullptr;
+  bool il_use_dev_flat = false;
+  hipEvent_t ev_rows = nullptr;
   bool il_begin_only = false;
   std::vector<const double *> il_trace_dev;
   std::vector<int> il_trace_its;      // [tree][phase 2]
@@ -327,6 +332,7 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
     if (q) (void)hipHostFree(q);
   if (c->ev_pl) (void)hipEventDestroy(c->ev_pl);
   if (c->ev_tab) (void)hipEventDestroy(c->ev_tab);
+  if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
   if (c->pl_copy) (void)hipStreamDestroy(c->pl_copy);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1474,6 +1480,9 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     double ox, oy;
     il_make_grid(W, H, grid_res, x0, gx.data(), gy.data(), ox, oy);
   }
+  // (mind_ilqr_contingency_begin_plan: the trees' agent arrays are the plan's own device buffers, tree t at node offset pl_tree_off[t])
+  const bool dev_flat = c->il_use_dev_flat && !gen && !ev && c->pl_dev_fmean && c->pl_dev_fcov;
+  c->il_use_dev_flat = false;
   // ---- launch mode: one workgroup per tree | wide trees: G workgroups share a tree's items | narrow trees: G workgroups take a tree's LM slots
   int maxM = 0;
   for (int t = 0; t < n_trees; ++t) maxM = trees[t].n_nodes > maxM ? trees[t].n_nodes : maxM;
@@ -1515,7 +1524,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   for (int t = 0; t < n_trees; ++t) tl[t].stats = takeD(2 * IL_NSTAT);
   for (int t = 0; t < n_trees; ++t) {
     const mind_cost_tree &tr = trees[t];
-    if (tr.n_nodes <= 0 || !tr.parent || (!gen && (!tr.prob || tr.n_agents <= 0)) || (use_exo && (!tr.agent_mean || !tr.agent_cov)))
+    if (tr.n_nodes <= 0 || !tr.parent || (!gen && (!tr.prob || tr.n_agents <= 0)) || (use_exo && !dev_flat && (!tr.agent_mean || !tr.agent_cov)))
       return fail(c, MIND_EINVAL, "tree %d: bad arrays", t);
     if (tr.n_agents > IL_MAXA) return fail(c, MIND_EINVAL, "tree %d: %d agents > %d supported", t, tr.n_agents, IL_MAXA);
     const size_t M = tr.n_nodes;
@@ -1526,7 +1535,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M);
     L.Lxx = takeD(36 * M); L.k = takeD(nslot * 2 * M); L.K = takeD(nslot * 12 * M); L.Vx = takeD(nslot * 6 * M); L.Vxx = takeD(nslot * 36 * M);
     L.xsn = takeD(nslot * 60 * M); L.usn = takeD(nslot * 20 * M); L.Ln = takeD(nslot * 10 * M);
-    L.prob = takeF(M); L.mean = takeF(M * L.a * 2); L.cov = takeF(M * L.a);
+    L.prob = takeF(M); L.mean = takeF(dev_flat ? 0 : M * L.a * 2); L.cov = takeF(dev_flat ? 0 : M * L.a);
     L.parent = takeI(M); L.lnodes = takeI(M); L.cstart = takeI(M + 1); L.clist = takeI(M); L.rel = takeI(M);
     Mtot += (long)M;
   }
@@ -1667,8 +1676,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     if (us_init) memcpy(hD.data() + L.us, us_init + moff * 2, 2 * M * sizeof(double));
     if (tr.prob) memcpy(hF.data() + L.prob, tr.prob, M * sizeof(float));
     if (gen) memcpy(hD.data() + L.nodew, tr.node_w, M * IL_NW * sizeof(double));
-    if (tr.agent_mean && !gen) memcpy(hF.data() + L.mean, tr.agent_mean, M * L.a * 2 * sizeof(float));
-    if (tr.agent_cov && !gen) memcpy(hF.data() + L.cov, tr.agent_cov, M * L.a * sizeof(float));
+    if (tr.agent_mean && !gen && !dev_flat) memcpy(hF.data() + L.mean, tr.agent_mean, M * L.a * 2 * sizeof(float));
+    if (tr.agent_cov && !gen && !dev_flat) memcpy(hF.data() + L.cov, tr.agent_cov, M * L.a * sizeof(float));
     memcpy(hI.data() + L.parent, tr.parent, M * sizeof(int));
     memcpy(hI.data() + L.lstart, lvl_start[t].data(), lvl_start[t].size() * sizeof(int));
     memcpy(hI.data() + L.lnodes, lvl_nodes[t].data(), M * sizeof(int));
@@ -1698,6 +1707,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     D.trace = trace_cap > 0 ? Dp(L.trace) : nullptr; D.trace_cap = trace_cap; D.padt = 0;
     D.fstep_start = dI + L.fsstart; D.fstep_q0 = dI + L.fsq0; D.fstep_q1 = dI + L.fsq1; D.fstep_nstart = dI + L.fsnstart; D.fstep_nodes = dI + L.fsnodes;
     D.prob = dF + L.prob; D.mean = dF + L.mean; D.cov = dF + L.cov;
+    if (dev_flat) { D.mean = c->pl_dev_fmean + (size_t)moff * L.a * 2; D.cov = c->pl_dev_fcov + (size_t)moff * L.a; }
     D.xs = Dp(L.xs); D.us = Dp(L.us); D.Fx = Dp(L.Fx); D.L = Dp(L.L); D.Lx = Dp(L.Lx); D.Lxx = Dp(L.Lxx);
     D.k = Dp(L.k); D.K = Dp(L.K); D.Vx = Dp(L.Vx); D.Vxx = Dp(L.Vxx);
     D.xs_new = Dp(L.xsn); D.us_new = Dp(L.usn); D.L_new = Dp(L.Ln); D.stats = Dp(L.stats);
@@ -1922,12 +1932,16 @@ extern "C" int mind_ilqr_contingency_begin_plan(mind_ctx *c, const mind_ilqr_cfg
     memset(&T, 0, sizeof(T));
     T.n_nodes = c->pl_tree_off[t + 1] - c->pl_tree_off[t];
     T.parent = c->pl_flat_parent.data() + lo; T.prob = c->pl_flat_prob.data() + lo;
-    T.n_agents = a; T.agent_mean = c->pl_fmean_p + lo * a * 2; T.agent_cov = c->pl_fcov_p + lo * a;
+    T.n_agents = a;
+    // (host copies when the plan has read them back already; the call itself reads the device buffers k_aime_flat filled)
+    T.agent_mean = c->pl_fmean_p ? c->pl_fmean_p + lo * a * 2 : nullptr; T.agent_cov = c->pl_fcov_p ? c->pl_fcov_p + lo * a : nullptr;
   }
   c->il_begin_only = true;
+  c->il_use_dev_flat = c->pl_dev_fmean != nullptr && c->pl_dev_fcov != nullptr;
   const int rc = ilqr_impl(c, cfg_warm, nullptr, trees.data(), nt, x0, target_lane, n_lane_pts, target_vel, 0, nullptr, xs, us, stats_warm, nullptr,
                            cfg_full, stats_full);
   c->il_begin_only = false;
+  c->il_use_dev_flat = false;
   return rc;
 }
 
