@@ -12,18 +12,38 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
+def _load(name):
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    L = C.CDLL(path)
+    L.oracle_ilqr_solve.restype = C.c_int
+    L.oracle_field_eval.restype = C.c_int
+    L.oracle_lane_field.restype = C.c_int
+    return L
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libilqr_oracle.so")
-        if not os.path.exists(path):
-            import subprocess
-            subprocess.check_call(["make", "-s", "-C", _HERE])
-        _LIB = C.CDLL(path)
-        _LIB.oracle_ilqr_solve.restype = C.c_int
-        _LIB.oracle_field_eval.restype = C.c_int
-        _LIB.oracle_lane_field.restype = C.c_int
+        _LIB = _load("libilqr_oracle.so")
     return _LIB
+
+
+class libm_trig:
+    """``with oracle.ilqr.libm_trig(): ...`` -- the calls inside run the oracle built with the C library's sin / cos / tan
+    (libilqr_oracle_libm.so) instead of mind_trig.h: the independent witness for the header kernel and oracle share."""
+
+    def __enter__(self):
+        global _LIB
+        self.before = lib()
+        _LIB = _load("libilqr_oracle_libm.so")
+        return self
+
+    def __exit__(self, *exc):
+        global _LIB
+        _LIB = self.before
 
 
 def default_cfg(w_vel=0.1, max_iter=100):

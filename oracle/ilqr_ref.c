@@ -29,6 +29,16 @@
 /* test hooks (tests/test_trig.py) */
 void oracle_sincos(double x, double *s, double *c) { mind_sincos(x, s, c); }
 void oracle_tan_cos(double x, double *t, double *c) { mind_tan_cos(x, t, c); }
+#ifdef ORACLE_LIBM_TRIG
+/* libilqr_oracle_libm.so (Makefile): the same oracle with the C library's sin / cos / tan, as numpy calls them in the reference.  Kernel ==
+ * oracle "to the bit" rests on the header both include; this build is the independent witness that a defect of that header cannot hide on both
+ * sides: tests/test_oracle_ilqr.py holds it to the reference goldens and to the shared-header build. */
+static inline void libm_sincos(double x, double *s, double *c) { *s = sin(x); *c = cos(x); }
+static inline void libm_tan_cos(double x, double *t, double *c) { *t = tan(x); *c = cos(x); }
+#define mind_sincos libm_sincos
+#define mind_tan_cos libm_tan_cos
+#define mind_tan tan
+#endif
 
 #define NS 6
 #define NU 2

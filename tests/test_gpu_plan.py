@@ -152,6 +152,29 @@ class _arithmetic:
         self.rt.set_pair_precision(self.before)
 
 
+_WAIVED_PATH = os.path.join(ROOT, "tests", "golden", "waived_cycles.json")
+
+
+def _check_waived(test, key, observed):
+    """The cycles a parity test does NOT compare outright are classified (better optimum under the same objective / a fit whose own
+    solution moves by more than the tolerance under its inputs' rounding noise) -- and pinned: the classified sets must equal the record
+    committed in tests/golden/waived_cycles.json, so that no cycle can silently join or leave them.  A change that moves last bits moves
+    the chaotic fits: re-run with MIND_UPDATE_WAIVED=<file> (the observed sets are written there), review the difference, commit the file."""
+    import json
+    observed = {k: sorted(int(x) for x in v) for k, v in observed.items()}
+    upd = os.environ.get("MIND_UPDATE_WAIVED")
+    if upd:
+        rec = json.load(open(upd)) if os.path.exists(upd) else {}
+        rec.setdefault(test, {})[key] = observed
+        with open(upd, "w") as f:
+            json.dump(rec, f, indent=1, sort_keys=True)
+        return
+    rec = json.load(open(_WAIVED_PATH))
+    want = rec.get(test, {}).get(key)
+    assert want is not None, f"no pinned record for {test} / {key}: observed {observed}"
+    assert observed == want, f"{test} / {key}: classified cycles {observed} != the pinned record {want} (tests/golden/waived_cycles.json)"
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "f32"])
 @pytest.mark.parametrize("scene", ["demo_1", "demo_2", "demo_3", "demo_4"])
 def test_recorded_demo_scenes_match_reference_closed_loop(scene, prec):
@@ -217,17 +240,38 @@ def test_recorded_demo_scenes_branching_weights(scene):
     poor local minima on some of these cost trees (its own candidate costs range from 0.1 to 22: DESIGN 2 "chaotic cases").
     A cycle where this planner chooses another tree is accepted only if the plan it chose is at least as good under the
     same objective (its cost <= the reference's best cost + 1e-3), i.e. the solver found a better optimum, not a different
-    problem; wherever the same tree is chosen, sibling probabilities, agent trajectories, covariances and -- for candidates
-    whose costs agree to 1e-3 -- the ego trajectory must match."""
+    problem; wherever the same tree is chosen, sibling probabilities, agent trajectories and covariances must match, and so must the
+    ego plan of the chosen candidate (<= 1e-3 m + float32 resolution of the map coordinates, controls <= 2e-3) -- unless that candidate's fit
+    is one where this solver's OWN solution moves by more than the tolerance when its inputs move by their rounding resolution (the
+    perturbation probe of the whole-run tests): every miss is classified, an unclassified one fails, and the classified cycles are pinned
+    in tests/golden/waived_cycles.json."""
     sys.path.insert(0, ROOT)
     from bench import WORKLOADS, make_closed_loop
+    from mind_amd.planners.mind.trajectory_tree import flatten_scenario_tree, ilqr_cfg_from
     D = np.load(os.path.join(ROOT, "tests", "golden", "demo_branch.npz"))
     pl, sim, w = make_closed_loop(dict(WORKLOADS[scene]), scripted=False, ckpt="formula_branching:20240121")
+    rt, opt = pl.network.rt, pl.traj_tree_opt
+    cap = {}
+    orig_batch = opt.solve_batch
+
+    def capture(scen_trees, init_state, init_ctrl, target_lane, target_vel):     # what the contingency solves were given
+        trees = orig_batch(scen_trees, init_state, init_ctrl, target_lane, target_vel)
+        cap["common"] = (ilqr_cfg_from(opt.config, "w_opt_cfg"), ilqr_cfg_from(opt.config, "opt_cfg"),
+                         opt._get_init_state(init_state, init_ctrl), np.asarray(target_lane, np.float64), target_vel)
+        cap["scen_trees"], cap["xs"] = scen_trees, [t._arrays[0][1:] for t in trees]
+        return trees
+
+    def ill_conditioned(j):
+        cw, cf, x0, lane, tv = cap["common"]
+        return _solution_moves_under_rounding_noise(rt.ilqr_contingency, (cw, cf, [flatten_scenario_tree(cap["scen_trees"][j])], x0, lane, tv), cap["xs"][j])
+
+    opt.solve_batch = capture
     ulp = float(np.spacing(np.float32(np.abs(w.pos[0, 0]).max())))
     tol = 1e-3 + 2 * ulp
     steps = list(D[scene + "_plan_steps"])
     state_in, ctrl_in = D[scene + "_state_in"], D[scene + "_ctrl_in"]
     same_choice = ego_ok = 0
+    better, other_ill, ego_ill = [], [], []
     for pi, step in enumerate(steps):
         while sim.n_plans <= pi:
             will_plan = sim.sim_time >= sim.enable_time and (sim.last_trigger is None or
@@ -253,7 +297,13 @@ def test_recorded_demo_scenes_branching_weights(scene):
         st, tt = sim.last_result[0][0], sim.last_result[1][0]
         keys = list(st.nodes.keys())
         if keys != list(D[f"{scene}_p{pi}_scen_keys"]):
-            assert costs.min() <= ref_costs.min() + 1e-3, (pi, keys, costs, ref_costs)      # a better optimum, not a different problem
+            if costs.min() <= ref_costs.min() + 1e-3:              # a better optimum, not a different problem
+                better.append(pi)
+            else:                                                  # ... or the candidate the two solvers disagree on is ill-conditioned
+                j = int(np.argmax(np.abs(costs - ref_costs)))
+                moved = ill_conditioned(j)
+                assert moved > tol, (pi, keys, costs, ref_costs, moved)
+                other_ill.append(pi)
             continue
         same_choice += 1
         probs = np.array([float(np.ravel(st.nodes[k].data[0])[0]) for k in keys])
@@ -267,15 +317,22 @@ def test_recorded_demo_scenes_branching_weights(scene):
         tk = [k for k in tt.nodes.keys() if k != -1]
         assert np.array_equal(np.array([tt.nodes[k].parent_key for k in tk]), D[f"{scene}_p{pi}_traj_parent"])
         best = int(np.argmin(ref_costs))
-        if abs(costs[best] - ref_costs[best]) < 1e-3:
-            xs = np.array([tt.nodes[k].data[0] for k in tk])
-            us = np.array([tt.nodes[k].data[1] for k in tk])
-            d = max(float(np.abs(xs[:, :2] - D[f"{scene}_p{pi}_traj_xs"][:, :2]).max()),
-                    float(np.abs(us - D[f"{scene}_p{pi}_traj_us"]).max()))
-            ego_ok += d < max(tol, 2e-3)
-            print(f"{scene} cycle {pi}: same tree {keys[0]}, ego plan max deviation {d:.2e}")
-    print(f"{scene}: chosen tree equal in {same_choice}/{len(steps)} cycles, ego plan within tolerance in {ego_ok}")
-    assert same_choice >= len(steps) - 1 and ego_ok >= same_choice - 1
+        xs = np.array([tt.nodes[k].data[0] for k in tk])
+        us = np.array([tt.nodes[k].data[1] for k in tk])
+        d_xy = float(np.abs(xs[:, :2] - D[f"{scene}_p{pi}_traj_xs"][:, :2]).max())
+        d_u = float(np.abs(us - D[f"{scene}_p{pi}_traj_us"]).max())
+        if d_xy < tol and d_u < 2e-3:
+            ego_ok += 1
+            continue
+        # the same tree with another ego plan: only where the chosen candidate's fit is ill-conditioned under its own inputs' noise
+        moved = ill_conditioned(int(pl.timing["best_traj_idx"]))
+        print(f"{scene} cycle {pi}: same tree {keys[0]}, ego plan deviates by {d_xy:.2e} m / {d_u:.2e} (controls); costs {costs[best]:.6f} vs the "
+              f"reference's {ref_costs[best]:.6f}; own solution moves by {moved:.2e} m under rounding noise")
+        assert moved > tol, (pi, d_xy, d_u, moved, costs, ref_costs)         # a well-conditioned fit that disagrees is a real failure
+        ego_ill.append(pi)
+    print(f"{scene}: chosen tree equal in {same_choice}/{len(steps)} cycles (better optimum in {better}, ill-conditioned other choice in {other_ill}), "
+          f"ego plan within tolerance in {ego_ok}, ill-conditioned chosen fit in {ego_ill}")
+    _check_waived("branching_weights_12_cycles", scene, {"better_optimum": better, "other_choice_ill_conditioned": other_ill, "ego_plan_ill_conditioned": ego_ill})
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "f32"])
@@ -289,8 +346,8 @@ def test_recorded_demo_scenes_branching_weights_whole_run(scene, prec):
     cost trees (DESIGN 2 "chaotic cases": either solver can stop in a poor local minimum -- candidate costs of 1e4 next to 0.2).
     A cycle with another choice is therefore accepted only if this planner's best cost is at least as good as the reference's,
     or if the candidate whose cost disagrees is one where this solver's OWN answer moves by more than the parity tolerance
-    when its inputs are perturbed by their rounding resolution (the criterion of the plain-weights whole-run test).  At least
-    the observed number of cycles (minus one) must choose the reference's tree outright: 58 / 53 / 59 / 59 of 60.
+    when its inputs are perturbed by their rounding resolution (the criterion of the plain-weights whole-run test).  The cycles of
+    either kind are pinned (tests/golden/waived_cycles.json): none can silently join or leave them.
     Both arithmetics of the predictor: the default (bf16x3) and fp32 throughout, the reference's own precision."""
     sys.path.insert(0, ROOT)
     from bench import WORKLOADS, make_closed_loop
@@ -358,11 +415,11 @@ def _whole_run_against_demo_branch_runs(scene, prec, pl, sim, w):
     print(f"{scene} [{prec}]: 60/60 cycles with the reference's AIME tree ({min(n_nodes)}..{max(n_nodes)} nodes); same tree chosen in "
           f"{same_choice}, better optimum in {better}, ill-conditioned candidate in {ill}; (cycle, own cost of own / of the reference's choice, "
           f"reference's cost of its own / of this planner's choice): {margins}")
-    # floor = the count observed on the MI355X minus one (profiles/r04aj_pytest_gpu_parity_lines.txt: fp32 59 / 54 / 60 / 60 of 60 = 233 of 240,
-    # bf16x3 59 / 53 / 60 / 60 = 232 -- demo_2 holds the ill-conditioned solves, its count moved between 50 and 54 with the last bits of
-    # the builds of this round; round 3: 233 in bf16x3; round 2: 221); the waived cycles are listed in the line printed above
-    floors = {"bf16x3": {"demo_1": 58, "demo_2": 52, "demo_3": 59, "demo_4": 59}, "f32": {"demo_1": 58, "demo_2": 53, "demo_3": 59, "demo_4": 59}}
-    assert max(n_nodes) > 1 and same_choice >= floors[prec][scene], same_choice
+    # every cycle with another choice is classified above; WHICH cycles are is pinned (tests/golden/waived_cycles.json: fp32 59 / 54 / 60 / 60 of
+    # 60 cycles choose the reference's tree outright = 233 of 240, bf16x3 59 / 53 / 60 / 60 = 232; the same sets on every box and build since
+    # round 4 -- the kernels are deterministic, the chaotic fits move only when somebody changes last bits)
+    assert max(n_nodes) > 1 and same_choice == 60 - len(better) - len(ill)
+    _check_waived("branching_weights_whole_run", f"{scene}/{prec}", {"better_optimum": better, "ill_conditioned": ill})
 
 
 def test_full_tree_plan_is_identical_with_device_assembled_windows():
@@ -571,8 +628,8 @@ def test_recorded_demo_scenes_whole_run_teacher_forced(scene):
     cell lookups and an LM schedule amplify 1e-16 differences into different local minima, DESIGN 2 "chaotic cases").
     A cycle whose ego plan differs by more than the tolerance must therefore be one where this solver's OWN answer moves
     by more than the tolerance when its inputs are perturbed by their rounding resolution (+-1 float32 ulp of the agent
-    means, 1e-13 relative on the initial state); otherwise the test fails.  The observed number of cycles (minus one) must
-    agree outright: 59 / 49 / 57 / 55 of 60."""
+    means, 1e-13 relative on the initial state); otherwise the test fails.  The ill-conditioned cycles are pinned
+    (tests/golden/waived_cycles.json): none can silently join or leave them."""
     sys.path.insert(0, ROOT)
     from bench import WORKLOADS, make_closed_loop
     D = np.load(os.path.join(ROOT, "tests", "golden", "demo_runs.npz"))
@@ -629,10 +686,10 @@ def test_recorded_demo_scenes_whole_run_teacher_forced(scene):
         assert moved > tol, (pi, d_ego, d_ctrl, moved)       # a well-conditioned cycle that disagrees is a real failure
         ill.append(pi)
     assert worst_agents < tol, worst_agents
-    # floor = the count observed on the MI355X minus one (profiles/r04aj_pytest_gpu_parity_lines.txt: 60 / 49 / 58 / 56 of 60 = 223 of 240;
-    # round 3: 60 / 50 / 58 / 56 with the root scene built on the device, 60 / 50 / 59 / 58 with the host featuriser: the chaotic cycles
-    # move with the last bits of their inputs -- every cycle that disagrees is shown ill-conditioned above)
-    assert agree >= {"demo_1": 59, "demo_2": 48, "demo_3": 57, "demo_4": 55}[scene], (agree, ill)
+    # every cycle that disagrees is shown ill-conditioned above; WHICH cycles do is pinned (tests/golden/waived_cycles.json: 60 / 49 / 58 / 56 of
+    # 60 agree outright = 223 of 240; the chaotic cycles move only with the last bits of their inputs)
+    assert agree == n - len(ill)
+    _check_waived("plain_weights_whole_run", scene, {"ill_conditioned": ill})
     # these scenes grow one chain-shaped tree every cycle: from the second cycle on the warm-start fit is the one that ran
     # beside the predictor (speculate_warm) -- the comparisons above therefore cover that path
     assert opt.counters["warm_hits"] >= n - 2, opt.counters

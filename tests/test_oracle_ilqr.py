@@ -129,3 +129,20 @@ def test_oracle_iteration_trace_equals_the_imported_references(kind, a):
         assert np.array_equal(got[:, 0], ref[:, 0])                                           # the Levenberg-Marquardt schedule
         assert np.array_equal(np.where(got[:, 2] >= 0, 1.0, got[:, 2]), ref[:, 2])            # accepted / rejected / singular
         assert np.allclose(got[:, 1], ref[:, 1], rtol=1e-9, atol=0.0)                         # cost of the nominal trajectory
+
+
+@pytest.mark.parametrize("kind,a,max_iter", CASES)
+def test_oracle_with_the_c_librarys_trigonometry_meets_the_same_goldens(kind, a, max_iter):
+    """Kernel == oracle bit for bit rests on ONE trigonometry routine both include (mind_amd/csrc/mind_trig.h).  The independent witness: the same
+    oracle built with the C library's sin / cos / tan (what numpy calls in the reference; oracle/Makefile libilqr_oracle_libm.so) meets the
+    reference goldens at the same tolerances, and the shared-header build stays within 1e-9 of it -- a defect of the header would show in
+    both comparisons (it cannot cancel on the two sides of a kernel-vs-oracle test)."""
+    key = f"{kind}_a{a}_it{max_iter}"
+    flat, w, f = run_oracle(kind, a, max_iter)
+    with oi.libm_trig():
+        flat2, w2, f2 = run_oracle(kind, a, max_iter)
+    assert np.abs(w2["xs"] - G[key + "_xs_w"]).max() < 1e-9 and np.abs(w2["us"] - G[key + "_us_w"]).max() < 1e-9
+    assert np.abs(f2["xs"] - G[key + "_xs_f"]).max() < 1e-8 and np.abs(f2["us"] - G[key + "_us_f"]).max() < 1e-8
+    assert w2["mu"] == G[key + "_Jw"][1] and f2["mu"] == G[key + "_Jf"][1] and w2["iterations"] == w["iterations"] and f2["iterations"] == f["iterations"]
+    assert np.abs(w2["xs"] - w["xs"]).max() < 1e-9 and np.abs(f2["xs"] - f["xs"]).max() < 1e-8
+    assert np.abs(w2["us"] - w["us"]).max() < 1e-9 and np.abs(f2["us"] - f["us"]).max() < 1e-8
