@@ -384,21 +384,28 @@ typedef struct {
  * per scene, planners/mind/networks/network.py:318,497, and prune_merge works scene by scene, scenario_tree.py:281-412.)
  * Per round: every rank runs predictor + pruning + branch-time test on its block -> ONE all-gather of the decisions (96 B per
  * scene) -> every rank replays create_nodes / decide_branch on the same table (the tree is replicated, 0.2 ms at 1 555 nodes) ->
- * the rank that holds a branching node's parent scene re-bases it (update_obser, on the device) -> ONE all-gather of the next
- * round's predictor inputs + history windows (packed and unpacked by the library).  At the end every rank packs the rows / cost
- * tree entries of the nodes whose predicted rows it holds and ONE all-reduce (sum over zero-filled buffers) completes them
- * everywhere.  With world == 1 the same code runs without exchanges.
+ * the rank that holds a branching node's parent scene re-bases it (update_obser, on the device) -> ONE small all-gather of the
+ * children's frames (28 floats per scene: the replicated tree's node records; + LaneNet's output after the root round) and ONE
+ * all-to-all that moves a re-based scene (predictor inputs + history windows, ~240 KB at 64 agents) from the rank that re-based it to
+ * the rank whose block of the next round holds it -- on a full tree the two are the same rank except at the block boundaries, so only
+ * the boundary scenes travel (skipped by every rank when nothing does).  At the end every rank packs the rows / cost tree entries of
+ * the nodes whose predicted rows it holds and ONE all-reduce (sum over zero-filled buffers) completes them everywhere.  With
+ * world == 1 the same code runs without exchanges.
  *
  * The transport is the caller's: a function that performs a collective on DEVICE buffers of this context's device,
  *   MIND_XCHG_ALLGATHER:  recv [world][bytes] <- every rank's send [bytes], in rank order;
  *   MIND_XCHG_ALLREDUCE:  recv [bytes / 4 words] <- sum over the ranks of send (send may equal recv).  Every word is non-zero on at most
  *                         one rank (its owner), so the transport should sum 32-bit INTEGERS: the owner's bits then arrive unchanged
  *                         (a float sum would turn an owner's -0.0 into +0.0).
+ *   MIND_XCHG_ALLTOALLV:  the last argument is the ADDRESS of a host table int64 [2][world]: bytes this rank sends to / receives from every
+ *                         rank; send / recv hold the per-rank segments packed in rank order (torch.distributed.all_to_all_single with split
+ *                         sizes).
  * It is called with everything the library queued on the context's stream complete, and must return with the result complete
  * (mind_amd/parallel.py: torch.distributed -- RCCL over xGMI on a node, gloo in the tests).  world <= 1 or fn == NULL switches
  * the sharding off; force != 0 runs the exchanges of a one-rank group too (tests: RCCL on a one-GPU box). */
 #define MIND_XCHG_ALLGATHER 0
 #define MIND_XCHG_ALLREDUCE 1
+#define MIND_XCHG_ALLTOALLV 2
 typedef int (*mind_exchange_fn)(void *user, int op, void *send, void *recv, int64_t bytes);
 int mind_set_exchange(mind_ctx *ctx, int rank, int world, mind_exchange_fn fn, void *user, int force);
 /* collectives run and bytes received by this context's sharded plans so far */

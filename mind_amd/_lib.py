@@ -114,7 +114,7 @@ EXPORTS = ["mind_ctx_create", "mind_ctx_destroy", "mind_last_error_string", "min
 
 # transport of the sharded mind_aime_plan (include/mind_hip.h): int fn(void *user, int op, void *send, void *recv, int64 bytes)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
-XCHG_ALLGATHER, XCHG_ALLREDUCE = 0, 1
+XCHG_ALLGATHER, XCHG_ALLREDUCE, XCHG_ALLTOALLV = 0, 1, 2
 
 _lib = None
 

@@ -76,6 +76,16 @@ int pl_exchange(mind_ctx *c, int op, void *send, void *recv, size_t bytes) {
   return MIND_OK;
 }
 
+// all-to-all with per-pair sizes: table = [2][world] bytes this rank sends to / receives from every rank (send / recv are packed in rank order)
+int pl_exchange_v(mind_ctx *c, void *send, void *recv, const int64_t *table) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int rc = c->xfn(c->xuser, MIND_XCHG_ALLTOALLV, send, recv, (int64_t)(intptr_t)table);
+  if (rc) return fail(c, MIND_EHIP, "mind_aime_plan: the exchange callback failed (%d)", rc);
+  c->x_collectives += 1;
+  for (int r = 0; r < c->xw; ++r) c->x_bytes += (long long)table[(size_t)c->xw + r];
+  return MIND_OK;
+}
+
 int pl_copy_segs(mind_ctx *c, const std::vector<CopySeg> &segs) {
   if (segs.empty()) return MIND_OK;
   long long mx = 0;
@@ -481,35 +491,92 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       HIPCHK(c, hipGetLastError());
     }
     if (dist) {
-      // ---- one all-gather completes the next round's inputs + windows everywhere: per rank [header | the twelve array slices of its
-      //      children, each laid out for the largest child count]; the header is LaneNet's output after the root round (rank 0 ran it)
+      // ---- the next round's inputs + windows go where they are NEEDED: scene s of the next round was re-based by the rank that predicted its
+      //      parent (its children are the contiguous range [s0_r, s0_r + cnt_r)) and is predicted -- and later branched from -- by the rank
+      //      whose block [nlo, nhi) of the next round holds it.  On a full tree the two ranges coincide up to the block boundaries, so only
+      //      the boundary scenes travel (all-to-all with per-pair sizes; round 4 handed every rank ALL scenes: 52 MB per cfg4 round,
+      //      3.7 GB on the deepest stress tree).  What every rank does need of every scene is small: its frame (ROT / ORIG / TGT_PTS, 28 floats:
+      //      the replicated tree's node records) and, after the root round, LaneNet's output -- one all-gather.
       struct Arr { float *base; size_t per; };
-      const Arr arrs[12] = {{d_in + q.actors, (size_t)a * 14 * 48}, {d_in + q.ctrs, (size_t)a * 2}, {d_in + q.vecs, (size_t)a * 2}, {d_in + q.lc, (size_t)l * 2},
-                            {d_in + q.lv, (size_t)l * 2}, {d_in + q.tn, 160}, {d_in + q.tr, 20}, {d_in + q.fr, 28}, {d_in + q.cov, (size_t)a},
+      const Arr arrs[11] = {{d_in + q.actors, (size_t)a * 14 * 48}, {d_in + q.ctrs, (size_t)a * 2}, {d_in + q.vecs, (size_t)a * 2}, {d_in + q.lc, (size_t)l * 2},
+                            {d_in + q.lv, (size_t)l * 2}, {d_in + q.tn, 160}, {d_in + q.tr, 20}, {d_in + q.cov, (size_t)a},
                             {w_pos, (size_t)a * OBS * 2}, {w_ang, (size_t)a * OBS}, {w_vel, (size_t)a * OBS * 2}};
+      float *fr_base = d_in + q.fr;
       int cmax = 0;
       for (int r = 0; r < XW; ++r) cmax = std::max(cmax, cnt_r[r]);
-      const size_t n_hdr = round == 0 ? (size_t)l * 128 : 0;
-      size_t off[13];
-      off[0] = n_hdr;
-      for (int k = 0; k < 12; ++k) off[k + 1] = off[k] + arrs[k].per * (size_t)cmax;
-      const size_t n_pay = (off[12] + 3) & ~(size_t)3;
-      if ((rc = ensure(c, c->x_send, n_pay * sizeof(float)))) return rc;
-      if ((rc = ensure(c, c->x_recv, (size_t)XW * n_pay * sizeof(float)))) return rc;
-      float *snd = (float *)c->x_send.p, *rcv = (float *)c->x_recv.p;
-      std::vector<CopySeg> segs;
-      if (n_hdr && XR == 0) segs.push_back({(const float *)c->pl_lf.p, snd, (long long)n_hdr});
-      for (int k = 0; k < 12 && Sm > 0; ++k) segs.push_back({arrs[k].base + arrs[k].per * (size_t)s0, snd + off[k], (long long)(arrs[k].per * (size_t)Sm)});
-      if ((rc = pl_copy_segs(c, segs))) return rc;
-      if ((rc = pl_exchange(c, MIND_XCHG_ALLGATHER, snd, rcv, n_pay * sizeof(float)))) return rc;
-      segs.clear();
-      if (n_hdr && XR != 0) segs.push_back({rcv, (float *)c->pl_lf.p, (long long)n_hdr});
-      for (int r = 0; r < XW; ++r) {
-        if (r == XR || cnt_r[r] == 0) continue;
-        for (int k = 0; k < 12; ++k)
-          segs.push_back({rcv + (size_t)r * n_pay + off[k], arrs[k].base + arrs[k].per * (size_t)s0_r[r], (long long)(arrs[k].per * (size_t)cnt_r[r])});
+      // (1) all-gather: [LaneNet output (root round, from rank 0) | the frames of this rank's children, laid out for the largest child count]
+      {
+        const size_t n_hdr = round == 0 ? (size_t)l * 128 : 0;
+        const size_t n_pay = (n_hdr + (size_t)cmax * 28 + 3) & ~(size_t)3;
+        if ((rc = ensure(c, c->x_send, n_pay * sizeof(float)))) return rc;
+        if ((rc = ensure(c, c->x_recv, (size_t)XW * n_pay * sizeof(float)))) return rc;
+        float *snd = (float *)c->x_send.p, *rcv = (float *)c->x_recv.p;
+        std::vector<CopySeg> segs;
+        if (n_hdr && XR == 0) segs.push_back({(const float *)c->pl_lf.p, snd, (long long)n_hdr});
+        if (Sm > 0) segs.push_back({fr_base + (size_t)s0 * 28, snd + n_hdr, (long long)Sm * 28});
+        if ((rc = pl_copy_segs(c, segs))) return rc;
+        if ((rc = pl_exchange(c, MIND_XCHG_ALLGATHER, snd, rcv, n_pay * sizeof(float)))) return rc;
+        segs.clear();
+        if (n_hdr && XR != 0) segs.push_back({rcv, (float *)c->pl_lf.p, (long long)n_hdr});
+        for (int r = 0; r < XW; ++r) {
+          if (r == XR || cnt_r[r] == 0) continue;
+          segs.push_back({rcv + (size_t)r * n_pay + n_hdr, fr_base + (size_t)s0_r[r] * 28, (long long)cnt_r[r] * 28});
+        }
+        if ((rc = pl_copy_segs(c, segs))) return rc;
       }
-      if ((rc = pl_copy_segs(c, segs))) return rc;
+      // (2) all-to-all: producer j -> consumer k, the scenes [max(s0_j, nlo_k), min(s0_j + cnt_j, nhi_k)); per pair the eleven array slices one
+      //     behind the other.  Every rank computes the same table, so a round whose ranges coincide everywhere is skipped by all of them
+      size_t per_scene = 0;
+      for (int k = 0; k < 11; ++k) per_scene += arrs[k].per;
+      auto isect = [&](int j, int k, int &i0, int &i1) {          // scenes rank j produced that rank k consumes
+        int klo, khi;
+        pl_block(S, k, XW, klo, khi);
+        i0 = std::max(s0_r[j], klo); i1 = std::min(s0_r[j] + cnt_r[j], khi);
+        if (i1 < i0) i1 = i0;
+      };
+      long long any = 0;
+      std::vector<int64_t> tab(2 * (size_t)XW, 0);               // bytes this rank sends to / receives from every rank
+      for (int j = 0; j < XW; ++j)
+        for (int k = 0; k < XW; ++k) {
+          if (j == k) continue;
+          int i0, i1;
+          isect(j, k, i0, i1);
+          any += i1 - i0;
+          if (j == XR) tab[k] = (int64_t)(i1 - i0) * (int64_t)per_scene * (int64_t)sizeof(float);
+          if (k == XR) tab[(size_t)XW + j] = (int64_t)(i1 - i0) * (int64_t)per_scene * (int64_t)sizeof(float);
+        }
+      if (any > 0) {
+        size_t n_snd = 0, n_rcv = 0;
+        for (int r = 0; r < XW; ++r) { n_snd += (size_t)tab[r] / sizeof(float); n_rcv += (size_t)tab[(size_t)XW + r] / sizeof(float); }
+        if ((rc = ensure(c, c->x_send, (n_snd + 4) * sizeof(float)))) return rc;
+        if ((rc = ensure(c, c->x_recv, (n_rcv + 4) * sizeof(float)))) return rc;
+        float *snd = (float *)c->x_send.p, *rcv = (float *)c->x_recv.p;
+        std::vector<CopySeg> segs;
+        size_t o = 0;
+        for (int k = 0; k < XW; ++k) {
+          if (k == XR) continue;
+          int i0, i1;
+          isect(XR, k, i0, i1);
+          for (int e = 0; e < 11 && i1 > i0; ++e) {
+            segs.push_back({arrs[e].base + arrs[e].per * (size_t)i0, snd + o, (long long)(arrs[e].per * (size_t)(i1 - i0))});
+            o += arrs[e].per * (size_t)(i1 - i0);
+          }
+        }
+        if ((rc = pl_copy_segs(c, segs))) return rc;
+        if ((rc = pl_exchange_v(c, snd, rcv, tab.data()))) return rc;
+        segs.clear();
+        o = 0;
+        for (int j = 0; j < XW; ++j) {
+          if (j == XR) continue;
+          int i0, i1;
+          isect(j, XR, i0, i1);
+          for (int e = 0; e < 11 && i1 > i0; ++e) {
+            segs.push_back({rcv + o, arrs[e].base + arrs[e].per * (size_t)i0, (long long)(arrs[e].per * (size_t)(i1 - i0))});
+            o += arrs[e].per * (size_t)(i1 - i0);
+          }
+        }
+        if ((rc = pl_copy_segs(c, segs))) return rc;
+      }
     }
     // LaneNet's output repeated for this rank's scenes of the next round
     int nlo, nhi;

@@ -115,6 +115,20 @@ class Shard:
                         r.copy_(out)
                         torch.cuda.current_stream().synchronize()
                     self.bytes_gathered += nbytes * W
+                elif op == _lib.XCHG_ALLTOALLV:
+                    # `nbytes` is the address of the library's table int64 [2][world]: bytes to / from every rank (include/mind_hip.h)
+                    tab = (C.c_int64 * (2 * W)).from_address(nbytes)
+                    sb, rb = [int(tab[r]) for r in range(W)], [int(tab[W + r]) for r in range(W)]
+                    s, r = dev_bytes(send, max(sum(sb), 1))[:sum(sb)], dev_bytes(recv, max(sum(rb), 1))[:sum(rb)]
+                    if self.backend == "nccl":
+                        dist.all_to_all_single(r, s, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
+                        torch.cuda.current_stream().synchronize()
+                    else:
+                        out = torch.empty(sum(rb), dtype=torch.uint8)
+                        self._all_to_all_cpu(out, s.cpu(), rb, sb)
+                        r.copy_(out)
+                        torch.cuda.current_stream().synchronize()
+                    self.bytes_gathered += sum(rb)
                 else:
                     # the plan completes buffers whose entries every rank but the owner left zero: summed as INTEGERS the owner's bits arrive
                     # unchanged whatever the transport's arithmetic (a float sum turns an owner's -0.0 into +0.0)
@@ -145,6 +159,32 @@ class Shard:
         self.native = on
         rt._exchange_owner = self if on else None       # (the exchange belongs to the context: planners sharing it re-attach / detach, see detach)
         return self
+
+    def _all_to_all_cpu(self, out, inp, rb, sb):
+        """all_to_all_single on CPU tensors for the gloo tests: gloo's own all-to-all where this build has it, else one broadcast per
+        (sender, receiver) pair's sender -- the same bytes end up in the same places"""
+        dist = self.dist
+        try:
+            dist.all_to_all_single(out, inp, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
+            return
+        except (RuntimeError, NotImplementedError):
+            pass
+        W, me = self.world, self.rank
+        so, ro = [0], [0]
+        for r in range(W):
+            so.append(so[-1] + sb[r]); ro.append(ro[-1] + rb[r])
+        # every rank tells the others how much it sends to whom (the receivers' sizes are known, the bystanders' are not)
+        sizes = [None] * W
+        dist.all_gather_object(sizes, sb, group=self.group)
+        for src in range(W):
+            for dst in range(W):
+                n = sizes[src][dst]
+                if n == 0 or src == dst:
+                    continue
+                buf = inp[so[dst]:so[dst + 1]].clone() if me == src else torch.empty(n, dtype=torch.uint8)
+                dist.broadcast(buf, src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+                if me == dst:
+                    out[ro[src]:ro[src + 1]] = buf
 
     @staticmethod
     def detach(rt):

@@ -58,8 +58,13 @@ def test_three_ranks_and_the_full_tree_sharded_natively(tmp_path):
     single = _run(1, tmp_path, n_plans=1, port=29571, extra_env=env)[0]
     ranks = _run(3, tmp_path, n_plans=1, port=29572, extra_env=env)
     assert single["expanded"] == 259 and sum(r["expanded"] for r in ranks) == 259 and [r["expanded"] for r in ranks] == [87, 86, 86]
+    print("cfg4tree on 3 ranks: collectives per rank", [r["collectives"] for r in ranks], "MB received per rank", [round(r["gathered"] / 1e6, 2) for r in ranks])
     for b in ranks:
         assert b["native_plans"] == 1
+        # what a rank receives per plan (mind_last_exchange_stats): the decisions and frames of every scene, LaneNet's output once, the
+        # BOUNDARY scenes of the next round's blocks (all-to-all; round 4's all-gather handed every rank all 258 re-based scenes: 66 MB),
+        # the completed rows / cost trees
+        assert b["gathered"] < 10e6, b["gathered"]
         for pa, pb in zip(single["res"], b["res"]):
             assert pa["keys"] == pb["keys"] and pa["best"] == pb["best"] and pa["n_trees"] == pb["n_trees"] == 6
             assert np.array_equal(pa["pos0"], pb["pos0"]) and np.array_equal(pa["xs"], pb["xs"]) and np.array_equal(pa["ctrl"], pb["ctrl"])
