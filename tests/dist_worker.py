@@ -68,7 +68,30 @@ def collectives():
     rr = gather_round_robin(sh, sizes, local)
     t = torch.full((5,), float(r + 7), device=sh.device)
     sh.broadcast(t, 0)
-    return {"ga": ga.numpy(), "gb": gb.numpy(), "rr": [x.copy() for x in rr], "bc": t.numpy(), "n_coll": sh.n_collectives}
+    n_coll = sh.n_collectives
+    # the all-to-all of the sharded native plan's exchange (MIND_XCHG_ALLTOALLV) as its CPU transport performs it: rank j sends (j + 1) * (k + 2)
+    # bytes of value 16 j + k to rank k != j, nothing to itself -- through gloo's own all-to-all where this build has it, and through the
+    # broadcast fallback
+    a2a = []
+    for force_fallback in (False, True):
+        sb = [0 if k == r else (r + 1) * (k + 2) for k in range(W)]
+        rb = [0 if j == r else (j + 1) * (r + 2) for j in range(W)]
+        inp = torch.cat([torch.full((sb[k],), 16 * r + k, dtype=torch.uint8) for k in range(W)]) if sum(sb) else torch.empty(0, dtype=torch.uint8)
+        out = torch.zeros(sum(rb), dtype=torch.uint8)
+        if force_fallback:
+            real = dist.all_to_all_single
+
+            def refuse(*a_, **k_):
+                raise RuntimeError("no all-to-all in this build")
+            dist.all_to_all_single = refuse
+            try:
+                sh._all_to_all_cpu(out, inp, rb, sb)
+            finally:
+                dist.all_to_all_single = real
+        else:
+            sh._all_to_all_cpu(out, inp, rb, sb)
+        a2a.append(out.numpy().copy())
+    return {"ga": ga.numpy(), "gb": gb.numpy(), "rr": [x.copy() for x in rr], "bc": t.numpy(), "n_coll": n_coll, "a2a": a2a, "rank": r}
 
 
 if __name__ == "__main__":

@@ -54,6 +54,10 @@ def test_packed_tensor_collectives_world_3(tmp_path):
         assert [x.shape[0] for x in r["rr"]] == sizes and all((x == i).all() for i, x in enumerate(r["rr"]))
         assert (r["bc"] == 7.0).all()
         assert r["n_coll"] == 3 + 2 + 1          # counts + two tensors; counts + one tensor; broadcast
+        # the all-to-all with per-pair sizes (the sharded native plan's boundary-scene exchange), gloo's own and the broadcast fallback
+        k = r["rank"]
+        want = np.concatenate([np.full(((j + 1) * (k + 2),), 16 * j + k, np.uint8) for j in range(3) if j != k])
+        assert np.array_equal(r["a2a"][0], want) and np.array_equal(r["a2a"][1], want)
 
 
 def test_block_and_round_robin_partition():
