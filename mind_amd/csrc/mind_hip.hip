@@ -22,6 +22,7 @@
 #include "pair_tile_kernels.hip"
 #include "token_mfma_kernels.hip"
 #include "actor_mfma_kernels.hip"
+#include "actor_f32_kernels.hip"
 #include "dec_mfma_kernels.hip"
 #include "ilqr_kernels.hip"
 #include "aime_kernels.hip"
@@ -77,6 +78,7 @@ struct mind_ctx {
   ActorW actorW;
   DmW decBW;     // actor part of the decoder, same packing (dec_mfma_kernels.hip)
   AmW actorBW;   // the same convolutions as bf16 hi / lo MFMA fragments (actor_mfma_kernels.hip)
+  AfW actorFW;   // ... and as fp32 MFMA A fragments (actor_f32_kernels.hip)
   DecW decW;
   TokWeights tokW[7];  // [L]: epilogue of layer L-1 (L>=1) + prologue of layer L (L<=5); [0] = init
   TokWeightsM tokWM[7]; // the same matrices as fp32 MFMA A fragments (k_token_mfma<0>)
@@ -116,6 +118,13 @@ struct mind_ctx {
   int ilqr_slots = 10;
   int dec_mfma_min = 1 << 30;   // agents per call from which the decoder's actor part runs on the MFMA kernel (MIND_DEC_MFMA_MIN; default: never)
   bool enc_mfma = true;         // MFMA ActorNet under the bf16x3 / bf16 settings (MIND_ENC_MFMA=0: the fp32 VALU kernel, for A/B)
+  // fp32-MFMA ActorNet (k_actor_f32): "actor_f32" 1 (default) = the ActorNet of the exact-fp32 setting (0: the fp32 VALU kernel, for A/B);
+  // "actor_f32_min" = actors per call from which every setting takes it with TWO actors per workgroup (the 256-channel layers' weight stream is
+  // then shared by two actors: 7.1 vs 8.1 ms for the 13.8 k actors of a cfg4 round); "actor_f32_pair_min" = the same threshold inside the
+  // exact-fp32 setting.  Both default to never: a threshold on the batch size would give the blocks of a sharded round another kernel -- other
+  // last bits -- than the whole round (a workload that wants it sets 0, as with "dec_mfma_min")
+  bool actor_f32 = true;
+  int actor_f32_min = 1 << 30, actor_f32_pair_min = 1 << 30;
   bool xcd_order = true;        // XCD-aware job order for big batches (MIND_XCD_ORDER=0 switches it off, for A/B measurements)
   int pair_prec = 1;            // arithmetic of the pair kernel: 0 = fp32 MFMA, 1 = bf16x3 (split operands, default), 2 = bf16
   // bf16 arithmetics: k_pair_t (tile-native edge tensor, pair_tile_kernels.hip; default) or the row-major k_pair_bf of rounds 2-3
@@ -284,6 +293,10 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *se = getenv("MIND_ACTOR_SPLIT")) c->actor_np = atoi(se) == 3 ? 3 : 6;
   (void)hipFuncSetAttribute((const void *)k_actor_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_mfma_lds_bytes());
   if (const char *me = getenv("MIND_ENC_MFMA")) c->enc_mfma = !(me[0] == '0');
+  if (const char *me = getenv("MIND_ACTOR_F32")) c->actor_f32 = !(me[0] == '0');
+  if (const char *me = getenv("MIND_ACTOR_F32_MIN")) c->actor_f32_min = atoi(me);
+  (void)hipFuncSetAttribute((const void *)k_actor_f32<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_f32_lds_bytes(1));
+  (void)hipFuncSetAttribute((const void *)k_actor_f32<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_f32_lds_bytes(2));
   if (const char *de = getenv("MIND_DEC_MFMA_MIN")) c->dec_mfma_min = atoi(de);
   if (const char *oe = getenv("MIND_DEC_OVERLAP")) c->dec_overlap = !(oe[0] == '0');
   (void)hipFuncSetAttribute((const void *)k_ilqr<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
@@ -361,6 +374,9 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   const std::string n = name;
   if (n == "dec_mfma_min") c->dec_mfma_min = value;
   else if (n == "enc_mfma") c->enc_mfma = value != 0;
+  else if (n == "actor_f32") c->actor_f32 = value != 0;
+  else if (n == "actor_f32_min") c->actor_f32_min = value;
+  else if (n == "actor_f32_pair_min") c->actor_f32_pair_min = value;
   else if (n == "actor_split") c->actor_np = value == 3 ? 3 : 6;
   else if (n == "xcd_order") c->xcd_order = value != 0;
   else if (n == "pair_tile") c->pair_tile = value != 0;
@@ -659,6 +675,26 @@ std::vector<float> pack_conv_frag(const float *w, int co, int ci, int ksz, int c
   return out;
 }
 
+// conv weight [co][ci][k] (torch layout) -> A-operand fragments of v_mfma_f32_16x16x4_f32 for the GEMM of actor_f32_kernels.hip:
+// [m-tile co/16][k-group of 16][lane 64][4 floats]; lane (r, q) holds row co = 16 mt + r, GEMM indices k = 16 g + 4 q + (0..3),
+// k = dk * ci_pad + ci (ci_pad = ci rounded up to a power of two >= 16; zeros beyond)
+std::vector<float> pack_conv_f32(const float *w, int co, int ci, int ksz) {
+  int cp = 16;
+  while (cp < ci) cp *= 2;
+  const int G = ksz * cp / 16, mts = co / 16;
+  std::vector<float> t((size_t)mts * G * 256, 0.f);
+  if (w)
+    for (int mt = 0; mt < mts; ++mt)
+      for (int g = 0; g < G; ++g)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int m = 0; m < 4; ++m) {
+            const int k = g * 16 + 4 * (lane >> 4) + m;
+            const int dk = k / cp, cc = k % cp, o = 16 * mt + (lane & 15);
+            t[((size_t)(mt * G + g) * 64 + lane) * 4 + m] = (dk < ksz && cc < ci) ? w[((size_t)o * ci + cc) * ksz + dk] : 0.f;
+          }
+  return t;
+}
+
 }  // namespace
 
 extern "C" int mind_debug_pack_conv_frag(const float *w, int co, int ci, int ksz, uint32_t *out, size_t cap) {
@@ -707,6 +743,8 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
       B.add(k + ".c2", conv_t(sd.get(p + ".conv2.weight", (int64_t)co * co * 3), co, co, 3));
       B.add(k + ".c1B", pack_conv_frag(sd.get(p + ".conv1.weight", (int64_t)co * ci * 3), co, ci, 3));
       B.add(k + ".c2B", pack_conv_frag(sd.get(p + ".conv2.weight", (int64_t)co * co * 3), co, co, 3));
+      B.add(k + ".c1F", pack_conv_f32(sd.get(p + ".conv1.weight", (int64_t)co * ci * 3), co, ci, 3));
+      B.add(k + ".c2F", pack_conv_f32(sd.get(p + ".conv2.weight", (int64_t)co * co * 3), co, co, 3));
       B.add(k + ".g1", vec(sd.get(p + ".bn1.weight", co), co));
       B.add(k + ".b1", vec(sd.get(p + ".bn1.bias", co), co));
       B.add(k + ".g2", vec(sd.get(p + ".bn2.weight", co), co));
@@ -714,6 +752,7 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
       if (ds) {
         B.add(k + ".ds", conv_t(sd.get(p + ".downsample.0.weight", (int64_t)co * ci), co, ci, 1));
         B.add(k + ".dsB", pack_conv_frag(sd.get(p + ".downsample.0.weight", (int64_t)co * ci), co, ci, 1));
+        B.add(k + ".dsF", pack_conv_f32(sd.get(p + ".downsample.0.weight", (int64_t)co * ci), co, ci, 1));
         B.add(k + ".gd", vec(sd.get(p + ".downsample.1.weight", co), co));
         B.add(k + ".bd", vec(sd.get(p + ".downsample.1.bias", co), co));
       }
@@ -728,6 +767,7 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
       std::string p = "actor_net.lateral." + std::to_string(g), k = "act.lat" + std::to_string(g);
       B.add(k + ".W", conv_t(sd.get(p + ".conv.weight", (int64_t)128 * chans[g] * 3), 128, chans[g], 3));
       B.add(k + ".WB", pack_conv_frag(sd.get(p + ".conv.weight", (int64_t)128 * chans[g] * 3), 128, chans[g], 3));
+      B.add(k + ".WF", pack_conv_f32(sd.get(p + ".conv.weight", (int64_t)128 * chans[g] * 3), 128, chans[g], 3));
       B.add(k + ".g", vec(sd.get(p + ".norm.weight", 128), 128));
       B.add(k + ".b", vec(sd.get(p + ".norm.bias", 128), 128));
     }
@@ -929,6 +969,18 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
   for (int g = 0; g < 4; ++g) {
     bw.lat[g].w = (const u32 *)P("act.lat" + std::to_string(g) + ".WB");
     bw.lat[g].g = aw.latG[g]; bw.lat[g].b = aw.latB[g];
+  }
+  AfW &fw = c->actorFW;
+  for (int r = 0; r < 9; ++r) {
+    std::string k = "act.r" + std::to_string(r);
+    AfRes &R = fw.res[r];
+    R.c1 = P(k + ".c1F"); R.c2 = P(k + ".c2F"); R.ds = P(k + ".dsF");
+    R.g1 = aw.res[r].g1; R.b1 = aw.res[r].b1; R.g2 = aw.res[r].g2; R.b2 = aw.res[r].b2;
+    R.gd = aw.res[r].gd; R.bd = aw.res[r].bd;
+  }
+  for (int g = 0; g < 4; ++g) {
+    fw.lat[g].w = P("act.lat" + std::to_string(g) + ".WF");
+    fw.lat[g].g = aw.latG[g]; fw.lat[g].b = aw.latB[g];
   }
   c->rtab = P("fus.rtab");
   for (int L = 0; L < 6; ++L) {
@@ -1210,7 +1262,14 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   }
   // ActorNet: fp32 VALU kernel under MIND_PAIR_F32, the bf16-split / bf16 MFMA kernel otherwise (the precision setting covers
   // every MFMA contraction of the predictor)
-  if (c->pair_prec == 0 || !c->enc_mfma)
+  // ... and the fp32-MFMA kernel (plain fp32 operands on the matrix core: the reference's arithmetic class): the ActorNet of the exact-fp32
+  // setting, and -- two actors per workgroup -- of every setting on full-tree rounds (thousands of actors per call)
+  const bool f32_pair = c->actor_f32 && A >= (c->pair_prec == 0 ? c->actor_f32_pair_min : c->actor_f32_min);
+  if (f32_pair)
+    hipLaunchKernelGGL(k_actor_f32<2>, dim3((A + 1) / 2), dim3(AF_T), mind_actor_f32_lds_bytes(2), st, in->actors, A, actor_feat, c->actorFW);
+  else if (c->pair_prec == 0 && c->actor_f32 && c->enc_mfma)
+    hipLaunchKernelGGL(k_actor_f32<1>, dim3(A), dim3(AF_T), mind_actor_f32_lds_bytes(1), st, in->actors, A, actor_feat, c->actorFW);
+  else if (c->pair_prec == 0 || !c->enc_mfma)
     hipLaunchKernelGGL(k_actor_net, dim3(A), dim3(AT), mind_actor_lds_bytes(), st, in->actors, A, actor_feat, c->actorW);
   else if (c->pair_prec == 1 && c->actor_np == 6)
     hipLaunchKernelGGL(k_actor_mfma<6>, dim3(A), dim3(AM_T), mind_actor_mfma_lds_bytes(), st, in->actors, A, actor_feat, c->actorBW);

@@ -38,8 +38,8 @@ def test_hip_matches_golden(a, l, B, seed, hip_predictor, golden_predictor):
 @pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("bf16x3", 5e-5)])
 @pytest.mark.parametrize("a,l,B,seed", [(3, 4, 1, 1), (8, 20, 2, 1), (40, 55, 1, 1)])
 def test_actor_net_tap_by_arithmetic(prec, tol, a, l, B, seed, hip_predictor, golden_predictor):
-    """ActorNet output against the reference's golden tap, 5e-5 absolute on values up to ~4: the fp32 VALU kernel (k_actor_net,
-    "f32") and the MFMA kernel with both operands split into three bf16 parts (k_actor_mfma<6>, the default)."""
+    """ActorNet output against the reference's golden tap, 5e-5 absolute on values up to ~4: the fp32 MFMA kernel (k_actor_f32, "f32")
+    and the MFMA kernel with both operands split into three bf16 parts (k_actor_mfma<6>, the default)."""
     g = golden_predictor
     pb = predictor_batch(a, l, B, seed=seed)
     before = hip_predictor.pair_precision()
@@ -50,6 +50,35 @@ def test_actor_net_tap_by_arithmetic(prec, tol, a, l, B, seed, hip_predictor, go
     finally:
         hip_predictor.set_pair_precision(before)
     assert np.abs(af - g[f"a{a}_l{l}_b{B}_s{seed}_actor_net"]).max() < tol
+
+
+@pytest.mark.parametrize("a,l,B,seed", [(3, 4, 1, 1), (8, 20, 2, 1), (40, 55, 1, 1)])
+def test_actor_net_on_the_fp32_mfma_one_and_two_actors_per_workgroup(a, l, B, seed, hip_predictor, golden_predictor):
+    """k_actor_f32 (actor_f32_kernels.hip: plain fp32 operands on v_mfma_f32_16x16x4_f32): the ActorNet of the exact-fp32 setting with one
+    actor per workgroup, and -- two actors per workgroup, the 6-step layers' weight fragments shared -- of every setting on full-tree rounds.
+    Both against the reference's golden tap at the fp32 tolerance (odd actor counts leave the last workgroup half empty), against each other,
+    and against the fp32 VALU kernel they replace ("actor_f32" 0)."""
+    g = golden_predictor
+    pb = predictor_batch(a, l, B, seed=seed)
+    before = hip_predictor.pair_precision()
+    outs = {}
+    try:
+        for name, prec, tun in (("f32 x1", "f32", {}), ("f32 x2", "f32", {"actor_f32_pair_min": 0}), ("valu", "f32", {"actor_f32": 0}),
+                                ("default x2", "bf16x3", {"actor_f32_min": 0})):
+            hip_predictor.set_pair_precision(prec)
+            for k, v in tun.items():
+                hip_predictor.set_tuning(k, v)
+            hip_predictor.predict_numpy_batch(pb)
+            outs[name] = hip_predictor.debug_read("actor_feat").reshape(-1, 128).copy()
+            hip_predictor.set_tuning("actor_f32", 1); hip_predictor.set_tuning("actor_f32_pair_min", 1 << 30); hip_predictor.set_tuning("actor_f32_min", 1 << 30)
+    finally:
+        hip_predictor.set_tuning("actor_f32", 1); hip_predictor.set_tuning("actor_f32_pair_min", 1 << 30); hip_predictor.set_tuning("actor_f32_min", 1 << 30)
+        hip_predictor.set_pair_precision(before)
+    want = g[f"a{a}_l{l}_b{B}_s{seed}_actor_net"]
+    for name, af in outs.items():
+        assert af.shape == want.shape and np.abs(af - want).max() < 5e-5, (name, float(np.abs(af - want).max()))
+    assert np.abs(outs["f32 x1"] - outs["f32 x2"]).max() < 1e-5 and np.array_equal(outs["f32 x2"], outs["default x2"])
+    assert np.abs(outs["f32 x1"] - outs["valu"]).max() < 2e-5
 
 
 @pytest.mark.parametrize("a,l,B,seed", [(1, 1, 1, 5), (5, 1, 2, 5), (16, 15, 3, 2), (17, 30, 3, 4), (33, 64, 2, 6)])
