@@ -654,6 +654,28 @@ def run_fused(args):
         "ms_per_plan_aggregate": dt / (args.steps * P) * 1e3}))
 
 
+def config3_block(P=4, steps=20, warmup=3):
+    """BASELINE configs[2] (demo_1..4 concurrently on one GPU) for the default line: two sibling runs of this script, `--concurrent P
+    --processes` (a host process + HIP context per scene) and `--concurrent P --pipelined` (ONE process, one host thread, a context per scene),
+    each reporting the aggregate rate of its P closed loops."""
+    out = {"scenes": P, "workload": "the recorded scenes demo_1..4, one closed loop each, planned concurrently on one GPU"}
+    for mode, key in (("--processes", "processes"), ("--pipelined", "one_thread_event_loop")):
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "demo_all", "--concurrent", str(P), mode, "--steps", str(steps),
+                                "--warmup", str(warmup), "--no-cpu-baseline", "--no-extras", "--no-traffic"], capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[key] = {"error": (r.stderr or "no output")[-200:]}
+                continue
+            d = json.loads(line[-1])
+            out[key] = {"sim_steps_per_s": d["value"], "ms_per_round_of_plans": d["ms_per_step"]}
+        except Exception as e:      # noqa: BLE001
+            out[key] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    best = max((v["sim_steps_per_s"] for v in out.values() if isinstance(v, dict) and "sim_steps_per_s" in v), default=None)
+    out["sim_steps_per_s"] = best
+    return out
+
+
 # ---- the contract line ------------------------------------------------------------------------------------------------------
 EXTRAS_FILE = "bench_extras.json"
 LINE_LIMIT = 4096
@@ -716,10 +738,15 @@ def contract_line(out, args):
     for key in ("collectives_per_plan", "gathered_mb_per_plan"):
         if key in out:
             line[key] = out[key]
+    c3 = out.get("config3")
+    if isinstance(c3, dict):
+        line["config3"] = {"scenes": c3.get("scenes"), "sim_steps_per_s": c3.get("sim_steps_per_s"),
+                           "processes": (c3.get("processes") or {}).get("sim_steps_per_s"),
+                           "one_thread_event_loop": (c3.get("one_thread_event_loop") or {}).get("sim_steps_per_s")}
     line["extras_file"] = extras
     text = json.dumps(_sig(line), separators=(",", ":"))
     if len(text) > LINE_LIMIT:          # never let an extra cost the contract line: drop the optional blocks, largest first
-        for key in ("stress_deep", "stress_bf16", "stress", "stress_deeper", "tree_replicas", "breakdown_ms", "k_ilqr", "tree", "tree_sharded"):
+        for key in ("stress_deep", "stress_bf16", "stress", "stress_deeper", "config3", "tree_replicas", "breakdown_ms", "k_ilqr", "tree", "tree_sharded"):
             line.pop(key, None)
             text = json.dumps(_sig(line), separators=(",", ":"))
             if len(text) <= LINE_LIMIT:
@@ -873,6 +900,7 @@ def main():
             out["synthetic_branching"] = dict(summarize(measure(dist, "demo1", args.steps, args.warmup, False), prec),
                                               workload="demo_1-like synthetic scene, scripted mode branching on the real predictor forward")
             out["recorded_scenes"] = recorded_scenes(prec)
+            out["config3"] = config3_block()
             # the headline workload in the reference's own arithmetic class (fp32 MFMA pair kernel, fp32 VALU ActorNet)
             fm = measure(dist, "demo_1", args.steps, args.warmup, False, pair_prec="f32")
             fr = roofline(fm, "f32")
