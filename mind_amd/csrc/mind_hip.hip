@@ -2225,15 +2225,18 @@ void eval_nodes(const double *st, const double *ct, long N, const T *lane, int P
   }
   for (long i = 0; i < N; ++i) {
     const double px = st[6 * i], py = st[6 * i + 1];
-    double dmin = INFINITY;
+    // min over the segments of sqrt(e) = sqrt of the min of e: the correctly rounded square root is monotone, so ONE square root per node
+    // gives numpy's bits (np.sqrt per segment, then min) -- the division and the square root share the host's divider unit
+    double emin = INFINITY;
     for (int q = 0; q < P - 1; ++q) {
       const double sx = (double)lane[2 * q], sy = (double)lane[2 * q + 1], ddx = (double)dx[q], ddy = (double)dy[q];
       double t = ((px - sx) * ddx + (py - sy) * ddy) / (double)l2[q];
       t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
       const double ex = px - (sx + t * ddx), ey = py - (sy + t * ddy);
-      const double d = sqrt(ex * ex + ey * ey);
-      dmin = d < dmin ? d : dmin;
+      const double e = ex * ex + ey * ey;
+      emin = e < emin ? e : emin;
     }
+    const double dmin = sqrt(emin);
     const double c0 = ct[2 * i], c1 = ct[2 * i + 1], dv = tv - st[6 * i + 2];
     per_node[i] = ((0.1 * (c0 * c0) + 5.0 * (c1 * c1)) + 0.01 * (dv * dv)) + 0.01 * dmin;
   }

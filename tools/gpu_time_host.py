@@ -53,6 +53,11 @@ rt.lib.mind_aime_plan = _LibTimer(rt.lib.mind_aime_plan, "C: mind_aime_plan")
 wrap(opt, "solve_batch_begin", "solve_batch_begin (tables + upload + launch of the contingency solves, returns with the kernel queued)")
 rt.lib.mind_ilqr_contingency_begin_plan = _LibTimer(rt.lib.mind_ilqr_contingency_begin_plan, "C: mind_ilqr_contingency_begin_plan")
 rt.lib.mind_ilqr_finish = _LibTimer(rt.lib.mind_ilqr_finish, "C: mind_ilqr_finish (waits for the kernel)")
+rt.lib.mind_ilqr_finish_plan = _LibTimer(rt.lib.mind_ilqr_finish_plan, "C: mind_ilqr_finish_plan (waits for the kernel)")
+import mind_amd._lib as _L
+_L.load().mind_eval_traj_trees = _LibTimer(_L.load().mind_eval_traj_trees, "C: mind_eval_traj_trees")
+_L.load().mind_fill_tracks = _LibTimer(_L.load().mind_fill_tracks, "C: mind_fill_tracks")
+wrap(gen, "_native_args"); wrap(gen, "_native_trees"); wrap(pl, "_solve_and_select"); wrap(pl, "_plan_begin"); wrap(pl, "_solve_hooks")
 wrap(sim, "step_begin", "sim.step_begin"); wrap(sim, "step_end", "sim.step_end")
 import mind_amd.closed_loop as CLm
 wrap(CLm, "kine_propagate")
