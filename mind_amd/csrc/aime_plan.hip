@@ -536,9 +536,12 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       };
       long long any = 0;
       std::vector<int64_t> tab(2 * (size_t)XW, 0);               // bytes this rank sends to / receives from every rank
+      // (a forced group -- tests, overhead measurements: mind_set_exchange(force) -- also sends a rank's own scenes to itself through the
+      // transport: the same values land where they are, and the all-to-all is exercised with real data even in a one-rank RCCL group)
+      const bool self_too = c->xforce != 0;
       for (int j = 0; j < XW; ++j)
         for (int k = 0; k < XW; ++k) {
-          if (j == k) continue;
+          if (j == k && !self_too) continue;
           int i0, i1;
           isect(j, k, i0, i1);
           any += i1 - i0;
@@ -554,7 +557,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
         std::vector<CopySeg> segs;
         size_t o = 0;
         for (int k = 0; k < XW; ++k) {
-          if (k == XR) continue;
+          if (k == XR && !self_too) continue;
           int i0, i1;
           isect(XR, k, i0, i1);
           for (int e = 0; e < 11 && i1 > i0; ++e) {
@@ -567,7 +570,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
         segs.clear();
         o = 0;
         for (int j = 0; j < XW; ++j) {
-          if (j == XR) continue;
+          if (j == XR && !self_too) continue;
           int i0, i1;
           isect(j, XR, i0, i1);
           for (int e = 0; e < 11 && i1 > i0; ++e) {
