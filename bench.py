@@ -798,6 +798,7 @@ def main():
                     help="strong scaling: all ranks plan the SAME scene, AIME rounds and contingency solves sharded over ranks "
                          "(the default for the full-tree workloads)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent closed loops per rank even for a full-tree workload")
+    ap.add_argument("--headline-first", action="store_true", help="measure the headline before the extra workloads (the default runs them first: a fresh box warms up on them)")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -823,6 +824,98 @@ def main():
             return run_pipelined(args)
         return run_concurrent_processes(args) if args.processes else run_concurrent(args)
     shard = world > 1 and not args.replicas and (args.shard or args.workload in FULL_TREE)
+    extras = not args.no_extras and args.workload == "demo_1"
+    # The demo-size measurements of the line (plain weights, synthetic branching, the other recorded scenes, config 3, exact fp32: seconds of
+    # closed loops) run BEFORE the headline: a fresh box (the driver's, gpurun's) needs a few seconds of work to reach its steady state -- the first
+    # invocation of the day measured the same AIME rounds at 2.07 ms of host wall instead of 1.78 (profiles/r05v_*: 1 233-1 374 sim steps/s
+    # first, 1 470-1 500 from the second process on) -- and the closed loop's rate is what a loop that has been running delivers.  The full-tree
+    # workloads run AFTER it (behind their 200 GB arenas the same process runs the small loop 10 % slower).  --headline-first: the old order.
+    # Every measurement builds its own planner and closed loop.
+    pre = {}
+
+    def run_small_extras():
+        if extras and rank == 0 and world == 1:
+            pm = measure(dist, "demo_1", args.steps, args.warmup, False, ckpt=PLAIN_WEIGHTS)
+            pre["plain_formula_weights"] = dict(summarize(pm, pm["pl"].network.rt.pair_precision()), workload="recorded demo_1 with the plain formula weights (all modes merge: one expansion per plan)")
+            pre["synthetic_branching"] = dict((lambda sb_: summarize(sb_, sb_["pl"].network.rt.pair_precision()))(measure(dist, "demo1", args.steps, args.warmup, False)),
+                                              workload="demo_1-like synthetic scene, scripted mode branching on the real predictor forward")
+            pre["recorded_scenes"] = recorded_scenes(pm["pl"].network.rt.pair_precision())
+            pre["config3"] = config3_block()
+            # the headline workload in the reference's own arithmetic class (fp32 MFMA pair kernel, fp32 MFMA ActorNet)
+            fm = measure(dist, "demo_1", args.steps, args.warmup, False, pair_prec="f32")
+            fr = roofline(fm, "f32")
+            pre["exact_fp32"] = {"value": fm["sim_steps"] / fm["dt"], "unit": "sim steps/s", "ms_per_step": fm["dt"] / fm["steps"] * 1e3,
+                                 "pair_kernel_avg_launch_ms": fr["avg_launch_ms"] if fr else None,
+                                 "pair_kernel_frac_of_fp32_mfma_peak": fr["mfma"]["frac"] if fr else None,
+                                 "pair_kernel_frac_of_hbm_peak": fr["hbm"]["frac"] if fr else None,
+                                 "note": "same workload with MIND_PAIR_PREC=f32: every contraction of the predictor in fp32 (v_mfma_f32_16x16x4_f32 pair "
+                                         "kernel, ActorNet on v_mfma_f32_16x16x4_f32); the headline runs them as bf16 split operands with fp32 accumulation"}
+
+    def run_extras(small):
+        if small:
+            return run_small_extras()
+        if extras:
+            # the full cfg4 scenario tree (259 expansions per plan): on one GPU, or planned once by all ranks together.  A failure
+            # here must not cost the headline line (every rank reaches the same except branch or none does: the plan is replicated)
+            key = "tree_sharded" if world > 1 else "tree"
+            try:
+                t = measure(dist, "cfg4tree", args.tree_steps, 2, world > 1)      # two warm-up plans: the arenas and table caches reach their final sizes
+                pre[key] = dict(summarize(t, t["pl"].network.rt.pair_precision()), workload="cfg4tree: 64 agents x 256 lane polylines, full scripted 6-ary "
+                                "depth-4 AIME tree on the real predictor forward", n_gpus=world,
+                                scaling="strong" if world > 1 else None, plans_timed=args.tree_steps)
+            except Exception as e:       # noqa: BLE001
+                pre[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            if world > 1:
+                # the same full tree planned by every rank for a scene of its own (independent trees, no data-path collective): the node
+                # throughput of the whole job when the scenes, not one scene's branches, are what is spread over the GPUs
+                try:
+                    t = measure(dist, "cfg4tree", args.tree_steps, 2, False, replica=rank)
+                    pre["tree_replicas"] = dict(summarize(t, t["pl"].network.rt.pair_precision()), workload="cfg4tree on every rank, one independent scene per rank (full scripted 6-ary "
+                                                "depth-4 AIME tree on the real predictor forward); nodes_expanded_per_s is the whole job's", n_gpus=world,
+                                                scaling="weak", plans_timed=args.tree_steps)
+                    if "ms_per_plan" in pre.get("tree_sharded", {}):
+                        # the same tree on one GPU (a replica's plan) over the plan all ranks share: north_star's strong-scaling figure
+                        pre["tree_sharded"]["speedup_vs_1"] = pre["tree_replicas"]["ms_per_plan"] / pre["tree_sharded"]["ms_per_plan"]
+                except Exception as e:       # noqa: BLE001
+                    pre["tree_replicas"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        if extras and rank == 0 and world == 1:
+            try:
+                sm = measure(dist, "stress128tree", 6, 2, False)
+                pre["stress"] = dict(summarize(sm, sm["pl"].network.rt.pair_precision()), workload="stress128tree: 128 agents x 256 lane polylines (N = 385), full scripted 6-ary depth-4 AIME "
+                                     "tree (259 expansions per plan: the largest tree the reference's probability floor lets grow), default arithmetic",
+                                     plans_timed=6)
+                bm = measure(dist, "stress128tree", 6, 2, False, pair_prec="bf16")
+                pre["stress_bf16"] = dict(summarize(bm, "bf16"), workload="the same in plain bf16 (BASELINE config 5's 'bf16 MFMA attention'; misses the 1e-3 m bar)",
+                                          plans_timed=6)
+            except Exception as e:       # noqa: BLE001
+                pre["stress"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            try:
+                # the deepest tree K = 6 modes allow (ScriptedDeepTree: floor lifted, five rounds, the last one 1 296 scenes = 51 GB of bf16
+                # edges, through the predictor in chunks under the default 96 GB budget only if it had to)
+                dm = measure(dist, "stressdeep", 2, 1, False, pair_prec="bf16")
+                pre["stress_deep"] = dict(summarize(dm, "bf16"), workload="stressdeep: 128 agents x 256 lane polylines (N = 385), scripted 6-ary depth-5 AIME tree with "
+                                          "the path-probability floor lifted (rounds of 1 / 6 / 36 / 216 / 1 296 scenes = 1 555 expansions, 7 776 leaves per "
+                                          "plan), plain bf16 (edge tensor in bf16)", plans_timed=2)
+            except Exception as e:       # noqa: BLE001
+                pre["stress_deep"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            try:
+                # one level deeper (ScriptedDeeperTree): six rounds, the last one 7 776 scenes = 307 GB of bf16 edges, in chunks under a
+                # 64 GB budget (about 200 GB of the 288 GB in use); one plan timed behind one warm-up plan (arena growth)
+                xm = measure(dist, "stressdeeper", 1, 1, False, pair_prec="bf16", tuning={"plan_chunk_mb": (64 * 1024, 96 * 1024)})
+                pre["stress_deeper"] = dict(summarize(xm, "bf16"), workload="stressdeeper: the same scene under the scripted 6-ary depth-6 tree (BASELINE configs[4]'s "
+                                            "depth at the branching K = 6 modes allow): rounds of 1 / 6 / 36 / 216 / 1 296 / 7 776 scenes = 9 331 expansions, 46 656 "
+                                            "leaves per plan, the last round in chunks under a 64 GB edge budget, plain bf16", plans_timed=1)
+            except Exception as e:       # noqa: BLE001
+                pre["stress_deeper"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+
+    def run_extras_guarded(small):
+        try:
+            run_extras(small)
+        except Exception as e:       # noqa: BLE001      (an extra must never cost the headline line)
+            pre["extras_error"] = f"{type(e).__name__}: {e}"[:400]
+
+    if not args.headline_first:
+        run_extras_guarded(True)
     m = measure(dist, args.workload, args.steps, args.warmup, shard, replica=0 if shard else rank, ckpt=args.ckpt)
     pl, sim = m["pl"], m["sim"]
     prec = pl.network.rt.pair_precision()
@@ -861,31 +954,10 @@ def main():
     if m["collectives"] is not None:
         out["collectives_per_plan"] = m["collectives"][0] / args.steps
         out["gathered_mb_per_plan"] = m["collectives"][1] / args.steps / 1e6
-    extras = not args.no_extras and args.workload == "demo_1"
-    if extras:
-        # the full cfg4 scenario tree (259 expansions per plan): on one GPU, or planned once by all ranks together.  A failure
-        # here must not cost the headline line (every rank reaches the same except branch or none does: the plan is replicated)
-        key = "tree_sharded" if world > 1 else "tree"
-        try:
-            t = measure(dist, "cfg4tree", args.tree_steps, 2, world > 1)      # two warm-up plans: the arenas and table caches reach their final sizes
-            out[key] = dict(summarize(t, prec), workload="cfg4tree: 64 agents x 256 lane polylines, full scripted 6-ary "
-                            "depth-4 AIME tree on the real predictor forward", n_gpus=world,
-                            scaling="strong" if world > 1 else None, plans_timed=args.tree_steps)
-        except Exception as e:       # noqa: BLE001
-            out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
-        if world > 1:
-            # the same full tree planned by every rank for a scene of its own (independent trees, no data-path collective): the node
-            # throughput of the whole job when the scenes, not one scene's branches, are what is spread over the GPUs
-            try:
-                t = measure(dist, "cfg4tree", args.tree_steps, 2, False, replica=rank)
-                out["tree_replicas"] = dict(summarize(t, prec), workload="cfg4tree on every rank, one independent scene per rank (full scripted 6-ary "
-                                            "depth-4 AIME tree on the real predictor forward); nodes_expanded_per_s is the whole job's", n_gpus=world,
-                                            scaling="weak", plans_timed=args.tree_steps)
-                if "ms_per_plan" in out.get("tree_sharded", {}):
-                    # the same tree on one GPU (a replica's plan) over the plan all ranks share: north_star's strong-scaling figure
-                    out["tree_sharded"]["speedup_vs_1"] = out["tree_replicas"]["ms_per_plan"] / out["tree_sharded"]["ms_per_plan"]
-            except Exception as e:       # noqa: BLE001
-                out["tree_replicas"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+    if args.headline_first:
+        run_extras_guarded(True)
+    run_extras_guarded(False)
+    out.update(pre)
     if rank == 0 and world == 1:
         if not args.no_traffic and out.get("roofline"):
             tb, det = measure_traffic(args.workload, out["roofline"]["algorithmic_bytes_per_launch"])
@@ -894,50 +966,6 @@ def main():
         if not args.no_cpu_baseline:
             lcl = sim._observation()
             out["cpu_baseline"] = cpu_baseline(pl, lcl, (a, l), max(int(round(exp_plan)), 1), pl.scen_tree_gen.get_scenario_tree())
-        if extras:
-            pm = measure(dist, "demo_1", args.steps, args.warmup, False, ckpt=PLAIN_WEIGHTS)
-            out["plain_formula_weights"] = dict(summarize(pm, prec), workload="recorded demo_1 with the plain formula weights (all modes merge: one expansion per plan)")
-            out["synthetic_branching"] = dict(summarize(measure(dist, "demo1", args.steps, args.warmup, False), prec),
-                                              workload="demo_1-like synthetic scene, scripted mode branching on the real predictor forward")
-            out["recorded_scenes"] = recorded_scenes(prec)
-            out["config3"] = config3_block()
-            # the headline workload in the reference's own arithmetic class (fp32 MFMA pair kernel, fp32 VALU ActorNet)
-            fm = measure(dist, "demo_1", args.steps, args.warmup, False, pair_prec="f32")
-            fr = roofline(fm, "f32")
-            out["exact_fp32"] = {"value": fm["sim_steps"] / fm["dt"], "unit": "sim steps/s", "ms_per_step": fm["dt"] / fm["steps"] * 1e3,
-                                 "pair_kernel_avg_launch_ms": fr["avg_launch_ms"] if fr else None,
-                                 "pair_kernel_frac_of_fp32_mfma_peak": fr["mfma"]["frac"] if fr else None,
-                                 "pair_kernel_frac_of_hbm_peak": fr["hbm"]["frac"] if fr else None,
-                                 "note": "same workload with MIND_PAIR_PREC=f32: every contraction of the predictor in fp32 (v_mfma_f32_16x16x4_f32 pair "
-                                         "kernel, fp32 VALU encoders); the headline runs them as bf16 hi + lo split operands with fp32 accumulation"}
-            try:
-                sm = measure(dist, "stress128tree", 6, 2, False)
-                out["stress"] = dict(summarize(sm, prec), workload="stress128tree: 128 agents x 256 lane polylines (N = 385), full scripted 6-ary depth-4 AIME "
-                                     "tree (259 expansions per plan: the largest tree the reference's probability floor lets grow), default arithmetic",
-                                     plans_timed=6)
-                bm = measure(dist, "stress128tree", 6, 2, False, pair_prec="bf16")
-                out["stress_bf16"] = dict(summarize(bm, "bf16"), workload="the same in plain bf16 (BASELINE config 5's 'bf16 MFMA attention'; misses the 1e-3 m bar)",
-                                          plans_timed=6)
-            except Exception as e:       # noqa: BLE001
-                out["stress"] = {"error": f"{type(e).__name__}: {e}"[:400]}
-            try:
-                # the deepest tree K = 6 modes allow (ScriptedDeepTree: floor lifted, five rounds, the last one 1 296 scenes = 51 GB of bf16
-                # edges, through the predictor in chunks under the default 96 GB budget only if it had to)
-                dm = measure(dist, "stressdeep", 2, 1, False, pair_prec="bf16")
-                out["stress_deep"] = dict(summarize(dm, "bf16"), workload="stressdeep: 128 agents x 256 lane polylines (N = 385), scripted 6-ary depth-5 AIME tree with "
-                                          "the path-probability floor lifted (rounds of 1 / 6 / 36 / 216 / 1 296 scenes = 1 555 expansions, 7 776 leaves per "
-                                          "plan), plain bf16 (edge tensor in bf16)", plans_timed=2)
-            except Exception as e:       # noqa: BLE001
-                out["stress_deep"] = {"error": f"{type(e).__name__}: {e}"[:400]}
-            try:
-                # one level deeper (ScriptedDeeperTree): six rounds, the last one 7 776 scenes = 307 GB of bf16 edges, in chunks under a
-                # 64 GB budget (about 200 GB of the 288 GB in use); one plan timed behind one warm-up plan (arena growth)
-                xm = measure(dist, "stressdeeper", 1, 1, False, pair_prec="bf16", tuning={"plan_chunk_mb": (64 * 1024, 96 * 1024)})
-                out["stress_deeper"] = dict(summarize(xm, "bf16"), workload="stressdeeper: the same scene under the scripted 6-ary depth-6 tree (BASELINE configs[4]'s "
-                                            "depth at the branching K = 6 modes allow): rounds of 1 / 6 / 36 / 216 / 1 296 / 7 776 scenes = 9 331 expansions, 46 656 "
-                                            "leaves per plan, the last round in chunks under a 64 GB edge budget, plain bf16", plans_timed=1)
-            except Exception as e:       # noqa: BLE001
-                out["stress_deeper"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if rank == 0:
         print(contract_line(out, args))
     dist.close()

@@ -37,7 +37,8 @@ int pl_pin(mind_ctx *c, int which, size_t bytes) {      // (declared ahead of il
   if (bytes <= c->pl_pin_cap[which]) return MIND_OK;
   if (c->pl_pin[which]) (void)hipHostFree(c->pl_pin[which]);
   c->pl_pin[which] = nullptr; c->pl_pin_cap[which] = 0;
-  const size_t want = bytes + bytes / 2 + 4096;
+  // (page-locked staging follows the device buffers' policy: small ones double from 1 MB -- hipHostFree + hipHostMalloc cost a millisecond)
+  const size_t want = bytes < ((size_t)64 << 20) ? std::max<size_t>(2 * bytes, (size_t)1 << 20) : bytes + bytes / 2 + 4096;
   if (hipHostMalloc(&c->pl_pin[which], want, hipHostMallocDefault) != hipSuccess)
     return fail(c, MIND_ENOMEM, "hipHostMalloc(%zu) failed", want);
   c->pl_pin_cap[which] = want;

@@ -235,7 +235,11 @@ static int ensure(mind_ctx *c, DevBuf &b, size_t bytes) {
   if (b.p) (void)hipFree(b.p);
   b.p = nullptr;
   b.cap = 0;
-  size_t want = bytes + bytes / 4 + 4096;
+  // growth: a buffer is re-allocated (hipFree + hipMalloc: a device synchronisation each) whenever a plan needs more than any before it --
+  // small buffers (demo-size scenes: the scene and tree-node counts of the first dozens of plans of a process creep upwards) double and start
+  // at 1 MB, so that a closed loop stops re-allocating after its first plans (a fresh process ran its first 20 timed cycles at 2.1-2.6 ms of
+  // AIME wall instead of 1.8, profiles/r05w_*); big arenas (the deep stress trees: hundreds of GB) keep the 25 % margin
+  size_t want = bytes < ((size_t)64 << 20) ? std::max<size_t>(2 * bytes, (size_t)1 << 20) : bytes + bytes / 4 + 4096;
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) {
     e = hipMalloc(&b.p, bytes);

@@ -190,6 +190,8 @@ class MINDPlanner:
         lane, info = self.resample_target_lane(lcl_smp)
         self.scen_tree_gen.set_target_lane(lane, info)
         n0 = self.scen_tree_gen.n_expanded
+        if hasattr(self.traj_tree_opt, "prewarm"):
+            self.traj_tree_opt.prewarm()          # (first plan only: one-time set-up of the speculative warm start's side context)
         # warm-start fits of the previous cycle's tree shapes start now, beside the predictor (trajectory_tree.py)
         self.traj_tree_opt.speculate_warm(self.state, self.ctrl, self.gt_tgt_lane, lcl_smp.target_velocity)
         # the native AIME plan hands its flattened cost trees over before the scenario trees exist as Python objects: the contingency

@@ -119,6 +119,24 @@ def to_traj_tree(flat, x0, xs, us, action_size=2):
     return _LazyTrajTree(flat["parent"], x0, xs, us, action_size)
 
 
+class _NoCall:
+    """makes the side context exist and its first-call allocations happen (TrajectoryTreeOptimizer.prewarm): a three-node lane-only fit --
+    device arena, page-locked staging, the kernel's attributes on that context -- whose result nobody reads"""
+
+    def __init__(self, lib, cfg):
+        self.lib, self.cfg = lib, cfg
+
+    def run(self, rt):
+        from ...predictor import IlqrCall
+        flat = dict(parent=np.array([-1, 0, 1], np.int32), prob=np.ones(3, np.float32), mean=np.zeros((3, 1, 2), np.float32), cov=np.zeros((3, 1), np.float32))
+        lane = np.array([[0.0, 0.0], [50.0, 0.0]])
+        try:
+            IlqrCall(self.lib, self.cfg, [flat], np.array([0.0, 0.0, 1.0, 0.0, 0.0, 0.0]), lane, 1.0, use_exo=0, background=True).run(rt)
+        except Exception:      # noqa: BLE001
+            pass
+        return self
+
+
 class _SideContext:
     """One background thread with its OWN HIP context on its own stream.  It only ever executes prepared tree-iLQR
     calls (`IlqrCall.run`: one C call, GIL released), so it neither competes for the interpreter with the main thread's
@@ -235,6 +253,17 @@ class TrajectoryTreeOptimizer:
         if self._worker is None:
             self._worker = _SideContext(self._runtime().device)
         return self._worker
+
+    def prewarm(self):
+        """One-time set-up that would otherwise land in the middle of a closed loop: the side context of the speculative warm start (a thread, a HIP
+        context on its own stream: 5 ms the first time a process creates one) is created at the FIRST plan instead of at the first probe a few
+        cycles later (a fresh process ran its first 20 timed cycles 8 % slower for it, tests/diag/gpu_cold_start.py)."""
+        if self.speculative and self.solver is None and self.shard is None and self._worker is None and not getattr(self, "_prewarmed", False):
+            self._prewarmed = True
+            try:
+                self._side().pool.submit(self._side()._run, _NoCall(self._runtime().lib, ilqr_cfg_from(self.config, "w_opt_cfg"))).result()
+            except Exception:      # noqa: BLE001      (no GPU / no library: the probe will report it)
+                pass
 
     def _take_speculation(self, flats, x0, lane, target_vel):
         """-> {index into flats: (us_warm, stats_warm)} for the trees whose warm-start fit is already done."""
