@@ -841,6 +841,11 @@ def main():
                                               workload="demo_1-like synthetic scene, scripted mode branching on the real predictor forward")
             pre["recorded_scenes"] = recorded_scenes(pm["pl"].network.rt.pair_precision())
             pre["config3"] = config3_block()
+
+    def run_extras(small):
+        if small:
+            return run_small_extras()
+        if extras and rank == 0 and world == 1:
             # the headline workload in the reference's own arithmetic class (fp32 MFMA pair kernel, fp32 MFMA ActorNet)
             fm = measure(dist, "demo_1", args.steps, args.warmup, False, pair_prec="f32")
             fr = roofline(fm, "f32")
@@ -850,10 +855,6 @@ def main():
                                  "pair_kernel_frac_of_hbm_peak": fr["hbm"]["frac"] if fr else None,
                                  "note": "same workload with MIND_PAIR_PREC=f32: every contraction of the predictor in fp32 (v_mfma_f32_16x16x4_f32 pair "
                                          "kernel, ActorNet on v_mfma_f32_16x16x4_f32); the headline runs them as bf16 split operands with fp32 accumulation"}
-
-    def run_extras(small):
-        if small:
-            return run_small_extras()
         if extras:
             # the full cfg4 scenario tree (259 expansions per plan): on one GPU, or planned once by all ranks together.  A failure
             # here must not cost the headline line (every rank reaches the same except branch or none does: the plan is replicated)
