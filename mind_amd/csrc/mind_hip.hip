@@ -25,6 +25,7 @@
 #include "actor_f32_kernels.hip"
 #include "dec_mfma_kernels.hip"
 #include "ilqr_kernels.hip"
+#include "pair_jobs.h"
 #include "aime_kernels.hip"
 
 namespace {
@@ -1128,12 +1129,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
       const int a = in->actor_off[b + 1] - in->actor_off[b], l = in->lane_off[b + 1] - in->lane_off[b];
       const int N = a + l + 1;
       const int tiles = (N + 15) / 16;
-      // split count depends on the scene's own size only, so a scene's result is bit-identical whatever
-      // batch it is collated into (needed for identical AIME node sets when rounds are sharded over GPUs)
-      int ns = (1024 + N - 1) / N;
-      ns = ns < 1 ? 1 : ns;
-      ns = ns > 8 ? 8 : ns;
-      ns = ns > tiles ? tiles : ns;
+      const int ns = pair_column_splits(N);      // (a function of the scene's own size only: pair_jobs.h)
       for (int j = 0; j < N; ++j) {
         TokMeta m;
         memset(&m, 0, sizeof(m));
@@ -1168,34 +1164,18 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
       pairs_full += (double)N * N;
       pairs_l5 += (double)N * (a + 1);
     }
-    // XCD-aware job order for big batches: workgroup b runs on XCD b % 8 and jobs are dealt job -> workgroup job % grid, so
-    // jobs are interleaved such that job index = scene (mod 8): all column jobs of a scene then run on one XCD, whose L2 keeps
-    // that scene's T rows (re-read by every tile of every column; PMC: they missed the per-XCD L2 40 % of the time when a
-    // scene's jobs were spread over all XCDs).  Lanes of unequal length are padded with empty jobs (t0 == t1).
-    // The last fusion layer runs the consumed columns only (actors + cls): k_pair_t walks a list of its own instead of
-    // skipping the other jobs after a dependent load each.
+    // The order of a job list is its schedule (pair_jobs.h): equal work per wave slot, and for batches of eight scenes or more all column
+    // jobs of a scene on one XCD.  The last fusion layer runs the consumed columns only (actors + cls): k_pair_t walks a list of its own
+    // instead of skipping the other jobs after a dependent load each.
     std::vector<PairJob> jobs5;
     for (const PairJob &J : jobs)
       if (J.flags & 1) jobs5.push_back(J);
-    auto xcd_order_jobs = [&](std::vector<PairJob> &jl) {
+    auto deal = [&](std::vector<PairJob> &jl) {
       const int grid_ = (int)jl.size() < c->n_cu ? (int)jl.size() : c->n_cu;
-      if (c->xcd_order && Bn >= 8 && grid_ % 8 == 0 && (int)jl.size() >= 4 * grid_) {
-        std::vector<std::vector<PairJob>> lanes(8);
-        for (const PairJob &J : jl) lanes[J.scene % 8].push_back(J);
-        size_t mx = 0;
-        for (const auto &l_ : lanes) mx = std::max(mx, l_.size());
-        PairJob nullj;
-        memset(&nullj, 0, sizeof(nullj));
-        nullj.N = 1;
-        std::vector<PairJob> re;
-        re.reserve(8 * mx);
-        for (size_t i = 0; i < mx; ++i)
-          for (int x = 0; x < 8; ++x) re.push_back(i < lanes[x].size() ? lanes[x][i] : nullj);
-        jl.swap(re);
-      }
+      pair_jobs_deal(jl, grid_, PAIR_WAVES, (c->xcd_order && Bn >= 8 && grid_ % 8 == 0) ? 8 : 1);
     };
-    xcd_order_jobs(jobs);
-    xcd_order_jobs(jobs5);
+    deal(jobs);
+    deal(jobs5);
     ts->key.clear();                    // invalid until the upload below has completed
     if ((rc = ensure(c, ts->meta, meta.size() * sizeof(TokMeta)))) return rc;
     if ((rc = ensure(c, ts->jobs, jobs.size() * sizeof(PairJob)))) return rc;

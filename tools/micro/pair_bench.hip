@@ -11,6 +11,7 @@
 #include <random>
 #include <string>
 #include <vector>
+#include "../../mind_amd/csrc/pair_jobs.h"
 #include "../../mind_amd/csrc/fusion_kernels.hip"
 #include "../../mind_amd/csrc/pair_bf16_kernels.hip"
 #include "../../mind_amd/csrc/pair_tile_kernels.hip"
@@ -34,7 +35,7 @@ int main(int argc, char **argv) {
   std::uniform_real_distribution<float> U(-1.f, 1.f);
   std::normal_distribution<float> G(0.f, 1.f);
   const int tiles = (N + 15) / 16;
-  int ns = (1024 + N - 1) / N; ns = std::max(1, std::min(ns, 8)); ns = std::min(ns, tiles);
+  int ns = pair_column_splits(N);
   if (argc > 4) ns = std::max(1, std::min(atoi(argv[4]), tiles));      // column splits (jobs per column): per-job overhead shows in the difference
   std::vector<PairJob> jobs;
   long long eb = 0, ebt = 0; int ntok = 0, slot = 0;
@@ -48,14 +49,19 @@ int main(int argc, char **argv) {
       }
     ntok += N; eb += (long long)N * N; ebt += (long long)N * tiles * 16;
   }
-  if (S >= 8) {   // XCD-aware order (mind_predict_batch)
-    std::vector<std::vector<PairJob>> lanes(8);
-    for (auto &J : jobs) lanes[J.scene % 8].push_back(J);
-    size_t mx = 0; for (auto &l : lanes) mx = std::max(mx, l.size());
-    PairJob nj; memset(&nj, 0, sizeof(nj)); nj.N = 1;
-    std::vector<PairJob> re;
-    for (size_t i = 0; i < mx; ++i) for (int x = 0; x < 8; ++x) re.push_back(i < lanes[x].size() ? lanes[x][i] : nj);
-    jobs.swap(re);
+  {   // the schedule of mind_predict_batch (pair_jobs.h); PAIR_BENCH_PLAIN_ORDER=1: round 3/4's order (scene lanes interleaved, no balancing)
+    hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
+    const int g_ = std::min((int)jobs.size(), pr.multiProcessorCount);
+    if (getenv("PAIR_BENCH_PLAIN_ORDER") && S >= 8) {
+      std::vector<std::vector<PairJob>> lanes(8);
+      for (auto &J : jobs) lanes[J.scene % 8].push_back(J);
+      size_t mx = 0; for (auto &l : lanes) mx = std::max(mx, l.size());
+      PairJob nj; memset(&nj, 0, sizeof(nj)); nj.N = 1;
+      std::vector<PairJob> re;
+      for (size_t i = 0; i < mx; ++i) for (int x = 0; x < 8; ++x) re.push_back(i < lanes[x].size() ? lanes[x][i] : nj);
+      jobs.swap(re);
+    } else
+      pair_jobs_deal(jobs, g_, PAIR_WAVES, (S >= 8 && g_ % 8 == 0) ? 8 : 1);
   }
   const int njobs = (int)jobs.size();
   const size_t edge_floats = (size_t)ebt * 128;
@@ -115,6 +121,7 @@ int main(int argc, char **argv) {
   add("  * half the jobs, one wave per SIMD, memory only", k_pair_t<1, 3, 2048 + 1 + 2 + 8 + 64 + 256>, true);
   add("  - memory only, no T loads", k_pair_t<1, 3, 1 + 2 + 8 + 16 + 64 + 256>, true);
   add("  - memory only, no store", k_pair_t<1, 3, 1 + 2 + 4 + 8 + 64 + 256>, true);
+  add("  - all operands of GEMM 1 split up front (round 4)", k_pair_t<1, 3, 16384>, true);
 #endif
   add("k_pair_bf<0,3> layer 0 (row-major)", k_pair_bf<0, 3>, false);
   add("k_pair_t<0,3> layer 0", k_pair_t<0, 3, 0>, true);
@@ -124,6 +131,8 @@ int main(int argc, char **argv) {
 #endif
   add("k_pair_bf<1,1> plain bf16 (row-major)", k_pair_bf<1, 1>, false);
   add("k_pair_t<1,1> plain bf16", k_pair_t<1, 1, 0>, true);
+#ifdef MIND_PAIR_ABL
+#endif
 #ifdef PAIR_BENCH_EXTRA_VARIANTS
   PAIR_BENCH_EXTRA_VARIANTS
 #endif
@@ -152,5 +161,32 @@ int main(int argc, char **argv) {
     printf("%-56s median %7.3f ms  min %7.3f ms   %5.2f TB/s edge traffic (%.3f of 8 TB/s)\n", v.name.c_str(), med, mn, pairs * 1024 / (med * 1e-3) / 1e12,
            pairs * 1024 / (med * 1e-3) / 8e12);
   }
+#ifdef MIND_PAIR_ABL
+  // ---- the late operand split against the split up front, bit for bit: edge tensor and column partials of one launch from the same operands
+  {
+    struct Chk { const char *name; KernelT base, alt; int um; };
+    const Chk chk[] = {{"k_pair_t<1,3> vs operands split up front, full update", k_pair_t<1, 3, 16384>, k_pair_t<1, 3, 0>, 0},
+                       {"k_pair_t<1,3> vs k_pair_t<1,3,16384>, flagged columns", k_pair_t<1, 3, 16384>, k_pair_t<1, 3, 0>, 1},
+                       {"k_pair_t<0,3> vs k_pair_t<0,3,16384>, layer 0", k_pair_t<0, 3, 16384>, k_pair_t<0, 3, 0>, 0}};
+    const size_t part_floats = (size_t)slot * PART_STRIDE;
+    std::vector<float> e0(edge_floats), e1(edge_floats), p0(part_floats), p1(part_floats);
+    for (const Chk &c : chk) {
+      for (int v = 0; v < 2; ++v) {
+        CK(hipMemcpy(d_edge, h_edge.data(), edge_floats * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(d_part, 0, part_floats * 4));
+        hipLaunchKernelGGL(v ? c.alt : c.base, dim3(grid), dim3(PAIR_THREADS), lds, 0, d_jobs, njobs, d_edge, d_ST, d_QK, d_part, d_W, d_W + 16384, d_vt, d_rt, d_tp,
+                           (const float *const *)nullptr, c.um);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy((v ? e1 : e0).data(), d_edge, edge_floats * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy((v ? p1 : p0).data(), d_part, part_floats * 4, hipMemcpyDeviceToHost));
+      }
+      size_t de = 0, dp = 0, changed = 0;
+      for (size_t i = 0; i < edge_floats; ++i) { de += memcmp(&e0[i], &e1[i], 4) != 0; changed += memcmp(&e0[i], &h_edge[i], 4) != 0; }
+      for (size_t i = 0; i < part_floats; ++i) dp += memcmp(&p0[i], &p1[i], 4) != 0;
+      printf("bits: %-40s edge words differing %zu of %zu (%zu updated by the launch), partial words differing %zu of %zu\n", c.name, de, edge_floats, changed, dp,
+             part_floats);
+    }
+  }
+#endif
   return 0;
 }
