@@ -32,7 +32,8 @@
 // ABL: timing-only ablation switches of tools/micro/pair_bench.hip (results are wrong with any bit set; the library instantiates 0)
 //   1 no second GEMM | 2 no LayerNorms | 4 no edge store | 8 no attention phase | 16 no T loads | 32 no edge loads | 64 no first GEMM
 //   128 phase timers (printed by workgroup 0) | 256 no operand splits | 512 no sum_p_mem pass | 1024 layer 0 without its edge build
-//   2048 only waves 0..3 work (one per SIMD, half the jobs) | 4096 only the even waves work | 16384 all operands of the first GEMM split up front
+//   2048 only waves 0..3 work (one per SIMD, half the jobs) | 4096 only the even waves work
+//   32768 column partials stored straight from the accumulator registers (round 4)
 // Measured with the same harness and dropped (profiles/r04d_pair_bench_experiments.txt; 24 x N = 321, base 0.723 ms): s_setprio 1 for the
 // younger wave of every SIMD 0.748, around the GEMMs 0.731, around the VALU phases 0.731; waves 4..7 starting late 0.823; the next tile
 // requested behind the second GEMM, before the edge store 0.970 (64 more live registers through two LayerNorms); non-temporal edge loads
@@ -48,78 +49,14 @@
 #define PT_TIME(i)
 #endif
 
-// ---- work placed in the shadow of the matrix pipe.  A wave issues in order: an MFMA occupies the matrix pipe for four passes (16 cycles) but the
-//      issue port for one, so up to three independent VALU / LDS instructions behind it cost nothing -- if they stand there in program order.
-//      PT_SHADOW_ORDER pins a scheduling region to `MFMA, up to K others, MFMA, ...`.
-//      Round 5 (profiles/r05y_pair_bench_shadow_experiments.txt, 24 x N = 321, base 0.741 ms): the operand split of the first GEMM's k-groups
-//      1..3 in the shadow of the steps before theirs 0.707 (kept); the whole attention branch (scores, online softmax, sum_p_mem) in the shadow of
-//      the second GEMM and of LN_e 0.747, both 0.784 (dropped: 248 registers, and with two waves per SIMD the partner wave already fills what one
-//      wave leaves idle -- the launch is bound by its memory-only form, 0.60 ms, and its arithmetic-only form, 0.67 ms, at the same time).
-#define PT_SG_MFMA 0x008
-#define PT_SG_OTHER (0x002 | 0x004 | 0x400 | 0x080)      // VALU, SALU, transcendental, LDS
-#define PT_SHADOW_ORDER(NM, K)                                                                                        \
-  _Pragma("unroll") for (int i_ = 0; i_ < (NM); ++i_) {                                                              \
-    __builtin_amdgcn_sched_group_barrier(PT_SG_MFMA, 1, 0);                                                           \
-    __builtin_amdgcn_sched_group_barrier(PT_SG_OTHER, (K), 0);                                                        \
-  }
-
-// one chunk (16 features of the lane's pair) of split_frag: dwords 2 c, 2 c + 1 of its k-group's operands
-template <int NP>
-__device__ __forceinline__ void split_chunk(const f32x4 &v, u32x4 &hi, u32x4 &lo, int c) {
-  const u32 h0 = pk_bf16(v[0], v[1]), h1 = pk_bf16(v[2], v[3]);
-  hi[2 * c] = h0;
-  hi[2 * c + 1] = h1;
-  if (NP == 3) {
-    lo[2 * c] = pk_bf16(v[0] - bf_lo_f32(h0), v[1] - bf_hi_f32(h0));
-    lo[2 * c + 1] = pk_bf16(v[2] - bf_lo_f32(h1), v[3] - bf_hi_f32(h1));
-  }
-}
-
-// gemm_bf with sixteen slices of independent work, f(0) .. f(15): slice 2 st in the region of step st's four lo.hi products, slice 2 st + 1 in the
-// region of its eight hi.hi / hi.lo products (NP == 1: f(2 st), f(2 st + 1) both behind the step's four products)
-template <int NP, class F>
-__device__ __forceinline__ void gemm_bf_shadow(frag8 &acc, const u32 *wa, const u32x4 (&bhi)[4], const u32x4 (&blo)[4], int lane, F &&f) {
-  int lo_ = lane * 4;
-  OPAQUE(lo_);
-  const u32 *wl = wa + lo_;
-  u32x4 ah[2][4], al[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    ah[0][k] = *(const u32x4 *)(wl + ((k * 4 + 0) * 256));
-    if (NP == 3) al[k] = *(const u32x4 *)(wl + 8192 + ((k * 4 + 0) * 256));
-  }
-#pragma unroll
-  for (int st = 0; st < 8; ++st) {
-    const int g = st >> 1, o0 = (st & 1) * 4, cur = st & 1, nxt = cur ^ 1;
-    const int gn = (st + 1) >> 1, on = ((st + 1) & 1) * 4;
-    if (st < 7) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) ah[nxt][k] = *(const u32x4 *)(wl + (((on + k) * 4 + gn) * 256));
-    }
-    if (NP == 3) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc[o0 + k] = MFMA_BF(al[k], bhi[g], acc[o0 + k]);
-      f(2 * st);
-      PT_SHADOW_ORDER(4, 4)
-      SCHED_FENCE();
-      if (st < 7) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) al[k] = *(const u32x4 *)(wl + 8192 + (((on + k) * 4 + gn) * 256));
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[o0 + k] = MFMA_BF(ah[cur][k], bhi[g], acc[o0 + k]);
-    if (NP == 3) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc[o0 + k] = MFMA_BF(ah[cur][k], blo[g], acc[o0 + k]);
-    } else
-      f(2 * st);
-    f(2 * st + 1);
-    PT_SHADOW_ORDER(NP == 3 ? 8 : 4, 4)
-    SCHED_FENCE();
-  }
-}
-
+// Round 5, intra-wave overlap of VALU work with the matrix pipe, measured and dropped.  Program order pinned with
+// sched_group_barrier to `MFMA, up to four VALU / LDS, MFMA, ...`: (a) the operand split of the first GEMM's k-groups 1..3 in the shadow of the steps
+// before theirs, (b) the whole attention branch (scores, online softmax, sum_p_mem) in the shadow of the second GEMM and of LN_e (248 registers).
+// A/B in one process with nothing else launched in between (PAIR_BENCH_ONLY; 24 x N = 321, 3 jobs per column): base 0.709 ms, (a) 0.711, (b) 0.75.
+// With two waves per SIMD the partner wave already fills what one wave leaves idle; the launch is bound by its memory-only form (0.53-0.60 ms)
+// and its arithmetic-only form (0.67 ms) at the same time.  (profiles/r05y_pair_bench_shadow_experiments.txt shows (a) at 0.707 against 0.741: an
+// artefact -- a launch is 5 % faster on the edge values the ablation variants before it leave behind (matrix-pipe power / clocks), which is why
+// that file's variants are only comparable with their own row of another run.)  What did pay is the schedule of the column jobs: pair_jobs.h.
 template <int MODE, int NP, int ABL = 0>
 __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_t(const PairJob *__restrict__ jobs, int n_jobs, float *__restrict__ edge,
                                                             const float *__restrict__ ST, const float *__restrict__ QK,
@@ -197,13 +134,15 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_t(const PairJob *__res
     if (!PT_ABL(16)) { _Pragma("unroll") for (int b = 0; b < 8; ++b) Tn[b] = *(const f32x4 *)(Ti_ + 16 * b); } \
   }
 
+  PairJob Jc = jobs[job < n_jobs ? job : 0];      // this wave's current job record: read one job ahead (a scalar load and its latency per job otherwise)
   for (; job < n_jobs; job += stride) {
-    const PairJob J = jobs[job];
-    if (J.t1 <= J.t0) { primed = false; continue; }       // padding job of the XCD-aware order
+    const PairJob J = Jc;
     // the next job of this wave: its first tile is requested during this job's last one
     const int jn = job + stride;
     const bool in_range = jn < n_jobs;
     const PairJob Jn = jobs[in_range ? jn : job];
+    Jc = Jn;
+    if (J.t1 <= J.t0) { primed = false; continue; }       // padding job (pair_jobs.h)
     const bool has_next = in_range && Jn.t1 > Jn.t0;
     const bool do_update = (update_mode == 0) || (update_mode == 1 && (J.flags & 1));
     const int N = J.N;
@@ -344,17 +283,12 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_t(const PairJob *__res
       u32x4 mhi[4], mlo[4];
       {
         u32x4 ehi[4], elo[4];
-        // the operands of the first k-group are split up front, those of the others in the shadow of the GEMM steps before theirs
-        constexpr bool SPLIT_LATE = !PT_ABL(16384) && !PT_ABL(256) && !PT_ABL(64) && !(EB && MODE == 1);
         if (PT_ABL(256)) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) { ehi[g] = __builtin_bit_cast(u32x4, ef[2 * g]); elo[g] = __builtin_bit_cast(u32x4, ef[2 * g + 1]); }
         } else if (EB && MODE == 1) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) ehi[g] = __builtin_bit_cast(u32x4, raw[g]);      // the stored chunk is the B operand
-        } else if (SPLIT_LATE) {
-          split_chunk<NP>(ef[0], ehi[0], elo[0], 0);
-          split_chunk<NP>(ef[1], ehi[0], elo[0], 1);
         } else
           split_frag<NP>(ef, ehi, elo);
         const float *svq = svec + lq * 4;
@@ -362,15 +296,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_t(const PairJob *__res
         for (int b = 0; b < 8; ++b) mem[b] += *(const f32x4 *)(svq + 16 * b);
         SCHED_FENCE();
         PT_TIME(1);            // (timers) tile top: wait for the prefetched chunk / T rows, split, S[j]
-        if (SPLIT_LATE) {
-          auto rest = [&](int k) __attribute__((always_inline)) {
-            if (k < 12 && (k & 3) < 2) {
-              const int g = (k >> 2) + 1, c = k & 1;
-              split_chunk<NP>(ef[2 * g + c], ehi[g], elo[g], c);
-            }
-          };
-          gemm_bf_shadow<NP>(mem, wbe, ehi, elo, lane, rest);
-        } else if (!PT_ABL(64)) gemm_bf<NP>(mem, wbe, ehi, elo, lane);
+        if (!PT_ABL(64)) gemm_bf<NP>(mem, wbe, ehi, elo, lane);
         else {
 #pragma unroll
           for (int g = 0; g < 4; ++g) { mem[2 * g] += __builtin_bit_cast(f32x4, ehi[g]); mem[2 * g + 1] += __builtin_bit_cast(f32x4, elo[g]); }
@@ -542,18 +468,45 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_t(const PairJob *__res
     // the next job's S row and folded query travel while this job's column partial is written (at the very end: this job's once more)
     if (has_next) PT_LOAD_SQ(Jn) else PT_LOAD_SQ(J)
 
-    // ---- column partial: m[8], l[8], mbar[8][128]
+    // ---- column partial: m[8], l[8], mbar[8][128], through the wave's idle LDS images so that it leaves as nine coalesced 16-byte stores per
+    //      lane instead of forty 4-byte ones from half the lanes (in order behind this job's last LDS reads; a wave's LDS accesses keep their order)
     float *po = part + (size_t)J.slot * PART_STRIDE;
+    if (PT_ABL(32768)) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float l = red_sum16(l_part[r]);
-      if (p == 0 && q < 2) { po[4 * q + r] = m_run[r]; po[8 + 4 * q + r] = l; }
-    }
-    if (q < 2) {
+      for (int r = 0; r < 4; ++r) {
+        const float l = red_sum16(l_part[r]);
+        if (p == 0 && q < 2) { po[4 * q + r] = m_run[r]; po[8 + 4 * q + r] = l; }
+      }
+      if (q < 2) {
 #pragma unroll
-      for (int b = 0; b < 8; ++b)
+        for (int b = 0; b < 8; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) po[16 + (4 * q + r) * 128 + 16 * b + p] = mbar[b][r];
+          for (int r = 0; r < 4; ++r) po[16 + (4 * q + r) * 128 + 16 * b + p] = mbar[b][r];
+      }
+    } else {
+      float lsum[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lsum[r] = red_sum16(l_part[r]);
+      if (p == 0 && q < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ptab[4 * q + r] = m_run[r]; ptab[8 + 4 * q + r] = lsum[r]; }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {      // heads 4 h .. 4 h + 3 fill the 512-float transposition image
+        if (q == h) {
+#pragma unroll
+          for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[r * 128 + 16 * b + p] = mbar[b][r];
+        }
+        PBF_FENCE();
+        const f32x4 v0 = *(const f32x4 *)(stage + lane * 4), v1 = *(const f32x4 *)(stage + 256 + lane * 4);
+        *(f32x4 *)(po + 16 + h * 512 + lane * 4) = v0;
+        *(f32x4 *)(po + 16 + h * 512 + 256 + lane * 4) = v1;
+        PBF_FENCE();
+      }
+      if (lane < 4) *(f32x4 *)(po + lane * 4) = *(const f32x4 *)(ptab + lane * 4);
+      PBF_FENCE();
     }
   }
 #undef PT_LOAD_E

@@ -121,7 +121,7 @@ int main(int argc, char **argv) {
   add("  * half the jobs, one wave per SIMD, memory only", k_pair_t<1, 3, 2048 + 1 + 2 + 8 + 64 + 256>, true);
   add("  - memory only, no T loads", k_pair_t<1, 3, 1 + 2 + 8 + 16 + 64 + 256>, true);
   add("  - memory only, no store", k_pair_t<1, 3, 1 + 2 + 4 + 8 + 64 + 256>, true);
-  add("  - all operands of GEMM 1 split up front (round 4)", k_pair_t<1, 3, 16384>, true);
+  add("  - column partials stored from the registers (round 4)", k_pair_t<1, 3, 32768>, true);
 #endif
   add("k_pair_bf<0,3> layer 0 (row-major)", k_pair_bf<0, 3>, false);
   add("k_pair_t<0,3> layer 0", k_pair_t<0, 3, 0>, true);
@@ -136,6 +136,14 @@ int main(int argc, char **argv) {
 #ifdef PAIR_BENCH_EXTRA_VARIANTS
   PAIR_BENCH_EXTRA_VARIANTS
 #endif
+  if (const char *only = getenv("PAIR_BENCH_ONLY")) {      // comma-separated substrings: a clean A/B of a few variants (the others leave their edge values behind)
+    std::vector<std::string> keys;
+    for (const char *a = only; *a;) { const char *e = strchr(a, ','); if (!e) e = a + strlen(a); keys.emplace_back(a, e); a = *e ? e + 1 : e; }
+    std::vector<Variant> keep;
+    for (auto &v : vs)
+      for (auto &k : keys) if (v.name.find(k) != std::string::npos) { keep.push_back(v); break; }
+    vs.swap(keep);
+  }
   const size_t lds = mind_pair_bf_lds_bytes();
   for (auto &v : vs) CK(hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
@@ -162,12 +170,11 @@ int main(int argc, char **argv) {
            pairs * 1024 / (med * 1e-3) / 8e12);
   }
 #ifdef MIND_PAIR_ABL
-  // ---- the late operand split against the split up front, bit for bit: edge tensor and column partials of one launch from the same operands
+  // ---- round-5 variants against their round-4 forms, bit for bit: edge tensor and column partials of one launch from the same operands
   {
     struct Chk { const char *name; KernelT base, alt; int um; };
-    const Chk chk[] = {{"k_pair_t<1,3> vs operands split up front, full update", k_pair_t<1, 3, 16384>, k_pair_t<1, 3, 0>, 0},
-                       {"k_pair_t<1,3> vs k_pair_t<1,3,16384>, flagged columns", k_pair_t<1, 3, 16384>, k_pair_t<1, 3, 0>, 1},
-                       {"k_pair_t<0,3> vs k_pair_t<0,3,16384>, layer 0", k_pair_t<0, 3, 16384>, k_pair_t<0, 3, 0>, 0}};
+    const Chk chk[] = {{"k_pair_t<1,3> vs partials stored from the registers", k_pair_t<1, 3, 32768>, k_pair_t<1, 3, 0>, 0},
+                       {"k_pair_t<1,1> vs partials stored from the registers", k_pair_t<1, 1, 32768>, k_pair_t<1, 1, 0>, 0}};
     const size_t part_floats = (size_t)slot * PART_STRIDE;
     std::vector<float> e0(edge_floats), e1(edge_floats), p0(part_floats), p1(part_floats);
     for (const Chk &c : chk) {
