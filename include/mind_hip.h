@@ -131,6 +131,15 @@ int mind_get_pair_precision(mind_ctx *ctx);   /* -> mode, or MIND_EINVAL */
  * out[16384] dwords = [part 2][out block 8][k group 4][lane 64][4] (see pair_bf16_kernels.hip).  Needs no GPU. */
 int mind_debug_pack_bfrag(const float *w, int row_stride, uint32_t *out);
 
+/* host-only helper (tests): the pair kernels' job schedule (mind_amd/csrc/pair_jobs.h) for a batch of n_scenes scenes of scene_tokens[b]
+ * tokens on a device of n_cu compute units -- exactly what mind_predict_batch builds.  last_layer != 0: the list of the last fusion layer
+ * (actor + cls columns only; scene_actors[b] actors per scene).  out_jobs receives up to cap records of six ints
+ * {scene, column, first tile, one past the last tile, partial slot, wave slot = wave * grid + workgroup} in list order without the empty
+ * padding jobs; out_info[4] = {jobs per column of scene 0, grid, list length with padding, number of jobs}.  Returns the number of jobs or a
+ * negative error.  Needs no GPU. */
+int mind_debug_pair_schedule(const int *scene_tokens, const int *scene_actors, int n_scenes, int n_cu, int last_layer, int *out_jobs, int cap,
+                             int *out_info);
+
 /* host-only helper (tests): the bf16 hi / mid / lo MFMA A-operand packing of one Conv1d weight [co][ci][ksz] (torch layout) for the
  * ActorNet GEMMs of actor_mfma_kernels.hip: [co/16][k-step][part 3 = hi, mid, lo][lane 64][4] dwords, GEMM index k = tap * ci_pad + ci
  * (ci_pad = ci rounded up to a power of two >= 16).  Returns the number of dwords written (<= cap) or a negative error. */

@@ -109,7 +109,7 @@ class IlqrStats(C.Structure):
 EXPORTS = ["mind_ctx_create", "mind_ctx_destroy", "mind_last_error_string", "mind_ctx_synchronize",
            "mind_weights_load", "mind_predict_batch", "mind_last_fusion_stats", "mind_set_profiling",
            "mind_ilqr_solve_trees", "mind_ilqr_contingency", "mind_ilqr_solve_fields", "mind_cost_eval", "mind_lane_dist_field", "mind_aime_world", "mind_aime_rebase", "mind_debug_set_layers",
-           "mind_debug_read", "mind_set_pair_precision", "mind_get_pair_precision", "mind_debug_pack_bfrag", "mind_debug_pack_conv_frag", "mind_set_tuning", "mind_last_ilqr_stats", "mind_aime_plan", "mind_last_ilqr_profile", "mind_eval_traj_trees", "mind_last_ilqr_trace", "mind_ilqr_contingency_begin", "mind_ilqr_finish", "mind_fill_tracks", "mind_ilqr_contingency_begin_plan", "mind_debug_trig", "mind_aime_plan_begin", "mind_aime_plan_poll", "mind_aime_plan_finish", "mind_ctx_busy", "mind_ilqr_finish_plan",
+           "mind_debug_read", "mind_set_pair_precision", "mind_get_pair_precision", "mind_debug_pack_bfrag", "mind_debug_pack_conv_frag", "mind_debug_pair_schedule", "mind_set_tuning", "mind_last_ilqr_stats", "mind_aime_plan", "mind_last_ilqr_profile", "mind_eval_traj_trees", "mind_last_ilqr_trace", "mind_ilqr_contingency_begin", "mind_ilqr_finish", "mind_fill_tracks", "mind_ilqr_contingency_begin_plan", "mind_debug_trig", "mind_aime_plan_begin", "mind_aime_plan_poll", "mind_aime_plan_finish", "mind_ctx_busy", "mind_ilqr_finish_plan",
            "mind_set_exchange", "mind_last_exchange_stats"]
 
 # transport of the sharded mind_aime_plan (include/mind_hip.h): int fn(void *user, int op, void *send, void *recv, int64 bytes)
@@ -176,6 +176,7 @@ def load():
                                          C.c_double, C.POINTER(C.c_double)]
     lib.mind_get_pair_precision.argtypes = [C.c_void_p]
     lib.mind_debug_pack_bfrag.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_uint32)]
+    lib.mind_debug_pair_schedule.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
     lib.mind_debug_trig.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
     lib.mind_debug_pack_conv_frag.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_size_t]
     lib.mind_debug_set_layers.argtypes = [C.c_void_p, C.c_int]

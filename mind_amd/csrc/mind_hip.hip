@@ -436,6 +436,44 @@ extern "C" int mind_debug_pack_bfrag(const float *w, int row_stride, uint32_t *o
   return MIND_OK;
 }
 
+// the pair kernels' job lists as mind_predict_batch builds them (same helpers of pair_jobs.h), for a host-side check of the schedule
+extern "C" int mind_debug_pair_schedule(const int *scene_tokens, const int *scene_actors, int n_scenes, int n_cu, int last_layer, int *out_jobs, int cap,
+                                        int *out_info) {
+  if (!scene_tokens || !scene_actors || n_scenes <= 0 || n_cu <= 0 || !out_jobs || !out_info) return MIND_EINVAL;
+  std::vector<PairJob> jl;
+  int slot = 0;
+  for (int b = 0; b < n_scenes; ++b) {
+    const int N = scene_tokens[b], a = scene_actors[b];
+    if (N <= 0 || a < 0 || a >= N) return MIND_EINVAL;
+    const int tiles = (N + 15) / 16, ns = pair_column_splits(N);
+    for (int j = 0; j < N; ++j)
+      for (int s_ = 0; s_ < ns; ++s_) {
+        PairJob J;
+        memset(&J, 0, sizeof(J));
+        J.N = N; J.j = j; J.scene = b; J.slot = slot++;
+        pair_job_range(tiles, ns, s_, &J.t0, &J.t1);
+        J.flags = (j < a || j == N - 1) ? 1 : 0;
+        if (!last_layer || (J.flags & 1)) jl.push_back(J);
+      }
+  }
+  const int njobs = (int)jl.size();
+  const int grid = njobs < n_cu ? njobs : n_cu;
+  pair_jobs_deal(jl, grid, PAIR_WAVES, (n_scenes >= 8 && grid % 8 == 0) ? 8 : 1);
+  const int stride = grid * PAIR_WAVES;
+  int n = 0;
+  for (size_t i = 0; i < jl.size(); ++i) {
+    const PairJob &J = jl[i];
+    if (J.t1 <= J.t0) continue;
+    if (n < cap) {
+      int *o = out_jobs + (size_t)6 * n;
+      o[0] = J.scene; o[1] = J.j; o[2] = J.t0; o[3] = J.t1; o[4] = J.slot; o[5] = (int)(i % stride);
+    }
+    ++n;
+  }
+  out_info[0] = pair_column_splits(scene_tokens[0]); out_info[1] = grid; out_info[2] = (int)jl.size(); out_info[3] = n;
+  return n;
+}
+
 extern "C" int mind_set_profiling(mind_ctx *c, int enable) {
   if (!c) return MIND_EINVAL;
   c->profiling = enable != 0;
@@ -1146,8 +1184,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
           J.edge_base_t = edge_pairs_t;
           J.N = N;
           J.j = j;
-          J.t0 = (int)((long long)tiles * s_ / ns);
-          J.t1 = (int)((long long)tiles * (s_ + 1) / ns);
+          pair_job_range(tiles, ns, s_, &J.t0, &J.t1);
           J.tok_base = ntok;
           J.slot = slot++;
           J.flags = m.flags;

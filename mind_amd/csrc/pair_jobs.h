@@ -5,8 +5,9 @@
 //   * every wave slot gets the same amount of work: a job costs its tiles plus a constant (job set-up, column partial), jobs are dealt longest first
 //     to the least loaded slot.  (The plain order gave slot s every 256th job of its lane: with 4 splits of a 21-tile column -- 5, 5, 5, 6 tiles --
 //     a quarter of the waves ran 6-tile jobs only and the launch waited for them: profiles/r05y_pair_bench_splits.txt, 3 splits 9 % faster than 4);
-//   * with `lanes` == 8 the jobs of scene s run on the workgroups b = s (mod 8), i.e. on one XCD, whose L2 then keeps that scene's T rows and
-//     folded queries (round 3: they missed the per-XCD L2 40 % of the time with a scene's jobs spread over all XCDs).
+//   * with `lanes` == 8 the list -- scene by scene -- is cut into eight runs of equal cost and run x goes to the workgroups b = x (mod 8), i.e. to
+//     one XCD, whose L2 then keeps the T rows and folded queries of its few scenes (round 3: they missed the per-XCD L2 40 % of the time with
+//     every scene's jobs spread over all XCDs).
 // Slots that run out get empty jobs (t0 == t1, skipped by the kernels).  The order does not touch a job's own arithmetic: results are bit-identical
 // whatever the deal.
 #pragma once
@@ -36,18 +37,37 @@ static inline int pair_column_splits(int N) {
   return ns > tiles ? tiles : ns;
 }
 
+// tile range [t0, t1) of a column's job s of ns
+static inline void pair_job_range(int tiles, int ns, int s, int *t0, int *t1) {
+  *t0 = (int)((long long)tiles * s / ns);
+  *t1 = (int)((long long)tiles * (s + 1) / ns);
+}
+
 template <class Job>
 static void pair_jobs_deal(std::vector<Job> &jl, int grid, int waves, int lanes) {
   const int slots = grid * waves;
   if (grid <= 0 || (int)jl.size() <= slots) return;      // at most one job per slot: nothing to balance
   if (lanes < 1 || grid % lanes != 0) lanes = 1;
+  // lanes: the list (scene by scene, column by column) cut into `lanes` runs of equal cost -- an XCD then works on its share of the scenes plus
+  // at most two scenes it shares with a neighbour, whatever the scenes' sizes
+  long long total = 0;
+  for (const Job &J : jl)
+    if (J.t1 > J.t0) total += J.t1 - J.t0 + PAIR_JOB_OVERHEAD_TILES;
+  std::vector<std::vector<const Job *>> lane_jobs(lanes);
+  {
+    long long acc = 0;
+    for (const Job &J : jl) {
+      if (J.t1 <= J.t0) continue;
+      int x = (int)(acc * lanes / (total > 0 ? total : 1));
+      lane_jobs[x < lanes ? x : lanes - 1].push_back(&J);
+      acc += J.t1 - J.t0 + PAIR_JOB_OVERHEAD_TILES;
+    }
+  }
   std::vector<std::vector<Job>> per_slot(slots);
   for (int x = 0; x < lanes; ++x) {
-    std::vector<const Job *> mine;
-    for (const Job &J : jl)
-      if (J.t1 > J.t0 && J.scene % lanes == x) mine.push_back(&J);
+    std::vector<const Job *> &mine = lane_jobs[x];
     std::stable_sort(mine.begin(), mine.end(), [](const Job *a, const Job *b) { return a->t1 - a->t0 > b->t1 - b->t0; });
-    typedef std::pair<long long, int> Load;      // (tiles so far, slot): the least loaded slot first, ties by slot number
+    typedef std::pair<long long, int> Load;      // (cost so far, slot): the least loaded slot first, ties by slot number
     std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
     for (int w = 0; w < waves; ++w)
       for (int b = x; b < grid; b += lanes) heap.push(Load(0, w * grid + b));
