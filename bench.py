@@ -31,7 +31,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-if "--pipelined" in sys.argv:
+if "--pipelined" in sys.argv or "--per-process" in sys.argv:
     # one thread drives P contexts of three streams each: more than the ROCm runtime's default four hardware queues per process, and
     # streams that share a queue run in order (measured: 3 134 -> 3 959 sim steps/s at P = 4 with eight queues).  Read at runtime start.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -526,6 +526,55 @@ def _proc_scene(i, workload, steps, warmup, ready, go, q, speculative, ckpt=None
     q.put((i, n, t0, time.time(), pl.scen_tree_gen.n_expanded))
 
 
+def _proc_group(g, scene_ids, workload, steps, warmup, ready, go, q, ckpt=None):
+    """A group of scenes in one process: ONE host thread, the event loop of mind_amd.pipelined over the group's closed loops (a HIP context
+    and stream per scene).  Signals ready, waits for the common start, reports back."""
+    import torch as th
+    from mind_amd.pipelined import PipelinedClosedLoops
+    th.cuda.set_stream(th.cuda.Stream())
+    loops = [make_closed_loop(scene_workload(workload, i), scripted="scene" not in scene_workload(workload, i), speculative=False, ckpt=ckpt,
+                              own_context=True) for i in scene_ids]
+    pc = PipelinedClosedLoops([l[1] for l in loops])
+    pc.run_plans(max(warmup, 1))
+    th.cuda.synchronize()
+    ready.wait()
+    go.wait()
+    t0 = time.time()
+    n = pc.run_plans(steps)
+    th.cuda.synchronize()
+    q.put((g, n, t0, time.time(), sum(l[0].scen_tree_gen.n_expanded for l in loops)))
+
+
+def run_concurrent_groups(args):
+    """BASELINE config 3 at the size that fills the GPU: P scenes as P / Q host processes of Q scenes each -- the interpreter work of the scenes
+    (about 0.9 ms per plan, the bound of the one-thread event loop) runs on P / Q cores, the device sees P / Q contexts instead of P (sixteen
+    processes time-slice it: profiles/r05l_*)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    P, Q = args.concurrent, args.per_process
+    groups = [list(range(a, min(a + Q, P))) for a in range(0, P, Q)]
+    G = len(groups)
+    ready, go, q = ctx.Barrier(G + 1), ctx.Barrier(G + 1), ctx.Queue()
+    procs = [ctx.Process(target=_proc_group, args=(g, ids, args.workload, args.steps, args.warmup, ready, go, q, args.ckpt)) for g, ids in enumerate(groups)]
+    for p_ in procs:
+        p_.start()
+    ready.wait(timeout=900)
+    go.wait(timeout=60)
+    res = [q.get(timeout=900) for _ in range(G)]
+    for p_ in procs:
+        p_.join(timeout=60)
+    dt = max(r[3] for r in res) - min(r[2] for r in res)       # same host clock: first start to last finish
+    steps = sum(r[1] for r in res)
+    print(json.dumps({
+        "metric": METRIC, "value": steps / dt, "unit": "sim steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16x3 pair kernel / f32 predictor / f64 iLQR", "data": _concurrent_label(args.workload, P)[1],
+        "config": {"workload": f"{_concurrent_label(args.workload, P)[0]} planned concurrently on one GPU: {G} host processes, each ONE thread over "
+                               f"{Q} scenes (a HIP context + stream per scene, event loop over three-piece plans), {args.steps} planning cycles each",
+                   "concurrent_scenes": P, "host_processes": G, "scenes_per_process": Q, "sim_steps_timed": steps},
+        "ms_per_plan_aggregate": dt / (args.steps * P) * 1e3}))
+
+
 def run_concurrent_processes(args):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -673,6 +722,20 @@ def config3_block(P=4, steps=20, warmup=3):
             out[key] = {"error": f"{type(e).__name__}: {e}"[:200]}
     best = max((v["sim_steps_per_s"] for v in out.values() if isinstance(v, dict) and "sim_steps_per_s" in v), default=None)
     out["sim_steps_per_s"] = best
+    # the size that fills the device: sixteen scenes as two host processes of eight (profiles/r05z_config3_groups.txt: two processes are the
+    # optimum from eight scenes on -- the interpreter work on two cores, two contexts on the device without time-slicing)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "demo_all", "--concurrent", "16", "--processes", "--per-process", "8",
+                            "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-extras", "--no-traffic"], capture_output=True, text=True,
+                           timeout=400)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and line:
+            d = json.loads(line[-1])
+            out["sixteen_scenes_two_processes"] = {"sim_steps_per_s": d["value"], "ms_per_round_of_plans": d["ms_per_step"]}
+        else:
+            out["sixteen_scenes_two_processes"] = {"error": (r.stderr or "no output")[-200:]}
+    except Exception as e:      # noqa: BLE001
+        out["sixteen_scenes_two_processes"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return out
 
 
@@ -742,7 +805,8 @@ def contract_line(out, args):
     if isinstance(c3, dict):
         line["config3"] = {"scenes": c3.get("scenes"), "sim_steps_per_s": c3.get("sim_steps_per_s"),
                            "processes": (c3.get("processes") or {}).get("sim_steps_per_s"),
-                           "one_thread_event_loop": (c3.get("one_thread_event_loop") or {}).get("sim_steps_per_s")}
+                           "one_thread_event_loop": (c3.get("one_thread_event_loop") or {}).get("sim_steps_per_s"),
+                           "x16_two_processes": (c3.get("sixteen_scenes_two_processes") or {}).get("sim_steps_per_s")}
     line["extras_file"] = extras
     text = json.dumps(_sig(line), separators=(",", ":"))
     if len(text) > LINE_LIMIT:          # never let an extra cost the contract line: drop the optional blocks, largest first
@@ -789,6 +853,8 @@ def main():
                          "HIP context and stream per scene); prints the aggregate rate")
     ap.add_argument("--processes", action="store_true",
                     help="with --concurrent: one host PROCESS per scene instead of one thread (host bookkeeping in parallel too)")
+    ap.add_argument("--per-process", type=int, default=1,
+                    help="with --concurrent P --processes: Q scenes per host process (P / Q processes, each one thread over its Q scenes as --pipelined)")
     ap.add_argument("--pipelined", action="store_true",
                     help="with --concurrent P: one process, one host thread, a context per scene, scene i's tree-iLQR beside scene i + 1's AIME rounds")
     ap.add_argument("--fused", action="store_true",
@@ -822,6 +888,8 @@ def main():
             return run_fused(args)
         if args.pipelined:
             return run_pipelined(args)
+        if args.processes and args.per_process > 1:
+            return run_concurrent_groups(args)
         return run_concurrent_processes(args) if args.processes else run_concurrent(args)
     shard = world > 1 and not args.replicas and (args.shard or args.workload in FULL_TREE)
     extras = not args.no_extras and args.workload == "demo_1"

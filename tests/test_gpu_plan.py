@@ -133,7 +133,7 @@ def test_bench_prints_one_contract_json_line(tmp_path):
     assert x["stress_deep"]["expansions_per_plan"] == 1555 and x["stress_deeper"]["expansions_per_plan"] == 9331
     assert x["plain_formula_weights"]["expansions_per_plan"] == 1.0
     # BASELINE configs[2] in the default line: four recorded scenes concurrently, a process per scene and one thread's event loop
-    assert d["config3"]["scenes"] == 4 and d["config3"]["sim_steps_per_s"] > 83.0 and d["config3"]["processes"] > 0 and d["config3"]["one_thread_event_loop"] > 0
+    assert d["config3"]["scenes"] == 4 and d["config3"]["sim_steps_per_s"] > 83.0 and d["config3"]["processes"] > 0 and d["config3"]["one_thread_event_loop"] > 0 and d["config3"]["x16_two_processes"] > 0
     assert x["synthetic_branching"]["expansions_per_plan"] >= 2 and x["tree"]["expansions_per_plan"] == 259
     assert x["tree"]["k_pair"]["frac"] <= 1.0 and set(x["recorded_scenes"]) >= {"demo_2", "demo_3", "demo_4", "demo_1_whole_run"}
 
