@@ -3,6 +3,7 @@
 #   tools/gpu.sh <command> <tag> [args...]           results -> gpurun_out/<tag>/ (copy what is to be kept into profiles/)
 #
 #   final <tag>                         the whole -m gpu suite, smoke(), the default bench line, kernel stats + host-time split (demo_1, cfg4tree)
+#   finalbench <tag>                    the same without the suite
 #   quick <tag>                         predictor / AIME / plan parity tests + the headline bench line
 #   tests <tag> <pytest args...>        pytest -m gpu on the given files / -k expression
 #   kstats <tag> <workload> [ENV=..]    rocprofv3 --kernel-trace --stats over a short bench run of the workload (demo_1, cfg4tree, stress128tree ...)
@@ -34,10 +35,12 @@ for l in sys.stdin:
 }
 
 case $cmd in
-final)
+final|finalbench)
+  if [ $cmd = final ]; then
   ( time timeout 2400 python -m pytest tests -m gpu -q -s ) > $O/pytest_gpu_full.txt 2>&1; grep -n "passed\|failed\|^real" $O/pytest_gpu_full.txt | tail -3
   grep "^\[demo\|^\.\[demo\|same tree chosen\|cycles agree outright\|^demo_\|^\.demo_\|^stress" $O/pytest_gpu_full.txt | sed 's/^\.*//' > $O/pytest_gpu_parity_lines.txt
   tail -25 $O/pytest_gpu_full.txt > $O/pytest_gpu.txt
+  fi
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
   ( time MIND_BENCH_EXTRAS=$ROOT/$O/bench_extras.json timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err ) 2>&1 | grep real
   tail -2 $O/bench.err; wc -c $O/bench.json
