@@ -13,7 +13,6 @@
 #pragma once
 #include <algorithm>
 #include <cstring>
-#include <queue>
 #include <vector>
 
 #define PAIR_JOB_OVERHEAD_TILES 1      // set-up + column partial of a job, in tiles (pair_bench: 4 against 3 jobs per column, ~7 us per job; a tile ~9 us)
@@ -46,46 +45,75 @@ static inline void pair_job_range(int tiles, int ns, int s, int *t0, int *t1) {
 template <class Job>
 static void pair_jobs_deal(std::vector<Job> &jl, int grid, int waves, int lanes) {
   const int slots = grid * waves;
-  if (grid <= 0 || (int)jl.size() <= slots) return;      // at most one job per slot: nothing to balance
+  const size_t n = jl.size();
+  if (grid <= 0 || (int)n <= slots) return;      // at most one job per slot: nothing to balance
   if (lanes < 1 || grid % lanes != 0) lanes = 1;
   // lanes: the list (scene by scene, column by column) cut into `lanes` runs of equal cost -- an XCD then works on its share of the scenes plus
   // at most two scenes it shares with a neighbour, whatever the scenes' sizes
   long long total = 0;
+  int max_cost = 0;
   for (const Job &J : jl)
-    if (J.t1 > J.t0) total += J.t1 - J.t0 + PAIR_JOB_OVERHEAD_TILES;
-  std::vector<std::vector<const Job *>> lane_jobs(lanes);
+    if (J.t1 > J.t0) {
+      const int c = J.t1 - J.t0 + PAIR_JOB_OVERHEAD_TILES;
+      total += c;
+      max_cost = std::max(max_cost, c);
+    }
+  // One pass per lane over its run of the list: the jobs by descending cost (a counting sort -- costs are a few tiles -- that keeps the list's
+  // order among equals), each to the least loaded slot of the lane.  Only (slot, position in the slot) are kept per job; every record is copied
+  // once, into its place (a stress round deals twelve million jobs).
+  std::vector<int> slot_of(n, -1), pos_of(n, 0), count(slots, 0);
+  std::vector<size_t> lane_begin(lanes + 1, n);
   {
     long long acc = 0;
-    for (const Job &J : jl) {
+    int x_prev = -1;
+    for (size_t i = 0; i < n; ++i) {
+      const Job &J = jl[i];
       if (J.t1 <= J.t0) continue;
       int x = (int)(acc * lanes / (total > 0 ? total : 1));
-      lane_jobs[x < lanes ? x : lanes - 1].push_back(&J);
+      x = x < lanes ? x : lanes - 1;
+      for (; x_prev < x; ++x_prev) lane_begin[x_prev + 1] = i;
       acc += J.t1 - J.t0 + PAIR_JOB_OVERHEAD_TILES;
     }
+    for (; x_prev < lanes; ++x_prev) lane_begin[x_prev + 1] = n;
   }
-  std::vector<std::vector<Job>> per_slot(slots);
+  std::vector<size_t> order;
+  std::vector<size_t> bucket(max_cost + 2);
   for (int x = 0; x < lanes; ++x) {
-    std::vector<const Job *> &mine = lane_jobs[x];
-    std::stable_sort(mine.begin(), mine.end(), [](const Job *a, const Job *b) { return a->t1 - a->t0 > b->t1 - b->t0; });
-    typedef std::pair<long long, int> Load;      // (cost so far, slot): the least loaded slot first, ties by slot number
-    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+    const size_t b0 = lane_begin[x], b1 = lane_begin[x + 1];
+    std::fill(bucket.begin(), bucket.end(), 0);
+    for (size_t i = b0; i < b1; ++i)
+      if (jl[i].t1 > jl[i].t0) ++bucket[max_cost - (jl[i].t1 - jl[i].t0 + PAIR_JOB_OVERHEAD_TILES) + 1];
+    for (int c = 0; c <= max_cost; ++c) bucket[c + 1] += bucket[c];
+    order.assign(bucket[max_cost + 1], 0);
+    for (size_t i = b0; i < b1; ++i)
+      if (jl[i].t1 > jl[i].t0) order[bucket[max_cost - (jl[i].t1 - jl[i].t0 + PAIR_JOB_OVERHEAD_TILES)]++] = i;
+    // the least loaded slot first: the loads of a lane's slots never differ by more than one job's cost, so a ring of max_cost + 2 queues
+    // indexed by load serves as the priority queue (first in, first out among equals)
+    const int R = max_cost + 2;
+    std::vector<std::vector<int>> ring(R);
+    std::vector<size_t> head(R, 0);
     for (int w = 0; w < waves; ++w)
-      for (int b = x; b < grid; b += lanes) heap.push(Load(0, w * grid + b));
-    for (const Job *J : mine) {
-      Load l = heap.top();
-      heap.pop();
-      per_slot[l.second].push_back(*J);
-      l.first += J->t1 - J->t0 + PAIR_JOB_OVERHEAD_TILES;
-      heap.push(l);
+      for (int b = x; b < grid; b += lanes) ring[0].push_back(w * grid + b);
+    long long lo = 0;
+    for (size_t i : order) {
+      while (head[lo % R] == ring[lo % R].size()) {
+        ring[lo % R].clear();
+        head[lo % R] = 0;
+        ++lo;
+      }
+      const int sl = ring[lo % R][head[lo % R]++];
+      slot_of[i] = sl;
+      pos_of[i] = count[sl]++;
+      ring[(lo + jl[i].t1 - jl[i].t0 + PAIR_JOB_OVERHEAD_TILES) % R].push_back(sl);
     }
   }
-  size_t rounds = 0;
-  for (const auto &s : per_slot) rounds = std::max(rounds, s.size());
+  int rounds = 0;
+  for (int c : count) rounds = std::max(rounds, c);
   Job nullj;
   memset(&nullj, 0, sizeof(nullj));
   nullj.N = 1;
-  std::vector<Job> out(rounds * (size_t)slots, nullj);
-  for (int s = 0; s < slots; ++s)
-    for (size_t k = 0; k < per_slot[s].size(); ++k) out[k * (size_t)slots + s] = per_slot[s][k];
+  std::vector<Job> out((size_t)rounds * slots, nullj);
+  for (size_t i = 0; i < n; ++i)
+    if (slot_of[i] >= 0) out[(size_t)pos_of[i] * slots + slot_of[i]] = jl[i];
   jl.swap(out);
 }
