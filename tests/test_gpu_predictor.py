@@ -318,14 +318,16 @@ def _mixed_check(hip_predictor, small, big, alone_small, out):
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("a,l,B,seed", [(1, 1, 1, 5), (16, 15, 3, 2), (17, 30, 3, 4), (40, 55, 2, 1), (64, 256, 1, 21), (64, 256, 9, 22), (40, 1000, 1, 23)])
+@pytest.mark.parametrize("a,l,B,seed", [(1, 1, 1, 5), (16, 15, 3, 2), (17, 30, 3, 4), (40, 55, 2, 1), (64, 256, 1, 21), (64, 256, 9, 22), (40, 1000, 1, 23),
+                                        (15, 239, 1, 24), (16, 239, 2, 25), (17, 239, 1, 26)])
 def test_tile_native_pair_kernel_equals_the_row_major_one(prec, a, l, B, seed, hip_predictor):
     """k_pair_t (edge tensor in 8 KB tile chunks of the MFMA C/D layout, next tile and its T rows requested across job boundaries, folded
     query in registers: the default under the bf16 arithmetics) against k_pair_bf (row-major tensor through LDS staging: rounds 2-3,
     mind_set_tuning("pair_tile", 0)).  bf16x3: the same contractions, the same summation orders -- the same bits (N = 3, 32, 48, 96, 321:
     one-tile columns, whole tiles, ragged last tiles, split columns).  Plain bf16: k_pair_t keeps the edge tensor in bf16 too, so the two
     differ by that rounding (both are 6e-3 .. 3e-2 away from the oracle).  Nine scenes of N = 321: more jobs than wave slots, dealt over XCD lanes
-    whose cuts fall inside scenes (pair_jobs.h); N = 1041: eight partials per column, 66 tiles."""
+    whose cuts fall inside scenes (pair_jobs.h); N = 1041: eight partials per column, 66 tiles; N = 255, 256, 257: either side of the size from
+    which a column is cut into jobs of about seven tiles."""
     pb = predictor_batch(a, l, B, seed=seed)
     before = hip_predictor.pair_precision()
     try:
