@@ -55,7 +55,8 @@
 // A/B in one process with nothing else launched in between (PAIR_BENCH_ONLY; 24 x N = 321, 3 jobs per column): base 0.709 ms, (a) 0.711, (b) 0.75.
 // With two waves per SIMD the partner wave already fills what one wave leaves idle; the launch is bound by its memory-only form (0.53-0.60 ms)
 // and its arithmetic-only form (0.67 ms) at the same time.  (profiles/r05y_pair_bench_shadow_experiments.txt shows (a) at 0.707 against 0.741: an
-// artefact -- a launch is 5 % faster on the edge values the ablation variants before it leave behind (cause not established -- the values turn to NaN / saturate under the ablations; presumably the power the matrix pipe draws), which is why
+// artefact of the variant's position in the list -- the same kernel times +- 3-5 % by what ran before it (behind the light ablation variants it is
+// faster; the VALUES do not matter: NaN / zero / normal edge tensors time the same, profiles/r05z_pair_bench_fill.txt), which is why
 // that file's variants are only comparable with their own row of another run.)  What did pay is the schedule of the column jobs: pair_jobs.h.
 template <int MODE, int NP, int ABL = 0>
 __global__ __launch_bounds__(PAIR_THREADS, 1) void k_pair_t(const PairJob *__restrict__ jobs, int n_jobs, float *__restrict__ edge,

@@ -5,6 +5,7 @@
 //   tools/micro/bin/pair_bench [scenes 24] [N 321] [rounds 7] [column splits: default as mind_predict_batch]
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -67,6 +68,11 @@ int main(int argc, char **argv) {
   const size_t edge_floats = (size_t)ebt * 128;
   std::vector<float> h_edge(edge_floats), h_ST((size_t)ntok * 256), h_vt(VT_SIZE), h_rt(1024), h_tp((size_t)ntok * 4);
   for (auto &v : h_edge) v = G(rng);
+  if (const char *fill = getenv("PAIR_BENCH_FILL")) {      // nan | zero: is a launch's time a function of the VALUES it streams?  (timing only)
+    const float f = fill[0] == 'n' ? NAN : 0.f;
+    for (auto &v : h_edge) v = f;
+    printf("edge tensor filled with %s\n", fill);
+  }
   for (auto &v : h_ST) v = 0.5f * G(rng);
   for (int i = 0; i < VT_SIZE; ++i) h_vt[i] = (i / 128) % 2 == 0 ? 1.f + 0.1f * U(rng) : 0.1f * U(rng);
   for (auto &v : h_rt) v = 0.3f * U(rng);
