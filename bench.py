@@ -71,6 +71,22 @@ PAIR_FULL = 69632.0        # folded algorithm, per pair and layer: 2 x (2*128*12
 PAIR_ATT = 36864.0         # a pair whose edge is not updated: first GEMM + attention
 PAIR_UPD = 32768.0         # the edge-update GEMM alone
 PEAK_F32_MFMA, PEAK_BF16_MFMA, PEAK_HBM = 157.3e12, 2500e12, 8.0e12      # MI355X_MICROARCH.md
+# The arithmetic of the CREDITED slots of the line (value, ms_per_step, dtype, roofline): an fp32-class one -- the reference computes the
+# predictor in fp32, and a narrower arithmetic than the reference's own is not a measurement of this metric.  "f32" = plain fp32
+# operands on v_mfma_f32_16x16x4_f32; "bf16x6" = operands split three ways into bf16 hi + mid + lo (3 x 8 = 24 significand bits, exact), the
+# six partial products >= 2^-24 on v_mfma_f32_16x16x32_bf16, fp32 accumulate.  bf16x3 (two-way split, 16 bits) is reported beside it.
+HEADLINE_PREC = os.environ.get("MIND_BENCH_PREC", "f32")
+PREC_DTYPE = {"f32": "f32 (fp32 operands on the fp32 MFMA)",
+              "bf16x6": "f32-class (bf16 hi+mid+lo split operands = 24 significand bits, six products, fp32 accumulate)",
+              "bf16x3": "bf16x3 (bf16 hi+lo split operands, fp32 accumulate)", "bf16": "bf16"}
+PREC_PASSES = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "bf16": 1}
+PREC_KERNEL = {"f32": "k_pair (fp32 MFMA)", "bf16x6": "k_pair_t<*,6>", "bf16x3": "k_pair_t<*,3>", "bf16": "k_pair_t<*,1>"}
+PREC_NOTE = {"f32": "v_mfma_f32_16x16x4_f32 (fp32 MFMA = the fp32 vector rate)",
+             "bf16x6": "operands split into bf16 hi + mid + lo (exact: 24 significand bits), the 6 products >= 2^-24 per term on "
+                       "v_mfma_f32_16x16x32_bf16, fp32 accumulate: peak = dense bf16 peak / 6 passes",
+             "bf16x3": "operands split into bf16 hi + lo, 3 products per term on v_mfma_f32_16x16x32_bf16, fp32 accumulate: "
+                       "peak = dense bf16 peak / 3 passes",
+             "bf16": "plain bf16 operands, fp32 accumulate"}
 
 
 def fold_flops(N, nf):
@@ -309,21 +325,18 @@ def roofline(m, prec):
     s = p["ms"] * 1e-3
     if s <= 0 or p["launches"] == 0:
         return None
-    passes = {"f32": 1, "bf16x3": 3, "bf16": 1}[prec]
+    passes = PREC_PASSES[prec]
     peak = PEAK_F32_MFMA if prec == "f32" else PEAK_BF16_MFMA / passes
     f_mfma = p["fold"] / s / peak
     f_hbm = p["bytes"] / s / PEAK_HBM
     bound = "hbm" if f_hbm > f_mfma else "mfma"
     return {
-        "kernel": "k_pair_t (RelaFusionLayer pair kernel, 6 launches per predictor call)", "bound": bound,
+        "kernel": PREC_KERNEL[prec] + " (RelaFusionLayer pair kernel, 6 launches per predictor call)", "bound": bound,
         "achieved": (p["bytes"] / s / 1e9) if bound == "hbm" else (p["fold"] / s / 1e12),
         "peak": PEAK_HBM / 1e9 if bound == "hbm" else peak / 1e12, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
         "frac": max(f_hbm, f_mfma), "traffic": None,
         "mfma": {"achieved_tflops": p["fold"] / s / 1e12, "peak_tflops": peak / 1e12, "frac": f_mfma,
-                 "arith": prec, "note": {"f32": "v_mfma_f32_16x16x4_f32 (fp32 MFMA = the fp32 vector rate)",
-                                         "bf16x3": "operands split into bf16 hi + lo, 3 products per term on v_mfma_f32_16x16x32_bf16, fp32 accumulate: "
-                                                   "peak = dense bf16 peak / 3 passes",
-                                         "bf16": "plain bf16 operands, fp32 accumulate"}[prec]},
+                 "arith": prec, "note": PREC_NOTE[prec]},
         "hbm": {"achieved_gbs": p["bytes"] / s / 1e9, "peak_gbs": PEAK_HBM / 1e9, "frac": f_hbm},
         "f_min_tflops": F_MIN_N2 * p["n2"] / s / 1e12,
         "launches_profiled": p["launches"], "avg_launch_ms": p["ms"] / p["launches"],
@@ -335,7 +348,7 @@ def roofline(m, prec):
                 "measured in this run"}
 
 
-def measure_traffic(workload, alg_bytes_per_launch, steps=6, warmup=2):
+def measure_traffic(workload, alg_bytes_per_launch, steps=6, warmup=2, prec=None):
     """HBM traffic of the pair kernel from the hardware counters: two sibling runs of this script under `rocprofv3 --pmc
     FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes with --kernel-trace only, as MI355X_MICROARCH.md prescribes: the two do not fit
     one pass).  FETCH_SIZE / WRITE_SIZE count kilobytes; FETCH_SIZE reports half the bytes of wide coalesced reads on gfx950 and is
@@ -354,7 +367,7 @@ def measure_traffic(workload, alg_bytes_per_launch, steps=6, warmup=2):
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run([prof, "--pmc", cnt, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                                 "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-extras",
-                                "--no-traffic"], cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+                                "--no-traffic"] + (["--prec", prec] if prec else []), cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {cnt} exited with {r.returncode}: {r.stderr[-200:]}"
             tot, disp = 0.0, set()
@@ -785,9 +798,9 @@ def contract_line(out, args):
     if k:
         line["k_ilqr"] = pick(k, "kernel_ms_per_launch", "share_of_step", "cost_trees_per_launch", "cus_busy")
     line["breakdown_ms"] = pick(out.get("breakdown_ms") or {}, "aime", "ilqr")
-    if "exact_fp32" in out:
-        line["exact_fp32"] = pick(out["exact_fp32"], "value", "ms_per_step")
-    for key in ("tree", "tree_sharded", "tree_replicas", "stress", "stress_bf16", "stress_deep", "stress_deeper"):
+    if "bf16x3" in out:
+        line["bf16x3"] = pick(out["bf16x3"], "value", "ms_per_step", "hbm_frac")
+    for key in ("tree_f32", "tree", "tree_sharded", "tree_replicas", "stress", "stress_bf16", "stress_deep", "stress_deeper"):
         t = out.get(key)
         if not isinstance(t, dict):
             continue
@@ -796,7 +809,7 @@ def contract_line(out, args):
             continue
         b = pick(t, "ms_per_plan", "nodes_expanded_per_s", "k_ilqr_ms_per_launch", "gathered_mb_per_plan", "collectives_per_plan", "speedup_vs_1")
         if "k_pair" in t:
-            b["k_pair"] = pick(t["k_pair"], "hbm_frac", "avg_launch_ms")
+            b["k_pair"] = pick(t["k_pair"], "hbm_frac", "mfma_frac", "avg_launch_ms")
         line[key] = b
     for key in ("collectives_per_plan", "gathered_mb_per_plan"):
         if key in out:
@@ -864,6 +877,8 @@ def main():
                     help="strong scaling: all ranks plan the SAME scene, AIME rounds and contingency solves sharded over ranks "
                          "(the default for the full-tree workloads)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent closed loops per rank even for a full-tree workload")
+    ap.add_argument("--prec", default=HEADLINE_PREC, choices=list(PREC_DTYPE),
+                    help="arithmetic of the predictor's MFMA contractions for the headline measurement (default: the fp32-class one; bf16x3 is reported beside it)")
     ap.add_argument("--headline-first", action="store_true", help="measure the headline before the extra workloads (the default runs them first: a fresh box warms up on them)")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "bench.py needs a GPU"
@@ -914,15 +929,17 @@ def main():
         if small:
             return run_small_extras()
         if extras and rank == 0 and world == 1:
-            # the headline workload in the reference's own arithmetic class (fp32 MFMA pair kernel, fp32 MFMA ActorNet)
-            fm = measure(dist, "demo_1", args.steps, args.warmup, False, pair_prec="f32")
-            fr = roofline(fm, "f32")
-            pre["exact_fp32"] = {"value": fm["sim_steps"] / fm["dt"], "unit": "sim steps/s", "ms_per_step": fm["dt"] / fm["steps"] * 1e3,
+            # the headline workload under the two-way split (bf16 hi + lo operands: 16 significand bits, narrower than the reference's fp32 --
+            # reported beside the credited fp32-class figures, never in their place)
+            if args.prec != "bf16x3":
+                fm = measure(dist, "demo_1", args.steps, args.warmup, False, pair_prec="bf16x3")
+                fr = roofline(fm, "bf16x3")
+                pre["bf16x3"] = {"value": fm["sim_steps"] / fm["dt"], "unit": "sim steps/s", "ms_per_step": fm["dt"] / fm["steps"] * 1e3,
                                  "pair_kernel_avg_launch_ms": fr["avg_launch_ms"] if fr else None,
-                                 "pair_kernel_frac_of_fp32_mfma_peak": fr["mfma"]["frac"] if fr else None,
-                                 "pair_kernel_frac_of_hbm_peak": fr["hbm"]["frac"] if fr else None,
-                                 "note": "same workload with MIND_PAIR_PREC=f32: every contraction of the predictor in fp32 (v_mfma_f32_16x16x4_f32 pair "
-                                         "kernel, ActorNet on v_mfma_f32_16x16x4_f32); the headline runs them as bf16 split operands with fp32 accumulation"}
+                                 "hbm_frac": fr["hbm"]["frac"] if fr else None, "mfma_frac": fr["mfma"]["frac"] if fr else None,
+                                 "k_ilqr_ms_per_launch": (fm["ilqr_kernel"]["ms"] / fm["ilqr_kernel"]["launches"]) if fm["ilqr_kernel"]["launches"] else None,
+                                 "note": "same workload with the pair kernel / ActorNet operands split two ways (bf16 hi + lo, 3 products per term): "
+                                         "meets the 2e-4 m parity bar but is narrower than the reference's fp32, hence an extra"}
         if extras:
             # the full cfg4 scenario tree (259 expansions per plan): on one GPU, or planned once by all ranks together.  A failure
             # here must not cost the headline line (every rank reaches the same except branch or none does: the plan is replicated)
@@ -934,6 +951,14 @@ def main():
                                 scaling="strong" if world > 1 else None, plans_timed=args.tree_steps)
             except Exception as e:       # noqa: BLE001
                 pre[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            if world == 1 and args.prec != "bf16x3":
+                # ... and in the headline's fp32-class arithmetic (the figure that carries credit for BASELINE configs[3] on one GPU)
+                try:
+                    t = measure(dist, "cfg4tree", max(args.tree_steps // 2, 2), 2, False, pair_prec=args.prec)
+                    pre["tree_f32"] = dict(summarize(t, args.prec), arith=args.prec, workload="cfg4tree in the headline's fp32-class arithmetic (" + PREC_DTYPE[args.prec] + ")",
+                                           plans_timed=max(args.tree_steps // 2, 2))
+                except Exception as e:       # noqa: BLE001
+                    pre["tree_f32"] = {"error": f"{type(e).__name__}: {e}"[:400]}
             if world > 1:
                 # the same full tree planned by every rank for a scene of its own (independent trees, no data-path collective): the node
                 # throughput of the whole job when the scenes, not one scene's branches, are what is spread over the GPUs
@@ -985,9 +1010,9 @@ def main():
 
     if not args.headline_first:
         run_extras_guarded(True)
-    m = measure(dist, args.workload, args.steps, args.warmup, shard, replica=0 if shard else rank, ckpt=args.ckpt)
+    m = measure(dist, args.workload, args.steps, args.warmup, shard, replica=0 if shard else rank, ckpt=args.ckpt, pair_prec=args.prec)
     pl, sim = m["pl"], m["sim"]
-    prec = pl.network.rt.pair_precision()
+    prec = args.prec
     value = m["sim_steps"] * (1 if shard else world) / m["dt"]
     a, l = m["a"], m["l"]
     exp_plan = m["expansions_all"] / args.steps / (1 if shard else world)
@@ -996,8 +1021,7 @@ def main():
     out = {
         "metric": METRIC, "value": value, "unit": "sim steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": m["dt"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
-        "dtype": {"f32": "f32", "bf16x3": "bf16x3 (bf16 hi+lo split operands, fp32 accumulate)", "bf16": "bf16"}[prec]
-                 + " pair kernel + ActorNet, f32 elsewhere in the predictor, f64 iLQR",
+        "dtype": PREC_DTYPE[prec] + " pair kernel + ActorNet, f32 elsewhere in the predictor, f64 iLQR",
         "data": ("recorded AV2 scene (map + tracks of the reference's %s, tests/golden/scenes), formula-initialised weights" % args.workload) if real else "synthetic",
         "nodes_expanded_per_s": m["expansions_all"] / m["dt"],
         "config": {"workload": (f"BASELINE configs[1]: closed loop on the recorded scene {args.workload}" if real else f"{args.workload}-like synthetic scene") +
@@ -1029,7 +1053,7 @@ def main():
     out.update(pre)
     if rank == 0 and world == 1:
         if not args.no_traffic and out.get("roofline"):
-            tb, det = measure_traffic(args.workload, out["roofline"]["algorithmic_bytes_per_launch"])
+            tb, det = measure_traffic(args.workload, out["roofline"]["algorithmic_bytes_per_launch"], prec=args.prec)
             out["roofline"]["traffic"] = tb
             out["roofline"]["traffic_detail"] = det
         if not args.no_cpu_baseline:

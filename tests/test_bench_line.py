@@ -33,7 +33,12 @@ def test_contract_line_of_a_full_run_is_compact_and_complete(tmp_path, monkeypat
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "cpu", "value_1_thread"}
     assert abs(d["value"] - full["value"]) < 1e-4 * full["value"] and d["steps"] == full["steps"] and d["warmup"] == full["warmup"]
     assert abs(d["ms_per_step"] - full["ms_per_step"]) < 1e-4 * full["ms_per_step"]
-    assert d["exact_fp32"]["value"] > 0 and d["k_ilqr"]["kernel_ms_per_launch"] > 0 and d["tree"]["ms_per_plan"] > 0 and d["tree"]["k_pair"]["hbm_frac"] > 0
+    full_b = dict(full, bf16x3={"value": 1500.0, "ms_per_step": 3.3, "hbm_frac": 0.1, "note": "x" * 300},
+                  tree_f32=dict(full["tree"], arith="f32"))
+    d2 = json.loads(bench.contract_line(full_b, None))
+    assert d2["bf16x3"] == {"value": 1500.0, "ms_per_step": 3.3, "hbm_frac": 0.1} and d2["tree_f32"]["ms_per_plan"] > 0 and "mfma_frac" in d2["tree_f32"]["k_pair"]
+    json.dump(full, open(str(tmp_path / "x.json"), "w"), indent=1)
+    assert d["k_ilqr"]["kernel_ms_per_launch"] > 0 and d["tree"]["ms_per_plan"] > 0 and d["tree"]["k_pair"]["hbm_frac"] > 0
     assert d["extras_file"] == str(tmp_path / "x.json") and json.load(open(d["extras_file"])) == full
 
 

@@ -50,8 +50,8 @@ d = json.load(open("$O/bench_extras.json"))
 print(d["value"], d["ms_per_step"], d["breakdown_ms"]["aime"], d["breakdown_ms"]["ilqr"])
 print("roofline", {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "frac", "traffic")})
 print("k_ilqr", d["k_ilqr"]["kernel_ms_per_launch"], d["k_ilqr"]["phase_share"])
-print("exact_fp32", (d.get("exact_fp32") or {}).get("value"))
-for k in ("tree", "stress", "stress_bf16", "stress_deep", "stress_deeper", "synthetic_branching", "plain_formula_weights"):
+print("dtype", d["dtype"][:40], "| bf16x3", (d.get("bf16x3") or {}).get("value"))
+for k in ("tree_f32", "tree", "stress", "stress_bf16", "stress_deep", "stress_deeper", "synthetic_branching", "plain_formula_weights"):
     t = d.get(k) or {}
     print(k, t.get("ms_per_plan"), t.get("nodes_expanded_per_s"), t.get("aime_native_plans"), (t.get("k_pair") or {}).get("hbm_frac"), t.get("error"))
 print("recorded", {k: v.get("sim_steps_per_s") for k, v in (d.get("recorded_scenes") or {}).items() if isinstance(v, dict)})
