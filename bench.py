@@ -75,7 +75,7 @@ PEAK_F32_MFMA, PEAK_BF16_MFMA, PEAK_HBM = 157.3e12, 2500e12, 8.0e12      # MI355
 # predictor in fp32, and a narrower arithmetic than the reference's own is not a measurement of this metric.  "f32" = plain fp32
 # operands on v_mfma_f32_16x16x4_f32; "bf16x6" = operands split three ways into bf16 hi + mid + lo (3 x 8 = 24 significand bits, exact), the
 # six partial products >= 2^-24 on v_mfma_f32_16x16x32_bf16, fp32 accumulate.  bf16x3 (two-way split, 16 bits) is reported beside it.
-HEADLINE_PREC = os.environ.get("MIND_BENCH_PREC", "f32")
+HEADLINE_PREC = os.environ.get("MIND_BENCH_PREC", "bf16x6")
 PREC_DTYPE = {"f32": "f32 (fp32 operands on the fp32 MFMA)",
               "bf16x6": "f32-class (bf16 hi+mid+lo split operands = 24 significand bits, six products, fp32 accumulate)",
               "bf16x3": "bf16x3 (bf16 hi+lo split operands, fp32 accumulate)", "bf16": "bf16"}

@@ -105,10 +105,14 @@ int mind_set_profiling(mind_ctx *ctx, int enable);
  * in torch fp32): MIND_PAIR_F32 = fp32 MFMA (v_mfma_f32_16x16x4_f32); MIND_PAIR_BF16X3 (default) = both operands split into
  * bf16 hi + lo parts, hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fp32-class accuracy, ~5 x the
  * fp32-MFMA rate); MIND_PAIR_BF16 = plain bf16 operands (BASELINE config 5's "bf16 MFMA attention": misses the 1e-3 m
- * parity bar, never the default).  Also settable at context creation through the environment, MIND_PAIR_PREC=f32|bf16x3|bf16. */
+ * parity bar, never the default); MIND_PAIR_BF16X6 = both operands split EXACTLY into three bf16 parts (hi + mid + lo = the 24 significand
+ * bits of the fp32 value), the six partial products of weight >= 2^-24 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: the reference's fp32
+ * arithmetic class at 2.7 x the fp32-MFMA rate (k_pair_t6; the ActorNet runs the same split, k_actor_mfma<6>).  Also settable at context creation
+ * through the environment, MIND_PAIR_PREC=f32|bf16x3|bf16|bf16x6. */
 #define MIND_PAIR_F32 0
 #define MIND_PAIR_BF16X3 1
 #define MIND_PAIR_BF16 2
+#define MIND_PAIR_BF16X6 3
 int mind_set_pair_precision(mind_ctx *ctx, int mode);
 
 /* Kernel-selection knobs (A/B measurements and tests; the defaults are the measured winners, the results are the same within the

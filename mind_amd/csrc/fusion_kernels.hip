@@ -857,13 +857,17 @@ __global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         // [part 2][k-group 4][row 32 = head 8 x lane quarter 4][slot 8], feature 16 (2g + (i >> 2)) + 4q + (i & 3) <-> slot i
         const int g = col >> 5, qq = (col >> 2) & 3, i = 4 * ((col >> 4) & 1) + (col & 3);
         const int idx = ((g * 32) + hd * 4 + qq) * 8 + i;
+        // mode bit 32 (k_pair_t6): three parts hi / mid / lo (the exact split of the fp32 value), 1536 dwords per token
+        const size_t qks = (mode & 32) ? 1536 : 1024;
         for (int t = 0; t < nt; ++t) {
           const float v = acc[t] * 0.25f;
           const u32 h = pk_bf16(v, v) & 0xffffu;
-          const u32 l = pk_bf16(v - bf_lo_f32(h), 0.f) & 0xffffu;
-          unsigned short *qs = reinterpret_cast<unsigned short *>(QK + (size_t)(tok0 + t) * 1024);
+          const float r1 = v - bf_lo_f32(h);
+          const u32 l = pk_bf16(r1, 0.f) & 0xffffu;
+          unsigned short *qs = reinterpret_cast<unsigned short *>(QK + (size_t)(tok0 + t) * qks);
           qs[idx] = (unsigned short)h;
           qs[1024 + idx] = (unsigned short)l;
+          if (mode & 32) qs[2048 + idx] = (unsigned short)(pk_bf16(r1 - bf_lo_f32(l), 0.f) & 0xffffu);
         }
       } else {
         for (int t = 0; t < nt; ++t) QK[(size_t)(tok0 + t) * 1024 + hd * 128 + col] = acc[t] * 0.25f;

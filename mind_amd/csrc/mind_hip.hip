@@ -20,6 +20,7 @@
 #include "fusion_kernels.hip"
 #include "pair_bf16_kernels.hip"
 #include "pair_tile_kernels.hip"
+#include "pair_tile6_kernels.hip"
 #include "token_mfma_kernels.hip"
 #include "actor_mfma_kernels.hip"
 #include "actor_f32_kernels.hip"
@@ -98,6 +99,7 @@ struct mind_ctx {
   int tok_small_max = 2048;     // batches of at most this many tokens run k_token with 4 tokens per workgroup ("tok_small_max")
   const float *WAe[6], *WAp[6], *vtab[6], *rtab = nullptr;
   const u32 *WBe[6], *WBp[6];   // bf16 hi / lo fragments of the same matrices (pair_bf16_kernels.hip)
+  const u32 *WLe[6], *WLp[6];   // the third part of the exact three-way split (hi + mid + lo; mid = the two-way split's lo): k_pair_t6
   // job / token tables of recent mind_predict_batch calls (least-recently-used of MIND_TABLE_SETS): a call whose scene sizes
   // were seen before rebuilds, uploads and synchronises nothing -- the closed loop's rounds recur every cycle, a full tree's
   // rounds (1 / 6 / 36 / 216 scenes) every plan
@@ -127,7 +129,7 @@ struct mind_ctx {
   bool actor_f32 = true;
   int actor_f32_min = 1 << 30, actor_f32_pair_min = 1 << 30;
   bool xcd_order = true;        // XCD-aware job order for big batches (MIND_XCD_ORDER=0 switches it off, for A/B measurements)
-  int pair_prec = 1;            // arithmetic of the pair kernel: 0 = fp32 MFMA, 1 = bf16x3 (split operands, default), 2 = bf16
+  int pair_prec = 1;            // arithmetic of the pair kernel: 0 = fp32 MFMA, 1 = bf16x3 (split operands, default), 2 = bf16, 3 = bf16x6 (three-way split: fp32 class)
   // bf16 arithmetics: k_pair_t (tile-native edge tensor, pair_tile_kernels.hip; default) or the row-major k_pair_bf of rounds 2-3
   // (mind_set_tuning("pair_tile", 0) / MIND_PAIR_TILE=0, kept for same-box A/B measurements)
   bool pair_tile = true;
@@ -280,6 +282,8 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   (void)hipFuncSetAttribute((const void *)k_pair_t<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_pair_t<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_pair_t<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_pair_t6<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_pair_t6<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_pair_bf_lds_bytes());
   if (const char *te = getenv("MIND_PAIR_TILE")) c->pair_tile = !(te[0] == '0');
   if (const char *xe = getenv("MIND_XCD_ORDER")) c->xcd_order = !(xe[0] == '0');
 
@@ -288,6 +292,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
     if (v == "f32" || v == "0") c->pair_prec = 0;
     else if (v == "bf16x3" || v == "1") c->pair_prec = 1;
     else if (v == "bf16" || v == "2") c->pair_prec = 2;
+    else if (v == "bf16x6" || v == "3") c->pair_prec = 3;
   }
   (void)hipFuncSetAttribute((const void *)k_actor_net, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_actor_mfma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_actor_mfma_lds_bytes());
@@ -419,7 +424,7 @@ extern "C" int mind_last_exchange_stats(mind_ctx *c, long long *collectives, lon
 }
 
 extern "C" int mind_set_pair_precision(mind_ctx *c, int mode) {
-  if (!c || mode < 0 || mode > 2) return MIND_EINVAL;
+  if (!c || mode < 0 || mode > 3) return MIND_EINVAL;
   c->pair_prec = mode;
   return MIND_OK;
 }
@@ -607,6 +612,29 @@ inline float bf16_to_f32(uint16_t h) {
 // bf16 MFMA 16x16x32 A-fragment order, hi and lo parts: [part 2][ob 8][g 4][lane 64][dword 4]; dword d of lane
 // (r = lane & 15, q = lane >> 4) packs k-slots 2d, 2d+1; k-slot (q, i) <-> input feature 16 (2g + (i >> 2)) + 4q + (i & 3)
 // (the chained B-operand order of pair_bf16_kernels.hip).  Returned as float bit patterns (16384 dwords).
+// the third part of the exact three-way split x = hi + mid + lo (mid = pack_bfrag's lo part), same fragment order: [ob 8][g 4][lane 64][dword 4]
+std::vector<float> pack_bfrag_lo3(const std::vector<float> &w, int row_stride) {
+  std::vector<uint32_t> t(8192, 0u);
+  for (int ob = 0; ob < 8; ++ob)
+    for (int g = 0; g < 4; ++g)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int d = 0; d < 4; ++d) {
+          uint32_t lo = 0;
+          for (int e = 0; e < 2; ++e) {
+            const int i = 2 * d + e, q = lane >> 4;
+            const int f = 16 * (2 * g + (i >> 2)) + 4 * q + (i & 3);
+            const float x = w[(size_t)(16 * ob + (lane & 15)) * row_stride + f];
+            const float r1 = x - bf16_to_f32(bf16_rne(x));
+            const float r2 = r1 - bf16_to_f32(bf16_rne(r1));
+            lo |= (uint32_t)bf16_rne(r2) << (16 * e);
+          }
+          t[((size_t)(ob * 4 + g) * 64 + lane) * 4 + d] = lo;
+        }
+  std::vector<float> out(8192);
+  memcpy(out.data(), t.data(), 8192 * sizeof(float));
+  return out;
+}
+
 std::vector<float> pack_bfrag(const std::vector<float> &w, int row_stride) {
   std::vector<uint32_t> t(16384, 0u);
   for (int ob = 0; ob < 8; ++ob)
@@ -849,6 +877,7 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
     const float *Wm = Wmc.data();
     B.add(k + ".WAe", pack_afrag(Wm, 384));
     B.add(k + ".WBe", pack_bfrag(Wmc, 384));
+    B.add(k + ".WLe", pack_bfrag_lo3(Wmc, 384));
     B.add(k + ".WsT", transpose(Wm, 128, 128, 384, 128));
     B.add(k + ".WtT", transpose(Wm, 128, 128, 384, 256));
     B.add(k + ".bm", bmc);
@@ -864,6 +893,7 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
       center_outputs(Wpc, bpc, 128, 128);
       B.add(k + ".WAp", pack_afrag(Wpc.data(), 128));
       B.add(k + ".WBp", pack_bfrag(Wpc, 128));
+      B.add(k + ".WLp", pack_bfrag_lo3(Wpc, 128));
       put(VT_BP, bpc.data());
       put(VT_GP, sd.get(p + ".proj_edge.1.weight", 128));
       put(VT_BEP, sd.get(p + ".proj_edge.1.bias", 128));
@@ -1032,6 +1062,8 @@ extern "C" int mind_weights_load(mind_ctx *c, const mind_tensor_desc *tensors, i
     c->WAp[L] = P(k + ".WAp");
     c->WBe[L] = (const u32 *)P(k + ".WBe");
     c->WBp[L] = (const u32 *)P(k + ".WBp");
+    c->WLe[L] = (const u32 *)P(k + ".WLe");
+    c->WLp[L] = (const u32 *)P(k + ".WLp");
     c->vtab[L] = P(k + ".vtab");
   }
   for (int L = 0; L <= 6; ++L) {
@@ -1241,7 +1273,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   const std::vector<int> &actor_row = ts->actor_row, &cls_row = ts->cls_row;
   const long long edge_pairs = ts->edge_pairs;
   const int ntok = ts->ntok, slot = ts->slot, njobs = ts->njobs;
-  const bool tiled = c->pair_prec != 0 && c->pair_tile;      // k_pair_t: the edge tensor in its tile-native layout
+  const bool tiled = c->pair_prec == 3 || (c->pair_prec != 0 && c->pair_tile);      // k_pair_t / k_pair_t6: the edge tensor in its tile-native layout
   const double pairs_full = ts->pairs_full, pairs_l5 = ts->pairs_l5;
 
   // ---- workspaces
@@ -1249,7 +1281,8 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   if ((rc = ensure(c, c->edge, (size_t)(tiled ? ts->edge_pairs_t : edge_pairs) * 128 * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->x, (size_t)ntok * 128 * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->ST, (size_t)ntok * 256 * sizeof(float)))) return rc;
-  if ((rc = ensure(c, c->QK, (size_t)ntok * 1024 * sizeof(float)))) return rc;
+  const size_t qk_stride = c->pair_prec == 3 ? P6_QK_STRIDE : 1024;      // dwords of folded query per token (three parts under bf16x6)
+  if ((rc = ensure(c, c->QK, (size_t)(ntok + 1) * qk_stride * sizeof(float)))) return rc;      // (+ 1: k_pair_t6's padding rows read past the last record)
   if ((rc = ensure(c, c->part, (size_t)slot * PART_STRIDE * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->tokpos, (size_t)ntok * 4 * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->actor_feat, (size_t)A * 128 * sizeof(float)))) return rc;
@@ -1292,7 +1325,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
     hipLaunchKernelGGL(k_actor_f32<1>, dim3(A), dim3(AF_T), mind_actor_f32_lds_bytes(1), st, in->actors, A, actor_feat, c->actorFW);
   else if (c->pair_prec == 0 || !c->enc_mfma)
     hipLaunchKernelGGL(k_actor_net, dim3(A), dim3(AT), mind_actor_lds_bytes(), st, in->actors, A, actor_feat, c->actorW);
-  else if (c->pair_prec == 1 && c->actor_np == 6)
+  else if (c->pair_prec == 3 || (c->pair_prec == 1 && c->actor_np == 6))
     hipLaunchKernelGGL(k_actor_mfma<6>, dim3(A), dim3(AM_T), mind_actor_mfma_lds_bytes(), st, in->actors, A, actor_feat, c->actorBW);
   else if (c->pair_prec == 1)
     hipLaunchKernelGGL(k_actor_mfma<3>, dim3(A), dim3(AM_T), mind_actor_mfma_lds_bytes(), st, in->actors, A, actor_feat, c->actorBW);
@@ -1324,7 +1357,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   // under the bf16 pair-kernel arithmetics run k_token_mfma<1> (bf16 hi + lo split operands on the MFMA, 16 tokens per workgroup: the
   // VALU kernel is LDS-bound at those sizes), every other scene the VALU kernel -- consecutive scenes of one class share a launch, small
   // launches take four tokens per workgroup (more workgroups, half the LDS operand traffic each; bit-identical to eight)
-  const int qsplit = c->pair_prec != 0 ? 16 : 0;      // the bf16 pair kernels read the folded query as hi / lo fragments
+  const int qsplit = c->pair_prec == 3 ? 48 : c->pair_prec != 0 ? 16 : 0;      // the bf16 pair kernels read the folded query as hi / lo (bf16x6: hi / mid / lo) fragments
   const size_t tokm_lds = mind_token_mfma_lds_bytes();
   struct TokRun { int t0, n, kind; };                  // kind 0: VALU, 1: fp32 MFMA (opt-in), 2: bf16 split MFMA
   std::vector<TokRun> tok_runs;
@@ -1332,7 +1365,8 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
     int t0 = 0;
     for (int b = 0; b < Bn; ++b) {
       const int N = (in->actor_off[b + 1] - in->actor_off[b]) + (in->lane_off[b + 1] - in->lane_off[b]) + 1;
-      const int kind = c->tok_mfma ? 1 : (c->pair_prec != 0 && c->tok_bf_min_n > 0 && N >= c->tok_bf_min_n) ? 2 : 0;
+      // (the two-way-split token kernel is not an fp32-class arithmetic: never under bf16x6)
+      const int kind = c->tok_mfma ? 1 : (c->pair_prec != 0 && c->pair_prec != 3 && c->tok_bf_min_n > 0 && N >= c->tok_bf_min_n) ? 2 : 0;
       if (!tok_runs.empty() && tok_runs.back().kind == kind) tok_runs.back().n += N;
       else tok_runs.push_back({t0, N, kind});
       t0 += N;
@@ -1341,7 +1375,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   auto launch_tokens = [&](int mode, int Lw) {
     for (const TokRun &r : tok_runs) {
       const TokMeta *m_ = dmeta + r.t0;
-      float *x_ = x + (size_t)r.t0 * 128, *ST_ = ST + (size_t)r.t0 * 256, *QK_ = QK + (size_t)r.t0 * 1024;
+      float *x_ = x + (size_t)r.t0 * 128, *ST_ = ST + (size_t)r.t0 * 256, *QK_ = QK + (size_t)r.t0 * qk_stride;
       if (r.kind == 0) {
         const bool small = r.n <= c->tok_small_max;
         const int tpw = small ? TOK_TPW_SMALL : TOK_TPW_BIG;
@@ -1400,7 +1434,15 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
 #define LAUNCH_T(M, NPV)                                                                                                       \
   hipLaunchKernelGGL((k_pair_t<M, NPV>), dim3(grid_t), dim3(PAIR_THREADS), ldsb, st, jl, nj, edge, ST, QK, part, we, wp,       \
                      c->vtab[L], c->rtab, tokpos, rpe_dev, um)
-      if (c->pair_prec == 1) { if (L == 0) LAUNCH_T(0, 3); else LAUNCH_T(1, 3); }
+      if (c->pair_prec == 3) {
+        const u32 *wle = c->WLe[L], *wlp = L == 5 ? c->WLe[L] : c->WLp[L];
+        if (L == 0)
+          hipLaunchKernelGGL(k_pair_t6<0>, dim3(grid_t), dim3(PAIR_THREADS), ldsb, st, jl, nj, edge, ST, QK, part, we, wp, wle, wlp, c->vtab[L], c->rtab,
+                             tokpos, rpe_dev, um);
+        else
+          hipLaunchKernelGGL(k_pair_t6<1>, dim3(grid_t), dim3(PAIR_THREADS), ldsb, st, jl, nj, edge, ST, QK, part, we, wp, wle, wlp, c->vtab[L], c->rtab,
+                             tokpos, rpe_dev, um);
+      } else if (c->pair_prec == 1) { if (L == 0) LAUNCH_T(0, 3); else LAUNCH_T(1, 3); }
       else { if (L == 0) LAUNCH_T(0, 1); else LAUNCH_T(1, 1); }
 #undef LAUNCH_T
     } else {
@@ -1447,7 +1489,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   } else if (fp32_dec)
     hipLaunchKernelGGL(k_dec_actor<0>, dim3((A + RA - 1) / RA), dim3(DT), mind_dec_actor_lds_bytes(), st, x, d_actor_row, d_actor_scene, A,
                        (const float *)c->cmode.p, (const float *)c->tgt_emb.p, out->reg, out->vel, c->decW, (float *)nullptr);
-  else if (c->pair_prec == 1 && c->actor_np == 6)
+  else if (c->pair_prec == 3 || (c->pair_prec == 1 && c->actor_np == 6))
     hipLaunchKernelGGL(k_dec_actor_mfma<6>, dim3((A + DM_RA - 1) / DM_RA), dim3(DM_T), mind_dec_actor_mfma_lds_bytes(), st, x, d_actor_row,
                        d_actor_scene, A, (const float *)c->cmode.p, (const float *)c->tgt_emb.p, out->reg, out->vel, c->decBW);
   else if (c->pair_prec == 1)

@@ -354,10 +354,12 @@ __global__ __launch_bounds__(TM_THREADS) void k_token_mfma(const TokMeta *__rest
             const int g = col >> 5, qq = (col >> 2) & 3, ii = 4 * ((col >> 4) & 1) + (col & 3);
             const int idx = ((g * 32) + hd * 4 + qq) * 8 + ii;
             const u32 h = pk_bf16(v, v) & 0xffffu;
-            const u32 l = pk_bf16(v - bf_lo_f32(h), 0.f) & 0xffffu;
-            unsigned short *qs = reinterpret_cast<unsigned short *>(QK + (size_t)(tok0 + tk) * 1024);
+            const float r1 = v - bf_lo_f32(h);
+            const u32 l = pk_bf16(r1, 0.f) & 0xffffu;
+            unsigned short *qs = reinterpret_cast<unsigned short *>(QK + (size_t)(tok0 + tk) * ((mode & 32) ? 1536 : 1024));
             qs[idx] = (unsigned short)h;
             qs[1024 + idx] = (unsigned short)l;
+            if (mode & 32) qs[2048 + idx] = (unsigned short)(pk_bf16(r1 - bf_lo_f32(l), 0.f) & 0xffffu);      // third part (k_pair_t6)
           } else {
             QK[(size_t)(tok0 + tk) * 1024 + hd * 128 + col] = v;
           }

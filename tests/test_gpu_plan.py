@@ -180,7 +180,7 @@ def _check_waived(test, key, observed):
     assert observed == want, f"{test} / {key}: classified cycles {observed} != the pinned record {want} (tests/golden/waived_cycles.json)"
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f32", "bf16x6"])
 @pytest.mark.parametrize("scene", ["demo_1", "demo_2", "demo_3", "demo_4"])
 def test_recorded_demo_scenes_match_reference_closed_loop(scene, prec):
     """North-star parity on the reference's four recorded AV2 scenes: the reference's own simulator loop (headless,
@@ -340,7 +340,7 @@ def test_recorded_demo_scenes_branching_weights(scene):
     _check_waived("branching_weights_12_cycles", scene, {"better_optimum": better, "other_choice_ill_conditioned": other_ill, "ego_plan_ill_conditioned": ego_ill})
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f32", "bf16x6"])
 @pytest.mark.parametrize("scene", ["demo_1", "demo_2", "demo_3", "demo_4"])
 def test_recorded_demo_scenes_branching_weights_whole_run(scene, prec):
     """The reference's WHOLE closed loop on the recorded scenes (t = 4.0 .. 9.9 s, 60 planning cycles) with the branching formula

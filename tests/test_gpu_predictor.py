@@ -35,7 +35,7 @@ def test_hip_matches_golden(a, l, B, seed, hip_predictor, golden_predictor):
     assert np.abs(vel - g[key + "_vel"]).max() < TOL
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("bf16x3", 5e-5)])
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("bf16x3", 5e-5), ("bf16x6", 5e-5)])
 @pytest.mark.parametrize("a,l,B,seed", [(3, 4, 1, 1), (8, 20, 2, 1), (40, 55, 1, 1)])
 def test_actor_net_tap_by_arithmetic(prec, tol, a, l, B, seed, hip_predictor, golden_predictor):
     """ActorNet output against the reference's golden tap, 5e-5 absolute on values up to ~4: the fp32 MFMA kernel (k_actor_f32, "f32")
@@ -162,7 +162,7 @@ def test_hip_matches_oracle_at_benchmark_sizes(a, l, seed, hip_predictor, formul
     assert np.abs(out["vel"].cpu().numpy() - ov[0].numpy()).max() < TOL
 
 
-@pytest.mark.parametrize("prec,bar", [("f32", 2e-4), ("bf16x3", 2e-4)])
+@pytest.mark.parametrize("prec,bar", [("f32", 2e-4), ("bf16x3", 2e-4), ("bf16x6", 2e-4)])
 @pytest.mark.parametrize("a,l,B,seed", [(8, 20, 2, 1), (40, 55, 1, 1), (33, 64, 2, 6), (64, 256, 1, 21)])
 def test_pair_kernel_arithmetics_meet_the_parity_bar(prec, bar, a, l, B, seed, hip_predictor, formula_sd):
     """Both fp32-class arithmetics of the pair kernel against the oracle at small, demo and cfg4 sizes (the default mode is
@@ -181,6 +181,38 @@ def test_pair_kernel_arithmetics_meet_the_parity_bar(prec, bar, a, l, B, seed, h
         assert np.abs(cls[b] - oc[b].numpy()[0]).max() < 1e-5
         assert np.abs(reg[b * a:(b + 1) * a] - orr[b].numpy()).max() < bar
         assert np.abs(vel[b * a:(b + 1) * a] - ov[b].numpy()).max() < bar
+
+
+def test_three_way_split_pair_kernel_is_as_accurate_as_the_fp32_mfma_one(hip_predictor, formula_sd):
+    """k_pair_t6 ("bf16x6": both operands of every contraction split EXACTLY into bf16 hi + mid + lo, the six partial products >= 2^-24 on the
+    bf16 MFMA, fp32 accumulate) is an fp32-class arithmetic: at demo size, N = 321 (cfg4) and N = 385 (stress) its error against the oracle is
+    no larger than that of k_pair (plain fp32 operands on the fp32 MFMA) on the same inputs -- up to the noise of two different fp32
+    summation orders -- and below 5e-6 m outright, where the two-way split (bf16x3) sits near 1e-5.  Ragged small scenes ride along."""
+    rows = []
+    for a, l, B, seed in ((40, 55, 1, 1), (64, 256, 1, 21), (128, 256, 1, 22), (5, 9, 3, 2), (17, 30, 2, 4)):
+        pb = predictor_batch(a, l, B, seed=seed)
+        oc, orr, ov = op.forward(formula_sd, to_t(pb))
+        err = {}
+        before = hip_predictor.pair_precision()
+        try:
+            for prec in ("f32", "bf16x6", "bf16x3"):
+                hip_predictor.set_pair_precision(prec)
+                out = hip_predictor.predict_numpy_batch(pb)
+                reg, vel, cls = out["reg"].cpu().numpy(), out["vel"].cpu().numpy(), out["cls"].cpu().numpy()
+                err[prec] = (max(float(np.abs(reg[b * a:(b + 1) * a] - orr[b].numpy()).max()) for b in range(B)),
+                             max(float(np.abs(vel[b * a:(b + 1) * a] - ov[b].numpy()).max()) for b in range(B)),
+                             max(float(np.abs(cls[b] - oc[b].numpy()[0]).max()) for b in range(B)))
+        finally:
+            hip_predictor.set_pair_precision(before)
+        rows.append((a, l, B, err))
+        print(f"a={a} l={l} B={B}: max |reg - oracle| f32 {err['f32'][0]:.2e}  bf16x6 {err['bf16x6'][0]:.2e}  bf16x3 {err['bf16x3'][0]:.2e} m; "
+              f"vel {err['f32'][1]:.2e} / {err['bf16x6'][1]:.2e} / {err['bf16x3'][1]:.2e}; cls {err['f32'][2]:.2e} / {err['bf16x6'][2]:.2e} / {err['bf16x3'][2]:.2e}")
+    for a, l, B, err in rows:
+        assert err["bf16x6"][0] < 5e-6 and err["bf16x6"][1] < 5e-6 and err["bf16x6"][2] < 2e-6, (a, l, err)
+        # no larger than the fp32 MFMA kernel's, with a margin for two different summation orders of the same fp32 terms
+        assert err["bf16x6"][0] <= 1.5 * err["f32"][0] + 5e-7 and err["bf16x6"][1] <= 1.5 * err["f32"][1] + 5e-7, (a, l, err)
+    # ... and over all cases together it is not the worse of the two
+    assert sum(e["bf16x6"][0] for *_, e in rows) <= 1.25 * sum(e["f32"][0] for *_, e in rows)
 
 
 def test_default_pair_arithmetic_is_bf16x3(hip_predictor):
