@@ -782,7 +782,7 @@ def contract_line(out, args):
     def pick(d, *keys):
         return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
 
-    line = pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "measured_after_warmup")
     line["config"] = pick(out["config"], "workload", "agents", "lane_polylines", "expansions_per_plan", "scenario_trees_per_plan", "weights", "parallelism", "sim_steps_timed")
     line["nodes_expanded_per_s"] = out.get("nodes_expanded_per_s")
     r = out.get("roofline")
@@ -1022,6 +1022,9 @@ def main():
         "metric": METRIC, "value": value, "unit": "sim steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": m["dt"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
         "dtype": PREC_DTYPE[prec] + " pair kernel + ActorNet, f32 elsewhere in the predictor, f64 iLQR",
+        # the headline loop runs behind a few seconds of the small extra workloads (a fresh box reaches its steady state on them: the first
+        # invocation on a cold box measured 1 233-1 374 where every later one measured 1 470-1 500, profiles/r05v_*); --headline-first measures it cold
+        "measured_after_warmup": bool(extras and not args.headline_first),
         "data": ("recorded AV2 scene (map + tracks of the reference's %s, tests/golden/scenes), formula-initialised weights" % args.workload) if real else "synthetic",
         "nodes_expanded_per_s": m["expansions_all"] / m["dt"],
         "config": {"workload": (f"BASELINE configs[1]: closed loop on the recorded scene {args.workload}" if real else f"{args.workload}-like synthetic scene") +

@@ -10,9 +10,11 @@
 //
 // Sharded (mind_set_exchange, include/mind_hip.h): the scenes of a round are block-distributed over the ranks; a rank runs the device
 // part of the round on its block only, the decisions (96 B per scene) are all-gathered, the bookkeeping below is replayed identically on
-// every rank, the rank that holds a branching node's parent scene re-bases it and the next round's inputs + history windows are
-// all-gathered (packed / unpacked by k_copy_segs); the final rows / cost-tree entries are completed by one all-reduce over zero-filled
-// buffers.  world == 1 runs the same code without the exchanges.
+// every rank, the rank that holds a branching node's parent scene re-bases it; of the next round's inputs only the small per-scene frames
+// (28 floats: the replicated tree's node records) + LaneNet's output travel in one all-gather, a re-based scene's inputs + history windows go
+// by an all-to-all from the rank that re-based it to the rank whose block of the next round holds it (MIND_XCHG_ALLTOALLV: on a full tree the
+// same rank except at block boundaries; packed / unpacked by k_copy_segs; a round whose ranges coincide on every rank is skipped); the final
+// rows / cost-tree entries are completed by one all-reduce over zero-filled buffers.  world == 1 runs the same code without the exchanges.
 #include <chrono>
 namespace {
 

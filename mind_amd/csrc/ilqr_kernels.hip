@@ -31,7 +31,7 @@
 #endif
 #define IL_SPEC 4     // Levenberg-Marquardt values evaluated speculatively per step INSIDE one workgroup (see k_ilqr)
 #define IL_SLOTS 12   // ... and by the follower workgroups of a tree (k_ilqr<GEN, 2>: one Levenberg-Marquardt value per workgroup); per-slot arrays
-                      // hold IL_SLOTS sets in that mode
+                      // hold max(workgroups per tree, IL_SPEC) sets in that mode (mind_hip.hip: what the launch can use)
 #define IL_MAXA 128   // agents per scene staged in LDS (cfg4: 64, stress: 128)
 #define IL_REL 15     // relevant-agent list length per node
 #define IL_RA 64      // doubles per node in T.relag: (1 + IL_REL) records x 4
@@ -1607,7 +1607,12 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       }
       sh_mu = mu; sh_delta = de; sh_it = it;
       sh_hint = (sh_accepted && sh_slot == 0) ? 1 : IL_SPEC;
-      // (an accepted candidate of a follower's slot is adopted from that slot's arrays: make its writes visible to this CU's loads)
+      // An accepted candidate of a follower's slot is adopted (at the top of the next pass, by every thread) from that slot's arrays.  What makes
+      // the follower's writes visible to this CU's plain loads is the pattern of il_tree_sync (MI355X_MICROARCH.md, inter-workgroup visibility):
+      // producer side -- every wave's stores are complete behind the follower's `__threadfence_block(); __syncthreads()`, then its thread 0
+      // publishes done[slot] with an agent-scope RELEASE (writes the XCD's L2 back); consumer side -- this thread read done[slot] and issued
+      // the agent-scope ACQUIRE above (invalidates THIS CU's vector L1, the only cache private to the workgroup), and the __syncthreads()
+      // below orders every other wave's loads behind it.  No per-thread __threadfence() is needed on either side.
     }
     __syncthreads();
     IL_MARK(t_sel);

@@ -1619,7 +1619,9 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   if (gen || ev || c->ilqr_wgs <= 1) GS = 1;
   while (GS > 1 && ((n_trees + 7) / 8) * 8 * GS > c->n_cu) --GS;
   const bool slots = GS > 1;
-  const size_t nslot = slots ? IL_SLOTS : IL_SPEC;                   // sets of per-slot arrays (gains, value functions, candidates)
+  // sets of per-slot arrays (gains, value functions, candidates: ~146 doubles per node and slot): what this launch can use -- the followers' slots
+  // (GS, after the residency loop above) or the master's own speculation (IL_SPEC), not IL_SLOTS for every narrow-tree launch
+  const size_t nslot = slots ? (size_t)(GS > IL_SPEC ? GS : IL_SPEC) : IL_SPEC;
   // ---- layout of one device arena: [doubles | floats | ints | tree structs]
   size_t nd = 0, nf = 0, ni = 0;
   auto takeD = [&](size_t n) { size_t o = nd; nd += (n + 1) & ~(size_t)1; return o; };

@@ -124,7 +124,7 @@ class Shard:
                         dist.all_to_all_single(r, s, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
                         torch.cuda.current_stream().synchronize()
                     else:
-                        out = torch.empty(sum(rb), dtype=torch.uint8)
+                        out = torch.zeros(sum(rb), dtype=torch.uint8)
                         self._all_to_all_cpu(out, s.cpu(), rb, sb)
                         r.copy_(out)
                         torch.cuda.current_stream().synchronize()
@@ -176,6 +176,9 @@ class Shard:
         # every rank tells the others how much it sends to whom (the receivers' sizes are known, the bystanders' are not)
         sizes = [None] * W
         dist.all_gather_object(sizes, sb, group=self.group)
+        # a rank's segment for itself never travels (a forced one-rank group -- mind_set_exchange force != 0 -- puts real bytes there)
+        if sb[me]:
+            out[ro[me]:ro[me + 1]] = inp[so[me]:so[me + 1]]
         for src in range(W):
             for dst in range(W):
                 n = sizes[src][dst]

@@ -72,12 +72,14 @@ def collectives():
     # the all-to-all of the sharded native plan's exchange (MIND_XCHG_ALLTOALLV) as its CPU transport performs it: rank j sends (j + 1) * (k + 2)
     # bytes of value 16 j + k to rank k != j, nothing to itself -- through gloo's own all-to-all where this build has it, and through the
     # broadcast fallback
+    # ... and once more with a segment for the rank itself (a forced one-rank group sends its own re-based scenes to itself): the fallback must
+    # copy it locally, into an output buffer that was NOT zeroed
     a2a = []
-    for force_fallback in (False, True):
-        sb = [0 if k == r else (r + 1) * (k + 2) for k in range(W)]
-        rb = [0 if j == r else (j + 1) * (r + 2) for j in range(W)]
+    for force_fallback, self_too in ((False, False), (True, False), (False, True), (True, True)):
+        sb = [0 if (k == r and not self_too) else (r + 1) * (k + 2) for k in range(W)]
+        rb = [0 if (j == r and not self_too) else (j + 1) * (r + 2) for j in range(W)]
         inp = torch.cat([torch.full((sb[k],), 16 * r + k, dtype=torch.uint8) for k in range(W)]) if sum(sb) else torch.empty(0, dtype=torch.uint8)
-        out = torch.zeros(sum(rb), dtype=torch.uint8)
+        out = torch.full((sum(rb),), 255, dtype=torch.uint8)
         if force_fallback:
             real = dist.all_to_all_single
 

@@ -58,6 +58,9 @@ def test_packed_tensor_collectives_world_3(tmp_path):
         k = r["rank"]
         want = np.concatenate([np.full(((j + 1) * (k + 2),), 16 * j + k, np.uint8) for j in range(3) if j != k])
         assert np.array_equal(r["a2a"][0], want) and np.array_equal(r["a2a"][1], want)
+        # ... and with a segment for the rank itself (forced one-rank groups send their own scenes to themselves): copied locally by the fallback
+        want_self = np.concatenate([np.full(((j + 1) * (k + 2),), 16 * j + k, np.uint8) for j in range(3)])
+        assert np.array_equal(r["a2a"][2], want_self) and np.array_equal(r["a2a"][3], want_self)
 
 
 def test_block_and_round_robin_partition():

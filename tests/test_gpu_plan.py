@@ -174,10 +174,15 @@ def _check_waived(test, key, observed):
         with open(upd, "w") as f:
             json.dump(rec, f, indent=1, sort_keys=True)
         return
-    rec = json.load(open(_WAIVED_PATH))
+    rec = json.load(open(_WAIVED_PATH))          # ("_meta": the toolchain the records were pinned on and the regeneration command)
     want = rec.get(test, {}).get(key)
+    if os.environ.get("MIND_PRINT_WAIVED") and observed != want:
+        # a legitimate last-bit change (compiler, driver, tuning) moves the chaotic fits: show every set that moved instead of stopping at the first
+        print(f"[waived] {test} / {key}: observed {observed} | pinned {want}")
+        return
     assert want is not None, f"no pinned record for {test} / {key}: observed {observed}"
-    assert observed == want, f"{test} / {key}: classified cycles {observed} != the pinned record {want} (tests/golden/waived_cycles.json)"
+    assert observed == want, (f"{test} / {key}: classified cycles {observed} != the pinned record {want} (tests/golden/waived_cycles.json; its _meta entry "
+                              f"names the toolchain the record was made on and how to regenerate it for review)")
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "f32", "bf16x6"])
