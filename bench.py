@@ -80,7 +80,7 @@ PREC_DTYPE = {"f32": "f32 (fp32 operands on the fp32 MFMA)",
               "bf16x6": "f32-class (bf16 hi+mid+lo split operands = 24 significand bits, six products, fp32 accumulate)",
               "bf16x3": "bf16x3 (bf16 hi+lo split operands, fp32 accumulate)", "bf16": "bf16"}
 PREC_PASSES = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "bf16": 1}
-PREC_KERNEL = {"f32": "k_pair (fp32 MFMA)", "bf16x6": "k_pair_t<*,6>", "bf16x3": "k_pair_t<*,3>", "bf16": "k_pair_t<*,1>"}
+PREC_KERNEL = {"f32": "k_pair (fp32 MFMA)", "bf16x6": "k_pair_t6", "bf16x3": "k_pair_t<*,3>", "bf16": "k_pair_t<*,1>"}
 PREC_NOTE = {"f32": "v_mfma_f32_16x16x4_f32 (fp32 MFMA = the fp32 vector rate)",
              "bf16x6": "operands split into bf16 hi + mid + lo (exact: 24 significand bits), the 6 products >= 2^-24 per term on "
                        "v_mfma_f32_16x16x32_bf16, fp32 accumulate: peak = dense bf16 peak / 6 passes",

@@ -63,7 +63,8 @@ __device__ __forceinline__ void split3_group(const f32x4 &v0, const f32x4 &v1, u
 // ABL: timing-only ablation switches of tools/micro/pair6_bench.hip (results are wrong with any bit set; the library instantiates 0)
 //   1 lo weight fragments re-read from LDS (the mid ones) instead of streamed from L2 | 2 no operand splits | 4 no query loads | 8 no T loads
 //   16 no sum_p_mem | 32 no attention at all | 64 no second GEMM | 128 phase timers (printed by workgroup 0) | 256 no first GEMM | 512 no LayerNorms
-//   1024 no edge store | 2048 no edge loads
+//   1024 no edge store | 2048 no edge loads | 4096 every other GEMM step re-uses the previous step's weight fragments (half the LDS and L2 fragment traffic:
+//   what a 32-pair tile would pay per pair)
 #ifdef MIND_PAIR_ABL
 #define P6_ABL(bit) ((ABL & (bit)) != 0)
 #define P6_TIME(i) do { if (P6_ABL(128)) { const long long n_ = clock64(); pt_[i] += n_ - pt_t; pt_t = n_; } } while (0)
@@ -118,7 +119,7 @@ __device__ __forceinline__ void gemm6(frag8 &acc, const u32 *wa, __amdgpu_buffer
 #pragma unroll
     for (int k = 0; k < NOB; ++k) acc[o0 + k] = MFMA_BF(al[cur][k], bh, acc[o0 + k]);
     SCHED_FENCE();
-    if (st + RING < NST) {
+    if (st + RING < NST && !(P6_ABL(4096) && ((st + RING) & 2))) {
 #pragma unroll
       for (int k = 0; k < NOB; ++k) al[cur][k] = P6_WL((P6_O(st + RING) + k) * 4 + P6_G(st + RING));
     }
@@ -127,7 +128,7 @@ __device__ __forceinline__ void gemm6(frag8 &acc, const u32 *wa, __amdgpu_buffer
 #pragma unroll
     for (int k = 0; k < NOB; ++k) acc[o0 + k] = MFMA_BF(am[k], bh, acc[o0 + k]);
     SCHED_FENCE();
-    if (st + 1 < NST) {
+    if (st + 1 < NST && !(P6_ABL(4096) && ((st + 1) & 1))) {
 #pragma unroll
       for (int k = 0; k < NOB; ++k) am[k] = *(const u32x4 *)(wl + 8192 + ((P6_O(st + 1) + k) * 4 + P6_G(st + 1)) * 256);
     }
@@ -138,7 +139,7 @@ __device__ __forceinline__ void gemm6(frag8 &acc, const u32 *wa, __amdgpu_buffer
 #pragma unroll
     for (int k = 0; k < NOB; ++k) acc[o0 + k] = MFMA_BF(ah[k], bh, acc[o0 + k]);
     SCHED_FENCE();
-    if (st + 1 < NST) {
+    if (st + 1 < NST && !(P6_ABL(4096) && ((st + 1) & 1))) {
 #pragma unroll
       for (int k = 0; k < NOB; ++k) ah[k] = *(const u32x4 *)(wl + ((P6_O(st + 1) + k) * 4 + P6_G(st + 1)) * 256);
     }

@@ -103,6 +103,9 @@ int main(int argc, char **argv) {
   add6("  - GEMMs only, lo fragments from LDS", k_pair_t6<1, 1 + 2 + 4 + 8 + 32 + 512>);
   add6("  - memory only (no GEMM / LN / split / attention)", k_pair_t6<1, 2 + 32 + 64 + 256 + 512>);
   add6("  - arithmetic only (no loads, no store)", k_pair_t6<1, 4 + 8 + 1024 + 2048>);
+  add6("  * half the weight-fragment traffic (LDS and L2)", k_pair_t6<1, 4096>);
+  add6("  * half the fragment traffic, no T / q loads", k_pair_t6<1, 4096 + 4 + 8>);
+  add6("  * half the fragment traffic, lo from LDS", k_pair_t6<1, 4096 + 1>);
   add6("  - timers", k_pair_t6<1, 128>);
 #endif
   add6("k_pair_t6<0> layer 0", k_pair_t6<0, 0>);
