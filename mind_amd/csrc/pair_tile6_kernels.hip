@@ -39,6 +39,12 @@
 // fragments -- and 8 KB more cost more than the longer prefetch distance buys
 #define P6_RESID_RELOAD 0
 #endif
+// Also measured and dropped (same harness): a second register set for the next tile's chunk, requested behind the first GEMM -- all eight chunks
+// spill inside the tile loop (17 scratch stores + 29 loads per tile), the first two / four chunks alone (8 / 16 registers, 2-3 stores + 2-8 loads per
+// tile) run at 1.53-1.58 / 1.64-1.66 ms against 1.43 on the same box (profiles/r06l_pair6_bench_early_prefetch.txt).  And the bound on what a
+// 32-pair tile in one 512-register wave per SIMD could buy (every weight fragment -- LDS and L2 -- serving two 16-pair tiles): with every other GEMM
+// step re-using the previous step's fragments (timing only, ABL 4096) the launch takes 1.195 against 1.321 ms, -9.5 %, before the loss of the second
+// wave's overlap (profiles/r06k_pair6_bench_half_fragment_traffic.txt): not built.
 #define P6_QK_STRIDE 1536      // dwords of folded query per token: three parts of 512
 
 // one k-group's three B operands from the lane's chunks 2 g and 2 g + 1
