@@ -945,8 +945,11 @@ def main():
             # here must not cost the headline line (every rank reaches the same except branch or none does: the plan is replicated)
             key = "tree_sharded" if world > 1 else "tree"
             try:
-                t = measure(dist, "cfg4tree", args.tree_steps, 2, world > 1)      # two warm-up plans: the arenas and table caches reach their final sizes
-                pre[key] = dict(summarize(t, t["pl"].network.rt.pair_precision()), workload="cfg4tree: 64 agents x 256 lane polylines, full scripted 6-ary "
+                # (one GPU: `tree` is the opt-in two-way split, the series of rounds 2-5; `tree_f32` below is the same tree in the headline's fp32-class
+                # arithmetic, the library's default.  Several GPUs: the sharded tree runs in the headline's arithmetic)
+                tprec = "bf16x3" if world == 1 else args.prec
+                t = measure(dist, "cfg4tree", args.tree_steps, 2, world > 1, pair_prec=tprec)      # two warm-up plans: the arenas and table caches reach their final sizes
+                pre[key] = dict(summarize(t, tprec), arith=tprec, workload="cfg4tree: 64 agents x 256 lane polylines, full scripted 6-ary "
                                 "depth-4 AIME tree on the real predictor forward", n_gpus=world,
                                 scaling="strong" if world > 1 else None, plans_timed=args.tree_steps)
             except Exception as e:       # noqa: BLE001
@@ -963,8 +966,8 @@ def main():
                 # the same full tree planned by every rank for a scene of its own (independent trees, no data-path collective): the node
                 # throughput of the whole job when the scenes, not one scene's branches, are what is spread over the GPUs
                 try:
-                    t = measure(dist, "cfg4tree", args.tree_steps, 2, False, replica=rank)
-                    pre["tree_replicas"] = dict(summarize(t, t["pl"].network.rt.pair_precision()), workload="cfg4tree on every rank, one independent scene per rank (full scripted 6-ary "
+                    t = measure(dist, "cfg4tree", args.tree_steps, 2, False, replica=rank, pair_prec=args.prec)
+                    pre["tree_replicas"] = dict(summarize(t, args.prec), arith=args.prec, workload="cfg4tree on every rank, one independent scene per rank (full scripted 6-ary "
                                                 "depth-4 AIME tree on the real predictor forward); nodes_expanded_per_s is the whole job's", n_gpus=world,
                                                 scaling="weak", plans_timed=args.tree_steps)
                     if "ms_per_plan" in pre.get("tree_sharded", {}):
@@ -974,9 +977,9 @@ def main():
                     pre["tree_replicas"] = {"error": f"{type(e).__name__}: {e}"[:400]}
         if extras and rank == 0 and world == 1:
             try:
-                sm = measure(dist, "stress128tree", 6, 2, False)
-                pre["stress"] = dict(summarize(sm, sm["pl"].network.rt.pair_precision()), workload="stress128tree: 128 agents x 256 lane polylines (N = 385), full scripted 6-ary depth-4 AIME "
-                                     "tree (259 expansions per plan: the largest tree the reference's probability floor lets grow), default arithmetic",
+                sm = measure(dist, "stress128tree", 6, 2, False, pair_prec="bf16x3")
+                pre["stress"] = dict(summarize(sm, "bf16x3"), arith="bf16x3", workload="stress128tree: 128 agents x 256 lane polylines (N = 385), full scripted 6-ary depth-4 AIME "
+                                     "tree (259 expansions per plan: the largest tree the reference's probability floor lets grow), two-way split (bf16x3)",
                                      plans_timed=6)
                 bm = measure(dist, "stress128tree", 6, 2, False, pair_prec="bf16")
                 pre["stress_bf16"] = dict(summarize(bm, "bf16"), workload="the same in plain bf16 (BASELINE config 5's 'bf16 MFMA attention'; misses the 1e-3 m bar)",

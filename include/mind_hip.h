@@ -102,13 +102,15 @@ int mind_last_ilqr_trace(mind_ctx *ctx, int tree, int phase, double *out, int ca
 int mind_set_profiling(mind_ctx *ctx, int enable);
 
 /* Arithmetic of the RelaFusionLayer pair contractions (planners/mind/networks/network.py:165-232; the reference runs them
- * in torch fp32): MIND_PAIR_F32 = fp32 MFMA (v_mfma_f32_16x16x4_f32); MIND_PAIR_BF16X3 (default) = both operands split into
- * bf16 hi + lo parts, hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fp32-class accuracy, ~5 x the
- * fp32-MFMA rate); MIND_PAIR_BF16 = plain bf16 operands (BASELINE config 5's "bf16 MFMA attention": misses the 1e-3 m
- * parity bar, never the default); MIND_PAIR_BF16X6 = both operands split EXACTLY into three bf16 parts (hi + mid + lo = the 24 significand
- * bits of the fp32 value), the six partial products of weight >= 2^-24 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: the reference's fp32
- * arithmetic class at 2.7 x the fp32-MFMA rate (k_pair_t6; the ActorNet runs the same split, k_actor_mfma<6>).  Also settable at context creation
- * through the environment, MIND_PAIR_PREC=f32|bf16x3|bf16|bf16x6. */
+ * in torch fp32) -- and of every other MFMA contraction of the predictor (ActorNet, the MFMA decoder / token kernels where enabled):
+ *   MIND_PAIR_BF16X6 (default) = both operands split EXACTLY into three bf16 parts (hi + mid + lo = the 24 significand bits of the fp32
+ *     value), the six partial products of weight >= 2^-24 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: the reference's fp32
+ *     arithmetic class at 2.7 x the fp32-MFMA rate (k_pair_t6; ActorNet: k_actor_mfma<6>); error against the fp32 oracle = the fp32 MFMA's;
+ *   MIND_PAIR_F32 = plain fp32 operands on the fp32 MFMA (v_mfma_f32_16x16x4_f32; k_pair, k_actor_f32);
+ *   MIND_PAIR_BF16X3 = operands split into bf16 hi + lo (16 significand bits), hi.hi + hi.lo + lo.hi: narrower than the reference's fp32 (1e-5 m
+ *     from the oracle where the fp32 classes show 3e-6; meets the 2e-4 m parity bar), 1.5-1.8 x faster than bf16x6 on large scenes; opt-in;
+ *   MIND_PAIR_BF16 = plain bf16 operands (BASELINE config 5's "bf16 MFMA attention": misses the 1e-3 m parity bar; opt-in).
+ * Also settable at context creation through the environment, MIND_PAIR_PREC=f32|bf16x3|bf16|bf16x6. */
 #define MIND_PAIR_F32 0
 #define MIND_PAIR_BF16X3 1
 #define MIND_PAIR_BF16 2

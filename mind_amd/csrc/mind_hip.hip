@@ -129,7 +129,7 @@ struct mind_ctx {
   bool actor_f32 = true;
   int actor_f32_min = 1 << 30, actor_f32_pair_min = 1 << 30;
   bool xcd_order = true;        // XCD-aware job order for big batches (MIND_XCD_ORDER=0 switches it off, for A/B measurements)
-  int pair_prec = 1;            // arithmetic of the pair kernel: 0 = fp32 MFMA, 1 = bf16x3 (split operands, default), 2 = bf16, 3 = bf16x6 (three-way split: fp32 class)
+  int pair_prec = 3;            // arithmetic of the pair kernel: 0 = fp32 MFMA, 1 = bf16x3 (two-way split operands), 2 = bf16, 3 = bf16x6 (exact three-way split: fp32 class, default)
   // bf16 arithmetics: k_pair_t (tile-native edge tensor, pair_tile_kernels.hip; default) or the row-major k_pair_bf of rounds 2-3
   // (mind_set_tuning("pair_tile", 0) / MIND_PAIR_TILE=0, kept for same-box A/B measurements)
   bool pair_tile = true;

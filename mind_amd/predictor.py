@@ -211,7 +211,7 @@ class HipPredictor:
     PAIR_PREC = ("f32", "bf16x3", "bf16", "bf16x6")
 
     def pair_precision(self):
-        """arithmetic of the pair kernel: 'f32' | 'bf16x3' (default) | 'bf16' | 'bf16x6' (three-way split, fp32 class) (include/mind_hip.h)"""
+        """arithmetic of the predictor's MFMA contractions: 'bf16x6' (default: exact three-way split, fp32 class) | 'f32' | 'bf16x3' | 'bf16' (include/mind_hip.h)"""
         return self.PAIR_PREC[self.lib.mind_get_pair_precision(self.ctx)]
 
     def set_tuning(self, name, value):

@@ -72,17 +72,30 @@ def test_native_plan_equals_the_round_by_round_path(scene):
 @pytest.mark.parametrize("scene", ["demo_1", "demo_2", "demo_4"])
 def test_device_built_root_equals_the_host_featuriser(scene):
     """process_data / prepare_root_data as kernels (k_aime_rebase on the raw windows, k_aime_root_lanes, k_aime_root_hist) against
-    the host featuriser feeding the same native plan: the same float32 / float64 expressions, so every discrete result (node ids,
-    CUR_T / END_T, flags, chosen tree) must be equal and the arrays agree to float32 rounding of the ~6 km map coordinates."""
+    the host featuriser feeding the same native plan: the same float32 / float64 expressions, so every discrete result of the
+    AIME tree (node ids, CUR_T / END_T, flags) must be equal and the arrays agree to float32 rounding of the ~6 km map coordinates; the chosen
+    tree is equal too except where a candidate's tree-iLQR fit is ill-conditioned under that rounding noise (probed, at most one cycle in ten)."""
     sys.path.insert(0, ROOT)
     from bench import BRANCHING_WEIGHTS, WORKLOADS, make_closed_loop
-    sims = []
+    from mind_amd.planners.mind.trajectory_tree import flatten_scenario_tree, ilqr_cfg_from
+    from test_gpu_plan import _solution_moves_under_rounding_noise
+    sims, caps = [], []
     for dev_root in (True, False):
         pl, sim, w = make_closed_loop(dict(WORKLOADS[scene]), ckpt=BRANCHING_WEIGHTS, speculative=False)
         pl.scen_tree_gen.device_root = dev_root
         sims.append((pl, sim))
+        cap, opt = {}, pl.traj_tree_opt
+
+        def capture(scen_trees, init_state, init_ctrl, target_lane, target_vel, cap=cap, opt=opt, orig=opt.solve_batch):
+            trees = orig(scen_trees, init_state, init_ctrl, target_lane, target_vel)     # what the contingency solves were given
+            cap["common"] = (ilqr_cfg_from(opt.config, "w_opt_cfg"), ilqr_cfg_from(opt.config, "opt_cfg"),
+                             opt._get_init_state(init_state, init_ctrl), np.asarray(target_lane, np.float64), target_vel)
+            cap["scen_trees"], cap["xs"] = scen_trees, [t._arrays[0][1:] for t in trees]
+            return trees
+        opt.solve_batch = capture
+        caps.append(cap)
     ulp = float(np.spacing(np.float32(np.abs(sims[0][1].world.pos[0, 0]).max())))
-    worst = 0.0
+    worst, ill = 0.0, []
     for cycle in range(10):
         res = []
         for pl, sim in sims:
@@ -94,7 +107,19 @@ def test_device_built_root_equals_the_host_featuriser(scene):
             res.append((internal, _flat(gen.get_scenario_tree()), np.array(sim.ctrl), pl.timing["best_traj_idx"]))
         (ia, fa, ca, ba), (ib, fb, cb, bb) = res
         assert ia == ib, (cycle, ia, ib)
-        assert len(fa) == len(fb) and ba == bb
+        assert len(fa) == len(fb)
+        if ba != bb:
+            # the two roots differ by float32 rounding of the inputs: another chosen tree is admissible only where the fit of the candidate
+            # the two runs price differently is ill-conditioned under exactly that noise (the probe of tests/test_gpu_plan.py)
+            ka, kb = np.array(sims[0][0].timing["tree_costs"]), np.array(sims[1][0].timing["tree_costs"])
+            j = int(np.argmax(np.abs(ka - kb)))
+            cw, cf, x0, lane, tv = caps[0]["common"]
+            moved = _solution_moves_under_rounding_noise(sims[0][0].network.rt.ilqr_contingency,
+                                                         (cw, cf, [flatten_scenario_tree(caps[0]["scen_trees"][j])], x0, lane, tv), caps[0]["xs"][j])
+            print(f"{scene} cycle {cycle}: chosen tree {ba} (device root) / {bb} (host root); costs {ka} / {kb}; candidate {j}'s own solution "
+                  f"moves by {moved:.2e} m under rounding noise")
+            assert moved > 1e-3 + 2 * ulp, (cycle, ba, bb, ka, kb, moved)
+            ill.append(cycle)
         for x, y in zip(fa, fb):
             assert x[0] == y[0] and x[1] == y[1]
             assert abs(float(np.ravel(x[2])[0]) - float(np.ravel(y[2])[0])) < 1e-4
@@ -102,7 +127,7 @@ def test_device_built_root_equals_the_host_featuriser(scene):
             assert np.abs(x[3] - y[3]).max() < 2e-3 + 4 * ulp and np.abs(x[4] - y[4]).max() < 1e-3 and np.array_equal(x[5], y[5]), (cycle, x[0])
         sims[1][1].state, sims[1][1].ctrl = sims[0][1].state.copy(), np.array(sims[0][1].ctrl).copy()      # keep the two loops on one trajectory
     print(f"{scene}: device-built vs host-built root, max |agent position difference| over 10 cycles = {worst:.2e} m (float32 ulp there {ulp:.1e})")
-    assert sims[0][0].scen_tree_gen.n_native_plans == 10
+    assert sims[0][0].scen_tree_gen.n_native_plans == 10 and len(ill) <= 1, ill
 
 
 def test_lazy_scenario_tree_read_after_the_next_plan_is_still_its_own_plans():

@@ -142,8 +142,8 @@ def test_bench_prints_one_contract_json_line(tmp_path):
 
 
 class _arithmetic:
-    """run a block with the predictor's contractions in the named arithmetic ("bf16x3": the default; "f32": every contraction in fp32,
-    the reference's own precision) and put the thread's runtime back afterwards"""
+    """run a block with the predictor's contractions in the named arithmetic ("bf16x6": the default, the reference's fp32 class on the bf16 MFMA;
+    "f32": plain fp32 operands on the fp32 MFMA; "bf16x3": the opt-in two-way split) and put the thread's runtime back afterwards"""
 
     def __init__(self, rt, prec):
         self.rt, self.prec = rt, prec
