@@ -136,9 +136,11 @@ def make_planner(wkw, scripted=True):
     return pl, lcl, w
 
 
-def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True, ckpt=None, own_context=False):
+def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True, ckpt=None, own_context=False, native=False):
     """planner + closed-loop simulator advanced to the enable time (t = 4.0 s: 40 observation updates).
-    ckpt: override of the planner config's ckpt_path (e.g. "formula_branching:20240121", mind_amd/weights.py)."""
+    ckpt: override of the planner config's ckpt_path (e.g. "formula_branching:20240121", mind_amd/weights.py).
+    native: ClosedLoopSim's argument -- False = the Python steps (tests that hook into the planner's pieces), None = the native loop
+    (one C call per planning cycle, mind_amd/native_loop.py) where it applies: the throughput runs below."""
     from mind_amd.closed_loop import ClosedLoopSim
     from mind_amd.planners.mind.planner import MINDPlanner
     from mind_amd.synth import ScriptedBranching, ScriptedDeepTree, ScriptedDeeperTree, ScriptedFullTree, SynthWorld
@@ -171,7 +173,7 @@ def make_closed_loop(wkw, scripted=True, full_tree=False, speculative=True, ckpt
     pl.traj_tree_opt.speculative = speculative and pl.traj_tree_opt.speculative      # MIND_SPECULATIVE_WARM_START=0 switches it off
     # episodes: the reference's 60 cycles for a recording; 24 for the synthetic worlds (all eight seeds the weak-scaling
     # and concurrent modes use stay on their lane that long; the default 3 + 20 cycles fit in one episode)
-    sim = ClosedLoopSim(w, pl, episode_plans=60 if "scene" in wkw else 24)
+    sim = ClosedLoopSim(w, pl, episode_plans=60 if "scene" in wkw else 24, native=native)
     sim.run_until(sim.enable_time)
     return pl, sim, w
 
@@ -219,7 +221,8 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None, pair_pre
     wkw = scene_workload(workload, replica)
     if ckpt is None and "scene" in wkw:
         ckpt = BRANCHING_WEIGHTS
-    pl, sim, w = make_closed_loop(wkw, full_tree=DEEP.get(workload, workload in FULL_TREE), ckpt=ckpt)
+    pl, sim, w = make_closed_loop(wkw, full_tree=DEEP.get(workload, workload in FULL_TREE), ckpt=ckpt,
+                                  native=None if (os.environ.get("MIND_NATIVE_LOOP", "1") != "0" and not (shard and dist.world > 1)) else False)
     sh = None
     if shard and dist.world > 1:
         sh = pl.enable_sharding()
@@ -291,6 +294,10 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None, pair_pre
     ctr0 = dict(pl.traj_tree_opt.counters)
     tsum0 = dict(pl.timing_sum)
     coll0 = (sh.n_collectives, sh.bytes_gathered) if sh is not None else (0, 0)
+    # the native loop (mind_amd/native_loop.py: the whole cycle behind one C call) never comes back to the hooks above: the library sums the
+    # same HIP-event durations itself (mind_loop_totals); differences over the timed region are taken below
+    nl = getattr(sim, "_native_now", lambda: None)()
+    tot0 = nl.totals() if nl is not None else None
     dist.barrier()
     t0 = time.perf_counter()
     n0 = pl.scen_tree_gen.n_expanded
@@ -302,6 +309,19 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None, pair_pre
     rt.aime_plan = orig_plan
     pl.traj_tree_opt.solve_batch = orig_solve
     rt.set_profiling(False)
+    n_agents_now = len(pl.agent_obs)
+    if nl is not None and sim._native is nl:
+        t1 = nl.totals()
+        df = lambda k: t1[k] - tot0[k]
+        acc["ms"] += df("pair_ms"); acc["launches"] += df("pair_launches"); acc["calls"] += df("rounds"); acc["n2"] += df("scene_n2")
+        acc["fold"] += (4 * PAIR_FULL + PAIR_ATT) * df("scene_n2") + (PAIR_UPD + PAIR_ATT) * df("scene_n_a1")        # = sum of fold_flops(N, a + 1) over the expanded scenes
+        acc["bytes"] += 512.0 * (8 * df("scene_n2") + 2 * df("scene_n_a1"))                                            # = sum of edge_bytes(N, a + 1)
+        il["ms"] += df("ilqr_ms"); il["launches"] += df("ilqr_launches"); il["trees"] += df("ilqr_trees"); il["wgs"] = t1["ilqr_workgroups_per_tree"] or il["wgs"]
+        keys = ("nodes", "depth", "passes", "derivatives", "backward", "state_chain", "cost_pass", "selection", "trees")
+        for kk, v1, v0 in zip(keys, t1["ilqr_prof"], tot0["ilqr_prof"]):
+            il["prof"][kk] = il["prof"].get(kk, 0.0) + (v1 - v0)
+        il["prof"]["node_steps"] = il["prof"].get("node_steps", 0.0) + df("ilqr_node_steps")
+        n_agents_now = nl.out.n_agents
     if pair_prec is not None:
         rt.set_pair_precision(prec_before)
     for k, v in (tuning or {}).items():
@@ -312,7 +332,7 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None, pair_pre
     brk = {"aime": (pl.timing_sum["aime_s"] - tsum0["aime_s"]) / npl * 1e3, "ilqr": (pl.timing_sum["ilqr_s"] - tsum0["ilqr_s"]) / npl * 1e3,
            "note": "host wall time per plan, mean over the timed plans: AIME rounds (predictor + glue) | tree-iLQR (solve_batch)"}
     return dict(pl=pl, sim=sim, w=w, dt=dt, breakdown_ms=brk, ilqr_kernel=il, sim_steps=sim_steps, expansions=expansions, expansions_all=dist.reduce(expansions),
-                pair=acc, ilqr=ctr, a=len(pl.agent_obs), l=int(pl.scen_tree_gen.n_lanes or pl.scen_tree_gen.lane_feat_in.shape[0]), steps=steps, weights=ckpt or PLAIN_WEIGHTS,
+                pair=acc, ilqr=ctr, a=n_agents_now, native_loop=nl is not None and sim._native is nl, l=int(pl.scen_tree_gen.n_lanes or pl.scen_tree_gen.lane_feat_in.shape[0]), steps=steps, weights=ckpt or PLAIN_WEIGHTS,
                 collectives=(sh.n_collectives - coll0[0], sh.bytes_gathered - coll0[1]) if sh is not None else None,
                 real_scene="scene" in wkw, sharded=sh is not None)
 
@@ -1063,6 +1083,9 @@ def main():
             out["roofline"]["traffic"] = tb
             out["roofline"]["traffic_detail"] = det
         if not args.no_cpu_baseline:
+            if getattr(sim, "_native", None) is not None:
+                sim._native.hand_back()          # (the oracle's sample is a plan's scenario trees and observation windows: back to Python objects,
+                sim.run_plans(1)                 #  one cycle of the Python steps builds them)
             lcl = sim._observation()
             out["cpu_baseline"] = cpu_baseline(pl, lcl, (a, l), max(int(round(exp_plan)), 1), pl.scen_tree_gen.get_scenario_tree())
     if rank == 0:

@@ -463,6 +463,110 @@ int mind_eval_traj_trees(const double *states, const double *ctrls, const int32_
                          int lane_is_f32, int n_lane_pts, double target_vel, double *out);
 
 /* ------------------------------------------------------------------------------------------------
+ * The closed loop of one scene behind ONE call per simulator step (or per planning cycle): Simulator.run_sim (simulator.py:51-107),
+ * CustomizedAgent.check_enable / check_trigger / step (agent.py:255-299), MINDAgent.observe / plan (agent.py:317-331), MINDPlanner.
+ * update_observation / plan (planner.py:50-145), kine_propagate (common/kinematics.py:22-36).  A step = take-over check -> planner
+ * trigger (every plan_step seconds) -> observation fan-out into the 50-frame windows of every track seen so far (unobserved tracks
+ * repeat their last state with observed = false) -> when the agent is enabled: get_agent_trajectories (kept tracks, AV first) ->
+ * mind_aime_plan with the device-built root and the plan-begun contingency solves -> mind_ilqr_finish_plan -> evaluate_traj_tree of
+ * every candidate -> the reference's strict `<` scan -> first control -> ego plant.  Everything the interpreter did between the two
+ * device waits of a cycle happens here; mind_amd/closed_loop.py ClosedLoopSim.step calls it once and reads the plan's objects only
+ * when somebody asks for them (mind_loop_last_plan).  Exo agents are replayed from tables the caller tabulated once (one row per
+ * simulator step, built with the driver's own observation code, so the windows hold the same float64 values).
+ * Host arithmetic is float64 in the reference's operation order; sin / cos / tan are the C library's (the Python driver uses
+ * math.sin / math.cos / math.tan for the same expressions).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mind_loop mind_loop;
+typedef struct {
+  /* replayed scene, one row per simulator step n (sim_time = n additions of sim_step): tables are copied */
+  int n_tracks;                 /* tracks of the world, track 0 = the closed-loop agent ("AV")                                  */
+  int n_steps;                  /* rows of the tables below                                                                     */
+  int clamp_last;               /* != 0: steps >= n_steps read row n_steps - 1 (a recording that holds its last frame)          */
+  const double *ego_state;      /* [n_steps][4] world.agent_state(0, t_n) = (x, y, v, yaw): observation before the take-over and    */
+                                /*   the state taken over at enable_time                                                        */
+  int ego_state_is_f32;         /* world.agent_state returns float32 arrays (the reference's loader keeps tracks in float32,       */
+                                /*   loader.py:166-168): numpy then evaluates the FIRST plant step after the take-over in float32   */
+                                /*   (Python floats are weak operands, the state array is float64 from the second step on)          */
+  const double *ego_obs;        /* [n_steps][5] ObjectState of the RECORDED ego at step n (x, y, heading, vx, vy), as the driver's     */
+                                /*   to_object_state builds it: the ego's window entry before the take-over and at the take-over step  */
+  const float *ego_trig32;      /* [n_steps][2] numpy's float32 cos / sin of the recorded yaw (the first plant step after a take-over  */
+                                /*   from a float32 recording uses them); may be NULL when ego_state_is_f32 == 0                      */
+  /* numpy's elementary functions where they are not the C library's: on AVX-512 hosts np.tan (float64) is a SIMD routine that differs
+   * from libm's by an ulp in 0.5 % of the arguments, and the reference's plant (kinematics.py:22-36) calls np.tan.  NULL = the C library's
+   * tan / sin / cos.  tan_fn is called once per control (the steer angle is constant between two plans), sincos_fn once per step. */
+  double (*tan_fn)(double);
+  void (*sincos_fn)(double, double *sin_cos);
+  const double *exo_obs;        /* [n_steps][n_tracks][5] ObjectState of track i at step n: x, y, heading, vx, vy (row 0 unused)    */
+  const uint8_t *exo_valid;     /* [n_steps][n_tracks] the track is reported at step n (simulator.py:60-63)                       */
+  const int32_t *timestep;      /* [n_steps] ObjectState.timestep = int(round(t_n / 0.1))                                        */
+  const int32_t *type_slot;     /* [n_tracks] one-hot slot of the track's object type (utils.py:245-342)                          */
+  /* simulator + ego plant (simulator.py:51-107, agent.py:255-299, kinematics.py:22-36) */
+  double sim_step, plan_step, enable_time;
+  double wheelbase, max_speed, max_steer, max_acc, max_dec;
+  /* planner constants of the scene (planner.py:147-171, scenario_tree.py:106-126): as mind_aime_plan_in with the device-built root */
+  int n_lanes; const double *lane_pts; const int32_t *lane_flags;      /* [l,11,2], [l,6]                                       */
+  int n_lane_pts; const float *target_lane, *target_lane_info;         /* resampled target lane [P,2], info [P,12]               */
+  double time_ahead; float min_vel, dist_thres; int max_depth, max_rounds, pred_len; float prob_floor;
+  /* contingency solves (planner.py:174-178) and candidate evaluation (planner.py:180-198) */
+  const mind_ilqr_cfg *cfg_warm, *cfg_full;
+  int solve_n_lane_pts; const double *solve_lane;                      /* gt_tgt_lane [P',2] float64                              */
+  double target_vel;
+  int eval_n_lane_pts, eval_lane_is_f32; const void *eval_lane;        /* lcl_smp.target_lane [P'',2] in its own dtype            */
+} mind_loop_desc;
+
+/* running totals over every plan of the loop since it was created (a caller's accounting takes differences) */
+typedef struct {
+  long long plans, expansions, scen_trees, rounds;
+  double aime_s, ilqr_s, total_s;   /* host wall time: the AIME call | collecting the solves | the whole planning cycle                */
+  long long iterations, node_iterations, node_iterations_exo;      /* warm + full fits (TrajectoryTreeOptimizer.counters)              */
+  /* with profiling on (mind_set_profiling): kernel durations from HIP events on the context stream, as mind_aime_plan_out.pair_ms /
+   * mind_last_ilqr_stats / mind_last_ilqr_profile report them per call */
+  double pair_ms; long long pair_launches;
+  double scene_n2, scene_n_a1;      /* sums over the expanded scenes of N^2 and N (a + 1), N = a + l + 1 tokens (algorithmic FLOPs / bytes) */
+  double ilqr_ms; long long ilqr_launches, ilqr_trees; int ilqr_workgroups_per_tree;
+  double ilqr_prof[9], ilqr_node_steps;
+} mind_loop_totals;
+
+typedef struct {
+  int planned;                  /* the call computed at least one plan                                                          */
+  int enabled;
+  long long n_steps, n_plans;   /* since the loop was created (resets do not clear them)                                        */
+  long long episode_steps;      /* simulator steps of the current episode (= table row of the next step)                          */
+  double sim_time, last_trigger;    /* last_trigger < 0: none yet                                                               */
+  double state[4], ctrl[2];     /* ego plant state (x, y, v, yaw) and the control in force                                      */
+  /* the last plan */
+  int n_agents, n_trees, best, n_expanded, n_rounds, n_traj_nodes;
+  const double *costs;          /* [n_trees] library-owned, valid until the loop's next plan                                    */
+  double aime_s, ilqr_s, total_s;
+  mind_loop_totals tot;
+} mind_loop_out;
+
+/* the loop runs on `ctx` (weights loaded; not sharded); one loop per context at a time plans */
+int mind_loop_create(mind_ctx *ctx, const mind_loop_desc *desc, mind_loop **out);
+int mind_loop_destroy(mind_loop *loop);
+/* ClosedLoopSim._start_episode: scene back to t = 0, windows cleared, agent disabled (n_steps / n_plans keep counting) */
+int mind_loop_reset(mind_loop *loop);
+/* Steps until `until_plans` more plans were computed (> 0), or sim_time >= until_time - 1e-9 (until_time >= 0: ClosedLoopSim.run_until),
+ * or `max_steps` steps were taken -- whichever comes first; until_plans = 0, until_time < 0, max_steps = 1 is ClosedLoopSim.step.
+ * MIND_ESTATE "unsupported: ..." = a plan only the round-by-round host path handles (see mind_aime_plan): the step's observation update has
+ * happened, the plan and the rest of the step have not; the caller takes the loop over (mind_loop_export) and finishes the step on the host. */
+int mind_loop_advance(mind_loop *loop, int until_plans, double until_time, long long max_steps, mind_loop_out *out);
+/* the state of the loop without stepping */
+int mind_loop_state(mind_loop *loop, mind_loop_out *out);
+/* The last plan's tables for a caller that builds the reference's objects from them (scenario trees, trajectory trees): *plan as
+ * mind_aime_plan returned it, the solves' results concatenated in tree order (xs [n_traj_nodes,6], us [n_traj_nodes,2], statistics
+ * [n_trees]), the tracks of the plan's agents (index into the world's tracks, AV first) and their TRAJS_TYPE [a,50,7] float32.
+ * Library-owned, valid until the next plan on the loop's context; MIND_ESTATE when another plan ran on the context since (a context may be
+ * shared by several planners). */
+int mind_loop_last_plan(mind_loop *loop, mind_aime_plan_out *plan, const double **xs, const double **us, const mind_ilqr_stats **stats_warm,
+                        const mind_ilqr_stats **stats_full, const int32_t **agent_tracks, const float **types, double *x0);
+/* Hands the loop over to a host driver (ClosedLoopSim falls back to its Python steps: a planner attribute changed under it, a plan the
+ * library reports unsupported): the tracks seen so far in first-appearance order (track 0 first), their window lengths and rows
+ * [n][50][7] = (observed, x, y, heading, vx, vy, timestep), oldest first, the first `count` rows of every window used.  cap = tracks the
+ * arrays hold; the number of tracks comes back in *n (MIND_EINVAL with *n set when cap is too small). */
+int mind_loop_export(mind_loop *loop, int cap, int *n, int32_t *track, int32_t *count, double *rows);
+
+/* ------------------------------------------------------------------------------------------------
  * planners/ilqr call surface (iLQR.fit over a TreeCost of arbitrary PotentialField / StatePotential /
  * StateConstraint / ControlPotential objects; solver.py:80-167, cost.py:326-446, potential.py:62-264).
  * The grid is what PotentialField.__init__ receives: field_offset, resolution, xx[0,:], yy[:,0].

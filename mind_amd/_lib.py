@@ -106,11 +106,47 @@ class IlqrStats(C.Structure):
     _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("J", C.c_double), ("mu", C.c_double)]
 
 
+LOOP_TAN_FN = C.CFUNCTYPE(C.c_double, C.c_double)                       # mind_loop_desc.tan_fn / .sincos_fn
+LOOP_SINCOS_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double))
+
+
+class LoopDesc(C.Structure):       # mind_loop_desc (include/mind_hip.h)
+    _fields_ = [("n_tracks", C.c_int), ("n_steps", C.c_int), ("clamp_last", C.c_int), ("ego_state", C.c_void_p), ("ego_state_is_f32", C.c_int), ("ego_obs", C.c_void_p), ("ego_trig32", C.c_void_p),
+                ("tan_fn", C.c_void_p), ("sincos_fn", C.c_void_p), ("exo_obs", C.c_void_p),
+                ("exo_valid", C.c_void_p), ("timestep", C.c_void_p), ("type_slot", C.c_void_p),
+                ("sim_step", C.c_double), ("plan_step", C.c_double), ("enable_time", C.c_double),
+                ("wheelbase", C.c_double), ("max_speed", C.c_double), ("max_steer", C.c_double), ("max_acc", C.c_double), ("max_dec", C.c_double),
+                ("n_lanes", C.c_int), ("lane_pts", C.c_void_p), ("lane_flags", C.c_void_p),
+                ("n_lane_pts", C.c_int), ("target_lane", C.c_void_p), ("target_lane_info", C.c_void_p),
+                ("time_ahead", C.c_double), ("min_vel", C.c_float), ("dist_thres", C.c_float), ("max_depth", C.c_int), ("max_rounds", C.c_int),
+                ("pred_len", C.c_int), ("prob_floor", C.c_float),
+                ("cfg_warm", C.c_void_p), ("cfg_full", C.c_void_p), ("solve_n_lane_pts", C.c_int), ("solve_lane", C.c_void_p), ("target_vel", C.c_double),
+                ("eval_n_lane_pts", C.c_int), ("eval_lane_is_f32", C.c_int), ("eval_lane", C.c_void_p)]
+
+
+class LoopTotals(C.Structure):     # mind_loop_totals
+    _fields_ = [("plans", C.c_longlong), ("expansions", C.c_longlong), ("scen_trees", C.c_longlong), ("rounds", C.c_longlong),
+                ("aime_s", C.c_double), ("ilqr_s", C.c_double), ("total_s", C.c_double),
+                ("iterations", C.c_longlong), ("node_iterations", C.c_longlong), ("node_iterations_exo", C.c_longlong),
+                ("pair_ms", C.c_double), ("pair_launches", C.c_longlong), ("scene_n2", C.c_double), ("scene_n_a1", C.c_double),
+                ("ilqr_ms", C.c_double), ("ilqr_launches", C.c_longlong), ("ilqr_trees", C.c_longlong), ("ilqr_workgroups_per_tree", C.c_int),
+                ("ilqr_prof", C.c_double * 9), ("ilqr_node_steps", C.c_double)]
+
+
+class LoopOut(C.Structure):        # mind_loop_out
+    _fields_ = [("planned", C.c_int), ("enabled", C.c_int), ("n_steps", C.c_longlong), ("n_plans", C.c_longlong), ("episode_steps", C.c_longlong),
+                ("sim_time", C.c_double), ("last_trigger", C.c_double), ("state", C.c_double * 4), ("ctrl", C.c_double * 2),
+                ("n_agents", C.c_int), ("n_trees", C.c_int), ("best", C.c_int), ("n_expanded", C.c_int), ("n_rounds", C.c_int), ("n_traj_nodes", C.c_int),
+                ("costs", C.POINTER(C.c_double)), ("aime_s", C.c_double), ("ilqr_s", C.c_double), ("total_s", C.c_double),
+                ("tot", LoopTotals)]
+
+
 EXPORTS = ["mind_ctx_create", "mind_ctx_destroy", "mind_last_error_string", "mind_ctx_synchronize",
            "mind_weights_load", "mind_predict_batch", "mind_last_fusion_stats", "mind_set_profiling",
            "mind_ilqr_solve_trees", "mind_ilqr_contingency", "mind_ilqr_solve_fields", "mind_cost_eval", "mind_lane_dist_field", "mind_aime_world", "mind_aime_rebase", "mind_debug_set_layers",
            "mind_debug_read", "mind_set_pair_precision", "mind_get_pair_precision", "mind_debug_pack_bfrag", "mind_debug_pack_conv_frag", "mind_debug_pair_schedule", "mind_set_tuning", "mind_last_ilqr_stats", "mind_aime_plan", "mind_last_ilqr_profile", "mind_eval_traj_trees", "mind_last_ilqr_trace", "mind_ilqr_contingency_begin", "mind_ilqr_finish", "mind_fill_tracks", "mind_ilqr_contingency_begin_plan", "mind_debug_trig", "mind_aime_plan_begin", "mind_aime_plan_poll", "mind_aime_plan_finish", "mind_ctx_busy", "mind_ilqr_finish_plan",
-           "mind_set_exchange", "mind_last_exchange_stats"]
+           "mind_set_exchange", "mind_last_exchange_stats",
+           "mind_loop_create", "mind_loop_destroy", "mind_loop_reset", "mind_loop_advance", "mind_loop_state", "mind_loop_last_plan", "mind_loop_export"]
 
 # transport of the sharded mind_aime_plan (include/mind_hip.h): int fn(void *user, int op, void *send, void *recv, int64 bytes)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
@@ -183,6 +219,13 @@ def load():
     lib.mind_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64]
     lib.mind_set_exchange.argtypes = [C.c_void_p, C.c_int, C.c_int, EXCHANGE_FN, C.c_void_p, C.c_int]
     lib.mind_last_exchange_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    lib.mind_loop_create.argtypes = [C.c_void_p, C.POINTER(LoopDesc), C.POINTER(C.c_void_p)]
+    lib.mind_loop_destroy.argtypes = [C.c_void_p]
+    lib.mind_loop_reset.argtypes = [C.c_void_p]
+    lib.mind_loop_advance.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_longlong, C.POINTER(LoopOut)]
+    lib.mind_loop_state.argtypes = [C.c_void_p, C.POINTER(LoopOut)]
+    lib.mind_loop_last_plan.argtypes = [C.c_void_p, C.POINTER(AimePlanOut)] + [C.POINTER(C.c_void_p)] * 6 + [C.c_void_p]
+    lib.mind_loop_export.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p]
     for n in EXPORTS:
         getattr(lib, n)
         if n not in ("mind_last_error_string", "mind_debug_read"):

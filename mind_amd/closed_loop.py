@@ -31,8 +31,11 @@ class ClosedLoopSim:
     PLAN_STEP = 1.0 / 10 - 1e-4
     WB, MAX_SPD, MAX_STR = 3.0, 15.0, np.deg2rad(45.0)
 
-    def __init__(self, world, planner, enable_time=None, episode_plans=None):
+    def __init__(self, world, planner, enable_time=None, episode_plans=None, native=None):
+        """native: None = use the native loop (mind_amd/native_loop.py: one C call per step / planning cycle) when it applies to this
+        planner and world, False = the Python steps below, True = raise when it does not apply"""
         self.world = world
+        self._native, self._last_result = None, None
         self.planner = planner
         self.enable_time = enable_time if enable_time is not None else getattr(world, "enable_time", 4.0)
         self.n_steps = 0
@@ -55,6 +58,35 @@ class ClosedLoopSim:
             except AttributeError:
                 pass
         self._start_episode()
+        if native is not False:
+            from .native_loop import NativeLoop
+            why = NativeLoop.why_not(self)
+            if why is None:
+                try:
+                    self._native = NativeLoop(self)
+                except ValueError as e:          # (a scene the native plan does not take: no lanes, a short target lane)
+                    why = str(e)
+            if why is not None and native:
+                raise RuntimeError("ClosedLoopSim(native=True): " + why)
+        self.native_reason = None if self._native is not None else "native=False" if native is False else why
+
+    @property
+    def last_result(self):
+        """[[scenario tree], [trajectory tree]] of the last plan; under the native loop the objects are built when this is read"""
+        nl = self._native
+        return nl.last_result() if nl is not None else self._last_result
+
+    @last_result.setter
+    def last_result(self, v):
+        self._last_result = v
+
+    def _native_now(self):
+        """the native loop if it still applies (a planner attribute may have changed under it: then the loop is handed back to the steps below)"""
+        nl = self._native
+        if nl is not None and not nl.ok():
+            nl.hand_back()
+            nl = None
+        return nl
 
     def _start_episode(self):
         self.sim_time = 0.0
@@ -68,6 +100,10 @@ class ClosedLoopSim:
         self._episode_plan0 = self.n_plans
         if hasattr(self.planner, "agent_obs"):
             self.planner.agent_obs.clear()
+        nl = getattr(self, "_native", None)
+        if nl is not None:
+            nl.lib.mind_loop_reset(nl.h)
+            nl._result = None
 
     def reset(self):
         """Start the next episode: scene back to t = 0, observation history rebuilt up to the enable time (these
@@ -111,6 +147,8 @@ class ClosedLoopSim:
     def step_begin(self):
         """First half of a simulator step: take-over check, observation fan-out, planner trigger.  Returns the local
         semantic map if a plan is due in this step (the caller plans and passes the result to step_end), else None."""
+        if self._native is not None:       # a driver that steps in halves (pipelined.py, fused.py) runs the Python steps: the loop is handed back
+            self._native.hand_back()
         if self.sim_time >= self.enable_time and not self.enabled:
             self.enabled = True                                  # check_enable: take over from the recording
             self.state = self.world.agent_state(0, self.sim_time)
@@ -140,10 +178,18 @@ class ClosedLoopSim:
 
     def step(self):
         """One simulator step (0.02 s).  Returns True if a plan was computed in this step."""
+        nl = self._native_now()
+        if nl is not None:
+            return nl.advance(0, -1.0, 1) > 0
         lcl = self.step_begin()
         return self.step_end(self.planner.plan(lcl) if lcl is not None else None)
 
     def run_until(self, t_end):
+        nl = self._native_now()
+        if nl is not None:
+            nl.advance(0, float(t_end), 1 << 40)
+            if self._native is nl:
+                return
         while self.sim_time < t_end - 1e-9:
             self.step()
 
@@ -162,5 +208,12 @@ class ClosedLoopSim:
                 s_keep = self.n_steps - s0
                 self.reset()
                 s0 = self.n_steps - s_keep
-            self.step()
+            nl = self._native_now()
+            if nl is not None:         # up to the end of the episode in one call
+                want = n - (self.n_plans - p0)
+                if self.episode_plans is not None:
+                    want = min(want, self.episode_plans - (self.n_plans - self._episode_plan0))
+                nl.advance(want, -1.0, 1 << 40)
+            else:
+                self.step()
         return self.n_steps - s0

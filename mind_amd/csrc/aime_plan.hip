@@ -130,6 +130,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = c->stream;
   c->pl_plan_agents = 0; c->pl_tree_top.clear();      // (the previous plan's cost trees are gone whatever happens below)
+  c->pl_gen += 1;
   if (!c->ev_pl) HIPCHK(c, hipEventCreateWithFlags(&c->ev_pl, hipEventDisableTiming));
   if (!c->ev_tab) HIPCHK(c, hipEventCreateWithFlags(&c->ev_tab, hipEventDisableTiming));
   if (!c->pl_copy) HIPCHK(c, hipStreamCreateWithFlags(&c->pl_copy, hipStreamNonBlocking));

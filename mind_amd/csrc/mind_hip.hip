@@ -174,6 +174,7 @@ struct mind_ctx {
   const float *pl_rows_p = nullptr, *pl_fmean_p = nullptr, *pl_fcov_p = nullptr;      // into page-locked slot 2, valid until the next plan
   std::vector<int32_t> pl_tree_top, pl_tree_off, pl_flat_parent;
   int pl_plan_agents = 0;       // agents per scene of the plan those tables belong to
+  long long pl_gen = 0;         // plans begun on this context so far: whoever holds a plan's library-owned tables (mind_loop) checks they are still that plan's
   DevBuf pl_flat;
   bool dec_overlap = true;      // actor_proj of the decoder on the side stream beside k_dec_scene (mind_set_tuning("dec_overlap"))
   int rb_cur = 0, rb_gen = 0;     // re-basing arenas: which one the last call filled, its generation and geometry
@@ -2458,3 +2459,6 @@ extern "C" int64_t mind_debug_read(mind_ctx *c, const char *name, float *host, i
   if (hipMemcpy(host, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return MIND_EHIP;
   return n;
 }
+
+// ---- the closed loop of one scene behind one call per step (host code: the interpreter's share of a planning cycle)
+#include "loop.hip"

@@ -371,7 +371,8 @@ class MINDPlanner:
         """evaluate_traj_tree for all candidate trees of a plan in one set of array ops (the per-tree sums are taken
         over each tree's own node range); falls back to the per-tree function for trees without solver arrays."""
         packs = [getattr(t, "_arrays", None) for t in traj_trees]
-        if len(traj_trees) < 2 or any(p is None or len(p[0]) != t.size() for p, t in zip(packs, traj_trees)):
+        # (a single candidate takes the same path: its cost decides nothing, and the native loop -- csrc/loop.hip -- prices every plan this way)
+        if len(traj_trees) < 1 or any(p is None or len(p[0]) != t.size() for p, t in zip(packs, traj_trees)):
             return [self.evaluate_traj_tree(lcl_smp, t) for t in traj_trees]
         st = np.concatenate([p[0] for p in packs])
         ct = np.concatenate([p[1] for p in packs])

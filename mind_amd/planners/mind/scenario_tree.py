@@ -328,7 +328,7 @@ class ScenarioTreeGenerator:
         with (host_context() if host_context is not None else contextlib.nullcontext()):
             return self._branch_aime_host(lcl_smp, agent_obs)
 
-    def _native_trees(self, res, root, on_flats):
+    def _native_trees(self, res, root, on_flats, count=True):
         if res is None:
             return None
         nodes, rows, info = res
@@ -361,9 +361,10 @@ class ScenarioTreeGenerator:
                 keys.append(key)
 
         self.tree = LazyTree(build_aime_tree, root="root")
-        self.n_expanded += info["n_expanded"]
-        self.branch_depth = info["n_rounds"]
-        self.n_native_plans += 1
+        if count:           # (count=False: the native loop -- mind_amd/native_loop.py -- counted the plan when it ran and builds its objects later)
+            self.n_expanded += info["n_expanded"]
+            self.branch_depth = info["n_rounds"]
+            self.n_native_plans += 1
         # The scenario trees handed to the contingency planner: the library flattened them already (TrajectoryTreeOptimizer.solve_batch
         # takes `_flat` instead of walking the nodes), in get_scenario_tree's order; their Python nodes -- tens of thousands on the deep
         # stress trees, a third of such a plan's wall time -- are built by the reference walk below only when somebody reads them.
