@@ -222,7 +222,7 @@ def measure(dist, workload, steps, warmup, shard, replica=0, ckpt=None, pair_pre
     if ckpt is None and "scene" in wkw:
         ckpt = BRANCHING_WEIGHTS
     pl, sim, w = make_closed_loop(wkw, full_tree=DEEP.get(workload, workload in FULL_TREE), ckpt=ckpt,
-                                  native=None if (os.environ.get("MIND_NATIVE_LOOP", "1") != "0" and not (shard and dist.world > 1)) else False)
+                                  native=NATIVE_LOOP if not (shard and dist.world > 1) else False)
     sh = None
     if shard and dist.world > 1:
         sh = pl.enable_sharding()
@@ -545,10 +545,17 @@ def recorded_scenes(prec, plans=20, warmup=3):
 
 
 # ---- concurrent scenes on one GPU (BASELINE config 3) ---------------------------------------------------------------------
+NATIVE_LOOP = None if os.environ.get("MIND_NATIVE_LOOP", "1") != "0" else False      # ClosedLoopSim(native=...) of the single-loop throughput runs
+# Several scenes on one GPU keep the Python steps unless MIND_CONCURRENT_NATIVE=1: measured on one box (profiles/r06q_config3_native*.txt) four
+# processes with the speculative warm start (a second context per planner, Python steps only) reach 7.5 k sim steps/s against 5.1 k for four
+# native loops, and sixteen scenes are bound by the device, not by the interpreter (two processes of event loops 9.5 k, native threads 8.0 k)
+CONCURRENT_NATIVE = None if os.environ.get("MIND_CONCURRENT_NATIVE", "0") == "1" else False
+
+
 def _proc_scene(i, workload, steps, warmup, ready, go, q, speculative, ckpt=None):
     """One scene in its own process (own HIP context): signals ready, waits for the common start, reports back."""
     import torch as th
-    pl, sim, w = make_closed_loop(scene_workload(workload, i), full_tree=workload in FULL_TREE, speculative=speculative, ckpt=ckpt)
+    pl, sim, w = make_closed_loop(scene_workload(workload, i), full_tree=workload in FULL_TREE, speculative=speculative, ckpt=ckpt, native=CONCURRENT_NATIVE)
     sim.run_plans(max(warmup, 1))
     th.cuda.synchronize()
     ready.wait()
@@ -564,6 +571,8 @@ def _proc_group(g, scene_ids, workload, steps, warmup, ready, go, q, ckpt=None):
     and stream per scene).  Signals ready, waits for the common start, reports back."""
     import torch as th
     from mind_amd.pipelined import PipelinedClosedLoops
+    if CONCURRENT_NATIVE is None:
+        return _proc_group_native_threads(g, scene_ids, workload, steps, warmup, ready, go, q, ckpt)
     th.cuda.set_stream(th.cuda.Stream())
     loops = [make_closed_loop(scene_workload(workload, i), scripted="scene" not in scene_workload(workload, i), speculative=False, ckpt=ckpt,
                               own_context=True) for i in scene_ids]
@@ -576,6 +585,47 @@ def _proc_group(g, scene_ids, workload, steps, warmup, ready, go, q, ckpt=None):
     n = pc.run_plans(steps)
     th.cuda.synchronize()
     q.put((g, n, t0, time.time(), sum(l[0].scen_tree_gen.n_expanded for l in loops)))
+
+
+def _proc_group_native_threads(g, scene_ids, workload, steps, warmup, ready, go, q, ckpt=None):
+    """A group of scenes in one process, one host thread per scene, every thread inside ONE native call for its whole run (mind_loop_advance: the
+    interpreter lock is released, a HIP context + stream per thread): the host work of a cycle is a few tens of microseconds of C per scene."""
+    import threading
+    import torch as th
+    n = len(scene_ids)
+    sims, done, errs = [None] * n, [0] * n, []
+    t_ready, t_go = threading.Barrier(n + 1), threading.Barrier(n + 1)
+
+    def worker(k):
+        try:
+            with th.cuda.stream(th.cuda.Stream()):
+                pl, sim, w = make_closed_loop(scene_workload(workload, scene_ids[k]), scripted="scene" not in scene_workload(workload, scene_ids[k]),
+                                              speculative=False, ckpt=ckpt, native=CONCURRENT_NATIVE)
+                sim.run_plans(max(warmup, 1))
+                th.cuda.current_stream().synchronize()
+                sims[k] = (pl, sim)
+                t_ready.wait()
+                t_go.wait()
+                done[k] = sim.run_plans(steps)
+                th.cuda.current_stream().synchronize()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+            for b in (t_ready, t_go):
+                b.abort()
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(n)]
+    for t in ths:
+        t.start()
+    t_ready.wait()
+    ready.wait()
+    go.wait()
+    t0 = time.time()
+    t_go.wait()
+    for t in ths:
+        t.join()
+    if errs:
+        raise errs[0]
+    q.put((g, sum(done), t0, time.time(), sum(s[0].scen_tree_gen.n_expanded for s in sims)))
 
 
 def run_concurrent_groups(args):
@@ -647,7 +697,9 @@ def run_concurrent(args):
     def worker(i):
         try:
             with torch.cuda.stream(torch.cuda.Stream()):
-                pl, sim, w = make_closed_loop(scene_workload(args.workload, i), full_tree=args.workload in FULL_TREE, speculative=P <= 4, ckpt=args.ckpt)
+                # (the native loop -- one C call for the thread's whole run, the interpreter lock released -- where it applies: recorded scenes)
+                pl, sim, w = make_closed_loop(scene_workload(args.workload, i), full_tree=args.workload in FULL_TREE, speculative=P <= 4, ckpt=args.ckpt,
+                                              native=CONCURRENT_NATIVE)
                 sim.run_plans(max(args.warmup, 1))
                 torch.cuda.current_stream().synchronize()
                 loops[i] = (pl, sim)
