@@ -422,7 +422,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees):
+def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees, trees_per_plan=None):
     """The oracle (CPU restatement, kind 'port') on this host: one predictor forward of the same scene size at
     1 / 8 / 16 / 32 / 64 threads (best kept, 1-thread figure quoted) + the contingency solves of this plan's
     scenario trees (plain C, 1 thread), timed on a bounded sample."""
@@ -460,14 +460,16 @@ def cpu_baseline(pl, lcl, n_scene_tokens, expansions, scen_trees):
         oi.contingency(cfg, nodes, pl.state, pl.ctrl, pl.gt_tgt_lane, lcl.target_velocity)
         n_tree += 1
     t_ilqr = (time.perf_counter() - t0) / max(n_tree, 1)
-    plan_s = expansions * t_pred + len(scen_trees) * t_ilqr
-    plan_1 = expansions * per_threads[1] + len(scen_trees) * t_ilqr
+    # a plan of the timed run holds `trees_per_plan` scenario trees on average (the sampled plan is one cycle of it)
+    n_solves = trees_per_plan if trees_per_plan else len(scen_trees)
+    plan_s = expansions * t_pred + n_solves * t_ilqr
+    plan_1 = expansions * per_threads[1] + n_solves * t_ilqr
     return {"value": 5.0 / plan_s, "unit": "sim steps/s", "cores": best_nt, "kind": "port", "cpu": cpu_model(), "hardware_threads": ncpu,
             "value_1_thread": 5.0 / plan_1,
             "predictor_ms_by_threads": {str(k): v * 1e3 for k, v in per_threads.items()},
             "sample": f"1 oracle predictor forward (a={a}, l={l}, torch-CPU fp32; best {t_pred*1e3:.0f} ms at {best_nt} threads of {sorted(per_threads)}, "
                       f"{per_threads[1]*1e3:.0f} ms at 1) + {n_tree} oracle C tree-iLQR contingency solves ({t_ilqr*1e3:.0f} ms each, 1 thread); "
-                      f"plan = {expansions} expansions + {len(scen_trees)} solves",
+                      f"plan = {expansions} expansions + {n_solves:.3g} solves (the timed run's mean)",
             "plan_ms": plan_s * 1e3}
 
 
@@ -1139,7 +1141,8 @@ def main():
                 sim._native.hand_back()          # (the oracle's sample is a plan's scenario trees and observation windows: back to Python objects,
                 sim.run_plans(1)                 #  one cycle of the Python steps builds them)
             lcl = sim._observation()
-            out["cpu_baseline"] = cpu_baseline(pl, lcl, (a, l), max(int(round(exp_plan)), 1), pl.scen_tree_gen.get_scenario_tree())
+            out["cpu_baseline"] = cpu_baseline(pl, lcl, (a, l), max(int(round(exp_plan)), 1), pl.scen_tree_gen.get_scenario_tree(),
+                                               trees_per_plan=m["ilqr"].get("solves", 0) / 2.0 / max(m["steps"], 1))
     if rank == 0:
         print(contract_line(out, args))
     dist.close()
