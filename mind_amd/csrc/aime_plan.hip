@@ -795,6 +795,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     if (!solves_tried) begin_solves();
     out->solves_begun = solves_rc == MIND_OK ? 1 : 0;      // (a failed begin is not the plan's failure: the caller then solves the usual way)
   }
+  TR("end: result handed out");
   return MIND_OK;
 }
 

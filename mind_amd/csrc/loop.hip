@@ -56,6 +56,7 @@ struct mind_loop {
   mind_aime_plan_out po;
   bool have_plan = false, half_step = false;
   long long plan_gen = -1;          // mind_ctx::pl_gen of the loop's last plan
+  std::chrono::steady_clock::time_point t_plan_end;
   double plan_x0[6];
   int last_agents = 0, best = -1;
   double aime_s = 0, ilqr_s = 0, total_s = 0;
@@ -186,6 +187,13 @@ int loop_plan(mind_loop *L) {
   mind_ctx *c = L->c;
   const mind_loop_desc &d = L->d;
   const auto t0 = std::chrono::steady_clock::now();
+  // MIND_LOOP_TRACE=1: host time stamps of the cycle's sections on stderr (diagnostic, as MIND_PLAN_TRACE inside the plan)
+  static const bool loop_trace = getenv("MIND_LOOP_TRACE") != nullptr;
+  auto TRL = [&](const char *what) {
+    if (loop_trace) fprintf(stderr, "[loop] %8.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what);
+  };
+  if (loop_trace && L->have_plan) fprintf(stderr, "[loop] %8.1f us since the last plan's end (evaluation excluded: steps, observation)\n",
+                                          std::chrono::duration<double, std::micro>(t0 - L->t_plan_end).count());
   // ---- get_agent_trajectories (utils.py:245-342): AV first, tracks whose last state is unobserved are dropped, windows left-padded
   L->kept.clear(); L->slots.clear();
   for (size_t s = 0; s < L->obs.size(); ++s) {
@@ -205,6 +213,7 @@ int loop_plan(mind_loop *L) {
   L->i_typ.resize((size_t)a * T * 7); L->i_have.resize((size_t)a * T);
   int rc = mind_fill_tracks(L->raw.data(), a, T, L->slots.data(), L->f_pos.data(), L->f_ang.data(), L->f_vel.data(), L->i_typ.data(), L->i_have.data());
   if (rc) return fail(c, rc, "mind_loop: mind_fill_tracks failed");
+  TRL("tracks filled");
   L->f_pad.resize((size_t)a * T); L->f_types.resize((size_t)a * T * 7);
   for (size_t i = 0; i < L->f_pad.size(); ++i) L->f_pad[i] = (float)L->i_have[i];
   for (size_t i = 0; i < L->f_types.size(); ++i) L->f_types[i] = (float)L->i_typ[i];
@@ -225,9 +234,11 @@ int loop_plan(mind_loop *L) {
   pi.solve_cfg_warm = &L->cfg_warm; pi.solve_cfg_full = &L->cfg_full;
   pi.solve_x0 = x0; pi.solve_lane = L->solve_lane.data(); pi.solve_n_lane_pts = d.solve_n_lane_pts; pi.solve_target_vel = d.target_vel;
   L->have_plan = false;
+  TRL("plan call begins");
   rc = mind_aime_plan(c, &pi, &L->po);
   if (rc) return rc;
   const auto t1 = std::chrono::steady_clock::now();
+  TRL("plan returned (solves begun)");
   const int nt = L->po.n_trees;
   if (nt <= 0) return fail(c, MIND_ESTATE, "mind_loop: the plan returned no scenario tree");
   if (!L->po.solves_begun) return fail(c, MIND_ESTATE, "mind_loop: the plan could not begin its contingency solves (%s)", c->err.c_str());
@@ -235,6 +246,7 @@ int loop_plan(mind_loop *L) {
   if (!c->il_finish || !c->il_finish_owned) return fail(c, MIND_ESTATE, "mind_loop: no plan-begun tree-iLQR call is pending");
   if ((rc = mind_ilqr_finish(c))) return rc;
   const auto t2 = std::chrono::steady_clock::now();
+  TRL("solves collected");
   const int32_t *off = L->po.tree_off;
   const int M = off[nt];
   if ((size_t)M * 6 != c->pl_sol_xs.size() || (size_t)nt != c->pl_sol_stf.size()) return fail(c, MIND_ESTATE, "mind_loop: the solves' results do not fit the plan");
@@ -285,6 +297,8 @@ int loop_plan(mind_loop *L) {
     }
   }
   const auto t3 = std::chrono::steady_clock::now();
+  TRL("evaluated, control chosen");
+  L->t_plan_end = t3;
   L->aime_s = std::chrono::duration<double>(t1 - t0).count();
   L->ilqr_s = std::chrono::duration<double>(t2 - t1).count();
   L->total_s = std::chrono::duration<double>(t3 - t0).count();

@@ -2283,26 +2283,70 @@ double np_pairwise(const double *a, long n) {
 }
 template <class T>
 void eval_nodes(const double *st, const double *ct, long N, const T *lane, int P, double tv, double *per_node) {
-  std::vector<T> dx(P - 1), dy(P - 1), l2(P - 1);
-  for (int q = 0; q < P - 1; ++q) {
+  const int S = P - 1;
+  std::vector<T> dx(S), dy(S), l2(S);
+  for (int q = 0; q < S; ++q) {
     dx[q] = lane[2 * q + 2] - lane[2 * q];
     dy[q] = lane[2 * q + 3] - lane[2 * q + 1];
     l2[q] = dx[q] * dx[q] + dy[q] * dy[q];                      // in the lane's own dtype, as numpy computes it
   }
+  // Only the MINIMUM over the segments is used, so a segment that provably cannot hold it is not priced: segments are grouped in blocks of
+  // eight with a bounding circle (centre, radius inflated by 1e-9 relative + 1e-9 m: far above any rounding of the distances involved), and a
+  // block -- then a segment, by its own circle -- is skipped when |p - centre| > sqrt(current minimum) + radius.  Every segment that could
+  // equal or undercut the running minimum is evaluated with numpy's expression, so the result is the same bits; a trajectory's
+  // nodes follow the lane, so the scan starts at the block that held the previous node's minimum.
+  constexpr int BS = 8;
+  const int NB = (S + BS - 1) / BS;
+  std::vector<double> sx_(S), sy_(S), sr_(S), bx(NB), by(NB), br(NB);
+  for (int q = 0; q < S; ++q) {
+    const double ax = (double)lane[2 * q], ay = (double)lane[2 * q + 1], ex = (double)lane[2 * q + 2], ey = (double)lane[2 * q + 3];
+    sx_[q] = 0.5 * (ax + ex); sy_[q] = 0.5 * (ay + ey);
+    sr_[q] = 0.5 * sqrt((ex - ax) * (ex - ax) + (ey - ay) * (ey - ay)) * (1.0 + 1e-9) + 1e-9;
+  }
+  for (int b = 0; b < NB; ++b) {
+    const int q0 = b * BS, q1 = std::min(S, q0 + BS);
+    double cx = 0.0, cy = 0.0;
+    for (int q = q0; q < q1; ++q) { cx += sx_[q]; cy += sy_[q]; }
+    cx /= (double)(q1 - q0); cy /= (double)(q1 - q0);
+    double r = 0.0;
+    for (int q = q0; q < q1; ++q) r = std::max(r, sqrt((sx_[q] - cx) * (sx_[q] - cx) + (sy_[q] - cy) * (sy_[q] - cy)) + sr_[q]);
+    bx[b] = cx; by[b] = cy; br[b] = r * (1.0 + 1e-9) + 1e-9;
+  }
+  int b_prev = 0;
   for (long i = 0; i < N; ++i) {
     const double px = st[6 * i], py = st[6 * i + 1];
     // min over the segments of sqrt(e) = sqrt of the min of e: the correctly rounded square root is monotone, so ONE square root per node
     // gives numpy's bits (np.sqrt per segment, then min) -- the division and the square root share the host's divider unit
-    double emin = INFINITY;
-    for (int q = 0; q < P - 1; ++q) {
-      const double sx = (double)lane[2 * q], sy = (double)lane[2 * q + 1], ddx = (double)dx[q], ddy = (double)dy[q];
-      double t = ((px - sx) * ddx + (py - sy) * ddy) / (double)l2[q];
-      t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
-      const double ex = px - (sx + t * ddx), ey = py - (sy + t * ddy);
-      const double e = ex * ex + ey * ey;
-      emin = e < emin ? e : emin;
+    double emin = INFINITY, rmin = INFINITY;
+    bool saw_nan = false;
+    int b_best = b_prev;
+    auto price_block = [&](int b) {
+      const int q0 = b * BS, q1 = std::min(S, q0 + BS);
+      for (int q = q0; q < q1; ++q) {
+        if (emin < INFINITY) {
+          const double cxq = px - sx_[q], cyq = py - sy_[q], lim = rmin + sr_[q];
+          if (cxq * cxq + cyq * cyq > lim * lim) continue;
+        }
+        const double sx = (double)lane[2 * q], sy = (double)lane[2 * q + 1], ddx = (double)dx[q], ddy = (double)dy[q];
+        double t = ((px - sx) * ddx + (py - sy) * ddy) / (double)l2[q];
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        const double ex = px - (sx + t * ddx), ey = py - (sy + t * ddy);
+        const double e = ex * ex + ey * ey;
+        if (e < emin) { emin = e; rmin = sqrt(e) * (1.0 + 1e-9) + 1e-9; b_best = b; }
+        else if (e != e) saw_nan = true;                            // numpy's min propagates a NaN
+      }
+    };
+    price_block(b_prev);
+    for (int b = 0; b < NB; ++b) {
+      if (b == b_prev) continue;
+      if (emin < INFINITY) {
+        const double cxb = px - bx[b], cyb = py - by[b], lim = rmin + br[b];
+        if (cxb * cxb + cyb * cyb > lim * lim) continue;
+      }
+      price_block(b);
     }
-    const double dmin = sqrt(emin);
+    b_prev = b_best;
+    const double dmin = saw_nan ? (double)NAN : sqrt(emin);
     const double c0 = ct[2 * i], c1 = ct[2 * i + 1], dv = tv - st[6 * i + 2];
     per_node[i] = ((0.1 * (c0 * c0) + 5.0 * (c1 * c1)) + 0.01 * (dv * dv)) + 0.01 * dmin;
   }
