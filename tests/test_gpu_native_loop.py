@@ -159,3 +159,31 @@ def test_native_loop_refuses_what_it_does_not_cover():
     from mind_amd.closed_loop import ClosedLoopSim
     with pytest.raises(RuntimeError, match="native=True"):
         ClosedLoopSim(w, pl, episode_plans=24, native=True)
+
+
+@pytest.mark.parametrize("scene", ["demo_1", "demo_2", "demo_3", "demo_4"])
+def test_native_loop_against_the_references_own_closed_loop(scene):
+    """The reference's simulator loop on its four recorded scenes (tests/golden/demo_plans.npz, captured from the imported reference: trigger
+    steps, AIME branch ids, agent and ego trajectories of the first four planning cycles, final state and control) -- the check of
+    tests/test_gpu_plan.py::test_recorded_demo_scenes_match_reference_closed_loop, driven through mind_loop_advance one simulator step at a time."""
+    sys.path.insert(0, ROOT)
+    from bench import WORKLOADS, make_closed_loop
+    from test_gpu_plan import _closed_loop_against_demo_plans
+    pl, sim, w = make_closed_loop(dict(WORKLOADS[scene]), scripted=False, native=None)
+    assert sim._native is not None, sim.native_reason
+    _closed_loop_against_demo_plans(scene, pl, sim, w)
+
+
+@pytest.mark.parametrize("scene", ["demo_1", "demo_4"])
+def test_native_loop_whole_episode_equals_the_python_steps(scene):
+    """all 60 planning cycles of the reference's episode (t = 4.0 .. 9.9 s): ego state, control, chosen tree and candidate costs after every
+    cycle, the native loop ten cycles per call"""
+    pa, sa = _make(scene, None, episode_plans=60)
+    pb, sb = _make(scene, False, episode_plans=60)
+    for block in range(6):
+        sa.run_plans(10)
+        a = (np.array(sa.state), np.array(sa.ctrl), pa.timing["best_traj_idx"], np.array(pa.timing["tree_costs"]), sa.n_steps, pa.scen_tree_gen.n_expanded)
+        sb.run_plans(10)
+        b = (np.array(sb.state), np.array(sb.ctrl), pb.timing["best_traj_idx"], np.array(pb.timing["tree_costs"]), sb.n_steps, pb.scen_tree_gen.n_expanded)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3]) and a[4:] == b[4:], block
+    assert sa._native is not None and sa.n_plans == 60

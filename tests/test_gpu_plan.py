@@ -231,6 +231,8 @@ def _closed_loop_against_demo_plans(scene, pl, sim, w):
         assert np.abs(us - D[f"{scene}_p{pi}_traj_us"]).max() < 2e-3
     while sim.n_steps < steps[-1] + 1:
         sim.step()
+    if getattr(sim, "_native", None) is not None:       # (the native loop keeps the observation windows in the library: back into planner.agent_obs)
+        sim._native.hand_back()
     assert len(pl.agent_obs) == int(D[scene + "_n_tracked"])
     assert np.abs(np.asarray(sim.ctrl) - D[scene + "_final_ctrl"]).max() < 2e-3
     assert np.abs(sim.state - D[scene + "_final_state"]).max() < tol
