@@ -114,6 +114,134 @@ __device__ __forceinline__ void dense_quads(const float *in, int ldi, int K, con
   }
 }
 
+#ifndef DT
+#define DT 1024   // threads of the latency-bound dense kernels (K-split over thread groups)
+#endif
+// ---- a dense_quads stage spread over the G workgroups of one scene (k_dec_scene_mw): workgroup `wg` owns the output quads
+// [NQ wg / G, NQ (wg + 1) / G) with EVERY K part of them -- the K split (KP, Kc) is the one dense_quads takes in a 1 024-thread workgroup that
+// owns all quads, and an item (K part, quad) is computed by one thread exactly as there, so every output is the same bits.  What changes is
+// the traffic through the CU's L2 port (a stage of 0.8-1.2 MB of weights runs at ~60 % of one port; an eighth of it per CU is latency only).
+// On return the workgroup's range of out[r][o] is valid in LDS.
+template <int R>
+__device__ __forceinline__ void dense_quads_part(const float *in, int ldi, int K, const float *__restrict__ WT, const float *__restrict__ b, int NOUT,
+                                                 float *out, int ldo, float *part, int part_floats, int wg, int G) {
+  const int nthr = blockDim.x;
+  const int NQ = NOUT >> 2;
+  int KP = 1;
+  while (KP * 2 * NQ <= DT && KP * 2 * R * NOUT <= part_floats && KP * 2 <= (K >> 2)) KP *= 2;        // (DT: the one-workgroup kernel's thread count)
+  const int Kc = ((K / 4 + KP - 1) / KP) * 4;
+  const int q_lo = NQ * wg / G, q_hi = NQ * (wg + 1) / G, NQg = q_hi - q_lo;
+  for (int item = threadIdx.x; item < KP * NQg; item += nthr) {
+    const int kp = item / NQg, o = (q_lo + item % NQg) * 4;
+    float acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[r][c] = (KP == 1 && b) ? b[o + c] : 0.f;
+    const int k0 = kp * Kc, k1 = min(K, k0 + Kc);
+    int k = k0;
+    for (; k + DBQ <= k1; k += DBQ) {
+      f32x4 w[DBQ];
+#pragma unroll
+      for (int q = 0; q < DBQ; ++q) w[q] = *(const f32x4 *)(WT + (size_t)(k + q) * NOUT + o);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int q4 = 0; q4 < DBQ / 4; ++q4) {
+          const f32x4 x = *(const f32x4 *)(in + r * ldi + k + 4 * q4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(w[4 * q4 + j][c], x[j], acc[r][c]);
+        }
+        DENSE_ROW_FENCE();
+      }
+    }
+    for (; k < k1; k += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 w = *(const f32x4 *)(WT + (size_t)(k + j) * NOUT + o);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float x = in[r * ldi + k + j];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(w[c], x, acc[r][c]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (KP == 1) out[r * ldo + o + c] = acc[r][c];
+        else part[(kp * R + r) * NOUT + o + c] = acc[r][c];
+      }
+  }
+  if (KP == 1) return;
+  __syncthreads();
+  const int o_lo = q_lo * 4, no = NQg * 4;
+  for (int i = threadIdx.x; i < R * no; i += nthr) {
+    const int r = i / no, oo = o_lo + i % no;
+    float v = b ? b[oo] : 0.f;
+    for (int q = 0; q < KP; ++q) v += part[(q * R + r) * NOUT + oo];
+    out[r * ldo + oo] = v;
+  }
+}
+
+// Barrier over the G workgroups of one scene (bar[0] arrivals, bar[1] generation: the pattern of il_tree_sync, ilqr_kernels.hip).  A workgroup
+// that waits ~seconds for its peers (they can only be missing if the launch is not resident) raises the launch's abort word -- host-visible
+// memory -- and every workgroup leaves at its next barrier: the host reports the failure instead of a hung device.
+#define DEC_SYNC_SPINS (1u << 22)
+__device__ __forceinline__ bool dec_grid_sync(unsigned *bar, int G, unsigned *abort_word) {
+  __shared__ int sh_ab;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int aborted = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == (unsigned)G - 1u) {
+      __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      unsigned spins = 0;
+      while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 0xfffu) == 0u) {
+          if (spins >= DEC_SYNC_SPINS) __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { aborted = 1; break; }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    sh_ab = aborted;
+  }
+  __syncthreads();
+  return sh_ab != 0;
+}
+
+// the stage's rows meet: every workgroup publishes its range of out[R][NOUT] (LDS) in `xb` (global), waits for the others and reads the rest
+template <int R>
+__device__ __forceinline__ bool dec_exchange(float *out, int ldo, int NOUT, int wg, int G, float *xb, unsigned *bar, unsigned *abort_word) {
+  const int NQ = NOUT >> 2;
+  const int o_lo = (NQ * wg / G) * 4, o_hi = (NQ * (wg + 1) / G) * 4, no = o_hi - o_lo;
+  __syncthreads();
+  for (int i = threadIdx.x; i < R * no; i += blockDim.x) { const int r = i / no, oo = o_lo + i % no; xb[r * NOUT + oo] = out[r * ldo + oo]; }
+  if (dec_grid_sync(bar, G, abort_word)) return true;
+  // (all of a thread's loads in flight before its first LDS write: the rows arrive in one L2 round trip instead of one per 1 024 floats)
+  constexpr int NV = (R * 1536 / 4 + DT - 1) / DT;          // f32x4 loads per thread at the widest stage
+  const int n4 = R * NOUT / 4;
+  f32x4 v[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) { const int i = threadIdx.x + q * DT; if (i < n4) v[q] = *(const f32x4 *)(xb + 4 * (size_t)i); }
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int i = threadIdx.x + q * DT;
+    if (i < n4) { const int r = (4 * i) / NOUT, oo = (4 * i) % NOUT; if (oo < o_lo || oo >= o_hi) *(f32x4 *)(out + r * ldo + oo) = v[q]; }
+  }
+  return false;
+}
+
 template <int R>
 __device__ __forceinline__ void dense(const float *in, int ldi, int K, const float *__restrict__ WT,
                                       const float *__restrict__ b, int NOUT, float *out, int ldo,
@@ -653,10 +781,18 @@ __device__ int dec_trn_;
 #else
 #define DEC_MARK() do {} while (0)
 #endif
-__global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*[tokens,128]*/,
-                                                  const int *__restrict__ cls_row /*[B]*/,
-                                                  float *__restrict__ Cout /*[B,6,128]*/,
-                                                  float *__restrict__ cls_out /*[B,6]*/, DecW W) {
+// MW (k_dec_scene_mw): G workgroups per scene.  Every workgroup runs the whole decoder -- the small stages redundantly, which costs no time --
+// except the five stages that stream 0.8-1.2 MB of weights through one CU's L2 port (ctx_proj's second layer, the two feed-forward layers of
+// both encoder layers: 57 % of the one-workgroup kernel's time at ~60 % of the port's rate): there a workgroup computes its eighth of the
+// outputs (dense_quads_part: the same K split and per-item arithmetic, the same bits) and the rows meet through global memory and a
+// barrier of the scene's workgroups (dec_exchange; two alternating buffers: a workgroup can be at most one stage ahead of the slowest).
+// Block b -> scene 8 (b / 8G) + b % 8, workgroup (b % 8G) / 8: a scene's workgroups share an XCD (one L2), as in k_ilqr.
+template <bool MW>
+__device__ __forceinline__ void k_dec_scene_body(const float *__restrict__ x /*[tokens,128]*/,
+                                                 const int *__restrict__ cls_row /*[B]*/,
+                                                 float *__restrict__ Cout /*[B,6,128]*/,
+                                                 float *__restrict__ cls_out /*[B,6]*/, const DecW &W, int b, int wg, int G,
+                                                 float *xbuf, unsigned *bar, unsigned *abort_word) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   float (*v0)[256] = (float (*)[256])(dsm);
   float (*v1)[768] = (float (*)[768])(dsm + 256);
@@ -669,7 +805,8 @@ __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*
   float *part = dsm + 14992;
   const int PF = DEC_SCENE_PART;
   const int tid = threadIdx.x;
-  const int b = blockIdx.x;
+  int xstage = 0;                           // big stages so far (MW): selects the exchange buffer
+  float *xb0 = xbuf, *xb1 = xbuf + 6 * 1536;
 #ifdef MIND_DEC_TRACE
   if (blockIdx.x == 0 && tid == 0) dec_trn_ = 0;
 #endif
@@ -683,7 +820,11 @@ __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*
   ln_rows(&v1[0][0], 768, 1, 384, W.c0g, W.c0be, true);
   DEC_MARK();
   __syncthreads();
-  dense<1>(&v1[0][0], 768, 384, W.c3W, W.c3b, 768, &ff[0][0], 1536, part, PF);
+  if (MW) {
+    dense_quads_part<1>(&v1[0][0], 768, 384, W.c3W, W.c3b, 768, &ff[0][0], 1536, part, PF, wg, G);
+    if (dec_exchange<1>(&ff[0][0], 1536, 768, wg, G, (xstage++ & 1) ? xb1 : xb0, bar, abort_word)) return;
+  } else
+    dense<1>(&v1[0][0], 768, 384, W.c3W, W.c3b, 768, &ff[0][0], 1536, part, PF);
   DEC_MARK();
   __syncthreads();
   ln_rows(&ff[0][0], 1536, 1, 768, W.c3g, W.c3be, true);
@@ -727,12 +868,20 @@ __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*
     ln_rows(&C[0][0], 128, 6, 128, W.n1g[L], W.n1b[L], false);
   DEC_MARK();
     __syncthreads();
-    dense<6>(&C[0][0], 128, 128, W.l1W[L], W.l1b[L], 1536, &ff[0][0], 1536, part, PF);
+    if (MW) {
+      dense_quads_part<6>(&C[0][0], 128, 128, W.l1W[L], W.l1b[L], 1536, &ff[0][0], 1536, part, PF, wg, G);
+      if (dec_exchange<6>(&ff[0][0], 1536, 1536, wg, G, (xstage++ & 1) ? xb1 : xb0, bar, abort_word)) return;
+    } else
+      dense<6>(&C[0][0], 128, 128, W.l1W[L], W.l1b[L], 1536, &ff[0][0], 1536, part, PF);
   DEC_MARK();
     __syncthreads();
     for (int i = tid; i < 6 * 1536; i += blockDim.x) ff[i / 1536][i % 1536] = fmaxf(ff[i / 1536][i % 1536], 0.f);
     __syncthreads();
-    dense<6>(&ff[0][0], 1536, 1536, W.l2W[L], W.l2b[L], 128, &t2[0][0], 128, part, PF);
+    if (MW) {
+      dense_quads_part<6>(&ff[0][0], 1536, 1536, W.l2W[L], W.l2b[L], 128, &t2[0][0], 128, part, PF, wg, G);
+      if (dec_exchange<6>(&t2[0][0], 128, 128, wg, G, (xstage++ & 1) ? xb1 : xb0, bar, abort_word)) return;
+    } else
+      dense<6>(&ff[0][0], 1536, 1536, W.l2W[L], W.l2b[L], 128, &t2[0][0], 128, part, PF);
   DEC_MARK();
     __syncthreads();
     for (int i = tid; i < 768; i += blockDim.x) C[i / 128][i % 128] += t2[i / 128][i % 128];
@@ -741,7 +890,8 @@ __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*
   DEC_MARK();
     __syncthreads();
   }
-  for (int i = tid; i < 768; i += blockDim.x) Cout[(size_t)b * 768 + i] = C[i / 128][i % 128];
+  if (!MW || wg == 0)
+    for (int i = tid; i < 768; i += blockDim.x) Cout[(size_t)b * 768 + i] = C[i / 128][i % 128];
   // ---- cls head on the mode tokens only (network.py:512, Q6), softmax over the 6 modes
   dense<6>(&C[0][0], 128, 128, W.k0W, W.k0b, 128, &att[0][0], 128, part, PF);
   DEC_MARK();
@@ -762,7 +912,7 @@ __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*
     if (lane == 0) sc[0][0][k] = s + W.k6b[0];
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0 && (!MW || wg == 0)) {
     float m = -INFINITY;
     for (int k = 0; k < 6; ++k) m = fmaxf(m, sc[0][0][k]);
     float e[6], sum = 0.f;
@@ -777,6 +927,21 @@ __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x /*
     printf("\n");
   }
 #endif
+}
+
+__global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x, const int *__restrict__ cls_row, float *__restrict__ Cout,
+                                                  float *__restrict__ cls_out, DecW W) {
+  k_dec_scene_body<false>(x, cls_row, Cout, cls_out, W, (int)blockIdx.x, 0, 1, nullptr, nullptr, nullptr);
+}
+#define DEC_MW_G 8
+// xbuf [B][2][6 x 1536] floats, bars [B][4] words (zero once, at allocation: the barrier resets itself), abort_word host-visible
+__global__ __launch_bounds__(DT) void k_dec_scene_mw(const float *__restrict__ x, const int *__restrict__ cls_row, float *__restrict__ Cout,
+                                                     float *__restrict__ cls_out, DecW W, int n_scenes, float *__restrict__ xbuf,
+                                                     unsigned *__restrict__ bars, unsigned *abort_word) {
+  const int r = (int)blockIdx.x % (8 * DEC_MW_G);
+  const int b = 8 * ((int)blockIdx.x / (8 * DEC_MW_G)) + (r & 7), wg = r >> 3;
+  if (b >= n_scenes) return;
+  k_dec_scene_body<true>(x, cls_row, Cout, cls_out, W, b, wg, DEC_MW_G, xbuf + (size_t)b * 2 * 6 * 1536, bars + 4 * (size_t)b, abort_word);
 }
 
 // =================================================================================================

@@ -177,6 +177,14 @@ struct mind_ctx {
   long long pl_gen = 0;         // plans begun on this context so far: whoever holds a plan's library-owned tables (mind_loop) checks they are still that plan's
   DevBuf pl_flat;
   bool dec_overlap = true;      // actor_proj of the decoder on the side stream beside k_dec_scene (mind_set_tuning("dec_overlap"))
+  // k_dec_scene_mw: eight workgroups per scene on the decoder's five big stages (bit-identical to the one-workgroup kernel), possible whenever
+  // every workgroup of the launch is resident, i.e. for calls of at most n_cu / 8 scenes.  Opt-in ("dec_mw" / MIND_DEC_MW=1): measured 88.6
+  // against 94.9 us per demo-size launch (profiles/r06aa_*) -- only ctx_proj's second layer is really bound by one CU's L2 port (30 k -> 20 k
+  // cycles); the feed-forward layers are bound by their 24 accumulators per thread and win 2-4 k cycles each, less the 36 KB exchange --
+  // 12 us per plan, not worth eight spinning workgroups per scene when several scenes share the device
+  bool dec_mw = false;
+  DevBuf dec_xbuf, dec_bars;
+  unsigned *dec_abort = nullptr;      // host-visible abort word of its barriers (page-locked, mapped)
   int rb_cur = 0, rb_gen = 0;     // re-basing arenas: which one the last call filled, its generation and geometry
   size_t rb_S = 0, rb_a = 0;
   // profiling
@@ -316,6 +324,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   (void)hipFuncSetAttribute((const void *)k_ilqr<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
   if (const char *te = getenv("MIND_TOK_MFMA")) c->tok_mfma = !(te[0] == '0');
   if (const char *te = getenv("MIND_TOK_SMALL_MAX")) c->tok_small_max = atoi(te);
+  if (const char *te = getenv("MIND_DEC_MW")) c->dec_mw = !(te[0] == '0');
   if (const char *te = getenv("MIND_TOK_BF_MIN_N")) c->tok_bf_min_n = atoi(te);
   if (const char *te = getenv("MIND_TGT_SIDE")) c->tgt_side = !(te[0] == '0');
   if (const char *te = getenv("MIND_PL_TAB_SIDE")) c->pl_tab_side = !(te[0] == '0');
@@ -326,6 +335,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
   if (const char *we = getenv("MIND_ILQR_SLOTS")) { const int v = atoi(we); c->ilqr_slots = v < 1 ? 1 : (v > IL_SLOTS ? IL_SLOTS : v); }
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_dec_scene_mw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_tgt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_actor<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_actor<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
@@ -347,6 +357,9 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
     for (DevBuf *b : {&t.meta, &t.jobs, &t.jobs5, &t.rows})
       if (b->p) (void)hipFree(b->p);
   if (c->wdev) (void)hipFree(c->wdev);
+  for (DevBuf *b : {&c->dec_xbuf, &c->dec_bars})
+    if (b->p) (void)hipFree(b->p);
+  if (c->dec_abort) (void)hipHostFree(c->dec_abort);
   for (DevBuf *b : {&c->pl_root, &c->pl_in[0], &c->pl_in[1], &c->pl_lf, &c->pl_lrep, &c->pl_pred, &c->pl_small, &c->pl_tab[0], &c->pl_tab[1], &c->pl_win[0],
                     &c->pl_win[1], &c->pl_flat, &c->x_send, &c->x_recv, &c->x_seg})
     if (b->p) (void)hipFree(b->p);
@@ -395,6 +408,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "dec_overlap") c->dec_overlap = value != 0;
   else if (n == "tok_mfma") c->tok_mfma = value != 0;
   else if (n == "tok_small_max") c->tok_small_max = (int)value;
+  else if (n == "dec_mw") c->dec_mw = value != 0;
   else if (n == "tok_bf_min_n") c->tok_bf_min_n = (int)value;
   else if (n == "tgt_side") c->tgt_side = value != 0;
   else if (n == "pl_tab_side") c->pl_tab_side = value != 0;
@@ -1478,7 +1492,30 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
                        (const float *)nullptr, (const float *)nullptr, (float *)nullptr, (float *)nullptr, c->decW, (float *)c->dec_h2.p);
     HIPCHK(c, hipEventRecord(c->ev_side, c->side));
   }
-  hipLaunchKernelGGL(k_dec_scene, dim3(Bn), dim3(DT), mind_dec_scene_lds_bytes(), st, x, d_cls_row, (float *)c->cmode.p, out->cls, c->decW);
+  // the scene part: eight workgroups per scene while the whole launch is resident (one workgroup per CU: 158 KB of LDS), else one per scene --
+  // the two kernels give the same bits, so a scene's result does not depend on the size of its batch
+  const int mw_blocks = ((Bn + 7) / 8) * 8 * DEC_MW_G;
+  bool mw = c->dec_mw && mw_blocks <= c->n_cu;
+  if (mw) {
+    if (c->dec_abort && *(volatile unsigned *)c->dec_abort) return fail(c, MIND_EHIP, "k_dec_scene_mw: a barrier of an earlier launch timed out (launch not resident)");
+    if (!c->dec_abort) {
+      if (hipHostMalloc((void **)&c->dec_abort, 64, hipHostMallocMapped) != hipSuccess) { c->dec_abort = nullptr; mw = false; }
+      else *c->dec_abort = 0u;
+    }
+    const size_t need_x = (size_t)(c->n_cu / DEC_MW_G) * 2 * 6 * 1536 * sizeof(float), need_b = (size_t)(c->n_cu / DEC_MW_G) * 4 * sizeof(unsigned);
+    if (mw && c->dec_xbuf.cap < need_x) {
+      if ((rc = ensure(c, c->dec_xbuf, need_x))) return rc;
+    }
+    if (mw && c->dec_bars.cap < need_b) {
+      if ((rc = ensure(c, c->dec_bars, need_b))) return rc;
+      HIPCHK(c, hipMemsetAsync(c->dec_bars.p, 0, c->dec_bars.cap, st));        // (once: the barrier resets its arrival count itself)
+    }
+  }
+  if (mw)
+    hipLaunchKernelGGL(k_dec_scene_mw, dim3(mw_blocks), dim3(DT), mind_dec_scene_lds_bytes(), st, x, d_cls_row, (float *)c->cmode.p, out->cls, c->decW, Bn,
+                       (float *)c->dec_xbuf.p, (unsigned *)c->dec_bars.p, c->dec_abort);
+  else
+    hipLaunchKernelGGL(k_dec_scene, dim3(Bn), dim3(DT), mind_dec_scene_lds_bytes(), st, x, d_cls_row, (float *)c->cmode.p, out->cls, c->decW);
   if (c->side) HIPCHK(c, hipStreamWaitEvent(st, c->ev_tgt, 0));      // the decoder's actor part reads the target embedding
   // actor part of the decoder: the K-split fp32 kernel (a handful of workgroups, bound by the latency of one pass over the weights:
   // 62 us at 40 agents), or -- opt-in, mind_set_tuning("dec_mfma_min") -- the MFMA kernel (16 agents per workgroup: 104 us at 40

@@ -320,6 +320,23 @@ def test_token_kernel_tokens_per_workgroup_do_not_change_results(a, l, B, seed, 
         assert torch.equal(big[k], small[k]), k
 
 
+def test_decoder_scene_part_on_eight_workgroups_equals_the_one_workgroup_kernel(hip_predictor):
+    """With mind_set_tuning("dec_mw", 1) calls of at most n_cu / 8 scenes run k_dec_scene_mw: eight workgroups per scene share the decoder's
+    five big stages with the K split and per-item arithmetic of the one-workgroup kernel (opt-in: 6 us of a 95 us launch).  Every output
+    must be the same bits: lone scenes, ragged batches, and a batch too big for the resident form (which then takes the one-workgroup
+    kernel by itself)."""
+    for pb in (predictor_batch(40, 55, 1, seed=1), predictor_batch(7, 12, 5, seed=3), predictor_batch(1, 3, 2, seed=5), predictor_batch(3, 5, 32, seed=7),
+               predictor_batch(2, 4, 40, seed=9)):
+        one = {k: v.clone() for k, v in hip_predictor.predict_numpy_batch(pb).items() if torch.is_tensor(v)}
+        try:
+            hip_predictor.set_tuning("dec_mw", 1)
+            mw = {k: v.clone() for k, v in hip_predictor.predict_numpy_batch(pb).items() if torch.is_tensor(v)}
+        finally:
+            hip_predictor.set_tuning("dec_mw", 0)
+        for k in ("cls", "reg", "vel"):
+            assert torch.equal(mw[k], one[k]), k
+
+
 def test_token_kernel_of_big_scenes_on_the_bf16_split_mfma(hip_predictor, formula_sd):
     """With mind_set_tuning("tok_bf_min_n", 256) scenes of >= 256 tokens run their per-token epilogue / prologue on k_token_mfma<1> (bf16
     hi + lo split operands, the pair kernel's arithmetic): against the oracle at the cfg4 scene size, against the VALU kernel it
