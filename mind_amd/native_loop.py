@@ -140,6 +140,7 @@ class NativeLoop:
         rc = self.lib.mind_loop_create(self.rt.ctx, C.byref(d), C.byref(h))
         _lib.check(self.lib, self.rt.ctx, rc, "mind_loop_create")
         self.h = h
+        self._ctx_value = self.rt.ctx.value
         self.out = _lib.LoopOut()
         self._out_ref = C.byref(self.out)
         self._result = None            # the last plan's [[scenario tree], [trajectory tree]] once somebody asked for it
@@ -149,8 +150,8 @@ class NativeLoop:
 
     def close(self):
         h, self.h = getattr(self, "h", None), None
-        if h is not None and getattr(self.rt, "ctx", None) is not None:
-            self.lib.mind_loop_destroy(h)
+        if h is not None:
+            self.lib.mind_loop_destroy(h)         # (host memory only: safe after the context is gone)
 
     def __del__(self):
         try:
@@ -219,7 +220,8 @@ class NativeLoop:
         pl = self.sim.planner
         gen, opt, w = pl.scen_tree_gen, pl.traj_tree_opt, self.sim.world
         cfg = gen.config
-        return (self.h is not None and gen.native_aime and gen.device_root and gen.device_glue and gen.device_select and gen.shard is None
+        ctx = self.rt.ctx         # (a runtime that was closed, or re-created, under the loop: the library's loop holds the old context)
+        return (self.h is not None and ctx is not None and ctx.value == self._ctx_value and gen.native_aime and gen.device_root and gen.device_glue and gen.device_select and gen.shard is None
                 and gen.network is self._net and pl.network is self._net and opt.solver is None and opt.shard is None and opt.overlap
                 and pl.gt_tgt_lane is self._gt_obj and cfg is self._gen_cfg and opt.config is self._opt_cfg and pl._native_eval
                 and (cfg.tar_time_ahead, cfg.tar_dist_thres, cfg.max_depth, gen.pred_len) == self._scen_fp
@@ -279,6 +281,8 @@ class NativeLoop:
             return self._result
         if self.out.n_plans == 0:
             return None
+        if self.rt.ctx is None or self.rt.ctx.value != self._ctx_value:
+            raise _lib.MindError("the runtime of this loop was closed: its last plan can no longer be read")
         from .planners.mind.trajectory_tree import to_traj_tree
         pl = self.sim.planner
         gen, opt, w = pl.scen_tree_gen, pl.traj_tree_opt, self.sim.world
@@ -340,7 +344,8 @@ class NativeLoop:
             pl.agent_obs[tid] = tr
         if sim.enabled:
             pl.update_state_ctrl(sim.state, sim.ctrl)
-        if self._result is None and o.n_plans and getattr(sim, "_last_result", None) is None:
+        ctx = self.rt.ctx
+        if self._result is None and o.n_plans and getattr(sim, "_last_result", None) is None and ctx is not None and ctx.value == self._ctx_value:
             try:
                 self.last_result()
             except _lib.MindError:
