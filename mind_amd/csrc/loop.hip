@@ -58,7 +58,7 @@ struct mind_loop {
   long long plan_gen = -1;          // mind_ctx::pl_gen of the loop's last plan
   std::chrono::steady_clock::time_point t_plan_end;
   double plan_x0[6];
-  int last_agents = 0, best = -1;
+  int last_agents = 0, last_nodes = 0, best = -1;
   double aime_s = 0, ilqr_s = 0, total_s = 0;
   mind_loop_totals tot;
   bool planned_last = false;
@@ -82,7 +82,7 @@ void loop_fill_out(const mind_loop *L, mind_loop_out *o) {
   if (L->have_plan) {
     o->n_agents = L->last_agents; o->n_trees = L->po.n_trees; o->best = L->best;
     o->n_expanded = L->po.n_expanded; o->n_rounds = L->po.n_rounds;
-    o->n_traj_nodes = L->po.n_trees ? L->po.tree_off[L->po.n_trees] : 0;
+    o->n_traj_nodes = L->last_nodes;        // (kept by value: the plan's tables are the context's and may be another plan's by now)
     o->costs = L->costs.data();
     o->aime_s = L->aime_s; o->ilqr_s = L->ilqr_s; o->total_s = L->total_s;
   }
@@ -278,7 +278,7 @@ int loop_plan(mind_loop *L) {
     if (L->po.flat_parent[k] == -1) { first = k; break; }
   if (first < 0) return fail(c, MIND_ESTATE, "mind_loop: the chosen tree has no root child");
   L->ctrl[0] = xs[(size_t)first * 6 + 4]; L->ctrl[1] = xs[(size_t)first * 6 + 5];
-  L->best = best; L->last_agents = a; L->have_plan = true; L->plan_gen = c->pl_gen;
+  L->best = best; L->last_agents = a; L->last_nodes = M; L->have_plan = true; L->plan_gen = c->pl_gen;
   // accounting (TrajectoryTreeOptimizer.counters, MINDPlanner.timing_sum; bench.py's live kernel durations when profiling is on)
   mind_loop_totals &S = L->tot;
   for (int t = 0; t < nt; ++t) {
