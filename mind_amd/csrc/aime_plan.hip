@@ -172,14 +172,24 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     R.actors = d + o_actors; R.actor_ctrs = d + o_ctrs; R.actor_vecs = d + o_vecs; R.lane_ctrs = nullptr; R.lane_vecs = nullptr;
     R.tgt_nodes = d + o_tn; R.tgt_rpe = d + o_tr; R.frames = d + o_fr;
     hipLaunchKernelGGL(k_aime_rebase, dim3(1, 1 + RB_FEAT_BLOCKS(a)), dim3(RB_THREADS), 5 * (size_t)a * sizeof(float), st, R);
-    hipLaunchKernelGGL(k_aime_root_lanes, dim3(l), dim3(64), 0, st, (const double *)(d + o_lpts), (const int *)(d + o_lfl), (const float *)(d + o_fr),
+    // The lane graph, the root's world-frame histories and the frame read-back feed LaneNet / the token positions (side stream) and the
+    // glue behind the predictor -- not ActorNet, which only needs k_aime_rebase's features: they go to the side stream, in front of the
+    // predictor's own side-stream work, and ActorNet starts right behind the re-basing (they stood 25 us in front of it)
+    hipStream_t rs = st;
+    if (c->side && !(c->xfn && (c->xw > 1 || c->xforce))) {
+      if (!c->ev_root) HIPCHK(c, hipEventCreateWithFlags(&c->ev_root, hipEventDisableTiming));
+      HIPCHK(c, hipEventRecord(c->ev_root, st));
+      HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_root, 0));
+      rs = c->side;
+    }
+    hipLaunchKernelGGL(k_aime_root_lanes, dim3(l), dim3(64), 0, rs, (const double *)(d + o_lpts), (const int *)(d + o_lfl), (const float *)(d + o_fr),
                        d + o_lc, d + o_lv, d + o_lanes);
-    hipLaunchKernelGGL(k_aime_root_hist, dim3(a), dim3(64), 0, st, (const float *)(d + o_rpos), (const float *)(d + o_rang), (const float *)(d + o_rvel),
+    hipLaunchKernelGGL(k_aime_root_hist, dim3(a), dim3(64), 0, rs, (const float *)(d + o_rpos), (const float *)(d + o_rang), (const float *)(d + o_rvel),
                        (const float *)(d + o_fr), (const float *)(d + o_ctrs), (const float *)(d + o_vecs), d + o_wpos, d + o_wang, d + o_wvel, d + o_cov);
     HIPCHK(c, hipGetLastError());
     if ((rc = pl_pin(c, 3, 28 * sizeof(float)))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->pl_pin[3], d + o_fr, 28 * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipEventRecord(c->ev_pl, st));
+    HIPCHK(c, hipMemcpyAsync(c->pl_pin[3], d + o_fr, 28 * sizeof(float), hipMemcpyDeviceToHost, rs));
+    HIPCHK(c, hipEventRecord(c->ev_pl, rs));
   } else {
     float *h = (float *)c->pl_pin[0];
     memcpy(h + o_actors, in->actors, (size_t)a * 14 * 48 * sizeof(float));
@@ -206,6 +216,10 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   }
   const float *droot = (const float *)c->pl_root.p;
   if ((rc = ensure(c, c->pl_lf, (size_t)l * 128 * sizeof(float)))) return rc;
+  // the lane-distance field of the contingency solves this plan will begin: everything it depends on is known now (ilqr_impl adopts it)
+  if (in->solve_cfg_full && in->solve_x0 && in->solve_lane && in->solve_n_lane_pts >= 2 && !(c->xfn && (c->xw > 1 || c->xforce)) &&
+      (rc = il_field_prepare(c, in->solve_cfg_full, in->solve_x0, in->solve_lane, in->solve_n_lane_pts, c->pl_copy)))
+    return rc;
 
   // ---- internal tree (scenario_tree.py:60-67): root = node 0, a leaf with branch_flag
   std::vector<PlNode> nodes(1);
@@ -588,15 +602,24 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     // LaneNet's output repeated for this rank's scenes of the next round
     int nlo, nhi;
     pl_block(S, XR, XW, nlo, nhi);
+    // (unsharded: the repeated lane features -- read by the token kernels, behind the predictor's side-stream work -- and the frames' read-back
+    // go to the side stream; ActorNet follows the re-basing directly)
+    hipStream_t rs = st;
+    if (c->side && !dist) {
+      if (!c->ev_root) HIPCHK(c, hipEventCreateWithFlags(&c->ev_root, hipEventDisableTiming));
+      HIPCHK(c, hipEventRecord(c->ev_root, st));
+      HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_root, 0));
+      rs = c->side;
+    }
     if (nhi - nlo > 1) {
       if ((rc = ensure(c, c->pl_lrep, (size_t)(nhi - nlo) * l * 128 * sizeof(float)))) return rc;
       const size_t n = (size_t)l * 128;
-      hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((n * (nhi - nlo) + 255) / 256)), dim3(256), 0, st, (const float *)c->pl_lf.p, n, nhi - nlo, (float *)c->pl_lrep.p);
+      hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((n * (nhi - nlo) + 255) / 256)), dim3(256), 0, rs, (const float *)c->pl_lf.p, n, nhi - nlo, (float *)c->pl_lrep.p);
       HIPCHK(c, hipGetLastError());
     }
     if ((rc = pl_pin(c, 3, (size_t)S * 28 * sizeof(float)))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->pl_pin[3], d_in + q.fr, (size_t)S * 28 * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipEventRecord(c->ev_pl, st));
+    HIPCHK(c, hipMemcpyAsync(c->pl_pin[3], d_in + q.fr, (size_t)S * 28 * sizeof(float), hipMemcpyDeviceToHost, rs));
+    HIPCHK(c, hipEventRecord(c->ev_pl, rs));
     frames_pending = true;
     // next round's batch = the branch set in leaf order (scenario_tree.py:102-108)
     batch.assign(S, PlScene());

@@ -149,7 +149,17 @@ struct mind_ctx {
   std::vector<DevBuf> pl_world;
   void *pl_pin[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // [4], [5]: upload / read-back staging of the tree-iLQR calls; [6], [7]: sharded plan
   size_t pl_pin_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  hipEvent_t ev_pl = nullptr, ev_tab = nullptr;
+  hipEvent_t ev_pl = nullptr, ev_tab = nullptr, ev_root = nullptr;
+  // the lane-distance field of a plan's contingency solves (gen_dist_field: a function of the ego position, the grid and the target lane --
+  // all known when the plan starts), computed on the side stream beside the plan's first round instead of between its last decisions and
+  // k_ilqr (il_field_prepare; adopted by ilqr_impl when grid and lane are the ones it was made for)
+  DevBuf il_field;
+  void *il_field_pin = nullptr;
+  size_t il_field_pin_cap = 0;
+  hipEvent_t ev_field = nullptr;
+  bool il_field_valid = false;
+  double il_field_key[5] = {0, 0, 0, 0, 0};       // x0[0], x0[1], W, H, res
+  std::vector<double> il_field_lane;
   // mind_set_exchange: the sharded mind_aime_plan (rank, world, the caller's transport, packing buffers, collectives of the last plan)
   int xr = 0, xw = 1;
   mind_exchange_fn xfn = nullptr;
@@ -368,6 +378,10 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
   for (void *q : c->pl_pin)
     if (q) (void)hipHostFree(q);
   if (c->ev_pl) (void)hipEventDestroy(c->ev_pl);
+  if (c->ev_root) (void)hipEventDestroy(c->ev_root);
+  if (c->ev_field) (void)hipEventDestroy(c->ev_field);
+  if (c->il_field.p) (void)hipFree(c->il_field.p);
+  if (c->il_field_pin) (void)hipHostFree(c->il_field_pin);
   if (c->ev_tab) (void)hipEventDestroy(c->ev_tab);
   if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
   if (c->pl_copy) (void)hipStreamDestroy(c->pl_copy);
@@ -1605,6 +1619,35 @@ namespace { int pl_pin(mind_ctx *c, int which, size_t bytes); }     // page-lock
 // Shared host side of mind_ilqr_solve_trees / mind_ilqr_solve_fields / mind_cost_eval: build the device
 // arena, then either run the solver (ev == nullptr) or evaluate node costs at the requested points.
 // grid != nullptr selects the generic mode (materialised per-node fields + per-node weights).
+// the field of the NEXT tree-iLQR call on this context, ahead of it: grid + lane up, k_lane_field on `s`, an event behind it
+static int il_field_prepare(mind_ctx *c, const mind_ilqr_cfg *cfg, const double *x0, const double *lane, int n_lane_pts, hipStream_t s) {
+  c->il_field_valid = false;
+  const int W = cfg->grid_w, H = cfg->grid_h;
+  if (W < 3 || H < 3 || n_lane_pts < 2 || !(cfg->grid_res > 0)) return MIND_OK;        // (the call itself reports bad arguments)
+  const size_t nin = (size_t)W + H + 2 * (size_t)n_lane_pts, nd = nin + (size_t)W * H;
+  int rc;
+  if ((rc = ensure(c, c->il_field, nd * sizeof(double)))) return rc;
+  if (c->il_field_pin_cap < nin * sizeof(double)) {
+    if (c->il_field_pin) (void)hipHostFree(c->il_field_pin);
+    c->il_field_pin = nullptr; c->il_field_pin_cap = 0;
+    if (hipHostMalloc(&c->il_field_pin, 2 * nin * sizeof(double), hipHostMallocDefault) != hipSuccess) { c->il_field_pin = nullptr; return MIND_OK; }
+    c->il_field_pin_cap = 2 * nin * sizeof(double);
+  }
+  if (!c->ev_field) HIPCHK(c, hipEventCreateWithFlags(&c->ev_field, hipEventDisableTiming));
+  double *h = (double *)c->il_field_pin, ox, oy;
+  il_make_grid(W, H, cfg->grid_res, x0, h, h + W, ox, oy);
+  memcpy(h + W + H, lane, 2 * (size_t)n_lane_pts * sizeof(double));
+  double *d = (double *)c->il_field.p;
+  HIPCHK(c, hipMemcpyAsync(d, h, nin * sizeof(double), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, s, d, d + W, W, H, d + W + H, n_lane_pts, d + nin);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev_field, s));
+  c->il_field_key[0] = x0[0]; c->il_field_key[1] = x0[1]; c->il_field_key[2] = W; c->il_field_key[3] = H; c->il_field_key[4] = cfg->grid_res;
+  c->il_field_lane.assign(lane, lane + 2 * (size_t)n_lane_pts);
+  c->il_field_valid = true;
+  return MIND_OK;
+}
+
 static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_grid *grid, const mind_cost_tree *trees, int n_trees,
                      const double *x0, const double *target_lane, int n_lane_pts, double target_vel,
                      int use_exo, const double *us_init, double *xs, double *us,
@@ -1889,6 +1932,12 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   K.W = W; K.H = H; K.max_iter = cfg->max_iter; K.use_exo = use_exo_first;
   for (int j = 0; j < IL_NA; ++j) K.alphas[j] = std::pow(1.1, -(double)(j * j));
   K.gx = Dp(o_gx); K.gy = Dp(o_gy); K.quad = Dp(o_quad);
+  // a field prepared ahead for exactly this grid and lane (il_field_prepare): the kernels read it where it is
+  const bool field_ahead = !gen && !ev && c->il_field_valid && c->il_field_key[0] == x0[0] && c->il_field_key[1] == x0[1] && c->il_field_key[2] == (double)W &&
+                           c->il_field_key[3] == (double)H && c->il_field_key[4] == grid_res && c->il_field_lane.size() == 2 * (size_t)n_lane_pts &&
+                           memcmp(c->il_field_lane.data(), target_lane, c->il_field_lane.size() * sizeof(double)) == 0;
+  c->il_field_valid = false;         // (one call's worth: the next call makes its own or prepares again)
+  if (field_ahead) K.quad = (double *)c->il_field.p + (size_t)W + H + 2 * (size_t)n_lane_pts;
   // cell centres are computed in the kernels when the grid is the numpy linspace (always in the planner mode)
   K.stepx = fsx / (double)(W - 1); K.stepy = fsy / (double)(H - 1); K.fsx = fsx; K.fsy = fsy;
   K.lin = 1;
@@ -1927,7 +1976,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     HIPCHK(c, hipMemcpyAsync(base, up, o_work, hipMemcpyHostToDevice, st));
   }
   const IlqrConst *dK = (const IlqrConst *)(base + o_consts);
-  if (!gen) hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, K.gx.p, K.gy.p, W, H, Dp(o_lane), n_lane_pts, Dp(o_quad));
+  if (field_ahead) HIPCHK(c, hipStreamWaitEvent(st, c->ev_field, 0));
+  else if (!gen) hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, K.gx.p, K.gy.p, W, H, Dp(o_lane), n_lane_pts, Dp(o_quad));
   int amax = 1;
   for (int t = 0; t < n_trees; ++t) amax = tl[t].a > amax ? tl[t].a : amax;
   const IlqrTreeDev *dT = (const IlqrTreeDev *)(base + o_structs);
