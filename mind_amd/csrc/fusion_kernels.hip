@@ -586,6 +586,53 @@ __device__ __forceinline__ void matvec_part(float (&acc)[TP], const float *__res
     }
 }
 
+// the two halves of matvec_part (k_token_m issues the weight loads of INDEPENDENT projections together and exchanges their partial sums behind
+// one pair of barriers: same loads, same multiply-adds, same summation order)
+template <int K>
+__device__ __forceinline__ void mv_load(float (&w)[K / TKG], const float *__restrict__ WT, int ldo, int col, int kg) {
+  constexpr int KQ = K / TKG;
+  const int k0 = kg * KQ;
+#pragma unroll
+  for (int k = 0; k < KQ; ++k) w[k] = WT[(size_t)(k0 + k) * ldo + col];
+}
+template <int K, int TP>
+__device__ __forceinline__ void mv_fma(float (&acc)[TP], const float (&w)[K / TKG], const float *xin, int ldx, int kg) {
+  constexpr int KQ = K / TKG;
+  const int k0 = kg * KQ;
+#pragma unroll
+  for (int t = 0; t < TP; ++t) acc[t] = 0.f;
+#pragma unroll
+  for (int k = 0; k < KQ; k += 4)
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+      const float4 xv = *reinterpret_cast<const float4 *>(xin + t * ldx + k0 + k);
+      acc[t] = fmaf(w[k], xv.x, acc[t]);
+      acc[t] = fmaf(w[k + 1], xv.y, acc[t]);
+      acc[t] = fmaf(w[k + 2], xv.z, acc[t]);
+      acc[t] = fmaf(w[k + 3], xv.w, acc[t]);
+    }
+}
+// N independent projections' partials meet behind ONE pair of barriers (rk holds N x [TKG][TP][128]); per projection the sums are ksum's
+template <int TP, int N>
+__device__ __forceinline__ void ksum_n(const float (&acc)[N][TP], const float (&bias)[N], float *rk, int kg, int col, float (&r0)[N], float (&r1)[N]) {
+  constexpr int TPW = TP, ST = TKG * TP * 128;
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) rk[n * ST + (kg * TPW + t) * 128 + col] = acc[n][t];
+  __syncthreads();
+  const int t0 = (TP / TKG) * kg;
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    const float *q = rk + n * ST;
+    r0[n] = ((q[(0 * TPW + t0) * 128 + col] + q[(1 * TPW + t0) * 128 + col]) + (q[(2 * TPW + t0) * 128 + col] + q[(3 * TPW + t0) * 128 + col])) + bias[n];
+    r1[n] = 0.f;
+    if (TP / TKG == 2)
+      r1[n] = ((q[(0 * TPW + t0 + 1) * 128 + col] + q[(1 * TPW + t0 + 1) * 128 + col]) + (q[(2 * TPW + t0 + 1) * 128 + col] + q[(3 * TPW + t0 + 1) * 128 + col])) + bias[n];
+  }
+}
+
 // meet the four partials: on return r0/r1 = bias + full sums for this thread's tokens (fixed order): 2kg, 2kg+1 of a workgroup of
 // eight tokens, kg alone (r1 unused) of a workgroup of four.  Contains two barriers; rk is [TKG][TP][128].
 template <int TP>
@@ -632,16 +679,19 @@ __device__ __forceinline__ void ln2tok(float &p0, float &p1, float g, float be, 
 // TPW = 8 tokens per workgroup (big batches: every weight fetched from L2 serves eight tokens) or 4 (small batches: twice the
 // workgroups, half the LDS operand traffic in each -- the per-stage time of a lone scene's launch).  The k split and every
 // summation order are the same, so the two instantiations give bit-identical results.
-template <int TPW>
-__global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_token(const TokMeta *__restrict__ meta, int n_tok, int mode,
-                                                      const float *__restrict__ actor_feat,
-                                                      const float *__restrict__ lane_feat, float *__restrict__ x,
-                                                      const float *__restrict__ part, float *__restrict__ ST,
-                                                      float *__restrict__ QK, TokWeights W) {
+// MG (k_token_m, small launches): the projections that do not depend on each other -- the two halves of the feed-forward layer's first
+// matrix, and S / T / q of the next layer's prologue -- load their weights together and exchange their partial sums behind one pair of
+// barriers (ksum_n): three of the launch's ten dependent stages fewer, every sum in the same order: bit-identical to the plain form.
+template <int TPW, bool MG>
+__device__ __forceinline__ void k_token_body(const TokMeta *__restrict__ meta, int n_tok, int mode,
+                                             const float *__restrict__ actor_feat,
+                                             const float *__restrict__ lane_feat, float *__restrict__ x,
+                                             const float *__restrict__ part, float *__restrict__ ST,
+                                             float *__restrict__ QK, const TokWeights &W) {
   __shared__ __attribute__((aligned(16))) float xs[TPW][132];        // current token vectors
   __shared__ __attribute__((aligned(16))) float tmp[TPW][260];       // scratch (o / h1 up to 256 wide)
   __shared__ __attribute__((aligned(16))) float mb[TPW][8][132];     // normalised sum p*mem per head
-  __shared__ float rk[TKG * TPW * 128];                              // k-group partial sums
+  __shared__ float rk[(MG ? 3 : 1) * TKG * TPW * 128];               // k-group partial sums (MG: of up to three projections at once)
   __shared__ float rd[TKG * 2 * 2];
   __shared__ float cw[TPW][8][8];       // combine weights per (token, head, split<=8)
   const int tid = threadIdx.x, kg = tid >> 7, col = tid & 127;
@@ -794,12 +844,24 @@ __global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     // ---- FFN 128 -> 256 -> 128, x2 = LN3(x1 + ff)
     {
       float acc[TPW], h0, h1;
-      matvec_part<128, TPW>(acc, W.W1T, 256, col, &xs[0][0], 132, kg);
-      ksum<TPW>(acc, W.b1[col], rk, kg, col, h0, h1);
-      tmp[ta][col] = fmaxf(h0, 0.f); if (TWO) tmp[tb][col] = fmaxf(h1, 0.f);
-      matvec_part<128, TPW>(acc, W.W1T, 256, 128 + col, &xs[0][0], 132, kg);
-      ksum<TPW>(acc, W.b1[128 + col], rk, kg, col, h0, h1);
-      tmp[ta][128 + col] = fmaxf(h0, 0.f); if (TWO) tmp[tb][128 + col] = fmaxf(h1, 0.f);
+      if (MG) {
+        float wa[32], wb[32], ac2[2][TPW], r0[2], r1[2];
+        mv_load<128>(wa, W.W1T, 256, col, kg);
+        mv_load<128>(wb, W.W1T, 256, 128 + col, kg);
+        mv_fma<128, TPW>(ac2[0], wa, &xs[0][0], 132, kg);
+        mv_fma<128, TPW>(ac2[1], wb, &xs[0][0], 132, kg);
+        const float bs[2] = {W.b1[col], W.b1[128 + col]};
+        ksum_n<TPW, 2>(ac2, bs, rk, kg, col, r0, r1);
+        tmp[ta][col] = fmaxf(r0[0], 0.f); if (TWO) tmp[tb][col] = fmaxf(r1[0], 0.f);
+        tmp[ta][128 + col] = fmaxf(r0[1], 0.f); if (TWO) tmp[tb][128 + col] = fmaxf(r1[1], 0.f);
+      } else {
+        matvec_part<128, TPW>(acc, W.W1T, 256, col, &xs[0][0], 132, kg);
+        ksum<TPW>(acc, W.b1[col], rk, kg, col, h0, h1);
+        tmp[ta][col] = fmaxf(h0, 0.f); if (TWO) tmp[tb][col] = fmaxf(h1, 0.f);
+        matvec_part<128, TPW>(acc, W.W1T, 256, 128 + col, &xs[0][0], 132, kg);
+        ksum<TPW>(acc, W.b1[128 + col], rk, kg, col, h0, h1);
+        tmp[ta][128 + col] = fmaxf(h0, 0.f); if (TWO) tmp[tb][128 + col] = fmaxf(h1, 0.f);
+      }
       __syncthreads();
       float p0, p1;
       matvec_part<256, TPW>(acc, W.W2T, 128, col, &tmp[0][0], 260, kg);
@@ -820,17 +882,32 @@ __global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     // ---- prologue of the next layer: S = W_s x, T = W_t x + b_m, q = W_q x + b_q,
     //      qk[hd][f] = sum_d q[hd*16+d] W_k[hd*16+d][f] / 4      (scale 1/sqrt(16))
     float acc[TPW], r0, r1;
-    matvec_part<128, TPW>(acc, W.WsT, 128, col, &xs[0][0], 132, kg);
-    ksum<TPW>(acc, 0.f, rk, kg, col, r0, r1);
-    if (va) ST[(size_t)(tok0 + ta) * 256 + col] = r0;
-    if (vb) ST[(size_t)(tok0 + tb) * 256 + col] = r1;
-    matvec_part<128, TPW>(acc, W.WtT, 128, col, &xs[0][0], 132, kg);
-    ksum<TPW>(acc, W.bm[col], rk, kg, col, r0, r1);
-    if (va) ST[(size_t)(tok0 + ta) * 256 + 128 + col] = r0;
-    if (vb) ST[(size_t)(tok0 + tb) * 256 + 128 + col] = r1;
-    matvec_part<128, TPW>(acc, W.WqT, 128, col, &xs[0][0], 132, kg);
-    ksum<TPW>(acc, W.bq[col], rk, kg, col, r0, r1);
-    tmp[ta][col] = r0; if (TWO) tmp[tb][col] = r1;
+    if (MG) {
+      float ws[32], wt[32], wq[32], ac3[3][TPW], q0[3], q1[3];
+      mv_load<128>(ws, W.WsT, 128, col, kg);
+      mv_load<128>(wt, W.WtT, 128, col, kg);
+      mv_load<128>(wq, W.WqT, 128, col, kg);
+      mv_fma<128, TPW>(ac3[0], ws, &xs[0][0], 132, kg);
+      mv_fma<128, TPW>(ac3[1], wt, &xs[0][0], 132, kg);
+      mv_fma<128, TPW>(ac3[2], wq, &xs[0][0], 132, kg);
+      const float bs[3] = {0.f, W.bm[col], W.bq[col]};
+      ksum_n<TPW, 3>(ac3, bs, rk, kg, col, q0, q1);
+      if (va) { ST[(size_t)(tok0 + ta) * 256 + col] = q0[0]; ST[(size_t)(tok0 + ta) * 256 + 128 + col] = q0[1]; }
+      if (vb) { ST[(size_t)(tok0 + tb) * 256 + col] = q1[0]; ST[(size_t)(tok0 + tb) * 256 + 128 + col] = q1[1]; }
+      tmp[ta][col] = q0[2]; if (TWO) tmp[tb][col] = q1[2];
+    } else {
+      matvec_part<128, TPW>(acc, W.WsT, 128, col, &xs[0][0], 132, kg);
+      ksum<TPW>(acc, 0.f, rk, kg, col, r0, r1);
+      if (va) ST[(size_t)(tok0 + ta) * 256 + col] = r0;
+      if (vb) ST[(size_t)(tok0 + tb) * 256 + col] = r1;
+      matvec_part<128, TPW>(acc, W.WtT, 128, col, &xs[0][0], 132, kg);
+      ksum<TPW>(acc, W.bm[col], rk, kg, col, r0, r1);
+      if (va) ST[(size_t)(tok0 + ta) * 256 + 128 + col] = r0;
+      if (vb) ST[(size_t)(tok0 + tb) * 256 + 128 + col] = r1;
+      matvec_part<128, TPW>(acc, W.WqT, 128, col, &xs[0][0], 132, kg);
+      ksum<TPW>(acc, W.bq[col], rk, kg, col, r0, r1);
+      tmp[ta][col] = r0; if (TWO) tmp[tb][col] = r1;
+    }
     __syncthreads();
     TT(6);
     // each k-group takes two of the eight heads, all tokens
@@ -880,4 +957,21 @@ __global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     printf("[k_token mode %d ntok %d] cycles: load %lld cw %lld combine %lld Wv %lld Wo+LN2 %lld FFN+LN3 %lld S,T,q %lld QK %lld\n", mode, n_tok,
            tt_[0], tt_[1], tt_[2], tt_[3], tt_[4], tt_[5], tt_[6], tt_[7]);
 #endif
+}
+
+template <int TPW>
+__global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_token(const TokMeta *__restrict__ meta, int n_tok, int mode,
+                                                      const float *__restrict__ actor_feat,
+                                                      const float *__restrict__ lane_feat, float *__restrict__ x,
+                                                      const float *__restrict__ part, float *__restrict__ ST,
+                                                      float *__restrict__ QK, TokWeights W) {
+  k_token_body<TPW, false>(meta, n_tok, mode, actor_feat, lane_feat, x, part, ST, QK, W);
+}
+// small launches (a lone demo-size scene: 24 workgroups, one per CU, two waves per SIMD): independent projections merged
+__global__ __launch_bounds__(TT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_token_m(const TokMeta *__restrict__ meta, int n_tok, int mode,
+                                                      const float *__restrict__ actor_feat,
+                                                      const float *__restrict__ lane_feat, float *__restrict__ x,
+                                                      const float *__restrict__ part, float *__restrict__ ST,
+                                                      float *__restrict__ QK, TokWeights W) {
+  k_token_body<TOK_TPW_SMALL, true>(meta, n_tok, mode, actor_feat, lane_feat, x, part, ST, QK, W);
 }

@@ -96,6 +96,7 @@ struct mind_ctx {
   // 0.80 ms for the largest, the same as the VALU kernel (which is LDS-bound there) -- with 97 KB of LDS the MFMA kernel keeps one
   // four-wave workgroup per CU and waits on its partial-sum and fragment loads instead (profiles/r03bb); opt-in until it is faster
   int tok_bf_min_n = 0;
+  bool tok_merge = true;        // small token launches merge their independent projections (k_token_m; MIND_TOK_MERGE=0 / "tok_merge": the plain kernel)
   int tok_small_max = 2048;     // batches of at most this many tokens run k_token with 4 tokens per workgroup ("tok_small_max")
   const float *WAe[6], *WAp[6], *vtab[6], *rtab = nullptr;
   const u32 *WBe[6], *WBp[6];   // bf16 hi / lo fragments of the same matrices (pair_bf16_kernels.hip)
@@ -334,6 +335,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   (void)hipFuncSetAttribute((const void *)k_ilqr<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_lds_bytes(0));
   if (const char *te = getenv("MIND_TOK_MFMA")) c->tok_mfma = !(te[0] == '0');
   if (const char *te = getenv("MIND_TOK_SMALL_MAX")) c->tok_small_max = atoi(te);
+  if (const char *te = getenv("MIND_TOK_MERGE")) c->tok_merge = !(te[0] == '0');
   if (const char *te = getenv("MIND_DEC_MW")) c->dec_mw = !(te[0] == '0');
   if (const char *te = getenv("MIND_TOK_BF_MIN_N")) c->tok_bf_min_n = atoi(te);
   if (const char *te = getenv("MIND_TGT_SIDE")) c->tgt_side = !(te[0] == '0');
@@ -422,6 +424,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "dec_overlap") c->dec_overlap = value != 0;
   else if (n == "tok_mfma") c->tok_mfma = value != 0;
   else if (n == "tok_small_max") c->tok_small_max = (int)value;
+  else if (n == "tok_merge") c->tok_merge = value != 0;
   else if (n == "dec_mw") c->dec_mw = value != 0;
   else if (n == "tok_bf_min_n") c->tok_bf_min_n = (int)value;
   else if (n == "tgt_side") c->tgt_side = value != 0;
@@ -1408,8 +1411,9 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
       if (r.kind == 0) {
         const bool small = r.n <= c->tok_small_max;
         const int tpw = small ? TOK_TPW_SMALL : TOK_TPW_BIG;
-        hipLaunchKernelGGL(small ? k_token<TOK_TPW_SMALL> : k_token<TOK_TPW_BIG>, dim3((r.n + tpw - 1) / tpw), dim3(TT_THREADS), 0, st, m_, r.n, mode,
-                           actor_feat, lane_feat, x_, part, ST_, QK_, c->tokW[Lw]);
+        // (small launches: independent projections merged, k_token_m -- bit-identical; "tok_merge" 0 keeps the plain form for A/B)
+        hipLaunchKernelGGL(small ? (c->tok_merge ? k_token_m : k_token<TOK_TPW_SMALL>) : k_token<TOK_TPW_BIG>, dim3((r.n + tpw - 1) / tpw), dim3(TT_THREADS), 0,
+                           st, m_, r.n, mode, actor_feat, lane_feat, x_, part, ST_, QK_, c->tokW[Lw]);
       } else if (r.kind == 1) {
         hipLaunchKernelGGL(k_token_mfma<0>, dim3((r.n + TM_TOK - 1) / TM_TOK), dim3(TM_THREADS), tokm_lds, st, m_, r.n, mode, actor_feat, lane_feat, x_,
                            part, ST_, QK_, c->tokW[Lw], c->tokWM[Lw]);

@@ -320,6 +320,22 @@ def test_token_kernel_tokens_per_workgroup_do_not_change_results(a, l, B, seed, 
         assert torch.equal(big[k], small[k]), k
 
 
+def test_token_kernel_with_merged_projections_equals_the_plain_one(hip_predictor):
+    """Small launches run k_token_m: the projections that do not depend on each other (the two halves of the feed-forward layer's first
+    matrix; S / T / q of the next layer's prologue) load their weights together and meet behind one pair of barriers -- three of ten
+    dependent stages fewer (mind_set_tuning("tok_merge", 0): the plain kernel).  Same loads, same multiply-adds, same summation order:
+    every output the same bits, on a lone scene and on ragged batches."""
+    for pb in (predictor_batch(40, 55, 1, seed=1), predictor_batch(7, 12, 5, seed=3), predictor_batch(1, 3, 2, seed=5)):
+        merged = {k: v.clone() for k, v in hip_predictor.predict_numpy_batch(pb).items() if torch.is_tensor(v)}
+        try:
+            hip_predictor.set_tuning("tok_merge", 0)
+            plain = {k: v.clone() for k, v in hip_predictor.predict_numpy_batch(pb).items() if torch.is_tensor(v)}
+        finally:
+            hip_predictor.set_tuning("tok_merge", 1)
+        for k in ("cls", "reg", "vel"):
+            assert torch.equal(merged[k], plain[k]), k
+
+
 def test_decoder_scene_part_on_eight_workgroups_equals_the_one_workgroup_kernel(hip_predictor):
     """With mind_set_tuning("dec_mw", 1) calls of at most n_cu / 8 scenes run k_dec_scene_mw: eight workgroups per scene share the decoder's
     five big stages with the K split and per-item arithmetic of the one-workgroup kernel (opt-in: 6 us of a 95 us launch).  Every output
