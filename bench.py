@@ -548,16 +548,22 @@ def recorded_scenes(prec, plans=20, warmup=3):
 
 # ---- concurrent scenes on one GPU (BASELINE config 3) ---------------------------------------------------------------------
 NATIVE_LOOP = None if os.environ.get("MIND_NATIVE_LOOP", "1") != "0" else False      # ClosedLoopSim(native=...) of the single-loop throughput runs
-# Several scenes on one GPU keep the Python steps unless MIND_CONCURRENT_NATIVE=1: measured on one box (profiles/r06q_config3_native*.txt) four
-# processes with the speculative warm start (a second context per planner, Python steps only) reach 7.5 k sim steps/s against 5.1 k for four
-# native loops, and sixteen scenes are bound by the device, not by the interpreter (two processes of event loops 9.5 k, native threads 8.0 k)
+# Several scenes on one GPU (profiles/r06q_config3_native*.txt, r06aj_*): up to four scenes as a process each run the NATIVE loop with its
+# speculative warm start (MIND_NATIVE_SPECULATE: warm-start fits of the previous plan's tree shapes on a second context beside the AIME rounds) --
+# 9.1-9.4 k sim steps/s against 7.3-7.6 k for the Python steps with the same speculation and 5.3 k for native loops without it; sixteen scenes
+# are bound by the device, not by the interpreter, and keep the Python event loops (two processes of eight: 9.0-9.5 k; native threads 7.6-8.0 k).
+# MIND_CONCURRENT_NATIVE=1 / 0 forces native loops / Python steps everywhere.
 CONCURRENT_NATIVE = None if os.environ.get("MIND_CONCURRENT_NATIVE", "0") == "1" else False
 
 
 def _proc_scene(i, workload, steps, warmup, ready, go, q, speculative, ckpt=None):
     """One scene in its own process (own HIP context): signals ready, waits for the common start, reports back."""
     import torch as th
-    pl, sim, w = make_closed_loop(scene_workload(workload, i), full_tree=workload in FULL_TREE, speculative=speculative, ckpt=ckpt, native=CONCURRENT_NATIVE)
+    native = CONCURRENT_NATIVE
+    if speculative and "MIND_CONCURRENT_NATIVE" not in os.environ:      # (a handful of processes: the native loop + its speculative warm start)
+        os.environ.setdefault("MIND_NATIVE_SPECULATE", "1")
+        native = None
+    pl, sim, w = make_closed_loop(scene_workload(workload, i), full_tree=workload in FULL_TREE, speculative=speculative, ckpt=ckpt, native=native)
     sim.run_plans(max(warmup, 1))
     th.cuda.synchronize()
     ready.wait()

@@ -512,6 +512,10 @@ typedef struct {
   int solve_n_lane_pts; const double *solve_lane;                      /* gt_tgt_lane [P',2] float64                              */
   double target_vel;
   int eval_n_lane_pts, eval_lane_is_f32; const void *eval_lane;        /* lcl_smp.target_lane [P'',2] in its own dtype            */
+  /* != 0: the speculative warm start of this repo's TrajectoryTreeOptimizer (trajectory_tree.py speculate_warm): the warm-start fits of
+   * the previous plan's tree shapes run on a second context of the loop beside the AIME rounds; a tree whose shape recurs runs the full fit
+   * only.  Same kernels on the same inputs: the results are the same bits either way; it pays when several loops share the device. */
+  int speculative;
 } mind_loop_desc;
 
 /* running totals over every plan of the loop since it was created (a caller's accounting takes differences) */
@@ -519,6 +523,7 @@ typedef struct {
   long long plans, expansions, scen_trees, rounds;
   double aime_s, ilqr_s, total_s;   /* host wall time: the AIME call | collecting the solves | the whole planning cycle                */
   long long iterations, node_iterations, node_iterations_exo;      /* warm + full fits (TrajectoryTreeOptimizer.counters)              */
+  long long warm_speculated, warm_hits;                             /* speculated warm-start fits begun / used                           */
   /* with profiling on (mind_set_profiling): kernel durations from HIP events on the context stream, as mind_aime_plan_out.pair_ms /
    * mind_last_ilqr_stats / mind_last_ilqr_profile report them per call */
   double pair_ms; long long pair_launches;

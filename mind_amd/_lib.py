@@ -121,13 +121,14 @@ class LoopDesc(C.Structure):       # mind_loop_desc (include/mind_hip.h)
                 ("time_ahead", C.c_double), ("min_vel", C.c_float), ("dist_thres", C.c_float), ("max_depth", C.c_int), ("max_rounds", C.c_int),
                 ("pred_len", C.c_int), ("prob_floor", C.c_float),
                 ("cfg_warm", C.c_void_p), ("cfg_full", C.c_void_p), ("solve_n_lane_pts", C.c_int), ("solve_lane", C.c_void_p), ("target_vel", C.c_double),
-                ("eval_n_lane_pts", C.c_int), ("eval_lane_is_f32", C.c_int), ("eval_lane", C.c_void_p)]
+                ("eval_n_lane_pts", C.c_int), ("eval_lane_is_f32", C.c_int), ("eval_lane", C.c_void_p), ("speculative", C.c_int)]
 
 
 class LoopTotals(C.Structure):     # mind_loop_totals
     _fields_ = [("plans", C.c_longlong), ("expansions", C.c_longlong), ("scen_trees", C.c_longlong), ("rounds", C.c_longlong),
                 ("aime_s", C.c_double), ("ilqr_s", C.c_double), ("total_s", C.c_double),
                 ("iterations", C.c_longlong), ("node_iterations", C.c_longlong), ("node_iterations_exo", C.c_longlong),
+                ("warm_speculated", C.c_longlong), ("warm_hits", C.c_longlong),
                 ("pair_ms", C.c_double), ("pair_launches", C.c_longlong), ("scene_n2", C.c_double), ("scene_n_a1", C.c_double),
                 ("ilqr_ms", C.c_double), ("ilqr_launches", C.c_longlong), ("ilqr_trees", C.c_longlong), ("ilqr_workgroups_per_tree", C.c_int),
                 ("ilqr_prof", C.c_double * 9), ("ilqr_node_steps", C.c_double)]

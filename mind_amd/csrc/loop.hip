@@ -57,8 +57,21 @@ struct mind_loop {
   bool have_plan = false, half_step = false;
   long long plan_gen = -1;          // mind_ctx::pl_gen of the loop's last plan
   std::chrono::steady_clock::time_point t_plan_end;
+  // speculative warm start (TrajectoryTreeOptimizer.speculate_warm / _take_speculation, this repo's trajectory_tree.py): the warm-start fits of the
+  // PREVIOUS plan's tree shapes run on a second context beside the AIME rounds; a tree whose shape recurs takes its warm-start controls from there
+  mind_ctx *side = nullptr;
+  hipStream_t side_stream = nullptr;
+  struct Shape { std::vector<int32_t> parent; std::vector<float> prob; };
+  std::vector<Shape> last_shapes, spec_shapes;
+  bool spec_pending = false;
+  int spec_skip = 0, spec_backoff = 4, spec_last = -1;
+  std::vector<double> spec_xs, spec_us, sol_xs, sol_us, hit_ui, miss_xs, miss_us;
+  std::vector<mind_ilqr_stats> spec_st, sol_stw, sol_stf, miss_stw, miss_stf;
+  std::vector<float> zero_mean, zero_cov;
+  long long warm_speculated = 0, warm_hits = 0;
   double plan_x0[6];
-  int last_agents = 0, last_nodes = 0, best = -1;
+  int last_agents = 0, last_nodes = 0, best = -1, last_agents_plan = 0;
+  bool sol_owned = false;           // the last plan's solve results are the loop's own arrays (a speculated cycle), not the context's
   double aime_s = 0, ilqr_s = 0, total_s = 0;
   mind_loop_totals tot;
   bool planned_last = false;
@@ -182,6 +195,142 @@ void loop_propagate(mind_loop *L) {
   L->state[0] = o0; L->state[1] = o1; L->state[2] = o2; L->state[3] = o3;
 }
 
+// TrajectoryTreeOptimizer.speculate_warm: the warm-start fit (lane term only: it sees the cost tree's shape, the ego state, the target lane and
+// velocity -- no prediction) of every shape of the previous plan, begun on the side context; returns at once
+int loop_speculate(mind_loop *L, const double *x0) {
+  mind_ctx *c = L->c;
+  const mind_loop_desc &d = L->d;
+  L->spec_pending = false;
+  if (!d.speculative || L->last_shapes.empty()) return MIND_OK;
+  if (L->spec_skip > 0) { L->spec_skip -= 1; L->spec_last = -1; return MIND_OK; }
+  if (!L->side) {
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&L->side_stream, hipStreamNonBlocking) != hipSuccess) return MIND_OK;
+    if (mind_ctx_create(c->device, (void *)L->side_stream, &L->side) != MIND_OK) { L->side = nullptr; return MIND_OK; }
+  }
+  mind_ctx *sc = L->side;
+  if (sc->il_finish) (void)mind_ilqr_finish(sc);
+  (void)mind_set_tuning(sc, "ilqr_wgs", 1);          // (a fit beside the predictor stays on one workgroup per tree: IlqrCall background)
+  L->spec_shapes = L->last_shapes;
+  const int n = (int)L->spec_shapes.size();
+  size_t M = 0, maxM = 0;
+  for (const auto &sh : L->spec_shapes) { M += sh.parent.size(); maxM = std::max(maxM, sh.parent.size()); }
+  L->zero_mean.assign(maxM * 2, 0.f); L->zero_cov.assign(maxM, 0.f);        // the warm-start cost has no agent term: one dummy agent per node
+  std::vector<mind_cost_tree> trees(n);
+  for (int t = 0; t < n; ++t) {
+    mind_cost_tree &T = trees[t];
+    memset(&T, 0, sizeof(T));
+    T.n_nodes = (int)L->spec_shapes[t].parent.size(); T.parent = L->spec_shapes[t].parent.data(); T.prob = L->spec_shapes[t].prob.data();
+    T.n_agents = 1; T.agent_mean = L->zero_mean.data(); T.agent_cov = L->zero_cov.data();
+  }
+  L->spec_xs.resize(M * 6); L->spec_us.resize(M * 2); L->spec_st.resize(n);
+  sc->il_begin_only = true;
+  const int rc = ilqr_impl(sc, &L->cfg_warm, nullptr, trees.data(), n, x0, L->solve_lane.data(), d.solve_n_lane_pts, d.target_vel, 0, nullptr,
+                           L->spec_xs.data(), L->spec_us.data(), L->spec_st.data(), nullptr);
+  sc->il_begin_only = false;
+  if (rc != MIND_OK) return MIND_OK;                 // (the in-line path then computes -- or reports -- the same thing)
+  L->spec_pending = true;
+  L->warm_speculated += n;
+  L->spec_last = n;
+  return MIND_OK;
+}
+
+// TrajectoryTreeOptimizer.solve_batch with a speculation in flight: trees whose shape was guessed right run the full fit only (from the
+// speculated warm-start controls), the others both fits on the side context beside them.  Results into L->sol_* (tree order).
+int loop_solve_speculated(mind_loop *L, const double *x0) {
+  mind_ctx *c = L->c, *sc = L->side;
+  const mind_loop_desc &d = L->d;
+  const int nt = L->po.n_trees, a = L->last_agents_plan;
+  const int32_t *off = L->po.tree_off;
+  const int M = off[nt];
+  // ---- _take_speculation
+  bool have = mind_ilqr_finish(sc) == MIND_OK;
+  L->spec_pending = false;
+  std::vector<int> hit_of(nt, -1);
+  std::vector<size_t> spec_off(L->spec_shapes.size() + 1, 0);
+  for (size_t j = 0; j < L->spec_shapes.size(); ++j) spec_off[j + 1] = spec_off[j] + L->spec_shapes[j].parent.size();
+  int n_hits = 0;
+  for (int t = 0; t < nt && have; ++t) {
+    const int m = off[t + 1] - off[t];
+    for (size_t j = 0; j < L->spec_shapes.size(); ++j) {
+      const auto &sh = L->spec_shapes[j];
+      if ((int)sh.parent.size() == m && memcmp(sh.parent.data(), L->po.flat_parent + off[t], (size_t)m * 4) == 0 &&
+          memcmp(sh.prob.data(), L->po.flat_prob + off[t], (size_t)m * 4) == 0) { hit_of[t] = (int)j; ++n_hits; break; }
+    }
+  }
+  L->warm_hits += n_hits;
+  if (L->spec_last >= 0) {
+    // a speculated fit only pays when the shape recurs: after a cycle in which fewer than half of the guesses were used, skip the next
+    // spec_backoff cycles (doubling after every failed probe, 4 .. 256), then probe again
+    if (2 * n_hits < L->spec_last) { L->spec_skip = L->spec_backoff; L->spec_backoff = std::min(2 * L->spec_backoff, 256); }
+    else L->spec_backoff = 4;
+  }
+  L->spec_last = -1;
+  L->sol_xs.assign((size_t)M * 6, 0.0); L->sol_us.assign((size_t)M * 2, 0.0); L->sol_stw.assign(nt, mind_ilqr_stats()); L->sol_stf.assign(nt, mind_ilqr_stats());
+  auto tree_of = [&](int t) {
+    mind_cost_tree T;
+    memset(&T, 0, sizeof(T));
+    T.n_nodes = off[t + 1] - off[t]; T.parent = L->po.flat_parent + off[t]; T.prob = L->po.flat_prob + off[t];
+    T.n_agents = a; T.agent_mean = L->po.flat_mean + (size_t)off[t] * a * 2; T.agent_cov = L->po.flat_cov + (size_t)off[t] * a;
+    return T;
+  };
+  std::vector<mind_cost_tree> hits, misses;
+  std::vector<int> hit_idx, miss_idx;
+  for (int t = 0; t < nt; ++t) { if (hit_of[t] >= 0) { hit_idx.push_back(t); hits.push_back(tree_of(t)); } else { miss_idx.push_back(t); misses.push_back(tree_of(t)); } }
+  int rc = MIND_OK;
+  size_t Mm = 0, Mh = 0;
+  for (const auto &T : misses) Mm += T.n_nodes;
+  for (const auto &T : hits) Mh += T.n_nodes;
+  bool miss_on_side = false;
+  if (!misses.empty()) {          // both fits, as without speculation: beside the hits' full fits when there are any
+    L->miss_xs.resize(Mm * 6); L->miss_us.resize(Mm * 2); L->miss_stw.resize(misses.size()); L->miss_stf.resize(misses.size());
+    if (!hits.empty()) {
+      (void)mind_set_tuning(sc, "ilqr_wgs", c->ilqr_wgs);
+      rc = mind_ilqr_contingency_begin(sc, &L->cfg_warm, &L->cfg_full, misses.data(), (int)misses.size(), x0, L->solve_lane.data(), d.solve_n_lane_pts, d.target_vel,
+                                       L->miss_xs.data(), L->miss_us.data(), L->miss_stw.data(), L->miss_stf.data());
+      if (rc) return fail(c, rc, "mind_loop: %s", sc->err.c_str());
+      miss_on_side = true;
+    } else {
+      if ((rc = mind_ilqr_contingency(c, &L->cfg_warm, &L->cfg_full, misses.data(), (int)misses.size(), x0, L->solve_lane.data(), d.solve_n_lane_pts, d.target_vel,
+                                      L->miss_xs.data(), L->miss_us.data(), L->miss_stw.data(), L->miss_stf.data())))
+        return rc;
+    }
+  }
+  if (!hits.empty()) {            // warm-start controls are there already: full fit only
+    L->hit_ui.resize(Mh * 2);
+    size_t o = 0;
+    for (int t : hit_idx) {
+      const int m = off[t + 1] - off[t];
+      memcpy(L->hit_ui.data() + o * 2, L->spec_us.data() + spec_off[hit_of[t]] * 2, (size_t)m * 2 * sizeof(double));
+      o += m;
+    }
+    std::vector<double> hx(Mh * 6), hu(Mh * 2);
+    std::vector<mind_ilqr_stats> hs(hits.size());
+    if ((rc = mind_ilqr_solve_trees(c, &L->cfg_full, hits.data(), (int)hits.size(), x0, L->solve_lane.data(), d.solve_n_lane_pts, d.target_vel, 1, L->hit_ui.data(),
+                                    hx.data(), hu.data(), hs.data()))) {
+      if (miss_on_side) (void)mind_ilqr_finish(sc);
+      return rc;
+    }
+    o = 0;
+    for (size_t k = 0; k < hit_idx.size(); ++k) {
+      const int t = hit_idx[k], m = off[t + 1] - off[t];
+      memcpy(L->sol_xs.data() + (size_t)off[t] * 6, hx.data() + o * 6, (size_t)m * 6 * sizeof(double));
+      memcpy(L->sol_us.data() + (size_t)off[t] * 2, hu.data() + o * 2, (size_t)m * 2 * sizeof(double));
+      L->sol_stw[t] = L->spec_st[hit_of[t]]; L->sol_stf[t] = hs[k];
+      o += m;
+    }
+  }
+  if (miss_on_side && (rc = mind_ilqr_finish(sc))) return fail(c, rc, "mind_loop: %s", sc->err.c_str());
+  size_t o = 0;
+  for (size_t k = 0; k < miss_idx.size(); ++k) {
+    const int t = miss_idx[k], m = off[t + 1] - off[t];
+    memcpy(L->sol_xs.data() + (size_t)off[t] * 6, L->miss_xs.data() + o * 6, (size_t)m * 6 * sizeof(double));
+    memcpy(L->sol_us.data() + (size_t)off[t] * 2, L->miss_us.data() + o * 2, (size_t)m * 2 * sizeof(double));
+    L->sol_stw[t] = L->miss_stw[k]; L->sol_stf[t] = L->miss_stf[k];
+    o += m;
+  }
+  return MIND_OK;
+}
+
 // MINDPlanner.plan (planner.py:66-145) of the enabled agent
 int loop_plan(mind_loop *L) {
   mind_ctx *c = L->c;
@@ -231,8 +380,13 @@ int loop_plan(mind_loop *L) {
   pi.max_depth = d.max_depth; pi.max_rounds = d.max_rounds; pi.pred_len = d.pred_len; pi.prob_floor = d.prob_floor;
   double *x0 = L->plan_x0;
   x0[0] = L->state[0]; x0[1] = L->state[1]; x0[2] = L->state[2]; x0[3] = L->state[3]; x0[4] = L->ctrl[0]; x0[5] = L->ctrl[1];
-  pi.solve_cfg_warm = &L->cfg_warm; pi.solve_cfg_full = &L->cfg_full;
-  pi.solve_x0 = x0; pi.solve_lane = L->solve_lane.data(); pi.solve_n_lane_pts = d.solve_n_lane_pts; pi.solve_target_vel = d.target_vel;
+  // warm-start fits of the previous plan's tree shapes start now, beside the predictor; with one in flight the plan does not begin the
+  // solves itself (TrajectoryTreeOptimizer.plan_solve_args returns None then)
+  if ((rc = loop_speculate(L, x0))) return rc;
+  if (!L->spec_pending) {
+    pi.solve_cfg_warm = &L->cfg_warm; pi.solve_cfg_full = &L->cfg_full;
+    pi.solve_x0 = x0; pi.solve_lane = L->solve_lane.data(); pi.solve_n_lane_pts = d.solve_n_lane_pts; pi.solve_target_vel = d.target_vel;
+  }
   L->have_plan = false;
   TRL("plan call begins");
   rc = mind_aime_plan(c, &pi, &L->po);
@@ -241,16 +395,33 @@ int loop_plan(mind_loop *L) {
   TRL("plan returned (solves begun)");
   const int nt = L->po.n_trees;
   if (nt <= 0) return fail(c, MIND_ESTATE, "mind_loop: the plan returned no scenario tree");
-  if (!L->po.solves_begun) return fail(c, MIND_ESTATE, "mind_loop: the plan could not begin its contingency solves (%s)", c->err.c_str());
-  // ---- collect the solves (mind_ilqr_finish_plan without the copy: the results stay in the context until its next plan)
-  if (!c->il_finish || !c->il_finish_owned) return fail(c, MIND_ESTATE, "mind_loop: no plan-begun tree-iLQR call is pending");
-  if ((rc = mind_ilqr_finish(c))) return rc;
-  const auto t2 = std::chrono::steady_clock::now();
-  TRL("solves collected");
   const int32_t *off = L->po.tree_off;
   const int M = off[nt];
-  if ((size_t)M * 6 != c->pl_sol_xs.size() || (size_t)nt != c->pl_sol_stf.size()) return fail(c, MIND_ESTATE, "mind_loop: the solves' results do not fit the plan");
-  const double *xs = c->pl_sol_xs.data(), *us = c->pl_sol_us.data();
+  const double *xs, *us;
+  const mind_ilqr_stats *stw, *stf;
+  L->last_agents_plan = a;
+  if (L->spec_pending) {
+    if ((rc = loop_solve_speculated(L, x0))) return rc;
+    xs = L->sol_xs.data(); us = L->sol_us.data(); stw = L->sol_stw.data(); stf = L->sol_stf.data();
+    L->sol_owned = true;
+  } else {
+    if (!L->po.solves_begun) return fail(c, MIND_ESTATE, "mind_loop: the plan could not begin its contingency solves (%s)", c->err.c_str());
+    // ---- collect the solves (mind_ilqr_finish_plan without the copy: the results stay in the context until its next plan)
+    if (!c->il_finish || !c->il_finish_owned) return fail(c, MIND_ESTATE, "mind_loop: no plan-begun tree-iLQR call is pending");
+    if ((rc = mind_ilqr_finish(c))) return rc;
+    if ((size_t)M * 6 != c->pl_sol_xs.size() || (size_t)nt != c->pl_sol_stf.size()) return fail(c, MIND_ESTATE, "mind_loop: the solves' results do not fit the plan");
+    xs = c->pl_sol_xs.data(); us = c->pl_sol_us.data(); stw = c->pl_sol_stw.data(); stf = c->pl_sol_stf.data();
+    L->sol_owned = false;
+  }
+  const auto t2 = std::chrono::steady_clock::now();
+  TRL("solves collected");
+  if (d.speculative) {           // the shapes the next cycle speculates on (_last_structs)
+    L->last_shapes.resize(nt);
+    for (int t = 0; t < nt; ++t) {
+      L->last_shapes[t].parent.assign(L->po.flat_parent + off[t], L->po.flat_parent + off[t + 1]);
+      L->last_shapes[t].prob.assign(L->po.flat_prob + off[t], L->po.flat_prob + off[t + 1]);
+    }
+  }
   // ---- evaluate_traj_tree of every candidate (planner.py:180-198): the tree's nodes = the root (x0, zero control) + its trajectory nodes
   L->eval_st.resize((size_t)(M + nt) * 6); L->eval_ct.resize((size_t)(M + nt) * 2); L->counts.resize(nt); L->costs.resize(nt);
   size_t o = 0;
@@ -282,9 +453,10 @@ int loop_plan(mind_loop *L) {
   // accounting (TrajectoryTreeOptimizer.counters, MINDPlanner.timing_sum; bench.py's live kernel durations when profiling is on)
   mind_loop_totals &S = L->tot;
   for (int t = 0; t < nt; ++t) {
-    const long long m = off[t + 1] - off[t], iw = c->pl_sol_stw[t].iterations, jf = c->pl_sol_stf[t].iterations;
+    const long long m = off[t + 1] - off[t], iw = stw[t].iterations, jf = stf[t].iterations;
     S.iterations += iw + jf; S.node_iterations += m * (iw + jf); S.node_iterations_exo += m * jf * a;
   }
+  S.warm_speculated = L->warm_speculated; S.warm_hits = L->warm_hits;
   S.plans += 1; S.expansions += L->po.n_expanded; S.scen_trees += nt; S.rounds += L->po.n_rounds;
   const double N = (double)(a + d.n_lanes + 1);
   S.scene_n2 += (double)L->po.n_expanded * N * N; S.scene_n_a1 += (double)L->po.n_expanded * N * (double)(a + 1);
@@ -385,6 +557,10 @@ extern "C" int mind_loop_create(mind_ctx *c, const mind_loop_desc *d, mind_loop 
 }
 
 extern "C" int mind_loop_destroy(mind_loop *L) {
+  if (L && L->side) {
+    (void)mind_ctx_destroy(L->side);
+    if (L->side_stream) (void)hipStreamDestroy(L->side_stream);
+  }
   delete L;
   return MIND_OK;
 }
@@ -394,6 +570,7 @@ extern "C" int mind_loop_reset(mind_loop *L) {
   L->sim_time = 0.0; L->have_trigger = false; L->last_trigger = -1.0; L->enabled = false; L->half_step = false;
   memcpy(L->state, L->ego_state.data(), 4 * sizeof(double));        // world.agent_state(0, 0.0)
   L->state_recorded = false; L->tan_valid = false;
+  if (L->spec_pending && L->side) { (void)mind_ilqr_finish(L->side); L->spec_pending = false; }
   L->ctrl[0] = 0.0; L->ctrl[1] = 0.0;
   L->ep_steps = 0;
   L->obs.clear();
@@ -432,10 +609,10 @@ extern "C" int mind_loop_last_plan(mind_loop *L, mind_aime_plan_out *plan, const
   if (!L->have_plan) return fail(L->c, MIND_ESTATE, "mind_loop_last_plan: the loop holds no plan");
   if (L->plan_gen != L->c->pl_gen) return fail(L->c, MIND_ESTATE, "mind_loop_last_plan: the context has planned again since (another planner shares it): the loop's plan tables are gone");
   *plan = L->po;
-  if (xs) *xs = L->c->pl_sol_xs.data();
-  if (us) *us = L->c->pl_sol_us.data();
-  if (stats_warm) *stats_warm = L->c->pl_sol_stw.data();
-  if (stats_full) *stats_full = L->c->pl_sol_stf.data();
+  if (xs) *xs = L->sol_owned ? L->sol_xs.data() : L->c->pl_sol_xs.data();
+  if (us) *us = L->sol_owned ? L->sol_us.data() : L->c->pl_sol_us.data();
+  if (stats_warm) *stats_warm = L->sol_owned ? L->sol_stw.data() : L->c->pl_sol_stw.data();
+  if (stats_full) *stats_full = L->sol_owned ? L->sol_stf.data() : L->c->pl_sol_stf.data();
   if (agent_tracks) *agent_tracks = L->kept.data();
   if (types) *types = L->f_types.data();
   if (x0) memcpy(x0, L->plan_x0, 6 * sizeof(double));

@@ -136,6 +136,10 @@ class NativeLoop:
         d.cfg_warm, d.cfg_full = C.addressof(keep["cw"]), C.addressof(keep["cf"])
         d.solve_n_lane_pts, d.solve_lane, d.target_vel = len(keep["gt"]), keep["gt"].ctypes.data, float(w.target_velocity)
         d.eval_n_lane_pts, d.eval_lane_is_f32, d.eval_lane = len(keep["ev"]), int(keep["ev"].dtype == np.float32), keep["ev"].ctypes.data
+        # the optimizer's speculative warm start inside the loop (a second context of the loop's own): opt-in, MIND_NATIVE_SPECULATE=1 --
+        # a lone loop gains nothing from it (profiles/r06q_*), several loops sharing the device do
+        self.speculative = bool(opt.speculative) and os.environ.get("MIND_NATIVE_SPECULATE", "0") == "1"
+        d.speculative = int(self.speculative)
         h = C.c_void_p()
         rc = self.lib.mind_loop_create(self.rt.ctx, C.byref(d), C.byref(h))
         _lib.check(self.lib, self.rt.ctx, rc, "mind_loop_create")
@@ -146,7 +150,8 @@ class NativeLoop:
         self._result = None            # the last plan's [[scenario tree], [trajectory tree]] once somebody asked for it
         cn, ts = opt.counters, pl.timing_sum
         self._base = dict(plans=ts["plans"], aime_s=ts["aime_s"], ilqr_s=ts["ilqr_s"], total_s=ts["total_s"], n_expanded=gen.n_expanded, solves=cn["solves"],
-                          iterations=cn["iterations"], node_iterations=cn.get("node_iterations", 0), node_iterations_exo=cn.get("node_iterations_exo", 0))
+                          iterations=cn["iterations"], node_iterations=cn.get("node_iterations", 0), node_iterations_exo=cn.get("node_iterations_exo", 0),
+                          warm_speculated=cn.get("warm_speculated", 0), warm_hits=cn.get("warm_hits", 0))
 
     def close(self):
         h, self.h = getattr(self, "h", None), None
@@ -223,7 +228,7 @@ class NativeLoop:
         ctx = self.rt.ctx         # (a runtime that was closed, or re-created, under the loop: the library's loop holds the old context)
         return (self.h is not None and ctx is not None and ctx.value == self._ctx_value and gen.native_aime and gen.device_root and gen.device_glue and gen.device_select and gen.shard is None
                 and gen.network is self._net and pl.network is self._net and opt.solver is None and opt.shard is None and opt.overlap
-                and pl.gt_tgt_lane is self._gt_obj and cfg is self._gen_cfg and opt.config is self._opt_cfg and pl._native_eval
+                and (not self.speculative or opt.speculative) and pl.gt_tgt_lane is self._gt_obj and cfg is self._gen_cfg and opt.config is self._opt_cfg and pl._native_eval
                 and (cfg.tar_time_ahead, cfg.tar_dist_thres, cfg.max_depth, gen.pred_len) == self._scen_fp
                 and w.target_lane is self._world_fp[0] and w.target_lane_info is self._world_fp[1] and w.target_velocity == self._world_fp[2]
                 and (self._fp(self._opt_cfg, "w_opt_cfg"), self._fp(self._opt_cfg, "opt_cfg")) == self._opt_fp)
@@ -262,6 +267,7 @@ class NativeLoop:
             gen.n_expanded = b["n_expanded"] + t.expansions
             cn["solves"], cn["iterations"] = b["solves"] + 2 * t.scen_trees, b["iterations"] + t.iterations
             cn["node_iterations"], cn["node_iterations_exo"] = b["node_iterations"] + t.node_iterations, b["node_iterations_exo"] + t.node_iterations_exo
+            cn["warm_speculated"], cn["warm_hits"] = b["warm_speculated"] + t.warm_speculated, b["warm_hits"] + t.warm_hits
             gen.n_native_plans += dp
             gen.branch_depth = o.n_rounds
         return dp

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _make(scene, native, episode_plans=None):
+def _make(scene, native, episode_plans=None, speculative=False):
     sys.path.insert(0, ROOT)
     from bench import BRANCHING_WEIGHTS, WORKLOADS
     from mind_amd.closed_loop import ClosedLoopSim
@@ -25,7 +25,7 @@ def _make(scene, native, episode_plans=None):
     w = ReplayWorld.from_scene_file(scene_fixture_path(wkw["scene"]))
     cfg = dict(json.load(open(cfg)), planning_config="planners.mind.configs.planning." + wkw["scene"], ckpt_path=BRANCHING_WEIGHTS)
     pl = MINDPlanner(cfg)
-    pl.traj_tree_opt.speculative = False
+    pl.traj_tree_opt.speculative = speculative
     sim = ClosedLoopSim(w, pl, episode_plans=episode_plans, native=native)
     sim.run_until(sim.enable_time)
     return pl, sim
@@ -187,3 +187,26 @@ def test_native_loop_whole_episode_equals_the_python_steps(scene):
         b = (np.array(sb.state), np.array(sb.ctrl), pb.timing["best_traj_idx"], np.array(pb.timing["tree_costs"]), sb.n_steps, pb.scen_tree_gen.n_expanded)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3]) and a[4:] == b[4:], block
     assert sa._native is not None and sa.n_plans == 60
+
+
+@pytest.mark.parametrize("scene", ["demo_2", "demo_4"])
+def test_native_loop_with_the_speculative_warm_start(scene, monkeypatch):
+    """MIND_NATIVE_SPECULATE=1: the loop runs the optimizer's speculative warm start itself (warm-start fits of the previous plan's tree shapes
+    on a second context beside the AIME rounds; hits run the full fit only, misses both fits beside them, the back-off schedule of
+    TrajectoryTreeOptimizer).  Same kernels on the same inputs: every cycle is the same bits as the Python steps WITHOUT speculation, and
+    the counters show that fits were speculated and used."""
+    monkeypatch.setenv("MIND_NATIVE_SPECULATE", "1")
+    pa, sa = _make(scene, None, episode_plans=30, speculative=True)
+    monkeypatch.delenv("MIND_NATIVE_SPECULATE")
+    pb, sb = _make(scene, False, episode_plans=30, speculative=False)
+    assert sa._native is not None and sa._native.speculative
+    for cycle in range(30):
+        sa.run_plans(1)
+        a = _snapshot(pa, sa)
+        sb.run_plans(1)
+        b = _snapshot(pb, sb)
+        a["counters"] = b["counters"] = {}            # (the speculation's own counters differ by design)
+        _same(a, b, cycle)
+    cn = pa.traj_tree_opt.counters
+    print(f"{scene}: {cn['warm_speculated']} warm-start fits speculated, {cn['warm_hits']} used, over 30 cycles")
+    assert cn["warm_speculated"] > 0
