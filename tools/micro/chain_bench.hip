@@ -14,7 +14,7 @@
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-__global__ __launch_bounds__(256) void k_link(const float *__restrict__ in, float *__restrict__ out, int n, long long work_cycles,
+__global__ __launch_bounds__(1024) void k_link(const float *__restrict__ in, float *__restrict__ out, int n, long long work_cycles,
                                                unsigned *flags, int idx, unsigned wait_count, int handoff, unsigned *err) {
   if (handoff && idx > 0) {
     if (threadIdx.x == 0) {
@@ -27,6 +27,8 @@ __global__ __launch_bounds__(256) void k_link(const float *__restrict__ in, floa
     }
     __syncthreads();
   }
+  extern __shared__ float dyn_lds[];
+  if (work_cycles < 0) dyn_lds[threadIdx.x] = 1.f;          // (never: keeps the dynamic LDS allocation alive)
   const long long t0 = wall_clock64();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float acc = 0.f;
@@ -43,6 +45,8 @@ __global__ __launch_bounds__(256) void k_link(const float *__restrict__ in, floa
 int main(int argc, char **argv) {
   const int links = argc > 1 ? atoi(argv[1]) : 26, grid = argc > 2 ? atoi(argv[2]) : 24, n = 1 << 18;
   const double work_us = argc > 3 ? atof(argv[3]) : 15.0;
+  const int lds_bytes = argc > 4 ? atoi(argv[4]) : 0, threads = argc > 5 ? atoi(argv[5]) : 256;      // dynamic LDS per workgroup, threads per workgroup
+  CK(hipFuncSetAttribute((const void *)k_link, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   int clk_khz = 0;
   CK(hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0));
   const long long work_cycles = (long long)(work_us * 100.0);          // wall_clock64 ticks at 100 MHz
@@ -65,7 +69,7 @@ int main(int argc, char **argv) {
       const auto t0 = std::chrono::steady_clock::now();
       for (int i = 0; i < links; ++i) {
         hipStream_t s = mode ? st[i & 1] : st[0];
-        hipLaunchKernelGGL(k_link, dim3(grid), dim3(256), 0, s, (const float *)buf[i & 1], buf[(i + 1) & 1], n, work_cycles, flags, i, (unsigned)grid, mode, err);
+        hipLaunchKernelGGL(k_link, dim3(grid), dim3(threads), lds_bytes, s, (const float *)buf[i & 1], buf[(i + 1) & 1], n, work_cycles, flags, i, (unsigned)grid, mode, err);
       }
       CK(hipStreamSynchronize(st[0]));
       if (mode) CK(hipStreamSynchronize(st[1]));
@@ -78,7 +82,7 @@ int main(int argc, char **argv) {
       if (!ok) { printf("mode %d rep %d: WRONG RESULT (err %u, h[0] = %g, want %d)\n", mode, rep, e, h[0], links); break; }
     }
     std::sort(ms.begin(), ms.end());
-    printf("mode %d (%s): %d links x %d workgroups, ~%.0f us of work each: median %.3f ms  min %.3f ms  -> %.2f us per link beyond the work\n", mode,
+    printf("[lds %d B, %d threads] mode %d (%s): %d links x %d workgroups, ~%.0f us of work each: median %.3f ms  min %.3f ms  -> %.2f us per link beyond the work\n", lds_bytes, threads, mode,
            mode ? "two streams, in-kernel hand-off" : "one stream", links, grid, work_us, ms[ms.size() / 2], ms[0], (ms[0] * 1e3 - links * work_us) / links);
   }
   (void)ev;
