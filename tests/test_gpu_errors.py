@@ -106,3 +106,47 @@ def test_plan_begun_solves_that_are_never_collected_do_not_outlive_their_plan():
         assert got[0] and want[0] and np.array_equal(np.asarray(got[1]), np.asarray(want[1])), cycle
         assert pl.timing["best_traj_idx"] == ref_pl.timing["best_traj_idx"]
         ref_sim.step_end(want); sim.step_end(got)
+
+
+def test_native_loop_errors_are_codes_and_messages():
+    """mind_loop_*: a bad descriptor, scene tables that end, a plan read before there is one, a sharded context -- negative codes and a
+    message, never a crash; the context (shared with the other tests of the process) stays usable."""
+    import ctypes as C
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    from bench import BRANCHING_WEIGHTS, WORKLOADS, make_closed_loop
+    pl, sim, w = make_closed_loop(dict(WORKLOADS["demo_1"]), ckpt=BRANCHING_WEIGHTS, native=None)
+    nl = sim._native
+    assert nl is not None
+    lib, ctx = nl.lib, nl.rt.ctx
+    # a descriptor without tables
+    bad = _lib.LoopDesc()
+    h = C.c_void_p()
+    assert lib.mind_loop_create(ctx, C.byref(bad), C.byref(h)) == _lib.MIND_EINVAL
+    assert b"bad argument" in lib.mind_last_error_string(ctx)
+    assert lib.mind_loop_create(ctx, None, C.byref(h)) == _lib.MIND_EINVAL
+    # no plan yet: nothing to hand out
+    po = _lib.AimePlanOut()
+    ptr = [C.c_void_p() for _ in range(6)]
+    x0 = np.zeros(6)
+    assert lib.mind_loop_last_plan(nl.h, C.byref(po), *[C.byref(p) for p in ptr], x0.ctypes.data) == _lib.MIND_ESTATE
+    assert sim.last_result is None
+    # the scene tables cover one episode (+ a cycle): stepping past them is refused, and the loop can be reset
+    sim.episode_plans = None
+    out = _lib.LoopOut()
+    rc = lib.mind_loop_advance(nl.h, 0, -1.0, 10 ** 6, C.byref(out))
+    assert rc == _lib.MIND_EINVAL and b"scene tables end" in lib.mind_last_error_string(ctx)
+    assert out.n_plans >= 60 and np.all(np.isfinite(np.array(out.state)))
+    assert lib.mind_loop_reset(nl.h) == 0
+    assert lib.mind_loop_advance(nl.h, 1, -1.0, 10 ** 6, C.byref(out)) == 0 and out.planned == 1
+    # a sharded context plans through its exchange: the loop refuses it
+    cb = _lib.EXCHANGE_FN(lambda user, op, send, recv, nbytes: 0)
+    assert lib.mind_set_exchange(ctx, 0, 2, cb, None, 0) == 0
+    try:
+        assert lib.mind_loop_advance(nl.h, 1, -1.0, 10 ** 6, C.byref(out)) == _lib.MIND_ESTATE
+        assert b"sharded" in lib.mind_last_error_string(ctx)
+    finally:
+        assert lib.mind_set_exchange(ctx, 0, 1, C.cast(None, _lib.EXCHANGE_FN), None, 0) == 0
+    assert lib.mind_loop_advance(nl.h, 1, -1.0, 10 ** 6, C.byref(out)) == 0 and out.planned == 1
