@@ -787,7 +787,9 @@ __device__ int dec_trn_;
 // outputs (dense_quads_part: the same K split and per-item arithmetic, the same bits) and the rows meet through global memory and a
 // barrier of the scene's workgroups (dec_exchange; two alternating buffers: a workgroup can be at most one stage ahead of the slowest).
 // Block b -> scene 8 (b / 8G) + b % 8, workgroup (b % 8G) / 8: a scene's workgroups share an XCD (one L2), as in k_ilqr.
-template <bool MW>
+// PART 0: the whole scene part; 1: up to the mode tokens C (what the actor part needs); 2: the cls head alone, from the C of a PART 1 launch
+// (k_dec_cls: on the side stream beside the actor part's head -- the same code on the same values: the same bits)
+template <bool MW, int PART = 0>
 __device__ __forceinline__ void k_dec_scene_body(const float *__restrict__ x /*[tokens,128]*/,
                                                  const int *__restrict__ cls_row /*[B]*/,
                                                  float *__restrict__ Cout /*[B,6,128]*/,
@@ -811,6 +813,11 @@ __device__ __forceinline__ void k_dec_scene_body(const float *__restrict__ x /*[
   if (blockIdx.x == 0 && tid == 0) dec_trn_ = 0;
 #endif
   DEC_MARK();
+  if (PART == 2) {
+    for (int i = tid; i < 768; i += blockDim.x) C[i / 128][i % 128] = Cout[(size_t)b * 768 + i];
+    __syncthreads();
+  }
+  if (PART != 2) {
   // ---- ctx_proj: cls token -> 6 mode tokens (network.py:501)
   if (tid < 128) v0[0][tid] = x[(size_t)cls_row[b] * 128 + tid];
   __syncthreads();
@@ -892,6 +899,8 @@ __device__ __forceinline__ void k_dec_scene_body(const float *__restrict__ x /*[
   }
   if (!MW || wg == 0)
     for (int i = tid; i < 768; i += blockDim.x) Cout[(size_t)b * 768 + i] = C[i / 128][i % 128];
+  }
+  if (PART == 1) return;
   // ---- cls head on the mode tokens only (network.py:512, Q6), softmax over the 6 modes
   dense<6>(&C[0][0], 128, 128, W.k0W, W.k0b, 128, &att[0][0], 128, part, PF);
   DEC_MARK();
@@ -932,6 +941,14 @@ __device__ __forceinline__ void k_dec_scene_body(const float *__restrict__ x /*[
 __global__ __launch_bounds__(DT) void k_dec_scene(const float *__restrict__ x, const int *__restrict__ cls_row, float *__restrict__ Cout,
                                                   float *__restrict__ cls_out, DecW W) {
   k_dec_scene_body<false>(x, cls_row, Cout, cls_out, W, (int)blockIdx.x, 0, 1, nullptr, nullptr, nullptr);
+}
+// the scene part in two launches: the mode tokens (k_dec_scene_c, context stream: the actor part's head waits for nothing else of it) and the
+// mode probabilities (k_dec_cls, side stream, beside that head)
+__global__ __launch_bounds__(DT) void k_dec_scene_c(const float *__restrict__ x, const int *__restrict__ cls_row, float *__restrict__ Cout, DecW W) {
+  k_dec_scene_body<false, 1>(x, cls_row, Cout, nullptr, W, (int)blockIdx.x, 0, 1, nullptr, nullptr, nullptr);
+}
+__global__ __launch_bounds__(DT) void k_dec_cls(float *__restrict__ Cout, float *__restrict__ cls_out, DecW W) {
+  k_dec_scene_body<false, 2>(nullptr, nullptr, Cout, cls_out, W, (int)blockIdx.x, 0, 1, nullptr, nullptr, nullptr);
 }
 #define DEC_MW_G 8
 // xbuf [B][2][6 x 1536] floats, bars [B][4] words (zero once, at allocation: the barrier resets itself), abort_word host-visible

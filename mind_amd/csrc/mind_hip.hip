@@ -68,7 +68,7 @@ struct mind_ctx {
   // internal side stream: the lane encoders run beside the actor encoder; always fenced against `stream` with
   // events on both sides, so callers only ever see work ordered on `stream`
   hipStream_t side = nullptr;
-  hipEvent_t ev_side = nullptr, ev_main = nullptr, ev_stage = nullptr, ev_tgt = nullptr;
+  hipEvent_t ev_side = nullptr, ev_main = nullptr, ev_stage = nullptr, ev_tgt = nullptr, ev_cls = nullptr;
   std::vector<char> aime_stage;   // host staging of mind_aime_world's small tables (guarded by ev_stage)
   bool aime_stage_busy = false;
   std::string err;
@@ -194,6 +194,10 @@ struct mind_ctx {
   // cycles); the feed-forward layers are bound by their 24 accumulators per thread and win 2-4 k cycles each, less the 36 KB exchange --
   // 12 us per plan, not worth eight spinning workgroups per scene when several scenes share the device
   bool dec_mw = false;
+  // the decoder's cls head as its own launch on the side stream beside the actor part's head ("dec_cls_side" / MIND_DEC_CLS_SIDE=1).  Opt-in:
+  // bit-identical, but the second launch and its two event waits cost more than the ~10 us of overlap (1 609-1 630 against 1 632-1 652
+  // sim steps/s, profiles/r06am_*)
+  bool dec_cls_side = false;
   DevBuf dec_xbuf, dec_bars;
   unsigned *dec_abort = nullptr;      // host-visible abort word of its barriers (page-locked, mapped)
   int rb_cur = 0, rb_gen = 0;     // re-basing arenas: which one the last call filled, its generation and geometry
@@ -337,6 +341,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *te = getenv("MIND_TOK_SMALL_MAX")) c->tok_small_max = atoi(te);
   if (const char *te = getenv("MIND_TOK_MERGE")) c->tok_merge = !(te[0] == '0');
   if (const char *te = getenv("MIND_DEC_MW")) c->dec_mw = !(te[0] == '0');
+  if (const char *te = getenv("MIND_DEC_CLS_SIDE")) c->dec_cls_side = !(te[0] == '0');
   if (const char *te = getenv("MIND_TOK_BF_MIN_N")) c->tok_bf_min_n = atoi(te);
   if (const char *te = getenv("MIND_TGT_SIDE")) c->tgt_side = !(te[0] == '0');
   if (const char *te = getenv("MIND_PL_TAB_SIDE")) c->pl_tab_side = !(te[0] == '0');
@@ -348,6 +353,8 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *we = getenv("MIND_ILQR_SLOTS")) { const int v = atoi(we); c->ilqr_slots = v < 1 ? 1 : (v > IL_SLOTS ? IL_SLOTS : v); }
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_scene_mw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_dec_scene_c, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
+  (void)hipFuncSetAttribute((const void *)k_dec_cls, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_tgt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_actor<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_actor<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_actor_lds_bytes());
@@ -393,6 +400,7 @@ extern "C" int mind_ctx_destroy(mind_ctx *c) {
   if (c->ev_main) (void)hipEventDestroy(c->ev_main);
   if (c->ev_tgt) (void)hipEventDestroy(c->ev_tgt);
   if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
+  if (c->ev_cls) (void)hipEventDestroy(c->ev_cls);
   if (c->ev_il0) (void)hipEventDestroy(c->ev_il0);
   if (c->ev_il1) (void)hipEventDestroy(c->ev_il1);
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
@@ -426,6 +434,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "tok_small_max") c->tok_small_max = (int)value;
   else if (n == "tok_merge") c->tok_merge = value != 0;
   else if (n == "dec_mw") c->dec_mw = value != 0;
+  else if (n == "dec_cls_side") c->dec_cls_side = value != 0;
   else if (n == "tok_bf_min_n") c->tok_bf_min_n = (int)value;
   else if (n == "tgt_side") c->tgt_side = value != 0;
   else if (n == "pl_tab_side") c->pl_tab_side = value != 0;
@@ -1512,6 +1521,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   }
   // the scene part: eight workgroups per scene while the whole launch is resident (one workgroup per CU: 158 KB of LDS), else one per scene --
   // the two kernels give the same bits, so a scene's result does not depend on the size of its batch
+  bool cls_on_side = false;
   const int mw_blocks = ((Bn + 7) / 8) * 8 * DEC_MW_G;
   bool mw = c->dec_mw && mw_blocks <= c->n_cu;
   if (mw) {
@@ -1532,7 +1542,17 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   if (mw)
     hipLaunchKernelGGL(k_dec_scene_mw, dim3(mw_blocks), dim3(DT), mind_dec_scene_lds_bytes(), st, x, d_cls_row, (float *)c->cmode.p, out->cls, c->decW, Bn,
                        (float *)c->dec_xbuf.p, (unsigned *)c->dec_bars.p, c->dec_abort);
-  else
+  else if (split_dec && c->dec_cls_side) {
+    // the mode tokens on the context stream, the mode probabilities (the cls head: ~10 us a launch) on the side stream beside the actor part's
+    // head, which needs the tokens only; the caller's next work on the context stream follows both
+    hipLaunchKernelGGL(k_dec_scene_c, dim3(Bn), dim3(DT), mind_dec_scene_lds_bytes(), st, x, d_cls_row, (float *)c->cmode.p, c->decW);
+    HIPCHK(c, hipEventRecord(c->ev_main, st));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0));
+    hipLaunchKernelGGL(k_dec_cls, dim3(Bn), dim3(DT), mind_dec_scene_lds_bytes(), c->side, (float *)c->cmode.p, out->cls, c->decW);
+    if (!c->ev_cls) HIPCHK(c, hipEventCreateWithFlags(&c->ev_cls, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_cls, c->side));
+    cls_on_side = true;
+  } else
     hipLaunchKernelGGL(k_dec_scene, dim3(Bn), dim3(DT), mind_dec_scene_lds_bytes(), st, x, d_cls_row, (float *)c->cmode.p, out->cls, c->decW);
   if (c->side) HIPCHK(c, hipStreamWaitEvent(st, c->ev_tgt, 0));      // the decoder's actor part reads the target embedding
   // actor part of the decoder: the K-split fp32 kernel (a handful of workgroups, bound by the latency of one pass over the weights:
@@ -1554,6 +1574,7 @@ extern "C" int mind_predict_batch(mind_ctx *c, const mind_scene_batch *in, mind_
   else
     hipLaunchKernelGGL(k_dec_actor_mfma<1>, dim3((A + DM_RA - 1) / DM_RA), dim3(DM_T), mind_dec_actor_mfma_lds_bytes(), st, x, d_actor_row,
                        d_actor_scene, A, (const float *)c->cmode.p, (const float *)c->tgt_emb.p, out->reg, out->vel, c->decBW);
+  if (cls_on_side) HIPCHK(c, hipStreamWaitEvent(st, c->ev_cls, 0));      // whatever follows on the context stream sees the mode probabilities too
   if (out->actor_emb || out->cls_emb) {
     // debug taps: gather fused tokens
     for (int a = 0; a < A && out->actor_emb; ++a)

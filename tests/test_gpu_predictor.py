@@ -336,6 +336,21 @@ def test_token_kernel_with_merged_projections_equals_the_plain_one(hip_predictor
             assert torch.equal(merged[k], plain[k]), k
 
 
+def test_decoder_cls_head_on_the_side_stream_equals_the_one_launch_form(hip_predictor):
+    """mind_set_tuning("dec_cls_side", 1): the scene part of the decoder as two launches -- the mode tokens (k_dec_scene_c) and, on the side stream
+    beside the actor part's head, the mode probabilities (k_dec_cls).  The same code on the same values: every output the same bits
+    (opt-in: measured slower than the one-launch kernel)."""
+    for pb in (predictor_batch(40, 55, 1, seed=1), predictor_batch(7, 12, 5, seed=3), predictor_batch(1, 3, 2, seed=5)):
+        one = {k: v.clone() for k, v in hip_predictor.predict_numpy_batch(pb).items() if torch.is_tensor(v)}
+        try:
+            hip_predictor.set_tuning("dec_cls_side", 1)
+            two = {k: v.clone() for k, v in hip_predictor.predict_numpy_batch(pb).items() if torch.is_tensor(v)}
+        finally:
+            hip_predictor.set_tuning("dec_cls_side", 0)
+        for k in ("cls", "reg", "vel"):
+            assert torch.equal(two[k], one[k]), k
+
+
 def test_decoder_scene_part_on_eight_workgroups_equals_the_one_workgroup_kernel(hip_predictor):
     """With mind_set_tuning("dec_mw", 1) calls of at most n_cu / 8 scenes run k_dec_scene_mw: eight workgroups per scene share the decoder's
     five big stages with the K split and per-item arithmetic of the one-workgroup kernel (opt-in: 6 us of a 95 us launch).  Every output
