@@ -88,7 +88,12 @@ __device__ __forceinline__ void split3_group(const f32x4 &v0, const f32x4 &v1, u
 template <bool FLY, int ABL>
 __device__ __forceinline__ void gemm6(frag8 &acc, const u32 *wa, __amdgpu_buffer_rsrc_t wg, const frag8 &src, const u32x4 (&bh4)[4],
                                       const u32x4 (&bm4)[4], const u32x4 (&bl4)[4], int lane, const float *trow = nullptr, f32x4 *Tn = nullptr) {
-  constexpr int NOB = P6_GEMM_NOB, SPG = 8 / NOB, NST = 4 * SPG, RING = NOB == 2 ? 2 : 1;
+#ifndef P6_LO_RING
+// steps the lo fragments travel ahead.  Measured 3 / 4 deep (24 x N = 321 launch, profiles/r06aq_pair6_bench_lo_ring.txt): 1.39 / 1.40 against 1.42-1.43 ms,
+// but both need 256 VGPRs + 32-40 B of scratch per wave (a private segment on every launch, the 30 us demo-size ones included): left at 2
+#define P6_LO_RING (P6_GEMM_NOB == 2 ? 2 : 1)
+#endif
+  constexpr int NOB = P6_GEMM_NOB, SPG = 8 / NOB, NST = 4 * SPG, RING = P6_LO_RING;
   int lo_ = lane * 4;
   OPAQUE(lo_);
   const u32 *wl = wa + lo_;
