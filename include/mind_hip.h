@@ -126,6 +126,9 @@ int mind_set_pair_precision(mind_ctx *ctx, int mode);
  * "ilqr_slots" (narrow cost trees: workgroups per tree that take the fit's Levenberg-Marquardt slots -- the master evaluates slot 0 of every
  * pass, a follower the value the schedule reaches after its number of rejections; default 10, at most 12, 1 = everything in one workgroup; followers
  * that are not resident are simply not used; same bits for every value; MIND_ILQR_SLOTS),
+ * "ilqr_spec_deriv" (1, default: with slots on follower workgroups one more workgroup per tree runs the derivative pass of a pass's first
+ * candidate beside the master's pricing of the candidates, and the master swaps derivative sets instead of differentiating when that
+ * candidate is the accepted one; same bits; mind_last_ilqr_stats counts it among the workgroups per tree; MIND_ILQR_SPEC_DERIV),
  * "actor_f32" (0: the fp32 VALU ActorNet instead of the fp32-MFMA one under the exact-fp32 setting), "actor_f32_min" / "actor_f32_pair_min" (actors per
  * call from which the fp32-MFMA ActorNet runs with two actors per workgroup, under every setting / under exact fp32; default never), "enc_mfma" (0: the fp32 VALU ActorNet / decoder kernels under every precision), "actor_split" (6: three-way operand split,
  * fp32-class; 3: two-way), "xcd_order" (XCD-aware job order of the pair kernel), "tok_mfma" (1: the per-token epilogue / prologue of the fusion layers on the fp32 MFMA kernel k_token_mfma instead of the fp32 VALU one; off by default: measured slower), "tok_small_max" (batches of at most this many tokens run k_token with four tokens per workgroup instead of eight; same bits), "tgt_side" (0: the context stream waits for the target embedding before the fusion layers), "dec_overlap" (0: the decoder's actor part as one kernel behind

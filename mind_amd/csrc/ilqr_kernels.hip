@@ -72,6 +72,8 @@ struct IlSlotCtl {
   unsigned done[IL_SLOTS];
   unsigned sing[IL_SLOTS];
   double Jnew[IL_SLOTS][IL_NA];
+  // the derivative speculator (il_speculate): sreq = generation of the pass whose first candidate it shall differentiate, sdone = the one it has
+  unsigned sreq, sdone, spad0, spad1;
 };
 
 struct IlqrTreeDev {
@@ -110,6 +112,11 @@ struct IlqrTreeDev {
   GP<const double> field;      // [M, H*W] cost_field of every node's PotentialField, or null
   GP<const double> node_w;     // [M, IL_NW]: w_des[6] w_con[6] lb[6] ub[6] w_ctrl[2] des[6], or null
   // outputs
+  // second set of what the derivative pass writes (k_ilqr<GEN, 2> with a derivative speculator; dset == 0 otherwise): the host lays both
+  // sets out alike, `dset` doubles (relag, Fx, L, Lx, Lxx) and `drel` ints (rel) apart -- two words instead of six more pointers in the
+  // kernel's scalar registers.  Inside the master Fx .. rel are always the set of the nominal trajectory (il_flip_sets moves them and negates
+  // the distances); followers and the speculator hold the launch's pointers and take the master's word (cmd bit 24) for which is which
+  long long dset, drel;
   GP<double> stats;            // [IL_NSTAT]: iterations, converged, J, mu, phase cycles, profile slots
   // per-iteration trace of the fit (mind_last_ilqr_trace): IL_TRACE_W doubles per reference iteration {mu the backward pass ran with,
   // J of the nominal trajectory, accepted alpha index (-1: step rejected, -2: singular Q_uu), J of the accepted candidate}
@@ -1326,8 +1333,15 @@ __device__ __forceinline__ void il_reject_update(double &mu, double &delta) {
 // SLOTS (k_ilqr<GEN, 2>, this workgroup = the master of its tree, T.ctl != null): every pass is published to the tree's follower workgroups,
 // which evaluate the Levenberg-Marquardt slots 1 .. n - 1 on their own CUs (il_follow) while this workgroup evaluates slot 0 as a single workgroup
 // would: a run of rejections costs one pass per n iterations and the accepted iterations cost what they always did.
+__device__ __forceinline__ void il_flip_sets(IlqrTreeDev &T) {
+  T.relag.p += T.dset; T.Fx.p += T.dset; T.L.p += T.dset; T.Lx.p += T.dset; T.Lxx.p += T.dset; T.rel.p += T.drel;
+  T.dset = -T.dset; T.drel = -T.drel;
+}
+
+// `cur` (SLOTS with a derivative speculator, T.dset != 0): which of the launch's two derivative sets T.Fx .. T.rel are at the moment (0 = as
+// launched); it lives across the fits of a launch -- a late speculation of the previous fit still writes the set that is NOT the nominal one.
 template <bool GEN, bool MULTI, bool SLOTS>
-__device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C, int ph, double *stats, double *trace, int wg, int G, unsigned *bar, unsigned *abort_word) {
+__device__ __forceinline__ void il_fit(IlqrTreeDev &T, int &cur, const IlqrConst &C, int ph, double *stats, double *trace, int wg, int G, unsigned *bar, unsigned *abort_word) {
   extern __shared__ double il_dsm[];
   // LDS carve: per-wave scratch [IL_WAVES][IL_SCR] | cost sums [IL_LSUM] | compact records [IL_RECS] | staging [IL_DSTG] floats
   double *scr = il_dsm + (size_t)(threadIdx.x >> 6) * IL_SCR;
@@ -1342,6 +1356,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
   __shared__ double Jnew[IL_SLOTS][IL_NA];
   __shared__ double sh_mu, sh_delta, sh_J;
   __shared__ int sh_accepted, sh_converged, sh_stop, sh_sing, sh_pick, sh_slot, sh_it, sh_nspec, sh_hint, sh_ntot;
+  __shared__ int sh_spec, sh_hit, sh_nreq, sh_nhit;      // derivative speculator: asked this pass / its set is the accepted candidate's / counts
   __shared__ unsigned sh_gen;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = T.M;
@@ -1353,6 +1368,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
 #endif
   if (tid == 0) {
     sh_mu = 1.0; sh_delta = 2.0; sh_accepted = 1; sh_converged = 0; sh_stop = 0; sh_J = 0.0; sh_pick = 0; sh_slot = 0; sh_it = 0; sh_hint = 1; sh_ntot = 1;
+    sh_spec = 0; sh_hit = 0; sh_nreq = 0; sh_nhit = 0;
     if (SLOTS) sh_gen = __hip_atomic_load(&T.ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (this workgroup is its only writer)
   }
   if (MULTI && wg == 0 && tid == 0) {       // singular-slot words of both pass parities (read behind the barriers below)
@@ -1368,6 +1384,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
     const int e = q % 36;
     T.Fx[q] = (e % 7 == 0) ? 1.0 : (e == 16 ? C.dt : 0.0);
     T.Lxx[q] = 0.0;
+    if (SLOTS && T.dset) { (T.Fx + T.dset)[q] = (e % 7 == 0) ? 1.0 : (e == 16 ? C.dt : 0.0); (T.Lxx + T.dset)[q] = 0.0; }
   }
   IL_SYNC();
   for (int s = 0; s < T.n_fsteps; ++s) {
@@ -1391,8 +1408,20 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       const GP<double> xn = T.xs_new + off * 6, un = T.us_new + off * 2;
       for (int q = gt; q < M * 6; q += nt) T.xs[q] = xn[q];
       for (int q = gt; q < M * 2; q += nt) T.us[q] = un[q];
-      IL_SYNC();
-      il_deriv_pass<GEN>(C, T, lsum, dstg, recs0, reinterpret_cast<unsigned *>(lsum + 9 * 64), MULTI ? wg : 0, MULTI ? G : 1, staged IL_PROF_PASS);
+      if (SLOTS && sh_hit) {
+        // the accepted candidate is the one the speculator took (slot 0, first step size) while this workgroup priced the candidates: its
+        // derivatives lie in the other set -- wait for the rest of them (il_speculate publishes as a follower does: see the selection below)
+        if (tid == 0) {
+          IlSlotCtl *ctl = T.ctl;
+          while (__hip_atomic_load(&ctl->sdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sh_gen) __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        il_flip_sets(T);
+        cur ^= 1;
+      } else {
+        IL_SYNC();
+        il_deriv_pass<GEN>(C, T, lsum, dstg, recs0, reinterpret_cast<unsigned *>(lsum + 9 * 64), MULTI ? wg : 0, MULTI ? G : 1, staged IL_PROF_PASS);
+      }
       IL_SYNC();
       if (M <= IL_LSUM) {
         for (int q = tid; q < M; q += IL_THREADS) lsum[q] = T.L[q];
@@ -1417,7 +1446,10 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       // followers: every pass carries as many slots as there are workgroups (their CUs would idle otherwise), this one evaluates slot 0.  They
       // are used only once ALL of them run (a launch that is not fully resident keeps its slots in this workgroup: nobody waits for a
       // workgroup that has not started)
-      const bool fol = SLOTS && G > 1 && (__hip_atomic_load(&T.ctl->alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | 1u) == (1u << G) - 1u;
+      const unsigned alive = SLOTS ? __hip_atomic_load(&T.ctl->alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      const bool fol = SLOTS && G > 1 && ((alive | 1u) & ((1u << G) - 1u)) == (1u << G) - 1u;
+      sh_spec = SLOTS && fol && T.dset && ((alive >> G) & 1u);        // (the speculator is workgroup G of the tree)
+      sh_hit = 0;
       if (fol) ns = G < IL_SLOTS ? G : IL_SLOTS;
       if (ns > C.max_iter - sh_it) ns = C.max_iter - sh_it;
       double mu = sh_mu, de = sh_delta;
@@ -1430,7 +1462,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
         // the command of this pass (the derivative pass above ended with a workgroup barrier: its writes are ordered before this release)
         IlSlotCtl *ctl = T.ctl;
         ctl->mu = sh_mu; ctl->delta = sh_delta;
-        __hip_atomic_store(&ctl->cmd, (unsigned)(fol ? sh_ntot : 1) | ((unsigned)ph << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->cmd, (unsigned)(fol ? sh_ntot : 1) | ((unsigned)ph << 8) | ((unsigned)cur << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sh_gen += 1u;
         __hip_atomic_store(&ctl->gen, sh_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -1543,6 +1575,12 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
         il_cost_pass<GEN>(C, T, nuse, recs, rank, nw, T.fstep_nodes + (size_t)n0, cnt, 0 IL_PROF_PASS);
       }
       IL_SYNC();
+      // the state chains are through: the speculator differentiates candidate (slot 0, first step size) while the last costs, the sums and the
+      // selection run here (every wave's xs_new / us_new stores are complete behind the barrier above; this release publishes them)
+      if (SLOTS && s == T.n_fsteps - 1 && tid == 0 && sh_spec) {
+        __hip_atomic_store(&T.ctl->sreq, sh_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        sh_spec = 2; sh_nreq += 1;
+      }
     }
     IL_MARK(t_ls);
     if (M * IL_NA * nuse <= IL_LSUM) {
@@ -1607,6 +1645,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
       }
       sh_mu = mu; sh_delta = de; sh_it = it;
       sh_hint = (sh_accepted && sh_slot == 0) ? 1 : IL_SPEC;
+      if (SLOTS && sh_spec == 2 && sh_accepted && sh_slot == 0 && sh_pick == 0) { sh_hit = 1; sh_nhit += 1; }
       // An accepted candidate of a follower's slot is adopted (at the top of the next pass, by every thread) from that slot's arrays.  What makes
       // the follower's writes visible to this CU's plain loads is the pattern of il_tree_sync (MI355X_MICROARCH.md, inter-workgroup visibility):
       // producer side -- every wave's stores are complete behind the follower's `__threadfence_block(); __syncthreads()`, then its thread 0
@@ -1635,6 +1674,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
     for (int q = 0; q < 16; ++q) stats[8 + q] = (double)prof[q];
 #else
     stats[8] = (double)t_roll;          // state-chain part of the line search (stats[6] = its cost pass)
+    stats[9] = (double)sh_nreq; stats[10] = (double)sh_nhit;      // derivative speculator: passes it was asked in / accepted candidates it had ready
 #endif
     stats[IL_NSTAT - 1] = (double)n_pass;
   }
@@ -1648,7 +1688,7 @@ __device__ __forceinline__ void il_fit(const IlqrTreeDev &T, const IlqrConst &C,
 // il_cost_pass: same arithmetic per item), publishes them and waits again.  It only ever READS the nominal trajectory and its derivatives; a
 // command it picks up late (the master accepted an earlier slot and moved on) yields a result nobody reads.
 template <bool GEN>
-__device__ __forceinline__ void il_follow(const IlqrTreeDev &T, const IlqrConst *consts, int wg) {
+__device__ __forceinline__ void il_follow(const IlqrTreeDev &T0, const IlqrConst *consts, int wg) {
   extern __shared__ double il_dsm[];
   double *scr = il_dsm + (size_t)(threadIdx.x >> 6) * IL_SCR;
   double *lsum = il_dsm + (size_t)IL_WAVES * IL_SCR;
@@ -1658,8 +1698,8 @@ __device__ __forceinline__ void il_follow(const IlqrTreeDev &T, const IlqrConst 
   __shared__ double f_mu, f_de;
   __shared__ int f_sing, f_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int M = T.M;
-  IlSlotCtl *ctl = T.ctl;
+  const int M = T0.M;
+  IlSlotCtl *ctl = T0.ctl;
   if (tid == 0) __hip_atomic_fetch_or(&ctl->alive, 1u << wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   unsigned last = 0;
   int ph_cst = -1;
@@ -1675,7 +1715,7 @@ __device__ __forceinline__ void il_follow(const IlqrTreeDev &T, const IlqrConst 
     __syncthreads();
     const unsigned g = f_gen, cmd = f_cmd;
     last = g;
-    if (cmd >> 16) return;
+    if ((cmd >> 16) & 0xffu) return;
     const int ns = (int)(cmd & 0xffu), ph = (int)((cmd >> 8) & 0xffu);
     if (wg >= ns) continue;
     const IlqrConst &C = consts[ph];
@@ -1685,6 +1725,8 @@ __device__ __forceinline__ void il_follow(const IlqrTreeDev &T, const IlqrConst 
     }
     double mu = f_mu, de = f_de;
     for (int e = 0; e < wg; ++e) il_reject_update(mu, de);
+    IlqrTreeDev T = T0;
+    if ((cmd >> 24) & 1u) il_flip_sets(T);        // the master's nominal derivatives are in the second set (a speculated pass was accepted)
     IlqrTreeDev Ts = T;
     Ts.k += (size_t)wg * M * 2; Ts.K += (size_t)wg * M * 12; Ts.Vx += (size_t)wg * M * 6; Ts.Vxx += (size_t)wg * M * 36;
     // ---- backward pass of this slot (solver.py:332-373), as in il_fit
@@ -1802,6 +1844,60 @@ __device__ __forceinline__ void il_follow(const IlqrTreeDev &T, const IlqrConst 
   }
 }
 
+// The derivative speculator of a tree whose slots are spread over workgroups (workgroup G, behind the followers).  An accepted pass of the
+// master is: backward sweep, state chains, [the last costs, the ten sums, the selection], then the derivative pass at the accepted candidate --
+// which is the pass's FIRST candidate (slot 0, step size alphas[0]) for three accepted iterations in four of the recorded loops
+// (tests/diag/gpu_ilqr_alpha_hist.py).  This workgroup runs that derivative pass -- il_deriv_pass itself, on xs_new / us_new of (slot 0, alpha 0),
+// into the derivative set the nominal trajectory does NOT use -- as soon as the master's state chains are through (ctl->sreq), i.e. beside the
+// bracketed part; the master, when its selection names exactly that candidate, waits for ctl->sdone and swaps the sets (il_flip_sets)
+// instead of differentiating.  Same code on the same inputs: the same bits; a miss costs the master nothing (it never waits for a result
+// it does not use) and a result nobody uses is overwritten by the next request.
+template <bool GEN>
+__device__ __forceinline__ void il_speculate(const IlqrTreeDev &T0, const IlqrConst *consts, int wg) {
+  extern __shared__ double il_dsm[];
+  double *lsum = il_dsm + (size_t)IL_WAVES * IL_SCR;
+  double *recs0 = lsum + IL_LSUM;
+  float *dstg = reinterpret_cast<float *>(recs0 + IL_RECS);
+  __shared__ unsigned s_req, s_cmd;
+  const int tid = threadIdx.x;
+  IlSlotCtl *ctl = T0.ctl;
+  if (tid == 0) __hip_atomic_fetch_or(&ctl->alive, 1u << wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned last = 0;
+  bool staged = false;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) {
+      unsigned r, cmd;
+      for (;;) {
+        r = __hip_atomic_load(&ctl->sreq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cmd = __hip_atomic_load(&ctl->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (r != last || (cmd >> 16) & 0xffu) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      s_req = r; s_cmd = __hip_atomic_load(&ctl->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned r = s_req, cmd = s_cmd;
+    if ((cmd >> 16) & 0xffu) return;
+    last = r;
+    // (cmd is the command of the pass that asked or of a later one of the same fit -- the master changes its set only while it waits for this
+    // workgroup, and a request that is overtaken by the next fit's first command yields a result nobody reads, written to the set that is not
+    // the nominal one there either: `cur` lives across the fits)
+    const int ph = (int)((cmd >> 8) & 0xffu);
+    IlqrTreeDev T = T0;
+    if (!((cmd >> 24) & 1u)) il_flip_sets(T);        // write the set the nominal trajectory does not use
+    T.xs = T0.xs_new; T.us = T0.us_new;            // candidate (slot 0, alpha index 0)
+#ifdef IL_PROFILE
+    long long prof[16];
+#endif
+    il_deriv_pass<GEN>(consts[ph], T, lsum, dstg, recs0, reinterpret_cast<unsigned *>(lsum + 9 * 64), 0, 1, staged IL_PROF_PASS);
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&ctl->sdone, r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // n_phases == 1: one fit with consts[0].  n_phases == 2: the contingency planner's sequence (planner.py:174-178) in
 // one launch -- the warm-start fit (consts[0]: lane term only) and then, from its controls, the full fit (consts[1]).
 // T.stats receives IL_NSTAT doubles per phase.
@@ -1811,23 +1907,26 @@ __device__ __forceinline__ void il_follow(const IlqrTreeDev &T, const IlqrConst 
 // for the launch, zeroed by the host.
 template <bool GEN, int MODE>
 __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restrict__ trees, const IlqrConst *__restrict__ consts,
-                                                     int n_phases, int n_trees, int G, unsigned *__restrict__ bars) {
+                                                     int n_phases, int n_trees, int G, unsigned *__restrict__ bars, int spec) {
   constexpr bool MULTI = MODE == 1, SLOTS = MODE == 2;
   int t = blockIdx.x, wg = 0;
   if (MODE != 0) {
-    const int r = blockIdx.x % (8 * G);
-    t = 8 * (blockIdx.x / (8 * G)) + (r & 7);
+    const int Gl = G + (SLOTS ? spec : 0);      // workgroups per tree in the launch: MODE 2 may carry a derivative speculator behind the G slots
+    const int r = blockIdx.x % (8 * Gl);
+    t = 8 * (blockIdx.x / (8 * Gl)) + (r & 7);
     wg = r >> 3;
     if (t >= n_trees) return;
   }
-  const IlqrTreeDev T = trees[t];
+  IlqrTreeDev T = trees[t];
   if (SLOTS && wg > 0) {
     if (bars[4 * n_trees + 1]) return;      // (tests: followers withheld -- the master then keeps its slots to itself)
-    il_follow<GEN>(T, consts, wg);
+    if (wg >= G) il_speculate<GEN>(T, consts, wg);
+    else il_follow<GEN>(T, consts, wg);
     return;
   }
+  int cur = 0;
   for (int ph = 0; ph < n_phases; ++ph)
-    il_fit<GEN, MULTI, SLOTS>(T, consts[ph], ph, (T.stats + (size_t)ph * IL_NSTAT).p, T.trace ? (T.trace + (size_t)ph * T.trace_cap * IL_TRACE_W).p : nullptr, wg, G, MULTI ? bars + 4 * t : nullptr, MULTI ? bars + 4 * n_trees : nullptr);
+    il_fit<GEN, MULTI, SLOTS>(T, cur, consts[ph], ph, (T.stats + (size_t)ph * IL_NSTAT).p, T.trace ? (T.trace + (size_t)ph * T.trace_cap * IL_TRACE_W).p : nullptr, wg, G, MULTI ? bars + 4 * t : nullptr, MULTI ? bars + 4 * n_trees : nullptr);
   if (SLOTS && threadIdx.x == 0) {          // the followers leave
     __hip_atomic_store(&T.ctl->cmd, 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&T.ctl->gen, __hip_atomic_load(&T.ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -120,6 +120,10 @@ struct mind_ctx {
   // narrow cost trees (below ilqr_multi_min nodes): workgroups per tree that take the fit's Levenberg-Marquardt slots (k_ilqr<GEN, 2>: a master +
   // ilqr_slots - 1 followers, one slot each; 1 = everything in one workgroup).  "ilqr_slots" / MIND_ILQR_SLOTS
   int ilqr_slots = 10;
+  // ... and one more workgroup per tree that differentiates a pass's first candidate while the master prices the candidates (il_speculate; the
+  // master swaps derivative sets instead of running its derivative pass when that candidate is the accepted one).  "ilqr_spec_deriv" / MIND_ILQR_SPEC_DERIV
+  bool ilqr_spec_deriv = true;
+  long long il_spec_req = 0, il_spec_hit = 0;       // last launch, all trees and fits: passes the speculator was asked in / results the master took
   int dec_mfma_min = 1 << 30;   // agents per call from which the decoder's actor part runs on the MFMA kernel (MIND_DEC_MFMA_MIN; default: never)
   bool enc_mfma = true;         // MFMA ActorNet under the bf16x3 / bf16 settings (MIND_ENC_MFMA=0: the fp32 VALU kernel, for A/B)
   // fp32-MFMA ActorNet (k_actor_f32): "actor_f32" 1 (default) = the ActorNet of the exact-fp32 setting (0: the fp32 VALU kernel, for A/B);
@@ -350,6 +354,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *we = getenv("MIND_ILQR_CHUNK")) c->ilqr_chunk = atoi(we) < 0 ? 0 : atoi(we);
   if (const char *ce = getenv("MIND_PLAN_CHUNK_MB")) { const long v = atol(ce); if (v > 0) c->plan_chunk_mb = v; }
   if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
+  if (const char *we = getenv("MIND_ILQR_SPEC_DERIV")) c->ilqr_spec_deriv = atoi(we) != 0;
   if (const char *we = getenv("MIND_ILQR_SLOTS")) { const int v = atoi(we); c->ilqr_slots = v < 1 ? 1 : (v > IL_SLOTS ? IL_SLOTS : v); }
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_scene_mw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
@@ -443,6 +448,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "ilqr_multi_min") c->ilqr_multi_min = value;
   else if (n == "ilqr_wgs_big") c->ilqr_wgs_big = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (n == "ilqr_big_min") c->ilqr_big_min = value;
+  else if (n == "ilqr_spec_deriv") c->ilqr_spec_deriv = value != 0;
   else if (n == "ilqr_slots") c->ilqr_slots = value < 1 ? 1 : (value > IL_SLOTS ? IL_SLOTS : value);
   else if (n == "ilqr_test_starve") c->ilqr_test_starve = value != 0;   // tests: launch a wide tree without its last workgroups
   else return fail(c, MIND_EINVAL, "mind_set_tuning: unknown knob '%s'", name);
@@ -1725,6 +1731,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   if (gen || ev || c->ilqr_wgs <= 1) GS = 1;
   while (GS > 1 && ((n_trees + 7) / 8) * 8 * GS > c->n_cu) --GS;
   const bool slots = GS > 1;
+  // the derivative speculator: one more workgroup per tree, only where the whole launch stays resident with it
+  const int spec = slots && c->ilqr_spec_deriv && GS < 31 && ((n_trees + 7) / 8) * 8 * (GS + 1) <= c->n_cu ? 1 : 0;
   // sets of per-slot arrays (gains, value functions, candidates: ~146 doubles per node and slot): what this launch can use -- the followers' slots
   // (GS, after the residency loop above) or the master's own speculation (IL_SPEC), not IL_SLOTS for every narrow-tree launch
   const size_t nslot = slots ? (size_t)(GS > IL_SPEC ? GS : IL_SPEC) : IL_SPEC;
@@ -1742,7 +1750,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   const size_t ctl_ints = (sizeof(IlSlotCtl) + 15) / 16 * 4;
   const size_t o_ctl = takeI(slots ? ctl_ints * (size_t)n_trees : 0);      // slot control blocks (zero at upload; 16-byte aligned: the ints region is)
   const int trace_cap = std::min(256, std::max(cfg->max_iter, cfg2 ? cfg2->max_iter : 0));      // rows of the per-iteration trace, per phase
-  struct TL { size_t nodew, field, relag; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, segrec, rel, fsstart, fsq0, fsq1, fsnstart, fsnodes, trace; int M, a, nl, nseg, nsl, maxls, nfs; };
+  struct TL { size_t nodew, field, relag, relag2, Fx2, L2, Lx2, Lxx2, rel2; size_t xs, us, Fx, L, Lx, Lxx, k, K, Vx, Vxx, xsn, usn, Ln, stats, prob, mean, cov, parent, lstart, lnodes, cstart, clist, sstart, snodes, slstart, slsegs, segrec, rel, fsstart, fsq0, fsq1, fsnstart, fsnodes, trace; int M, a, nl, nseg, nsl, maxls, nfs; };
   std::vector<TL> tl(n_trees);
   long Mtot = 0;
   for (int t = 0; t < n_trees; ++t) tl[t].us = takeD(2 * (size_t)(trees[t].n_nodes > 0 ? trees[t].n_nodes : 0));
@@ -1760,13 +1768,15 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     const size_t M = tr.n_nodes;
     TL &L = tl[t];
     L.M = (int)M; L.a = gen ? 1 : tr.n_agents;
-    L.relag = takeD(use_exo ? M * IL_RA : 0);
     L.trace = takeD((size_t)2 * trace_cap * IL_TRACE_W);
-    L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M);
-    L.Lxx = takeD(36 * M); L.k = takeD(nslot * 2 * M); L.K = takeD(nslot * 12 * M); L.Vx = takeD(nslot * 6 * M); L.Vxx = takeD(nslot * 36 * M);
+    // what the derivative pass writes, and (derivative speculator) a second set laid out alike right behind it
+    L.relag = takeD(use_exo ? M * IL_RA : 0); L.Fx = takeD(36 * M); L.L = takeD(M); L.Lx = takeD(6 * M); L.Lxx = takeD(36 * M);
+    L.relag2 = takeD(spec && use_exo ? M * IL_RA : 0); L.Fx2 = takeD(spec ? 36 * M : 0); L.L2 = takeD(spec ? M : 0); L.Lx2 = takeD(spec ? 6 * M : 0);
+    L.Lxx2 = takeD(spec ? 36 * M : 0);
+    L.k = takeD(nslot * 2 * M); L.K = takeD(nslot * 12 * M); L.Vx = takeD(nslot * 6 * M); L.Vxx = takeD(nslot * 36 * M);
     L.xsn = takeD(nslot * 60 * M); L.usn = takeD(nslot * 20 * M); L.Ln = takeD(nslot * 10 * M);
     L.prob = takeF(M); L.mean = takeF(dev_flat ? 0 : M * L.a * 2); L.cov = takeF(dev_flat ? 0 : M * L.a);
-    L.parent = takeI(M); L.lnodes = takeI(M); L.cstart = takeI(M + 1); L.clist = takeI(M); L.rel = takeI(M);
+    L.parent = takeI(M); L.lnodes = takeI(M); L.cstart = takeI(M + 1); L.clist = takeI(M); L.rel = takeI(M); L.rel2 = takeI(spec ? M : 0);
     Mtot += (long)M;
   }
   // levels need the depth first
@@ -1942,6 +1952,9 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     D.k = Dp(L.k); D.K = Dp(L.K); D.Vx = Dp(L.Vx); D.Vxx = Dp(L.Vxx);
     D.xs_new = Dp(L.xsn); D.us_new = Dp(L.usn); D.L_new = Dp(L.Ln); D.stats = Dp(L.stats);
     D.ctl = slots ? (IlSlotCtl *)(dI + o_ctl + ctl_ints * (size_t)t) : nullptr;
+    D.dset = spec ? (long long)L.Fx2 - (long long)L.Fx : 0; D.drel = spec ? (long long)L.rel2 - (long long)L.rel : 0;
+    if (spec && (L.L2 - L.L != L.Fx2 - L.Fx || L.Lx2 - L.Lx != L.Fx2 - L.Fx || L.Lxx2 - L.Lxx != L.Fx2 - L.Fx || (use_exo && L.relag2 - L.relag != L.Fx2 - L.Fx)))
+      return fail(c, MIND_EINVAL, "tree-iLQR arena: the two derivative sets are laid out differently");
     moff += (long)M;
   }
   for (int t = 0; t < n_trees && gen; ++t)
@@ -2027,20 +2040,21 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     if (!c->ev_il0) { HIPCHK(c, hipEventCreate(&c->ev_il0)); HIPCHK(c, hipEventCreate(&c->ev_il1)); }
     HIPCHK(c, hipEventRecord(c->ev_il0, st));
   }
-  c->ilqr_trees = n_trees; c->ilqr_multi = multi ? G : (slots ? GS : 1); c->ilqr_ms = 0.f;
+  c->ilqr_trees = n_trees; c->ilqr_multi = multi ? G : (slots ? GS + spec : 1); c->ilqr_ms = 0.f;
   auto launch = [=](bool multi_) {
     if (gen) {
-      hipLaunchKernelGGL((k_ilqr<true, 0>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
+      hipLaunchKernelGGL((k_ilqr<true, 0>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars, 0);
     } else if (slots) {
       // a master + GS - 1 followers per tree; a follower that is not resident yet is simply not used (IlSlotCtl.alive): no co-residency needed
-      hipLaunchKernelGGL((k_ilqr<false, 2>), dim3(((n_trees + 7) / 8) * 8 * GS), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, GS, dBars);
+      // (+ the derivative speculator, the last workgroup of a tree)
+      hipLaunchKernelGGL((k_ilqr<false, 2>), dim3(((n_trees + 7) / 8) * 8 * (GS + spec)), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, GS, dBars, spec);
     } else if (multi_) {
       // (ilqr_test_starve: the last eight workgroups are withheld, as if the device could not hold the whole launch: their peers wait
       // at the first barrier, raise the abort word and the call falls back to the one-workgroup kernel below)
       hipLaunchKernelGGL((k_ilqr<false, 1>), dim3(((n_trees + 7) / 8) * 8 * G - (c->ilqr_test_starve ? 8 : 0)), dim3(IL_THREADS), il_lds, st, dT, dK,
-                         n_phases, n_trees, G, dBars);
+                         n_phases, n_trees, G, dBars, 0);
     } else {
-      hipLaunchKernelGGL((k_ilqr<false, 0>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars);
+      hipLaunchKernelGGL((k_ilqr<false, 0>), dim3(n_trees), dim3(IL_THREADS), il_lds, st, dT, dK, n_phases, n_trees, 1, dBars, 0);
     }
   };
   launch(multi);
@@ -2089,6 +2103,14 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     c->il_trace_dev[t] = trace_cap > 0 ? Dp(tl[t].trace) : nullptr;
     for (int ph = 0; ph < n_phases; ++ph) c->il_trace_its[2 * t + ph] = (int)hs[(size_t)2 * IL_NSTAT * t + (size_t)ph * IL_NSTAT];
   }
+  c->il_spec_req = 0; c->il_spec_hit = 0;
+#ifndef IL_PROFILE
+  for (int t = 0; t < n_trees; ++t)
+    for (int ph = 0; ph < n_phases; ++ph) {
+      const double *h = hs.data() + (size_t)2 * IL_NSTAT * t + (size_t)ph * IL_NSTAT;
+      c->il_spec_req += (long long)h[9]; c->il_spec_hit += (long long)h[10];
+    }
+#endif
   {
     // phase cycles of the launch's critical tree (the one with the most cycles over all its fits): what bounds the launch
     double best = -1.0;
@@ -2570,6 +2592,12 @@ extern "C" int64_t mind_debug_read(mind_ctx *c, const char *name, float *host, i
   else if (k == "cmode") { src = c->cmode.p; n = (int64_t)c->last_B * 768; }
   else if (k == "tgt_emb") { src = c->tgt_emb.p; n = (int64_t)c->last_B * 128; }
   else if (k == "tgt_feat") { src = c->tgt_feat.p; n = (int64_t)c->last_B * 128; }
+  else if (k == "il_spec") {        // the derivative speculator in the last tree-iLQR launch: {passes it was asked in, results the master took}
+    if (!host) return 2;
+    if (max_floats < 2) return MIND_EINVAL;
+    host[0] = (float)c->il_spec_req; host[1] = (float)c->il_spec_hit;
+    return 2;
+  }
   else if (k.rfind("il_", 0) == 0 && c->il_dbg[5]) {
     // float64 arrays of tree 0 of the last tree-iLQR call, returned as raw bytes (2 floats per double)
     const size_t M = c->il_dbg[5];

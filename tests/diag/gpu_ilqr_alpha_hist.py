@@ -13,6 +13,9 @@ rt, opt = pl.network.rt, pl.traj_tree_opt
 opt.speculative = False
 hist = [collections.Counter(), collections.Counter()]
 mus = [collections.Counter(), collections.Counter()]
+where = [collections.Counter(), collections.Counter()]      # (slot 0 or a follower's slot, first step size or a later one) of every accepted iteration
+spec = [0, 0]
+nslots = int(os.environ.get("MIND_ILQR_SLOTS", "10"))
 orig = opt.solve_batch
 
 
@@ -21,10 +24,18 @@ def cap(scen_trees, *a):
     for t in range(len(scen_trees)):
         for ph in (0, 1):
             tr = rt.ilqr_trace(t, ph)
+            run = 0          # rejections since the last accepted iteration: the slot of the accepted one is run % slots (a pass = up to `slots` iterations)
             for row in tr:
                 hist[ph][int(row[2])] += 1
                 if row[2] >= 0:
+                    where[ph][("slot 0" if run % nslots == 0 else "slot > 0", "alpha 0" if row[2] == 0 else "alpha > 0")] += 1
+                    run = 0
+                elif row[2] == -1:
+                    run += 1
+                if row[2] >= 0:
                     mus[ph]["mu=0" if row[0] == 0 else ("mu<=1e-3" if row[0] <= 1e-3 else "mu>1e-3")] += 1
+    a, h = rt.debug_read("il_spec")
+    spec[0] += int(a); spec[1] += int(h)
     return r
 
 
@@ -32,4 +43,6 @@ opt.solve_batch = cap
 sim.run_plans(n)
 for ph in (0, 1):
     tot = sum(hist[ph].values())
+    print("phase", ph, "accepted at", sorted(where[ph].items()))
     print("phase", ph, "iterations", tot, "accepted step index histogram", sorted(hist[ph].items()), "mu at accepted", dict(mus[ph]))
+print("derivative speculator: asked in", spec[0], "passes, result adopted in", spec[1])

@@ -359,7 +359,9 @@ def test_levenberg_marquardt_slots_on_follower_workgroups_equal_one_workgroup(hi
     """k_ilqr<GEN, 2>: the master workgroup of a tree evaluates slot 0 of every pass, follower workgroups the slots the LM schedule reaches after
     1 .. n - 1 rejections (solver.py:133-158 is sequential: the first slot with an improving step is what it would have reached).  Every
     slot count must return the single workgroup's bits -- trajectories, statistics and the per-iteration traces of both fits -- and so
-    must a launch whose followers never start (the master then keeps its slots)."""
+    must a launch whose followers never start (the master then keeps its slots), with and without the derivative speculator (il_speculate:
+    one more workgroup per tree differentiates a pass's first candidate beside the master's pricing of the candidates; "il_spec" counts the
+    passes it was asked in and the results the master adopted by swapping derivative sets)."""
     cw, cf = oi.default_cfg(), oi.default_cfg()
     for name, sst, flat, x0 in _contingency_cases():
         try:
@@ -368,20 +370,28 @@ def test_levenberg_marquardt_slots_on_follower_workgroups_equal_one_workgroup(hi
             assert hip_predictor.ilqr_stats()[2] == 1
             ref_tr = [(hip_predictor.ilqr_trace(t, 0), hip_predictor.ilqr_trace(t, 1)) for t in range(3)]
             assert sum(int((tr[:, 2] < 0).sum()) for tr, _ in ref_tr) + sum(int((tr[:, 2] < 0).sum()) for _, tr in ref_tr) > 0, name   # rejections happen
-            for slots, starve in ((2, 0), (3, 0), (4, 0), (8, 0), (12, 0), (10, 1)):
+            taken = 0
+            for slots, starve, spec in ((2, 0, 0), (3, 0, 1), (4, 0, 0), (4, 0, 1), (8, 0, 1), (12, 0, 0), (12, 0, 1), (10, 1, 1), (10, 0, 1)):
                 hip_predictor.set_tuning("ilqr_slots", slots)
                 hip_predictor.set_tuning("ilqr_test_starve", starve)
+                hip_predictor.set_tuning("ilqr_spec_deriv", spec)
                 for rep in range(2):
                     got = hip_predictor.ilqr_contingency(cw, cf, [flat, flat, flat], x0, sst["target_lane"], sst["target_vel"])
-                    assert hip_predictor.ilqr_stats()[2] == slots
+                    assert hip_predictor.ilqr_stats()[2] == slots + spec
+                    asked, hits = (int(v) for v in hip_predictor.debug_read("il_spec"))
+                    assert hits <= asked and (asked > 0) == bool(spec and not starve), (name, slots, starve, spec, asked, hits)
+                    taken += hits
                     for t in range(3):
-                        assert np.array_equal(got[0][t], ref[0][t]) and np.array_equal(got[1][t], ref[1][t]), (name, slots, starve, t)
-                        assert got[2][t] == ref[2][t] and got[3][t] == ref[3][t], (name, slots, starve, t)
+                        assert np.array_equal(got[0][t], ref[0][t]) and np.array_equal(got[1][t], ref[1][t]), (name, slots, starve, spec, t)
+                        assert got[2][t] == ref[2][t] and got[3][t] == ref[3][t], (name, slots, starve, spec, t)
                         for ph in (0, 1):
-                            assert np.array_equal(hip_predictor.ilqr_trace(t, ph), ref_tr[t][ph]), (name, slots, starve, t, ph)
+                            assert np.array_equal(hip_predictor.ilqr_trace(t, ph), ref_tr[t][ph]), (name, slots, starve, spec, t, ph)
+            # the derivative speculator's set really became the nominal one: accepted first candidates of slot 0 exist in every case
+            assert taken > 0, name
         finally:
             hip_predictor.set_tuning("ilqr_test_starve", 0)
             hip_predictor.set_tuning("ilqr_slots", 10)
+            hip_predictor.set_tuning("ilqr_spec_deriv", 1)
     # the oracle's result, for good measure (the other tests of this file run with the default slot count)
     name, sst, flat, x0 = _contingency_cases()[0]
     w = oi.solve(cw, flat, x0, sst["target_lane"], sst["target_vel"], 0)
