@@ -670,8 +670,12 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
   }
   // ---- the cost trees of the finished branches, flattened as TrajectoryTreeOptimizer would (trajectory_tree.py:19-124 / get_scenario_tree
   //      :208-272): sibling-normalised probabilities in float64, LIFO depth-first creation order, every even step = one trajectory node
-  std::vector<std::vector<int>> kids(nodes.size());
+  auto &kids = c->pl_scr_kids;            // (scratch kept in the context: no allocations per plan)
+  if (kids.size() < nodes.size()) kids.resize(nodes.size());
+  for (size_t i = 0; i < nodes.size(); ++i) kids[i].clear();
   for (int i = 1; i < (int)nodes.size(); ++i) kids[nodes[i].parent].push_back(i);
+  auto &pr = c->pl_scr_pr;
+  auto &queue = c->pl_scr_i[0], &last = c->pl_scr_i[1], &stack = c->pl_scr_i[2];
   c->pl_tree_top.clear(); c->pl_tree_off.assign(1, 0); c->pl_flat_parent.clear(); c->pl_flat_prob.clear();
   std::vector<AimeFlat> fjobs;
   std::vector<const float *> fworld;
@@ -681,9 +685,9 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     // probabilities: breadth-first renormalisation over the siblings that lie on finished branches
     // (float32 throughout: SCEN_PROB is a float32 scalar and the Python literals 0.0 / 1.0 it meets are weak scalars under numpy >= 2,
     // which is what the host path -- pinned against the reference's sibling probabilities in tests/golden/aime.npz -- computes with)
-    std::vector<float> pr(nodes.size(), 0.f);
+    pr.assign(nodes.size(), 0.f);
     pr[top] = 1.f;
-    std::vector<int> queue(1, top);
+    queue.assign(1, top);
     for (size_t qh = 0; qh < queue.size(); ++qh) {
       const int cur = queue[qh];
       float total = 0.f;
@@ -693,7 +697,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     // flatten: stack pop() = the last child first; a node's trajectory nodes are chained, the first hangs off its parent's last
     const int base = c->pl_tree_off.back();
     int count = 0;
-    std::vector<int> last(nodes.size(), -1), stack(1, top);
+    last.assign(nodes.size(), -1); stack.assign(1, top);
     while (!stack.empty()) {
       const int q = stack.back();
       stack.pop_back();
@@ -771,26 +775,32 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     if (!fjobs.empty())
       hipLaunchKernelGGL(k_aime_flat, dim3((unsigned)fjob_of_block.size()), dim3(64), 0, st, (const AimeFlat *)d, (const int *)(d + fJ + fW),
                          (const int *)(d + fJ + fW + fB), (const float *const *)(d + fJ), d_fmean, d_fcov);
-    if (!jobs.empty())
-      hipLaunchKernelGGL(k_aime_gather, dim3((unsigned)job_of_block.size()), dim3(64), 0, st, (const AimeGather *)(d + o_g),
-                         (const int *)(d + o_g + gJ + gW), (const int *)(d + o_g + gJ + gW + gB), (const float *const *)(d + o_g + gJ), d_rows);
+    auto gather = [&](hipStream_t gs) {
+      if (!jobs.empty())
+        hipLaunchKernelGGL(k_aime_gather, dim3((unsigned)job_of_block.size()), dim3(64), 0, gs, (const AimeGather *)(d + o_g),
+                           (const int *)(d + o_g + gJ + gW), (const int *)(d + o_g + gJ + gW + gB), (const float *const *)(d + o_g + gJ), d_rows);
+    };
+    if (!want_solves) gather(st);
     HIPCHK(c, hipGetLastError());
     if (dist && (rc = pl_exchange(c, MIND_XCHG_ALLREDUCE, d_rows, d_rows, n_res * sizeof(float)))) return rc;
     c->pl_dev_fmean = d_fmean; c->pl_dev_fcov = d_fcov;
     if ((rc = pl_pin(c, 2, n_res * sizeof(float)))) return rc;
     float *hp = (float *)c->pl_pin[2];
     if (want_solves) {
-      // k_ilqr right behind k_aime_flat: the cost trees' agent arrays stay where that kernel wrote them (ilqr_impl reads them on the device),
-      // the host builds the solver's tables while the two packing kernels run, and the plan's read-back (rows | flat means | sigmas: what
-      // the caller's tree objects and the candidate evaluation want) travels on the copy stream BESIDE the solve instead of in front of it.
+      // k_ilqr right behind k_aime_flat: the cost trees' agent arrays stay where that kernel wrote them (ilqr_impl reads them on the device)
+      // and the host builds the solver's tables while it runs.  What only the CALLER wants -- the finished branches' rows (k_aime_gather) and the
+      // plan's read-back (rows | flat means | sigmas: the tree objects, the candidate evaluation) -- is queued on the copy stream AFTER the
+      // solves have been launched: beside k_ilqr on the device, and behind its launch on the host (the five calls stood 10 us in front of it).
       if (!c->ev_rows) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming));
-      HIPCHK(c, hipEventRecord(c->ev_tab, st));
-      HIPCHK(c, hipStreamWaitEvent(c->pl_copy, c->ev_tab, 0));
-      HIPCHK(c, hipMemcpyAsync(hp, d_rows, n_res * sizeof(float), hipMemcpyDeviceToHost, c->pl_copy));
-      HIPCHK(c, hipEventRecord(c->ev_rows, c->pl_copy));
-      TR("end: packing kernels + read-back queued");
+      HIPCHK(c, hipEventRecord(c->ev_tab, st));          // (the job tables are up, the flat arrays written)
+      TR("end: flat kernel queued");
       begin_solves();
       TR("end: solves begun");
+      HIPCHK(c, hipStreamWaitEvent(c->pl_copy, c->ev_tab, 0));
+      gather(c->pl_copy);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipMemcpyAsync(hp, d_rows, n_res * sizeof(float), hipMemcpyDeviceToHost, c->pl_copy));
+      HIPCHK(c, hipEventRecord(c->ev_rows, c->pl_copy));
       HIPCHK(c, hipEventSynchronize(c->ev_rows));
       TR("end: read-back on the host");
     } else {

@@ -123,6 +123,9 @@ struct mind_ctx {
   // ... and one more workgroup per tree that differentiates a pass's first candidate while the master prices the candidates (il_speculate; the
   // master swaps derivative sets instead of running its derivative pass when that candidate is the accepted one).  "ilqr_spec_deriv" / MIND_ILQR_SPEC_DERIV
   bool ilqr_spec_deriv = true;
+  // host tables of a tree-iLQR call (ilqr_impl): kept between calls so that a planning cycle does not allocate a hundred small vectors
+  struct IlScratch { std::vector<std::vector<int>> vv[14]; std::vector<int> tmp[6]; std::vector<double> hD; std::vector<float> hF; std::vector<int> hI; } il_scr;
+  std::vector<std::vector<int>> pl_scr_kids; std::vector<float> pl_scr_pr; std::vector<int> pl_scr_i[3];      // mind_aime_plan's flattening scratch
   long long il_spec_req = 0, il_spec_hit = 0;       // last launch, all trees and fits: passes the speculator was asked in / results the master took
   int dec_mfma_min = 1 << 30;   // agents per call from which the decoder's actor part runs on the MFMA kernel (MIND_DEC_MFMA_MIN; default: never)
   bool enc_mfma = true;         // MFMA ActorNet under the bf16x3 / bf16 settings (MIND_ENC_MFMA=0: the fp32 VALU kernel, for A/B)
@@ -1702,6 +1705,12 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
       return fail(c, MIND_EINVAL, "tree %d: field / node_w must be given exactly in the generic (grid) mode", t);
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = c->stream;
+  // MIND_PLAN_TRACE=1: host time stamps of this call's sections on stderr (as in mind_aime_plan)
+  static const bool il_trace = getenv("MIND_PLAN_TRACE") != nullptr;
+  const auto il_t0 = std::chrono::steady_clock::now();
+  auto ITR = [&](const char *what) {
+    if (il_trace) fprintf(stderr, "[ilqr] %8.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - il_t0).count(), what);
+  };
   const double grid_res = gen ? grid->res : cfg->grid_res;
   // ---- grid coordinates exactly as numpy builds them (ilqr/utils.py:7-13)
   std::vector<double> gx(W), gy(H);
@@ -1780,13 +1789,16 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     Mtot += (long)M;
   }
   // levels need the depth first
-  std::vector<std::vector<int>> lvl_start(n_trees), lvl_nodes(n_trees), cst(n_trees), cls(n_trees);
-  std::vector<std::vector<int>> sg_start(n_trees), sg_nodes(n_trees), sl_start(n_trees), sl_segs(n_trees);
-  std::vector<std::vector<int>> seg_rec(n_trees), fs_start(n_trees), fs_q0(n_trees), fs_q1(n_trees), fs_nstart(n_trees), fs_nodes(n_trees);
+  // (the vectors live in the context: their capacity survives the call)
+  for (auto &v : c->il_scr.vv) if ((int)v.size() < n_trees) v.resize(n_trees);
+  auto &lvl_start = c->il_scr.vv[0], &lvl_nodes = c->il_scr.vv[1], &cst = c->il_scr.vv[2], &cls = c->il_scr.vv[3];
+  auto &sg_start = c->il_scr.vv[4], &sg_nodes = c->il_scr.vv[5], &sl_start = c->il_scr.vv[6], &sl_segs = c->il_scr.vv[7];
+  auto &seg_rec = c->il_scr.vv[8], &fs_start = c->il_scr.vv[9], &fs_q0 = c->il_scr.vv[10], &fs_q1 = c->il_scr.vv[11], &fs_nstart = c->il_scr.vv[12], &fs_nodes = c->il_scr.vv[13];
+  auto &depth = c->il_scr.tmp[0], &fill = c->il_scr.tmp[1], &cf = c->il_scr.tmp[2], &seg_of = c->il_scr.tmp[3], &seg_depth = c->il_scr.tmp[4], &sf = c->il_scr.tmp[5];
   for (int t = 0; t < n_trees; ++t) {
     const mind_cost_tree &tr = trees[t];
     const int M = tr.n_nodes;
-    std::vector<int> depth(M, 0);
+    depth.assign(M, 0);
     int maxd = 0;
     for (int i = 0; i < M; ++i) {
       const int p = tr.parent[i];
@@ -1799,17 +1811,17 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     for (int i = 0; i < M; ++i) lvl_start[t][depth[i] + 1]++;
     for (int d = 0; d <= maxd; ++d) lvl_start[t][d + 1] += lvl_start[t][d];
     lvl_nodes[t].resize(M);
-    std::vector<int> fill(maxd + 1, 0);
+    fill.assign(maxd + 1, 0);
     for (int i = 0; i < M; ++i) lvl_nodes[t][lvl_start[t][depth[i]] + fill[depth[i]]++] = i;
     cst[t].assign(M + 1, 0);
     for (int i = 1; i < M; ++i) cst[t][tr.parent[i] + 1]++;
     for (int i = 0; i < M; ++i) cst[t][i + 1] += cst[t][i];
     cls[t].assign(M > 1 ? M : 1, 0);
-    std::vector<int> cf(M, 0);
+    cf.assign(M, 0);
     for (int i = 1; i < M; ++i) cls[t][cst[t][tr.parent[i]] + cf[tr.parent[i]]++] = i;
     tl[t].lstart = takeI(maxd + 2);
     // chain segments: a node starts a segment if it is node 0 or its parent has >= 2 children
-    std::vector<int> seg_of(M, -1), seg_depth;
+    seg_of.assign(M, -1); seg_depth.clear();
     auto nchild = [&](int i) { return cst[t][i + 1] - cst[t][i]; };
     sg_start[t].clear(); sg_nodes[t].clear();
     for (int i = 0; i < M; ++i) {
@@ -1833,7 +1845,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     for (int d : seg_depth) sl_start[t][d + 1]++;
     for (int d = 0; d <= maxsd; ++d) sl_start[t][d + 1] += sl_start[t][d];
     sl_segs[t].resize(nseg);
-    std::vector<int> sf(maxsd + 1, 0);
+    sf.assign(maxsd + 1, 0);
     for (int sgi = 0; sgi < nseg; ++sgi) sl_segs[t][sl_start[t][seg_depth[sgi]] + sf[seg_depth[sgi]]++] = sgi;
     tl[t].nseg = nseg; tl[t].nsl = maxsd + 1;
     tl[t].maxls = 1;
@@ -1877,6 +1889,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     tl[t].fsstart = takeI(fs_start[t].size()); tl[t].fsq0 = takeI(fs_q0[t].size()); tl[t].fsq1 = takeI(fs_q1[t].size());
     tl[t].fsnstart = takeI(fs_nstart[t].size()); tl[t].fsnodes = takeI(M);
   }
+  ITR("tables built");
   // arena: [uploaded doubles (nd_in) | floats | ints | tree structs | constants] = ONE host->device copy, then the doubles the
   // kernels produce (workspace + results), then (generic mode) the materialised fields
   const size_t bytesIn = nd_in * sizeof(double), bytesF = nf * sizeof(float), bytesI = ni * sizeof(int);
@@ -1894,9 +1907,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   float *dF = (float *)(base + bytesIn);
   int *dI = (int *)(base + bytesIn + bytesF);
   // host staging of the read-only part
-  std::vector<double> hD(nd_in, 0.0);
-  std::vector<float> hF(nf, 0.f);
-  std::vector<int> hI(ni, 0);
+  auto &hD = c->il_scr.hD; auto &hF = c->il_scr.hF; auto &hI = c->il_scr.hI;
+  hD.assign(nd_in, 0.0); hF.assign(nf, 0.f); hI.assign(ni, 0);
   memcpy(hD.data() + o_gx, gx.data(), W * sizeof(double));
   memcpy(hD.data() + o_gy, gy.data(), H * sizeof(double));
   if (n_lane_pts) memcpy(hD.data() + o_lane, target_lane, (size_t)n_lane_pts * 2 * sizeof(double));
@@ -2000,6 +2012,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   // one staged copy of everything the host provides (`up` lives until the stream has been synchronised below)
   // (page-locked staging: a pageable source makes hipMemcpyAsync a blocking staged copy that also stalls the other contexts of the
   // process -- several planner threads on one GPU then run slower together than one alone)
+  ITR("staged in vectors");
   if ((rc = pl_pin(c, 4, o_work))) return rc;
   char *up = (char *)c->pl_pin[4];
   {
@@ -2013,6 +2026,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     memcpy(up + o_consts, K2, 2 * sizeof(IlqrConst));
     HIPCHK(c, hipMemcpyAsync(base, up, o_work, hipMemcpyHostToDevice, st));
   }
+  ITR("upload queued");
   const IlqrConst *dK = (const IlqrConst *)(base + o_consts);
   if (field_ahead) HIPCHK(c, hipStreamWaitEvent(st, c->ev_field, 0));
   else if (!gen) hipLaunchKernelGGL(k_lane_field, dim3((W * H + 255) / 256), dim3(256), 0, st, K.gx.p, K.gy.p, W, H, Dp(o_lane), n_lane_pts, Dp(o_quad));
@@ -2058,6 +2072,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     }
   };
   launch(multi);
+  ITR("kernel launched");
   HIPCHK(c, hipGetLastError());
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_il1, st));
   std::vector<double> hs((size_t)2 * IL_NSTAT * n_trees);
