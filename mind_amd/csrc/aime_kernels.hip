@@ -251,8 +251,12 @@ __global__ __launch_bounds__(64) void k_aime_windows(const float *__restrict__ p
 // hit[b][j] (two 32-bit words) is set when some agent's predicted max-sigma at step t exceeds 9 x its max-sigma at the scene's
 // compare step (float32 division and comparison, as the reference).  The host picks the first even t inside (CUR_T, END_T).
 // One wave per (scene, kept slot), lane = step; sel as written by k_aime_select.
+// h_sel != null (unsharded plans): this last kernel of a round also writes the round's decisions -- kept mode, its probability, the hit bits --
+// where the HOST reads them (page-locked, mapped staging), so that no copy stands between the kernel's end and the host's replay.
 __global__ __launch_bounds__(64) void k_aime_branch(const AimeScene *__restrict__ scenes, const float *__restrict__ sel,
-                                                    const float *__restrict__ world, unsigned *__restrict__ hit) {
+                                                    const float *__restrict__ world, unsigned *__restrict__ hit,
+                                                    const float *__restrict__ sel_prob, float *__restrict__ h_sel, float *__restrict__ h_selp,
+                                                    unsigned *__restrict__ h_hit) {
   const int b = blockIdx.x / AIME_K, j = blockIdx.x % AIME_K, t = threadIdx.x;
   const AimeScene S = scenes[b];
   const int k = (int)sel[(size_t)b * AIME_K + j];
@@ -265,6 +269,10 @@ __global__ __launch_bounds__(64) void k_aime_branch(const AimeScene *__restrict_
   }
   const unsigned long long m = __ballot(h);
   if (t == 0) { hit[2 * (size_t)blockIdx.x] = (unsigned)m; hit[2 * (size_t)blockIdx.x + 1] = (unsigned)(m >> 32); }
+  if (h_sel && t == 0) {
+    h_hit[2 * (size_t)blockIdx.x] = (unsigned)m; h_hit[2 * (size_t)blockIdx.x + 1] = (unsigned)(m >> 32);
+    h_sel[blockIdx.x] = sel[blockIdx.x]; h_selp[blockIdx.x] = sel_prob[blockIdx.x];
+  }
 }
 
 // Rows of the returned scenario trees (get_scenario_tree, scenario_tree.py:208-272): the first `dur` predicted steps (x, y, max-sigma)

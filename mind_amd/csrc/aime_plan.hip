@@ -162,7 +162,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     memcpy(h + o_lpts, in->lane_pts, (size_t)l * 22 * sizeof(double));
     memcpy(h + o_lfl, in->lane_flags, (size_t)l * 6 * sizeof(int));
     // one copy: [types .. lane flags] (the slots before o_types are produced on the device)
-    HIPCHK(c, hipMemcpyAsync((float *)c->pl_root.p + o_types, h + o_types, (n_root - o_types) * sizeof(float), hipMemcpyHostToDevice, st));
+    if ((rc = pl_upload(c, (float *)c->pl_root.p + o_types, h + o_types, (n_root - o_types) * sizeof(float), st))) return rc;
     float *d = (float *)c->pl_root.p;
     RebaseArgs R;
     R.a = a; R.l = 0; R.n_lane = P; R.pad_ones = 0;
@@ -285,6 +285,12 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     if ((rc = ensure(c, c->pl_small, (n_topo + n_ego + n_back) * sizeof(float)))) return rc;
     float *d_topo = (float *)c->pl_small.p, *d_ego = d_topo + n_topo, *d_sel = d_ego + n_ego, *d_selp = d_sel + (size_t)Bmax * 6;
     unsigned *d_hit = (unsigned *)(d_selp + (size_t)Bmax * 6);
+    // unsharded: the round's last kernel writes the decisions where the host reads them (same layout as the device buffer)
+    float *h_mirror = nullptr;
+    if (!dist && c->dec_mirror) {
+      if ((rc = pl_pin(c, 2, n_back * sizeof(float)))) return rc;
+      h_mirror = (float *)c->pl_pin[2];
+    }
     DevBuf &tabb = c->pl_tab[round & 1];
     const size_t bS = ((size_t)Bk * sizeof(AimeScene) + 15) & ~(size_t)15, bI = ((size_t)A * sizeof(int) + 15) & ~(size_t)15;
     const size_t bP = ((size_t)Bk * sizeof(float) + 15) & ~(size_t)15;
@@ -395,7 +401,10 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
                          cov_last_dev + (size_t)g0 * a, w_c, d_topo + (size_t)c0 * a * 6, d_ego + (size_t)c0 * 24, droot + o_tl, P);
       hipLaunchKernelGGL(k_aime_select, dim3(cb), dim3(64), 0, st, t_sc, d_cls, (const float *)(dtab + bS + bI) + c0, d_topo + (size_t)c0 * a * 6,
                          d_ego + (size_t)c0 * 24, 1, in->dist_thres, d_sel + (size_t)c0 * 6, d_selp + (size_t)c0 * 6, in->prob_floor > 0.f ? in->prob_floor : 0.001f);
-      hipLaunchKernelGGL(k_aime_branch, dim3(cb * AIME_K), dim3(64), 0, st, t_sc, d_sel + (size_t)c0 * 6, w_c, d_hit + (size_t)c0 * 12);
+      hipLaunchKernelGGL(k_aime_branch, dim3(cb * AIME_K), dim3(64), 0, st, t_sc, d_sel + (size_t)c0 * 6, w_c, d_hit + (size_t)c0 * 12,
+                         (const float *)d_selp + (size_t)c0 * 6, h_mirror ? h_mirror + (size_t)c0 * 6 : nullptr,
+                         h_mirror ? h_mirror + (size_t)Bmax * 6 + (size_t)c0 * 6 : nullptr,
+                         h_mirror ? (unsigned *)(h_mirror + (size_t)Bmax * 12) + (size_t)c0 * 12 : nullptr);
       HIPCHK(c, hipGetLastError());
     }
     if (!tables_done && (rc = prepare_tables())) return rc;      // (a rank without scenes in this round still needs the frames)
@@ -406,7 +415,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       if ((rc = pl_exchange(c, MIND_XCHG_ALLGATHER, d_sel, c->x_recv.p, n_back * sizeof(float)))) return rc;
       if ((rc = pl_pin(c, 2, (size_t)XW * n_back * sizeof(float)))) return rc;
       HIPCHK(c, hipMemcpyAsync(c->pl_pin[2], c->x_recv.p, (size_t)XW * n_back * sizeof(float), hipMemcpyDeviceToHost, st));
-    } else {
+    } else if (!h_mirror) {
       if ((rc = pl_pin(c, 2, n_back * sizeof(float)))) return rc;
       HIPCHK(c, hipMemcpyAsync(c->pl_pin[2], d_sel, n_back * sizeof(float), hipMemcpyDeviceToHost, st));
     }

@@ -117,6 +117,8 @@ struct IlqrTreeDev {
   // kernel's scalar registers.  Inside the master Fx .. rel are always the set of the nominal trajectory (il_flip_sets moves them and negates
   // the distances); followers and the speculator hold the launch's pointers and take the master's word (cmd bit 24) for which is which
   long long dset, drel;
+  // small launches: where the host reads the results (page-locked, mapped staging) -- written by the kernel at its end; null = copies follow
+  GP<double> h_xs, h_us, h_stats;
   GP<double> stats;            // [IL_NSTAT]: iterations, converged, J, mu, phase cycles, profile slots
   // per-iteration trace of the fit (mind_last_ilqr_trace): IL_TRACE_W doubles per reference iteration {mu the backward pass ran with,
   // J of the nominal trajectory, accepted alpha index (-1: step rejected, -2: singular Q_uu), J of the accepted candidate}
@@ -1927,6 +1929,13 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
   int cur = 0;
   for (int ph = 0; ph < n_phases; ++ph)
     il_fit<GEN, MULTI, SLOTS>(T, cur, consts[ph], ph, (T.stats + (size_t)ph * IL_NSTAT).p, T.trace ? (T.trace + (size_t)ph * T.trace_cap * IL_TRACE_W).p : nullptr, wg, G, MULTI ? bars + 4 * t : nullptr, MULTI ? bars + 4 * n_trees : nullptr);
+  if (T.h_xs && wg == 0) {
+    // (il_fit ended with a barrier of the tree's workgroups behind the last adoption and the statistics)
+    const int M = T.M;
+    for (int q = threadIdx.x; q < M * 6; q += IL_THREADS) T.h_xs[q] = T.xs[q];
+    for (int q = threadIdx.x; q < M * 2; q += IL_THREADS) T.h_us[q] = T.us[q];
+    for (int q = threadIdx.x; q < n_phases * IL_NSTAT; q += IL_THREADS) T.h_stats[q] = T.stats[q];
+  }
   if (SLOTS && threadIdx.x == 0) {          // the followers leave
     __hip_atomic_store(&T.ctl->cmd, 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&T.ctl->gen, __hip_atomic_load(&T.ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -123,6 +123,14 @@ struct mind_ctx {
   // ... and one more workgroup per tree that differentiates a pass's first candidate while the master prices the candidates (il_speculate; the
   // master swaps derivative sets instead of running its derivative pass when that candidate is the accepted one).  "ilqr_spec_deriv" / MIND_ILQR_SPEC_DERIV
   bool ilqr_spec_deriv = true;
+  // uploads of at most this many bytes from the context's page-locked staging run as a kernel on the consumer's queue (pl_upload; 0 = always
+  // hipMemcpyAsync).  "upload_kernel_max" / MIND_UPLOAD_KERNEL_MAX
+  int upload_kernel_max = 1 << 20;
+  // tree-iLQR launches of at most this many nodes in all write their results (xs, us, statistics) to the host staging themselves at the kernel's
+  // end instead of two copies behind it (0 = always copies).  "ilqr_host_out_max" / MIND_ILQR_HOST_OUT_MAX
+  long ilqr_host_out_max = 4096;
+  // mind_aime_plan, unsharded: k_aime_branch writes a round's decisions to the host staging itself (no copy behind it).  "dec_mirror" / MIND_DEC_MIRROR
+  bool dec_mirror = true;
   // host tables of a tree-iLQR call (ilqr_impl): kept between calls so that a planning cycle does not allocate a hundred small vectors
   struct IlScratch { std::vector<std::vector<int>> vv[14]; std::vector<int> tmp[6]; std::vector<double> hD; std::vector<float> hF; std::vector<int> hI; } il_scr;
   std::vector<std::vector<int>> pl_scr_kids; std::vector<float> pl_scr_pr; std::vector<int> pl_scr_i[3];      // mind_aime_plan's flattening scratch
@@ -358,6 +366,9 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *ce = getenv("MIND_PLAN_CHUNK_MB")) { const long v = atol(ce); if (v > 0) c->plan_chunk_mb = v; }
   if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
   if (const char *we = getenv("MIND_ILQR_SPEC_DERIV")) c->ilqr_spec_deriv = atoi(we) != 0;
+  if (const char *we = getenv("MIND_DEC_MIRROR")) c->dec_mirror = atoi(we) != 0;
+  if (const char *we = getenv("MIND_ILQR_HOST_OUT_MAX")) c->ilqr_host_out_max = std::max(0, atoi(we));
+  if (const char *we = getenv("MIND_UPLOAD_KERNEL_MAX")) c->upload_kernel_max = std::max(0, atoi(we));
   if (const char *we = getenv("MIND_ILQR_SLOTS")) { const int v = atoi(we); c->ilqr_slots = v < 1 ? 1 : (v > IL_SLOTS ? IL_SLOTS : v); }
   (void)hipFuncSetAttribute((const void *)k_dec_scene, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
   (void)hipFuncSetAttribute((const void *)k_dec_scene_mw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mind_dec_scene_lds_bytes());
@@ -452,6 +463,9 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "ilqr_wgs_big") c->ilqr_wgs_big = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (n == "ilqr_big_min") c->ilqr_big_min = value;
   else if (n == "ilqr_spec_deriv") c->ilqr_spec_deriv = value != 0;
+  else if (n == "dec_mirror") c->dec_mirror = value != 0;
+  else if (n == "ilqr_host_out_max") c->ilqr_host_out_max = value < 0 ? 0 : value;
+  else if (n == "upload_kernel_max") c->upload_kernel_max = value < 0 ? 0 : value;
   else if (n == "ilqr_slots") c->ilqr_slots = value < 1 ? 1 : (value > IL_SLOTS ? IL_SLOTS : value);
   else if (n == "ilqr_test_starve") c->ilqr_test_starve = value != 0;   // tests: launch a wide tree without its last workgroups
   else return fail(c, MIND_EINVAL, "mind_set_tuning: unknown knob '%s'", name);
@@ -1650,6 +1664,26 @@ extern "C" int mind_lane_dist_field(mind_ctx *c, const double *ego_xy, const dou
 struct IlqrEvalReq { int nq; const int32_t *node; const double *x, *u; double *out; };
 namespace { int pl_pin(mind_ctx *c, int which, size_t bytes); }     // page-locked staging buffers of the context (aime_plan.hip)
 
+// Upload of a few ten KB from the context's page-locked staging (hipHostMalloc: mapped into the device's address space) as a KERNEL on the
+// consumer's own queue: the device reads the host buffer over PCIe (a few us) and the consumer follows back to back.  hipMemcpyAsync sends
+// copies above its blit threshold to the SDMA engine, whose hand-over to the compute queue stood 10-15 us on either side of the copy in the
+// plan's timeline (root scene: 60 KB, the solver's tables: 40 KB; profiles/r06az_timeline.txt).  16-byte words; large uploads stay copies.
+typedef unsigned up_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_upload(const up_u4 *__restrict__ src, up_u4 *__restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = __builtin_nontemporal_load(src + i);
+}
+static int pl_upload(mind_ctx *c, void *dst, const void *pinned_src, size_t bytes, hipStream_t s) {
+  if (!bytes) return MIND_OK;
+  if (c->upload_kernel_max > 0 && bytes <= (size_t)c->upload_kernel_max && bytes % 16 == 0 && (uintptr_t)dst % 16 == 0 && (uintptr_t)pinned_src % 16 == 0) {
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(k_upload, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 256)), dim3(256), 0, s, (const up_u4 *)pinned_src, (up_u4 *)dst, n16);
+    HIPCHK(c, hipGetLastError());
+    return MIND_OK;
+  }
+  HIPCHK(c, hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, s));
+  return MIND_OK;
+}
+
 // Shared host side of mind_ilqr_solve_trees / mind_ilqr_solve_fields / mind_cost_eval: build the device
 // arena, then either run the solver (ev == nullptr) or evaluate node costs at the requested points.
 // grid != nullptr selects the generic mode (materialised per-node fields + per-node weights).
@@ -1919,6 +1953,15 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     for (int q = 0; q < ev->nq; ++q)
       if (ev->node[q] < 0 || ev->node[q] >= trees[0].n_nodes) return fail(c, MIND_EINVAL, "mind_cost_eval: node %d out of range", ev->node[q]);
   }
+  // where the results land on the host: xs of all trees and, right behind them, the stats of all trees; us (it lives in the uploaded region).
+  // A launch of small trees writes them there ITSELF at its end (k_ilqr: the staging is page-locked and mapped), instead of two copies behind it
+  const size_t n_hs = (size_t)2 * IL_NSTAT * n_trees;
+  const size_t n_xs = (size_t)(tl[0].stats - tl[0].xs);
+  const size_t n_hx = n_xs + n_hs, n_us = (size_t)Mtot * 2;
+  if ((rc = pl_pin(c, 5, (n_hx + n_us + 2) * sizeof(double)))) return rc;
+  double *hx = (double *)c->pl_pin[5], *hus = hx + n_hx;
+  unsigned *h_abort = (unsigned *)(hus + n_us);
+  const bool host_out = !ev && c->ilqr_host_out_max > 0 && Mtot <= c->ilqr_host_out_max;
   std::vector<IlqrTreeDev> hT(n_trees);
   long moff = 0;
   for (int t = 0; t < n_trees; ++t) {
@@ -1964,6 +2007,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     D.k = Dp(L.k); D.K = Dp(L.K); D.Vx = Dp(L.Vx); D.Vxx = Dp(L.Vxx);
     D.xs_new = Dp(L.xsn); D.us_new = Dp(L.usn); D.L_new = Dp(L.Ln); D.stats = Dp(L.stats);
     D.ctl = slots ? (IlSlotCtl *)(dI + o_ctl + ctl_ints * (size_t)t) : nullptr;
+    D.h_xs = host_out ? hx + (L.xs - tl[0].xs) : nullptr; D.h_us = host_out ? hus + (L.us - tl[0].us) : nullptr;
+    D.h_stats = host_out ? hx + (L.stats - tl[0].xs) : nullptr;
     D.dset = spec ? (long long)L.Fx2 - (long long)L.Fx : 0; D.drel = spec ? (long long)L.rel2 - (long long)L.rel : 0;
     if (spec && (L.L2 - L.L != L.Fx2 - L.Fx || L.Lx2 - L.Lx != L.Fx2 - L.Fx || L.Lxx2 - L.Lxx != L.Fx2 - L.Fx || (use_exo && L.relag2 - L.relag != L.Fx2 - L.Fx)))
       return fail(c, MIND_EINVAL, "tree-iLQR arena: the two derivative sets are laid out differently");
@@ -2024,7 +2069,7 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     if (slots && c->ilqr_test_starve) ((unsigned *)(up + bytesIn + bytesF))[o_bars + 4 * (size_t)n_trees + 1] = 1u;
     memcpy(up + o_structs, hT.data(), (size_t)n_trees * sizeof(IlqrTreeDev));
     memcpy(up + o_consts, K2, 2 * sizeof(IlqrConst));
-    HIPCHK(c, hipMemcpyAsync(base, up, o_work, hipMemcpyHostToDevice, st));
+    if ((rc = pl_upload(c, base, up, o_work, st))) return rc;
   }
   ITR("upload queued");
   const IlqrConst *dK = (const IlqrConst *)(base + o_consts);
@@ -2075,19 +2120,14 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   ITR("kernel launched");
   HIPCHK(c, hipGetLastError());
   if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_il1, st));
-  std::vector<double> hs((size_t)2 * IL_NSTAT * n_trees);
-  // xs of all trees and, right behind them, the stats of all trees: one copy; us lives in the uploaded region
-  const size_t n_xs = (size_t)(tl[0].stats - tl[0].xs);
-  const size_t n_hx = n_xs + hs.size(), n_us = (size_t)Mtot * 2;
-  if ((rc = pl_pin(c, 5, (n_hx + n_us + 2) * sizeof(double)))) return rc;
-  double *hx = (double *)c->pl_pin[5], *hus = hx + n_hx;
-  unsigned *h_abort = (unsigned *)(hus + n_us);
-  HIPCHK(c, hipMemcpyAsync(hx, Dp(tl[0].xs), n_hx * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(hus, Dp(tl[0].us), n_us * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (!host_out) {
+    HIPCHK(c, hipMemcpyAsync(hx, Dp(tl[0].xs), n_hx * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hus, Dp(tl[0].us), n_us * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
   if (multi) HIPCHK(c, hipMemcpyAsync(h_abort, dBars + 4 * (size_t)n_trees, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   // everything behind the launch -- the wait, the fallback of a launch that was not resident, the outputs -- as one closure over values:
   // run at once, or kept in the context by mind_ilqr_contingency_begin and run by mind_ilqr_finish (the caller's thread is free meanwhile)
-  const size_t hs_size = hs.size();
+  const size_t hs_size = n_hs;
   std::function<int()> fin = [=]() -> int {
   std::vector<double> hs(hs_size);
   HIPCHK(c, hipStreamSynchronize(st));
@@ -2103,8 +2143,10 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
       launch(false);
       HIPCHK(c, hipGetLastError());
       c->ilqr_multi = 1;
-      HIPCHK(c, hipMemcpyAsync(hx, Dp(tl[0].xs), n_hx * sizeof(double), hipMemcpyDeviceToHost, st));
-      HIPCHK(c, hipMemcpyAsync(hus, Dp(tl[0].us), n_us * sizeof(double), hipMemcpyDeviceToHost, st));
+      if (!host_out) {
+        HIPCHK(c, hipMemcpyAsync(hx, Dp(tl[0].xs), n_hx * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(hus, Dp(tl[0].us), n_us * sizeof(double), hipMemcpyDeviceToHost, st));
+      }
       HIPCHK(c, hipStreamSynchronize(st));
     }
   }
