@@ -501,8 +501,10 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
         hi_[Sm + s] = n.lscene * a * AIME_K + n.mode;      // first row (agent 0) of the node's mode in this rank's d_world
         hi_[2 * Sm + s] = n.end_t - n.cur_t;               // steps kept
       }
-      HIPCHK(c, hipMemcpyAsync((char *)tabb.p + tab_bytes, hi_, 3 * (size_t)Sm * sizeof(int), hipMemcpyHostToDevice, st));
-      const int *d_idx = (const int *)((const char *)tabb.p + tab_bytes);
+      // (a small branch set: k_aime_windows reads its three ints per scene from the page-locked staging itself -- no copy in front of it)
+      const bool tab_host = c->tab_host_max > 0 && (size_t)Sm * a <= (size_t)c->tab_host_max;
+      if (!tab_host) HIPCHK(c, hipMemcpyAsync((char *)tabb.p + tab_bytes, hi_, 3 * (size_t)Sm * sizeof(int), hipMemcpyHostToDevice, st));
+      const int *d_idx = tab_host ? (const int *)hi_ : (const int *)((const char *)tabb.p + tab_bytes);
       hipLaunchKernelGGL(k_aime_windows, dim3((unsigned)(Sm * a)), dim3(64), 0, st, prev_pos, prev_ang, prev_vel, (const float *)d_world, d_idx, d_idx + Sm,
                          d_idx + 2 * Sm, a, w_pos + (size_t)s0 * a * OBS * 2, w_ang + (size_t)s0 * a * OBS, w_vel + (size_t)s0 * a * OBS * 2, AIME_K,
                          d_in + q.cov + (size_t)s0 * a);
@@ -777,9 +779,11 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       memcpy(h + o_g + gJ + gW + gB, agent_of_block.data(), agent_of_block.size() * sizeof(int));
     }
     TR("end: trees flattened on the host");
-    if (n_tab) HIPCHK(c, hipMemcpyAsync(c->pl_flat.p, h, n_tab, hipMemcpyHostToDevice, st));
-    char *d = (char *)c->pl_flat.p;
-    float *d_rows = (float *)(d + o_rows), *d_fmean = d_rows + n_rows, *d_fcov = d_fmean + Mtot * a * 2;
+    // (few jobs: the two packing kernels read their tables from the page-locked staging themselves)
+    const bool tab_host = !dist && c->tab_host_max > 0 && fjob_of_block.size() + job_of_block.size() <= (size_t)c->tab_host_max;
+    if (n_tab && !tab_host) HIPCHK(c, hipMemcpyAsync(c->pl_flat.p, h, n_tab, hipMemcpyHostToDevice, st));
+    char *d = tab_host ? h : (char *)c->pl_flat.p;
+    float *d_rows = (float *)((char *)c->pl_flat.p + o_rows), *d_fmean = d_rows + n_rows, *d_fcov = d_fmean + Mtot * a * 2;
     if (dist) HIPCHK(c, hipMemsetAsync(d_rows, 0, n_res * sizeof(float), st));      // every entry is written by exactly one rank: the sum completes it
     if (!fjobs.empty())
       hipLaunchKernelGGL(k_aime_flat, dim3((unsigned)fjob_of_block.size()), dim3(64), 0, st, (const AimeFlat *)d, (const int *)(d + fJ + fW),

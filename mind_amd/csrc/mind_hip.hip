@@ -131,6 +131,9 @@ struct mind_ctx {
   long ilqr_host_out_max = 4096;
   // mind_aime_plan, unsharded: k_aime_branch writes a round's decisions to the host staging itself (no copy behind it).  "dec_mirror" / MIND_DEC_MIRROR
   bool dec_mirror = true;
+  // ... and its small index tables (the branch set of a round, the job tables of the two packing kernels) are read by the kernels from the
+  // page-locked staging directly while they name at most this many workgroups (0 = always uploaded).  "tab_host_max" / MIND_TAB_HOST_MAX
+  int tab_host_max = 4096;
   // host tables of a tree-iLQR call (ilqr_impl): kept between calls so that a planning cycle does not allocate a hundred small vectors
   struct IlScratch { std::vector<std::vector<int>> vv[14]; std::vector<int> tmp[6]; std::vector<double> hD; std::vector<float> hF; std::vector<int> hI; } il_scr;
   std::vector<std::vector<int>> pl_scr_kids; std::vector<float> pl_scr_pr; std::vector<int> pl_scr_i[3];      // mind_aime_plan's flattening scratch
@@ -366,6 +369,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *ce = getenv("MIND_PLAN_CHUNK_MB")) { const long v = atol(ce); if (v > 0) c->plan_chunk_mb = v; }
   if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
   if (const char *we = getenv("MIND_ILQR_SPEC_DERIV")) c->ilqr_spec_deriv = atoi(we) != 0;
+  if (const char *we = getenv("MIND_TAB_HOST_MAX")) c->tab_host_max = std::max(0, atoi(we));
   if (const char *we = getenv("MIND_DEC_MIRROR")) c->dec_mirror = atoi(we) != 0;
   if (const char *we = getenv("MIND_ILQR_HOST_OUT_MAX")) c->ilqr_host_out_max = std::max(0, atoi(we));
   if (const char *we = getenv("MIND_UPLOAD_KERNEL_MAX")) c->upload_kernel_max = std::max(0, atoi(we));
@@ -463,6 +467,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "ilqr_wgs_big") c->ilqr_wgs_big = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (n == "ilqr_big_min") c->ilqr_big_min = value;
   else if (n == "ilqr_spec_deriv") c->ilqr_spec_deriv = value != 0;
+  else if (n == "tab_host_max") c->tab_host_max = value < 0 ? 0 : value;
   else if (n == "dec_mirror") c->dec_mirror = value != 0;
   else if (n == "ilqr_host_out_max") c->ilqr_host_out_max = value < 0 ? 0 : value;
   else if (n == "upload_kernel_max") c->upload_kernel_max = value < 0 ? 0 : value;
