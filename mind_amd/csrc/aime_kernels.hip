@@ -18,6 +18,15 @@ struct AimeScene {
   float ox, oy, theta_g, pad2;
 };
 
+// The scene tables of a SMALL round by value in the kernel arguments (mind_aime_plan: at most AIME_SMALL scenes per chunk, all with the
+// same agent count): the three glue kernels then need no table upload between the predictor and themselves.  n = 0: tables in memory.
+#define AIME_SMALL 8
+struct AimeSmall {
+  AimeScene s[AIME_SMALL];
+  float prob[AIME_SMALL];
+  int n, a, pad0, pad1;       // scenes, agents per scene (agent row i belongs to scene i / a)
+};
+
 #define AIME_T 60
 #define AIME_K 6
 #define AIME_PK 6   // packed world-frame record per (agent, mode, step): x, y, vx, vy, heading, max-sigma
@@ -36,10 +45,10 @@ __global__ __launch_bounds__(64) void k_aime_world(const AimeScene *__restrict__
                                                    const float *__restrict__ ctrs, const float *__restrict__ vecs,
                                                    const float *__restrict__ cov_last, float *__restrict__ world,
                                                    float *__restrict__ topo, float *__restrict__ ego_end,
-                                                   const float *__restrict__ lane, int n_lane) {
+                                                   const float *__restrict__ lane, int n_lane, const AimeSmall sm) {
   const int i = blockIdx.x / AIME_K, k = blockIdx.x % AIME_K, t = threadIdx.x;
-  const int b = agent_scene[i];
-  const AimeScene S = scenes[b];
+  const int b = sm.n ? i / sm.a : agent_scene[i];
+  const AimeScene S = sm.n ? sm.s[b] : scenes[b];
   const bool live = t < AIME_T;
   const int tc = live ? t : AIME_T - 1;
   const float th = atan2f(vecs[2 * i + 1], vecs[2 * i]);
@@ -109,12 +118,12 @@ __global__ __launch_bounds__(64) void k_aime_world(const AimeScene *__restrict__
 __global__ __launch_bounds__(64) void k_aime_select(const AimeScene *__restrict__ scenes, const float *__restrict__ cls,
                                                     const float *__restrict__ scen_prob, const float *__restrict__ topo,
                                                     const float *__restrict__ ego_end, int lane_check, float dist_thres,
-                                                    float *__restrict__ sel, float *__restrict__ sel_prob, float prob_floor) {
+                                                    float *__restrict__ sel, float *__restrict__ sel_prob, float prob_floor, const AimeSmall sm) {
   const int b = blockIdx.x, t = threadIdx.x;
-  const AimeScene S = scenes[b];
+  const AimeScene S = sm.n ? sm.s[b] : scenes[b];
   float cl[AIME_K], pr[AIME_K];
   bool keep[AIME_K];
-  const float sp = scen_prob[b];
+  const float sp = sm.n ? sm.prob[b] : scen_prob[b];
 #pragma unroll
   for (int k = 0; k < AIME_K; ++k) {
     cl[k] = cls[b * AIME_K + k];
@@ -256,9 +265,9 @@ __global__ __launch_bounds__(64) void k_aime_windows(const float *__restrict__ p
 __global__ __launch_bounds__(64) void k_aime_branch(const AimeScene *__restrict__ scenes, const float *__restrict__ sel,
                                                     const float *__restrict__ world, unsigned *__restrict__ hit,
                                                     const float *__restrict__ sel_prob, float *__restrict__ h_sel, float *__restrict__ h_selp,
-                                                    unsigned *__restrict__ h_hit) {
+                                                    unsigned *__restrict__ h_hit, const AimeSmall sm) {
   const int b = blockIdx.x / AIME_K, j = blockIdx.x % AIME_K, t = threadIdx.x;
-  const AimeScene S = scenes[b];
+  const AimeScene S = sm.n ? sm.s[b] : scenes[b];
   const int k = (int)sel[(size_t)b * AIME_K + j];
   bool h = false;
   if (k >= 0 && t < AIME_T) {

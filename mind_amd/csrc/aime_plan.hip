@@ -314,6 +314,7 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
     // ---- the frames of the re-based scenes + the scene tables of the block: prepared BEHIND the launch of the round's first predictor
     //      call (which needs neither): waiting for the frames first put a host round trip between k_aime_rebase and the predictor
     bool tables_done = false;
+    const bool all_small = c->tab_small && std::min(chunk, std::max(Bk, 1)) <= AIME_SMALL;
     auto prepare_tables = [&]() -> int {
       tables_done = true;
       // ---- the frames of the re-based scenes (ROT, ORIG, TGT_PTS; queued behind k_aime_rebase / the unpacking): needed by the scene tables
@@ -344,7 +345,9 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
           for (int i = 0; i < a; ++i) as[(size_t)b * a + i] = bc;
           sp[b] = q.prob;
         }
-        if (c->pl_tab_side) {
+        if (all_small) {
+          // (the glue kernels take these tables by value: AimeSmall)
+        } else if (c->pl_tab_side) {
           HIPCHK(c, hipMemcpyAsync(tabb.p, h, tab_bytes, hipMemcpyHostToDevice, c->pl_copy));
           HIPCHK(c, hipEventRecord(c->ev_tab, c->pl_copy));
           HIPCHK(c, hipStreamWaitEvent(st, c->ev_tab, 0));
@@ -397,14 +400,22 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       // prune_merge arithmetic + decisions + branch-time bits of the chunk, written at the chunk's place in the block's buffers
       const AimeScene *t_sc = (const AimeScene *)dtab + c0;
       float *w_c = d_world + (size_t)c0 * a * 6 * T * 6;
+      AimeSmall sm;
+      memset(&sm, 0, sizeof(sm));
+      if (all_small) {
+        const char *h = (const char *)c->pl_pin[1];
+        memcpy(sm.s, (const AimeScene *)h + c0, (size_t)cb * sizeof(AimeScene));
+        memcpy(sm.prob, (const float *)(h + bS + bI) + c0, (size_t)cb * sizeof(float));
+        sm.n = cb; sm.a = a;
+      }
       hipLaunchKernelGGL(k_aime_world, dim3(Ac * AIME_K), dim3(64), 0, st, t_sc, (const int *)(dtab + bS) + (size_t)c0 * a, d_reg, d_vel, d_ctrs, d_vecs,
-                         cov_last_dev + (size_t)g0 * a, w_c, d_topo + (size_t)c0 * a * 6, d_ego + (size_t)c0 * 24, droot + o_tl, P);
+                         cov_last_dev + (size_t)g0 * a, w_c, d_topo + (size_t)c0 * a * 6, d_ego + (size_t)c0 * 24, droot + o_tl, P, sm);
       hipLaunchKernelGGL(k_aime_select, dim3(cb), dim3(64), 0, st, t_sc, d_cls, (const float *)(dtab + bS + bI) + c0, d_topo + (size_t)c0 * a * 6,
-                         d_ego + (size_t)c0 * 24, 1, in->dist_thres, d_sel + (size_t)c0 * 6, d_selp + (size_t)c0 * 6, in->prob_floor > 0.f ? in->prob_floor : 0.001f);
+                         d_ego + (size_t)c0 * 24, 1, in->dist_thres, d_sel + (size_t)c0 * 6, d_selp + (size_t)c0 * 6, in->prob_floor > 0.f ? in->prob_floor : 0.001f, sm);
       hipLaunchKernelGGL(k_aime_branch, dim3(cb * AIME_K), dim3(64), 0, st, t_sc, d_sel + (size_t)c0 * 6, w_c, d_hit + (size_t)c0 * 12,
                          (const float *)d_selp + (size_t)c0 * 6, h_mirror ? h_mirror + (size_t)c0 * 6 : nullptr,
                          h_mirror ? h_mirror + (size_t)Bmax * 6 + (size_t)c0 * 6 : nullptr,
-                         h_mirror ? (unsigned *)(h_mirror + (size_t)Bmax * 12) + (size_t)c0 * 12 : nullptr);
+                         h_mirror ? (unsigned *)(h_mirror + (size_t)Bmax * 12) + (size_t)c0 * 12 : nullptr, sm);
       HIPCHK(c, hipGetLastError());
     }
     if (!tables_done && (rc = prepare_tables())) return rc;      // (a rank without scenes in this round still needs the frames)

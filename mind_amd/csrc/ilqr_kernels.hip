@@ -119,6 +119,10 @@ struct IlqrTreeDev {
   long long dset, drel;
   // small launches: where the host reads the results (page-locked, mapped staging) -- written by the kernel at its end; null = copies follow
   GP<double> h_xs, h_us, h_stats;
+  // ... and a word the kernel sets to h_gen (system scope, behind those results) when this tree's are complete: the host may price a candidate
+  // tree while the launch still works on the others (null: wide trees, whose launch can abort)
+  unsigned *h_done;
+  unsigned h_gen, pad_h;
   GP<double> stats;            // [IL_NSTAT]: iterations, converged, J, mu, phase cycles, profile slots
   // per-iteration trace of the fit (mind_last_ilqr_trace): IL_TRACE_W doubles per reference iteration {mu the backward pass ran with,
   // J of the nominal trajectory, accepted alpha index (-1: step rejected, -2: singular Q_uu), J of the accepted candidate}
@@ -1935,6 +1939,11 @@ __global__ __launch_bounds__(IL_THREADS) void k_ilqr(const IlqrTreeDev *__restri
     for (int q = threadIdx.x; q < M * 6; q += IL_THREADS) T.h_xs[q] = T.xs[q];
     for (int q = threadIdx.x; q < M * 2; q += IL_THREADS) T.h_us[q] = T.us[q];
     for (int q = threadIdx.x; q < n_phases * IL_NSTAT; q += IL_THREADS) T.h_stats[q] = T.stats[q];
+    if (T.h_done) {
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(T.h_done, T.h_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   if (SLOTS && threadIdx.x == 0) {          // the followers leave
     __hip_atomic_store(&T.ctl->cmd, 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -50,6 +50,7 @@ struct mind_loop {
   std::vector<int> slot_of_track;       // world track -> index in obs, -1 = not seen yet
   // per-plan scratch + the last plan
   std::vector<double> raw, eval_st, eval_ct, costs, per;
+  std::vector<char> early_seen;      // candidate trees priced while the solves of the others still ran
   std::vector<float> f_pos, f_ang, f_vel, f_pad, f_types;
   std::vector<int16_t> i_typ, i_have;
   std::vector<int32_t> kept, slots, counts;
@@ -397,6 +398,7 @@ int loop_plan(mind_loop *L) {
   if (nt <= 0) return fail(c, MIND_ESTATE, "mind_loop: the plan returned no scenario tree");
   const int32_t *off = L->po.tree_off;
   const int M = off[nt];
+  bool early_done = false;        // the candidates were priced while the solves ran (below)
   const double *xs, *us;
   const mind_ilqr_stats *stw, *stf;
   L->last_agents_plan = a;
@@ -408,6 +410,37 @@ int loop_plan(mind_loop *L) {
     if (!L->po.solves_begun) return fail(c, MIND_ESTATE, "mind_loop: the plan could not begin its contingency solves (%s)", c->err.c_str());
     // ---- collect the solves (mind_ilqr_finish_plan without the copy: the results stay in the context until its next plan)
     if (!c->il_finish || !c->il_finish_owned) return fail(c, MIND_ESTATE, "mind_loop: no plan-begun tree-iLQR call is pending");
+    // ---- a launch of small trees writes every tree's results to the host and marks it when they are complete: price the candidates as they
+    //      arrive (evaluate_traj_tree of one tree is independent of the others), beside the trees the device is still solving -- only the
+    //      last one's evaluation stays between the kernel's end and the chosen control
+    const mind_ctx::IlEarly E = c->il_early;
+    if (c->early_eval && E.done && E.n_trees == nt && E.nodes == (long)M) {
+      L->costs.assign(nt, 0.0);
+      L->early_seen.assign(nt, 0);
+      const void *elane_e = d.eval_lane_is_f32 ? (const void *)L->eval_lane_f32.data() : (const void *)L->eval_lane_f64.data();
+      int left = nt;
+      const auto te0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (left > 0) {
+        bool any = false;
+        for (int t = 0; t < nt; ++t) {
+          if (L->early_seen[t] || __atomic_load_n((const unsigned *)&E.done[t], __ATOMIC_ACQUIRE) != E.gen) continue;
+          const int m = off[t + 1] - off[t];
+          L->eval_st.resize((size_t)(m + 1) * 6); L->eval_ct.resize((size_t)(m + 1) * 2);
+          memcpy(L->eval_st.data(), x0, 6 * sizeof(double));
+          L->eval_ct[0] = 0.0; L->eval_ct[1] = 0.0;
+          memcpy(L->eval_st.data() + 6, E.xs + (size_t)off[t] * 6, (size_t)m * 6 * sizeof(double));
+          memcpy(L->eval_ct.data() + 2, E.us + (size_t)off[t] * 2, (size_t)m * 2 * sizeof(double));
+          const int32_t cnt1 = m + 1;
+          if ((rc = mind_eval_traj_trees(L->eval_st.data(), L->eval_ct.data(), &cnt1, 1, elane_e, d.eval_lane_is_f32, d.eval_n_lane_pts, d.target_vel, &L->costs[t])))
+            return fail(c, rc, "mind_loop: mind_eval_traj_trees failed");
+          L->early_seen[t] = 1; --left; any = true;
+        }
+        if (!any && (++spins & 0x3ffu) == 0u &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - te0).count() > 0.25) break;      // (never hang on a word: the usual path below)
+      }
+      early_done = left == 0;
+    }
     if ((rc = mind_ilqr_finish(c))) return rc;
     if ((size_t)M * 6 != c->pl_sol_xs.size() || (size_t)nt != c->pl_sol_stf.size()) return fail(c, MIND_ESTATE, "mind_loop: the solves' results do not fit the plan");
     xs = c->pl_sol_xs.data(); us = c->pl_sol_us.data(); stw = c->pl_sol_stw.data(); stf = c->pl_sol_stf.data();
@@ -423,7 +456,10 @@ int loop_plan(mind_loop *L) {
     }
   }
   // ---- evaluate_traj_tree of every candidate (planner.py:180-198): the tree's nodes = the root (x0, zero control) + its trajectory nodes
-  L->eval_st.resize((size_t)(M + nt) * 6); L->eval_ct.resize((size_t)(M + nt) * 2); L->counts.resize(nt); L->costs.resize(nt);
+  L->counts.resize(nt);
+  if (early_done) { for (int t = 0; t < nt; ++t) L->counts[t] = off[t + 1] - off[t] + 1; }
+  else {
+  L->eval_st.resize((size_t)(M + nt) * 6); L->eval_ct.resize((size_t)(M + nt) * 2); L->costs.resize(nt);
   size_t o = 0;
   for (int t = 0; t < nt; ++t) {
     const int m = off[t + 1] - off[t];
@@ -437,6 +473,7 @@ int loop_plan(mind_loop *L) {
   const void *elane = d.eval_lane_is_f32 ? (const void *)L->eval_lane_f32.data() : (const void *)L->eval_lane_f64.data();
   if ((rc = mind_eval_traj_trees(L->eval_st.data(), L->eval_ct.data(), L->counts.data(), nt, elane, d.eval_lane_is_f32, d.eval_n_lane_pts, d.target_vel, L->costs.data())))
     return fail(c, rc, "mind_loop: mind_eval_traj_trees failed");
+  }
   // ---- the reference's strict `<` scan (planner.py:131-136): the first minimum, a NaN never wins
   int best = -1;
   double min_cost = INFINITY;

@@ -131,12 +131,21 @@ struct mind_ctx {
   long ilqr_host_out_max = 4096;
   // mind_aime_plan, unsharded: k_aime_branch writes a round's decisions to the host staging itself (no copy behind it).  "dec_mirror" / MIND_DEC_MIRROR
   bool dec_mirror = true;
+  // mind_loop: price a candidate tree as soon as the pending tree-iLQR launch marks it complete, beside the trees still being solved.  "early_eval" / MIND_EARLY_EVAL
+  bool early_eval = true;
   // ... and its small index tables (the branch set of a round, the job tables of the two packing kernels) are read by the kernels from the
   // page-locked staging directly while they name at most this many workgroups (0 = always uploaded).  "tab_host_max" / MIND_TAB_HOST_MAX
   int tab_host_max = 4096;
+  // ... and the scene tables of a round of at most AIME_SMALL scenes per chunk travel in the glue kernels' arguments (no upload between the
+  // predictor and k_aime_world).  "tab_small" / MIND_TAB_SMALL
+  bool tab_small = true;
   // host tables of a tree-iLQR call (ilqr_impl): kept between calls so that a planning cycle does not allocate a hundred small vectors
   struct IlScratch { std::vector<std::vector<int>> vv[14]; std::vector<int> tmp[6]; std::vector<double> hD; std::vector<float> hF; std::vector<int> hI; } il_scr;
   std::vector<std::vector<int>> pl_scr_kids; std::vector<float> pl_scr_pr; std::vector<int> pl_scr_i[3];      // mind_aime_plan's flattening scratch
+  // the pending tree-iLQR launch writes its results to the host itself and marks every tree when it is complete (ilqr_impl `early`): where, and
+  // the word's value that means "complete" for THIS launch.  Valid between the launch and its mind_ilqr_finish.
+  struct IlEarly { const double *xs = nullptr, *us = nullptr; volatile unsigned *done = nullptr; unsigned gen = 0; int n_trees = 0; long nodes = 0; } il_early;
+  unsigned il_gen = 0;
   long long il_spec_req = 0, il_spec_hit = 0;       // last launch, all trees and fits: passes the speculator was asked in / results the master took
   int dec_mfma_min = 1 << 30;   // agents per call from which the decoder's actor part runs on the MFMA kernel (MIND_DEC_MFMA_MIN; default: never)
   bool enc_mfma = true;         // MFMA ActorNet under the bf16x3 / bf16 settings (MIND_ENC_MFMA=0: the fp32 VALU kernel, for A/B)
@@ -369,7 +378,9 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *ce = getenv("MIND_PLAN_CHUNK_MB")) { const long v = atol(ce); if (v > 0) c->plan_chunk_mb = v; }
   if (const char *we = getenv("MIND_ILQR_WGS")) { const int v = atoi(we); c->ilqr_wgs = v < 1 ? 1 : (v > 32 ? 32 : v); }
   if (const char *we = getenv("MIND_ILQR_SPEC_DERIV")) c->ilqr_spec_deriv = atoi(we) != 0;
+  if (const char *we = getenv("MIND_TAB_SMALL")) c->tab_small = atoi(we) != 0;
   if (const char *we = getenv("MIND_TAB_HOST_MAX")) c->tab_host_max = std::max(0, atoi(we));
+  if (const char *we = getenv("MIND_EARLY_EVAL")) c->early_eval = atoi(we) != 0;
   if (const char *we = getenv("MIND_DEC_MIRROR")) c->dec_mirror = atoi(we) != 0;
   if (const char *we = getenv("MIND_ILQR_HOST_OUT_MAX")) c->ilqr_host_out_max = std::max(0, atoi(we));
   if (const char *we = getenv("MIND_UPLOAD_KERNEL_MAX")) c->upload_kernel_max = std::max(0, atoi(we));
@@ -467,7 +478,9 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "ilqr_wgs_big") c->ilqr_wgs_big = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (n == "ilqr_big_min") c->ilqr_big_min = value;
   else if (n == "ilqr_spec_deriv") c->ilqr_spec_deriv = value != 0;
+  else if (n == "tab_small") c->tab_small = value != 0;
   else if (n == "tab_host_max") c->tab_host_max = value < 0 ? 0 : value;
+  else if (n == "early_eval") c->early_eval = value != 0;
   else if (n == "dec_mirror") c->dec_mirror = value != 0;
   else if (n == "ilqr_host_out_max") c->ilqr_host_out_max = value < 0 ? 0 : value;
   else if (n == "upload_kernel_max") c->upload_kernel_max = value < 0 ? 0 : value;
@@ -1963,10 +1976,20 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
   const size_t n_hs = (size_t)2 * IL_NSTAT * n_trees;
   const size_t n_xs = (size_t)(tl[0].stats - tl[0].xs);
   const size_t n_hx = n_xs + n_hs, n_us = (size_t)Mtot * 2;
-  if ((rc = pl_pin(c, 5, (n_hx + n_us + 2) * sizeof(double)))) return rc;
+  if ((rc = pl_pin(c, 5, (n_hx + n_us + 2) * sizeof(double) + (size_t)n_trees * sizeof(unsigned)))) return rc;
   double *hx = (double *)c->pl_pin[5], *hus = hx + n_hx;
   unsigned *h_abort = (unsigned *)(hus + n_us);
+  unsigned *h_done = h_abort + 4;               // (behind the two doubles kept for the abort word)
   const bool host_out = !ev && c->ilqr_host_out_max > 0 && Mtot <= c->ilqr_host_out_max;
+  // per-tree completion words (a launch that cannot abort): the caller may look at a tree's results before the launch has ended (mind_loop)
+  const bool early = host_out && !multi && !gen;
+  c->il_early = mind_ctx::IlEarly();
+  if (early) {
+    c->il_gen += 1u;
+    if (c->il_gen == 0u) c->il_gen = 1u;
+    for (int t = 0; t < n_trees; ++t) h_done[t] = 0u;
+    c->il_early.xs = hx; c->il_early.us = hus; c->il_early.done = h_done; c->il_early.gen = c->il_gen; c->il_early.n_trees = n_trees; c->il_early.nodes = Mtot;
+  }
   std::vector<IlqrTreeDev> hT(n_trees);
   long moff = 0;
   for (int t = 0; t < n_trees; ++t) {
@@ -2014,6 +2037,8 @@ static int ilqr_impl(mind_ctx *c, const mind_ilqr_cfg *cfg, const mind_field_gri
     D.ctl = slots ? (IlSlotCtl *)(dI + o_ctl + ctl_ints * (size_t)t) : nullptr;
     D.h_xs = host_out ? hx + (L.xs - tl[0].xs) : nullptr; D.h_us = host_out ? hus + (L.us - tl[0].us) : nullptr;
     D.h_stats = host_out ? hx + (L.stats - tl[0].xs) : nullptr;
+    D.h_done = early ? h_done + t : nullptr; D.h_gen = c->il_gen; D.pad_h = 0;
+    if (early && ((L.xs - tl[0].xs) != (size_t)moff * 6 || (L.us - tl[0].us) != (size_t)moff * 2)) return fail(c, MIND_EINVAL, "tree-iLQR arena: results are not contiguous");
     D.dset = spec ? (long long)L.Fx2 - (long long)L.Fx : 0; D.drel = spec ? (long long)L.rel2 - (long long)L.rel : 0;
     if (spec && (L.L2 - L.L != L.Fx2 - L.Fx || L.Lx2 - L.Lx != L.Fx2 - L.Fx || L.Lxx2 - L.Lxx != L.Fx2 - L.Fx || (use_exo && L.relag2 - L.relag != L.Fx2 - L.Fx)))
       return fail(c, MIND_EINVAL, "tree-iLQR arena: the two derivative sets are laid out differently");
@@ -2272,6 +2297,7 @@ extern "C" int mind_ilqr_finish(mind_ctx *c) {
   std::function<int()> fin = std::move(c->il_finish);
   c->il_finish = nullptr;
   c->il_finish_owned = false;
+  c->il_early = mind_ctx::IlEarly();
   return fin();
 }
 
@@ -2359,12 +2385,14 @@ extern "C" int mind_aime_world(mind_ctx *c, const mind_world_in *in, const mind_
     HIPCHK(c, hipEventRecord(c->ev_stage, st));
     c->aime_stage_busy = true;
   }
+  AimeSmall sm0;                  // (tables in memory)
+  memset(&sm0, 0, sizeof(sm0));
   hipLaunchKernelGGL(k_aime_world, dim3(A * AIME_K), dim3(64), 0, st, (const AimeScene *)base, (const int *)(base + bS), in->reg, in->vel,
                      in->actor_ctrs, in->actor_vecs, (const float *)(base + bS + bI), out->world, out->topo, out->ego_end,
-                     (const float *)(base + bS + bI + bC + bP), n_lane);
+                     (const float *)(base + bS + bI + bC + bP), n_lane, sm0);
   if (select)
     hipLaunchKernelGGL(k_aime_select, dim3(B), dim3(64), 0, st, (const AimeScene *)base, in->cls, (const float *)(base + bS + bI + bC),
-                       out->topo, out->ego_end, in->lane_check ? 1 : 0, in->dist_thres, out->sel, out->sel_prob, 0.001f);
+                       out->topo, out->ego_end, in->lane_check ? 1 : 0, in->dist_thres, out->sel, out->sel_prob, 0.001f, sm0);
   HIPCHK(c, hipGetLastError());
   return MIND_OK;
 }
