@@ -1296,6 +1296,16 @@ __device__ __forceinline__ void il_deriv_pass(const IlqrConst &C, const IlqrTree
 // launch was not fully resident) raises the launch-wide abort word, and every workgroup leaves at its next barrier; the host
 // reports the failure instead of a hung device.
 #define IL_SYNC_SPINS (1u << 24)
+// poll intervals (s_sleep units of 64 cycles) of the workgroups that wait for another one's word
+#ifndef IL_SLEEP_FOLLOW
+#define IL_SLEEP_FOLLOW 8
+#endif
+#ifndef IL_SLEEP_SPEC
+#define IL_SLEEP_SPEC 2
+#endif
+#ifndef IL_SLEEP_DONE
+#define IL_SLEEP_DONE 2
+#endif
 __device__ __forceinline__ bool il_tree_sync(unsigned *bar, int G, unsigned *abort_word) {
   __shared__ int sh_aborted;
   __syncthreads();
@@ -1622,7 +1632,7 @@ __device__ __forceinline__ void il_fit(IlqrTreeDev &T, int &cur, const IlqrConst
           // a follower's slot, looked at only because every earlier slot was rejected: wait for its result (it started a command latency
           // behind this workgroup's own slot and has had the selection's time to catch up)
           IlSlotCtl *ctl = T.ctl;
-          while (__hip_atomic_load(&ctl->done[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sh_gen) __builtin_amdgcn_s_sleep(2);
+          while (__hip_atomic_load(&ctl->done[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sh_gen) __builtin_amdgcn_s_sleep(IL_SLEEP_DONE);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           if (__hip_atomic_load(&ctl->sing[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;     // slots behind a singular slot cannot be used this pass
           for (int a = 0; a < IL_NA; ++a) Jnew[slot][a] = ctl->Jnew[slot][a];
@@ -1713,7 +1723,7 @@ __device__ __forceinline__ void il_follow(const IlqrTreeDev &T0, const IlqrConst
     __syncthreads();
     if (tid == 0) {
       unsigned g;
-      while ((g = __hip_atomic_load(&ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == last) __builtin_amdgcn_s_sleep(8);
+      while ((g = __hip_atomic_load(&ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == last) __builtin_amdgcn_s_sleep(IL_SLEEP_FOLLOW);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       f_gen = g; f_cmd = __hip_atomic_load(&ctl->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       f_mu = ctl->mu; f_de = ctl->delta; f_sing = 0; f_abort = 0;
@@ -1878,7 +1888,7 @@ __device__ __forceinline__ void il_speculate(const IlqrTreeDev &T0, const IlqrCo
         r = __hip_atomic_load(&ctl->sreq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cmd = __hip_atomic_load(&ctl->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (r != last || (cmd >> 16) & 0xffu) break;
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(IL_SLEEP_SPEC);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       s_req = r; s_cmd = __hip_atomic_load(&ctl->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
