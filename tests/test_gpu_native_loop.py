@@ -210,3 +210,37 @@ def test_native_loop_with_the_speculative_warm_start(scene, monkeypatch):
     cn = pa.traj_tree_opt.counters
     print(f"{scene}: {cn['warm_speculated']} warm-start fits speculated, {cn['warm_hits']} used, over 30 cycles")
     assert cn["warm_speculated"] > 0
+
+
+def test_copy_and_table_knobs_leave_every_cycle_bit_identical():
+    """The copies taken off the cycle's critical path are pure data movement: uploads as kernels that read the page-locked staging (pl_upload),
+    results written to the host staging by k_ilqr / k_aime_branch themselves, small index tables read from the staging or passed in the
+    kernel arguments (AimeSmall), candidates priced as soon as their tree is marked complete, the tree-iLQR kernel's derivative
+    speculator.  With all of them off (copies, uploaded tables, the batch evaluation behind the finish, the master's own derivative pass)
+    the native loop must walk exactly the same cycles -- on a scene whose plans branch."""
+    knobs = {"upload_kernel_max": (0, 1 << 20), "ilqr_host_out_max": (0, 4096), "dec_mirror": (0, 1), "tab_host_max": (0, 4096), "tab_small": (0, 1),
+             "early_eval": (0, 1), "ilqr_spec_deriv": (0, 1)}
+    runs = []
+    rt = None
+    try:
+        for arm in (0, 1):
+            pl, sim = _make("demo_4", None, episode_plans=5)
+            rt = pl.network.rt
+            for k, v in knobs.items():
+                rt.set_tuning(k, v[arm])
+            assert sim._native is not None
+            snaps = []
+            for cycle in range(8):
+                sim.run_plans(1)
+                snaps.append(_snapshot(pl, sim))
+            runs.append(snaps)
+            if arm == 1:
+                asked, hits = (int(v) for v in rt.debug_read("il_spec"))
+                assert asked > 0 and 0 < hits <= asked          # (last launch of the run: the speculator's set became the nominal one)
+    finally:
+        if rt is not None:
+            for k, v in knobs.items():
+                rt.set_tuning(k, v[1])
+    assert sum(len(s["costs"]) > 1 for s in runs[0]) >= 2
+    for cycle, (a, b) in enumerate(zip(*runs)):
+        _same(a, b, cycle)
