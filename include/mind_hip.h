@@ -135,7 +135,7 @@ int mind_set_pair_precision(mind_ctx *ctx, int mode);
  * most this many nodes write xs / us / statistics to the host staging themselves; default 4 096), "dec_mirror" (mind_aime_plan, unsharded: the
  * round's last glue kernel writes the decisions where the host reads them), "tab_host_max" / "tab_small" (its small index tables are read from
  * the host staging / travel in the kernel arguments), "early_eval" (mind_loop prices a candidate tree as soon as the pending launch marks it
- * complete); MIND_UPLOAD_KERNEL_MAX, MIND_ILQR_HOST_OUT_MAX, MIND_DEC_MIRROR, MIND_TAB_HOST_MAX, MIND_TAB_SMALL, MIND_EARLY_EVAL,
+ * complete), "glue_fused" (mind_aime_plan's pruning decisions and branch-time bits from one launch, k_aime_select_branch); MIND_GLUE_FUSED, MIND_UPLOAD_KERNEL_MAX, MIND_ILQR_HOST_OUT_MAX, MIND_DEC_MIRROR, MIND_TAB_HOST_MAX, MIND_TAB_SMALL, MIND_EARLY_EVAL,
  * "actor_f32" (0: the fp32 VALU ActorNet instead of the fp32-MFMA one under the exact-fp32 setting), "actor_f32_min" / "actor_f32_pair_min" (actors per
  * call from which the fp32-MFMA ActorNet runs with two actors per workgroup, under every setting / under exact fp32; default never), "enc_mfma" (0: the fp32 VALU ActorNet / decoder kernels under every precision), "actor_split" (6: three-way operand split,
  * fp32-class; 3: two-way), "xcd_order" (XCD-aware job order of the pair kernel), "tok_mfma" (1: the per-token epilogue / prologue of the fusion layers on the fp32 MFMA kernel k_token_mfma instead of the fp32 VALU one; off by default: measured slower), "tok_small_max" (batches of at most this many tokens run k_token with four tokens per workgroup instead of eight; same bits), "tgt_side" (0: the context stream waits for the target embedding before the fusion layers), "dec_overlap" (0: the decoder's actor part as one kernel behind

@@ -115,15 +115,12 @@ __global__ __launch_bounds__(64) void k_aime_world(const AimeScene *__restrict__
 // agent.  Same float32 expressions as the reference's per-mode loop; the signatures and end points are the ones k_aime_world
 // just wrote.  sel[b][j] = mode index of the j-th kept mode (visiting order) or -1, sel_prob[b][j] its path probability.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_aime_select(const AimeScene *__restrict__ scenes, const float *__restrict__ cls,
-                                                    const float *__restrict__ scen_prob, const float *__restrict__ topo,
-                                                    const float *__restrict__ ego_end, int lane_check, float dist_thres,
-                                                    float *__restrict__ sel, float *__restrict__ sel_prob, float prob_floor, const AimeSmall sm) {
-  const int b = blockIdx.x, t = threadIdx.x;
-  const AimeScene S = sm.n ? sm.s[b] : scenes[b];
+// (the decisions of scene b by one 64-lane wave: every lane ends with the same so / po)
+__device__ __forceinline__ void aime_select_scene(const AimeScene &S, float sp, int b, int t, const float *__restrict__ cls,
+                                                  const float *__restrict__ topo, const float *__restrict__ ego_end, int lane_check,
+                                                  float dist_thres, float prob_floor, float (&so)[AIME_K], float (&po)[AIME_K]) {
   float cl[AIME_K], pr[AIME_K];
   bool keep[AIME_K];
-  const float sp = sm.n ? sm.prob[b] : scen_prob[b];
 #pragma unroll
   for (int k = 0; k < AIME_K; ++k) {
     cl[k] = cls[b * AIME_K + k];
@@ -161,13 +158,13 @@ __global__ __launch_bounds__(64) void k_aime_select(const AimeScene *__restrict_
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mask |= __shfl_xor(mask, o, 64);
-  if (t != 0) return;
   // greedy merge over the kept modes in visiting order, all state in bit masks (no indexed arrays): the next selected mode is the
   // alive one of lowest rank; the modes that stay alive are those that differ from it
   unsigned alive = 0;
 #pragma unroll
   for (int k = 0; k < AIME_K; ++k) alive |= keep[k] ? 1u << k : 0u;
-  float *so = sel + (size_t)b * AIME_K, *po = sel_prob + (size_t)b * AIME_K;
+#pragma unroll
+  for (int k = 0; k < AIME_K; ++k) { so[k] = -1.f; po[k] = 0.f; }
   int ns = 0;
 #pragma unroll
   for (int it = 0; it < AIME_K; ++it) {
@@ -188,13 +185,26 @@ __global__ __launch_bounds__(64) void k_aime_select(const AimeScene *__restrict_
         brow = row;
       }
     if (best >= 0) {
-      so[ns] = (float)best;
-      po[ns] = bp;
+#pragma unroll
+      for (int q = 0; q < AIME_K; ++q) if (q == ns) { so[q] = (float)best; po[q] = bp; }      // (no indexed register arrays)
       ++ns;
       alive &= brow;            // drops the selected mode itself (its own bit is 0) and everything merged into it
     }
   }
-  for (; ns < AIME_K; ++ns) { so[ns] = -1.f; po[ns] = 0.f; }
+}
+
+__global__ __launch_bounds__(64) void k_aime_select(const AimeScene *__restrict__ scenes, const float *__restrict__ cls,
+                                                    const float *__restrict__ scen_prob, const float *__restrict__ topo,
+                                                    const float *__restrict__ ego_end, int lane_check, float dist_thres,
+                                                    float *__restrict__ sel, float *__restrict__ sel_prob, float prob_floor, const AimeSmall sm) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  const AimeScene S = sm.n ? sm.s[b] : scenes[b];
+  const float sp = sm.n ? sm.prob[b] : scen_prob[b];
+  float so[AIME_K], po[AIME_K];
+  aime_select_scene(S, sp, b, t, cls, topo, ego_end, lane_check, dist_thres, prob_floor, so, po);
+  if (t != 0) return;
+#pragma unroll
+  for (int k = 0; k < AIME_K; ++k) { sel[(size_t)b * AIME_K + k] = so[k]; sel_prob[(size_t)b * AIME_K + k] = po[k]; }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -281,6 +291,50 @@ __global__ __launch_bounds__(64) void k_aime_branch(const AimeScene *__restrict_
   if (h_sel && t == 0) {
     h_hit[2 * (size_t)blockIdx.x] = (unsigned)m; h_hit[2 * (size_t)blockIdx.x + 1] = (unsigned)(m >> 32);
     h_sel[blockIdx.x] = sel[blockIdx.x]; h_selp[blockIdx.x] = sel_prob[blockIdx.x];
+  }
+}
+
+// k_aime_select + k_aime_branch in ONE launch (mind_aime_plan): a block per (scene, kept slot) works out its scene's decisions itself -- the
+// same code on the same inputs as k_aime_select, six times per scene, a few hundred instructions -- and then runs its slot's branch-time
+// test with the agents' two values requested eight agents at a time (they were 16 dependent round trips).  Block (b, 0) writes the scene's
+// decisions (device buffer + the host mirror).  Same expressions per item: the same bits as the two kernels.
+__global__ __launch_bounds__(64) void k_aime_select_branch(const AimeScene *__restrict__ scenes, const float *__restrict__ cls,
+                                                           const float *__restrict__ scen_prob, const float *__restrict__ topo,
+                                                           const float *__restrict__ ego_end, int lane_check, float dist_thres, float prob_floor,
+                                                           const float *__restrict__ world, float *__restrict__ sel, float *__restrict__ sel_prob,
+                                                           unsigned *__restrict__ hit, float *__restrict__ h_sel, float *__restrict__ h_selp,
+                                                           unsigned *__restrict__ h_hit, const AimeSmall sm) {
+  const int b = blockIdx.x / AIME_K, j = blockIdx.x % AIME_K, t = threadIdx.x;
+  const AimeScene S = sm.n ? sm.s[b] : scenes[b];
+  const float sp = sm.n ? sm.prob[b] : scen_prob[b];
+  float so[AIME_K], po[AIME_K];
+  aime_select_scene(S, sp, b, t, cls, topo, ego_end, lane_check, dist_thres, prob_floor, so, po);
+  float kf = -1.f, pj = 0.f;
+#pragma unroll
+  for (int q = 0; q < AIME_K; ++q) if (q == j) { kf = so[q]; pj = po[q]; }
+  const int k = (int)kf;
+  bool h = false;
+  if (k >= 0 && t < AIME_T) {
+    for (int i0 = S.a0; i0 < S.a1; i0 += 8) {
+      float num[8], den[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = i0 + q < S.a1 ? i0 + q : S.a1 - 1;
+        const float *r = world + ((size_t)i * AIME_K + k) * AIME_T * AIME_PK;
+        num[q] = r[t * AIME_PK + 5]; den[q] = r[S.cmp * AIME_PK + 5];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (i0 + q < S.a1) h |= (num[q] / den[q]) > 9.0f;
+    }
+  }
+  const unsigned long long m = __ballot(h);
+  if (t == 0) {
+    hit[2 * (size_t)blockIdx.x] = (unsigned)m; hit[2 * (size_t)blockIdx.x + 1] = (unsigned)(m >> 32);
+    sel[blockIdx.x] = kf; sel_prob[blockIdx.x] = pj;
+    if (h_sel) {
+      h_hit[2 * (size_t)blockIdx.x] = (unsigned)m; h_hit[2 * (size_t)blockIdx.x + 1] = (unsigned)(m >> 32);
+      h_sel[blockIdx.x] = kf; h_selp[blockIdx.x] = pj;
+    }
   }
 }
 

@@ -410,12 +410,19 @@ extern "C" int mind_aime_plan(mind_ctx *c, const mind_aime_plan_in *in, mind_aim
       }
       hipLaunchKernelGGL(k_aime_world, dim3(Ac * AIME_K), dim3(64), 0, st, t_sc, (const int *)(dtab + bS) + (size_t)c0 * a, d_reg, d_vel, d_ctrs, d_vecs,
                          cov_last_dev + (size_t)g0 * a, w_c, d_topo + (size_t)c0 * a * 6, d_ego + (size_t)c0 * 24, droot + o_tl, P, sm);
-      hipLaunchKernelGGL(k_aime_select, dim3(cb), dim3(64), 0, st, t_sc, d_cls, (const float *)(dtab + bS + bI) + c0, d_topo + (size_t)c0 * a * 6,
-                         d_ego + (size_t)c0 * 24, 1, in->dist_thres, d_sel + (size_t)c0 * 6, d_selp + (size_t)c0 * 6, in->prob_floor > 0.f ? in->prob_floor : 0.001f, sm);
-      hipLaunchKernelGGL(k_aime_branch, dim3(cb * AIME_K), dim3(64), 0, st, t_sc, d_sel + (size_t)c0 * 6, w_c, d_hit + (size_t)c0 * 12,
-                         (const float *)d_selp + (size_t)c0 * 6, h_mirror ? h_mirror + (size_t)c0 * 6 : nullptr,
-                         h_mirror ? h_mirror + (size_t)Bmax * 6 + (size_t)c0 * 6 : nullptr,
-                         h_mirror ? (unsigned *)(h_mirror + (size_t)Bmax * 12) + (size_t)c0 * 12 : nullptr, sm);
+      float *hs_ = h_mirror ? h_mirror + (size_t)c0 * 6 : nullptr, *hp_ = h_mirror ? h_mirror + (size_t)Bmax * 6 + (size_t)c0 * 6 : nullptr;
+      unsigned *hh_ = h_mirror ? (unsigned *)(h_mirror + (size_t)Bmax * 12) + (size_t)c0 * 12 : nullptr;
+      const float pf_ = in->prob_floor > 0.f ? in->prob_floor : 0.001f;
+      if (c->glue_fused) {
+        // pruning decisions + branch-time bits in one launch (every block derives its scene's decisions itself)
+        hipLaunchKernelGGL(k_aime_select_branch, dim3(cb * AIME_K), dim3(64), 0, st, t_sc, d_cls, (const float *)(dtab + bS + bI) + c0, d_topo + (size_t)c0 * a * 6,
+                           d_ego + (size_t)c0 * 24, 1, in->dist_thres, pf_, w_c, d_sel + (size_t)c0 * 6, d_selp + (size_t)c0 * 6, d_hit + (size_t)c0 * 12, hs_, hp_, hh_, sm);
+      } else {
+        hipLaunchKernelGGL(k_aime_select, dim3(cb), dim3(64), 0, st, t_sc, d_cls, (const float *)(dtab + bS + bI) + c0, d_topo + (size_t)c0 * a * 6,
+                           d_ego + (size_t)c0 * 24, 1, in->dist_thres, d_sel + (size_t)c0 * 6, d_selp + (size_t)c0 * 6, pf_, sm);
+        hipLaunchKernelGGL(k_aime_branch, dim3(cb * AIME_K), dim3(64), 0, st, t_sc, d_sel + (size_t)c0 * 6, w_c, d_hit + (size_t)c0 * 12,
+                           (const float *)d_selp + (size_t)c0 * 6, hs_, hp_, hh_, sm);
+      }
       HIPCHK(c, hipGetLastError());
     }
     if (!tables_done && (rc = prepare_tables())) return rc;      // (a rank without scenes in this round still needs the frames)

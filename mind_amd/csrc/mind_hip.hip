@@ -131,6 +131,8 @@ struct mind_ctx {
   long ilqr_host_out_max = 4096;
   // mind_aime_plan, unsharded: k_aime_branch writes a round's decisions to the host staging itself (no copy behind it).  "dec_mirror" / MIND_DEC_MIRROR
   bool dec_mirror = true;
+  // ... and its pruning decisions + branch-time bits come from one launch (k_aime_select_branch) instead of two.  "glue_fused" / MIND_GLUE_FUSED
+  bool glue_fused = true;
   // mind_loop: price a candidate tree as soon as the pending tree-iLQR launch marks it complete, beside the trees still being solved.  "early_eval" / MIND_EARLY_EVAL
   bool early_eval = true;
   // ... and its small index tables (the branch set of a round, the job tables of the two packing kernels) are read by the kernels from the
@@ -381,6 +383,7 @@ extern "C" int mind_ctx_create(int device, void *stream, mind_ctx **out) {
   if (const char *we = getenv("MIND_TAB_SMALL")) c->tab_small = atoi(we) != 0;
   if (const char *we = getenv("MIND_TAB_HOST_MAX")) c->tab_host_max = std::max(0, atoi(we));
   if (const char *we = getenv("MIND_EARLY_EVAL")) c->early_eval = atoi(we) != 0;
+  if (const char *we = getenv("MIND_GLUE_FUSED")) c->glue_fused = atoi(we) != 0;
   if (const char *we = getenv("MIND_DEC_MIRROR")) c->dec_mirror = atoi(we) != 0;
   if (const char *we = getenv("MIND_ILQR_HOST_OUT_MAX")) c->ilqr_host_out_max = std::max(0, atoi(we));
   if (const char *we = getenv("MIND_UPLOAD_KERNEL_MAX")) c->upload_kernel_max = std::max(0, atoi(we));
@@ -481,6 +484,7 @@ extern "C" int mind_set_tuning(mind_ctx *c, const char *name, int value) {
   else if (n == "tab_small") c->tab_small = value != 0;
   else if (n == "tab_host_max") c->tab_host_max = value < 0 ? 0 : value;
   else if (n == "early_eval") c->early_eval = value != 0;
+  else if (n == "glue_fused") c->glue_fused = value != 0;
   else if (n == "dec_mirror") c->dec_mirror = value != 0;
   else if (n == "ilqr_host_out_max") c->ilqr_host_out_max = value < 0 ? 0 : value;
   else if (n == "upload_kernel_max") c->upload_kernel_max = value < 0 ? 0 : value;

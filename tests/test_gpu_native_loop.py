@@ -216,10 +216,10 @@ def test_copy_and_table_knobs_leave_every_cycle_bit_identical():
     """The copies taken off the cycle's critical path are pure data movement: uploads as kernels that read the page-locked staging (pl_upload),
     results written to the host staging by k_ilqr / k_aime_branch themselves, small index tables read from the staging or passed in the
     kernel arguments (AimeSmall), candidates priced as soon as their tree is marked complete, the tree-iLQR kernel's derivative
-    speculator.  With all of them off (copies, uploaded tables, the batch evaluation behind the finish, the master's own derivative pass)
+    speculator, the pruning decisions and branch-time bits from one launch (k_aime_select_branch).  With all of them off (copies, uploaded tables, the batch evaluation behind the finish, the master's own derivative pass)
     the native loop must walk exactly the same cycles -- on a scene whose plans branch."""
     knobs = {"upload_kernel_max": (0, 1 << 20), "ilqr_host_out_max": (0, 4096), "dec_mirror": (0, 1), "tab_host_max": (0, 4096), "tab_small": (0, 1),
-             "early_eval": (0, 1), "ilqr_spec_deriv": (0, 1)}
+             "early_eval": (0, 1), "ilqr_spec_deriv": (0, 1), "glue_fused": (0, 1)}
     runs = []
     rt = None
     try:
