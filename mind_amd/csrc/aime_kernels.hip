@@ -217,6 +217,7 @@ __global__ __launch_bounds__(64) void k_aime_select(const AimeScene *__restrict_
 #define RB_THREADS 256
 #define RB_FEAT_BLOCKS(a) ((int)(((size_t)(a) * 48 + RB_THREADS - 1) / RB_THREADS))     // feature blocks per scene (k_aime_rebase grid y = 1 + this)
 #define RB_T 50
+#define RB_LANE_LDS 1024   // target-lane points staged in LDS by k_aime_rebase's frame block (longer lanes are walked in global memory)
 
 struct RebaseArgs {
   int a, l, n_lane, pad_ones;
@@ -450,10 +451,19 @@ __global__ __launch_bounds__(RB_THREADS) void k_aime_rebase(RebaseArgs A) {
   }
   // ---- high-level command: target-lane window ahead of the ego (scenario_tree.py:613-652)
   {
+    // the target lane's points in LDS: thread 0 walks them one after the other below (a dependent global load per step -- some thirty of
+    // them at 10 m/s -- made this block the longest of the kernel, and ActorNet waits for the kernel); same values, same operations
+    __shared__ float tl_sm[2 * RB_LANE_LDS];
+    const bool tl_lds = A.n_lane <= RB_LANE_LDS;
+    if (tl_lds) {
+      for (int q = tid; q < 2 * A.n_lane; q += RB_THREADS) tl_sm[q] = A.tlane[q];
+      __syncthreads();
+    }
+    const float *tlane = tl_lds ? tl_sm : A.tlane;
     float best = INFINITY;
     int bi = 0x7fffffff;
     for (int q = tid; q < A.n_lane; q += RB_THREADS) {
-      const float dx = A.tlane[2 * q] - ox, dy = A.tlane[2 * q + 1] - oy;
+      const float dx = tlane[2 * q] - ox, dy = tlane[2 * q + 1] - oy;
       const float d = sqrtf(dx * dx + dy * dy);
       if (d < best) { best = d; bi = q; }            // strided scan keeps the lowest index per thread
     }
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_aime_rebase(RebaseArgs A) {
       const int n = A.n_lane;
       while (idx < n - 1 && travel > 0.f) {
         ++idx;
-        const float sx = A.tlane[2 * idx] - A.tlane[2 * idx - 2], sy = A.tlane[2 * idx + 1] - A.tlane[2 * idx - 1];
+        const float sx = tlane[2 * idx] - tlane[2 * idx - 2], sy = tlane[2 * idx + 1] - tlane[2 * idx - 1];
         travel = travel - sqrtf(sx * sx + sy * sy);
       }
       if (idx == n - 1) --idx;
@@ -493,13 +503,18 @@ __global__ __launch_bounds__(RB_THREADS) void k_aime_rebase(RebaseArgs A) {
     float *frm = A.frames + (size_t)sc * 28;
     if (tid < 11) {
       const int q = idx - 5 + tid;
-      const float px = A.tlane[2 * q], py = A.tlane[2 * q + 1];
+      const float px = tlane[2 * q], py = tlane[2 * q + 1];
       frm[6 + 2 * tid] = px; frm[6 + 2 * tid + 1] = py;                 // TGT_PTS (world frame)
       const float dx = px - ox, dy = py - oy;
       ctr[tid][0] = dx * c0 + dy * s0;
       ctr[tid][1] = dx * (-s0) + dy * c0;
     }
     __syncthreads();
+    // the per-point info of the ten window pieces: plain copies, one per thread
+    if (tid >= 64 && tid < 64 + 120) {
+      const int e = tid - 64, q = e / 12, k = e - 12 * q;
+      A.tgt_nodes[(size_t)sc * 160 + q * 16 + 4 + k] = A.tinfo[(size_t)(idx - 5 + q + 1) * 12 + k];
+    }
     if (tid == 0) {
       frm[0] = c0; frm[1] = -s0; frm[2] = s0; frm[3] = c0; frm[4] = ox; frm[5] = oy;      // ROT (row-major), ORIG
       float mx = 0.f, my = 0.f;
@@ -520,7 +535,6 @@ __global__ __launch_bounds__(RB_THREADS) void k_aime_rebase(RebaseArgs A) {
         tn[q * 16 + 1] = (ln[q][1] + ln[q + 1][1]) / 2.0f;
         tn[q * 16 + 2] = ln[q + 1][0] - ln[q][0];
         tn[q * 16 + 3] = ln[q + 1][1] - ln[q][1];
-        for (int k = 0; k < 12; ++k) tn[q * 16 + 4 + k] = A.tinfo[(size_t)(idx - 5 + q + 1) * 12 + k];
       }
       // TGT_RPE = get_rpe([anchor, ego], [anchor direction, ego direction]) flattened [5][i][j]
       const float cxs[2] = {mx, rb_sm[0]}, cys[2] = {my, rb_sm[1]};
