@@ -1374,6 +1374,7 @@ __device__ __forceinline__ void il_fit(IlqrTreeDev &T, int &cur, const IlqrConst
   __shared__ int sh_accepted, sh_converged, sh_stop, sh_sing, sh_pick, sh_slot, sh_it, sh_nspec, sh_hint, sh_ntot;
   __shared__ int sh_spec, sh_hit, sh_nreq, sh_nhit;      // derivative speculator: asked this pass / its set is the accepted candidate's / counts
   __shared__ unsigned sh_gen;
+  __shared__ unsigned sh_fsing[IL_SLOTS];      // followers' singular flags of the pass (collected side by side before the selection)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = T.M;
   const int gw = MULTI ? wg * IL_WAVES + wave : wave, nw = MULTI ? G * IL_WAVES : IL_WAVES;      // this wave among the tree's waves
@@ -1622,13 +1623,35 @@ __device__ __forceinline__ void il_fit(IlqrTreeDev &T, int &cur, const IlqrConst
       Jnew[tid / IL_NA][tid % IL_NA] = J;
     }
     __syncthreads();
+    // With followers, and every slot of this workgroup rejected: the followers' results are collected by one lane each, side by side (the
+    // selection below then scans them in slot order from LDS) -- thread 0 used to wait for them one after the other, a word, a fence and ten
+    // loads per slot, in the run of rejections that ends every fit.  The followers do equal work and publish at about the same time.
+    bool gathered = false;
+    if (SLOTS && sh_ntot > nspec) {
+      bool own = false;          // (uniform: every thread reads the same LDS values)
+      for (int slot = 0; slot < nuse; ++slot)
+        for (int a = 0; a < IL_NA; ++a) own |= Jnew[slot][a] < sh_J;
+      if (!own) {
+        if (tid >= nuse && tid < sh_ntot) {
+          IlSlotCtl *ctl = T.ctl;
+          while (__hip_atomic_load(&ctl->done[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sh_gen) __builtin_amdgcn_s_sleep(IL_SLEEP_DONE);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          sh_fsing[tid] = __hip_atomic_load(&ctl->sing[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int a = 0; a < IL_NA; ++a) Jnew[tid][a] = ctl->Jnew[tid][a];
+        }
+        __syncthreads();
+        gathered = true;
+      }
+    }
     if (tid == 0) {
       double mu = sh_mu, de = sh_delta;
       int it = sh_it;
       bool done = false;
       const int nsel = (SLOTS && sh_ntot > nspec) ? sh_ntot : nuse;      // with followers: their slots behind this workgroup's
       for (int slot = 0; slot < nsel && !done; ++slot) {
-        if (SLOTS && slot >= nuse) {
+        if (SLOTS && slot >= nuse && gathered) {
+          if (sh_fsing[slot]) break;          // slots behind a singular slot cannot be used this pass
+        } else if (SLOTS && slot >= nuse) {
           // a follower's slot, looked at only because every earlier slot was rejected: wait for its result (it started a command latency
           // behind this workgroup's own slot and has had the selection's time to catch up)
           IlSlotCtl *ctl = T.ctl;
